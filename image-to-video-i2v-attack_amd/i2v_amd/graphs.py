@@ -1,0 +1,319 @@
+"""Architecture IR for the image backbones the attack classes hook.
+
+The reference obtains its backbones from torchvision 0.10.1
+(`/root/reference/image_attacks.py:84-108`, `TPAMI_attack.py:100-124`); torchvision
+is third-party and not vendored, so the graphs are restated here from the public
+architecture definitions as a flat list of nodes.  The same IR is consumed by
+
+  * the HIP engine (`engine.py` -> `i2v_net_add_*` of the C-ABI), and
+  * the CPU oracle (`oracle/restate.py`) -- test infrastructure only.
+
+Only what lies at or before a hook layer is ever executed; everything behind the
+deepest hook (layer4 / avgpool / fc / classifier tails) cannot influence the loss
+(`image_attacks.py:336-347`) and is never emitted.
+
+Tensor ids index `Graph.tensors`.  A tensor is a channel-slice *view* of a buffer
+(`buf`, `c_off`, buffer width `Graph.buffers[buf]`) so that SqueezeNet Fire
+concatenation needs no copy.
+
+Weight keys follow the torchvision `state_dict` layout, so a real ImageNet
+checkpoint loads unchanged when one is supplied.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+
+@dataclass
+class TensorSpec:
+    C: int
+    H: int
+    W: int
+    buf: int            # buffer id
+    c_off: int          # channel offset inside the buffer
+    post_relu: bool     # values are outputs of a ReLU (gradient mask = value > 0)
+    name: str = ""
+
+
+@dataclass
+class ConvNode:
+    src: int
+    dst: int
+    cin: int
+    cout: int
+    kh: int
+    kw: int
+    stride: int
+    pad: int
+    weight: str                 # state_dict key of the conv weight
+    bias: Optional[str]         # state_dict key of the conv bias (VGG/AlexNet/SqueezeNet)
+    bn: Optional[str]           # state_dict prefix of the BatchNorm2d that follows (ResNet)
+    relu: bool                  # ReLU applied after (bias/bn [+ residual])
+    residual: Optional[int] = None   # tensor added before the ReLU (Bottleneck identity)
+    op: str = "conv"
+
+
+@dataclass
+class PoolNode:
+    src: int
+    dst: int
+    k: int
+    stride: int
+    pad: int
+    ceil_mode: bool
+    op: str = "maxpool"
+
+
+@dataclass
+class Graph:
+    arch: str
+    in_hw: Tuple[int, int]
+    tensors: List[TensorSpec] = field(default_factory=list)
+    buffers: List[int] = field(default_factory=list)          # channel width per buffer
+    nodes: list = field(default_factory=list)
+    hooks: Dict[int, int] = field(default_factory=dict)       # depth (1..4) -> tensor id
+    input: int = 0
+
+    # -- construction helpers -------------------------------------------------
+    def new_buffer(self, C: int) -> int:
+        self.buffers.append(C)
+        return len(self.buffers) - 1
+
+    def new_tensor(self, C, H, W, post_relu, name="", buf=None, c_off=0) -> int:
+        if buf is None:
+            buf = self.new_buffer(C)
+        self.tensors.append(TensorSpec(C, H, W, buf, c_off, post_relu, name))
+        return len(self.tensors) - 1
+
+    def conv(self, src, cout, k, stride, pad, weight, bias=None, bn=None, relu=True,
+             residual=None, name="", dst_buf=None, dst_c_off=0) -> int:
+        s = self.tensors[src]
+        Ho = (s.H + 2 * pad - k) // stride + 1
+        Wo = (s.W + 2 * pad - k) // stride + 1
+        dst = self.new_tensor(cout, Ho, Wo, relu, name, dst_buf, dst_c_off)
+        self.nodes.append(ConvNode(src, dst, s.C, cout, k, k, stride, pad, weight, bias, bn,
+                                   relu, residual))
+        return dst
+
+    def maxpool(self, src, k, stride, pad=0, ceil_mode=False, name="") -> int:
+        s = self.tensors[src]
+
+        def out(n):
+            if ceil_mode:
+                o = -(-(n + 2 * pad - k) // stride) + 1
+                if (o - 1) * stride >= n + pad:     # last window must start inside the input
+                    o -= 1
+            else:
+                o = (n + 2 * pad - k) // stride + 1
+            return o
+        dst = self.new_tensor(s.C, out(s.H), out(s.W), False, name)
+        self.nodes.append(PoolNode(src, dst, k, stride, pad, ceil_mode))
+        return dst
+
+    # -- analysis -------------------------------------------------------------
+    def truncated(self, hook_tensors: List[int]) -> "Graph":
+        """Copy of the graph holding only the nodes some hook tensor depends on."""
+        needed_bufs = set()
+        keep = [False] * len(self.nodes)
+        needed = set(hook_tensors)
+        for i in range(len(self.nodes) - 1, -1, -1):
+            nd = self.nodes[i]
+            d = self.tensors[nd.dst]
+            hit = nd.dst in needed or any(
+                self.tensors[t].buf == d.buf and _overlap(self.tensors[t], d) for t in needed)
+            if hit:
+                keep[i] = True
+                needed.add(nd.src)
+                if getattr(nd, "residual", None) is not None:
+                    needed.add(nd.residual)
+        g = Graph(self.arch, self.in_hw, self.tensors, self.buffers,
+                  [n for n, k in zip(self.nodes, keep) if k], dict(self.hooks), self.input)
+        return g
+
+    def macs_per_frame(self) -> int:
+        tot = 0
+        for nd in self.nodes:
+            if nd.op == "conv":
+                d = self.tensors[nd.dst]
+                tot += d.H * d.W * nd.cout * nd.cin * nd.kh * nd.kw
+        return tot
+
+    def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        """state_dict key -> shape for every parameter the nodes reference."""
+        out = {}
+        for nd in self.nodes:
+            if nd.op != "conv":
+                continue
+            out[nd.weight] = (nd.cout, nd.cin, nd.kh, nd.kw)
+            if nd.bias:
+                out[nd.bias] = (nd.cout,)
+            if nd.bn:
+                for s in ("weight", "bias", "running_mean", "running_var"):
+                    out[f"{nd.bn}.{s}"] = (nd.cout,)
+        return out
+
+
+def _overlap(a: TensorSpec, b: TensorSpec) -> bool:
+    return a.c_off < b.c_off + b.C and b.c_off < a.c_off + a.C
+
+
+# ---------------------------------------------------------------------------
+# ResNet v1.5 Bottleneck nets (torchvision `resnet50` / `resnet101`)
+# ---------------------------------------------------------------------------
+def resnet(layers=(3, 4, 23, 3), width=64, in_hw=(224, 224), arch="resnet101") -> Graph:
+    """Bottleneck ResNet.  Hook d = output of `layer{d}[-1]` (post-ReLU), as in
+    `/root/reference/image_attacks.py:261-262`."""
+    g = Graph(arch, in_hw)
+    x = g.new_tensor(3, in_hw[0], in_hw[1], False, "input")
+    g.input = x
+    x = g.conv(x, width, 7, 2, 3, "conv1.weight", bn="bn1", relu=True, name="stem")
+    x = g.maxpool(x, 3, 2, 1, name="maxpool")
+    inplanes = width
+    for li, nblocks in enumerate(layers):
+        planes = width * (2 ** li)
+        for b in range(nblocks):
+            stride = 2 if (b == 0 and li > 0) else 1
+            p = f"layer{li + 1}.{b}"
+            if stride != 1 or inplanes != planes * 4:
+                idt = g.conv(x, planes * 4, 1, stride, 0, f"{p}.downsample.0.weight",
+                             bn=f"{p}.downsample.1", relu=False, name=f"{p}.downsample")
+            else:
+                idt = x
+            a = g.conv(x, planes, 1, 1, 0, f"{p}.conv1.weight", bn=f"{p}.bn1", relu=True,
+                       name=f"{p}.conv1")
+            a = g.conv(a, planes, 3, stride, 1, f"{p}.conv2.weight", bn=f"{p}.bn2", relu=True,
+                       name=f"{p}.conv2")
+            x = g.conv(a, planes * 4, 1, 1, 0, f"{p}.conv3.weight", bn=f"{p}.bn3", relu=True,
+                       residual=idt, name=f"{p}.out")
+            inplanes = planes * 4
+        g.hooks[li + 1] = x
+    return g
+
+
+# ---------------------------------------------------------------------------
+# VGG-16 `features`
+# ---------------------------------------------------------------------------
+VGG16_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
+
+
+def vgg(cfg=VGG16_CFG, in_hw=(224, 224), arch="vgg16", hook_index=None) -> Graph:
+    """Hook d = ReLU module `features[{1:1,2:11,3:20,4:29}[d]]`
+    (`/root/reference/image_attacks.py:266-268`)."""
+    g = Graph(arch, in_hw)
+    x = g.new_tensor(3, in_hw[0], in_hw[1], False, "input")
+    g.input = x
+    idx = 0
+    relu_at = {}
+    for v in cfg:
+        if v == "M":
+            x = g.maxpool(x, 2, 2, 0, name=f"features.{idx}")
+            idx += 1
+        else:
+            x = g.conv(x, v, 3, 1, 1, f"features.{idx}.weight", bias=f"features.{idx}.bias",
+                       relu=True, name=f"features.{idx + 1}")
+            relu_at[idx + 1] = x
+            idx += 2
+    hook_index = hook_index or {1: 1, 2: 11, 3: 20, 4: 29}
+    for d, i in hook_index.items():
+        if i in relu_at:
+            g.hooks[d] = relu_at[i]
+    return g
+
+
+# ---------------------------------------------------------------------------
+# AlexNet `features`
+# ---------------------------------------------------------------------------
+def alexnet(width_div=1, in_hw=(224, 224), arch="alexnet") -> Graph:
+    """Hook d = ReLU module `features[{1:1,2:4,3:7,4:11}[d]]`
+    (`/root/reference/image_attacks.py:263-265`)."""
+    c = [max(4, v // width_div) for v in (64, 192, 384, 256, 256)]
+    g = Graph(arch, in_hw)
+    x = g.new_tensor(3, in_hw[0], in_hw[1], False, "input")
+    g.input = x
+    x = g.conv(x, c[0], 11, 4, 2, "features.0.weight", bias="features.0.bias", name="features.1")
+    g.hooks[1] = x
+    x = g.maxpool(x, 3, 2, 0, name="features.2")
+    x = g.conv(x, c[1], 5, 1, 2, "features.3.weight", bias="features.3.bias", name="features.4")
+    g.hooks[2] = x
+    x = g.maxpool(x, 3, 2, 0, name="features.5")
+    x = g.conv(x, c[2], 3, 1, 1, "features.6.weight", bias="features.6.bias", name="features.7")
+    g.hooks[3] = x
+    x = g.conv(x, c[3], 3, 1, 1, "features.8.weight", bias="features.8.bias", name="features.9")
+    x = g.conv(x, c[4], 3, 1, 1, "features.10.weight", bias="features.10.bias", name="features.11")
+    g.hooks[4] = x
+    return g
+
+
+# ---------------------------------------------------------------------------
+# SqueezeNet 1.1 `features`
+# ---------------------------------------------------------------------------
+def squeezenet(width_div=1, in_hw=(224, 224), arch="squeezenet1_1") -> Graph:
+    """Hook d = `features[{1:3,2:6,3:9,4:12}[d]].expand3x3_activation`, i.e. only the
+    3x3 branch of the Fire module (`/root/reference/image_attacks.py:269-271`)."""
+    def ch(v):
+        return max(4, v // width_div)
+    g = Graph(arch, in_hw)
+    x = g.new_tensor(3, in_hw[0], in_hw[1], False, "input")
+    g.input = x
+    x = g.conv(x, ch(64), 3, 2, 0, "features.0.weight", bias="features.0.bias", name="features.1")
+    x = g.maxpool(x, 3, 2, 0, ceil_mode=True, name="features.2")
+    fires = {3: (16, 64, 64), 4: (16, 64, 64), 6: (32, 128, 128), 7: (32, 128, 128),
+             9: (48, 192, 192), 10: (48, 192, 192), 11: (64, 256, 256), 12: (64, 256, 256)}
+    hook_of = {3: 1, 6: 2, 9: 3, 12: 4}
+    for idx in range(3, 13):
+        if idx in (5, 8):
+            x = g.maxpool(x, 3, 2, 0, ceil_mode=True, name=f"features.{idx}")
+            continue
+        sq, e1, e3 = (ch(v) for v in fires[idx])
+        p = f"features.{idx}"
+        s = g.conv(x, sq, 1, 1, 0, f"{p}.squeeze.weight", bias=f"{p}.squeeze.bias",
+                   name=f"{p}.squeeze_activation")
+        st = g.tensors[s]
+        cat_buf = g.new_buffer(e1 + e3)
+        g.conv(s, e1, 1, 1, 0, f"{p}.expand1x1.weight", bias=f"{p}.expand1x1.bias",
+               name=f"{p}.expand1x1_activation", dst_buf=cat_buf, dst_c_off=0)
+        t3 = g.conv(s, e3, 3, 1, 1, f"{p}.expand3x3.weight", bias=f"{p}.expand3x3.bias",
+                    name=f"{p}.expand3x3_activation", dst_buf=cat_buf, dst_c_off=e1)
+        x = g.new_tensor(e1 + e3, st.H, st.W, True, f"{p}.cat", buf=cat_buf, c_off=0)
+        if idx in hook_of:
+            g.hooks[hook_of[idx]] = t3
+    return g
+
+
+# ---------------------------------------------------------------------------
+# name -> graph, following the reference's `get_model` vocabulary
+# ---------------------------------------------------------------------------
+def build(model_name: str, in_hw=(224, 224)) -> Graph:
+    """`model_name` uses the reference's names (`image_attacks.py:85-87`):
+    'resnet' is ResNet-101 there (`:94-95`); 'resnet50' is added because
+    BASELINE.json quotes its metric on ResNet-50."""
+    if model_name == "resnet":
+        return resnet((3, 4, 23, 3), 64, in_hw, "resnet101")
+    if model_name == "resnet50":
+        return resnet((3, 4, 6, 3), 64, in_hw, "resnet50")
+    if model_name == "vgg":
+        return vgg(VGG16_CFG, in_hw, "vgg16")
+    if model_name == "alexnet":
+        return alexnet(1, in_hw)
+    if model_name == "squeezenet":
+        return squeezenet(1, in_hw)
+    if model_name == "densenet":
+        # The reference constructs densenet161 (`image_attacks.py:96-97`) but no attack class
+        # has a densenet branch in `_find_target_layer` (`:260-271`): the hook lookup returns
+        # None and `None.register_forward_hook` raises AttributeError.  Mirror that error.
+        raise AttributeError("'NoneType' object has no attribute 'register_forward_hook'")
+    # the reference leaves `model` unbound for unknown names (`image_attacks.py:103`)
+    raise UnboundLocalError("local variable 'model' referenced before assignment")
+
+
+#: tiny variants used by parity tests / golden fixtures (same topology, fewer channels/blocks)
+def build_tiny(model_name: str, in_hw=(64, 64)) -> Graph:
+    if model_name in ("resnet", "resnet50"):
+        return resnet((2, 1, 2, 1), 8, in_hw, "resnet_tiny")
+    if model_name == "vgg":
+        cfg = (8, 8, "M", 16, 16, "M", 16, 16, 16, "M", 32, 32, 32, "M", 32, 32, 32, "M")
+        return vgg(cfg, in_hw, "vgg_tiny")
+    if model_name == "alexnet":
+        return alexnet(8, in_hw, "alexnet_tiny")
+    if model_name == "squeezenet":
+        return squeezenet(4, in_hw, "squeezenet_tiny")
+    return build(model_name, in_hw)

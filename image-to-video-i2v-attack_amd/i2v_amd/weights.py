@@ -1,0 +1,71 @@
+"""Backbone weights in torchvision `state_dict` layout.
+
+The reference downloads ImageNet checkpoints with `models.<arch>(pretrained=True)`
+(`/root/reference/image_attacks.py:88-101`).  There is no network here, so the default is a
+seeded synthetic initialiser: Kaiming-normal(fan_out) convolutions and
+randomised BatchNorm statistics, so that BN folding is actually exercised.  A real checkpoint
+(`torch.save(model.state_dict())` of the torchvision model) is picked up from
+`$I2V_WEIGHTS_DIR/<arch>.pth` when present.
+"""
+import os
+from typing import Dict
+
+import torch
+
+from .graphs import Graph
+
+BN_EPS = 1e-5   # torchvision BatchNorm2d default, used by every ResNet BN
+
+
+def synthetic_state_dict(graph: Graph, seed: int = 0) -> Dict[str, torch.Tensor]:
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(seed)
+    sd = {}
+    for nd in graph.nodes:
+        if nd.op != "conv":
+            continue
+        fan_out = nd.cout * nd.kh * nd.kw
+        std = (2.0 / fan_out) ** 0.5
+        sd[nd.weight] = torch.randn(nd.cout, nd.cin, nd.kh, nd.kw, generator=gen) * std
+        if nd.bias:
+            sd[nd.bias] = torch.randn(nd.cout, generator=gen) * 0.05
+        if nd.bn:
+            sd[nd.bn + ".weight"] = torch.rand(nd.cout, generator=gen) + 0.5
+            sd[nd.bn + ".bias"] = torch.randn(nd.cout, generator=gen) * 0.1
+            sd[nd.bn + ".running_mean"] = torch.randn(nd.cout, generator=gen) * 0.1
+            sd[nd.bn + ".running_var"] = torch.rand(nd.cout, generator=gen) + 0.5
+    return sd
+
+
+def load_state_dict(graph: Graph, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Real checkpoint if `$I2V_WEIGHTS_DIR/<arch>.pth` exists, else the seeded initialiser."""
+    root = os.environ.get("I2V_WEIGHTS_DIR", "")
+    path = os.path.join(root, graph.arch + ".pth") if root else ""
+    if path and os.path.exists(path):
+        sd = torch.load(path, map_location="cpu")
+        shapes = graph.param_shapes()
+        missing = [k for k in shapes if k not in sd]
+        if missing:
+            raise KeyError(f"{path}: missing keys {missing[:4]}...")
+        for k, shp in shapes.items():
+            if tuple(sd[k].shape) != tuple(shp):
+                raise ValueError(f"{path}: {k} has shape {tuple(sd[k].shape)}, expected {shp}")
+        return {k: sd[k].float().contiguous() for k in shapes}
+    return synthetic_state_dict(graph, seed)
+
+
+def fold_affine(nd, sd):
+    """Per-output-channel (scale, shift) such that the node computes
+    `y = conv(x, W) * scale + shift` -- BatchNorm in eval mode
+    (`image_attacks.py:253-256` freezes every BN) or the conv bias."""
+    if nd.bn:
+        g = sd[nd.bn + ".weight"].double()
+        b = sd[nd.bn + ".bias"].double()
+        m = sd[nd.bn + ".running_mean"].double()
+        v = sd[nd.bn + ".running_var"].double()
+        s = g / torch.sqrt(v + BN_EPS)
+        t = b - m * s
+        return s.float(), t.float()
+    s = torch.ones(nd.cout)
+    t = sd[nd.bias].float() if nd.bias else torch.zeros(nd.cout)
+    return s, t

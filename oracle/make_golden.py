@@ -1,0 +1,159 @@
+"""TEST INFRASTRUCTURE -- generate `tests/golden/*.npz` from the IMPORTED reference classes.
+
+Run in the build container only (needs `/root/reference`):
+
+    python -m oracle.make_golden
+
+Each fixture is data: seeded inputs (uint8 clips), hyper-parameters, and what the unmodified
+reference class produced for them -- per-step cost strings (`loss_info`), the first-step
+gradient and per-step delta (captured by wrapping `torch.optim.Adam.step`), AENS weights, and
+the returned adversarial clip.  Backbones are the tiny nets of `oracle/tv_models.py` handed to
+the reference through the `torchvision.models` shim with the seeded weights of
+`i2v_amd.weights.synthetic_state_dict` (seed stored in the fixture).
+
+Two precisions are captured (SURVEY.md section 0.5 -- the loop is chaotic in fp32):
+  * "f64": backbone in float64 (delta/Adam stay float32 as the reference hard-codes
+    `torch.Tensor(...)`, image_attacks.py:304) -- pins the SEMANTICS to ~1e-7;
+  * "f32": everything float32 -- what the product computes in; used for cost-trajectory and
+    statistical parity.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "image-to-video-i2v-attack_amd"))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim, restate  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def make_clip(seed, b, f, hw):
+    """Synthetic clip per SURVEY.md 8(d): uint8 noise so exact 0.0/1.0 pixels occur."""
+    gen = torch.Generator().manual_seed(seed)
+    return torch.randint(0, 256, (b, 3, f, hw, hw), generator=gen, dtype=torch.uint8)
+
+
+def normalise(u8, dtype):
+    mean = torch.tensor(restate.MEAN, dtype=dtype).view(1, 3, 1, 1, 1)
+    std = torch.tensor(restate.STD, dtype=dtype).view(1, 3, 1, 1, 1)
+    return (u8.to(dtype) / 255 - mean) / std
+
+
+def costs_of(atk, name, steps):
+    return np.array([atk.loss_info[name][i]["cost"] for i in range(steps)])
+
+
+def run_image_attack(kind, prec, models, depth, steps, lr, b, f, hw, clip_seed, wseed=0, **kw):
+    dtype = torch.float64 if prec == "f64" else torch.float32
+    ref_shim.FACTORY.tiny, ref_shim.FACTORY.seed = True, wseed
+    ref_shim.FACTORY.in_hw, ref_shim.FACTORY.dtype = (hw, hw), dtype
+    ia = ref_shim.import_reference("image_attacks")
+    tp = ref_shim.import_reference("TPAMI_attack")
+    u8 = make_clip(clip_seed, b, f, hw)
+    vid = normalise(u8, dtype)
+    names = [f"clip{i}" for i in range(b)]
+    extra = {}
+    with ref_shim.quiet():
+        if kind == "i2v":
+            atk = ia.ImageGuidedFMDirection_Adam(models, depth=depth, step_size=lr, steps=steps)
+        elif kind == "std":
+            atk = ia.ImageGuidedStd_Adam(models, depth=depth, step_size=lr, steps=steps)
+        elif kind == "ens":
+            atk = ia.ImageGuidedFML2_Adam_MultiModels(models, depths=depth, steps=steps)
+            lr = 0.005                                     # hard-wired, image_attacks.py:376
+        elif kind == "aens":
+            atk = tp.AENS_I2V_MF(models, depths=depth, step_size=lr, steps=steps, **kw)
+        with ref_shim.AdamTap() as tap:
+            ret = atk(vid.clone(), torch.zeros(b, dtype=torch.long), names)
+            if kind == "aens" and kw.get("second_call", False) is False:
+                pass
+    if kind == "aens":
+        adv, _, cost_saved = ret
+        extra["weights"] = np.stack(atk.weights).astype(np.float32)
+        extra["cost_saved"] = np.asarray(cost_saved)
+        extra["coeffs_after"] = atk.coeffs.detach().numpy().astype(np.float32)
+    else:
+        adv = ret
+    fix = dict(kind=kind, prec=prec, models=np.array(models), depth=repr(depth), steps=steps, lr=lr,
+               b=b, f=f, hw=hw, clip_seed=clip_seed, wseed=wseed, clip_u8=u8.numpy(),
+               cost_str=costs_of(atk, names[0], steps),
+               grad0=tap.grad0.numpy().astype(np.float32),
+               delta_first=tap.deltas[0].numpy().astype(np.float32),
+               delta_last=tap.deltas[-1].numpy().astype(np.float32),
+               adv=adv.detach().numpy().astype(np.float32),
+               kw=repr({k: v for k, v in kw.items()}), **extra)
+    return fix
+
+
+def run_sign_step(clip_seed=77):
+    """BIM / MIFGSM update idiom (`base_attacks.py:261-340`) on a toy 5-D video model: pins
+    sign -> clip(+-eps) -> clip[0,1] -> renormalise, given the gradient the reference saw."""
+    ba = ref_shim.import_reference("base_attacks")
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(torch.nn.Conv3d(3, 4, 3, padding=1), torch.nn.ReLU(),
+                                torch.nn.AdaptiveAvgPool3d(1), torch.nn.Flatten(),
+                                torch.nn.Linear(4, 5))
+    u8 = make_clip(clip_seed, 1, 32, 12)
+    vid = normalise(u8, torch.float32)
+    labels = torch.tensor([2])
+    grads = []
+    orig = torch.autograd.grad
+
+    def grad_tap(*a, **k):
+        r = orig(*a, **k)
+        grads.append(r[0].detach().clone())
+        return r
+    out = {}
+    for cls in ("BIM", "MIFGSM"):
+        grads.clear()
+        torch.autograd.grad = grad_tap
+        try:
+            with ref_shim.quiet():
+                atk = getattr(ba, cls)(model, epsilon=16 / 255, steps=4)
+                adv = atk(vid.clone(), labels)
+        finally:
+            torch.autograd.grad = orig
+        out[cls + "_grads"] = torch.stack(grads).numpy()
+        out[cls + "_adv"] = adv.detach().numpy()
+    return dict(clip_u8=u8.numpy(), steps=4, eps=16 / 255, **out)
+
+
+CASES = {
+    # name: (kind, prec, models, depth(s), steps, lr, b, f, hw, clip_seed)
+    "i2v_resnet_d3_f64": ("i2v", "f64", ["resnet"], 3, 4, 0.005, 1, 3, 64, 1001),
+    "i2v_resnet_d2_f32": ("i2v", "f32", ["resnet"], 2, 6, 0.005, 1, 3, 64, 1002),
+    "i2v_vgg_d2_f64": ("i2v", "f64", ["vgg"], 2, 3, 0.004, 1, 2, 64, 1003),
+    "i2v_alexnet_d3_f64": ("i2v", "f64", ["alexnet"], 3, 3, 0.005, 1, 3, 64, 1004),
+    "i2v_squeezenet_d2_f64": ("i2v", "f64", ["squeezenet"], 2, 3, 0.005, 1, 3, 64, 1005),
+    "std_resnet_d2_f64": ("std", "f64", ["resnet"], 2, 3, 0.005, 1, 3, 64, 1006),
+    "ens_4models_f64": ("ens", "f64", ["resnet", "vgg", "squeezenet", "alexnet"],
+                        {"resnet": 2, "vgg": 3, "squeezenet": 2, "alexnet": 3}, 3, 0.005, 2, 2, 64, 1007),
+    "aens_2x2_f64": ("aens", "f64", ["resnet", "vgg"], {"resnet": [2, 3], "vgg": [2, 3]},
+                     4, 0.005, 2, 2, 64, 1008),
+}
+AENS_KW = {"aens_2x2_f64": dict(momentum=0.5, coef_CE=False)}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for name, args in CASES.items():
+        fix = run_image_attack(*args, **AENS_KW.get(name, {}))
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **fix)
+        print(name, os.path.getsize(path) // 1024, "KiB", fix["cost_str"][-1])
+    fix = run_image_attack("aens", "f64", ["resnet", "alexnet"], {"resnet": [2, 3], "alexnet": [2, 3]},
+                           3, 0.004, 1, 3, 64, 1009, momentum=0.0, coef_CE=True)
+    np.savez_compressed(os.path.join(OUT, "aens_coefce_f64.npz"), **fix)
+    print("aens_coefce_f64", fix["cost_str"][-1])
+    np.savez_compressed(os.path.join(OUT, "sign_step.npz"), **run_sign_step())
+    print("sign_step ok")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,295 @@
+"""TEST INFRASTRUCTURE -- CPU restatement ("oracle") of the reference's attack-loop arithmetic.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module; the product path (`i2v_amd`) never does and fails loudly without its HIP library.
+
+Parity status: the LOOP arithmetic (frame flattening, delta_0, compose/clamp semantics, cosine
+loss, cost definition, Adam state evolution, AENS re-weighting, output layout) is PINNED by
+golden vectors captured from the imported reference classes (`oracle/make_golden.py`,
+`tests/golden/*.npz`, re-checked live by `tests/test_oracle_vs_reference.py` whenever
+`/root/reference` is present).  The BACKBONE arithmetic (torchvision 0.10.1 graphs, ATen
+conv/BN/pool of pytorch 1.9.1) is third-party to the reference, which holds no tests or golden
+vectors for it: that part is pinned only against the locally installed torch 2.10 CPU ops
+through the same golden vectors.
+
+Everything here is written WITHOUT autograd: truncated forward to the hook layers, analytic
+cosine gradient, input-gradient-only backward (ReLU masks, pool arg-max, residual fan-out),
+inclusive clamp masks, and Adam spelled out op by op.
+"""
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+MEAN = (0.485, 0.456, 0.406)     # /root/reference/image_attacks.py:33-34
+STD = (0.229, 0.224, 0.225)
+BN_EPS = 1e-5
+COS_EPS = 1e-8                   # F.cosine_similarity default, image_attacks.py:343
+
+
+def _cvec(v, like):
+    return torch.tensor(v, dtype=like.dtype).view(1, 3, 1, 1)
+
+
+# ---------------------------------------------------------------------------
+# backbone: forward to the hooks / backward to the input, interpreting the graph IR
+# ---------------------------------------------------------------------------
+class OracleNet:
+    """Truncated backbone.  Forward follows the reference's call `self.model(x)` with BN
+    frozen in eval mode (`image_attacks.py:253-256,318,334`); backward is what
+    `cost.backward()` (`:352`) delivers to the input, minus the wasted weight gradients."""
+
+    def __init__(self, graph, state_dict, hook_tensors: Sequence[int], dtype=torch.float32):
+        self.g = graph.truncated(list(hook_tensors))
+        self.hooks = list(hook_tensors)
+        self.sd = {k: v.to(dtype) for k, v in state_dict.items()}
+        self.dtype = dtype
+        self.buf: Dict[int, torch.Tensor] = {}
+        self.pool_idx: Dict[int, torch.Tensor] = {}
+
+    def _view(self, store, tid, N=None):
+        t = self.g.tensors[tid]
+        if t.buf not in store:
+            store[t.buf] = torch.zeros(N, self.g.buffers[t.buf], t.H, t.W, dtype=self.dtype)
+        return store[t.buf][:, t.c_off:t.c_off + t.C]
+
+    def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
+        g, N = self.g, x.shape[0]
+        self.buf, self.pool_idx = {}, {}
+        self._view(self.buf, g.input, N).copy_(x)
+        for i, nd in enumerate(g.nodes):
+            src = self._view(self.buf, nd.src, N)
+            if nd.op == "conv":
+                bias = self.sd[nd.bias] if nd.bias else None
+                y = F.conv2d(src, self.sd[nd.weight], bias, nd.stride, nd.pad)
+                if nd.bn:
+                    y = F.batch_norm(y, self.sd[nd.bn + ".running_mean"],
+                                     self.sd[nd.bn + ".running_var"], self.sd[nd.bn + ".weight"],
+                                     self.sd[nd.bn + ".bias"], False, 0.1, BN_EPS)
+                if nd.residual is not None:
+                    y = y + self._view(self.buf, nd.residual, N)
+                if nd.relu:
+                    y = F.relu(y)
+            else:
+                y, idx = F.max_pool2d(src, nd.k, nd.stride, nd.pad, ceil_mode=nd.ceil_mode,
+                                      return_indices=True)
+                self.pool_idx[i] = idx
+            self._view(self.buf, nd.dst, N).copy_(y)
+        return [self._view(self.buf, h, N) for h in self.hooks]
+
+    def tensor(self, tid):
+        return self._view(self.buf, tid)
+
+    def backward(self, hook_grads: Sequence[torch.Tensor]) -> torch.Tensor:
+        """d(cost)/d(input) given d(cost)/d(hook feature) for every hook (same order)."""
+        g = self.g
+        N = hook_grads[0].shape[0]
+        gb: Dict[int, torch.Tensor] = {}
+        for h, hg in zip(self.hooks, hook_grads):
+            self._view(gb, h, N).add_(hg)
+        self._view(gb, g.input, N)
+        for i in range(len(g.nodes) - 1, -1, -1):
+            nd = g.nodes[i]
+            gd = self._view(gb, nd.dst, N)
+            src = self._view(self.buf, nd.src, N)
+            if nd.op == "conv":
+                dz = gd
+                if nd.relu:
+                    dz = dz * (self._view(self.buf, nd.dst, N) > 0).to(self.dtype)
+                if nd.residual is not None:
+                    self._view(gb, nd.residual, N).add_(dz)
+                if nd.bn:
+                    inv = self.sd[nd.bn + ".weight"] / torch.sqrt(self.sd[nd.bn + ".running_var"] + BN_EPS)
+                    dz = dz * inv.view(1, -1, 1, 1)
+                gx = torch.nn.grad.conv2d_input(src.shape, self.sd[nd.weight], dz.contiguous(),
+                                                nd.stride, nd.pad)
+                self._view(gb, nd.src, N).add_(gx)
+            else:
+                idx = self.pool_idx[i]
+                C = src.shape[1]
+                gx = torch.zeros(N, C, src.shape[2] * src.shape[3], dtype=self.dtype)
+                gx.scatter_add_(2, idx.reshape(N, C, -1), gd.reshape(N, C, -1))
+                self._view(gb, nd.src, N).add_(gx.view_as(src))
+        return self._view(gb, g.input, N).clone()
+
+
+# ---------------------------------------------------------------------------
+# elementwise pieces of the loop
+# ---------------------------------------------------------------------------
+def flatten_frames(videos: torch.Tensor) -> torch.Tensor:
+    """(b,c,f,h,w) -> (b*f,c,h,w), frame n = b_idx*f + f_idx (`image_attacks.py:300-301`)."""
+    b, c, f, h, w = videos.shape
+    return videos.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+
+
+def unflatten_frames(x: torch.Tensor, b: int, f: int) -> torch.Tensor:
+    """`image_attacks.py:362-363`."""
+    n, c, h, w = x.shape
+    return x.reshape(b, f, c, h, w).permute(0, 2, 1, 3, 4)
+
+
+def unnormalise(x: torch.Tensor) -> torch.Tensor:
+    """u = x*std + mean with in-place mul_ then add_ (`image_attacks.py:62,308`)."""
+    return x.clone().mul_(_cvec(STD, x)).add_(_cvec(MEAN, x))
+
+
+def compose(u, delta, eps):
+    """x = (clamp(u + clamp(delta,-eps,eps),0,1) - mean)/std (`image_attacks.py:331-332`,
+    `:59` -- subtraction then DIVISION by std).  Also returns the inclusive pass-through
+    mask of the two clamps (ATen clamp_backward: (x >= min) & (x <= max))."""
+    dc = torch.clamp(delta, -eps, eps)
+    s = u + dc
+    xi = torch.clamp(s, 0, 1)
+    xn = (xi - _cvec(MEAN, u)) / _cvec(STD, u)
+    mask = ((delta >= -eps) & (delta <= eps) & (s >= 0) & (s <= 1)).to(u.dtype)
+    return xn, mask
+
+
+def compose_backward(gx, mask):
+    """d/d(delta) of compose: divide by std (div_ backward), gate by both clamps."""
+    return gx / _cvec(STD, gx) * mask
+
+
+def cosine_fwd_bwd(a: torch.Tensor, b: torch.Tensor):
+    """Per-frame cosine similarity over the flattened feature and its gradient w.r.t. `a`
+    (`image_attacks.py:341-343`; b is detached `:322`).  Returns (cos[N], dcos/da)."""
+    N = a.shape[0]
+    af, bf = a.reshape(N, -1), b.reshape(N, -1)
+    n1 = af.norm(dim=1, keepdim=True).clamp_min(COS_EPS)
+    n2 = bf.norm(dim=1, keepdim=True).clamp_min(COS_EPS)
+    cos = ((af / n1) * (bf / n2)).sum(1)
+    grad = bf / (n1 * n2) - cos.view(N, 1) * af / (n1 * n1)
+    return cos, grad.view_as(a)
+
+
+class AdamState:
+    """`torch.optim.Adam([delta], lr)` with defaults betas=(0.9,0.999), eps=1e-8
+    (`image_attacks.py:306`), single-tensor path of torch/optim/adam.py: lerp_ for m,
+    mul_+addcmul_ for v, host-side bias corrections in double."""
+
+    def __init__(self, like, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.m = torch.zeros_like(like)
+        self.v = torch.zeros_like(like)
+        self.t = 0
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+
+    def step(self, delta, grad):
+        self.t += 1
+        self.m.lerp_(grad, 1 - self.b1)
+        self.v.mul_(self.b2).addcmul_(grad, grad, value=1 - self.b2)
+        bc1 = 1 - self.b1 ** self.t
+        bc2 = 1 - self.b2 ** self.t
+        step_size = self.lr / bc1
+        denom = (self.v.sqrt() / (bc2 ** 0.5)).add_(self.eps)
+        delta.addcdiv_(self.m, denom, value=-step_size)
+
+
+def sign_step_bim(adv_norm, u, grad, step_size, eps):
+    """BIM-style update (`/root/reference/base_attacks.py:289-293`): un-normalise, sign step,
+    project delta to +-eps, clamp to [0,1], re-normalise.  5-D (b,3,f,h,w) tensors."""
+    mean = torch.tensor(MEAN, dtype=u.dtype).view(3, 1, 1, 1)
+    std = torch.tensor(STD, dtype=u.dtype).view(3, 1, 1, 1)
+    a = adv_norm.clone().mul_(std).add_(mean)
+    a = a + step_size * grad.sign()
+    d = torch.clamp(a - u, -eps, eps)
+    a = torch.clamp(u + d, 0, 1)
+    return a.sub_(mean).div_(std)
+
+
+def sign_step_ilaf(delta, grad, step_size):
+    """ILAF update `modifier.data -= step_size * grad.sign()` (`image_attacks.py:617`)."""
+    return delta - step_size * grad.sign()
+
+
+def aens_coeffs(prev, coeffs, momentum):
+    """`coeffs = softmax(softmax(prev) + momentum*coeffs)` (`TPAMI_attack.py:265`)."""
+    return torch.softmax(torch.softmax(prev, 0) + momentum * coeffs, 0)
+
+
+# ---------------------------------------------------------------------------
+# the attack loops
+# ---------------------------------------------------------------------------
+def run_attack(nets: Sequence[OracleNet], videos: torch.Tensor, *, steps: int, step_size: float,
+               epsilon: float = 16 / 255, mode: str = "i2v", coeffs: Optional[torch.Tensor] = None,
+               momentum: float = 0.0, coef_CE: bool = False, trace: bool = False,
+               forced_deltas: Optional[Sequence[torch.Tensor]] = None):
+    """Restates `ImageGuidedFMDirection_Adam.forward` (`image_attacks.py:294-364`, one net, one
+    hook), `ImageGuidedFML2_Adam_MultiModels.forward` (`:426-496`, several nets) [mode 'i2v'],
+    `AENS_I2V_MF.forward` (`TPAMI_attack.py:223-320`) [mode 'aens'] and
+    `ImageGuidedStd_Adam.forward` (`image_attacks.py:187-234`) [mode 'std'].
+
+    `forced_deltas[i]`, when given, replaces delta at the START of step i (teacher forcing).
+    Returns a dict: adv (b,3,f,h,w), costs[steps] (float32), and with trace=True per-step
+    delta (after the update), first-step gradient, cos per (step, layer, frame), weights.
+    """
+    dt = nets[0].dtype
+    b, c, f, h, w = videos.shape
+    x = flatten_frames(videos.to(dt)).contiguous()
+    N = b * f
+    delta = torch.full((N, c, h, w), 0.01 / 255, dtype=dt)          # image_attacks.py:304
+    opt = AdamState(delta, step_size)
+    u = unnormalise(x)                                              # :308
+    init = None
+    if mode != "std":
+        init = [[t.clone() for t in net.forward(x)] for net in nets]   # :318-323 (raw x, not norm(u))
+    L = sum(len(net.hooks) for net in nets)
+    out = {"costs": np.zeros(steps, np.float32), "deltas": [], "cos": [], "weights": [], "grad0": None}
+    prev = torch.ones(L, dtype=dt) if mode == "aens" else None
+    for i in range(steps):
+        if forced_deltas is not None:
+            delta = forced_deltas[i].clone().to(dt)
+        if mode == "aens":
+            coeffs = aens_coeffs(prev, coeffs, momentum)            # TPAMI_attack.py:265
+            out["weights"].append(coeffs.clone().numpy())
+        xn, mask = compose(u, delta, epsilon)
+        gx = torch.zeros_like(xn)
+        cos_all = []
+        l = 0
+        cost = torch.zeros((), dtype=dt)
+        for n, net in enumerate(nets):
+            feats = net.forward(xn)
+            hgrads = []
+            for k, a in enumerate(feats):
+                if mode == "std":
+                    # cost += a.std() over the WHOLE tensor, unbiased (image_attacks.py:218)
+                    cnt = a.numel()
+                    mu = a.mean()
+                    sd = a.std()
+                    cost = cost + sd
+                    hgrads.append((a - mu) / ((cnt - 1) * sd))
+                    cos_all.append(torch.full((N,), float(sd), dtype=dt))
+                    continue
+                cs, gr = cosine_fwd_bwd(a, init[n][k])
+                cos_all.append(cs)
+                if mode == "aens":
+                    hgrads.append(gr * (coeffs[l] / L))             # mean over L of coeff*sum_frames
+                else:
+                    hgrads.append(gr)                               # cost = sum_l sum_f cos
+                l += 1
+            gx += net.backward(hgrads)
+        cosm = torch.stack(cos_all)                                 # (L, N)
+        if mode == "aens":
+            each = (coeffs.view(-1, 1) * cosm).sum(1)               # TPAMI_attack.py:289-291
+            cost = each.mean()
+            prev = each.clone() if coef_CE else cosm.sum(1)         # :293-297
+        elif mode == "i2v":
+            cost = cosm.sum()                                       # image_attacks.py:347
+        out["costs"][i] = float(cost)
+        g = compose_backward(gx, mask)
+        if i == 0 and trace:
+            out["grad0"] = g.clone()
+        opt.step(delta, g)                                          # :351-353
+        if trace:
+            out["deltas"].append(delta.clone())
+            out["cos"].append(cosm.clone())
+    xn, _ = compose(u, delta, epsilon)                              # :360-361
+    out["adv"] = unflatten_frames(xn, b, f)
+    out["coeffs"] = coeffs
+    return out
+
+
+def cost_strings(costs: np.ndarray) -> List[str]:
+    """`str(cost.detach().cpu().numpy())` of a float32 scalar (`image_attacks.py:358`)."""
+    return [str(np.float32(c)) for c in costs]
