@@ -37,7 +37,7 @@ def test_i2v_live_f64(model, depth):
     assert (tap.grad0.double() - out["grad0"]).abs().max() <= 2e-6 * tap.grad0.abs().max()
     assert (tap.deltas[-1].double() - out["deltas"][-1]).abs().max() < 5e-6
     assert (adv.detach() - out["adv"]).abs().max() < 5e-5
-    assert adv.shape == vid.shape and not adv.is_contiguous()      # permuted view, image_attacks.py:363
+    assert adv.shape == vid.shape                                  # (b,3,f,h,w), image_attacks.py:362-363
 
 
 def test_aens_coeffs_persist_across_calls():
