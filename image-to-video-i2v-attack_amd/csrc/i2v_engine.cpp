@@ -1,0 +1,719 @@
+// Graph planner + executor behind the C ABI of include/i2v_hip.h.
+//
+// The host declares a backbone as buffers, channel-slice tensor views and conv/maxpool nodes.
+// `i2v_net_plan` then
+//   * packs every convolution twice -- forward [K=(tap,cin)][cout] and input-gradient
+//     [K=(tap,cout)][cin] per stride-parity class -- with the eval-mode BatchNorm scale folded in
+//     (reference: image_attacks.py:253-256 freezes BN; autograd's BN backward is a per-channel
+//     multiply by the same scale),
+//   * lays out one arena (activations + gradients + temporaries) for `max_frames` frames,
+//   * emits a flat launch list for the forward pass to the deepest hook and one for the
+//     input-gradient pass.  Only d(cost)/d(input) is produced: the reference's weight gradients
+//     (image_attacks.py:352, wasted -- weights are frozen) are never computed.
+//
+// Backward fusion rule: every tensor's gradient is finalised by exactly one launch -- the dgrad of
+// its FIRST consumer in forward order -- whose epilogue adds the pending contributions of the
+// other consumers (residual alias, downsample dgrad, hook gradient) and applies the tensor's own
+// ReLU mask.  Non-final contributions are written raw into temporaries.
+#include "../../include/i2v_hip.h"
+#include "i2v_kernels.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+
+static int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define CHECK_BE(expr)                                                            \
+    do {                                                                          \
+        if ((expr) != 0) return fail("%s: %s", #expr, be_error() ? be_error() : "backend error"); \
+    } while (0)
+
+namespace {
+
+struct Buffer { int C, H, W; size_t act_off = 0, grad_off = 0; bool is_input = false; };
+struct Tensor { int buf, c_off, C; bool post_relu; };
+
+struct Packed {               // one implicit-GEMM operand set
+    float* wp = nullptr; I2VKEntry* ktab = nullptr;
+    int Kpad = 0, Cd = 0, Cdpad = 0;
+    int ph = 0, pw = 0, Hg = 0, Wg = 0;
+};
+
+struct Node {
+    int type;                 // 0 conv, 1 maxpool
+    i2v_conv_desc cd; i2v_pool_desc pd;
+    std::vector<float> w;     // [cout][cin][kh][kw] with scale folded
+    std::vector<float> shift;
+    float* shift_d = nullptr; float* w_d = nullptr;
+    Packed fwd; std::vector<Packed> bwd;
+};
+
+enum Kind { L_CONV, L_IMGGRAD, L_POOLF, L_POOLB, L_ADDMASK };
+struct Launch {
+    Kind kind;
+    I2VConvParams conv; I2VImgGradParams img; I2VPoolParams pool; I2VAddMaskParams am;
+    bool src_is_input = false;     // conv: src pointer patched with the caller's x
+};
+
+struct Addend { const float* p; int64_t nstride; int stride, H, W; };
+
+struct Net {
+    std::vector<Buffer> bufs; std::vector<Tensor> tens; std::vector<Node> nodes;
+    int input = -1; std::vector<int> hooks; int maxN = 0; bool planned = false;
+    float* arena = nullptr; size_t arena_floats = 0; std::vector<void*> dev_allocs;
+    std::vector<Launch> fwd, bwd;
+    int frames = 0;
+    size_t weight_bytes = 0;
+    std::vector<float*> hook_tmp;  // per hook: separate gradient buffer when the hooked tensor is also consumed
+};
+
+}  // namespace
+
+struct i2v_ctx { int device; std::vector<Net*> nets; };
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <typename T>
+static int upload(Net& n, const std::vector<T>& host, T** dev) {
+    size_t bytes = host.size() * sizeof(T);
+    void* d = be_malloc(bytes ? bytes : 16);
+    if (!d) return fail("device allocation of %zu bytes failed", bytes);
+    n.dev_allocs.push_back(d);
+    n.weight_bytes += bytes;
+    if (bytes) CHECK_BE(be_h2d(d, host.data(), bytes));
+    *dev = (T*)d;
+    return 0;
+}
+
+static Net* get_net(i2v_handle h, int id) {
+    if (!h || id < 0 || id >= (int)h->nets.size() || !h->nets[id]) { fail("bad net id %d", id); return nullptr; }
+    return h->nets[id];
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+static int posmod(int a, int b) { int m = a % b; return m < 0 ? m + b : m; }
+
+static int pack_fwd(Net& n, Node& nd) {
+    const i2v_conv_desc& c = nd.cd;
+    const Buffer& sb = n.bufs[n.tens[c.src].buf];
+    int K = c.kh * c.kw * c.cin;
+    Packed& P = nd.fwd;
+    P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cout; P.Cdpad = (int)align_up(c.cout, 128);
+    std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
+    std::vector<I2VKEntry> kt(P.Kpad, I2VKEntry{0, 0, 0, 0});
+    for (int r = 0; r < c.kh; ++r)
+        for (int s = 0; s < c.kw; ++s)
+            for (int ci = 0; ci < c.cin; ++ci) {
+                int k = (r * c.kw + s) * c.cin + ci;
+                kt[k] = I2VKEntry{ci * sb.H * sb.W, r - c.pad, s - c.pad, 1};
+                for (int co = 0; co < c.cout; ++co)
+                    wp[(size_t)k * P.Cdpad + co] = nd.w[(((size_t)co * c.cin + ci) * c.kh + r) * c.kw + s];
+            }
+    if (upload(n, wp, &P.wp)) return 1;
+    return upload(n, kt, &P.ktab);
+}
+
+static int pack_bwd(Net& n, Node& nd) {
+    const i2v_conv_desc& c = nd.cd;
+    const Buffer& sb = n.bufs[n.tens[c.src].buf];
+    const Buffer& db = n.bufs[n.tens[c.dst].buf];
+    int st = c.stride;
+    for (int ph = 0; ph < st; ++ph)
+        for (int pw = 0; pw < st; ++pw) {
+            Packed P;
+            P.ph = ph; P.pw = pw;
+            P.Hg = (sb.H - ph + st - 1) / st; P.Wg = (sb.W - pw + st - 1) / st;
+            std::vector<int> tr, ts;
+            for (int r = 0; r < c.kh; ++r) if (posmod(ph + c.pad - r, st) == 0) tr.push_back(r);
+            for (int s = 0; s < c.kw; ++s) if (posmod(pw + c.pad - s, st) == 0) ts.push_back(s);
+            int K = (int)(tr.size() * ts.size()) * c.cout;
+            P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cin; P.Cdpad = (int)align_up(c.cin, 128);
+            std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
+            std::vector<I2VKEntry> kt(P.Kpad ? P.Kpad : 1, I2VKEntry{0, 0, 0, 0});
+            int t = 0;
+            for (int r : tr)
+                for (int s : ts) {
+                    int dh = floordiv(ph + c.pad - r, st), dw = floordiv(pw + c.pad - s, st);
+                    for (int co = 0; co < c.cout; ++co) {
+                        int k = t * c.cout + co;
+                        kt[k] = I2VKEntry{co * db.H * db.W, dh, dw, 1};
+                        for (int ci = 0; ci < c.cin; ++ci)
+                            wp[(size_t)k * P.Cdpad + ci] =
+                                nd.w[(((size_t)co * c.cin + ci) * c.kh + r) * c.kw + s];
+                    }
+                    ++t;
+                }
+            if (upload(n, wp, &P.wp)) return 1;
+            if (upload(n, kt, &P.ktab)) return 1;
+            nd.bwd.push_back(P);
+        }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// views
+// ---------------------------------------------------------------------------------------------
+struct View { float* p; int64_t nstride; int C, H, W; };
+
+static View view_of(Net& n, int t, bool grad) {
+    const Tensor& T = n.tens[t];
+    const Buffer& B = n.bufs[T.buf];
+    size_t off = grad ? B.grad_off : B.act_off;
+    View v;
+    v.p = n.arena + off + (size_t)T.c_off * B.H * B.W;
+    v.nstride = (int64_t)B.C * B.H * B.W;
+    v.C = T.C; v.H = B.H; v.W = B.W;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI: lifetime
+// ---------------------------------------------------------------------------------------------
+extern "C" const char* i2v_last_error(void) { return g_err.c_str(); }
+extern "C" int i2v_abi_version(void) { return 1; }
+extern "C" const char* i2v_backend(void) { return be_name(); }
+
+extern "C" int i2v_create(int device, i2v_handle* out) {
+    if (!out) return fail("i2v_create: null out");
+    if (be_set_device(device)) return fail("i2v_create: cannot select device %d: %s", device,
+                                           be_error() ? be_error() : "?");
+    *out = new i2v_ctx{device, {}};
+    return 0;
+}
+
+static void free_net(Net* n) {
+    if (!n) return;
+    for (void* p : n->dev_allocs) be_free(p);
+    if (n->arena) be_free(n->arena);
+    delete n;
+}
+
+extern "C" int i2v_destroy(i2v_handle h) {
+    if (!h) return 0;
+    for (Net* n : h->nets) free_net(n);
+    delete h;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI: description
+// ---------------------------------------------------------------------------------------------
+extern "C" int i2v_net_create(i2v_handle h, int* net) {
+    if (!h || !net) return fail("i2v_net_create: null argument");
+    h->nets.push_back(new Net());
+    *net = (int)h->nets.size() - 1;
+    return 0;
+}
+
+extern "C" int i2v_net_add_buffer(i2v_handle h, int net, int C, int H, int W, int* buf) {
+    Net* n = get_net(h, net); if (!n) return 1;
+    if (n->planned) return fail("net already planned");
+    if (C <= 0 || H <= 0 || W <= 0) return fail("bad buffer shape %dx%dx%d", C, H, W);
+    n->bufs.push_back(Buffer{C, H, W});
+    *buf = (int)n->bufs.size() - 1;
+    return 0;
+}
+
+extern "C" int i2v_net_add_tensor(i2v_handle h, int net, int buf, int c_off, int C, int post_relu, int* tensor) {
+    Net* n = get_net(h, net); if (!n) return 1;
+    if (buf < 0 || buf >= (int)n->bufs.size()) return fail("bad buffer id %d", buf);
+    if (c_off < 0 || C <= 0 || c_off + C > n->bufs[buf].C) return fail("tensor view outside buffer");
+    n->tens.push_back(Tensor{buf, c_off, C, post_relu != 0});
+    *tensor = (int)n->tens.size() - 1;
+    return 0;
+}
+
+extern "C" int i2v_net_set_input(i2v_handle h, int net, int tensor) {
+    Net* n = get_net(h, net); if (!n) return 1;
+    if (tensor < 0 || tensor >= (int)n->tens.size()) return fail("bad tensor id");
+    n->input = tensor;
+    n->bufs[n->tens[tensor].buf].is_input = true;
+    return 0;
+}
+
+extern "C" int i2v_net_add_conv(i2v_handle h, int net, const i2v_conv_desc* d, const float* weight,
+                                const float* scale, const float* shift) {
+    Net* n = get_net(h, net); if (!n) return 1;
+    if (n->planned) return fail("net already planned");
+    if (!d || !weight || !scale || !shift) return fail("i2v_net_add_conv: null argument");
+    int nt = (int)n->tens.size();
+    if (d->src < 0 || d->src >= nt || d->dst < 0 || d->dst >= nt || d->residual >= nt)
+        return fail("i2v_net_add_conv: bad tensor id");
+    const Tensor& S = n->tens[d->src]; const Tensor& D = n->tens[d->dst];
+    const Buffer& sb = n->bufs[S.buf]; const Buffer& db = n->bufs[D.buf];
+    if (S.C != d->cin || D.C != d->cout) return fail("conv channel mismatch");
+    if (d->stride < 1 || d->kh < 1 || d->kw < 1 || d->pad < 0) return fail("bad conv geometry");
+    int Ho = (sb.H + 2 * d->pad - d->kh) / d->stride + 1, Wo = (sb.W + 2 * d->pad - d->kw) / d->stride + 1;
+    if (Ho != db.H || Wo != db.W) return fail("conv output %dx%d does not match buffer %dx%d", Ho, Wo, db.H, db.W);
+    if (d->residual >= 0) {
+        const Tensor& R = n->tens[d->residual]; const Buffer& rb = n->bufs[R.buf];
+        if (R.C != d->cout || rb.H != db.H || rb.W != db.W) return fail("residual shape mismatch");
+    }
+    Node nd; nd.type = 0; nd.cd = *d; memset(&nd.pd, 0, sizeof nd.pd);
+    size_t per = (size_t)d->cin * d->kh * d->kw;
+    nd.w.resize((size_t)d->cout * per);
+    for (int co = 0; co < d->cout; ++co)
+        for (size_t i = 0; i < per; ++i) nd.w[co * per + i] = weight[co * per + i] * scale[co];
+    nd.shift.assign(shift, shift + d->cout);
+    n->nodes.push_back(std::move(nd));
+    return 0;
+}
+
+extern "C" int i2v_net_add_maxpool(i2v_handle h, int net, const i2v_pool_desc* d) {
+    Net* n = get_net(h, net); if (!n) return 1;
+    if (n->planned) return fail("net already planned");
+    int nt = (int)n->tens.size();
+    if (!d || d->src < 0 || d->src >= nt || d->dst < 0 || d->dst >= nt) return fail("bad pool desc");
+    if (n->tens[d->src].C != n->tens[d->dst].C) return fail("pool channel mismatch");
+    Node nd; nd.type = 1; nd.pd = *d; memset(&nd.cd, 0, sizeof nd.cd);
+    n->nodes.push_back(std::move(nd));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// planning
+// ---------------------------------------------------------------------------------------------
+static void conv_common(I2VConvParams& p, const Packed& P) {
+    memset(&p, 0, sizeof p);
+    p.wp = P.wp; p.ktab = P.ktab; p.Kpad = P.Kpad; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
+    p.add0_stride = 1;
+}
+
+static bool overlaps(const Tensor& a, const Tensor& b) {
+    return a.buf == b.buf && a.c_off < b.c_off + b.C && b.c_off < a.c_off + a.C;
+}
+
+namespace {
+
+struct Planner {
+    Net& n; bool dry; size_t off; size_t N;
+    std::vector<int> left; std::vector<std::vector<Addend>> pending;
+    std::vector<float*> hook_tmp;      // per hook: temp gradient buffer or null (direct)
+    std::vector<View> galias; std::vector<char> has_alias;   // residual gradient that is just a view
+    std::string err;
+
+    float* base() const { return dry ? (float*)nullptr : n.arena; }
+    size_t carve(size_t floats) { size_t o = off; off = align_up(off + floats, 64); return o; }
+    float* temp(size_t floats) { return base() + carve(floats); }
+
+    View view(int t, bool grad) {
+        if (grad && has_alias[t]) return galias[t];
+        const Tensor& T = n.tens[t]; const Buffer& B = n.bufs[T.buf];
+        View v; v.p = base() + (grad ? B.grad_off : B.act_off) + (size_t)T.c_off * B.H * B.W;
+        v.nstride = (int64_t)B.C * B.H * B.W; v.C = T.C; v.H = B.H; v.W = B.W;
+        return v;
+    }
+    void emit(std::vector<Launch>& L, const Launch& l) { if (!dry) L.push_back(l); }
+
+    void emit_addmask(View out, const std::vector<Addend>& adds, int t) {
+        Launch l; memset(&l.am, 0, sizeof l.am); l.kind = L_ADDMASK;
+        l.am.out = out.p; l.am.out_nstride = out.nstride;
+        for (size_t i = 0; i < adds.size() && i < 3; ++i) { l.am.a[i] = adds[i].p; l.am.a_nstride[i] = adds[i].nstride; }
+        if (n.tens[t].post_relu) { View a = view(t, false); l.am.mask = a.p; l.am.mask_nstride = a.nstride; }
+        l.am.N = 0; l.am.C = out.C; l.am.HW = out.H * out.W;
+        emit(n.bwd, l);
+    }
+
+    // reduce pending list of tensor t to at most `keep` plain/compact addends
+    bool squeeze_pending(int t, size_t keep) {
+        auto& P = pending[t];
+        while (P.size() > keep) {
+            // fold the last two plain addends into a temp
+            size_t a = P.size() - 1, b = P.size() - 2;
+            if (P[a].stride != 1 || P[b].stride != 1) { err = "cannot fold compact addends"; return false; }
+            View g = view(t, true);
+            View tv = g; tv.p = temp(N * g.C * g.H * g.W); tv.nstride = (int64_t)g.C * g.H * g.W;
+            Launch l; memset(&l.am, 0, sizeof l.am); l.kind = L_ADDMASK;
+            l.am.out = tv.p; l.am.out_nstride = tv.nstride;
+            l.am.a[0] = P[a].p; l.am.a_nstride[0] = P[a].nstride;
+            l.am.a[1] = P[b].p; l.am.a_nstride[1] = P[b].nstride;
+            l.am.C = g.C; l.am.HW = g.H * g.W;
+            emit(n.bwd, l);
+            P.pop_back(); P.pop_back();
+            P.push_back(Addend{tv.p, tv.nstride, 1, g.H, g.W});
+        }
+        return true;
+    }
+
+    void conv_launches(const Node& nd, View dz, View out, bool raw, int t, bool compact) {
+        const i2v_conv_desc& c = nd.cd;
+        for (const Packed& P : nd.bwd) {
+            if (compact && (P.ph || P.pw)) continue;
+            if (P.Hg <= 0 || P.Wg <= 0) continue;
+            Launch l; l.kind = L_CONV; conv_common(l.conv, P);
+            I2VConvParams& p = l.conv;
+            p.src = dz.p; p.src_nstride = dz.nstride; p.Hs = dz.H; p.Ws = dz.W;
+            p.Hg = P.Hg; p.Wg = P.Wg; p.sh = 1; p.sw = 1;
+            p.dst = out.p; p.dst_nstride = out.nstride;
+            if (compact) { p.Ho = P.Hg; p.Wo = P.Wg; p.osh = p.osw = 1; p.oh0 = p.ow0 = 0; }
+            else { p.Ho = out.H; p.Wo = out.W; p.osh = p.osw = c.stride; p.oh0 = P.ph; p.ow0 = P.pw; }
+            if (!raw) {
+                for (const Addend& a : pending[t]) {
+                    if (a.stride != 1 || p.add0 == nullptr) {
+                        if (p.add0 != nullptr) { p.add1 = p.add0; p.add1_nstride = p.add0_nstride; }
+                        p.add0 = a.p; p.add0_nstride = a.nstride; p.add0_stride = a.stride; p.add0_H = a.H; p.add0_W = a.W;
+                    } else { p.add1 = a.p; p.add1_nstride = a.nstride; }
+                }
+                if (n.tens[t].post_relu) { View a = view(t, false); p.mask = a.p; p.mask_nstride = a.nstride; }
+            }
+            p.pointwise = (c.kh == 1 && c.kw == 1 && c.stride == 1 && c.pad == 0 && (dz.H * dz.W) % 4 == 0 &&
+                           !compact) ? 1 : 0;
+            emit(n.bwd, l);
+        }
+    }
+    bool is_hook(int t) const { for (int hk : n.hooks) if (hk == t) return true; return false; }
+    static bool has_compact(const std::vector<Addend>& A) { for (auto& a : A) if (a.stride != 1) return true; return false; }
+
+    bool contribute_conv(int t, const Node& nd, View dz) {
+        left[t]--;
+        View g = view(t, true);
+        const i2v_conv_desc& c = nd.cd;
+        if (left[t] > 0) {
+            bool compact = (c.kh == 1 && c.kw == 1 && c.stride > 1 && c.pad == 0);
+            if (compact) {
+                const Packed& P = nd.bwd[0];
+                View tv; tv.C = g.C; tv.H = P.Hg; tv.W = P.Wg; tv.nstride = (int64_t)g.C * P.Hg * P.Wg;
+                tv.p = temp(N * tv.nstride);
+                conv_launches(nd, dz, tv, true, t, true);
+                pending[t].push_back(Addend{tv.p, tv.nstride, c.stride, P.Hg, P.Wg});
+            } else {
+                View tv = g; tv.nstride = (int64_t)g.C * g.H * g.W; tv.p = temp(N * tv.nstride);
+                conv_launches(nd, dz, tv, true, t, false);
+                pending[t].push_back(Addend{tv.p, tv.nstride, 1, g.H, g.W});
+            }
+            return true;
+        }
+        // final contributor: at most one compact + one plain, or two plain addends fit the epilogue
+        size_t ncompact = 0; for (auto& a : pending[t]) if (a.stride != 1) ncompact++;
+        if (ncompact > 1) { err = "more than one strided addend"; return false; }
+        if (ncompact == 1) {
+            // keep the compact one, fold plain ones down to a single addend
+            std::vector<Addend> plain, comp;
+            for (auto& a : pending[t]) (a.stride == 1 ? plain : comp).push_back(a);
+            pending[t] = plain; if (!squeeze_pending(t, 1)) return false;
+            pending[t].push_back(comp[0]);
+        } else if (!squeeze_pending(t, 2)) return false;
+        conv_launches(nd, dz, g, false, t, false);
+        pending[t].clear();
+        return true;
+    }
+
+    bool contribute_alias(int t, View dz) {
+        if (left[t] == 1 && pending[t].empty() && !n.tens[t].post_relu && !is_hook(t)) {
+            left[t] = 0; galias[t] = dz; has_alias[t] = 1;     // sole consumer, no gate: alias the view
+            return true;
+        }
+        left[t]--;
+        pending[t].push_back(Addend{dz.p, dz.nstride, 1, dz.H, dz.W});
+        if (left[t] > 0) return true;
+        if (has_compact(pending[t])) { err = "alias finaliser with strided addend"; return false; }
+        if (!squeeze_pending(t, 3)) return false;
+        emit_addmask(view(t, true), pending[t], t);
+        pending[t].clear();
+        return true;
+    }
+
+    bool run() {
+        const int NT = (int)n.tens.size();
+        left.assign(NT, 0); pending.assign(NT, {}); galias.assign(NT, View{}); has_alias.assign(NT, 0);
+        for (const Node& nd : n.nodes) {
+            if (nd.type == 0) { left[nd.cd.src]++; if (nd.cd.residual >= 0) left[nd.cd.residual]++; }
+            else left[nd.pd.src]++;
+        }
+        // ---------------- forward ----------------
+        for (const Node& nd : n.nodes) {
+            Launch l;
+            if (nd.type == 0) {
+                const i2v_conv_desc& c = nd.cd;
+                l.kind = L_CONV; conv_common(l.conv, nd.fwd);
+                I2VConvParams& p = l.conv;
+                View d = view(c.dst, false);
+                const Buffer& sb = n.bufs[n.tens[c.src].buf];
+                if (c.src == n.input) { l.src_is_input = true; p.src = nullptr; p.src_nstride = (int64_t)sb.C * sb.H * sb.W; }
+                else { View s = view(c.src, false); p.src = s.p; p.src_nstride = s.nstride; }
+                p.Hs = sb.H; p.Ws = sb.W; p.Hg = d.H; p.Wg = d.W; p.sh = p.sw = c.stride;
+                p.dst = d.p; p.dst_nstride = d.nstride; p.Ho = d.H; p.Wo = d.W; p.osh = p.osw = 1;
+                p.shift = nd.shift_d; p.relu = c.relu;
+                if (c.residual >= 0) { View r = view(c.residual, false); p.add0 = r.p; p.add0_nstride = r.nstride; p.add0_stride = 1; }
+                p.pointwise = (c.kh == 1 && c.kw == 1 && c.stride == 1 && c.pad == 0 && (sb.H * sb.W) % 4 == 0 &&
+                               c.src != n.input) ? 1 : 0;
+            } else {
+                const i2v_pool_desc& q = nd.pd;
+                l.kind = L_POOLF; memset(&l.pool, 0, sizeof l.pool);
+                View s = view(q.src, false), d = view(q.dst, false);
+                if (q.src == n.input) { err = "maxpool directly on the input is not supported"; return false; }
+                l.pool.x = s.p; l.pool.x_nstride = s.nstride; l.pool.C = s.C; l.pool.Hs = s.H; l.pool.Ws = s.W;
+                l.pool.y = d.p; l.pool.y_nstride = d.nstride; l.pool.Ho = d.H; l.pool.Wo = d.W;
+                l.pool.k = q.k; l.pool.stride = q.stride; l.pool.pad = q.pad;
+            }
+            emit(n.fwd, l);
+        }
+        // ---------------- hooks ----------------
+        hook_tmp.assign(n.hooks.size(), nullptr);
+        for (size_t hk = 0; hk < n.hooks.size(); ++hk) {
+            int t = n.hooks[hk];
+            bool consumed = false;
+            for (const Node& nd : n.nodes) {
+                int srcs[2] = {nd.type == 0 ? nd.cd.src : nd.pd.src, nd.type == 0 ? nd.cd.residual : -1};
+                for (int s : srcs) if (s >= 0 && overlaps(n.tens[s], n.tens[t])) consumed = true;
+            }
+            if (consumed) { View g = view(t, true); hook_tmp[hk] = temp(N * g.C * g.H * g.W); }
+        }
+        // ---------------- backward ----------------
+        for (int i = (int)n.nodes.size() - 1; i >= 0; --i) {
+            const Node& nd = n.nodes[i];
+            int dst = nd.type == 0 ? nd.cd.dst : nd.pd.dst;
+            for (size_t hk = 0; hk < n.hooks.size(); ++hk)
+                if (n.hooks[hk] == dst && hook_tmp[hk]) {
+                    View g = view(dst, true);
+                    std::vector<Addend> adds = {Addend{g.p, g.nstride, 1, g.H, g.W},
+                                                Addend{hook_tmp[hk], (int64_t)g.C * g.H * g.W, 1, g.H, g.W}};
+                    emit_addmask(g, adds, dst);
+                }
+            View dz = view(dst, true);
+            if (nd.type == 0) {
+                const i2v_conv_desc& c = nd.cd;
+                if (c.residual >= 0 && !contribute_alias(c.residual, dz)) return false;
+                if (c.src == n.input) {
+                    Launch l; l.kind = L_IMGGRAD; memset(&l.img, 0, sizeof l.img);
+                    const Buffer& ib = n.bufs[n.tens[n.input].buf];
+                    l.img.dz = dz.p; l.img.dz_nstride = dz.nstride; l.img.Cout = c.cout; l.img.Ho = dz.H; l.img.Wo = dz.W;
+                    l.img.w = nd.w_d; l.img.Cin = c.cin; l.img.H = ib.H; l.img.W = ib.W;
+                    l.img.kh = c.kh; l.img.kw = c.kw; l.img.stride = c.stride; l.img.pad = c.pad;
+                    if (c.cin > I2V_MAX_IMG_C) { err = "input conv with more than 4 channels"; return false; }
+                    emit(n.bwd, l);
+                } else if (!contribute_conv(c.src, nd, dz)) return false;
+            } else {
+                const i2v_pool_desc& q = nd.pd;
+                left[q.src]--;
+                if (left[q.src] > 0 || !pending[q.src].empty()) { err = "maxpool input with several consumers is not supported"; return false; }
+                Launch l; l.kind = L_POOLB; memset(&l.pool, 0, sizeof l.pool);
+                View x = view(q.src, false), gx = view(q.src, true);
+                l.pool.x = x.p; l.pool.x_nstride = x.nstride; l.pool.C = x.C; l.pool.Hs = x.H; l.pool.Ws = x.W;
+                l.pool.y = dz.p; l.pool.y_nstride = dz.nstride; l.pool.Ho = dz.H; l.pool.Wo = dz.W;
+                l.pool.gx = gx.p; l.pool.gx_nstride = gx.nstride;
+                l.pool.k = q.k; l.pool.stride = q.stride; l.pool.pad = q.pad;
+                l.pool.mask_relu = n.tens[q.src].post_relu ? 1 : 0;
+                emit(n.bwd, l);
+            }
+        }
+        return true;
+    }
+};
+
+}  // namespace
+
+extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int n_hooks, int max_frames) {
+    Net* np = get_net(h, net); if (!np) return 1;
+    Net& n = *np;
+    if (n.planned) return fail("net already planned");
+    if (n.input < 0) return fail("input tensor not set");
+    if (n_hooks <= 0 || max_frames <= 0) return fail("need >=1 hook and >=1 frame");
+    for (int i = 0; i < n_hooks; ++i)
+        if (hook_tensors[i] < 0 || hook_tensors[i] >= (int)n.tens.size()) return fail("bad hook tensor");
+    n.hooks.assign(hook_tensors, hook_tensors + n_hooks);
+    n.maxN = max_frames;
+    const size_t N = (size_t)max_frames;
+
+    for (Node& nd : n.nodes) {
+        if (nd.type != 0) continue;
+        if (upload(n, nd.shift, &nd.shift_d)) return 1;
+        if (pack_fwd(n, nd)) return 1;
+        if (nd.cd.src == n.input) { if (upload(n, nd.w, &nd.w_d)) return 1; }
+        else if (pack_bwd(n, nd)) return 1;
+    }
+    size_t off = 0;
+    for (Buffer& b : n.bufs) {
+        if (b.is_input) continue;
+        size_t sz = N * b.C * b.H * b.W;
+        b.act_off = off; off = align_up(off + sz, 64);
+        b.grad_off = off; off = align_up(off + sz, 64);
+    }
+    Planner dry{n, true, off, N};
+    if (!dry.run()) return fail("plan: %s", dry.err.c_str());
+    n.arena_floats = dry.off;
+    n.arena = (float*)be_malloc(n.arena_floats * sizeof(float));
+    if (!n.arena) return fail("arena allocation of %zu bytes failed", n.arena_floats * sizeof(float));
+    CHECK_BE(be_memset0(n.arena, n.arena_floats * sizeof(float), nullptr));
+    Planner real{n, false, off, N};
+    if (!real.run()) return fail("plan: %s", real.err.c_str());
+    n.hook_tmp = real.hook_tmp;
+    n.planned = true;
+    return 0;
+}
+
+extern "C" size_t i2v_net_workspace_bytes(i2v_handle h, int net) {
+    Net* n = get_net(h, net); if (!n) return 0;
+    return n->arena_floats * sizeof(float) + n->weight_bytes;
+}
+
+// ---------------------------------------------------------------------------------------------
+// execution
+// ---------------------------------------------------------------------------------------------
+static int run_list(Net& n, std::vector<Launch>& L, int frames, const float* x, float* gx, int accumulate,
+                    i2v_stream_t s) {
+    for (Launch& l : L) {
+        switch (l.kind) {
+            case L_CONV: {
+                I2VConvParams p = l.conv; p.N = frames;
+                if (l.src_is_input) p.src = x;
+                if (p.N * p.Hg * p.Wg == 0) break;
+                CHECK_BE(k_conv(p, s));
+            } break;
+            case L_IMGGRAD: {
+                I2VImgGradParams p = l.img; p.N = frames; p.gx = gx; p.accumulate = accumulate;
+                CHECK_BE(k_imggrad(p, s));
+            } break;
+            case L_POOLF: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool_fwd(p, s)); } break;
+            case L_POOLB: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool_bwd(p, s)); } break;
+            case L_ADDMASK: { I2VAddMaskParams p = l.am; p.N = frames; CHECK_BE(k_addmask(p, s)); } break;
+        }
+    }
+    return 0;
+}
+
+extern "C" int i2v_net_forward(i2v_handle h, int net, const float* x, int frames, void* stream) {
+    Net* n = get_net(h, net); if (!n) return 1;
+    if (!n->planned) return fail("net not planned");
+    if (frames <= 0 || frames > n->maxN) return fail("frames=%d outside 1..%d", frames, n->maxN);
+    if (!x) return fail("null input");
+    n->frames = frames;
+    return run_list(*n, n->fwd, frames, x, nullptr, 0, stream);
+}
+
+extern "C" int i2v_net_backward(i2v_handle h, int net, float* gx, int accumulate, void* stream) {
+    Net* n = get_net(h, net); if (!n) return 1;
+    if (!n->planned || n->frames <= 0) return fail("backward before forward");
+    if (!gx) return fail("null gradient output");
+    return run_list(*n, n->bwd, n->frames, nullptr, gx, accumulate, stream);
+}
+
+extern "C" int i2v_net_hook_info(i2v_handle h, int net, int hook, float** act, int64_t* act_stride,
+                                 float** grad, int64_t* grad_stride, int64_t* D, int32_t* post_relu) {
+    Net* n = get_net(h, net); if (!n) return 1;
+    if (!n->planned) return fail("net not planned");
+    if (hook < 0 || hook >= (int)n->hooks.size()) return fail("bad hook index");
+    int t = n->hooks[hook];
+    View a = view_of(*n, t, false), g = view_of(*n, t, true);
+    int64_t d = (int64_t)a.C * a.H * a.W;
+    if (act) *act = a.p;
+    if (act_stride) *act_stride = a.nstride;
+    if (grad_stride) *grad_stride = n->hook_tmp[hook] ? d : g.nstride;
+    if (grad) *grad = n->hook_tmp[hook] ? n->hook_tmp[hook] : g.p;
+    if (D) *D = d;
+    if (post_relu) *post_relu = n->tens[t].post_relu ? 1 : 0;
+    return 0;
+}
+
+extern "C" int i2v_net_read_tensor(i2v_handle h, int net, int tensor, int which, float* out, int frames,
+                                   void* stream) {
+    Net* n = get_net(h, net); if (!n) return 1;
+    if (!n->planned) return fail("net not planned");
+    if (tensor < 0 || tensor >= (int)n->tens.size() || tensor == n->input) return fail("bad tensor id");
+    if (frames <= 0 || frames > n->maxN) return fail("bad frame count");
+    View v = view_of(*n, tensor, which != 0);
+    size_t row = (size_t)v.C * v.H * v.W * sizeof(float);
+    CHECK_BE(be_d2d_2d(out, row, v.p, (size_t)v.nstride * sizeof(float), row, frames, stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// loop kernels
+// ---------------------------------------------------------------------------------------------
+extern "C" int i2v_frames_from_video_f32(const float* video, float* x, float* u, int b, int f, int hh, int w,
+                                         void* stream) {
+    if (!video || !x || !u || b <= 0 || f <= 0 || hh <= 0 || w <= 0) return fail("i2v_frames_from_video_f32: bad argument");
+    CHECK_BE(k_frames_from_video(video, x, u, b, f, hh, w, stream));
+    return 0;
+}
+
+extern "C" int i2v_compose_f32(const float* u, const float* delta, float* x, int b, int f, int hh, int w,
+                               float eps, int video_layout, void* stream) {
+    if (!u || !delta || !x || b <= 0 || f <= 0 || hh <= 0 || w <= 0) return fail("i2v_compose_f32: bad argument");
+    CHECK_BE(k_compose(u, delta, x, b, f, hh, w, eps, video_layout, stream));
+    return 0;
+}
+
+extern "C" size_t i2v_cossim_scratch_bytes(int64_t D, int frames) {
+    return (size_t)frames * cos_nblk(D) * 4 * sizeof(double);
+}
+
+extern "C" int i2v_cossim_fwd_bwd_f32(const float* a, int64_t a_stride, const float* b, int64_t b_stride,
+                                      int64_t D, int frames, const float* coef_dev, int coef_index,
+                                      float coef_host, int mask_relu, int accumulate, float* cos_out,
+                                      float* grad, int64_t grad_stride, void* scratch, void* stream) {
+    if (!a || !b || !cos_out || !grad || !scratch || D <= 0 || frames <= 0) return fail("i2v_cossim_fwd_bwd_f32: bad argument");
+    I2VCosParams p; memset(&p, 0, sizeof p);
+    p.a = a; p.a_nstride = a_stride; p.b = b; p.b_nstride = b_stride; p.D = D; p.N = frames;
+    p.partial = (float*)scratch; p.nblk = cos_nblk(D); p.cos_out = cos_out; p.grad = grad; p.grad_nstride = grad_stride;
+    p.coef_dev = coef_dev; p.coef_index = coef_index; p.coef_host = coef_host; p.mask_relu = mask_relu; p.accumulate = accumulate;
+    CHECK_BE(k_cos(p, stream));
+    return 0;
+}
+
+extern "C" int i2v_std_fwd_bwd_f32(const float* a, int64_t a_stride, int64_t D, int frames, int mask_relu,
+                                   int accumulate, float* std_out, float* grad, int64_t grad_stride,
+                                   void* scratch, void* stream) {
+    if (!a || !std_out || !grad || !scratch || D <= 0 || frames <= 0) return fail("i2v_std_fwd_bwd_f32: bad argument");
+    I2VStdParams p; memset(&p, 0, sizeof p);
+    p.a = a; p.a_nstride = a_stride; p.D = D; p.N = frames; p.partial = (double*)scratch; p.nblk = cos_nblk(D);
+    p.std_out = std_out; p.grad = grad; p.grad_nstride = grad_stride; p.mask_relu = mask_relu; p.accumulate = accumulate;
+    CHECK_BE(k_std(p, stream));
+    return 0;
+}
+
+extern "C" int i2v_adam_step_f32(float* delta, float* m, float* v, const float* gx, const float* u,
+                                 int64_t frames, int hw, float eps, float lr, float beta1, float beta2,
+                                 float adam_eps, int step_t, void* stream) {
+    if (!delta || !m || !v || !gx || !u || frames <= 0 || hw <= 0 || step_t < 1) return fail("i2v_adam_step_f32: bad argument");
+    // host-side bias corrections in double, as torch/optim/adam.py does for the non-capturable path
+    double bc1 = 1.0 - pow((double)beta1, step_t), bc2 = 1.0 - pow((double)beta2, step_t);
+    float step_size = (float)((double)lr / bc1);
+    float bc2_sqrt = (float)sqrt(bc2);
+    CHECK_BE(k_adam(delta, m, v, gx, u, frames * 3 * (int64_t)hw, hw, eps, step_size, bc2_sqrt, beta1, beta2, adam_eps, stream));
+    return 0;
+}
+
+extern "C" int i2v_sign_step_f32(float* adv, const float* u, const float* grad, int64_t nel, int64_t chan_stride,
+                                 float step, float eps, void* stream) {
+    if (!adv || !u || !grad || nel <= 0 || chan_stride <= 0) return fail("i2v_sign_step_f32: bad argument");
+    CHECK_BE(k_sign_bim(adv, u, grad, nel, chan_stride, step, eps, stream));
+    return 0;
+}
+
+extern "C" int i2v_sign_step_delta_f32(float* delta, const float* grad, int64_t nel, float step, void* stream) {
+    if (!delta || !grad || nel <= 0) return fail("i2v_sign_step_delta_f32: bad argument");
+    CHECK_BE(k_sign_delta(delta, grad, nel, step, stream));
+    return 0;
+}
+
+extern "C" int i2v_aens_coeffs_f32(const float* prev, float* coeffs, float momentum, int L, void* stream) {
+    if (!prev || !coeffs || L <= 0 || L > 64) return fail("i2v_aens_coeffs_f32: bad argument");
+    CHECK_BE(k_aens_coeffs(prev, coeffs, momentum, L, stream));
+    return 0;
+}
+
+extern "C" int i2v_aens_reduce_f32(const float* cos, const float* coeffs, int L, int frames, float* feat_sum,
+                                   float* weighted, void* stream) {
+    if (!cos || !coeffs || !feat_sum || !weighted || L <= 0 || frames <= 0) return fail("i2v_aens_reduce_f32: bad argument");
+    CHECK_BE(k_aens_reduce(cos, coeffs, L, frames, feat_sum, weighted, stream));
+    return 0;
+}

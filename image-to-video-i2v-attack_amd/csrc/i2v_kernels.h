@@ -1,0 +1,38 @@
+// Internal interface between the planner/executor (i2v_engine.cpp) and a kernel backend.
+// The product backend is i2v_kernels.hip (gfx950).  tests/hostsim/ holds a scalar host backend of
+// the same interface that exists ONLY so the planner can be unit-tested without a GPU.
+#pragma once
+#include "i2v_params.h"
+
+typedef void* i2v_stream_t;
+
+const char* be_name();
+int  be_set_device(int device);
+void* be_malloc(size_t bytes);
+void be_free(void* p);
+int  be_h2d(void* dst, const void* src, size_t bytes);                       // synchronous upload
+int  be_d2d_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows,
+               i2v_stream_t s);                                               // async strided copy
+int  be_memset0(void* p, size_t bytes, i2v_stream_t s);
+const char* be_error();                                                       // last backend error or null
+
+int k_conv(const I2VConvParams& p, i2v_stream_t s);
+int k_imggrad(const I2VImgGradParams& p, i2v_stream_t s);
+int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t s);
+int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s);
+int k_addmask(const I2VAddMaskParams& p, i2v_stream_t s);
+int k_cos(const I2VCosParams& p, i2v_stream_t s);
+int k_std(const I2VStdParams& p, i2v_stream_t s);
+int k_frames_from_video(const float* video, float* x, float* u, int b, int f, int h, int w, i2v_stream_t s);
+int k_compose(const float* u, const float* delta, float* x, int b, int f, int h, int w, float eps,
+              int video_layout, i2v_stream_t s);
+int k_adam(float* delta, float* m, float* v, const float* gx, const float* u, int64_t n, int hw,
+           float eps, float step_size, float bc2_sqrt, float beta1, float beta2, float adam_eps,
+           i2v_stream_t s);
+int k_sign_bim(float* adv, const float* u, const float* grad, int64_t n, int64_t chan_stride,
+               float step, float eps, i2v_stream_t s);
+int k_sign_delta(float* delta, const float* grad, int64_t n, float step, i2v_stream_t s);
+int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t s);
+int k_aens_reduce(const float* cos, const float* coeffs, int L, int frames, float* feat_sum,
+                  float* weighted, i2v_stream_t s);
+int cos_nblk(int64_t D);   // blocks per frame used by k_cos / k_std (scratch sizing)

@@ -1,0 +1,76 @@
+// Launch-parameter structs shared by the planner (i2v_engine.cpp) and the gfx950 kernels
+// (i2v_kernels.hip).  Plain data, no HIP types, so the planner can be unit-tested on the host.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#define I2V_KC 16          // K-chunk of the implicit GEMM; packed weights/k-tables are padded to it
+#define I2V_MAX_IMG_C 4    // image-gradient kernel: at most 4 input channels (always 3 here)
+
+// One row of the implicit-GEMM reduction axis: which source plane and which spatial tap.
+struct I2VKEntry {
+    int32_t chan_off;      // element offset of the source channel plane (c * Hs * Ws)
+    int32_t dh, dw;        // tap offset in source coordinates
+    int32_t valid;         // 0 for padding rows
+};
+
+// Implicit-GEMM convolution, forward and input-gradient alike:
+//   acc[cd][p] = sum_k wp[k][cd] * src[n(p)][ktab[k].chan][i(p)*sh + dh_k][j(p)*sw + dw_k]
+//   v = acc + shift[cd] + add0[..] + add1[..];  relu -> max(v,0);  mask -> (mask[..] > 0 ? v : 0)
+//   dst[n][cd][i*osh + oh0][j*osw + ow0] = v
+// p enumerates (n, i, j) over an N x Hg x Wg grid.
+struct I2VConvParams {
+    const float* src;  int64_t src_nstride;  int32_t Hs, Ws;
+    const float* wp;   const I2VKEntry* ktab; int32_t Kpad, Cd, Cdpad;
+    int32_t N, Hg, Wg, sh, sw;
+    float* dst;        int64_t dst_nstride;  int32_t Ho, Wo, osh, osw, oh0, ow0;
+    const float* shift;
+    const float* add0; int64_t add0_nstride; int32_t add0_stride, add0_H, add0_W;  // stride s>1: compact addend
+    const float* add1; int64_t add1_nstride;
+    const float* mask; int64_t mask_nstride;
+    int32_t relu;
+    int32_t pointwise;  // 1: 1x1 / stride 1 / no padding, planes 16-byte aligned -> vector path
+};
+
+// Gradient w.r.t. the network input (3-channel image) of the first convolution.
+//   gx[n][ci][h][w] (+)= sum_{co,r,s} w[co][ci][r][s] * dz[n][co][(h+pad-r)/st][(w+pad-s)/st]
+struct I2VImgGradParams {
+    const float* dz;   int64_t dz_nstride;   int32_t Cout, Ho, Wo;
+    const float* w;    // [Cout][Cin][kh][kw], BN scale folded in
+    float* gx;         int32_t N, Cin, H, W, kh, kw, stride, pad;
+    int32_t accumulate;
+};
+
+struct I2VPoolParams {
+    const float* x;    int64_t x_nstride;    int32_t C, Hs, Ws;
+    float* y;          int64_t y_nstride;    int32_t Ho, Wo;       // fwd: output; bwd: upstream grad
+    float* gx;         int64_t gx_nstride;                           // bwd only
+    int32_t N, k, stride, pad, mask_relu;
+};
+
+// out = (a0 + a1 + a2) gated by (mask > 0); planes of HW elements, C channels, N frames
+struct I2VAddMaskParams {
+    float* out;        int64_t out_nstride;
+    const float* a[3]; int64_t a_nstride[3];
+    const float* mask; int64_t mask_nstride;
+    int32_t N, C, HW;
+};
+
+struct I2VCosParams {
+    const float* a;    int64_t a_nstride;    // current feature (view: frame stride, D contiguous)
+    const float* b;    int64_t b_nstride;    // clean feature
+    int64_t D;         int32_t N;
+    float* partial;    int32_t nblk;         // [N][nblk][4] partial sums (dot, aa, bb, -)
+    float* cos_out;                          // [N]
+    float* grad;       int64_t grad_nstride;
+    const float* coef_dev; int32_t coef_index; float coef_host;
+    int32_t mask_relu, accumulate;
+};
+
+struct I2VStdParams {                          // Dispersion-Reduction loss: unbiased std of a tensor
+    const float* a;    int64_t a_nstride; int64_t D; int32_t N;
+    double* partial;   int32_t nblk;         // [N*nblk][2] (sum, sumsq)
+    float* std_out;                          // [1]
+    float* grad;       int64_t grad_nstride;
+    int32_t mask_relu, accumulate;
+};

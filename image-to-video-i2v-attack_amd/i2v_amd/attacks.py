@@ -1,0 +1,259 @@
+"""Attack classes with the reference's names, constructor signatures and call protocol
+(SURVEY.md section 8(b)); the per-frame arithmetic runs in `libi2v_hip.so`.
+
+    ImageGuidedFMDirection_Adam(model_name_lists, depth, step_size, epsilon=16/255, steps=10)   # I2V
+    ImageGuidedStd_Adam(model_name_lists, depth, step_size, epsilon=16/255, steps=10)           # DR
+    ImageGuidedFML2_Adam_MultiModels(model_name_lists, depths, epsilon=16/255, steps=60)        # ENS-I2V
+    AENS_I2V_MF(model_name_lists, depths, step_size, momentum=0, coef_CE=False, ...)            # adaptive ENS
+    adv = attack(videos, labels, video_names)          # videos (b,3,f,h,w) ImageNet-normalised
+
+Differences from the reference that do not change results: nothing behind the deepest hook is
+executed, no weight gradients are formed, the per-step cost is kept on the device and read back
+once per call (the reference syncs twice per step, image_attacks.py:349,358), and the returned clip
+is a contiguous (b,3,f,h,w) tensor (the reference returns a permuted view of the same values).
+"""
+import os
+import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import graphs as _graphs
+from . import weights as _weights
+from .engine import Engine
+
+_ENGINES: Dict[str, Engine] = {}
+
+
+def default_device() -> str:
+    return f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+
+
+def get_engine(device: Optional[str] = None) -> Engine:
+    """Process-wide engine per device (the reference's single `.cuda()` device)."""
+    device = device or default_device()
+    if device not in _ENGINES:
+        _ENGINES[device] = Engine(device)
+    return _ENGINES[device]
+
+
+class Attack(object):
+    """Base class, `/root/reference/image_attacks.py:12-82`: attack name, ImageNet mean/std,
+    `__call__ -> forward`."""
+
+    def __init__(self, name, model=None):
+        self.attack = name
+        self.model = model
+        self.model_name = str(model).split("(")[0]
+        self.mean = [0.485, 0.456, 0.406]
+        self.std = [0.229, 0.224, 0.225]
+
+    def forward(self, *input):
+        raise NotImplementedError
+
+    def __call__(self, *input, **kwargs):
+        return self.forward(*input, **kwargs)
+
+
+class _ImageGuided(Attack):
+    """Shared loop of the image-model-guided attacks."""
+    _mode = "i2v"
+
+    def _setup(self, model_names: Sequence[str], depths_per_model: List[List[int]], engine, graph_builder,
+               weight_seed):
+        self.model_names = list(model_names)
+        self._depths = depths_per_model
+        self._engine = engine
+        self._builder = graph_builder or _graphs.build
+        self._wseed = weight_seed
+        self._nets = None
+        self._net_key = None
+        self.loss_info = {}
+        # validate names / hook depths now, as the reference does at construction
+        # (unknown model -> UnboundLocalError image_attacks.py:103; densenet -> AttributeError :291)
+        for m, ds in zip(self.model_names, depths_per_model):
+            g = self._builder(m, (224, 224))
+            for d in ds:
+                if d not in g.hooks:
+                    raise KeyError(d)
+
+    @property
+    def engine(self) -> Engine:
+        if self._engine is None:
+            self._engine = get_engine()
+        return self._engine
+
+    def _get_nets(self, frames: int, hw):
+        key = (hw, )
+        if self._nets is not None and self._net_key == key and self._max_frames >= frames:
+            return self._nets
+        nets = []
+        for m, ds in zip(self.model_names, self._depths):
+            g = self._builder(m, hw)
+            sd = _weights.load_state_dict(g, self._wseed)
+            nets.append(self.engine.build_net(g, sd, [g.hooks[d] for d in ds], frames))
+        self._nets, self._net_key, self._max_frames = nets, key, frames
+        return nets
+
+    # hooks for the adaptive subclass
+    def _begin(self, L, dev):
+        pass
+
+    def _run(self, videos: torch.Tensor, video_names):
+        eng = self.engine
+        dev = eng.device
+        videos = videos.detach().to(device=dev, dtype=torch.float32).contiguous()
+        b, c, f, h, w = videos.shape
+        N = b * f
+        nets = self._get_nets(N, (h, w))
+        L = sum(len(n.hooks) for n in nets)
+        steps, eps = self.steps, float(self.epsilon)
+        mode = self._mode
+        kw = dict(dtype=torch.float32, device=dev)
+        x = torch.empty(N, 3, h, w, **kw)
+        u = torch.empty_like(x)
+        eng.frames_from_video(videos, x, u)                             # image_attacks.py:300-301,308
+        delta = torch.full((N, 3, h, w), 0.01 / 255, **kw)              # :304
+        m = torch.zeros_like(delta)
+        v = torch.zeros_like(delta)
+        gx = torch.empty_like(delta)
+        xadv = torch.empty_like(delta)
+        scratch = torch.empty(max(n.scratch_bytes(N) for n in nets), dtype=torch.uint8, device=dev)
+        init = []
+        if mode != "std":
+            for net in nets:                                            # clean pass on the RAW input, :318-323
+                net.forward(x)
+                init.append([net.save_hook(i, N) for i in range(len(net.hooks))])
+        vals = torch.zeros(max(steps, 1), L, N if mode != "std" else 1, **kw)
+        aens = mode == "aens"
+        if aens:
+            if self.coeffs is None or self.coeffs.device != dev:
+                self.coeffs = torch.ones(L, **kw)                       # TPAMI_attack.py:165
+            prev = torch.ones(L, **kw)                                  # :257
+            feat_sum = torch.empty(L, **kw)
+            weighted = torch.empty(steps, L, **kw)
+            wts = torch.empty(steps, L, **kw)
+        begin = time.time()
+        for i in range(steps):
+            if aens:
+                eng.aens_coeffs(prev, self.coeffs, float(self.momentum))   # :265
+                wts[i].copy_(self.coeffs)
+            eng.compose(u, delta, xadv, b, f, eps)                      # image_attacks.py:331-332
+            l = 0
+            for n, net in enumerate(nets):
+                net.forward(xadv)                                       # :334
+                for k in range(len(net.hooks)):
+                    if mode == "std":
+                        net.stdloss(k, vals[i, l], scratch, N)          # :218
+                    elif aens:
+                        net.cossim(k, init[n][k], vals[i, l], scratch, N, coef_dev=self.coeffs, coef_index=l,
+                                   coef_host=1.0 / L)                   # TPAMI_attack.py:289-291
+                    else:
+                        net.cossim(k, init[n][k], vals[i, l], scratch, N)   # image_attacks.py:341-347
+                    l += 1
+                net.backward(gx, accumulate=n > 0)                      # :352 (input gradient only)
+            if aens:
+                eng.aens_reduce(vals[i], self.coeffs, feat_sum, weighted[i])
+                self._exchange(feat_sum, weighted[i])
+                prev = (weighted[i] if self.coef_CE else feat_sum).clone()   # TPAMI_attack.py:293-297
+            eng.adam_step(delta, m, v, gx, u, eps, float(self.step_size), i + 1)   # :351-353
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        self.used_time = time.time() - begin
+        out = torch.empty(b, 3, f, h, w, **kw)
+        eng.compose(u, delta, out, b, f, eps, video_layout=True)        # :360-364
+        # one read-back for the whole call
+        if aens:
+            costs = weighted.mean(dim=1).cpu().numpy().astype(np.float32)   # TPAMI_attack.py:291
+            self.weights = [wts[i].cpu().numpy() for i in range(steps)]     # :266
+        else:
+            costs = vals[:steps].sum(dim=(1, 2)).cpu().numpy().astype(np.float32)   # image_attacks.py:347
+        self.last_costs = costs
+        self.last_values = vals
+        for vid_name in video_names:                                    # :355-358 (batch-total cost per name)
+            if vid_name not in self.loss_info.keys():
+                self.loss_info[vid_name] = {}
+            for i in range(steps):
+                self.loss_info[vid_name][i] = {"cost": str(costs[i])}
+        self._delta = delta
+        return out
+
+    def _exchange(self, feat_sum, weighted_row):
+        pass
+
+    def forward(self, videos, labels, video_names):
+        return self._run(videos, video_names)
+
+
+class ImageGuidedFMDirection_Adam(_ImageGuided):
+    """The I2V attack (`/root/reference/image_attacks.py:236-364`)."""
+
+    def __init__(self, model_name_lists, depth, step_size, epsilon=16 / 255, steps=10, *, engine=None,
+                 graph_builder=None, weight_seed=0):
+        super().__init__("ImageGuidedFMDirection_Adam")
+        self.epsilon, self.steps, self.step_size, self.depth = epsilon, steps, step_size, depth
+        self.model_name = model_name_lists[0]
+        self._setup(model_name_lists[:1], [[depth]], engine, graph_builder, weight_seed)
+
+
+class ImageGuidedStd_Adam(_ImageGuided):
+    """Dispersion-Reduction baseline (`/root/reference/image_attacks.py:129-234`): minimises the
+    unbiased std of the hooked activation over the whole (N,C,H,W) tensor; no clean pass."""
+    _mode = "std"
+
+    def __init__(self, model_name_lists, depth, step_size, epsilon=16 / 255, steps=10, *, engine=None,
+                 graph_builder=None, weight_seed=0):
+        super().__init__("ImageGuidedStd_Adam")
+        self.epsilon, self.steps, self.step_size, self.depth = epsilon, steps, step_size, depth
+        self.model_name = model_name_lists[0]
+        self._setup(model_name_lists[:1], [[depth]], engine, graph_builder, weight_seed)
+
+
+class ImageGuidedFML2_Adam_MultiModels(_ImageGuided):
+    """ENS-I2V (`/root/reference/image_attacks.py:366-496`): several backbones, one hook each,
+    cost = sum over models and frames; lr is hard-wired to 0.005 (`:376`)."""
+
+    def __init__(self, model_name_lists, depths, epsilon=16 / 255, steps=60, *, engine=None, graph_builder=None,
+                 weight_seed=0):
+        super().__init__("ImageGuidedFML2_Adam_MultiModels")
+        self.epsilon, self.steps, self.step_size, self.depths = epsilon, steps, 0.005, depths
+        self._setup(model_name_lists, [[depths[m]] for m in model_name_lists], engine, graph_builder, weight_seed)
+
+
+class AENS_I2V_MF(_ImageGuided):
+    """Adaptive ENS-I2V (`/root/reference/TPAMI_attack.py:141-320`): several models x several
+    layers, per-step re-weighting; returns `(adv, used_time, cost_saved)`.  `coeffs` persists on
+    the object across calls as in the reference (`:165,265`).
+
+    Multi-GPU: clips are sharded over ranks; `feat_sum`/`weighted` (2L floats) are all-reduced
+    (RCCL) every step so the weights follow the GLOBAL batch, as on one device."""
+    _mode = "aens"
+
+    def __init__(self, model_name_lists, depths, step_size, momentum=0, coef_CE=False, epsilon=16 / 255, steps=60,
+                 *, engine=None, graph_builder=None, weight_seed=0, process_group=None, distributed=None):
+        super().__init__("AENS_I2V_MF")
+        self.epsilon, self.steps, self.step_size, self.depths = epsilon, steps, step_size, depths
+        self.momentum, self.coef_CE = momentum, coef_CE
+        self.coeffs = None
+        self.weights = []
+        per_model = [list(depths[m]) if isinstance(depths[m], (list, tuple)) else [depths[m]] for m in model_name_lists]
+        self._setup(model_name_lists, per_model, engine, graph_builder, weight_seed)
+        self._pg = process_group
+        self._dist = distributed
+
+    def _exchange(self, feat_sum, weighted_row):
+        import torch.distributed as dist
+        on = self._dist if self._dist is not None else (dist.is_available() and dist.is_initialized()
+                                                          and dist.get_world_size(self._pg) > 1)
+        if on:
+            packed = torch.cat([feat_sum, weighted_row])
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self._pg)
+            L = feat_sum.numel()
+            feat_sum.copy_(packed[:L])
+            weighted_row.copy_(packed[L:])
+
+    def forward(self, videos, labels, video_names):
+        adv = self._run(videos, video_names)
+        cost_saved = np.asarray(self.last_costs, dtype=np.float64)     # np.zeros(steps) of float64, :256
+        return adv, self.used_time, cost_saved

@@ -1,0 +1,186 @@
+"""Host-side owner of the native handle: turns a graph IR + state_dict into a planned backbone
+inside `libi2v_hip.so` and exposes forward-to-hooks / backward-to-input on torch tensors.
+
+PyTorch is used for device memory and streams only (`tensor.data_ptr()`,
+`torch.cuda.current_stream().cuda_stream`); all arithmetic happens behind the C ABI.
+"""
+import ctypes as C
+from typing import List, Sequence
+
+import torch
+
+from . import lib as _lib
+from .graphs import Graph
+from .weights import fold_affine
+
+
+def _ptr(t: torch.Tensor):
+    assert t.is_contiguous() and t.dtype == torch.float32, (t.dtype, t.is_contiguous())
+    return C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One per (process, device) -- mirrors the reference's single `.cuda()` device
+    (`image_attacks.py:103`).  `capi` is injected only by the planner unit tests."""
+
+    def __init__(self, device="cuda:0", capi=None):
+        self.device = torch.device(device)
+        self.capi = capi if capi is not None else _lib.load()
+        if capi is None and self.device.type != "cuda":
+            raise _lib.I2VError("the I2V engine needs a ROCm device; there is no CPU path")
+        self.h = C.c_void_p()
+        idx = self.device.index or 0
+        _lib.check(self.capi, self.capi.i2v_create(idx, C.byref(self.h)))
+
+    def stream(self):
+        if self.device.type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(0)
+
+    def close(self):
+        if self.h:
+            self.capi.i2v_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build_net(self, graph: Graph, state_dict, hook_tensors: Sequence[int], max_frames: int) -> "Net":
+        return Net(self, graph, state_dict, list(hook_tensors), max_frames)
+
+    # ---- loop kernels (thin, typed wrappers) ----
+    def frames_from_video(self, video, x, u):
+        b, c, f, h, w = video.shape
+        _lib.check(self.capi, self.capi.i2v_frames_from_video_f32(_ptr(video), _ptr(x), _ptr(u), b, f, h, w, self.stream()))
+
+    def compose(self, u, delta, out, b, f, eps, video_layout=False):
+        h, w = u.shape[-2:]
+        _lib.check(self.capi, self.capi.i2v_compose_f32(_ptr(u), _ptr(delta), _ptr(out), b, f, h, w, eps,
+                                                        1 if video_layout else 0, self.stream()))
+
+    def adam_step(self, delta, m, v, gx, u, eps, lr, step_t, beta1=0.9, beta2=0.999, adam_eps=1e-8):
+        n, _, h, w = delta.shape
+        _lib.check(self.capi, self.capi.i2v_adam_step_f32(_ptr(delta), _ptr(m), _ptr(v), _ptr(gx), _ptr(u), n, h * w,
+                                                          eps, lr, beta1, beta2, adam_eps, step_t, self.stream()))
+
+    def sign_step(self, adv, u, grad, chan_stride, step, eps):
+        _lib.check(self.capi, self.capi.i2v_sign_step_f32(_ptr(adv), _ptr(u), _ptr(grad), adv.numel(), chan_stride,
+                                                          step, eps, self.stream()))
+
+    def sign_step_delta(self, delta, grad, step):
+        _lib.check(self.capi, self.capi.i2v_sign_step_delta_f32(_ptr(delta), _ptr(grad), delta.numel(), step, self.stream()))
+
+    def aens_coeffs(self, prev, coeffs, momentum):
+        _lib.check(self.capi, self.capi.i2v_aens_coeffs_f32(_ptr(prev), _ptr(coeffs), momentum, coeffs.numel(), self.stream()))
+
+    def aens_reduce(self, cos, coeffs, feat_sum, weighted):
+        L, n = cos.shape
+        _lib.check(self.capi, self.capi.i2v_aens_reduce_f32(_ptr(cos), _ptr(coeffs), L, n, _ptr(feat_sum), _ptr(weighted), self.stream()))
+
+
+class HookInfo:
+    __slots__ = ("act", "act_stride", "grad", "grad_stride", "D", "post_relu", "shape")
+
+
+class Net:
+    """A planned backbone truncated at its deepest hook."""
+
+    def __init__(self, eng: Engine, graph: Graph, sd, hook_tensors: List[int], max_frames: int):
+        self.eng, capi, h = eng, eng.capi, eng.h
+        self.graph = g = graph.truncated(hook_tensors)
+        self.max_frames = max_frames
+        nid = C.c_int()
+        _lib.check(capi, capi.i2v_net_create(h, C.byref(nid)))
+        self.id = nid.value
+        # buffers / tensors actually referenced
+        used_t = {g.input}
+        for nd in g.nodes:
+            used_t.update([nd.src, nd.dst])
+            if getattr(nd, "residual", None) is not None:
+                used_t.add(nd.residual)
+        used_t.update(hook_tensors)
+        self.buf_id, self.ten_id = {}, {}
+        for t in sorted(used_t):
+            ts = g.tensors[t]
+            if ts.buf not in self.buf_id:
+                out = C.c_int()
+                _lib.check(capi, capi.i2v_net_add_buffer(h, self.id, g.buffers[ts.buf], ts.H, ts.W, C.byref(out)))
+                self.buf_id[ts.buf] = out.value
+            out = C.c_int()
+            _lib.check(capi, capi.i2v_net_add_tensor(h, self.id, self.buf_id[ts.buf], ts.c_off, ts.C,
+                                                     1 if ts.post_relu else 0, C.byref(out)))
+            self.ten_id[t] = out.value
+        _lib.check(capi, capi.i2v_net_set_input(h, self.id, self.ten_id[g.input]))
+        for nd in g.nodes:
+            if nd.op == "conv":
+                w = sd[nd.weight].float().contiguous()
+                scale, shift = fold_affine(nd, sd)
+                scale, shift = scale.contiguous(), shift.contiguous()
+                d = _lib.ConvDesc(self.ten_id[nd.src], self.ten_id[nd.dst], nd.cin, nd.cout, nd.kh, nd.kw,
+                                  nd.stride, nd.pad, 1 if nd.relu else 0,
+                                  -1 if nd.residual is None else self.ten_id[nd.residual])
+                _lib.check(capi, capi.i2v_net_add_conv(h, self.id, C.byref(d), _ptr(w), _ptr(scale), _ptr(shift)))
+            else:
+                d = _lib.PoolDesc(self.ten_id[nd.src], self.ten_id[nd.dst], nd.k, nd.stride, nd.pad)
+                _lib.check(capi, capi.i2v_net_add_maxpool(h, self.id, C.byref(d)))
+        hooks = (C.c_int * len(hook_tensors))(*[self.ten_id[t] for t in hook_tensors])
+        _lib.check(capi, capi.i2v_net_plan(h, self.id, hooks, len(hook_tensors), max_frames))
+        self.hook_tensors = hook_tensors
+        self.hooks = [self._hook_info(i) for i in range(len(hook_tensors))]
+
+    def _hook_info(self, i) -> HookInfo:
+        act, grad = C.c_void_p(), C.c_void_p()
+        a_s, g_s, D, pr = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        _lib.check(self.eng.capi, self.eng.capi.i2v_net_hook_info(
+            self.eng.h, self.id, i, C.byref(act), C.byref(a_s), C.byref(grad), C.byref(g_s), C.byref(D), C.byref(pr)))
+        hi = HookInfo()
+        hi.act, hi.act_stride, hi.grad, hi.grad_stride = act.value, a_s.value, grad.value, g_s.value
+        hi.D, hi.post_relu = D.value, pr.value
+        ts = self.graph.tensors[self.hook_tensors[i]]
+        hi.shape = (ts.C, ts.H, ts.W)
+        return hi
+
+    def workspace_bytes(self) -> int:
+        return self.eng.capi.i2v_net_workspace_bytes(self.eng.h, self.id)
+
+    def forward(self, x: torch.Tensor):
+        _lib.check(self.eng.capi, self.eng.capi.i2v_net_forward(self.eng.h, self.id, _ptr(x), x.shape[0], self.eng.stream()))
+
+    def backward(self, gx: torch.Tensor, accumulate=False):
+        _lib.check(self.eng.capi, self.eng.capi.i2v_net_backward(self.eng.h, self.id, _ptr(gx), 1 if accumulate else 0,
+                                                                 self.eng.stream()))
+
+    def read_tensor(self, tid: int, frames: int, grad=False) -> torch.Tensor:
+        ts = self.graph.tensors[tid]
+        out = torch.empty(frames, ts.C, ts.H, ts.W, dtype=torch.float32, device=self.eng.device)
+        _lib.check(self.eng.capi, self.eng.capi.i2v_net_read_tensor(self.eng.h, self.id, self.ten_id[tid], 1 if grad else 0,
+                                                                    _ptr(out), frames, self.eng.stream()))
+        return out
+
+    def save_hook(self, i: int, frames: int) -> torch.Tensor:
+        """Detached copy of hook i's feature (the clean `init_feature_maps`, image_attacks.py:319-323)."""
+        return self.read_tensor(self.hook_tensors[i], frames)
+
+    def cossim(self, i: int, init: torch.Tensor, cos_out: torch.Tensor, scratch: torch.Tensor, frames: int,
+               coef_dev=None, coef_index=0, coef_host=1.0):
+        """cos of hook i against its clean feature, gradient written into the hook's gradient view."""
+        hi = self.hooks[i]
+        capi = self.eng.capi
+        _lib.check(capi, capi.i2v_cossim_fwd_bwd_f32(
+            C.c_void_p(hi.act), hi.act_stride, _ptr(init), hi.D, hi.D, frames,
+            C.c_void_p(coef_dev.data_ptr()) if coef_dev is not None else C.c_void_p(0), coef_index, coef_host,
+            hi.post_relu, 0, C.c_void_p(cos_out.data_ptr()), C.c_void_p(hi.grad), hi.grad_stride,
+            C.c_void_p(scratch.data_ptr()), self.eng.stream()))
+
+    def stdloss(self, i: int, std_out: torch.Tensor, scratch: torch.Tensor, frames: int):
+        hi = self.hooks[i]
+        capi = self.eng.capi
+        _lib.check(capi, capi.i2v_std_fwd_bwd_f32(
+            C.c_void_p(hi.act), hi.act_stride, hi.D, frames, hi.post_relu, 0, C.c_void_p(std_out.data_ptr()),
+            C.c_void_p(hi.grad), hi.grad_stride, C.c_void_p(scratch.data_ptr()), self.eng.stream()))
+
+    def scratch_bytes(self, frames: int) -> int:
+        return max(self.eng.capi.i2v_cossim_scratch_bytes(hi.D, frames) for hi in self.hooks)

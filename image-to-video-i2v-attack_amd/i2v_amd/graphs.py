@@ -173,15 +173,17 @@ def resnet(layers=(3, 4, 23, 3), width=64, in_hw=(224, 224), arch="resnet101") -
         for b in range(nblocks):
             stride = 2 if (b == 0 and li > 0) else 1
             p = f"layer{li + 1}.{b}"
+            a = g.conv(x, planes, 1, 1, 0, f"{p}.conv1.weight", bn=f"{p}.bn1", relu=True,
+                       name=f"{p}.conv1")
+            a = g.conv(a, planes, 3, stride, 1, f"{p}.conv2.weight", bn=f"{p}.bn2", relu=True,
+                       name=f"{p}.conv2")
+            # the projection shortcut is emitted AFTER conv1/conv2: in the reversed (gradient)
+            # order its input-gradient is then a pending addend of conv1's, which finalises x
             if stride != 1 or inplanes != planes * 4:
                 idt = g.conv(x, planes * 4, 1, stride, 0, f"{p}.downsample.0.weight",
                              bn=f"{p}.downsample.1", relu=False, name=f"{p}.downsample")
             else:
                 idt = x
-            a = g.conv(x, planes, 1, 1, 0, f"{p}.conv1.weight", bn=f"{p}.bn1", relu=True,
-                       name=f"{p}.conv1")
-            a = g.conv(a, planes, 3, stride, 1, f"{p}.conv2.weight", bn=f"{p}.bn2", relu=True,
-                       name=f"{p}.conv2")
             x = g.conv(a, planes * 4, 1, 1, 0, f"{p}.conv3.weight", bn=f"{p}.bn3", relu=True,
                        residual=idt, name=f"{p}.out")
             inplanes = planes * 4

@@ -1,0 +1,88 @@
+"""ctypes binding of `libi2v_hip.so` (C ABI: `include/i2v_hip.h`).
+
+The product path has NO fallback: `load()` raises if the HIP library is missing or is not the
+gfx950 build.  (`bind()` only attaches prototypes to an already opened library; the planner unit
+tests use it for their host simulation of the ABI.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libi2v_hip.so")
+HIP_BACKEND = b"hip:gfx950"
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("src", "dst", "cin", "cout", "kh", "kw", "stride", "pad", "relu", "residual")]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("src", "dst", "k", "stride", "pad")]
+
+
+class I2VError(RuntimeError):
+    pass
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_PROTOS = {
+    "i2v_create": ([_I, C.POINTER(_P)], _I),
+    "i2v_destroy": ([_P], _I),
+    "i2v_last_error": ([], C.c_char_p),
+    "i2v_abi_version": ([], _I),
+    "i2v_backend": ([], C.c_char_p),
+    "i2v_net_create": ([_P, C.POINTER(_I)], _I),
+    "i2v_net_add_buffer": ([_P, _I, _I, _I, _I, C.POINTER(_I)], _I),
+    "i2v_net_add_tensor": ([_P, _I, _I, _I, _I, _I, C.POINTER(_I)], _I),
+    "i2v_net_set_input": ([_P, _I, _I], _I),
+    "i2v_net_add_conv": ([_P, _I, C.POINTER(ConvDesc), _P, _P, _P], _I),
+    "i2v_net_add_maxpool": ([_P, _I, C.POINTER(PoolDesc)], _I),
+    "i2v_net_plan": ([_P, _I, C.POINTER(_I), _I, _I], _I),
+    "i2v_net_workspace_bytes": ([_P, _I], C.c_size_t),
+    "i2v_net_forward": ([_P, _I, _P, _I, _P], _I),
+    "i2v_net_hook_info": ([_P, _I, _I, C.POINTER(_P), C.POINTER(_L), C.POINTER(_P), C.POINTER(_L),
+                           C.POINTER(_L), C.POINTER(C.c_int32)], _I),
+    "i2v_net_backward": ([_P, _I, _P, _I, _P], _I),
+    "i2v_net_read_tensor": ([_P, _I, _I, _I, _P, _I, _P], _I),
+    "i2v_frames_from_video_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "i2v_compose_f32": ([_P, _P, _P, _I, _I, _I, _I, _F, _I, _P], _I),
+    "i2v_cossim_scratch_bytes": ([_L, _I], C.c_size_t),
+    "i2v_cossim_fwd_bwd_f32": ([_P, _L, _P, _L, _L, _I, _P, _I, _F, _I, _I, _P, _P, _L, _P, _P], _I),
+    "i2v_std_fwd_bwd_f32": ([_P, _L, _L, _I, _I, _I, _P, _P, _L, _P, _P], _I),
+    "i2v_adam_step_f32": ([_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _I, _P], _I),
+    "i2v_sign_step_f32": ([_P, _P, _P, _L, _L, _F, _F, _P], _I),
+    "i2v_sign_step_delta_f32": ([_P, _P, _L, _F, _P], _I),
+    "i2v_aens_coeffs_f32": ([_P, _P, _F, _I, _P], _I),
+    "i2v_aens_reduce_f32": ([_P, _P, _I, _I, _P, _P, _P], _I),
+}
+EXPORTS = tuple(_PROTOS)
+
+
+def bind(cdll):
+    for name, (args, res) in _PROTOS.items():
+        fn = getattr(cdll, name)
+        fn.argtypes, fn.restype = args, res
+    return cdll
+
+
+_lib = None
+
+
+def load():
+    """Open the gfx950 library or fail loudly -- there is no CPU path in the product."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise I2VError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                           "(hipcc --offload-arch=gfx950); the attack engine has no CPU fallback")
+        lib = bind(C.CDLL(LIB_PATH))
+        if lib.i2v_backend() != HIP_BACKEND:
+            raise I2VError(f"{LIB_PATH} reports backend {lib.i2v_backend()!r}, expected {HIP_BACKEND!r}")
+        _lib = lib
+    return _lib
+
+
+def check(capi, status):
+    if status != 0:
+        raise I2VError(capi.i2v_last_error().decode())

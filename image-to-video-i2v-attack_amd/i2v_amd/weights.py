@@ -8,6 +8,7 @@ randomised BatchNorm statistics, so that BN folding is actually exercised.  A re
 `$I2V_WEIGHTS_DIR/<arch>.pth` when present.
 """
 import os
+import zlib
 from typing import Dict
 
 import torch
@@ -17,23 +18,30 @@ from .graphs import Graph
 BN_EPS = 1e-5   # torchvision BatchNorm2d default, used by every ResNet BN
 
 
+def _gen(seed: int, key: str) -> torch.Generator:
+    """One generator per parameter, keyed by its state_dict name: the values do not depend on
+    the order in which the graph lists its nodes."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed((seed * 1000003 + zlib.crc32(key.encode())) % (2 ** 63))
+    return g
+
+
 def synthetic_state_dict(graph: Graph, seed: int = 0) -> Dict[str, torch.Tensor]:
-    gen = torch.Generator(device="cpu")
-    gen.manual_seed(seed)
     sd = {}
     for nd in graph.nodes:
         if nd.op != "conv":
             continue
         fan_out = nd.cout * nd.kh * nd.kw
         std = (2.0 / fan_out) ** 0.5
-        sd[nd.weight] = torch.randn(nd.cout, nd.cin, nd.kh, nd.kw, generator=gen) * std
+        sd[nd.weight] = torch.randn(nd.cout, nd.cin, nd.kh, nd.kw, generator=_gen(seed, nd.weight)) * std
         if nd.bias:
-            sd[nd.bias] = torch.randn(nd.cout, generator=gen) * 0.05
+            sd[nd.bias] = torch.randn(nd.cout, generator=_gen(seed, nd.bias)) * 0.05
         if nd.bn:
-            sd[nd.bn + ".weight"] = torch.rand(nd.cout, generator=gen) + 0.5
-            sd[nd.bn + ".bias"] = torch.randn(nd.cout, generator=gen) * 0.1
-            sd[nd.bn + ".running_mean"] = torch.randn(nd.cout, generator=gen) * 0.1
-            sd[nd.bn + ".running_var"] = torch.rand(nd.cout, generator=gen) + 0.5
+            g = _gen(seed, nd.bn)
+            sd[nd.bn + ".weight"] = torch.rand(nd.cout, generator=g) + 0.5
+            sd[nd.bn + ".bias"] = torch.randn(nd.cout, generator=g) * 0.1
+            sd[nd.bn + ".running_mean"] = torch.randn(nd.cout, generator=g) * 0.1
+            sd[nd.bn + ".running_var"] = torch.rand(nd.cout, generator=g) + 0.5
     return sd
 
 

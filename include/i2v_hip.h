@@ -1,0 +1,132 @@
+/* libi2v_hip.so -- C ABI of the MI355X (gfx950) I2V adversarial-perturbation engine.
+ *
+ * The reference (zhipeng-wei/Image-to-Video-I2V-attack) has NO native boundary: its hot path is
+ * Python calling PyTorch/cuDNN.  This header is the boundary a binding
+ * for that path attaches to; every entry point cites the reference lines it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on error; `i2v_last_error()` gives the text;
+ *    nothing throws across the ABI;
+ *  - tensors passed by the caller are caller-owned DEVICE pointers, contiguous fp32;
+ *  - `stream` is a `hipStream_t` passed as `void*` (0 = default stream); all work is enqueued
+ *    asynchronously on it, nothing synchronises the host;
+ *  - the library owns only what hangs off the opaque handle: packed weights, the plan and the
+ *    activation/gradient arena of each backbone.  One handle per (process, device).
+ */
+#ifndef I2V_HIP_H
+#define I2V_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct i2v_ctx* i2v_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int i2v_create(int device, i2v_handle* out);
+int i2v_destroy(i2v_handle h);
+const char* i2v_last_error(void);
+int i2v_abi_version(void);
+/* "hip:gfx950" for the product library.  (The planner unit tests build a host simulation of
+ * the same ABI that answers "hostsim"; the Python package refuses to load anything else than
+ * the HIP build.) */
+const char* i2v_backend(void);
+
+/* ---- backbone description --------------------------------------------------------------
+ * Replaces `get_model`/`get_models` + `.cuda()` (image_attacks.py:84-115) and the hook lookup
+ * `_find_target_layer` (image_attacks.py:260-271, TPAMI_attack.py:176-200): the host walks its
+ * graph IR and declares buffers, tensor views and nodes in execution order. */
+typedef struct {
+    int32_t src, dst;             /* tensor ids */
+    int32_t cin, cout, kh, kw, stride, pad;
+    int32_t relu;                 /* ReLU after scale/shift (+residual) */
+    int32_t residual;             /* tensor id added before the ReLU, or -1 */
+} i2v_conv_desc;
+
+typedef struct {
+    int32_t src, dst;
+    int32_t k, stride, pad;
+} i2v_pool_desc;
+
+int i2v_net_create(i2v_handle h, int* net);
+int i2v_net_add_buffer(i2v_handle h, int net, int C, int H, int W, int* buf);
+int i2v_net_add_tensor(i2v_handle h, int net, int buf, int c_off, int C, int post_relu, int* tensor);
+int i2v_net_set_input(i2v_handle h, int net, int tensor);
+/* weight: host [cout][cin][kh][kw]; scale/shift: host [cout] -- the node computes
+ * relu(conv(x,W)*scale + shift + residual): eval-mode BatchNorm folded (image_attacks.py:253-256)
+ * or the conv bias. */
+int i2v_net_add_conv(i2v_handle h, int net, const i2v_conv_desc* d, const float* weight,
+                     const float* scale, const float* shift);
+int i2v_net_add_maxpool(i2v_handle h, int net, const i2v_pool_desc* d);
+/* Freeze the graph: pack weights for forward and input-gradient, plan both passes for up to
+ * `max_frames` frames and allocate the arena.  `hook_tensors` are the hooked layer outputs in
+ * the order the reference's forward hooks fire (image_attacks.py:281-283). */
+int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int n_hooks, int max_frames);
+size_t i2v_net_workspace_bytes(i2v_handle h, int net);
+
+/* ---- backbone execution ----------------------------------------------------------------
+ * `_ = self.model(x)` up to the deepest hook (image_attacks.py:318,334).  x: (frames,3,H,W). */
+int i2v_net_forward(i2v_handle h, int net, const float* x, int frames, void* stream);
+/* Where hook `hook` lives: activation view and gradient view (frame stride in elements, D
+ * contiguous elements per frame).  The gradient view is what `i2v_cossim_fwd_bwd_f32` fills. */
+int i2v_net_hook_info(i2v_handle h, int net, int hook, float** act, int64_t* act_stride,
+                      float** grad, int64_t* grad_stride, int64_t* D, int32_t* post_relu);
+/* `cost.backward()` restricted to d(cost)/d(input) (image_attacks.py:352): consumes the hook
+ * gradient views, writes (accumulate=0) or adds (accumulate=1) gx: (frames,3,H,W). */
+int i2v_net_backward(i2v_handle h, int net, float* gx, int accumulate, void* stream);
+/* Test/debug: copy a tensor's activation (which=0) or gradient (which=1) to a contiguous
+ * caller buffer (frames,C,H,W). */
+int i2v_net_read_tensor(i2v_handle h, int net, int tensor, int which, float* out, int frames,
+                        void* stream);
+
+/* ---- loop kernels ------------------------------------------------------------------------ */
+/* videos (b,3,f,h,w) normalised -> frames x:(b*f,3,h,w), frame n = b_idx*f + f_idx
+ * (image_attacks.py:300-301) and u = x*std + mean (`_transform_video(...,'back')`, :62,308). */
+int i2v_frames_from_video_f32(const float* video, float* x, float* u, int b, int f, int h, int w,
+                              void* stream);
+/* x = (clamp(u + clamp(delta,-eps,eps),0,1) - mean)/std (image_attacks.py:331-332).
+ * video_layout=1 writes (b,3,f,h,w) instead of (b*f,3,h,w) (final output, :360-363). */
+int i2v_compose_f32(const float* u, const float* delta, float* x, int b, int f, int h, int w,
+                    float eps, int video_layout, void* stream);
+/* Per-frame cosine similarity of `a` against the detached clean feature `b` and its gradient
+ * (image_attacks.py:341-347; F.cosine_similarity eps 1e-8):
+ *   cos_out[n] = <a_n,b_n>/(max(|a_n|,1e-8) max(|b_n|,1e-8))
+ *   grad_n (+)= coef * (b_n/(|a_n||b_n|) - cos_n a_n/|a_n|^2) [gated by a>0 if mask_relu]
+ * coef = coef_host * (coef_dev ? coef_dev[coef_index] : 1).  `scratch` >= i2v_cossim_scratch_bytes. */
+size_t i2v_cossim_scratch_bytes(int64_t D, int frames);
+int i2v_cossim_fwd_bwd_f32(const float* a, int64_t a_stride, const float* b, int64_t b_stride,
+                           int64_t D, int frames, const float* coef_dev, int coef_index,
+                           float coef_host, int mask_relu, int accumulate, float* cos_out,
+                           float* grad, int64_t grad_stride, void* scratch, void* stream);
+/* Dispersion-Reduction loss `activation.std()` over the WHOLE tensor, unbiased
+ * (image_attacks.py:218), and its gradient.  Same scratch size as the cosine kernel. */
+int i2v_std_fwd_bwd_f32(const float* a, int64_t a_stride, int64_t D, int frames, int mask_relu,
+                        int accumulate, float* std_out, float* grad, int64_t grad_stride,
+                        void* scratch, void* stream);
+/* Compose backward + `torch.optim.Adam.step` on delta (image_attacks.py:306,351-353):
+ *   g = gx/std[c] where -eps<=delta<=eps and 0<=u+clamp(delta)<=1 (inclusive), else 0
+ *   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; delta -= lr/(1-b1^t) * m/(sqrt(v)/sqrt(1-b2^t)+1e-8) */
+int i2v_adam_step_f32(float* delta, float* m, float* v, const float* gx, const float* u,
+                      int64_t frames, int hw, float eps, float lr, float beta1, float beta2,
+                      float adam_eps, int step_t, void* stream);
+/* BIM-style update (base_attacks.py:289-293) on a normalised clip of any rank whose channel
+ * index is (i / chan_stride) % 3:  a = adv*std+mean + step*sign(g); d = clamp(a-u,+-eps);
+ * adv = (clamp(u+d,0,1)-mean)/std. */
+int i2v_sign_step_f32(float* adv, const float* u, const float* grad, int64_t n, int64_t chan_stride,
+                      float step, float eps, void* stream);
+/* ILAF update `modifier -= step*sign(grad)` (image_attacks.py:617). */
+int i2v_sign_step_delta_f32(float* delta, const float* grad, int64_t n, float step, void* stream);
+/* Adaptive ENS-I2V re-weighting `coeffs = softmax(softmax(prev) + momentum*coeffs)`
+ * (TPAMI_attack.py:265), L <= 64, in place on device. */
+int i2v_aens_coeffs_f32(const float* prev, float* coeffs, float momentum, int L, void* stream);
+/* sum_l coeffs[l]*sum_n cos[l][n] bookkeeping for AENS (TPAMI_attack.py:289-297):
+ * feat_sum[l] = sum_n cos[l*frames+n]; weighted[l] = coeffs[l]*feat_sum[l]. */
+int i2v_aens_reduce_f32(const float* cos, const float* coeffs, int L, int frames, float* feat_sum,
+                        float* weighted, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,280 @@
+// TEST INFRASTRUCTURE -- scalar host implementation of csrc/i2v_kernels.h.
+//
+// Linked with csrc/i2v_engine.cpp into tests/hostsim/libi2v_hostsim.so so that the graph planner
+// (weight packing, k-tables, stride-parity classes, addend/mask fusion, arena layout) can be
+// checked against the oracle WITHOUT a GPU (`pytest -m "not gpu"`).  It is never loaded by the
+// product package: `i2v_amd.lib` only accepts a library whose `i2v_backend()` is "hip:gfx950".
+// Every routine is the literal definition of the launch-parameter structs in i2v_params.h.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../image-to-video-i2v-attack_amd/csrc/i2v_kernels.h"
+
+static const float MEAN[3] = {0.485f, 0.456f, 0.406f};
+static const float STD[3] = {0.229f, 0.224f, 0.225f};
+
+const char* be_name() { return "hostsim"; }
+int be_set_device(int) { return 0; }
+void* be_malloc(size_t b) { return malloc(b ? b : 16); }
+void be_free(void* p) { free(p); }
+int be_h2d(void* d, const void* s, size_t b) { memcpy(d, s, b); return 0; }
+int be_d2d_2d(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t rows, i2v_stream_t) {
+    for (size_t r = 0; r < rows; ++r) memcpy((char*)d + r * dp, (const char*)s + r * sp, w);
+    return 0;
+}
+int be_memset0(void* p, size_t b, i2v_stream_t) { memset(p, 0, b); return 0; }
+const char* be_error() { return nullptr; }
+int cos_nblk(int64_t D) { return (int)std::min<int64_t>(64, std::max<int64_t>(1, D / 4096)); }
+
+int k_conv(const I2VConvParams& p, i2v_stream_t) {
+    for (int n = 0; n < p.N; ++n)
+        for (int i = 0; i < p.Hg; ++i)
+            for (int j = 0; j < p.Wg; ++j) {
+                int oh = i * p.osh + p.oh0, ow = j * p.osw + p.ow0;
+                if (oh >= p.Ho || ow >= p.Wo) continue;
+                for (int cd = 0; cd < p.Cd; ++cd) {
+                    float acc = 0.f;
+                    for (int k = 0; k < p.Kpad; ++k) {
+                        const I2VKEntry& e = p.ktab[k];
+                        if (!e.valid) continue;
+                        int hs = i * p.sh + e.dh, ws = j * p.sw + e.dw;
+                        if (hs < 0 || hs >= p.Hs || ws < 0 || ws >= p.Ws) continue;
+                        acc += p.wp[(size_t)k * p.Cdpad + cd] *
+                               p.src[(size_t)n * p.src_nstride + e.chan_off + (size_t)hs * p.Ws + ws];
+                    }
+                    size_t oidx = (size_t)cd * p.Ho * p.Wo + (size_t)oh * p.Wo + ow;
+                    float v = acc;
+                    if (p.shift) v += p.shift[cd];
+                    if (p.add0) {
+                        if (p.add0_stride == 1) v += p.add0[(size_t)n * p.add0_nstride + oidx];
+                        else if (oh % p.add0_stride == 0 && ow % p.add0_stride == 0 &&
+                                 oh / p.add0_stride < p.add0_H && ow / p.add0_stride < p.add0_W)
+                            v += p.add0[(size_t)n * p.add0_nstride + (size_t)cd * p.add0_H * p.add0_W +
+                                        (size_t)(oh / p.add0_stride) * p.add0_W + ow / p.add0_stride];
+                    }
+                    if (p.add1) v += p.add1[(size_t)n * p.add1_nstride + oidx];
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    if (p.mask && !(p.mask[(size_t)n * p.mask_nstride + oidx] > 0.f)) v = 0.f;
+                    p.dst[(size_t)n * p.dst_nstride + oidx] = v;
+                }
+            }
+    return 0;
+}
+
+int k_imggrad(const I2VImgGradParams& p, i2v_stream_t) {
+    for (int n = 0; n < p.N; ++n)
+        for (int ci = 0; ci < p.Cin; ++ci)
+            for (int h = 0; h < p.H; ++h)
+                for (int w = 0; w < p.W; ++w) {
+                    float acc = 0.f;
+                    for (int co = 0; co < p.Cout; ++co)
+                        for (int r = 0; r < p.kh; ++r) {
+                            int th = h + p.pad - r;
+                            if (th < 0 || th % p.stride) continue;
+                            int ho = th / p.stride;
+                            if (ho >= p.Ho) continue;
+                            for (int s = 0; s < p.kw; ++s) {
+                                int tw = w + p.pad - s;
+                                if (tw < 0 || tw % p.stride) continue;
+                                int wo = tw / p.stride;
+                                if (wo >= p.Wo) continue;
+                                acc += p.w[(((size_t)co * p.Cin + ci) * p.kh + r) * p.kw + s] *
+                                       p.dz[(size_t)n * p.dz_nstride + ((size_t)co * p.Ho + ho) * p.Wo + wo];
+                            }
+                        }
+                    size_t o = (((size_t)n * p.Cin + ci) * p.H + h) * p.W + w;
+                    p.gx[o] = p.accumulate ? p.gx[o] + acc : acc;
+                }
+    return 0;
+}
+
+static inline int pool_argmax(const float* plane, int Hs, int Ws, int ho, int wo, int k, int st, int pad) {
+    // first maximum in scan order (ATen max_pool2d: update on `val > max || isnan(val)`)
+    int best = -1; float bv = -INFINITY;
+    for (int r = 0; r < k; ++r) {
+        int h = ho * st - pad + r; if (h < 0 || h >= Hs) continue;
+        for (int s = 0; s < k; ++s) {
+            int w = wo * st - pad + s; if (w < 0 || w >= Ws) continue;
+            float v = plane[h * Ws + w];
+            if (best < 0 || v > bv || v != v) { bv = v; best = h * Ws + w; }
+        }
+    }
+    return best;
+}
+
+int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t) {
+    for (int n = 0; n < p.N; ++n)
+        for (int c = 0; c < p.C; ++c) {
+            const float* pl = p.x + (size_t)n * p.x_nstride + (size_t)c * p.Hs * p.Ws;
+            for (int ho = 0; ho < p.Ho; ++ho)
+                for (int wo = 0; wo < p.Wo; ++wo)
+                    p.y[(size_t)n * p.y_nstride + ((size_t)c * p.Ho + ho) * p.Wo + wo] =
+                        pl[pool_argmax(pl, p.Hs, p.Ws, ho, wo, p.k, p.stride, p.pad)];
+        }
+    return 0;
+}
+
+int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t) {
+    for (int n = 0; n < p.N; ++n)
+        for (int c = 0; c < p.C; ++c) {
+            const float* pl = p.x + (size_t)n * p.x_nstride + (size_t)c * p.Hs * p.Ws;
+            float* g = p.gx + (size_t)n * p.gx_nstride + (size_t)c * p.Hs * p.Ws;
+            for (int i = 0; i < p.Hs * p.Ws; ++i) g[i] = 0.f;
+            for (int ho = 0; ho < p.Ho; ++ho)
+                for (int wo = 0; wo < p.Wo; ++wo)
+                    g[pool_argmax(pl, p.Hs, p.Ws, ho, wo, p.k, p.stride, p.pad)] +=
+                        p.y[(size_t)n * p.y_nstride + ((size_t)c * p.Ho + ho) * p.Wo + wo];
+            if (p.mask_relu) for (int i = 0; i < p.Hs * p.Ws; ++i) if (!(pl[i] > 0.f)) g[i] = 0.f;
+        }
+    return 0;
+}
+
+int k_addmask(const I2VAddMaskParams& p, i2v_stream_t) {
+    size_t plane = (size_t)p.C * p.HW;
+    for (int n = 0; n < p.N; ++n)
+        for (size_t i = 0; i < plane; ++i) {
+            float v = 0.f;
+            for (int a = 0; a < 3; ++a) if (p.a[a]) v += p.a[a][(size_t)n * p.a_nstride[a] + i];
+            if (p.mask && !(p.mask[(size_t)n * p.mask_nstride + i] > 0.f)) v = 0.f;
+            p.out[(size_t)n * p.out_nstride + i] = v;
+        }
+    return 0;
+}
+
+int k_cos(const I2VCosParams& p, i2v_stream_t) {
+    float coef = p.coef_host * (p.coef_dev ? p.coef_dev[p.coef_index] : 1.f);
+    for (int n = 0; n < p.N; ++n) {
+        const float* a = p.a + (size_t)n * p.a_nstride; const float* b = p.b + (size_t)n * p.b_nstride;
+        double dot = 0, aa = 0, bb = 0;
+        for (int64_t i = 0; i < p.D; ++i) { dot += (double)a[i] * b[i]; aa += (double)a[i] * a[i]; bb += (double)b[i] * b[i]; }
+        double n1 = std::max(sqrt(aa), 1e-8), n2 = std::max(sqrt(bb), 1e-8);
+        double cs = dot / (n1 * n2);
+        p.cos_out[n] = (float)cs;
+        float* g = p.grad + (size_t)n * p.grad_nstride;
+        for (int64_t i = 0; i < p.D; ++i) {
+            float v = (float)(coef * (b[i] / (n1 * n2) - cs * a[i] / (n1 * n1)));
+            if (p.mask_relu && !(a[i] > 0.f)) v = 0.f;
+            g[i] = p.accumulate ? g[i] + v : v;
+        }
+    }
+    return 0;
+}
+
+int k_std(const I2VStdParams& p, i2v_stream_t) {
+    double s = 0, ss = 0; double cnt = (double)p.N * p.D;
+    for (int n = 0; n < p.N; ++n) { const float* a = p.a + (size_t)n * p.a_nstride; for (int64_t i = 0; i < p.D; ++i) s += a[i]; }
+    double mu = s / cnt;
+    for (int n = 0; n < p.N; ++n) { const float* a = p.a + (size_t)n * p.a_nstride; for (int64_t i = 0; i < p.D; ++i) ss += (a[i] - mu) * (a[i] - mu); }
+    double sd = sqrt(ss / (cnt - 1));
+    p.std_out[0] = (float)sd;
+    for (int n = 0; n < p.N; ++n) {
+        const float* a = p.a + (size_t)n * p.a_nstride; float* g = p.grad + (size_t)n * p.grad_nstride;
+        for (int64_t i = 0; i < p.D; ++i) {
+            float v = (float)((a[i] - mu) / ((cnt - 1) * sd));
+            if (p.mask_relu && !(a[i] > 0.f)) v = 0.f;
+            g[i] = p.accumulate ? g[i] + v : v;
+        }
+    }
+    return 0;
+}
+
+int k_frames_from_video(const float* video, float* x, float* u, int b, int f, int h, int w, i2v_stream_t) {
+    size_t hw = (size_t)h * w;
+    for (int bi = 0; bi < b; ++bi) for (int c = 0; c < 3; ++c) for (int fi = 0; fi < f; ++fi)
+        for (size_t i = 0; i < hw; ++i) {
+            float v = video[(((size_t)bi * 3 + c) * f + fi) * hw + i];
+            size_t o = (((size_t)bi * f + fi) * 3 + c) * hw + i;
+            x[o] = v;
+            volatile float t = v * STD[c];          // mul_ then add_, two roundings
+            u[o] = t + MEAN[c];
+        }
+    return 0;
+}
+
+int k_compose(const float* u, const float* d, float* x, int b, int f, int h, int w, float eps, int video_layout, i2v_stream_t) {
+    size_t hw = (size_t)h * w;
+    for (int bi = 0; bi < b; ++bi) for (int fi = 0; fi < f; ++fi) for (int c = 0; c < 3; ++c)
+        for (size_t i = 0; i < hw; ++i) {
+            size_t o = (((size_t)bi * f + fi) * 3 + c) * hw + i;
+            float dc = std::min(std::max(d[o], -eps), eps);
+            float s = u[o] + dc;
+            float xi = std::min(std::max(s, 0.f), 1.f);
+            float v = (xi - MEAN[c]) / STD[c];
+            size_t oo = video_layout ? (((size_t)bi * 3 + c) * f + fi) * hw + i : o;
+            x[oo] = v;
+        }
+    return 0;
+}
+
+int k_adam(float* delta, float* m, float* v, const float* gx, const float* u, int64_t n, int hw, float eps,
+           float step_size, float bc2_sqrt, float beta1, float beta2, float adam_eps, i2v_stream_t) {
+    for (int64_t i = 0; i < n; ++i) {
+        int c = (int)((i / hw) % 3);
+        float d = delta[i];
+        float dc = std::min(std::max(d, -eps), eps);
+        float s = u[i] + dc;
+        bool pass = d >= -eps && d <= eps && s >= 0.f && s <= 1.f;
+        float g = pass ? gx[i] / STD[c] : 0.f;
+        float mm = fmaf(1.f - beta1, g - m[i], m[i]);
+        volatile float v1 = v[i] * beta2;
+        volatile float t1 = (1.f - beta2) * g;
+        volatile float t2 = t1 * g;
+        float vv = v1 + t2;
+        volatile float den0 = sqrtf(vv) / bc2_sqrt;
+        float den = den0 + adam_eps;
+        volatile float q = mm / den;
+        volatile float upd = -step_size * q;
+        delta[i] = d + upd;
+        m[i] = mm; v[i] = vv;
+    }
+    return 0;
+}
+
+int k_sign_bim(float* adv, const float* u, const float* grad, int64_t n, int64_t cs, float step, float eps, i2v_stream_t) {
+    for (int64_t i = 0; i < n; ++i) {
+        int c = (int)((i / cs) % 3);
+        volatile float t = adv[i] * STD[c];
+        float a = t + MEAN[c];
+        float g = grad[i];
+        float sg = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
+        volatile float st = step * sg;
+        a = a + st;
+        float d = std::min(std::max(a - u[i], -eps), eps);
+        float r = std::min(std::max(u[i] + d, 0.f), 1.f);
+        adv[i] = (r - MEAN[c]) / STD[c];
+    }
+    return 0;
+}
+
+int k_sign_delta(float* delta, const float* grad, int64_t n, float step, i2v_stream_t) {
+    for (int64_t i = 0; i < n; ++i) {
+        float g = grad[i];
+        delta[i] -= step * (g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f));
+    }
+    return 0;
+}
+
+int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t) {
+    std::vector<float> a(L), b(L);
+    float mx = -INFINITY, sum = 0.f;
+    for (int i = 0; i < L; ++i) mx = std::max(mx, prev[i]);
+    for (int i = 0; i < L; ++i) { a[i] = expf(prev[i] - mx); sum += a[i]; }
+    for (int i = 0; i < L; ++i) b[i] = a[i] / sum + momentum * coeffs[i];
+    mx = -INFINITY; sum = 0.f;
+    for (int i = 0; i < L; ++i) mx = std::max(mx, b[i]);
+    for (int i = 0; i < L; ++i) { a[i] = expf(b[i] - mx); sum += a[i]; }
+    for (int i = 0; i < L; ++i) coeffs[i] = a[i] / sum;
+    return 0;
+}
+
+int k_aens_reduce(const float* cos, const float* coeffs, int L, int frames, float* feat_sum, float* weighted, i2v_stream_t) {
+    for (int l = 0; l < L; ++l) {
+        double s = 0; for (int n = 0; n < frames; ++n) s += cos[(size_t)l * frames + n];
+        feat_sum[l] = (float)s; weighted[l] = coeffs[l] * (float)s;
+    }
+    return 0;
+}

@@ -1,0 +1,135 @@
+"""CPU: the graph planner/executor of csrc/i2v_engine.cpp (weight packing, k-tables, stride-parity
+classes, addend/mask fusion, arena) driven through the C ABI with the scalar host backend of
+tests/hostsim/, against the oracle.  The HIP kernels themselves are checked by the -m gpu tests."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from i2v_amd import graphs, weights, attacks
+from oracle import restate
+from tests import golden_util as gu
+from tests.hostsim_util import hostsim_engine
+
+CASES = [("resnet", [3], 64), ("resnet", [2, 3], 64), ("resnet", [1], 32), ("vgg", [2], 32), ("vgg", [3], 32),
+         ("alexnet", [3], 64), ("alexnet", [2, 4], 64), ("squeezenet", [2], 64), ("squeezenet", [2, 3], 64),
+         ("squeezenet", [4], 64)]
+
+
+def write_hook_grads(net, feats, hg, N):
+    """Put d(cost)/d(hook) where the library expects it, gated by the hook's own ReLU (what
+    i2v_cossim_fwd_bwd_f32 does on the device)."""
+    for i, hi in enumerate(net.hooks):
+        gate = (feats[i] > 0).to(hg[i].dtype) if hi.post_relu else torch.ones_like(feats[i])
+        flat = (hg[i] * gate).float().reshape(N, -1).contiguous()
+        for n in range(N):
+            ctypes.memmove(hi.grad + 4 * n * hi.grad_stride, flat[n].data_ptr(), 4 * hi.D)
+
+
+@pytest.mark.parametrize("model,depths,hw", CASES)
+def test_forward_backward_match_oracle(model, depths, hw):
+    eng = hostsim_engine()
+    g = graphs.build_tiny(model, (hw, hw))
+    sd = weights.synthetic_state_dict(g, 3)
+    hooks = [g.hooks[d] for d in depths]
+    N = 3
+    net = eng.build_net(g, sd, hooks, N)
+    onet = restate.OracleNet(g, sd, hooks, dtype=torch.float64)
+    torch.manual_seed(hw + len(depths))
+    x = torch.randn(N, 3, hw, hw)
+    feats = onet.forward(x.double())
+    net.forward(x)
+    for nd in net.graph.nodes:                       # every activation the truncated graph produces
+        got = net.read_tensor(nd.dst, N).double()
+        assert torch.allclose(got, onet.tensor(nd.dst), rtol=1e-4, atol=1e-5), nd
+    hg = [torch.randn_like(f) for f in feats]        # well-conditioned random hook gradients
+    write_hook_grads(net, feats, hg, N)
+    gx = torch.empty(N, 3, hw, hw)
+    net.backward(gx)
+    ref = onet.backward(hg)
+    err = (gx.double() - ref).abs().max() / ref.abs().max()
+    assert err < 1e-4, err
+    gx2 = gx.clone()
+    net.backward(gx2, accumulate=True)
+    assert torch.allclose(gx2, 2 * gx, rtol=1e-6, atol=1e-9)
+
+
+MODE = {"i2v": attacks.ImageGuidedFMDirection_Adam, "std": attacks.ImageGuidedStd_Adam}
+
+
+@pytest.mark.parametrize("name", ["i2v_resnet_d2_f32", "i2v_vgg_d2_f64", "i2v_alexnet_d3_f64",
+                                  "i2v_squeezenet_d2_f64", "std_resnet_d2_f64"])
+def test_attack_loop_against_golden(name):
+    fx = gu.load(name)
+    atk = MODE[fx["kind"]](fx["models"], depth=fx["depth"], step_size=fx["lr"], steps=fx["steps"],
+                           engine=hostsim_engine(), graph_builder=graphs.build_tiny, weight_seed=fx["wseed"])
+    vid = gu.videos_of(fx)
+    adv = atk(vid, torch.zeros(fx["b"], dtype=torch.long), ["clip0"])
+    ref_cost = np.array([float(s) for s in fx["cost_str"]])
+    np.testing.assert_allclose(atk.last_costs, ref_cost, rtol=2e-4)
+    assert adv.shape == vid.shape
+    assert list(atk.loss_info["clip0"].keys()) == list(range(fx["steps"]))
+    assert atk.loss_info["clip0"][0]["cost"] == str(np.float32(atk.last_costs[0]))
+    # L_inf / box invariants of the composed output
+    mean = torch.tensor(gu.MEAN).view(1, 3, 1, 1, 1)
+    std = torch.tensor(gu.STD).view(1, 3, 1, 1, 1)
+    un = adv * std + mean
+    clean = torch.from_numpy(fx["clip_u8"]).float() / 255
+    assert (un - clean).abs().max() <= 16 / 255 + 1e-6
+    assert un.min() >= -1e-6 and un.max() <= 1 + 1e-6
+    assert np.abs(adv.numpy() - fx["adv"]).mean() < 5e-3
+
+
+def test_ens_and_aens_against_golden():
+    fx = gu.load("ens_4models_f64")
+    atk = attacks.ImageGuidedFML2_Adam_MultiModels(fx["models"], depths=fx["depth"], steps=fx["steps"],
+                                                   engine=hostsim_engine(), graph_builder=graphs.build_tiny)
+    adv = atk(gu.videos_of(fx), torch.zeros(fx["b"], dtype=torch.long), ["clip0", "clip1"])
+    ref_cost = np.array([float(s) for s in fx["cost_str"]])
+    np.testing.assert_allclose(atk.last_costs, ref_cost, rtol=2e-4)
+    assert np.abs(adv.numpy() - fx["adv"]).mean() < 5e-3
+
+    for name in ("aens_2x2_f64", "aens_coefce_f64"):
+        fx = gu.load(name)
+        atk = attacks.AENS_I2V_MF(fx["models"], depths=fx["depth"], step_size=fx["lr"], steps=fx["steps"],
+                                  engine=hostsim_engine(), graph_builder=graphs.build_tiny, **fx["kw"])
+        adv, used_time, cost_saved = atk(gu.videos_of(fx), torch.zeros(fx["b"], dtype=torch.long), ["c"] * fx["b"])
+        np.testing.assert_allclose(cost_saved, fx["cost_saved"], rtol=2e-4)
+        np.testing.assert_allclose(np.stack(atk.weights), fx["weights"], rtol=1e-4)
+        np.testing.assert_allclose(atk.coeffs.numpy(), fx["coeffs_after"], rtol=1e-4)
+        assert cost_saved.dtype == np.float64 and used_time >= 0
+
+
+def test_teacher_forced_first_step_matches_reference_gradient():
+    """First step from delta_0: the sign of the gradient handed to Adam against the reference's
+    (f64-backbone fixture => the reference value is accurate)."""
+    fx = gu.load("i2v_resnet_d3_f64")
+    atk = attacks.ImageGuidedFMDirection_Adam(fx["models"], depth=fx["depth"], step_size=fx["lr"], steps=1,
+                                              engine=hostsim_engine(), graph_builder=graphs.build_tiny)
+    atk(gu.videos_of(fx), torch.zeros(1, dtype=torch.long), ["c"])
+    r0 = fx["grad0"]
+    d1 = atk._delta.numpy()
+    big = np.abs(r0) > 2e-2 * np.abs(r0).max()
+    moved = np.sign(0.01 / 255 - d1)                 # first Adam step moves by -lr*sign(g)
+    assert (moved[big] == np.sign(r0[big])).mean() > 0.995
+    # |g| is ~1e-7 on many pixels, comparable to Adam's eps=1e-8 and to fp32 gradient noise, so the
+    # step g/(|g|+1e-8) is only reproducible where the gradient is well above that floor
+    well = np.abs(r0) > 5e-2 * np.abs(r0).max()      # |g| >= ~1e-7 = 10x Adam's eps
+    assert (np.abs(d1 - fx["delta_first"])[well] < 1e-4).all()
+    assert (np.abs(d1 - fx["delta_first"])[well] < 2e-5).mean() > 0.99
+    assert (np.abs(d1 - fx["delta_first"]) < 1e-4).mean() > 0.9
+
+
+def test_error_paths():
+    eng = hostsim_engine()
+    with pytest.raises(AttributeError):
+        attacks.ImageGuidedFMDirection_Adam(["densenet"], depth=2, step_size=0.005, engine=eng)
+    with pytest.raises(UnboundLocalError):
+        attacks.ImageGuidedFMDirection_Adam(["inception"], depth=2, step_size=0.005, engine=eng)
+    g = graphs.build_tiny("resnet", (32, 32))
+    sd = weights.synthetic_state_dict(g, 0)
+    net = eng.build_net(g, sd, [g.hooks[2]], 2)
+    from i2v_amd.lib import I2VError
+    with pytest.raises(I2VError):
+        net.forward(torch.zeros(3, 3, 32, 32))          # more frames than planned
