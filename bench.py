@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py -- adversarial frames/s of the I2V attack on MI355X (BASELINE.json metric).
+
+One "step" = one complete I2V attack over one batch of synthetic clips: flatten + un-normalise,
+clean feature pass, S=10 iterations of (compose, ResNet-50 forward to layer3, cosine loss, input
+gradient, Adam) and the final compose -- i.e. `ImageGuidedFMDirection_Adam.forward`
+(/root/reference/image_attacks.py:294-364).  Workload at N=1: BASELINE.json configs[1], batch = 4
+clips of 32 x 224^2 (128 frames), ResNet-50 hook layer3, eps = 16/255, lr = 0.005, inputs
+resident in HBM before the timed region.  With --gpus N every rank attacks its own 4 clips (weak
+scaling, no data-path collective: frames are independent).
+
+Prints ONE JSON line (rank 0) with `roofline` (conv_igemm, fp32 MFMA) and `cpu_baseline`
+(the CPU oracle timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "image-to-video-i2v-attack_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32-input MFMA (= vector) peak
+ATTACK_STEPS = 10
+CLIPS_PER_GPU = 4
+FRAMES, HW = 32, 224
+MODEL, DEPTH = "resnet50", 3
+
+
+def synthetic_clips(b, seed0=1000):
+    """uint8 noise clips (exact 0/1 pixels occur), ImageNet-normalised."""
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1, 1)
+    clips = []
+    for i in range(b):
+        gen = torch.Generator().manual_seed(seed0 + i)
+        u8 = torch.randint(0, 256, (1, 3, FRAMES, HW, HW), generator=gen, dtype=torch.uint8)
+        clips.append((u8.float() / 255 - mean) / std)
+    return torch.cat(clips)
+
+
+def cpu_baseline():
+    """The CPU oracle (a port of the reference path; `oracle/restate.py`) on a bounded sample of
+    the same workload: ResNet-50 layer3, 224^2, 4 frames, clean pass + 2 attack iterations, all
+    host cores; extrapolated to the 10-iteration attack: frames / (t_clean + 10 * t_iter)."""
+    from i2v_amd import graphs, weights
+    from oracle import restate
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = graphs.build(MODEL, (HW, HW))
+    net = restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hooks[DEPTH]])
+    nf = 4
+    vid = synthetic_clips(1)[:, :, :nf].contiguous()
+    x = restate.flatten_frames(vid).contiguous()
+    u = restate.unnormalise(x)
+    t0 = time.time()
+    init = [t.clone() for t in net.forward(x)]
+    t_clean = time.time() - t0
+    delta = torch.full_like(x, 0.01 / 255)
+    opt = restate.AdamState(delta, 0.005)
+    iters = 2
+    t0 = time.time()
+    for _ in range(iters):
+        xn, mask = restate.compose(u, delta, 16 / 255)
+        feats = net.forward(xn)
+        _, gr = restate.cosine_fwd_bwd(feats[0], init[0])
+        opt.step(delta, restate.compose_backward(net.backward([gr]), mask))
+    t_iter = (time.time() - t0) / iters
+    fps = nf / (t_clean + ATTACK_STEPS * t_iter)
+    return {"value": round(fps, 4), "unit": "adversarial frames/s", "cores": cores, "kind": "port",
+            "sample": f"{nf} frames x 224^2, ResNet-50 layer3, clean pass + {iters} of {ATTACK_STEPS} attack "
+                      f"iterations timed ({t_clean:.2f}s + {t_iter:.2f}s/iter), extrapolated to {ATTACK_STEPS}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="do not bracket backbone launches with HIP events in the timed region")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        dist = None
+        torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+
+    from i2v_amd import attacks, graphs
+    eng = attacks.get_engine(dev)
+    atk = attacks.ImageGuidedFMDirection_Adam([MODEL], depth=DEPTH, step_size=0.005, steps=ATTACK_STEPS, engine=eng)
+    b = args.clips
+    videos = synthetic_clips(b, seed0=1000 + rank * b).to(dev)         # resident in HBM before timing
+    labels = torch.zeros(b, dtype=torch.long)
+    names = [f"clip{rank * b + i}" for i in range(b)]
+
+    for _ in range(max(args.warmup, 0)):
+        atk(videos, labels, names)
+    torch.cuda.synchronize()
+    timing = not args.no_kernel_timing
+    if timing:
+        eng.timing_enable(True)
+        atk(videos, labels, names)          # pre-create the event pool outside the timed region
+        eng.timing_collect()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        atk(videos, labels, names)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kt = eng.timing_collect() if timing else None
+    if timing:
+        eng.timing_enable(False)
+
+    frames_total = args.steps * b * FRAMES * world
+    value = frames_total / elapsed
+    g = graphs.build(MODEL, (HW, HW)).truncated([graphs.build(MODEL, (HW, HW)).hooks[DEPTH]])
+    mac = g.macs_per_frame()
+    flop_per_frame = (4 * ATTACK_STEPS + 2) * mac
+    out = {
+        "metric": "adversarial frames/sec (10-step I2V, ResNet-50 layer3, 32x224^2 clips)",
+        "value": round(value, 2), "unit": "adversarial frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"I2V ResNet-50 layer3, batch={b} synthetic 32-frame 224^2 clips per GPU, "
+                               f"{ATTACK_STEPS} steps eps=16/255 lr=0.005 (BASELINE.json configs[1])",
+                   "frames_per_gpu": b * FRAMES, "attack_steps": ATTACK_STEPS, "weights": "seeded synthetic (seed 0)",
+                   "parallelism": f"clips sharded over {world} GPU(s), no collective"},
+        "end_to_end_tflops_per_gpu": round(value / world * flop_per_frame / 1e12, 2),
+        "algorithmic_gflop_per_frame": round(flop_per_frame / 1e9, 2),
+    }
+    if kt is not None and kt["conv_igemm"]["launches"]:
+        c = kt["conv_igemm"]
+        ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "conv_igemm (fp32 MFMA implicit GEMM, fwd + dgrad)", "bound": "mfma",
+                           "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                           "launches": c["launches"], "avg_launch_us": round(1e3 * c["ms"] / c["launches"], 2),
+                           "avg_gflop_per_launch": round(c["flops"] / c["launches"] / 1e9, 3),
+                           "device_ms_by_kernel": {k: round(v["ms"], 2) for k, v in kt.items()},
+                           "wall_ms_timed_region": round(1e3 * elapsed, 2)}
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,7 +50,7 @@ struct Tensor { int buf, c_off, C; bool post_relu; };
 
 struct Packed {               // one implicit-GEMM operand set
     float* wp = nullptr; I2VKEntry* ktab = nullptr;
-    int Kpad = 0, Cd = 0, Cdpad = 0;
+    int K = 0, Kpad = 0, Cd = 0, Cdpad = 0;
     int ph = 0, pw = 0, Hg = 0, Wg = 0;
 };
 
@@ -84,7 +84,11 @@ struct Net {
 
 }  // namespace
 
-struct i2v_ctx { int device; std::vector<Net*> nets; };
+struct TimedLaunch { void* start; void* stop; int kind; double flops; };
+struct i2v_ctx {
+    int device; std::vector<Net*> nets;
+    bool timing = false; std::vector<TimedLaunch> timed; size_t timed_used = 0; i2v_stream_t timed_stream = nullptr;
+};
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -116,7 +120,7 @@ static int pack_fwd(Net& n, Node& nd) {
     const Buffer& sb = n.bufs[n.tens[c.src].buf];
     int K = c.kh * c.kw * c.cin;
     Packed& P = nd.fwd;
-    P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cout; P.Cdpad = (int)align_up(c.cout, 128);
+    P.K = K; P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cout; P.Cdpad = (int)align_up(c.cout, 128);
     std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
     std::vector<I2VKEntry> kt(P.Kpad, I2VKEntry{0, 0, 0, 0});
     for (int r = 0; r < c.kh; ++r)
@@ -145,7 +149,7 @@ static int pack_bwd(Net& n, Node& nd) {
             for (int r = 0; r < c.kh; ++r) if (posmod(ph + c.pad - r, st) == 0) tr.push_back(r);
             for (int s = 0; s < c.kw; ++s) if (posmod(pw + c.pad - s, st) == 0) ts.push_back(s);
             int K = (int)(tr.size() * ts.size()) * c.cout;
-            P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cin; P.Cdpad = (int)align_up(c.cin, 128);
+            P.K = K; P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cin; P.Cdpad = (int)align_up(c.cin, 128);
             std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
             std::vector<I2VKEntry> kt(P.Kpad ? P.Kpad : 1, I2VKEntry{0, 0, 0, 0});
             int t = 0;
@@ -195,7 +199,7 @@ extern "C" int i2v_create(int device, i2v_handle* out) {
     if (!out) return fail("i2v_create: null out");
     if (be_set_device(device)) return fail("i2v_create: cannot select device %d: %s", device,
                                            be_error() ? be_error() : "?");
-    *out = new i2v_ctx{device, {}};
+    *out = new i2v_ctx(); (*out)->device = device;
     return 0;
 }
 
@@ -209,6 +213,7 @@ static void free_net(Net* n) {
 extern "C" int i2v_destroy(i2v_handle h) {
     if (!h) return 0;
     for (Net* n : h->nets) free_net(n);
+    for (auto& t : h->timed) { be_event_destroy(t.start); be_event_destroy(t.stop); }
     delete h;
     return 0;
 }
@@ -293,7 +298,7 @@ extern "C" int i2v_net_add_maxpool(i2v_handle h, int net, const i2v_pool_desc* d
 // ---------------------------------------------------------------------------------------------
 static void conv_common(I2VConvParams& p, const Packed& P) {
     memset(&p, 0, sizeof p);
-    p.wp = P.wp; p.ktab = P.ktab; p.Kpad = P.Kpad; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
+    p.wp = P.wp; p.ktab = P.ktab; p.K = P.K; p.Kpad = P.Kpad; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
     p.add0_stride = 1;
 }
 
@@ -568,9 +573,28 @@ extern "C" size_t i2v_net_workspace_bytes(i2v_handle h, int net) {
 // ---------------------------------------------------------------------------------------------
 // execution
 // ---------------------------------------------------------------------------------------------
-static int run_list(Net& n, std::vector<Launch>& L, int frames, const float* x, float* gx, int accumulate,
+static TimedLaunch* timing_begin(i2v_ctx* h, int kind, double flops, i2v_stream_t s) {
+    if (!h->timing) return nullptr;
+    if (h->timed_used == h->timed.size()) {
+        TimedLaunch t{be_event_create(), be_event_create(), 0, 0.0};
+        if (!t.start || !t.stop) return nullptr;
+        h->timed.push_back(t);
+    }
+    TimedLaunch* t = &h->timed[h->timed_used++];
+    t->kind = kind; t->flops = flops; h->timed_stream = s;
+    be_event_record(t->start, s);
+    return t;
+}
+
+static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int frames, const float* x, float* gx, int accumulate,
                     i2v_stream_t s) {
     for (Launch& l : L) {
+        double flops = 0.0;
+        if (l.kind == L_CONV) flops = 2.0 * frames * l.conv.Hg * l.conv.Wg * (double)l.conv.Cd * l.conv.K;
+        else if (l.kind == L_IMGGRAD)
+            flops = 2.0 * frames * (double)l.img.Ho * l.img.Wo * l.img.Cout * l.img.Cin * l.img.kh * l.img.kw;
+        TimedLaunch* tl = timing_begin(h, (int)l.kind, flops, s);
+        struct Stop { TimedLaunch* t; i2v_stream_t s; ~Stop() { if (t) be_event_record(t->stop, s); } } stop{tl, s};
         switch (l.kind) {
             case L_CONV: {
                 I2VConvParams p = l.conv; p.N = frames;
@@ -596,14 +620,36 @@ extern "C" int i2v_net_forward(i2v_handle h, int net, const float* x, int frames
     if (frames <= 0 || frames > n->maxN) return fail("frames=%d outside 1..%d", frames, n->maxN);
     if (!x) return fail("null input");
     n->frames = frames;
-    return run_list(*n, n->fwd, frames, x, nullptr, 0, stream);
+    return run_list(h, *n, n->fwd, frames, x, nullptr, 0, stream);
 }
 
 extern "C" int i2v_net_backward(i2v_handle h, int net, float* gx, int accumulate, void* stream) {
     Net* n = get_net(h, net); if (!n) return 1;
     if (!n->planned || n->frames <= 0) return fail("backward before forward");
     if (!gx) return fail("null gradient output");
-    return run_list(*n, n->bwd, n->frames, nullptr, gx, accumulate, stream);
+    return run_list(h, *n, n->bwd, n->frames, nullptr, gx, accumulate, stream);
+}
+
+extern "C" int i2v_timing_enable(i2v_handle h, int enable) {
+    if (!h) return fail("null handle");
+    h->timing = enable != 0; h->timed_used = 0;
+    return 0;
+}
+
+// kinds: 0 conv_igemm (MFMA), 1 first-layer image gradient, 2 pool fwd, 3 pool bwd, 4 addmask
+extern "C" int i2v_timing_collect(i2v_handle h, double* ms_by_kind, double* flops_by_kind, int64_t* launches_by_kind,
+                                  int n_kinds) {
+    if (!h || !ms_by_kind || !flops_by_kind || !launches_by_kind || n_kinds < 5) return fail("i2v_timing_collect: bad argument");
+    for (int i = 0; i < n_kinds; ++i) { ms_by_kind[i] = 0; flops_by_kind[i] = 0; launches_by_kind[i] = 0; }
+    if (h->timed_used) CHECK_BE(be_stream_sync(h->timed_stream));
+    for (size_t i = 0; i < h->timed_used; ++i) {
+        float ms = 0.f;
+        CHECK_BE(be_event_elapsed_ms(h->timed[i].start, h->timed[i].stop, &ms));
+        int k = h->timed[i].kind;
+        ms_by_kind[k] += ms; flops_by_kind[k] += h->timed[i].flops; launches_by_kind[k] += 1;
+    }
+    h->timed_used = 0;
+    return 0;
 }
 
 extern "C" int i2v_net_hook_info(i2v_handle h, int net, int hook, float** act, int64_t* act_stride,

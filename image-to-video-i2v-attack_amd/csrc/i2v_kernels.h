@@ -14,7 +14,13 @@ int  be_h2d(void* dst, const void* src, size_t bytes);                       // 
 int  be_d2d_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows,
                i2v_stream_t s);                                               // async strided copy
 int  be_memset0(void* p, size_t bytes, i2v_stream_t s);
-const char* be_error();                                                       // last backend error or null
+const char* be_error();
+// timing instrumentation (bench.py roofline): stream-ordered event pairs around a launch
+void* be_event_create();
+void be_event_destroy(void* ev);
+int  be_event_record(void* ev, i2v_stream_t s);
+int  be_event_elapsed_ms(void* start, void* stop, float* ms);           // both must have completed
+int  be_stream_sync(i2v_stream_t s);                                                       // last backend error or null
 
 int k_conv(const I2VConvParams& p, i2v_stream_t s);
 int k_imggrad(const I2VImgGradParams& p, i2v_stream_t s);

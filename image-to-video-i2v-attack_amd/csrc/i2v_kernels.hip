@@ -1,0 +1,682 @@
+// gfx950 (MI355X / CDNA4) kernel backend of the I2V engine.  Wave64, fp32-input MFMA.
+//
+//   conv_igemm      implicit-GEMM convolution, forward and input-gradient (I2VConvParams):
+//                   D[cd][pixel] = Wp[k][cd]^T * im2col[k][pixel] on v_mfma_f32_32x32x2_f32, with the
+//                   pixel axis on the MFMA column (lane) index so that NCHW loads AND stores are
+//                   coalesced along W; im2col is formed while staging into LDS.
+//   imggrad_direct  gradient of the first convolution w.r.t. the 3-channel image (GEMM-N = 3 is not
+//                   an MFMA shape) as a direct gather kernel with the filter bank in LDS.
+//   pool / addmask / cosine / std / compose / Adam / sign-step: HBM-bound streaming kernels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "i2v_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static thread_local char g_be_err[256];
+static thread_local bool g_be_has_err = false;
+
+static int hip_fail(hipError_t e, const char* what) {
+    snprintf(g_be_err, sizeof g_be_err, "%s: %s", what, hipGetErrorString(e));
+    g_be_has_err = true;
+    return 1;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x); } while (0)
+#define LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return hip_fail(e_, name); } while (0)
+
+const char* be_name() { return "hip:gfx950"; }
+const char* be_error() { return g_be_has_err ? g_be_err : nullptr; }
+int be_set_device(int device) { HIPCHK(hipSetDevice(device)); return 0; }
+void* be_malloc(size_t bytes) { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; return p; }
+void be_free(void* p) { (void)hipFree(p); }
+int be_h2d(void* dst, const void* src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+int be_d2d_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, i2v_stream_t s) {
+    HIPCHK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return 0;
+}
+int be_memset0(void* p, size_t bytes, i2v_stream_t s) { HIPCHK(hipMemsetAsync(p, 0, bytes, (hipStream_t)s)); return 0; }
+
+void* be_event_create() { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; return (void*)e; }
+void be_event_destroy(void* ev) { (void)hipEventDestroy((hipEvent_t)ev); }
+int be_event_record(void* ev, i2v_stream_t s) { HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)s)); return 0; }
+int be_event_elapsed_ms(void* a, void* b, float* ms) { HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return 0; }
+int be_stream_sync(i2v_stream_t s) { HIPCHK(hipStreamSynchronize((hipStream_t)s)); return 0; }
+
+__constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};
+__constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
+
+// =============================================================================================
+// implicit-GEMM convolution on fp32 MFMA
+// =============================================================================================
+// Block: 256 threads = 4 waves arranged WD x WP; block tile BD (output channels) x BP (pixels),
+// K consumed in chunks of I2V_KC=16 through double-buffered LDS (register-staged prefetch).
+// MFMA operand roles: A = weights (row i = channel), B = activations (column j = pixel):
+//   A: lane l holds Wp[k = kk + (l>>5)][cd = l&31]      B: lane l holds X[k = kk + (l>>5)][px = l&31]
+//   D: lane l, register r  ->  pixel l&31, channel (r&3) + 8*(r>>2) + 4*(l>>5)
+// so every global store instruction writes 32 consecutive pixels of one channel plane.
+template <int BD, int BP, int WD, int WP, bool PW>
+__global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
+    constexpr int KC = I2V_KC;
+    constexpr int TD = BD / WD / 32, TP = BP / WP / 32;
+    __shared__ __attribute__((aligned(16))) float As[2][KC][BD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][KC][BP];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wd = wave / WP, wpx = wave % WP;
+
+    // XCD-aware remap: consecutive logical tiles (same pixel tile, neighbouring channel tiles) share
+    // one XCD's L2 instead of being dealt round-robin over the 8 XCDs (bijective form).
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int cd_tile = lid % n_cd_tiles;
+    const int64_t px0 = (int64_t)(lid / n_cd_tiles) * BP;
+    const int cd0 = cd_tile * BD;
+
+    const int HWg = p.Hg * p.Wg;
+    const int64_t P = (int64_t)p.N * HWg;
+
+    // ---- activation (B) loader state ----
+    constexpr int BROWS = PW ? (1024 / BP) : (256 / BP);     // k-rows covered per pass
+    constexpr int BQ = KC / BROWS;                            // passes per chunk
+    const float* srcn = p.src;
+    int h0 = 0, w0 = 0, brow;
+    bool pvalid;
+    if (PW) {
+        const int px4 = t % (BP / 4);
+        brow = t / (BP / 4);
+        const int64_t pp = px0 + (int64_t)px4 * 4;
+        pvalid = pp < P;
+        const int64_t n = pvalid ? pp / HWg : 0;
+        srcn += n * p.src_nstride + (pp - n * HWg);
+    } else {
+        const int pl = t % BP;
+        brow = t / BP;
+        const int64_t pp = px0 + pl;
+        pvalid = pp < P;
+        const int64_t n = pvalid ? pp / HWg : 0;
+        const int rem = (int)(pp - n * HWg);
+        const int i = rem / p.Wg, j = rem - i * p.Wg;
+        h0 = i * p.sh; w0 = j * p.sw;
+        srcn += n * p.src_nstride + (int64_t)h0 * p.Ws + w0;
+    }
+    // ---- weight (A) loader state ----
+    constexpr int AC4 = BD / 4;                 // float4 columns
+    constexpr int AROWS = 256 / AC4;            // rows per pass (8, 16, 32)
+    constexpr int AQ = (KC + AROWS - 1) / AROWS;
+    const int acol = (t % AC4) * 4, arow = t / AC4;
+    const float* wsrc = p.wp + (int64_t)arow * p.Cdpad + cd0 + acol;
+
+    float4 areg0 = make_float4(0.f, 0.f, 0.f, 0.f), areg1 = areg0;   // AQ <= 2 (named: arrays went to scratch)
+    static_assert(AQ <= 2, "weight staging assumes at most two passes");
+    float breg[PW ? 1 : BQ];
+    float4 breg4[PW ? BQ : 1];
+    const int HWs = p.Hs * p.Ws;
+
+// global -> registers for the K-chunk starting at row k0 (macro, not a lambda: keeps the staging
+// registers out of scratch)
+#define I2V_LOAD_CHUNK(k0_)                                                                              \
+    {                                                                                                    \
+        const int k0 = (k0_);                                                                            \
+        if (AROWS * AQ == KC || arow < KC)                                                               \
+            areg0 = *reinterpret_cast<const float4*>(wsrc + (int64_t)k0 * p.Cdpad);                      \
+        if (AQ == 2) areg1 = *reinterpret_cast<const float4*>(wsrc + (int64_t)(k0 + AROWS) * p.Cdpad);   \
+        if (PW) {                                                                                        \
+            _Pragma("unroll") for (int q = 0; q < BQ; ++q) {                                             \
+                const int k = k0 + brow + q * BROWS;                                                     \
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                              \
+                if (pvalid && k < p.K) v = *reinterpret_cast<const float4*>(srcn + (int64_t)k * HWs);    \
+                breg4[q] = v;                                                                            \
+            }                                                                                            \
+        } else {                                                                                         \
+            _Pragma("unroll") for (int q = 0; q < BQ; ++q) {                                             \
+                const int ku = __builtin_amdgcn_readfirstlane(k0 + brow + q * BROWS);                    \
+                const I2VKEntry e = p.ktab[ku];                                                          \
+                const int hs = h0 + e.dh, ws = w0 + e.dw;                                                \
+                const bool ok = pvalid && e.valid && (unsigned)hs < (unsigned)p.Hs &&                    \
+                                (unsigned)ws < (unsigned)p.Ws;                                           \
+                float v = 0.f;                                                                           \
+                if (ok) v = srcn[e.chan_off + e.dh * p.Ws + e.dw];                                       \
+                breg[q] = v;                                                                             \
+            }                                                                                            \
+        }                                                                                                \
+    }
+#define I2V_STORE_CHUNK(buf_)                                                                            \
+    {                                                                                                    \
+        const int sb = (buf_);                                                                           \
+        if (AROWS * AQ == KC || arow < KC) *reinterpret_cast<float4*>(&As[sb][arow][acol]) = areg0;     \
+        if (AQ == 2) *reinterpret_cast<float4*>(&As[sb][(arow + AROWS) % KC][acol]) = areg1;             \
+        if (PW) {                                                                                        \
+            _Pragma("unroll") for (int q = 0; q < BQ; ++q)                                               \
+                *reinterpret_cast<float4*>(&Bs[sb][brow + q * BROWS][(t % (BP / 4)) * 4]) = breg4[q];    \
+        } else {                                                                                         \
+            _Pragma("unroll") for (int q = 0; q < BQ; ++q) Bs[sb][brow + q * BROWS][t % BP] = breg[q];   \
+        }                                                                                                \
+    }
+
+    f32x16 acc[TD][TP];
+#pragma unroll
+    for (int a = 0; a < TD; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nchunks = p.Kpad / KC;
+    if (nchunks > 0) I2V_LOAD_CHUNK(0);
+    const int l31 = lane & 31, lk = lane >> 5;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        I2V_STORE_CHUNK(buf);
+        __syncthreads();
+        if (c + 1 < nchunks) I2V_LOAD_CHUNK((c + 1) * KC);
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 2) {
+            float a[TD], b[TP];
+#pragma unroll
+            for (int i = 0; i < TD; ++i) a[i] = As[buf][kk + lk][wd * (BD / WD) + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) b[j] = Bs[buf][kk + lk][wpx * (BP / WP) + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TD; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#undef I2V_LOAD_CHUNK
+#undef I2V_STORE_CHUNK
+
+    // ---- epilogue: shift, addends, ReLU, gradient gate, NCHW store ----
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const int64_t pp = px0 + wpx * (BP / WP) + j * 32 + l31;
+        if (pp >= P) continue;
+        const int64_t n = pp / HWg;
+        const int rem = (int)(pp - n * HWg);
+        const int gi = rem / p.Wg, gj = rem - gi * p.Wg;
+        const int oh = gi * p.osh + p.oh0, ow = gj * p.osw + p.ow0;
+        if (oh >= p.Ho || ow >= p.Wo) continue;
+        const int opix = oh * p.Wo + ow;
+        float* dstn = p.dst + n * p.dst_nstride + opix;
+        const float* a0 = nullptr; int a0_plane = HoWo;
+        if (p.add0) {
+            if (p.add0_stride == 1) a0 = p.add0 + n * p.add0_nstride + opix;
+            else {
+                const int s = p.add0_stride, qh = oh / s, qw = ow / s;
+                if (qh * s == oh && qw * s == ow && qh < p.add0_H && qw < p.add0_W) {
+                    a0 = p.add0 + n * p.add0_nstride + qh * p.add0_W + qw;
+                    a0_plane = p.add0_H * p.add0_W;
+                }
+            }
+        }
+        const float* a1 = p.add1 ? p.add1 + n * p.add1_nstride + opix : nullptr;
+        const float* mk = p.mask ? p.mask + n * p.mask_nstride + opix : nullptr;
+#pragma unroll
+        for (int i = 0; i < TD; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cd = cd0 + wd * (BD / WD) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (cd >= p.Cd) continue;
+                float v = acc[i][j][r];
+                if (p.shift) v += p.shift[cd];
+                if (a0) v += a0[(int64_t)cd * a0_plane];
+                if (a1) v += a1[(int64_t)cd * HoWo];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (mk && !(mk[(int64_t)cd * HoWo] > 0.f)) v = 0.f;
+                dstn[(int64_t)cd * HoWo] = v;
+            }
+        }
+    }
+}
+
+template <int BD, int BP, int WD, int WP>
+static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
+    const int64_t P = (int64_t)p.N * p.Hg * p.Wg;
+    const int n_cd = (p.Cd + BD - 1) / BD;
+    const int64_t n_px = (P + BP - 1) / BP;
+    const int64_t grid = n_px * n_cd;
+    if (grid <= 0) return 0;
+    if (grid > 0x7fffffff) { snprintf(g_be_err, sizeof g_be_err, "conv grid too large"); g_be_has_err = true; return 1; }
+    if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+    else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, false>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+    LAUNCH_CHECK("conv_igemm");
+    return 0;
+}
+
+int k_conv(const I2VConvParams& p, i2v_stream_t s) {
+    hipStream_t st = (hipStream_t)s;
+    if (p.Cd > 64) return launch_conv_cfg<128, 128, 2, 2>(p, st);
+    if (p.Cd > 32) return launch_conv_cfg<64, 128, 2, 2>(p, st);
+    return launch_conv_cfg<32, 256, 1, 4>(p, st);
+}
+
+// =============================================================================================
+// gradient of the first convolution w.r.t. the image (direct gather, filters in LDS)
+// =============================================================================================
+#define IMG_LDS_FLOATS 12288
+__global__ void __launch_bounds__(256) imggrad_direct(const I2VImgGradParams p, const int co_chunk) {
+    __shared__ float wl[IMG_LDS_FLOATS];
+    const int per_co = p.Cin * p.kh * p.kw;
+    const int tiles_w = (p.W + 15) / 16;
+    const int tile = blockIdx.x, n = blockIdx.y;
+    const int h = (tile / tiles_w) * 16 + (threadIdx.x >> 4), w = (tile % tiles_w) * 16 + (threadIdx.x & 15);
+    const bool inside = h < p.H && w < p.W;
+    float acc[I2V_MAX_IMG_C] = {0.f, 0.f, 0.f, 0.f};
+    // taps r with (h + pad - r) % stride == 0: r = r0, r0 + stride, ...
+    const int r0 = (h + p.pad) % p.stride, s0 = (w + p.pad) % p.stride;
+    const float* dzn = p.dz + (int64_t)n * p.dz_nstride;
+    for (int cb = 0; cb < p.Cout; cb += co_chunk) {
+        const int cn = min(co_chunk, p.Cout - cb);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cn * per_co; i += 256) wl[i] = p.w[(int64_t)cb * per_co + i];
+        __syncthreads();
+        if (!inside) continue;
+        for (int co = 0; co < cn; ++co) {
+            const float* dzc = dzn + (int64_t)(cb + co) * p.Ho * p.Wo;
+            const float* wc = wl + co * per_co;
+            for (int r = r0; r < p.kh; r += p.stride) {
+                const int th = h + p.pad - r;
+                if (th < 0) break;
+                const int ho = th / p.stride;
+                if (ho >= p.Ho) continue;
+                for (int s = s0; s < p.kw; s += p.stride) {
+                    const int tw = w + p.pad - s;
+                    if (tw < 0) break;
+                    const int wo = tw / p.stride;
+                    if (wo >= p.Wo) continue;
+                    const float g = dzc[ho * p.Wo + wo];
+#pragma unroll
+                    for (int ci = 0; ci < I2V_MAX_IMG_C; ++ci)
+                        if (ci < p.Cin) acc[ci] = fmaf(wc[(ci * p.kh + r) * p.kw + s], g, acc[ci]);
+                }
+            }
+        }
+    }
+    if (!inside) return;
+#pragma unroll
+    for (int ci = 0; ci < I2V_MAX_IMG_C; ++ci)
+        if (ci < p.Cin) {
+            float* o = p.gx + (((int64_t)n * p.Cin + ci) * p.H + h) * p.W + w;
+            *o = p.accumulate ? *o + acc[ci] : acc[ci];
+        }
+}
+
+int k_imggrad(const I2VImgGradParams& p, i2v_stream_t s) {
+    const int per_co = p.Cin * p.kh * p.kw;
+    int co_chunk = IMG_LDS_FLOATS / per_co;
+    if (co_chunk < 1) { snprintf(g_be_err, sizeof g_be_err, "first-layer filter too large for LDS"); g_be_has_err = true; return 1; }
+    if (co_chunk > p.Cout) co_chunk = p.Cout;
+    dim3 grid(((p.H + 15) / 16) * ((p.W + 15) / 16), p.N);
+    hipLaunchKernelGGL(imggrad_direct, grid, dim3(256), 0, (hipStream_t)s, p, co_chunk);
+    LAUNCH_CHECK("imggrad_direct");
+    return 0;
+}
+
+// =============================================================================================
+// max pooling (arg-max recomputed in backward: first maximum in scan order, as ATen)
+// =============================================================================================
+__device__ __forceinline__ int pool_argmax(const float* pl, int Hs, int Ws, int ho, int wo, int k, int st, int pad) {
+    int best = -1; float bv = 0.f;
+    for (int r = 0; r < k; ++r) {
+        const int h = ho * st - pad + r; if (h < 0 || h >= Hs) continue;
+        for (int s = 0; s < k; ++s) {
+            const int w = wo * st - pad + s; if (w < 0 || w >= Ws) continue;
+            const float v = pl[h * Ws + w];
+            if (best < 0 || v > bv || v != v) { bv = v; best = h * Ws + w; }
+        }
+    }
+    return best;
+}
+
+__global__ void pool_fwd_kernel(const I2VPoolParams p) {
+    const int64_t total = (int64_t)p.N * p.C * p.Ho * p.Wo;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int wo = idx % p.Wo; int64_t r = idx / p.Wo;
+        const int ho = r % p.Ho; r /= p.Ho;
+        const int c = r % p.C; const int64_t n = r / p.C;
+        const float* pl = p.x + n * p.x_nstride + (int64_t)c * p.Hs * p.Ws;
+        p.y[n * p.y_nstride + ((int64_t)c * p.Ho + ho) * p.Wo + wo] = pl[pool_argmax(pl, p.Hs, p.Ws, ho, wo, p.k, p.stride, p.pad)];
+    }
+}
+
+__global__ void pool_bwd_kernel(const I2VPoolParams p) {
+    const int64_t total = (int64_t)p.N * p.C * p.Hs * p.Ws;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int w = idx % p.Ws; int64_t r = idx / p.Ws;
+        const int h = r % p.Hs; r /= p.Hs;
+        const int c = r % p.C; const int64_t n = r / p.C;
+        const float* pl = p.x + n * p.x_nstride + (int64_t)c * p.Hs * p.Ws;
+        const float* gy = p.y + n * p.y_nstride + (int64_t)c * p.Ho * p.Wo;
+        const int me = h * p.Ws + w;
+        float g = 0.f;
+        if (!p.mask_relu || pl[me] > 0.f) {
+            // windows containing (h,w): ho*st - pad <= h <= ho*st - pad + k - 1
+            int ho_lo = h + p.pad - p.k + 1; ho_lo = ho_lo <= 0 ? 0 : (ho_lo + p.stride - 1) / p.stride;
+            int ho_hi = min((h + p.pad) / p.stride, p.Ho - 1);
+            int wo_lo = w + p.pad - p.k + 1; wo_lo = wo_lo <= 0 ? 0 : (wo_lo + p.stride - 1) / p.stride;
+            int wo_hi = min((w + p.pad) / p.stride, p.Wo - 1);
+            for (int ho = ho_lo; ho <= ho_hi; ++ho)
+                for (int wo = wo_lo; wo <= wo_hi; ++wo)
+                    if (pool_argmax(pl, p.Hs, p.Ws, ho, wo, p.k, p.stride, p.pad) == me) g += gy[ho * p.Wo + wo];
+        }
+        p.gx[n * p.gx_nstride + (int64_t)c * p.Hs * p.Ws + me] = g;
+    }
+}
+
+static unsigned stream_grid(int64_t total, int per_block) {
+    int64_t b = (total + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > 256 * 16) b = 256 * 16;
+    return (unsigned)b;
+}
+
+int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t s) {
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(stream_grid((int64_t)p.N * p.C * p.Ho * p.Wo, 256)), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("pool_fwd"); return 0;
+}
+int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s) {
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(stream_grid((int64_t)p.N * p.C * p.Hs * p.Ws, 256)), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("pool_bwd"); return 0;
+}
+
+// =============================================================================================
+// out = (a0 + a1 + a2) gated by mask > 0
+// =============================================================================================
+__global__ void addmask_kernel(const I2VAddMaskParams p) {
+    const int64_t plane = (int64_t)p.C * p.HW, total = plane * p.N;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = idx / plane, i = idx - n * plane;
+        float v = 0.f;
+        if (p.a[0]) v += p.a[0][n * p.a_nstride[0] + i];
+        if (p.a[1]) v += p.a[1][n * p.a_nstride[1] + i];
+        if (p.a[2]) v += p.a[2][n * p.a_nstride[2] + i];
+        if (p.mask && !(p.mask[n * p.mask_nstride + i] > 0.f)) v = 0.f;
+        p.out[n * p.out_nstride + i] = v;
+    }
+}
+int k_addmask(const I2VAddMaskParams& p, i2v_stream_t s) {
+    hipLaunchKernelGGL(addmask_kernel, dim3(stream_grid((int64_t)p.N * p.C * p.HW, 256)), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("addmask"); return 0;
+}
+
+// =============================================================================================
+// cosine similarity forward + gradient (two launches, deterministic: no atomics)
+// =============================================================================================
+int cos_nblk(int64_t D) { int64_t b = D / 4096; if (b < 1) b = 1; if (b > 64) b = 64; return (int)b; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// grid (nblk, N): partial[n][blk] = (dot, aa, bb) over this block's slice of the feature
+__global__ void __launch_bounds__(256) cos_reduce_kernel(const I2VCosParams p) {
+    const int blk = blockIdx.x, n = blockIdx.y;
+    const int64_t chunk = ((p.D + p.nblk - 1) / p.nblk + 3) & ~(int64_t)3;
+    const int64_t lo = blk * chunk, hi = (lo + chunk < p.D) ? lo + chunk : p.D;
+    const float* a = p.a + (int64_t)n * p.a_nstride;
+    const float* b = p.b + (int64_t)n * p.b_nstride;
+    float dot = 0.f, aa = 0.f, bb = 0.f;
+    const bool vec = ((p.a_nstride | p.b_nstride) & 3) == 0 && (((uintptr_t)p.a | (uintptr_t)p.b) & 15) == 0;
+    if (vec) {
+        const int64_t hi4 = lo + ((hi - lo) & ~(int64_t)3);
+        for (int64_t i = lo + threadIdx.x * 4; i < hi4; i += 1024) {
+            const float4 x = *reinterpret_cast<const float4*>(a + i), y = *reinterpret_cast<const float4*>(b + i);
+            dot += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+            aa += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+            bb += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+        }
+        for (int64_t i = hi4 + threadIdx.x; i < hi; i += 256) { dot += a[i] * b[i]; aa += a[i] * a[i]; bb += b[i] * b[i]; }
+    } else {
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) { dot += a[i] * b[i]; aa += a[i] * a[i]; bb += b[i] * b[i]; }
+    }
+    __shared__ float red[3][4];
+    dot = wave_sum(dot); aa = wave_sum(aa); bb = wave_sum(bb);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = dot; red[1][threadIdx.x >> 6] = aa; red[2][threadIdx.x >> 6] = bb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = p.partial + ((int64_t)n * p.nblk + blk) * 4;
+        o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        o[2] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    }
+}
+
+// grid (gblk, N): finish the reduction (double), write cos, then the gradient elementwise
+__global__ void __launch_bounds__(256) cos_grad_kernel(const I2VCosParams p) {
+    const int n = blockIdx.y;
+    __shared__ double fin[3];
+    if (threadIdx.x < 64) {
+        double d = 0, x = 0, y = 0;
+        if ((int)threadIdx.x < p.nblk) {
+            const float* o = p.partial + ((int64_t)n * p.nblk + threadIdx.x) * 4;
+            d = o[0]; x = o[1]; y = o[2];
+        }
+        d = wave_sum_d(d); x = wave_sum_d(x); y = wave_sum_d(y);
+        if (threadIdx.x == 0) { fin[0] = d; fin[1] = x; fin[2] = y; }
+    }
+    __syncthreads();
+    const double n1 = fmax(sqrt(fin[1]), 1e-8), n2 = fmax(sqrt(fin[2]), 1e-8);
+    const double cs = fin[0] / (n1 * n2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.cos_out[n] = (float)cs;
+    double coef = (double)p.coef_host;
+    if (p.coef_dev) coef *= (double)p.coef_dev[p.coef_index];
+    const double c1 = coef / (n1 * n2), c2 = coef * cs / (n1 * n1);
+    const float* a = p.a + (int64_t)n * p.a_nstride;
+    const float* b = p.b + (int64_t)n * p.b_nstride;
+    float* g = p.grad + (int64_t)n * p.grad_nstride;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < p.D; i += (int64_t)gridDim.x * 256) {
+        const float av = a[i];
+        float v = (float)(c1 * (double)b[i] - c2 * (double)av);
+        if (p.mask_relu && !(av > 0.f)) v = 0.f;
+        g[i] = p.accumulate ? g[i] + v : v;
+    }
+}
+
+int k_cos(const I2VCosParams& p, i2v_stream_t s) {
+    hipLaunchKernelGGL(cos_reduce_kernel, dim3(p.nblk, p.N), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("cos_reduce");
+    int gblk = (int)((p.D + 2047) / 2048); if (gblk > 64) gblk = 64;
+    hipLaunchKernelGGL(cos_grad_kernel, dim3(gblk, p.N), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("cos_grad");
+    return 0;
+}
+
+// =============================================================================================
+// Dispersion-Reduction loss: unbiased std over the whole tensor
+// =============================================================================================
+__global__ void __launch_bounds__(256) std_reduce_kernel(const I2VStdParams p) {
+    const int blk = blockIdx.x, n = blockIdx.y;
+    const int64_t chunk = (p.D + p.nblk - 1) / p.nblk;
+    const int64_t lo = blk * chunk, hi = (lo + chunk < p.D) ? lo + chunk : p.D;
+    const float* a = p.a + (int64_t)n * p.a_nstride;
+    double s = 0, ss = 0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) { const double v = a[i]; s += v; ss += v * v; }
+    __shared__ double red[2][4];
+    s = wave_sum_d(s); ss = wave_sum_d(ss);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* o = p.partial + ((int64_t)n * p.nblk + blk) * 2;
+        o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+__global__ void __launch_bounds__(256) std_grad_kernel(const I2VStdParams p) {
+    const int n = blockIdx.y;
+    __shared__ double red[2][4];
+    double s = 0, ss = 0;
+    const int np = p.N * p.nblk;
+    for (int i = threadIdx.x; i < np; i += 256) { s += p.partial[2 * i]; ss += p.partial[2 * i + 1]; }
+    s = wave_sum_d(s); ss = wave_sum_d(ss);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; }
+    __syncthreads();
+    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double cnt = (double)p.N * (double)p.D;
+    const double mu = s / cnt;
+    const double var = fmax((ss - cnt * mu * mu) / (cnt - 1.0), 0.0);
+    const double sd = sqrt(var);
+    if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) p.std_out[0] = (float)sd;
+    const double inv = 1.0 / ((cnt - 1.0) * sd);
+    const float* a = p.a + (int64_t)n * p.a_nstride;
+    float* g = p.grad + (int64_t)n * p.grad_nstride;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < p.D; i += (int64_t)gridDim.x * 256) {
+        const float av = a[i];
+        float v = (float)(((double)av - mu) * inv);
+        if (p.mask_relu && !(av > 0.f)) v = 0.f;
+        g[i] = p.accumulate ? g[i] + v : v;
+    }
+}
+
+int k_std(const I2VStdParams& p, i2v_stream_t s) {
+    hipLaunchKernelGGL(std_reduce_kernel, dim3(p.nblk, p.N), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("std_reduce");
+    int gblk = (int)((p.D + 2047) / 2048); if (gblk > 64) gblk = 64;
+    hipLaunchKernelGGL(std_grad_kernel, dim3(gblk, p.N), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("std_grad");
+    return 0;
+}
+
+// =============================================================================================
+// frame flatten + un-normalise, compose, Adam (+ compose backward), sign steps, AENS weights
+// =============================================================================================
+__global__ void frames_from_video_kernel(const float* __restrict__ video, float* __restrict__ x, float* __restrict__ u,
+                                         int b, int f, int hw) {
+    const int64_t total = (int64_t)b * 3 * f * hw;
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        // o indexes the FRAME layout (b, f, 3, hw)
+        const int i = o % hw; int64_t r = o / hw;
+        const int c = r % 3; r /= 3;
+        const int fi = r % f; const int64_t bi = r / f;
+        const float v = video[((bi * 3 + c) * f + fi) * hw + i];
+        x[o] = v;
+        u[o] = __fadd_rn(__fmul_rn(v, c_std[c]), c_mean[c]);       // mul_ then add_: two roundings
+    }
+}
+
+__global__ void compose_kernel(const float* __restrict__ u, const float* __restrict__ d, float* __restrict__ x,
+                               int b, int f, int hw, float eps, int video_layout) {
+    const int64_t total = (int64_t)b * 3 * f * hw;
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int i = o % hw; int64_t r = o / hw;
+        const int c = r % 3; r /= 3;
+        const int fi = r % f; const int64_t bi = r / f;
+        const float dc = fminf(fmaxf(d[o], -eps), eps);
+        const float s = u[o] + dc;
+        const float xi = fminf(fmaxf(s, 0.f), 1.f);
+        const float v = __fdiv_rn(__fsub_rn(xi, c_mean[c]), c_std[c]);
+        const int64_t oo = video_layout ? ((bi * 3 + c) * f + fi) * hw + i : o;
+        x[oo] = v;
+    }
+}
+
+__global__ void adam_kernel(float* __restrict__ delta, float* __restrict__ m, float* __restrict__ v,
+                            const float* __restrict__ gx, const float* __restrict__ u, int64_t n, int hw, float eps,
+                            float step_size, float bc2_sqrt, float beta1, float beta2, float adam_eps) {
+    const float w1 = 1.f - beta1, w2 = 1.f - beta2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / hw) % 3);
+        const float d = delta[i];
+        const float dc = fminf(fmaxf(d, -eps), eps);
+        const float s = u[i] + dc;
+        const bool pass = d >= -eps && d <= eps && s >= 0.f && s <= 1.f;     // inclusive clamp masks
+        const float g = pass ? __fdiv_rn(gx[i], c_std[c]) : 0.f;
+        const float mm = fmaf(w1, __fsub_rn(g, m[i]), m[i]);                  // lerp_(g, 1-b1)
+        const float vv = __fadd_rn(__fmul_rn(v[i], beta2), __fmul_rn(__fmul_rn(w2, g), g));   // mul_, addcmul_
+        const float den = __fadd_rn(__fdiv_rn(__fsqrt_rn(vv), bc2_sqrt), adam_eps);
+        delta[i] = __fadd_rn(d, __fmul_rn(-step_size, __fdiv_rn(mm, den)));   // addcdiv_
+        m[i] = mm; v[i] = vv;
+    }
+}
+
+__global__ void sign_bim_kernel(float* __restrict__ adv, const float* __restrict__ u, const float* __restrict__ grad,
+                                int64_t n, int64_t cs, float step, float eps) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / cs) % 3);
+        float a = __fadd_rn(__fmul_rn(adv[i], c_std[c]), c_mean[c]);
+        const float g = grad[i];
+        const float sg = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
+        a = __fadd_rn(a, __fmul_rn(step, sg));
+        const float d = fminf(fmaxf(__fsub_rn(a, u[i]), -eps), eps);
+        const float r = fminf(fmaxf(__fadd_rn(u[i], d), 0.f), 1.f);
+        adv[i] = __fdiv_rn(__fsub_rn(r, c_mean[c]), c_std[c]);
+    }
+}
+
+__global__ void sign_delta_kernel(float* __restrict__ delta, const float* __restrict__ grad, int64_t n, float step) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = grad[i];
+        delta[i] = __fsub_rn(delta[i], __fmul_rn(step, g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f)));
+    }
+}
+
+__global__ void aens_coeffs_kernel(const float* prev, float* coeffs, float momentum, int L) {
+    // one wave: softmax(softmax(prev) + momentum*coeffs)
+    const int l = threadIdx.x;
+    float pv = l < L ? prev[l] : -INFINITY;
+    float mx = pv;
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float e = l < L ? expf(pv - mx) : 0.f;
+    float sum = e;
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    float b = l < L ? e / sum + momentum * coeffs[l] : -INFINITY;
+    mx = b;
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    e = l < L ? expf(b - mx) : 0.f;
+    sum = e;
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (l < L) coeffs[l] = e / sum;
+}
+
+__global__ void aens_reduce_kernel(const float* cosv, const float* coeffs, int L, int frames, float* feat_sum, float* weighted) {
+    const int l = blockIdx.x;
+    double s = 0;
+    for (int n = threadIdx.x; n < frames; n += 64) s += cosv[(int64_t)l * frames + n];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) { feat_sum[l] = (float)s; weighted[l] = coeffs[l] * (float)s; }
+}
+
+int k_frames_from_video(const float* video, float* x, float* u, int b, int f, int h, int w, i2v_stream_t s) {
+    const int64_t total = (int64_t)b * 3 * f * h * w;
+    hipLaunchKernelGGL(frames_from_video_kernel, dim3(stream_grid(total, 1024)), dim3(256), 0, (hipStream_t)s, video, x, u, b, f, h * w);
+    LAUNCH_CHECK("frames_from_video"); return 0;
+}
+int k_compose(const float* u, const float* delta, float* x, int b, int f, int h, int w, float eps, int video_layout, i2v_stream_t s) {
+    const int64_t total = (int64_t)b * 3 * f * h * w;
+    hipLaunchKernelGGL(compose_kernel, dim3(stream_grid(total, 1024)), dim3(256), 0, (hipStream_t)s, u, delta, x, b, f, h * w, eps, video_layout);
+    LAUNCH_CHECK("compose"); return 0;
+}
+int k_adam(float* delta, float* m, float* v, const float* gx, const float* u, int64_t n, int hw, float eps,
+           float step_size, float bc2_sqrt, float beta1, float beta2, float adam_eps, i2v_stream_t s) {
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n, 1024)), dim3(256), 0, (hipStream_t)s, delta, m, v, gx, u, n, hw, eps,
+                       step_size, bc2_sqrt, beta1, beta2, adam_eps);
+    LAUNCH_CHECK("adam"); return 0;
+}
+int k_sign_bim(float* adv, const float* u, const float* grad, int64_t n, int64_t cs, float step, float eps, i2v_stream_t s) {
+    hipLaunchKernelGGL(sign_bim_kernel, dim3(stream_grid(n, 1024)), dim3(256), 0, (hipStream_t)s, adv, u, grad, n, cs, step, eps);
+    LAUNCH_CHECK("sign_bim"); return 0;
+}
+int k_sign_delta(float* delta, const float* grad, int64_t n, float step, i2v_stream_t s) {
+    hipLaunchKernelGGL(sign_delta_kernel, dim3(stream_grid(n, 1024)), dim3(256), 0, (hipStream_t)s, delta, grad, n, step);
+    LAUNCH_CHECK("sign_delta"); return 0;
+}
+int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t s) {
+    hipLaunchKernelGGL(aens_coeffs_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, prev, coeffs, momentum, L);
+    LAUNCH_CHECK("aens_coeffs"); return 0;
+}
+int k_aens_reduce(const float* cosv, const float* coeffs, int L, int frames, float* feat_sum, float* weighted, i2v_stream_t s) {
+    hipLaunchKernelGGL(aens_reduce_kernel, dim3(L), dim3(64), 0, (hipStream_t)s, cosv, coeffs, L, frames, feat_sum, weighted);
+    LAUNCH_CHECK("aens_reduce"); return 0;
+}

@@ -51,6 +51,18 @@ class Engine:
     def build_net(self, graph: Graph, state_dict, hook_tensors: Sequence[int], max_frames: int) -> "Net":
         return Net(self, graph, state_dict, list(hook_tensors), max_frames)
 
+    # ---- measurement ----
+    KINDS = ("conv_igemm", "imggrad_direct", "pool_fwd", "pool_bwd", "addmask")
+
+    def timing_enable(self, on=True):
+        _lib.check(self.capi, self.capi.i2v_timing_enable(self.h, 1 if on else 0))
+
+    def timing_collect(self):
+        n = len(self.KINDS)
+        ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
+        _lib.check(self.capi, self.capi.i2v_timing_collect(self.h, ms, fl, cnt, n))
+        return {k: dict(ms=ms[i], flops=fl[i], launches=cnt[i]) for i, k in enumerate(self.KINDS)}
+
     # ---- loop kernels (thin, typed wrappers) ----
     def frames_from_video(self, video, x, u):
         b, c, f, h, w = video.shape

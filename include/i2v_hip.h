@@ -81,6 +81,16 @@ int i2v_net_backward(i2v_handle h, int net, float* gx, int accumulate, void* str
 int i2v_net_read_tensor(i2v_handle h, int net, int tensor, int which, float* out, int frames,
                         void* stream);
 
+/* ---- measurement (bench.py `roofline`) ---------------------------------------------------
+ * When enabled, every backbone launch is bracketed by a HIP event pair on its own stream;
+ * `i2v_timing_collect` synchronises that stream and returns, per kernel kind (0 conv_igemm,
+ * 1 first-layer image gradient, 2 pool fwd, 3 pool bwd, 4 addmask), the summed device time,
+ * the summed ALGORITHMIC flops (2*pixels*Cout*Cin*kh*kw per convolution launch) and the launch
+ * count since the last collect. */
+int i2v_timing_enable(i2v_handle h, int enable);
+int i2v_timing_collect(i2v_handle h, double* ms_by_kind, double* flops_by_kind,
+                       int64_t* launches_by_kind, int n_kinds);
+
 /* ---- loop kernels ------------------------------------------------------------------------ */
 /* videos (b,3,f,h,w) normalised -> frames x:(b*f,3,h,w), frame n = b_idx*f + f_idx
  * (image_attacks.py:300-301) and u = x*std + mean (`_transform_video(...,'back')`, :62,308). */

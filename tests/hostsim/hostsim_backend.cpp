@@ -28,6 +28,11 @@ int be_d2d_2d(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t row
 }
 int be_memset0(void* p, size_t b, i2v_stream_t) { memset(p, 0, b); return 0; }
 const char* be_error() { return nullptr; }
+void* be_event_create() { return malloc(8); }
+void be_event_destroy(void* e) { free(e); }
+int be_event_record(void*, i2v_stream_t) { return 0; }
+int be_event_elapsed_ms(void*, void*, float* ms) { *ms = 0.f; return 0; }
+int be_stream_sync(i2v_stream_t) { return 0; }
 int cos_nblk(int64_t D) { return (int)std::min<int64_t>(64, std::max<int64_t>(1, D / 4096)); }
 
 int k_conv(const I2VConvParams& p, i2v_stream_t) {

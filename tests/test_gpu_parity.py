@@ -1,0 +1,292 @@
+"""GPU (-m gpu): the hand-written HIP path of libi2v_hip.so, called through the C ABI, against
+the CPU oracle and the golden vectors captured from the reference.
+
+Tolerances (fp32 path; north_star: atol 1e-4 on teacher-forced tensors):
+  * elementwise kernels: bit-exact or <= 2 ulp (stated per test);
+  * backbone activations: rtol 1e-4 / atol 1e-5 against the oracle run in float64;
+  * input gradients for well-conditioned hook gradients: max-abs error <= 1e-4 * max|g|;
+  * attack loops: cost trajectory rtol 2e-4 per step, L_inf/box invariants exact, statistics.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from i2v_amd import attacks, graphs, weights  # noqa: E402
+from oracle import restate  # noqa: E402
+from tests import golden_util as gu  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    e = attacks.get_engine("cuda:0")
+    assert e.capi.i2v_backend() == b"hip:gfx950"
+    return e
+
+
+def dev(t):
+    return t.to("cuda:0").contiguous()
+
+
+# ------------------------------------------------------------------ elementwise kernels
+def test_frames_compose_bit_exact(eng):
+    gen = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 256, (2, 3, 5, 24, 20), generator=gen, dtype=torch.uint8)
+    vid = gu.videos_of({"clip_u8": u8.numpy()})
+    x = torch.empty(10, 3, 24, 20, device="cuda:0")
+    u = torch.empty_like(x)
+    eng.frames_from_video(dev(vid), x, u)
+    xr = restate.flatten_frames(vid).contiguous()
+    ur = restate.unnormalise(xr)
+    assert torch.equal(x.cpu(), xr) and torch.equal(u.cpu(), ur)
+    delta = (torch.rand(10, 3, 24, 20, generator=gen) - 0.5) * 0.2        # beyond +-eps too
+    delta[0, 0, 0, :4] = torch.tensor([16 / 255, -16 / 255, 0.0, 1.0])     # exact clamp edges
+    out = torch.empty_like(x)
+    eng.compose(u, dev(delta), out, 2, 5, 16 / 255)
+    ref, _ = restate.compose(ur, delta, 16 / 255)
+    assert torch.equal(out.cpu(), ref)
+    outv = torch.empty(2, 3, 5, 24, 20, device="cuda:0")
+    eng.compose(u, dev(delta), outv, 2, 5, 16 / 255, video_layout=True)
+    assert torch.equal(outv.cpu(), restate.unflatten_frames(ref, 2, 5).contiguous())
+
+
+def test_adam_step_matches_torch_optim(eng):
+    """Compose-backward + Adam against restate (itself bit-equal to torch.optim.Adam)."""
+    gen = torch.Generator().manual_seed(6)
+    N, H, W = 4, 16, 12
+    u = torch.randint(0, 256, (N, 3, H, W), generator=gen).float() / 255   # exact 0.0 / 1.0 occur
+    delta = torch.full((N, 3, H, W), 0.01 / 255)
+    delta.view(-1)[::7] = 16 / 255           # exactly on the clamp edge -> gradient passes (inclusive)
+    delta.view(-1)[3::11] = 0.07             # outside -> gradient gated off
+    st = restate.AdamState(delta, 0.005)
+    d_ref = delta.clone()
+    d, m, v = dev(delta), torch.zeros(N, 3, H, W, device="cuda:0"), torch.zeros(N, 3, H, W, device="cuda:0")
+    ud = dev(u)
+    for t in range(1, 5):
+        gx = torch.randn(N, 3, H, W, generator=gen) * 1e-5
+        _, mask = restate.compose(u, d_ref, 16 / 255)
+        st.step(d_ref, restate.compose_backward(gx, mask))
+        eng.adam_step(d, m, v, dev(gx), ud, 16 / 255, 0.005, t)
+        # same op order; the only freedom is fma contraction inside ATen's vectorised CPU kernels
+        assert torch.allclose(d.cpu(), d_ref, rtol=0, atol=2e-9 + 3e-7 * 0.005)
+        assert torch.allclose(m.cpu(), st.m, rtol=1e-6, atol=1e-12)
+        assert torch.allclose(v.cpu(), st.v, rtol=1e-6, atol=1e-18)
+
+
+def test_sign_step_golden_bit_exact(eng):
+    """BIM update (base_attacks.py:289-293) replayed on the gradients the reference saw."""
+    fx = gu.load("sign_step")
+    vid = gu.videos_of(fx)
+    mean = torch.tensor(gu.MEAN).view(1, 3, 1, 1, 1)
+    std = torch.tensor(gu.STD).view(1, 3, 1, 1, 1)
+    u = dev(vid.clone().mul_(std).add_(mean))
+    adv = dev(vid.clone())
+    eps, steps = float(fx["eps"]), int(fx["steps"])
+    cs = vid.shape[2] * vid.shape[3] * vid.shape[4]
+    for g in torch.from_numpy(fx["BIM_grads"]):
+        eng.sign_step(adv, u, dev(g), cs, eps / steps, eps)
+    assert torch.equal(adv.cpu(), torch.from_numpy(fx["BIM_adv"]))
+    d = torch.full((5, 7), 0.01, device="cuda:0")
+    g = dev(torch.tensor([[-1.0, 0.0, 2.0, -0.0, 1e-30, -3.0, 5.0]]).repeat(5, 1))
+    eng.sign_step_delta(d, g, 0.005)
+    assert torch.equal(d.cpu(), restate.sign_step_ilaf(torch.full((5, 7), 0.01), g.cpu(), 0.005))
+
+
+def test_aens_coeffs(eng):
+    prev = torch.tensor([3.9, 4.0, 3.5, 3.99, 2.0, 3.0])
+    c = torch.tensor([0.2, 0.1, 0.3, 0.15, 0.05, 0.2])
+    cd = dev(c)
+    eng.aens_coeffs(dev(prev), cd, 0.7)
+    assert torch.allclose(cd.cpu(), restate.aens_coeffs(prev, c, 0.7), rtol=1e-6)
+
+
+@pytest.mark.parametrize("D,N,stride_pad", [(200704, 3, 0), (5000, 4, 24), (37, 2, 3)])
+def test_cossim_fwd_bwd(eng, D, N, stride_pad):
+    gen = torch.Generator().manual_seed(D)
+    b = torch.relu(torch.randn(N, D, generator=gen))
+    a = torch.relu(b + 0.05 * torch.randn(N, D, generator=gen))
+    stride = D + stride_pad
+    abuf = torch.zeros(N, stride)
+    abuf[:, :D] = a
+    ad, bd = dev(abuf), dev(b)
+    cos = torch.empty(N, device="cuda:0")
+    grad = torch.full((N, stride), 7.0, device="cuda:0")
+    scratch = torch.empty(eng.capi.i2v_cossim_scratch_bytes(D, N), dtype=torch.uint8, device="cuda:0")
+    from i2v_amd import lib
+    P = ctypes.c_void_p
+    lib.check(eng.capi, eng.capi.i2v_cossim_fwd_bwd_f32(P(ad.data_ptr()), stride, P(bd.data_ptr()), D, D, N, P(0), 0, 0.5,
+                                                        1, 0, P(cos.data_ptr()), P(grad.data_ptr()), stride,
+                                                        P(scratch.data_ptr()), eng.stream()))
+    cr, gr = restate.cosine_fwd_bwd(a.double(), b.double())
+    gr = 0.5 * gr * (a > 0)
+    assert torch.allclose(cos.cpu().double(), cr, atol=2e-7)
+    got = grad.cpu()[:, :D].double()
+    assert (got - gr).abs().max() <= 2e-6 * gr.abs().max()
+    assert torch.equal(grad.cpu()[:, D:], torch.full((N, stride_pad), 7.0))     # padding untouched
+
+
+# ------------------------------------------------------------------ backbone forward / backward
+CASES = [("resnet", [3], 64), ("resnet", [2, 3], 64), ("resnet", [1], 32), ("vgg", [2], 32), ("vgg", [3], 32),
+         ("alexnet", [3], 64), ("alexnet", [2, 4], 64), ("squeezenet", [2], 64), ("squeezenet", [2, 3], 64),
+         ("squeezenet", [4], 64), ("resnet", [4], 96)]
+
+
+_hip = None
+
+
+def _memcpy_d2d(dst, src, nbytes):
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert _hip.hipMemcpy(dst, src, nbytes, 3) == 0          # hipMemcpyDeviceToDevice
+
+
+def write_hook_grads(net, feats, hg, N):
+    """Put d(cost)/d(hook) where the library expects it, gated by the hook's own ReLU (what
+    i2v_cossim_fwd_bwd_f32 does on the device)."""
+    torch.cuda.synchronize()
+    for i, hi in enumerate(net.hooks):
+        gate = (feats[i] > 0).to(hg[i].dtype) if hi.post_relu else torch.ones_like(feats[i])
+        flat = dev((hg[i] * gate).float().reshape(N, -1))
+        for n in range(N):
+            _memcpy_d2d(hi.grad + 4 * n * hi.grad_stride, flat[n].data_ptr(), 4 * hi.D)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("model,depths,hw", CASES)
+def test_net_forward_backward_match_oracle(eng, model, depths, hw):
+    g = graphs.build_tiny(model, (hw, hw))
+    sd = weights.synthetic_state_dict(g, 3)
+    hooks = [g.hooks[d] for d in depths]
+    N = 5
+    net = eng.build_net(g, sd, hooks, N)
+    onet = restate.OracleNet(g, sd, hooks, dtype=torch.float64)
+    torch.manual_seed(hw + len(depths))
+    x = torch.randn(N, 3, hw, hw)
+    feats = onet.forward(x.double())
+    net.forward(dev(x))
+    for nd in net.graph.nodes:
+        got = net.read_tensor(nd.dst, N).cpu().double()
+        assert torch.allclose(got, onet.tensor(nd.dst), rtol=1e-4, atol=1e-5), nd
+    hg = [torch.randn_like(f) for f in feats]
+    write_hook_grads(net, feats, hg, N)
+    gx = torch.empty(N, 3, hw, hw, device="cuda:0")
+    net.backward(gx)
+    ref = onet.backward(hg)
+    err = (gx.cpu().double() - ref).abs().max() / ref.abs().max()
+    assert err < 1e-4, err
+    gx2 = gx.clone()
+    net.backward(gx2, accumulate=True)
+    assert torch.allclose(gx2, 2 * gx, rtol=1e-6, atol=1e-12)
+    # fewer frames than planned
+    net.forward(dev(x[:2]))
+    assert torch.allclose(net.read_tensor(hooks[-1], 2).cpu().double(), feats[-1][:2], rtol=1e-4, atol=1e-5)
+
+
+def test_resnet50_full_size_layers(eng):
+    """Real ResNet-50 shapes (224^2, hook layer3) on 2 frames: every conv configuration of
+    SURVEY.md 8(a4) against the oracle's ATen ops."""
+    g = graphs.build("resnet50", (224, 224))
+    sd = weights.synthetic_state_dict(g, 0)
+    hooks = [g.hooks[3]]
+    N = 2
+    net = eng.build_net(g, sd, hooks, N)
+    onet = restate.OracleNet(g, sd, hooks, dtype=torch.float32)
+    x = gu.videos_of({"clip_u8": torch.randint(0, 256, (1, 3, N, 224, 224), generator=torch.Generator().manual_seed(1),
+                                               dtype=torch.uint8).numpy()})
+    x = restate.flatten_frames(x).contiguous()
+    feats = onet.forward(x)
+    net.forward(dev(x))
+    for nd in net.graph.nodes:
+        got = net.read_tensor(nd.dst, N).cpu()
+        ref = onet.tensor(nd.dst)
+        assert (got - ref).abs().max() <= 2e-4 * ref.abs().max() + 1e-5, nd
+    hg = [torch.randn_like(f) for f in feats]
+    write_hook_grads(net, feats, hg, N)
+    gx = torch.empty(N, 3, 224, 224, device="cuda:0")
+    net.backward(gx)
+    ref = onet.backward(hg)
+    assert (gx.cpu() - ref).abs().max() <= 2e-4 * ref.abs().max()
+
+
+# ------------------------------------------------------------------ attack loops
+MODE = {"i2v": attacks.ImageGuidedFMDirection_Adam, "std": attacks.ImageGuidedStd_Adam}
+
+
+@pytest.mark.parametrize("name", ["i2v_resnet_d3_f64", "i2v_resnet_d2_f32", "i2v_vgg_d2_f64", "i2v_alexnet_d3_f64",
+                                  "i2v_squeezenet_d2_f64", "std_resnet_d2_f64"])
+def test_attack_loop_against_golden(eng, name):
+    fx = gu.load(name)
+    atk = MODE[fx["kind"]](fx["models"], depth=fx["depth"], step_size=fx["lr"], steps=fx["steps"],
+                           graph_builder=graphs.build_tiny, weight_seed=fx["wseed"])
+    vid = gu.videos_of(fx)
+    adv = atk(vid, torch.zeros(fx["b"], dtype=torch.long), ["clip0"]).cpu()
+    ref_cost = np.array([float(s) for s in fx["cost_str"]])
+    np.testing.assert_allclose(atk.last_costs, ref_cost, rtol=2e-4)
+    assert adv.shape == vid.shape
+    assert atk.loss_info["clip0"][0]["cost"] == str(np.float32(atk.last_costs[0]))
+    mean = torch.tensor(gu.MEAN).view(1, 3, 1, 1, 1)
+    std = torch.tensor(gu.STD).view(1, 3, 1, 1, 1)
+    un = adv * std + mean
+    clean = torch.from_numpy(fx["clip_u8"]).float() / 255
+    assert (un - clean).abs().max() <= 16 / 255 + 1e-6
+    assert un.min() >= -1e-6 and un.max() <= 1 + 1e-6
+    assert np.abs(adv.numpy() - fx["adv"]).mean() < 5e-3
+    dl, rl = atk._delta.cpu().numpy(), fx["delta_last"]
+    assert abs(np.abs(dl).mean() / np.abs(rl).mean() - 1) < 0.02
+
+
+def test_first_step_against_reference_gradient(eng):
+    fx = gu.load("i2v_resnet_d3_f64")
+    atk = attacks.ImageGuidedFMDirection_Adam(fx["models"], depth=fx["depth"], step_size=fx["lr"], steps=1,
+                                              graph_builder=graphs.build_tiny)
+    atk(gu.videos_of(fx), torch.zeros(1, dtype=torch.long), ["c"])
+    r0, d1 = fx["grad0"], atk._delta.cpu().numpy()
+    well = np.abs(r0) > 5e-2 * np.abs(r0).max()
+    assert (np.abs(d1 - fx["delta_first"])[well] < 1e-4).all()          # north_star atol on a forced step
+    assert (np.abs(d1 - fx["delta_first"])[well] < 2e-5).mean() > 0.99
+    assert (np.abs(d1 - fx["delta_first"]) < 1e-4).mean() > 0.9
+
+
+def test_ens_and_aens_against_golden(eng):
+    fx = gu.load("ens_4models_f64")
+    atk = attacks.ImageGuidedFML2_Adam_MultiModels(fx["models"], depths=fx["depth"], steps=fx["steps"],
+                                                   graph_builder=graphs.build_tiny)
+    adv = atk(gu.videos_of(fx), torch.zeros(fx["b"], dtype=torch.long), ["clip0", "clip1"]).cpu()
+    np.testing.assert_allclose(atk.last_costs, np.array([float(s) for s in fx["cost_str"]]), rtol=2e-4)
+    assert np.abs(adv.numpy() - fx["adv"]).mean() < 5e-3
+    for name in ("aens_2x2_f64", "aens_coefce_f64"):
+        fx = gu.load(name)
+        atk = attacks.AENS_I2V_MF(fx["models"], depths=fx["depth"], step_size=fx["lr"], steps=fx["steps"],
+                                  graph_builder=graphs.build_tiny, **fx["kw"])
+        adv, used_time, cost_saved = atk(gu.videos_of(fx), torch.zeros(fx["b"], dtype=torch.long), ["c"] * fx["b"])
+        np.testing.assert_allclose(cost_saved, fx["cost_saved"], rtol=2e-4)
+        np.testing.assert_allclose(np.stack(atk.weights), fx["weights"], rtol=1e-4)
+        np.testing.assert_allclose(atk.coeffs.cpu().numpy(), fx["coeffs_after"], rtol=1e-4)
+
+
+def test_full_size_properties_resnet50(eng):
+    """BASELINE config 1 size (1 clip x 32 x 224^2, ResNet-50 layer3, 10 steps): size-independent
+    properties -- L_inf bound, [0,1] box, falling cost, bit-reproducibility (no atomics anywhere),
+    frame independence (a frame's trajectory does not depend on its batch neighbours)."""
+    gen = torch.Generator().manual_seed(1000)
+    u8 = torch.randint(0, 256, (1, 3, 32, 224, 224), generator=gen, dtype=torch.uint8)
+    vid = gu.videos_of({"clip_u8": u8.numpy()})
+    atk = attacks.ImageGuidedFMDirection_Adam(["resnet50"], depth=3, step_size=0.005, steps=10)
+    adv = atk(vid, torch.zeros(1, dtype=torch.long), ["v"]).cpu()
+    costs = atk.last_costs.copy()
+    assert costs[0] > 31.9 and costs[-1] < costs[0] and np.all(np.diff(costs) < 1e-3)
+    mean = torch.tensor(gu.MEAN).view(1, 3, 1, 1, 1)
+    std = torch.tensor(gu.STD).view(1, 3, 1, 1, 1)
+    un = adv * std + mean
+    assert (un - u8.float() / 255).abs().max() <= 16 / 255 + 1e-6
+    assert un.min() >= -1e-6 and un.max() <= 1 + 1e-6
+    adv2 = atk(vid, torch.zeros(1, dtype=torch.long), ["v"]).cpu()
+    assert torch.equal(adv, adv2)
+    sub = atk(vid[:, :, 8:12].contiguous(), torch.zeros(1, dtype=torch.long), ["w"]).cpu()
+    assert torch.equal(sub, adv[:, :, 8:12])
