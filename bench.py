@@ -156,7 +156,8 @@ def main():
         "algorithmic_gflop_per_frame": round(flop_per_frame / 1e9, 2),
     }
     if kt is not None and kt["conv_igemm"]["launches"]:
-        c = kt["conv_igemm"]
+        # every instantiation of conv_igemm: backbone fwd + dgrad, and the class-packed image gradient
+        c = {k: kt["conv_igemm"][k] + kt["conv_igemm_imggrad"][k] for k in ("ms", "flops", "launches")}
         ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
         out["roofline"] = {"kernel": "conv_igemm (fp32 MFMA implicit GEMM, fwd + dgrad)", "bound": "mfma",
                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

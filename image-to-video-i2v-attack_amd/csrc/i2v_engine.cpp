@@ -21,6 +21,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -50,7 +51,7 @@ struct Tensor { int buf, c_off, C; bool post_relu; };
 
 struct Packed {               // one implicit-GEMM operand set
     float* wp = nullptr; I2VKEntry* ktab = nullptr;
-    int K = 0, Kpad = 0, Cd = 0, Cdpad = 0;
+    int K = 0, Kpad = 0, Cd = 0, Cdpad = 0, tap_uniform = 0;
     int ph = 0, pw = 0, Hg = 0, Wg = 0;
 };
 
@@ -59,15 +60,18 @@ struct Node {
     i2v_conv_desc cd; i2v_pool_desc pd;
     std::vector<float> w;     // [cout][cin][kh][kw] with scale folded
     std::vector<float> shift;
-    float* shift_d = nullptr; float* w_d = nullptr;
+    float* shift_d = nullptr;
     Packed fwd; std::vector<Packed> bwd;
+    Packed img; int img_blk = 0, img_sh = 1;      // input-gradient of the first conv (class-packed)
+    size_t idx_off = 0;                           // maxpool: arg-max bytes, arena offset in floats
 };
 
-enum Kind { L_CONV, L_IMGGRAD, L_POOLF, L_POOLB, L_ADDMASK };
+enum Kind { L_CONV, L_IMGGRAD, L_POOLF, L_POOLB, L_ADDMASK };   // L_IMGGRAD: conv_igemm with class-packed Cd
 struct Launch {
     Kind kind;
-    I2VConvParams conv; I2VImgGradParams img; I2VPoolParams pool; I2VAddMaskParams am;
+    I2VConvParams conv; I2VPoolParams pool; I2VAddMaskParams am;
     bool src_is_input = false;     // conv: src pointer patched with the caller's x
+    double alg_flops_per_frame = 0; // L_IMGGRAD: algorithmic (not class-padded) flops
 };
 
 struct Addend { const float* p; int64_t nstride; int stride, H, W; };
@@ -84,7 +88,7 @@ struct Net {
 
 }  // namespace
 
-struct TimedLaunch { void* start; void* stop; int kind; double flops; };
+struct TimedLaunch { void* start; void* stop; int kind; double flops; int Cd, K, HWg, frames, pw; };
 struct i2v_ctx {
     int device; std::vector<Net*> nets;
     bool timing = false; std::vector<TimedLaunch> timed; size_t timed_used = 0; i2v_stream_t timed_stream = nullptr;
@@ -121,6 +125,7 @@ static int pack_fwd(Net& n, Node& nd) {
     int K = c.kh * c.kw * c.cin;
     Packed& P = nd.fwd;
     P.K = K; P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cout; P.Cdpad = (int)align_up(c.cout, 128);
+    P.tap_uniform = (c.cin % I2V_KC == 0) ? 1 : 0;
     std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
     std::vector<I2VKEntry> kt(P.Kpad, I2VKEntry{0, 0, 0, 0});
     for (int r = 0; r < c.kh; ++r)
@@ -150,6 +155,7 @@ static int pack_bwd(Net& n, Node& nd) {
             for (int s = 0; s < c.kw; ++s) if (posmod(pw + c.pad - s, st) == 0) ts.push_back(s);
             int K = (int)(tr.size() * ts.size()) * c.cout;
             P.K = K; P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cin; P.Cdpad = (int)align_up(c.cin, 128);
+            P.tap_uniform = (c.cout % I2V_KC == 0) ? 1 : 0;
             std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
             std::vector<I2VKEntry> kt(P.Kpad ? P.Kpad : 1, I2VKEntry{0, 0, 0, 0});
             int t = 0;
@@ -170,6 +176,53 @@ static int pack_bwd(Net& n, Node& nd) {
             nd.bwd.push_back(P);
         }
     return 0;
+}
+
+// Gradient of the FIRST convolution w.r.t. the image.  GEMM-N would be Cin = 3; instead the output is
+// cut into B x B position blocks (B = stride, or 2 for stride 1) and the B*B*Cin (class, channel)
+// pairs form the Cd axis: out[(ph,pw),ci][i][j] = sum_{co,dh,dw} w'[(co,dh,dw)][(ph,pw),ci] *
+// dz[co][i*m + dh][j*m + dw], m = B/stride, with zero weights where a class has no such tap.
+static int pack_img(Net& n, Node& nd) {
+    const i2v_conv_desc& c = nd.cd;
+    const Buffer& sb = n.bufs[n.tens[c.src].buf];
+    const Buffer& db = n.bufs[n.tens[c.dst].buf];
+    const int st = c.stride, B = st == 1 ? 2 : st, m = B / st;
+    int dh_lo = 1 << 30, dh_hi = -(1 << 30), dw_lo = 1 << 30, dw_hi = -(1 << 30);
+    for (int ph = 0; ph < B; ++ph)
+        for (int r = 0; r < c.kh; ++r)
+            if (posmod(ph + c.pad - r, st) == 0) { int d = floordiv(ph + c.pad - r, st); dh_lo = d < dh_lo ? d : dh_lo; dh_hi = d > dh_hi ? d : dh_hi; }
+    for (int pw = 0; pw < B; ++pw)
+        for (int s = 0; s < c.kw; ++s)
+            if (posmod(pw + c.pad - s, st) == 0) { int d = floordiv(pw + c.pad - s, st); dw_lo = d < dw_lo ? d : dw_lo; dw_hi = d > dw_hi ? d : dw_hi; }
+    const int TH = dh_hi - dh_lo + 1, TW = dw_hi - dw_lo + 1;
+    Packed& P = nd.img;
+    P.K = TH * TW * c.cout; P.Kpad = (int)align_up(P.K, I2V_KC);
+    P.Cd = B * B * c.cin; P.Cdpad = (int)align_up(P.Cd, 128);
+    P.tap_uniform = (c.cout % I2V_KC == 0) ? 1 : 0;
+    P.Hg = (sb.H + B - 1) / B; P.Wg = (sb.W + B - 1) / B;
+    nd.img_blk = B; nd.img_sh = m;
+    std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
+    std::vector<I2VKEntry> kt(P.Kpad, I2VKEntry{0, 0, 0, 0});
+    for (int th = 0; th < TH; ++th)
+        for (int tw = 0; tw < TW; ++tw)
+            for (int co = 0; co < c.cout; ++co)
+                kt[(th * TW + tw) * c.cout + co] = I2VKEntry{co * db.H * db.W, th + dh_lo, tw + dw_lo, 1};
+    for (int ph = 0; ph < B; ++ph)
+        for (int pw = 0; pw < B; ++pw)
+            for (int r = 0; r < c.kh; ++r) {
+                if (posmod(ph + c.pad - r, st)) continue;
+                const int th = floordiv(ph + c.pad - r, st) - dh_lo;
+                for (int s = 0; s < c.kw; ++s) {
+                    if (posmod(pw + c.pad - s, st)) continue;
+                    const int tw = floordiv(pw + c.pad - s, st) - dw_lo;
+                    for (int co = 0; co < c.cout; ++co)
+                        for (int ci = 0; ci < c.cin; ++ci)
+                            wp[(size_t)((th * TW + tw) * c.cout + co) * P.Cdpad + (ph * B + pw) * c.cin + ci] =
+                                nd.w[(((size_t)co * c.cin + ci) * c.kh + r) * c.kw + s];
+                }
+            }
+    if (upload(n, wp, &P.wp)) return 1;
+    return upload(n, kt, &P.ktab);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -298,7 +351,7 @@ extern "C" int i2v_net_add_maxpool(i2v_handle h, int net, const i2v_pool_desc* d
 // ---------------------------------------------------------------------------------------------
 static void conv_common(I2VConvParams& p, const Packed& P) {
     memset(&p, 0, sizeof p);
-    p.wp = P.wp; p.ktab = P.ktab; p.K = P.K; p.Kpad = P.Kpad; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
+    p.wp = P.wp; p.ktab = P.ktab; p.K = P.K; p.Kpad = P.Kpad; p.tap_uniform = P.tap_uniform; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
     p.add0_stride = 1;
 }
 
@@ -468,6 +521,7 @@ struct Planner {
                 l.pool.x = s.p; l.pool.x_nstride = s.nstride; l.pool.C = s.C; l.pool.Hs = s.H; l.pool.Ws = s.W;
                 l.pool.y = d.p; l.pool.y_nstride = d.nstride; l.pool.Ho = d.H; l.pool.Wo = d.W;
                 l.pool.k = q.k; l.pool.stride = q.stride; l.pool.pad = q.pad;
+                l.pool.idx = (uint8_t*)(base() + nd.idx_off);
             }
             emit(n.fwd, l);
         }
@@ -498,12 +552,14 @@ struct Planner {
                 const i2v_conv_desc& c = nd.cd;
                 if (c.residual >= 0 && !contribute_alias(c.residual, dz)) return false;
                 if (c.src == n.input) {
-                    Launch l; l.kind = L_IMGGRAD; memset(&l.img, 0, sizeof l.img);
+                    Launch l; l.kind = L_IMGGRAD; conv_common(l.conv, nd.img);
                     const Buffer& ib = n.bufs[n.tens[n.input].buf];
-                    l.img.dz = dz.p; l.img.dz_nstride = dz.nstride; l.img.Cout = c.cout; l.img.Ho = dz.H; l.img.Wo = dz.W;
-                    l.img.w = nd.w_d; l.img.Cin = c.cin; l.img.H = ib.H; l.img.W = ib.W;
-                    l.img.kh = c.kh; l.img.kw = c.kw; l.img.stride = c.stride; l.img.pad = c.pad;
-                    if (c.cin > I2V_MAX_IMG_C) { err = "input conv with more than 4 channels"; return false; }
+                    I2VConvParams& p = l.conv;
+                    p.src = dz.p; p.src_nstride = dz.nstride; p.Hs = dz.H; p.Ws = dz.W;
+                    p.Hg = nd.img.Hg; p.Wg = nd.img.Wg; p.sh = p.sw = nd.img_sh;
+                    p.dst = nullptr; p.dst_nstride = (int64_t)ib.C * ib.H * ib.W; p.Ho = ib.H; p.Wo = ib.W;
+                    p.osh = p.osw = nd.img_blk; p.blk = nd.img_blk;
+                    l.alg_flops_per_frame = 2.0 * dz.H * dz.W * c.cout * c.cin * c.kh * c.kw;
                     emit(n.bwd, l);
                 } else if (!contribute_conv(c.src, nd, dz)) return false;
             } else {
@@ -517,6 +573,7 @@ struct Planner {
                 l.pool.gx = gx.p; l.pool.gx_nstride = gx.nstride;
                 l.pool.k = q.k; l.pool.stride = q.stride; l.pool.pad = q.pad;
                 l.pool.mask_relu = n.tens[q.src].post_relu ? 1 : 0;
+                l.pool.idx = (uint8_t*)(base() + nd.idx_off);
                 emit(n.bwd, l);
             }
         }
@@ -542,7 +599,7 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
         if (nd.type != 0) continue;
         if (upload(n, nd.shift, &nd.shift_d)) return 1;
         if (pack_fwd(n, nd)) return 1;
-        if (nd.cd.src == n.input) { if (upload(n, nd.w, &nd.w_d)) return 1; }
+        if (nd.cd.src == n.input) { if (pack_img(n, nd)) return 1; }
         else if (pack_bwd(n, nd)) return 1;
     }
     size_t off = 0;
@@ -552,6 +609,11 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
         b.act_off = off; off = align_up(off + sz, 64);
         b.grad_off = off; off = align_up(off + sz, 64);
     }
+    for (Node& nd : n.nodes)
+        if (nd.type == 1) {
+            const Buffer& db = n.bufs[n.tens[nd.pd.dst].buf];
+            nd.idx_off = off; off = align_up(off + (N * n.tens[nd.pd.dst].C * db.H * db.W + 3) / 4, 64);
+        }
     Planner dry{n, true, off, N};
     if (!dry.run()) return fail("plan: %s", dry.err.c_str());
     n.arena_floats = dry.off;
@@ -581,7 +643,7 @@ static TimedLaunch* timing_begin(i2v_ctx* h, int kind, double flops, i2v_stream_
         h->timed.push_back(t);
     }
     TimedLaunch* t = &h->timed[h->timed_used++];
-    t->kind = kind; t->flops = flops; h->timed_stream = s;
+    t->kind = kind; t->flops = flops; h->timed_stream = s; t->Cd = t->K = t->HWg = t->frames = t->pw = 0;
     be_event_record(t->start, s);
     return t;
 }
@@ -591,9 +653,9 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int frames, cons
     for (Launch& l : L) {
         double flops = 0.0;
         if (l.kind == L_CONV) flops = 2.0 * frames * l.conv.Hg * l.conv.Wg * (double)l.conv.Cd * l.conv.K;
-        else if (l.kind == L_IMGGRAD)
-            flops = 2.0 * frames * (double)l.img.Ho * l.img.Wo * l.img.Cout * l.img.Cin * l.img.kh * l.img.kw;
+        else if (l.kind == L_IMGGRAD) flops = l.alg_flops_per_frame * frames;
         TimedLaunch* tl = timing_begin(h, (int)l.kind, flops, s);
+        if (tl && (l.kind == L_CONV || l.kind == L_IMGGRAD)) { tl->Cd = l.conv.Cd; tl->K = l.conv.K; tl->HWg = l.conv.Hg * l.conv.Wg; tl->frames = frames; tl->pw = l.conv.pointwise; }
         struct Stop { TimedLaunch* t; i2v_stream_t s; ~Stop() { if (t) be_event_record(t->stop, s); } } stop{tl, s};
         switch (l.kind) {
             case L_CONV: {
@@ -603,8 +665,9 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int frames, cons
                 CHECK_BE(k_conv(p, s));
             } break;
             case L_IMGGRAD: {
-                I2VImgGradParams p = l.img; p.N = frames; p.gx = gx; p.accumulate = accumulate;
-                CHECK_BE(k_imggrad(p, s));
+                I2VConvParams p = l.conv; p.N = frames; p.dst = gx;
+                if (accumulate) { p.add1 = gx; p.add1_nstride = p.dst_nstride; }
+                CHECK_BE(k_conv(p, s));
             } break;
             case L_POOLF: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool_fwd(p, s)); } break;
             case L_POOLB: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool_bwd(p, s)); } break;
@@ -642,12 +705,17 @@ extern "C" int i2v_timing_collect(i2v_handle h, double* ms_by_kind, double* flop
     if (!h || !ms_by_kind || !flops_by_kind || !launches_by_kind || n_kinds < 5) return fail("i2v_timing_collect: bad argument");
     for (int i = 0; i < n_kinds; ++i) { ms_by_kind[i] = 0; flops_by_kind[i] = 0; launches_by_kind[i] = 0; }
     if (h->timed_used) CHECK_BE(be_stream_sync(h->timed_stream));
+    const char* dump_path = getenv("I2V_TIMING_DUMP");      // debug: one line per launch
+    FILE* dump = dump_path ? fopen(dump_path, "a") : nullptr;
     for (size_t i = 0; i < h->timed_used; ++i) {
         float ms = 0.f;
         CHECK_BE(be_event_elapsed_ms(h->timed[i].start, h->timed[i].stop, &ms));
         int k = h->timed[i].kind;
+        if (dump) fprintf(dump, "%d %d %d %d %d %d %.4f %.3f\n", k, h->timed[i].Cd, h->timed[i].K, h->timed[i].HWg,
+                          h->timed[i].frames, h->timed[i].pw, ms, h->timed[i].flops * 1e-9);
         ms_by_kind[k] += ms; flops_by_kind[k] += h->timed[i].flops; launches_by_kind[k] += 1;
     }
+    if (dump) fclose(dump);
     h->timed_used = 0;
     return 0;
 }
@@ -727,14 +795,13 @@ extern "C" int i2v_std_fwd_bwd_f32(const float* a, int64_t a_stride, int64_t D, 
 }
 
 extern "C" int i2v_adam_step_f32(float* delta, float* m, float* v, const float* gx, const float* u,
-                                 int64_t frames, int hw, float eps, float lr, float beta1, float beta2,
-                                 float adam_eps, int step_t, void* stream) {
+                                 int64_t frames, int hw, float eps, double lr, double beta1, double beta2,
+                                 double adam_eps, int step_t, void* stream) {
     if (!delta || !m || !v || !gx || !u || frames <= 0 || hw <= 0 || step_t < 1) return fail("i2v_adam_step_f32: bad argument");
-    // host-side bias corrections in double, as torch/optim/adam.py does for the non-capturable path
-    double bc1 = 1.0 - pow((double)beta1, step_t), bc2 = 1.0 - pow((double)beta2, step_t);
-    float step_size = (float)((double)lr / bc1);
-    float bc2_sqrt = (float)sqrt(bc2);
-    CHECK_BE(k_adam(delta, m, v, gx, u, frames * 3 * (int64_t)hw, hw, eps, step_size, bc2_sqrt, beta1, beta2, adam_eps, stream));
+    // scalar prep in double, as torch/optim/adam.py does on the host for the non-capturable path
+    const double bc1 = 1.0 - pow(beta1, step_t), bc2 = 1.0 - pow(beta2, step_t);
+    CHECK_BE(k_adam(delta, m, v, gx, u, frames * 3 * (int64_t)hw, hw, eps, (float)(lr / bc1), (float)sqrt(bc2),
+                    (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)adam_eps, stream));
     return 0;
 }
 

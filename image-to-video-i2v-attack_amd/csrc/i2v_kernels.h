@@ -23,7 +23,6 @@ int  be_event_elapsed_ms(void* start, void* stop, float* ms);           // both 
 int  be_stream_sync(i2v_stream_t s);                                                       // last backend error or null
 
 int k_conv(const I2VConvParams& p, i2v_stream_t s);
-int k_imggrad(const I2VImgGradParams& p, i2v_stream_t s);
 int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_addmask(const I2VAddMaskParams& p, i2v_stream_t s);
@@ -33,8 +32,8 @@ int k_frames_from_video(const float* video, float* x, float* u, int b, int f, in
 int k_compose(const float* u, const float* delta, float* x, int b, int f, int h, int w, float eps,
               int video_layout, i2v_stream_t s);
 int k_adam(float* delta, float* m, float* v, const float* gx, const float* u, int64_t n, int hw,
-           float eps, float step_size, float bc2_sqrt, float beta1, float beta2, float adam_eps,
-           i2v_stream_t s);
+           float eps, float step_size, float bc2_sqrt, float w1, float beta2, float w2, float adam_eps,
+           i2v_stream_t s);   // w1 = 1-beta1, w2 = 1-beta2 (rounded from double)
 int k_sign_bim(float* adv, const float* u, const float* grad, int64_t n, int64_t chan_stride,
                float step, float eps, i2v_stream_t s);
 int k_sign_delta(float* delta, const float* grad, int64_t n, float step, i2v_stream_t s);

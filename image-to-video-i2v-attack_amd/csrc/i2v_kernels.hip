@@ -4,10 +4,12 @@
 //                   D[cd][pixel] = Wp[k][cd]^T * im2col[k][pixel] on v_mfma_f32_32x32x2_f32, with the
 //                   pixel axis on the MFMA column (lane) index so that NCHW loads AND stores are
 //                   coalesced along W; im2col is formed while staging into LDS.
-//   imggrad_direct  gradient of the first convolution w.r.t. the 3-channel image (GEMM-N = 3 is not
-//                   an MFMA shape) as a direct gather kernel with the filter bank in LDS.
+//                   The gradient w.r.t. the 3-channel image reuses it with the Cd axis packing
+//                   (position-class, channel) pairs (I2VConvParams::blk), since GEMM-N = 3 alone is
+//                   not an MFMA shape.
 //   pool / addmask / cosine / std / compose / Adam / sign-step: HBM-bound streaming kernels.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -56,7 +58,9 @@ __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
 //   A: lane l holds Wp[k = kk + (l>>5)][cd = l&31]      B: lane l holds X[k = kk + (l>>5)][px = l&31]
 //   D: lane l, register r  ->  pixel l&31, channel (r&3) + 8*(r>>2) + 4*(l>>5)
 // so every global store instruction writes 32 consecutive pixels of one channel plane.
-template <int BD, int BP, int WD, int WP, bool PW>
+// MODE 0: per-row k-table gather (any geometry); 1: pointwise float4 (1x1, stride 1, planes 16-B aligned);
+// 2: tap-uniform chunks (every 16-row K chunk shares one spatial tap: channel count % 16 == 0)
+template <int BD, int BP, int WD, int WP, int MODE>
 __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
     constexpr int KC = I2V_KC;
     constexpr int TD = BD / WD / 32, TP = BP / WP / 32;
@@ -78,6 +82,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     const int HWg = p.Hg * p.Wg;
     const int64_t P = (int64_t)p.N * HWg;
 
+    constexpr bool PW = MODE == 1;
     // ---- activation (B) loader state ----
     constexpr int BROWS = PW ? (1024 / BP) : (256 / BP);     // k-rows covered per pass
     constexpr int BQ = KC / BROWS;                            // passes per chunk
@@ -129,6 +134,16 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                              \
                 if (pvalid && k < p.K) v = *reinterpret_cast<const float4*>(srcn + (int64_t)k * HWs);    \
                 breg4[q] = v;                                                                            \
+            }                                                                                            \
+        } else if (MODE == 2) {                                                                          \
+            const I2VKEntry e = p.ktab[k0];                                                              \
+            const int hs = h0 + e.dh, ws = w0 + e.dw;                                                    \
+            const bool ok = pvalid && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;    \
+            const float* bsrc = srcn + e.chan_off + e.dh * p.Ws + e.dw + (int64_t)brow * HWs;            \
+            _Pragma("unroll") for (int q = 0; q < BQ; ++q) {                                             \
+                float v = 0.f;                                                                           \
+                if (ok) v = bsrc[(int64_t)(q * BROWS) * HWs];                                            \
+                breg[q] = v;                                                                             \
             }                                                                                            \
         } else {                                                                                         \
             _Pragma("unroll") for (int q = 0; q < BQ; ++q) {                                             \
@@ -191,6 +206,36 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
 
     // ---- epilogue: shift, addends, ReLU, gradient gate, NCHW store ----
     const int HoWo = p.Ho * p.Wo;
+    if (p.blk > 1) {
+        // class-packed Cd (image gradient): cd = (ph*blk + pw)*Creal + c -> channel c at (gi*osh+ph, gj*osw+pw)
+        const int Creal = p.Cd / (p.blk * p.blk);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int64_t pp = px0 + wpx * (BP / WP) + j * 32 + l31;
+            if (pp >= P) continue;
+            const int64_t n = pp / HWg;
+            const int rem = (int)(pp - n * HWg);
+            const int gi = rem / p.Wg, gj = rem - gi * p.Wg;
+#pragma unroll
+            for (int i = 0; i < TD; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cd = cd0 + wd * (BD / WD) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (cd >= p.Cd) continue;
+                    const int cls = cd / Creal, c = cd - cls * Creal;
+                    const int oh = gi * p.osh + cls / p.blk + p.oh0, ow = gj * p.osw + cls % p.blk + p.ow0;
+                    if (oh >= p.Ho || ow >= p.Wo) continue;
+                    const int64_t o = (int64_t)c * HoWo + oh * p.Wo + ow;
+                    float v = acc[i][j][r];
+                    if (p.shift) v += p.shift[c];
+                    if (p.add1) v += p.add1[n * p.add1_nstride + o];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.mask && !(p.mask[n * p.mask_nstride + o] > 0.f)) v = 0.f;
+                    p.dst[n * p.dst_nstride + o] = v;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         const int64_t pp = px0 + wpx * (BP / WP) + j * 32 + l31;
@@ -241,97 +286,49 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     const int64_t grid = n_px * n_cd;
     if (grid <= 0) return 0;
     if (grid > 0x7fffffff) { snprintf(g_be_err, sizeof g_be_err, "conv grid too large"); g_be_has_err = true; return 1; }
-    if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
-    else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, false>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+    if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+    else if (p.tap_uniform) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+    else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 0>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
     LAUNCH_CHECK("conv_igemm");
     return 0;
 }
 
-int k_conv(const I2VConvParams& p, i2v_stream_t s) {
-    hipStream_t st = (hipStream_t)s;
-    if (p.Cd > 64) return launch_conv_cfg<128, 128, 2, 2>(p, st);
-    if (p.Cd > 32) return launch_conv_cfg<64, 128, 2, 2>(p, st);
-    return launch_conv_cfg<32, 256, 1, 4>(p, st);
-}
-
-// =============================================================================================
-// gradient of the first convolution w.r.t. the image (direct gather, filters in LDS)
-// =============================================================================================
-#define IMG_LDS_FLOATS 12288
-__global__ void __launch_bounds__(256) imggrad_direct(const I2VImgGradParams p, const int co_chunk) {
-    __shared__ float wl[IMG_LDS_FLOATS];
-    const int per_co = p.Cin * p.kh * p.kw;
-    const int tiles_w = (p.W + 15) / 16;
-    const int tile = blockIdx.x, n = blockIdx.y;
-    const int h = (tile / tiles_w) * 16 + (threadIdx.x >> 4), w = (tile % tiles_w) * 16 + (threadIdx.x & 15);
-    const bool inside = h < p.H && w < p.W;
-    float acc[I2V_MAX_IMG_C] = {0.f, 0.f, 0.f, 0.f};
-    // taps r with (h + pad - r) % stride == 0: r = r0, r0 + stride, ...
-    const int r0 = (h + p.pad) % p.stride, s0 = (w + p.pad) % p.stride;
-    const float* dzn = p.dz + (int64_t)n * p.dz_nstride;
-    for (int cb = 0; cb < p.Cout; cb += co_chunk) {
-        const int cn = min(co_chunk, p.Cout - cb);
-        __syncthreads();
-        for (int i = threadIdx.x; i < cn * per_co; i += 256) wl[i] = p.w[(int64_t)cb * per_co + i];
-        __syncthreads();
-        if (!inside) continue;
-        for (int co = 0; co < cn; ++co) {
-            const float* dzc = dzn + (int64_t)(cb + co) * p.Ho * p.Wo;
-            const float* wc = wl + co * per_co;
-            for (int r = r0; r < p.kh; r += p.stride) {
-                const int th = h + p.pad - r;
-                if (th < 0) break;
-                const int ho = th / p.stride;
-                if (ho >= p.Ho) continue;
-                for (int s = s0; s < p.kw; s += p.stride) {
-                    const int tw = w + p.pad - s;
-                    if (tw < 0) break;
-                    const int wo = tw / p.stride;
-                    if (wo >= p.Wo) continue;
-                    const float g = dzc[ho * p.Wo + wo];
-#pragma unroll
-                    for (int ci = 0; ci < I2V_MAX_IMG_C; ++ci)
-                        if (ci < p.Cin) acc[ci] = fmaf(wc[(ci * p.kh + r) * p.kw + s], g, acc[ci]);
-                }
-            }
-        }
-    }
-    if (!inside) return;
-#pragma unroll
-    for (int ci = 0; ci < I2V_MAX_IMG_C; ++ci)
-        if (ci < p.Cin) {
-            float* o = p.gx + (((int64_t)n * p.Cin + ci) * p.H + h) * p.W + w;
-            *o = p.accumulate ? *o + acc[ci] : acc[ci];
-        }
-}
-
-int k_imggrad(const I2VImgGradParams& p, i2v_stream_t s) {
-    const int per_co = p.Cin * p.kh * p.kw;
-    int co_chunk = IMG_LDS_FLOATS / per_co;
-    if (co_chunk < 1) { snprintf(g_be_err, sizeof g_be_err, "first-layer filter too large for LDS"); g_be_has_err = true; return 1; }
-    if (co_chunk > p.Cout) co_chunk = p.Cout;
-    dim3 grid(((p.H + 15) / 16) * ((p.W + 15) / 16), p.N);
-    hipLaunchKernelGGL(imggrad_direct, grid, dim3(256), 0, (hipStream_t)s, p, co_chunk);
-    LAUNCH_CHECK("imggrad_direct");
-    return 0;
-}
-
-// =============================================================================================
-// max pooling (arg-max recomputed in backward: first maximum in scan order, as ATen)
-// =============================================================================================
-__device__ __forceinline__ int pool_argmax(const float* pl, int Hs, int Ws, int ho, int wo, int k, int st, int pad) {
-    int best = -1; float bv = 0.f;
-    for (int r = 0; r < k; ++r) {
-        const int h = ho * st - pad + r; if (h < 0 || h >= Hs) continue;
-        for (int s = 0; s < k; ++s) {
-            const int w = wo * st - pad + s; if (w < 0 || w >= Ws) continue;
-            const float v = pl[h * Ws + w];
-            if (best < 0 || v > bv || v != v) { bv = v; best = h * Ws + w; }
-        }
+// Tile choice per launch.  A 32x32x2 fp32 MFMA occupies its SIMD for 64 cycles, so a block's matrix
+// time is fixed by its tile; what varies is how evenly the grid covers the 256 CUs (the 14x14 layers
+// have only a few hundred 128x128 tiles) against the extra operand traffic of small tiles.
+static int conv_pick(const I2VConvParams& p) {
+    static const struct { int BD, BP, occ; double ineff; } C[5] = {
+        {128, 128, 3, 1.00}, {64, 128, 5, 1.04}, {128, 64, 5, 1.04}, {64, 64, 8, 1.10}, {32, 256, 4, 1.06}};
+    const double P = (double)p.N * p.Hg * p.Wg;
+    const int nchunks = p.Kpad / I2V_KC;
+    int best = 0; double best_t = 1e300;
+    for (int i = 0; i < 5; ++i) {
+        if (C[i].BD > 32 && p.Cd <= C[i].BD / 2) continue;        // more than half the rows would be padding
+        if (C[i].BD == 32 && p.Cd > 32) continue;
+        const double blocks = ceil(p.Cd / (double)C[i].BD) * ceil(P / C[i].BP);
+        const double rounds = ceil(blocks / 256.0);
+        const double mfma = (double)nchunks * (C[i].BD / 32) * (C[i].BP / 32) / 4 * 8 * 64 * C[i].ineff;
+        const double overhead = 2500.0 + (C[i].BD * C[i].BP / 256) * 14.0;
+        const double t = rounds * mfma + ceil(rounds / C[i].occ) * overhead;
+        if (t < best_t) { best_t = t; best = i; }
     }
     return best;
 }
 
+int k_conv(const I2VConvParams& p, i2v_stream_t s) {
+    hipStream_t st = (hipStream_t)s;
+    switch (conv_pick(p)) {
+        case 0: return launch_conv_cfg<128, 128, 2, 2>(p, st);
+        case 1: return launch_conv_cfg<64, 128, 2, 2>(p, st);
+        case 2: return launch_conv_cfg<128, 64, 2, 2>(p, st);
+        case 3: return launch_conv_cfg<64, 64, 2, 2>(p, st);
+        default: return launch_conv_cfg<32, 256, 1, 4>(p, st);
+    }
+}
+
+// =============================================================================================
+// max pooling (window-relative arg-max byte saved by forward: first maximum in scan order, as ATen)
+// =============================================================================================
 __global__ void pool_fwd_kernel(const I2VPoolParams p) {
     const int64_t total = (int64_t)p.N * p.C * p.Ho * p.Wo;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -339,31 +336,43 @@ __global__ void pool_fwd_kernel(const I2VPoolParams p) {
         const int ho = r % p.Ho; r /= p.Ho;
         const int c = r % p.C; const int64_t n = r / p.C;
         const float* pl = p.x + n * p.x_nstride + (int64_t)c * p.Hs * p.Ws;
-        p.y[n * p.y_nstride + ((int64_t)c * p.Ho + ho) * p.Wo + wo] = pl[pool_argmax(pl, p.Hs, p.Ws, ho, wo, p.k, p.stride, p.pad)];
+        int best = -1; float bv = 0.f;
+        for (int kr = 0; kr < p.k; ++kr) {
+            const int h = ho * p.stride - p.pad + kr; if (h < 0 || h >= p.Hs) continue;
+            for (int ks = 0; ks < p.k; ++ks) {
+                const int w = wo * p.stride - p.pad + ks; if (w < 0 || w >= p.Ws) continue;
+                const float v = pl[h * p.Ws + w];
+                if (best < 0 || v > bv || v != v) { bv = v; best = kr * p.k + ks; }    // first maximum wins
+            }
+        }
+        p.y[n * p.y_nstride + ((int64_t)c * p.Ho + ho) * p.Wo + wo] = bv;
+        p.idx[idx] = (uint8_t)best;
     }
 }
 
+// gather form (no atomics): an input element collects from the <= ceil(k/stride)^2 windows holding it
+// whose stored arg-max points back at it
 __global__ void pool_bwd_kernel(const I2VPoolParams p) {
     const int64_t total = (int64_t)p.N * p.C * p.Hs * p.Ws;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int w = idx % p.Ws; int64_t r = idx / p.Ws;
         const int h = r % p.Hs; r /= p.Hs;
         const int c = r % p.C; const int64_t n = r / p.C;
-        const float* pl = p.x + n * p.x_nstride + (int64_t)c * p.Hs * p.Ws;
-        const float* gy = p.y + n * p.y_nstride + (int64_t)c * p.Ho * p.Wo;
-        const int me = h * p.Ws + w;
         float g = 0.f;
-        if (!p.mask_relu || pl[me] > 0.f) {
-            // windows containing (h,w): ho*st - pad <= h <= ho*st - pad + k - 1
+        if (!p.mask_relu || p.x[n * p.x_nstride + ((int64_t)c * p.Hs + h) * p.Ws + w] > 0.f) {
+            const float* gy = p.y + n * p.y_nstride + (int64_t)c * p.Ho * p.Wo;
+            const uint8_t* ix = p.idx + (n * p.C + c) * (int64_t)p.Ho * p.Wo;
             int ho_lo = h + p.pad - p.k + 1; ho_lo = ho_lo <= 0 ? 0 : (ho_lo + p.stride - 1) / p.stride;
-            int ho_hi = min((h + p.pad) / p.stride, p.Ho - 1);
+            const int ho_hi = min((h + p.pad) / p.stride, p.Ho - 1);
             int wo_lo = w + p.pad - p.k + 1; wo_lo = wo_lo <= 0 ? 0 : (wo_lo + p.stride - 1) / p.stride;
-            int wo_hi = min((w + p.pad) / p.stride, p.Wo - 1);
+            const int wo_hi = min((w + p.pad) / p.stride, p.Wo - 1);
             for (int ho = ho_lo; ho <= ho_hi; ++ho)
-                for (int wo = wo_lo; wo <= wo_hi; ++wo)
-                    if (pool_argmax(pl, p.Hs, p.Ws, ho, wo, p.k, p.stride, p.pad) == me) g += gy[ho * p.Wo + wo];
+                for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                    const int me = (h - (ho * p.stride - p.pad)) * p.k + (w - (wo * p.stride - p.pad));
+                    if (ix[ho * p.Wo + wo] == me) g += gy[ho * p.Wo + wo];
+                }
         }
-        p.gx[n * p.gx_nstride + (int64_t)c * p.Hs * p.Ws + me] = g;
+        p.gx[n * p.gx_nstride + ((int64_t)c * p.Hs + h) * p.Ws + w] = g;
     }
 }
 
@@ -584,8 +593,7 @@ __global__ void compose_kernel(const float* __restrict__ u, const float* __restr
 
 __global__ void adam_kernel(float* __restrict__ delta, float* __restrict__ m, float* __restrict__ v,
                             const float* __restrict__ gx, const float* __restrict__ u, int64_t n, int hw, float eps,
-                            float step_size, float bc2_sqrt, float beta1, float beta2, float adam_eps) {
-    const float w1 = 1.f - beta1, w2 = 1.f - beta2;
+                            float step_size, float bc2_sqrt, float w1, float beta2, float w2, float adam_eps) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)((i / hw) % 3);
         const float d = delta[i];
@@ -659,9 +667,9 @@ int k_compose(const float* u, const float* delta, float* x, int b, int f, int h,
     LAUNCH_CHECK("compose"); return 0;
 }
 int k_adam(float* delta, float* m, float* v, const float* gx, const float* u, int64_t n, int hw, float eps,
-           float step_size, float bc2_sqrt, float beta1, float beta2, float adam_eps, i2v_stream_t s) {
+           float step_size, float bc2_sqrt, float w1, float beta2, float w2, float adam_eps, i2v_stream_t s) {
     hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n, 1024)), dim3(256), 0, (hipStream_t)s, delta, m, v, gx, u, n, hw, eps,
-                       step_size, bc2_sqrt, beta1, beta2, adam_eps);
+                       step_size, bc2_sqrt, w1, beta2, w2, adam_eps);
     LAUNCH_CHECK("adam"); return 0;
 }
 int k_sign_bim(float* adv, const float* u, const float* grad, int64_t n, int64_t cs, float step, float eps, i2v_stream_t s) {

@@ -5,7 +5,6 @@
 #include <stdint.h>
 
 #define I2V_KC 16          // K-chunk of the implicit GEMM; packed weights/k-tables are padded to it
-#define I2V_MAX_IMG_C 4    // image-gradient kernel: at most 4 input channels (always 3 here)
 
 // One row of the implicit-GEMM reduction axis: which source plane and which spatial tap.
 struct I2VKEntry {
@@ -30,21 +29,19 @@ struct I2VConvParams {
     const float* mask; int64_t mask_nstride;
     int32_t relu;
     int32_t pointwise;  // 1: 1x1 / stride 1 / no padding, planes 16-byte aligned -> vector path
-};
-
-// Gradient w.r.t. the network input (3-channel image) of the first convolution.
-//   gx[n][ci][h][w] (+)= sum_{co,r,s} w[co][ci][r][s] * dz[n][co][(h+pad-r)/st][(w+pad-s)/st]
-struct I2VImgGradParams {
-    const float* dz;   int64_t dz_nstride;   int32_t Cout, Ho, Wo;
-    const float* w;    // [Cout][Cin][kh][kw], BN scale folded in
-    float* gx;         int32_t N, Cin, H, W, kh, kw, stride, pad;
-    int32_t accumulate;
+    int32_t tap_uniform; // 1: K rows are (tap-major, channel-minor) with channels % I2V_KC == 0, so every
+                         //    K-chunk has ONE spatial tap: ktab[k0] describes the whole chunk
+    // blk > 1: the Cd axis packs blk*blk output-position classes: cd = (ph*blk + pw)*(Cd/blk^2) + c is
+    // stored to channel c at (i*osh + ph, j*osw + pw).  Used for the gradient w.r.t. the 3-channel image,
+    // where 3 output channels alone would waste 29/32 of every MFMA.
+    int32_t blk;
 };
 
 struct I2VPoolParams {
     const float* x;    int64_t x_nstride;    int32_t C, Hs, Ws;
     float* y;          int64_t y_nstride;    int32_t Ho, Wo;       // fwd: output; bwd: upstream grad
     float* gx;         int64_t gx_nstride;                           // bwd only
+    uint8_t* idx;      // [N][C][Ho][Wo] window-relative arg-max (r*k+s), written by fwd, read by bwd
     int32_t N, k, stride, pad, mask_relu;
 };
 

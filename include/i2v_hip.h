@@ -117,10 +117,12 @@ int i2v_std_fwd_bwd_f32(const float* a, int64_t a_stride, int64_t D, int frames,
                         void* scratch, void* stream);
 /* Compose backward + `torch.optim.Adam.step` on delta (image_attacks.py:306,351-353):
  *   g = gx/std[c] where -eps<=delta<=eps and 0<=u+clamp(delta)<=1 (inclusive), else 0
- *   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; delta -= lr/(1-b1^t) * m/(sqrt(v)/sqrt(1-b2^t)+1e-8) */
+ *   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; delta -= lr/(1-b1^t) * m/(sqrt(v)/sqrt(1-b2^t)+1e-8)
+ * lr/betas/eps are doubles as in torch.optim: 1-b1, 1-b2 and the bias corrections are formed in
+ * double on the host and only then rounded to fp32 scalars. */
 int i2v_adam_step_f32(float* delta, float* m, float* v, const float* gx, const float* u,
-                      int64_t frames, int hw, float eps, float lr, float beta1, float beta2,
-                      float adam_eps, int step_t, void* stream);
+                      int64_t frames, int hw, float eps, double lr, double beta1, double beta2,
+                      double adam_eps, int step_t, void* stream);
 /* BIM-style update (base_attacks.py:289-293) on a normalised clip of any rank whose channel
  * index is (i / chan_stride) % 3:  a = adv*std+mean + step*sign(g); d = clamp(a-u,+-eps);
  * adv = (clamp(u+d,0,1)-mean)/std. */

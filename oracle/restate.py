@@ -82,6 +82,19 @@ class OracleNet:
     def tensor(self, tid):
         return self._view(self.buf, tid)
 
+    def adopt_activations(self, acts: Dict[int, torch.Tensor]):
+        """Replace the stored activations (tensor id -> value) by externally computed ones and
+        recompute the pool arg-max from them, so that a following `backward` uses exactly the same
+        ReLU gates / arg-max as the implementation under test (removes the chaotic gate flips of
+        near-zero activations from a gradient comparison)."""
+        for tid, val in acts.items():
+            self._view(self.buf, tid).copy_(val.to(self.dtype))
+        for i, nd in enumerate(self.g.nodes):
+            if nd.op == "maxpool":
+                src = self._view(self.buf, nd.src)
+                _, idx = F.max_pool2d(src, nd.k, nd.stride, nd.pad, ceil_mode=nd.ceil_mode, return_indices=True)
+                self.pool_idx[i] = idx
+
     def backward(self, hook_grads: Sequence[torch.Tensor]) -> torch.Tensor:
         """d(cost)/d(input) given d(cost)/d(hook feature) for every hook (same order)."""
         g = self.g

@@ -40,7 +40,7 @@ int k_conv(const I2VConvParams& p, i2v_stream_t) {
         for (int i = 0; i < p.Hg; ++i)
             for (int j = 0; j < p.Wg; ++j) {
                 int oh = i * p.osh + p.oh0, ow = j * p.osw + p.ow0;
-                if (oh >= p.Ho || ow >= p.Wo) continue;
+                if (p.blk <= 1 && (oh >= p.Ho || ow >= p.Wo)) continue;
                 for (int cd = 0; cd < p.Cd; ++cd) {
                     float acc = 0.f;
                     for (int k = 0; k < p.Kpad; ++k) {
@@ -50,6 +50,19 @@ int k_conv(const I2VConvParams& p, i2v_stream_t) {
                         if (hs < 0 || hs >= p.Hs || ws < 0 || ws >= p.Ws) continue;
                         acc += p.wp[(size_t)k * p.Cdpad + cd] *
                                p.src[(size_t)n * p.src_nstride + e.chan_off + (size_t)hs * p.Ws + ws];
+                    }
+                    if (p.blk > 1) {            // class-packed Cd (image gradient)
+                        int Creal = p.Cd / (p.blk * p.blk), cls = cd / Creal, c = cd % Creal;
+                        int bh = i * p.osh + cls / p.blk + p.oh0, bw = j * p.osw + cls % p.blk + p.ow0;
+                        if (bh >= p.Ho || bw >= p.Wo) continue;
+                        size_t o = (size_t)c * p.Ho * p.Wo + (size_t)bh * p.Wo + bw;
+                        float v = acc;
+                        if (p.shift) v += p.shift[c];
+                        if (p.add1) v += p.add1[(size_t)n * p.add1_nstride + o];
+                        if (p.relu) v = v > 0.f ? v : 0.f;
+                        if (p.mask && !(p.mask[(size_t)n * p.mask_nstride + o] > 0.f)) v = 0.f;
+                        p.dst[(size_t)n * p.dst_nstride + o] = v;
+                        continue;
                     }
                     size_t oidx = (size_t)cd * p.Ho * p.Wo + (size_t)oh * p.Wo + ow;
                     float v = acc;
@@ -70,55 +83,25 @@ int k_conv(const I2VConvParams& p, i2v_stream_t) {
     return 0;
 }
 
-int k_imggrad(const I2VImgGradParams& p, i2v_stream_t) {
-    for (int n = 0; n < p.N; ++n)
-        for (int ci = 0; ci < p.Cin; ++ci)
-            for (int h = 0; h < p.H; ++h)
-                for (int w = 0; w < p.W; ++w) {
-                    float acc = 0.f;
-                    for (int co = 0; co < p.Cout; ++co)
-                        for (int r = 0; r < p.kh; ++r) {
-                            int th = h + p.pad - r;
-                            if (th < 0 || th % p.stride) continue;
-                            int ho = th / p.stride;
-                            if (ho >= p.Ho) continue;
-                            for (int s = 0; s < p.kw; ++s) {
-                                int tw = w + p.pad - s;
-                                if (tw < 0 || tw % p.stride) continue;
-                                int wo = tw / p.stride;
-                                if (wo >= p.Wo) continue;
-                                acc += p.w[(((size_t)co * p.Cin + ci) * p.kh + r) * p.kw + s] *
-                                       p.dz[(size_t)n * p.dz_nstride + ((size_t)co * p.Ho + ho) * p.Wo + wo];
-                            }
-                        }
-                    size_t o = (((size_t)n * p.Cin + ci) * p.H + h) * p.W + w;
-                    p.gx[o] = p.accumulate ? p.gx[o] + acc : acc;
-                }
-    return 0;
-}
-
-static inline int pool_argmax(const float* plane, int Hs, int Ws, int ho, int wo, int k, int st, int pad) {
-    // first maximum in scan order (ATen max_pool2d: update on `val > max || isnan(val)`)
-    int best = -1; float bv = -INFINITY;
-    for (int r = 0; r < k; ++r) {
-        int h = ho * st - pad + r; if (h < 0 || h >= Hs) continue;
-        for (int s = 0; s < k; ++s) {
-            int w = wo * st - pad + s; if (w < 0 || w >= Ws) continue;
-            float v = plane[h * Ws + w];
-            if (best < 0 || v > bv || v != v) { bv = v; best = h * Ws + w; }
-        }
-    }
-    return best;
-}
-
 int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t) {
     for (int n = 0; n < p.N; ++n)
         for (int c = 0; c < p.C; ++c) {
             const float* pl = p.x + (size_t)n * p.x_nstride + (size_t)c * p.Hs * p.Ws;
             for (int ho = 0; ho < p.Ho; ++ho)
-                for (int wo = 0; wo < p.Wo; ++wo)
-                    p.y[(size_t)n * p.y_nstride + ((size_t)c * p.Ho + ho) * p.Wo + wo] =
-                        pl[pool_argmax(pl, p.Hs, p.Ws, ho, wo, p.k, p.stride, p.pad)];
+                for (int wo = 0; wo < p.Wo; ++wo) {
+                    // first maximum in scan order (ATen max_pool2d: update on `val > max || isnan(val)`)
+                    int best = -1; float bv = 0.f;
+                    for (int r = 0; r < p.k; ++r) {
+                        int h = ho * p.stride - p.pad + r; if (h < 0 || h >= p.Hs) continue;
+                        for (int s = 0; s < p.k; ++s) {
+                            int w = wo * p.stride - p.pad + s; if (w < 0 || w >= p.Ws) continue;
+                            float v = pl[h * p.Ws + w];
+                            if (best < 0 || v > bv || v != v) { bv = v; best = r * p.k + s; }
+                        }
+                    }
+                    p.y[(size_t)n * p.y_nstride + ((size_t)c * p.Ho + ho) * p.Wo + wo] = bv;
+                    p.idx[(((size_t)n * p.C + c) * p.Ho + ho) * p.Wo + wo] = (uint8_t)best;
+                }
         }
     return 0;
 }
@@ -130,9 +113,11 @@ int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t) {
             float* g = p.gx + (size_t)n * p.gx_nstride + (size_t)c * p.Hs * p.Ws;
             for (int i = 0; i < p.Hs * p.Ws; ++i) g[i] = 0.f;
             for (int ho = 0; ho < p.Ho; ++ho)
-                for (int wo = 0; wo < p.Wo; ++wo)
-                    g[pool_argmax(pl, p.Hs, p.Ws, ho, wo, p.k, p.stride, p.pad)] +=
-                        p.y[(size_t)n * p.y_nstride + ((size_t)c * p.Ho + ho) * p.Wo + wo];
+                for (int wo = 0; wo < p.Wo; ++wo) {
+                    int code = p.idx[(((size_t)n * p.C + c) * p.Ho + ho) * p.Wo + wo];
+                    int h = ho * p.stride - p.pad + code / p.k, w = wo * p.stride - p.pad + code % p.k;
+                    g[h * p.Ws + w] += p.y[(size_t)n * p.y_nstride + ((size_t)c * p.Ho + ho) * p.Wo + wo];
+                }
             if (p.mask_relu) for (int i = 0; i < p.Hs * p.Ws; ++i) if (!(pl[i] > 0.f)) g[i] = 0.f;
         }
     return 0;
@@ -216,7 +201,7 @@ int k_compose(const float* u, const float* d, float* x, int b, int f, int h, int
 }
 
 int k_adam(float* delta, float* m, float* v, const float* gx, const float* u, int64_t n, int hw, float eps,
-           float step_size, float bc2_sqrt, float beta1, float beta2, float adam_eps, i2v_stream_t) {
+           float step_size, float bc2_sqrt, float w1, float beta2, float w2, float adam_eps, i2v_stream_t) {
     for (int64_t i = 0; i < n; ++i) {
         int c = (int)((i / hw) % 3);
         float d = delta[i];
@@ -224,9 +209,9 @@ int k_adam(float* delta, float* m, float* v, const float* gx, const float* u, in
         float s = u[i] + dc;
         bool pass = d >= -eps && d <= eps && s >= 0.f && s <= 1.f;
         float g = pass ? gx[i] / STD[c] : 0.f;
-        float mm = fmaf(1.f - beta1, g - m[i], m[i]);
+        float mm = fmaf(w1, g - m[i], m[i]);
         volatile float v1 = v[i] * beta2;
-        volatile float t1 = (1.f - beta2) * g;
+        volatile float t1 = w2 * g;
         volatile float t2 = t1 * g;
         float vv = v1 + t2;
         volatile float den0 = sqrtf(vv) / bc2_sqrt;

@@ -72,7 +72,7 @@ def test_adam_step_matches_torch_optim(eng):
         st.step(d_ref, restate.compose_backward(gx, mask))
         eng.adam_step(d, m, v, dev(gx), ud, 16 / 255, 0.005, t)
         # same op order; the only freedom is fma contraction inside ATen's vectorised CPU kernels
-        assert torch.allclose(d.cpu(), d_ref, rtol=0, atol=2e-9 + 3e-7 * 0.005)
+        assert torch.allclose(d.cpu(), d_ref, rtol=2.5e-7, atol=1e-9)      # <= 2 ulp
         assert torch.allclose(m.cpu(), st.m, rtol=1e-6, atol=1e-12)
         assert torch.allclose(v.cpu(), st.v, rtol=1e-6, atol=1e-18)
 
@@ -172,7 +172,8 @@ def test_net_forward_backward_match_oracle(eng, model, depths, hw):
     net.forward(dev(x))
     for nd in net.graph.nodes:
         got = net.read_tensor(nd.dst, N).cpu().double()
-        assert torch.allclose(got, onet.tensor(nd.dst), rtol=1e-4, atol=1e-5), nd
+        ref = onet.tensor(nd.dst)
+        assert (got - ref).abs().max() <= 1e-4 * ref.abs().max() + 1e-6, nd
     hg = [torch.randn_like(f) for f in feats]
     write_hook_grads(net, feats, hg, N)
     gx = torch.empty(N, 3, hw, hw, device="cuda:0")
@@ -206,6 +207,10 @@ def test_resnet50_full_size_layers(eng):
         got = net.read_tensor(nd.dst, N).cpu()
         ref = onet.tensor(nd.dst)
         assert (got - ref).abs().max() <= 2e-4 * ref.abs().max() + 1e-5, nd
+    # gradient comparison with the oracle gated by the DEVICE's activations: 10.5M activations per
+    # frame, a handful within fp32 noise of zero would otherwise gate differently
+    onet.adopt_activations({nd.dst: net.read_tensor(nd.dst, N).cpu() for nd in net.graph.nodes})
+    feats = [onet.tensor(h) for h in hooks]
     hg = [torch.randn_like(f) for f in feats]
     write_hook_grads(net, feats, hg, N)
     gx = torch.empty(N, 3, 224, 224, device="cuda:0")
