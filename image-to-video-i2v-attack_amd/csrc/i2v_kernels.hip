@@ -64,8 +64,12 @@ template <int BD, int BP, int WD, int WP, int MODE>
 __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
     constexpr int KC = I2V_KC;
     constexpr int TD = BD / WD / 32, TP = BP / WP / 32;
-    __shared__ __attribute__((aligned(16))) float As[2][KC][BD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][KC][BP];
+    // one LDS array: operand staging [2][KC][BD] + [2][KC][BP], re-used by the epilogue as a
+    // [WD*32][BP] transpose buffer
+    constexpr int STAGE_FLOATS = 2 * KC * (BD + BP), EPI_FLOATS = WD * 32 * BP;
+    __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS];
+    float (*As)[KC][BD] = reinterpret_cast<float (*)[KC][BD]>(smem);
+    float (*Bs)[KC][BP] = reinterpret_cast<float (*)[KC][BP]>(smem + 2 * KC * BD);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wd = wave / WP, wpx = wave % WP;
@@ -206,6 +210,57 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
 
     // ---- epilogue: shift, addends, ReLU, gradient gate, NCHW store ----
     const int HoWo = p.Ho * p.Wo;
+    if (p.vec_epilogue) {
+        // Dense output (grid == output plane, plane % 4 == 0): transpose the accumulators through LDS so
+        // that each lane owns 4 consecutive pixels of one channel; addends, gate and result then move as
+        // 16-byte accesses, 512 contiguous bytes per channel row.
+        constexpr int C4 = BP / 4, RSTEP = 1024 / BP, NQ = WD * 32 / RSTEP;
+        const int c4 = t % C4, rbase = t / C4;
+        const int64_t pp = px0 + (int64_t)c4 * 4;
+        const bool pok = pp < P;
+        const int64_t n = pok ? pp / HWg : 0;
+        const int64_t poff = pp - n * HWg;
+        float (*Cs)[BP] = reinterpret_cast<float (*)[BP]>(smem);
+#pragma unroll
+        for (int i = 0; i < TD; ++i) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Cs[wd * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk][wpx * (BP / WP) + j * 32 + l31] = acc[i][j][r];
+            __syncthreads();
+            if (pok) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int row = rbase + q * RSTEP;
+                    const int cd = cd0 + (row >> 5) * (BD / WD) + i * 32 + (row & 31);
+                    if (cd >= p.Cd) continue;
+                    float4 v = *reinterpret_cast<const float4*>(&Cs[row][c4 * 4]);
+                    const int64_t o = (int64_t)cd * HoWo + poff;
+                    if (p.shift) { const float sh = p.shift[cd]; v.x += sh; v.y += sh; v.z += sh; v.w += sh; }
+                    if (p.add0) {
+                        const float4 a = *reinterpret_cast<const float4*>(p.add0 + n * p.add0_nstride + o);
+                        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                    }
+                    if (p.add1) {
+                        const float4 a = *reinterpret_cast<const float4*>(p.add1 + n * p.add1_nstride + o);
+                        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                    }
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (p.mask) {
+                        const float4 m = *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
+                        if (!(m.x > 0.f)) v.x = 0.f;
+                        if (!(m.y > 0.f)) v.y = 0.f;
+                        if (!(m.z > 0.f)) v.z = 0.f;
+                        if (!(m.w > 0.f)) v.w = 0.f;
+                    }
+                    *reinterpret_cast<float4*>(p.dst + n * p.dst_nstride + o) = v;
+                }
+            }
+        }
+        return;
+    }
     if (p.blk > 1) {
         // class-packed Cd (image gradient): cd = (ph*blk + pw)*Creal + c -> channel c at (gi*osh+ph, gj*osw+pw)
         const int Creal = p.Cd / (p.blk * p.blk);

@@ -35,6 +35,9 @@ struct I2VConvParams {
     // stored to channel c at (i*osh + ph, j*osw + pw).  Used for the gradient w.r.t. the 3-channel image,
     // where 3 output channels alone would waste 29/32 of every MFMA.
     int32_t blk;
+    // 1: output is dense over the pixel grid (osh=osw=1, Hg x Wg == Ho x Wo, plane % 4 == 0, every
+    // plane 16-byte aligned, plain addends): the epilogue may use 16-byte accesses along W
+    int32_t vec_epilogue;
 };
 
 struct I2VPoolParams {

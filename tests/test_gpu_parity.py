@@ -68,13 +68,17 @@ def test_adam_step_matches_torch_optim(eng):
     ud = dev(u)
     for t in range(1, 5):
         gx = torch.randn(N, 3, H, W, generator=gen) * 1e-5
+        d.copy_(d_ref); m.copy_(st.m); v.copy_(st.v)                 # teacher-forced: one step at a time
         _, mask = restate.compose(u, d_ref, 16 / 255)
         st.step(d_ref, restate.compose_backward(gx, mask))
         eng.adam_step(d, m, v, dev(gx), ud, 16 / 255, 0.005, t)
-        # same op order; the only freedom is fma contraction inside ATen's vectorised CPU kernels
-        assert torch.allclose(d.cpu(), d_ref, rtol=2.5e-7, atol=1e-9)      # <= 2 ulp
-        assert torch.allclose(m.cpu(), st.m, rtol=1e-6, atol=1e-12)
-        assert torch.allclose(v.cpu(), st.v, rtol=1e-6, atol=1e-18)
+        # same op order and host-side scalar preparation; the only freedom left is fma contraction inside
+        # ATen's vectorised CPU kernels: <= 2 ulp on the states, <= lr * 3e-7 on the step
+        assert torch.allclose(m.cpu(), st.m, rtol=2.5e-7, atol=0)
+        assert torch.allclose(v.cpu(), st.v, rtol=2.5e-7, atol=0)
+        assert torch.allclose(d.cpu(), d_ref, rtol=2.5e-7, atol=0.005 * 3e-7)
+    # gated-off elements never moved
+    assert torch.equal(d.cpu().view(-1)[3::11], torch.full_like(d_ref.view(-1)[3::11], 0.07))
 
 
 def test_sign_step_golden_bit_exact(eng):
