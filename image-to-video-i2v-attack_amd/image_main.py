@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""Drop-in for `/root/reference/image_main.py`: same flags and defaults (`:15-48`), same shard
+window (`:61-63`), same artefacts -- `OPT_PATH/Image-{method}-{step}-{prefix}/{label}-adv.npy`
+(float32 (3,32,224,224), normalised) and `loss_info_{batch_index}.json` (`:45,90-95`).
+
+Differences: `OPT_PATH` comes from `$I2V_OPT_PATH` (the reference hard-codes an empty constant,
+`utils.py:21`); clips come from `i2v_amd.clips` (synthetic or `--clip_dir`), not decord; under
+`torchrun` the shard defaults to (WORLD_SIZE, RANK+1) so 8 GPUs need no manual `--batch_index`;
+`--resume` skips clips whose `{label}-adv.npy` already exists."""
+import argparse
+import json
+import os
+
+import numpy as np
+import torch
+
+import image_attacks
+import TPAMI_attack
+from i2v_amd import clips
+
+OPT_PATH = os.environ.get("I2V_OPT_PATH", "")
+
+
+def arg_parse(argv=None):
+    parser = argparse.ArgumentParser(description="")
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    parser.add_argument("--batch_nums", type=int, default=world)
+    parser.add_argument("--batch_index", type=int, default=rank + 1)
+    parser.add_argument("--gpu", type=str, default="0", help="gpu device.")
+    parser.add_argument("--batch_size", type=int, default=1, metavar="N")
+    parser.add_argument("--attack_method", type=str, default="ImageGuidedAttentionMap", help="")
+    parser.add_argument("--step", type=int, default=60, metavar="N")
+    parser.add_argument("--file_prefix", type=str, default="")
+    parser.add_argument("--depth", type=int, default=1, help="1,2,3,4")
+    parser.add_argument("--lamb", type=float, default=0.1, help="")
+    parser.add_argument("--mode", type=str, default="direction", help="diff_norm\\direction")
+    parser.add_argument("--step_size", type=float, default=0.004, help="")
+    parser.add_argument("--dropout", type=float, default=0.1, help="")
+    parser.add_argument("--direction_image_model", type=str, default="resnet",
+                        help="resnet, densenet, squeezenet, vgg, alexnet (resnet50 added)")
+    # additions (not in the reference)
+    parser.add_argument("--anno", type=str, default=os.environ.get("I2V_ANNO", os.path.join(os.path.dirname(
+        os.path.abspath(__file__)), "kinetics400_attack_samples.csv")),
+                        help="sample list csv `path,gt_label,clip_index` (kinetics400_attack_samples.csv)")
+    parser.add_argument("--clip_dir", type=str, default="", help="directory of {label}-ori.npy clips")
+    parser.add_argument("--num_clips", type=int, default=400, help="use only the first N rows of the sample list")
+    parser.add_argument("--frames", type=int, default=32)
+    parser.add_argument("--hw", type=int, default=224)
+    parser.add_argument("--resume", action="store_true")
+    args = parser.parse_args(argv)
+    args.adv_path = os.path.join(OPT_PATH, "{}-{}-{}-{}".format("Image", args.attack_method, args.step, args.file_prefix))
+    os.makedirs(args.adv_path, exist_ok=True)
+    return args
+
+
+def build_attack(args):
+    if args.attack_method in ("ImageGuidedStd_Adam", "ImageGuidedFMDirection_Adam"):
+        return getattr(image_attacks, args.attack_method)([args.direction_image_model], depth=args.depth,
+                                                          step_size=args.step_size, steps=args.step)
+    if args.attack_method == "ImageGuidedFML2_Adam_MultiModels":
+        # the reference ignores --step/--step_size here (image_main.py:80): 60 steps, lr 0.005
+        names = ["resnet", "vgg", "squeezenet", "alexnet"]
+        return image_attacks.ImageGuidedFML2_Adam_MultiModels(names, depths={"resnet": 2, "vgg": 3, "squeezenet": 2, "alexnet": 3})
+    if args.attack_method == "AENS_I2V_MF":
+        names = ["resnet", "vgg", "squeezenet", "alexnet"]
+        return TPAMI_attack.AENS_I2V_MF(names, depths={n: [2, 3] for n in names}, step_size=args.step_size, steps=args.step)
+    return getattr(image_attacks, args.attack_method)          # AttributeError, as in the reference
+
+
+def main(argv=None):
+    args = arg_parse(argv)
+    if "LOCAL_RANK" not in os.environ:
+        os.environ["LOCAL_RANK"] = args.gpu.split(",")[0]
+    print(args)
+    total = clips.num_batches(args.batch_size, args.anno, args.clip_dir, args.num_clips)
+    nums_contained = int(total / args.batch_nums)                      # int(400 / batch_nums), :61
+    left = (args.batch_index - 1) * nums_contained
+    right = args.batch_index * nums_contained
+    attack_method = build_attack(args)
+    for step, (val_batch, val_label, video_names) in enumerate(
+            clips.batches(args.batch_size, args.anno, args.clip_dir, args.frames, args.hw, args.num_clips)):
+        if not (left <= step < right):
+            continue
+        if args.resume and all(os.path.exists(os.path.join(args.adv_path, f"{l.item()}-adv.npy")) for l in val_label):
+            continue
+        print("Running {}, {}/{}".format(args.attack_method, step + 1, total))
+        adv_batches = attack_method(val_batch, val_label, video_names)
+        if isinstance(adv_batches, tuple):                             # AENS returns (adv, time, costs)
+            adv_batches = adv_batches[0]
+        for ind, label in enumerate(val_label):
+            np.save(os.path.join(args.adv_path, "{}-adv".format(label.item())), adv_batches[ind].detach().cpu().numpy())
+    with open(os.path.join(args.adv_path, "loss_info_{}.json".format(args.batch_index)), "w") as opt:
+        json.dump(attack_method.loss_info, opt)
+
+
+if __name__ == "__main__":
+    main()

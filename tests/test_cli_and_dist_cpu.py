@@ -1,0 +1,87 @@
+"""CPU: the drop-in CLI's file contract (image_main.py) and the multi-process path (gloo,
+world_size 2) -- both on the host simulation of the kernel backend, tiny backbones."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.hostsim_util import hostsim_engine
+
+
+@pytest.fixture
+def tiny_engine(monkeypatch):
+    from i2v_amd import attacks, graphs
+    eng = hostsim_engine()
+    monkeypatch.setitem(attacks._ENGINES, attacks.default_device(), eng)
+    monkeypatch.setattr(graphs, "build", graphs.build_tiny)
+    return eng
+
+
+def test_image_main_file_contract(tiny_engine, tmp_path, monkeypatch):
+    """`{label}-adv.npy` per clip (float32 (3,f,h,w), normalised), `loss_info_{i}.json`, shard
+    window arithmetic of /root/reference/image_main.py:45,61-63,90-95."""
+    monkeypatch.setenv("I2V_OPT_PATH", str(tmp_path))
+    import importlib
+    import image_main
+    importlib.reload(image_main)
+    common = ["--attack_method", "ImageGuidedFMDirection_Adam", "--step", "2", "--step_size", "0.005", "--depth", "2",
+              "--direction_image_model", "resnet", "--num_clips", "4", "--frames", "2", "--hw", "64",
+              "--file_prefix", "t", "--batch_nums", "2"]
+    image_main.main(common + ["--batch_index", "2"])
+    out = tmp_path / "Image-ImageGuidedFMDirection_Adam-2-t"
+    assert sorted(os.listdir(out)) == ["2-adv.npy", "3-adv.npy", "loss_info_2.json"]     # second half of 4 clips
+    adv = np.load(out / "2-adv.npy")
+    assert adv.dtype == np.float32 and adv.shape == (3, 2, 64, 64)
+    info = json.load(open(out / "loss_info_2.json"))
+    name = list(info)[0]
+    assert list(info[name]) == ["0", "1"] and float(info[name]["0"]["cost"]) > 1.9
+    # evaluator-side label parsing (reference.py:43): int(fname.split('-')[0])
+    assert int("2-adv.npy".split("-")[0]) == 2
+    image_main.main(common + ["--batch_index", "1", "--resume"])
+    assert sorted(os.listdir(out)) == ["0-adv.npy", "1-adv.npy", "2-adv.npy", "3-adv.npy", "loss_info_1.json",
+                                       "loss_info_2.json"]
+    # default attack name does not exist, as in the reference (image_main.py:25)
+    with pytest.raises(AttributeError):
+        image_main.main(["--num_clips", "1"])
+
+
+def test_run_image_guided_plan():
+    import run_image_guided
+    jobs = run_image_guided.plan("0", 1)
+    assert len(jobs) == 25 + 16 + 8 + 1
+    assert any("ImageGuidedFML2_Adam_MultiModels" in j[0] for j in jobs)
+    assert jobs[0][1] == "Image-ImageGuidedFMDirection_Adam-20-resnet_step_size_0.001_paper_study"
+
+
+def _aens_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from i2v_amd import attacks, graphs
+    from tests import golden_util as gu
+    fx = gu.load("aens_2x2_f64")
+    vid = gu.videos_of(fx)
+    atk = attacks.AENS_I2V_MF(fx["models"], depths=fx["depth"], step_size=fx["lr"], steps=fx["steps"],
+                              engine=hostsim_engine(), graph_builder=graphs.build_tiny, **fx["kw"])
+    shard = vid[rank:rank + 1]                                            # one clip per rank
+    adv, _, costs = atk(shard, torch.zeros(1, dtype=torch.long), [f"c{rank}"])
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), adv=adv.numpy(), costs=costs, weights=np.stack(atk.weights))
+    dist.destroy_process_group()
+
+
+def test_aens_two_ranks_match_single_device(tmp_path):
+    """2 ranks x 1 clip with the per-step all-reduce == 1 device x 2 clips (the golden fixture):
+    same weight trajectory and cost (TPAMI_attack.py:265,289-297), same adversarial clips."""
+    from tests import golden_util as gu
+    fx = gu.load("aens_2x2_f64")
+    port = 29500 + os.getpid() % 2000
+    mp.start_processes(_aens_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    np.testing.assert_allclose(r0["weights"], fx["weights"], rtol=1e-4)
+    np.testing.assert_array_equal(r0["weights"], r1["weights"])
+    np.testing.assert_allclose(r0["costs"], fx["cost_saved"], rtol=2e-4)
+    adv = np.concatenate([r0["adv"], r1["adv"]])
+    assert np.abs(adv - fx["adv"]).mean() < 5e-3
