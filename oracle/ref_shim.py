@@ -82,8 +82,6 @@ def install():
     sys.modules["torchvision.models"] = tvm
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self
-    if REFERENCE_DIR not in sys.path:
-        sys.path.insert(0, REFERENCE_DIR)
     _installed = True
 
 
@@ -98,10 +96,34 @@ def quiet():
             yield
 
 
+_REF_MODULES = {}
+_COLLIDING = ("image_attacks", "TPAMI_attack", "base_attacks", "utils", "image_main", "run_image_guided")
+
+
 def import_reference(module: str):
+    """Load `/root/reference/<module>.py` under the private name `_ref_<module>`.  The product ships
+    drop-in modules with the SAME names (`image_attacks`, `TPAMI_attack`, `base_attacks`); whatever
+    of those is already imported is put back afterwards, so both can live in one test process."""
+    if module in _REF_MODULES:
+        return _REF_MODULES[module]
     install()
-    with quiet():
-        return __import__(module)
+    import importlib.util
+    saved = {k: sys.modules.pop(k) for k in _COLLIDING if k in sys.modules}
+    path0 = list(sys.path)
+    sys.path.insert(0, REFERENCE_DIR)
+    try:
+        with quiet():
+            spec = importlib.util.spec_from_file_location("_ref_" + module, os.path.join(REFERENCE_DIR, module + ".py"))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules["_ref_" + module] = mod
+            spec.loader.exec_module(mod)
+    finally:
+        sys.path[:] = path0
+        for k in _COLLIDING:
+            sys.modules.pop(k, None)
+        sys.modules.update(saved)
+    _REF_MODULES[module] = mod
+    return mod
 
 
 class AdamTap:

@@ -44,14 +44,10 @@ def test_ilaf_matches_reference_live():
     with ref_shim.quiet():
         ref_atk = ia.ILAF(model, "tpn", step_size=0.005, steps=3)
         ref = ref_atk(adv0.clone(), ori.clone(), torch.zeros(1, dtype=torch.long), ["v"]).detach()
-    model2 = torch.nn.Sequential(*[m for m in model])          # fresh hooks
-    model2.layer2 = model2[1]
-    ours = sa.ILAF(model2, "tpn", step_size=0.005, steps=3, engine=hostsim_engine())
+    ours = sa.ILAF(model, "tpn", step_size=0.005, steps=3, engine=hostsim_engine())
     got = ours(adv0.clone(), ori.clone(), torch.zeros(1, dtype=torch.long), ["v"]).detach()
     assert got.shape == ref.shape
-    # the toy model's gradient is ~0 on many pixels; sign(g) of those is fp noise in BOTH runs, so a
-    # small fraction of pixels may take the opposite +-lr step (same chaotic regime as SURVEY.md 0.5)
-    assert ((got - ref).abs() > 1e-5).float().mean() < 0.02
+    assert (got - ref).abs().max() < 1e-6
     assert ours.loss_info["v"][0]["cost"] == ref_atk.loss_info["v"][0]["cost"]
     c_ours = np.array([float(ours.loss_info["v"][i]["cost"]) for i in range(3)])
     c_ref = np.array([float(ref_atk.loss_info["v"][i]["cost"]) for i in range(3)])
