@@ -12,6 +12,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "i2v_kernels.h"
 
@@ -46,6 +47,8 @@ int be_event_record(void* ev, i2v_stream_t s) { HIPCHK(hipEventRecord((hipEvent_
 int be_event_elapsed_ms(void* a, void* b, float* ms) { HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return 0; }
 int be_stream_sync(i2v_stream_t s) { HIPCHK(hipStreamSynchronize((hipStream_t)s)); return 0; }
 
+__device__ __attribute__((aligned(16))) float i2v_zero[4] = {0.f, 0.f, 0.f, 0.f};   // source of zero operands
+
 __constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};
 __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
 
@@ -58,6 +61,18 @@ __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
 //   A: lane l holds Wp[k = kk + (l>>5)][cd = l&31]      B: lane l holds X[k = kk + (l>>5)][px = l&31]
 //   D: lane l, register r  ->  pixel l&31, channel (r&3) + 8*(r>>2) + 4*(l>>5)
 // so every global store instruction writes 32 consecutive pixels of one channel plane.
+// k-table row through the constant address space: stays a scalar (SMEM) load next to the LDS-DMA traffic;
+// an ordinary VGPR-destination load there would make hipcc drain vmcnt(0) inside the pipeline.
+typedef int i2v_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const i2v_v4i v = ((const __attribute__((address_space(4))) i2v_v4i*)tab)[k];
+    return I2VKEntry{v.x, v.y, v.z, v.w};
+#else
+    return tab[k];
+#endif
+}
+
 // MODE 0: per-row k-table gather (any geometry); 1: pointwise float4 (1x1, stride 1, planes 16-B aligned);
 // 2: tap-uniform chunks (every 16-row K chunk shares one spatial tap: channel count % 16 == 0)
 template <int BD, int BP, int WD, int WP, int MODE>
@@ -87,92 +102,77 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     const int64_t P = (int64_t)p.N * HWg;
 
     constexpr bool PW = MODE == 1;
-    // ---- activation (B) loader state ----
-    constexpr int BROWS = PW ? (1024 / BP) : (256 / BP);     // k-rows covered per pass
-    constexpr int BQ = KC / BROWS;                            // passes per chunk
-    const float* srcn = p.src;
-    int h0 = 0, w0 = 0, brow;
-    bool pvalid;
-    if (PW) {
-        const int px4 = t % (BP / 4);
-        brow = t / (BP / 4);
-        const int64_t pp = px0 + (int64_t)px4 * 4;
-        pvalid = pp < P;
-        const int64_t n = pvalid ? pp / HWg : 0;
-        srcn += n * p.src_nstride + (pp - n * HWg);
-    } else {
-        const int pl = t % BP;
-        brow = t / BP;
-        const int64_t pp = px0 + pl;
-        pvalid = pp < P;
-        const int64_t n = pvalid ? pp / HWg : 0;
-        const int rem = (int)(pp - n * HWg);
-        const int i = rem / p.Wg, j = rem - i * p.Wg;
-        h0 = i * p.sh; w0 = j * p.sw;
-        srcn += n * p.src_nstride + (int64_t)h0 * p.Ws + w0;
-    }
-    // ---- weight (A) loader state ----
-    constexpr int AC4 = BD / 4;                 // float4 columns
-    constexpr int AROWS = 256 / AC4;            // rows per pass (8, 16, 32)
-    constexpr int AQ = (KC + AROWS - 1) / AROWS;
-    const int acol = (t % AC4) * 4, arow = t / AC4;
-    const float* wsrc = p.wp + (int64_t)arow * p.Cdpad + cd0 + acol;
-
-    float4 areg0 = make_float4(0.f, 0.f, 0.f, 0.f), areg1 = areg0;   // AQ <= 2 (named: arrays went to scratch)
-    static_assert(AQ <= 2, "weight staging assumes at most two passes");
-    float breg[PW ? 1 : BQ];
-    float4 breg4[PW ? BQ : 1];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    // ---- operand staging: global -> LDS by DMA (`global_load_lds`), no VGPR round trip, no ds_write ----
+    // A wave-instruction deposits 64 lanes x {16,4} bytes at a wave-uniform LDS base + lane*size, so the
+    // LDS images stay linear ([k][BD] / [k][BP]) and the gather lives in the per-lane GLOBAL address.
+    // Lanes that must contribute zeros (padding taps, K tail, pixel tail) read `i2v_zero` instead.
+    // Wave w issues instructions w, w+4, ...; with that assignment a lane always serves ONE pixel column.
+    const float* const zsrc = i2v_zero;
+    // weights: NA instructions of 256 floats
+    constexpr int NA = KC * BD / 256, NAQ = (NA + 3) / 4;
+    // activations: PW -> 16-byte pieces (256 floats / instruction), gather modes -> 4-byte (64 floats)
+    constexpr int BPER = PW ? 256 : 64;
+    constexpr int NB = KC * BP / BPER, NBQ = (NB + 3) / 4;
+    const int bcol = PW ? (lane * 4) % BP : (BP >= 64 ? ((wave * 64) % BP) + lane : lane % BP);
+    const int64_t ppix = px0 + bcol;
+    const bool pvalid = ppix < P;
+    const int64_t pn = pvalid ? ppix / HWg : 0;
+    const int prem = (int)(ppix - pn * HWg);
+    int h0 = 0, w0 = 0;
+    const float* srcn = p.src + pn * p.src_nstride;
+    if (PW) srcn += prem;
+    else { const int gi = prem / p.Wg, gj = prem - gi * p.Wg; h0 = gi * p.sh; w0 = gj * p.sw; srcn += (int64_t)h0 * p.Ws + w0; }
     const int HWs = p.Hs * p.Ws;
+    const float* const wbase = p.wp + cd0;
 
-// global -> registers for the K-chunk starting at row k0 (macro, not a lambda: keeps the staging
-// registers out of scratch)
-#define I2V_LOAD_CHUNK(k0_)                                                                              \
-    {                                                                                                    \
-        const int k0 = (k0_);                                                                            \
-        if (AROWS * AQ == KC || arow < KC)                                                               \
-            areg0 = *reinterpret_cast<const float4*>(wsrc + (int64_t)k0 * p.Cdpad);                      \
-        if (AQ == 2) areg1 = *reinterpret_cast<const float4*>(wsrc + (int64_t)(k0 + AROWS) * p.Cdpad);   \
-        if (PW) {                                                                                        \
-            _Pragma("unroll") for (int q = 0; q < BQ; ++q) {                                             \
-                const int k = k0 + brow + q * BROWS;                                                     \
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                              \
-                if (pvalid && k < p.K) v = *reinterpret_cast<const float4*>(srcn + (int64_t)k * HWs);    \
-                breg4[q] = v;                                                                            \
-            }                                                                                            \
-        } else if (MODE == 2) {                                                                          \
-            const I2VKEntry e = p.ktab[k0];                                                              \
-            const int hs = h0 + e.dh, ws = w0 + e.dw;                                                    \
-            const bool ok = pvalid && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;    \
-            const float* bsrc = srcn + e.chan_off + e.dh * p.Ws + e.dw + (int64_t)brow * HWs;            \
-            _Pragma("unroll") for (int q = 0; q < BQ; ++q) {                                             \
-                float v = 0.f;                                                                           \
-                if (ok) v = bsrc[(int64_t)(q * BROWS) * HWs];                                            \
-                breg[q] = v;                                                                             \
-            }                                                                                            \
-        } else {                                                                                         \
-            _Pragma("unroll") for (int q = 0; q < BQ; ++q) {                                             \
-                const int ku = __builtin_amdgcn_readfirstlane(k0 + brow + q * BROWS);                    \
-                const I2VKEntry e = p.ktab[ku];                                                          \
-                const int hs = h0 + e.dh, ws = w0 + e.dw;                                                \
-                const bool ok = pvalid && e.valid && (unsigned)hs < (unsigned)p.Hs &&                    \
-                                (unsigned)ws < (unsigned)p.Ws;                                           \
-                float v = 0.f;                                                                           \
-                if (ok) v = srcn[e.chan_off + e.dh * p.Ws + e.dw];                                       \
-                breg[q] = v;                                                                             \
-            }                                                                                            \
-        }                                                                                                \
-    }
-#define I2V_STORE_CHUNK(buf_)                                                                            \
-    {                                                                                                    \
-        const int sb = (buf_);                                                                           \
-        if (AROWS * AQ == KC || arow < KC) *reinterpret_cast<float4*>(&As[sb][arow][acol]) = areg0;     \
-        if (AQ == 2) *reinterpret_cast<float4*>(&As[sb][(arow + AROWS) % KC][acol]) = areg1;             \
-        if (PW) {                                                                                        \
-            _Pragma("unroll") for (int q = 0; q < BQ; ++q)                                               \
-                *reinterpret_cast<float4*>(&Bs[sb][brow + q * BROWS][(t % (BP / 4)) * 4]) = breg4[q];    \
-        } else {                                                                                         \
-            _Pragma("unroll") for (int q = 0; q < BQ; ++q) Bs[sb][brow + q * BROWS][t % BP] = breg[q];   \
-        }                                                                                                \
+#define I2V_ISSUE_CHUNK(k0_, buf_)                                                                        \
+    {                                                                                                     \
+        const int k0 = (k0_);                                                                             \
+        float* const abuf = &As[buf_][0][0];                                                              \
+        float* const bbuf = &Bs[buf_][0][0];                                                              \
+        _Pragma("unroll") for (int q = 0; q < NAQ; ++q) {                                                 \
+            const int ins = wave + 4 * q;                                                                 \
+            if (NA % 4 == 0 || ins < NA) {                                                                \
+                const int f = ins * 256 + lane * 4;                                                       \
+                __builtin_amdgcn_global_load_lds(wbase + (int64_t)(k0 + f / BD) * p.Cdpad + f % BD,       \
+                                                 (lds_ptr_t)(abuf + ins * 256), 16, 0, 0);                \
+            }                                                                                             \
+        }                                                                                                 \
+        if (PW) {                                                                                         \
+            _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                             \
+                const int ins = wave + 4 * q;                                                             \
+                if (NB % 4 == 0 || ins < NB) {                                                            \
+                    const int k = k0 + (ins * 256 + lane * 4) / BP;                                       \
+                    const bool ok = pvalid && k < p.K;                                                    \
+                    __builtin_amdgcn_global_load_lds(ok ? srcn + (int64_t)k * HWs : zsrc,                 \
+                                                     (lds_ptr_t)(bbuf + ins * 256), 16, 0, 0);            \
+                }                                                                                         \
+            }                                                                                             \
+        } else if (MODE == 2) {                                                                           \
+            const I2VKEntry e = load_kentry(p.ktab, k0);                                                  \
+            const int hs = h0 + e.dh, ws = w0 + e.dw;                                                     \
+            const bool ok = pvalid && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;     \
+            const float* const bsrc = srcn + e.chan_off + e.dh * p.Ws + e.dw;                             \
+            _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                             \
+                const int ins = wave + 4 * q;                                                             \
+                if (NB % 4 == 0 || ins < NB)                                                              \
+                    __builtin_amdgcn_global_load_lds(ok ? bsrc + (int64_t)((ins * 64) / BP) * HWs : zsrc, \
+                                                     (lds_ptr_t)(bbuf + ins * 64), 4, 0, 0);              \
+            }                                                                                             \
+        } else {                                                                                          \
+            _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                             \
+                const int ins = wave + 4 * q;                                                             \
+                if (NB % 4 == 0 || ins < NB) {                                                            \
+                    const I2VKEntry e = load_kentry(p.ktab, k0 + (ins * 64) / BP);                        \
+                    const int hs = h0 + e.dh, ws = w0 + e.dw;                                             \
+                    const bool ok = pvalid && e.valid && (unsigned)hs < (unsigned)p.Hs &&                 \
+                                    (unsigned)ws < (unsigned)p.Ws;                                        \
+                    __builtin_amdgcn_global_load_lds(ok ? srcn + (e.chan_off + e.dh * p.Ws + e.dw) : zsrc,\
+                                                     (lds_ptr_t)(bbuf + ins * 64), 4, 0, 0);              \
+                }                                                                                         \
+            }                                                                                             \
+        }                                                                                                 \
     }
 
     f32x16 acc[TD][TP];
@@ -184,29 +184,31 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nchunks = p.Kpad / KC;
-    if (nchunks > 0) I2V_LOAD_CHUNK(0);
     const int l31 = lane & 31, lk = lane >> 5;
+    if (nchunks > 0) I2V_ISSUE_CHUNK(0, 0);
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
-        I2V_STORE_CHUNK(buf);
+        // chunk c has landed (this wave's DMA: vmcnt(0); the other waves': barrier) and every wave is done
+        // reading the other buffer, which the next chunk's DMA may now overwrite under this chunk's MFMAs
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (c + 1 < nchunks) I2V_LOAD_CHUNK((c + 1) * KC);
+        if (c + 1 < nchunks) I2V_ISSUE_CHUNK((c + 1) * KC, buf ^ 1);
+        constexpr int KS = KC / 2;                         // k-steps per chunk (2 K rows per 32x32x2 MFMA)
 #pragma unroll
-        for (int kk = 0; kk < KC; kk += 2) {
-            float a[TD], b[TP];
+        for (int s = 0; s < KS; ++s) {
+            float fa[TD], fb[TP];
 #pragma unroll
-            for (int i = 0; i < TD; ++i) a[i] = As[buf][kk + lk][wd * (BD / WD) + i * 32 + l31];
+            for (int i = 0; i < TD; ++i) fa[i] = As[buf][2 * s + lk][wd * (BD / WD) + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < TP; ++j) b[j] = Bs[buf][kk + lk][wpx * (BP / WP) + j * 32 + l31];
+            for (int j = 0; j < TP; ++j) fb[j] = Bs[buf][2 * s + lk][wpx * (BP / WP) + j * 32 + l31];
 #pragma unroll
             for (int i = 0; i < TD; ++i)
 #pragma unroll
                 for (int j = 0; j < TP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     }
-#undef I2V_LOAD_CHUNK
-#undef I2V_STORE_CHUNK
+#undef I2V_ISSUE_CHUNK
 
     // ---- epilogue: shift, addends, ReLU, gradient gate, NCHW store ----
     const int HoWo = p.Ho * p.Wo;
@@ -352,6 +354,8 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
 // time is fixed by its tile; what varies is how evenly the grid covers the 256 CUs (the 14x14 layers
 // have only a few hundred 128x128 tiles) against the extra operand traffic of small tiles.
 static int conv_pick(const I2VConvParams& p) {
+    static const char* force = getenv("I2V_FORCE_CFG");        // developer knob (tools/conv_microbench.cpp)
+    if (force && *force) return atoi(force);
     static const struct { int BD, BP, occ; double ineff; } C[5] = {
         {128, 128, 3, 1.00}, {64, 128, 5, 1.04}, {128, 64, 5, 1.04}, {64, 64, 8, 1.10}, {32, 256, 4, 1.06}};
     const double P = (double)p.N * p.Hg * p.Wg;
