@@ -418,7 +418,7 @@ struct Planner {
             if (P.Hg <= 0 || P.Wg <= 0) continue;
             Launch l; l.kind = L_CONV; conv_common(l.conv, P);
             I2VConvParams& p = l.conv;
-            p.src = dz.p; p.src_nstride = dz.nstride; p.Hs = dz.H; p.Ws = dz.W;
+            p.src = dz.p; p.src_nstride = dz.nstride; p.Hs = dz.H; p.Ws = dz.W; p.Cs = dz.C;
             p.Hg = P.Hg; p.Wg = P.Wg; p.sh = 1; p.sw = 1;
             p.dst = out.p; p.dst_nstride = out.nstride;
             if (compact) { p.Ho = P.Hg; p.Wo = P.Wg; p.osh = p.osw = 1; p.oh0 = p.ow0 = 0; }
@@ -507,7 +507,7 @@ struct Planner {
                 const Buffer& sb = n.bufs[n.tens[c.src].buf];
                 if (c.src == n.input) { l.src_is_input = true; p.src = nullptr; p.src_nstride = (int64_t)sb.C * sb.H * sb.W; }
                 else { View s = view(c.src, false); p.src = s.p; p.src_nstride = s.nstride; }
-                p.Hs = sb.H; p.Ws = sb.W; p.Hg = d.H; p.Wg = d.W; p.sh = p.sw = c.stride;
+                p.Hs = sb.H; p.Ws = sb.W; p.Cs = c.cin; p.Hg = d.H; p.Wg = d.W; p.sh = p.sw = c.stride;
                 p.dst = d.p; p.dst_nstride = d.nstride; p.Ho = d.H; p.Wo = d.W; p.osh = p.osw = 1;
                 p.shift = nd.shift_d; p.relu = c.relu;
                 if (c.residual >= 0) { View r = view(c.residual, false); p.add0 = r.p; p.add0_nstride = r.nstride; p.add0_stride = 1; }
@@ -555,7 +555,7 @@ struct Planner {
                     Launch l; l.kind = L_IMGGRAD; conv_common(l.conv, nd.img);
                     const Buffer& ib = n.bufs[n.tens[n.input].buf];
                     I2VConvParams& p = l.conv;
-                    p.src = dz.p; p.src_nstride = dz.nstride; p.Hs = dz.H; p.Ws = dz.W;
+                    p.src = dz.p; p.src_nstride = dz.nstride; p.Hs = dz.H; p.Ws = dz.W; p.Cs = dz.C;
                     p.Hg = nd.img.Hg; p.Wg = nd.img.Wg; p.sh = p.sw = nd.img_sh;
                     p.dst = nullptr; p.dst_nstride = (int64_t)ib.C * ib.H * ib.W; p.Ho = ib.H; p.Wo = ib.W;
                     p.osh = p.osw = nd.img_blk; p.blk = nd.img_blk;
@@ -658,21 +658,32 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int frames, cons
         if (tl && (l.kind == L_CONV || l.kind == L_IMGGRAD)) { tl->Cd = l.conv.Cd; tl->K = l.conv.K; tl->HWg = l.conv.Hg * l.conv.Wg; tl->frames = frames; tl->pw = l.conv.pointwise; }
         struct Stop { TimedLaunch* t; i2v_stream_t s; ~Stop() { if (t) be_event_record(t->stop, s); } } stop{tl, s};
         switch (l.kind) {
-            case L_CONV: {
-                I2VConvParams p = l.conv; p.N = frames;
+            case L_CONV:
+            case L_IMGGRAD: {
+                I2VConvParams p = l.conv;
                 if (l.src_is_input) p.src = x;
-                if (p.N * p.Hg * p.Wg == 0) break;
+                if (l.kind == L_IMGGRAD) { p.dst = gx; if (accumulate) { p.add1 = gx; p.add1_nstride = p.dst_nstride; } }
+                if (frames * p.Hg * p.Wg == 0) break;
                 p.vec_epilogue = (p.blk <= 1 && p.osh == 1 && p.osw == 1 && p.oh0 == 0 && p.ow0 == 0 && p.Hg == p.Ho &&
                                   p.Wg == p.Wo && (p.Ho * p.Wo) % 4 == 0 && p.add0_stride == 1 && p.dst_nstride % 4 == 0 &&
                                   p.add0_nstride % 4 == 0 && p.add1_nstride % 4 == 0 && p.mask_nstride % 4 == 0 &&
                                   (((uintptr_t)p.dst | (uintptr_t)p.add0 | (uintptr_t)p.add1 | (uintptr_t)p.mask) & 15) == 0)
                                      ? 1 : 0;
-                CHECK_BE(k_conv(p, s));
-            } break;
-            case L_IMGGRAD: {
-                I2VConvParams p = l.conv; p.N = frames; p.dst = gx;
-                if (accumulate) { p.add1 = gx; p.add1_nstride = p.dst_nstride; }
-                CHECK_BE(k_conv(p, s));
+                // the source is addressed through a buffer descriptor with 32-bit offsets: keep the span of
+                // one launch below 2 GiB by walking the frames in slices
+                const int64_t plane_bytes = (int64_t)p.Cs * p.Hs * p.Ws * 4, stride_bytes = p.src_nstride * 4;
+                int64_t per = plane_bytes >= (1ll << 31) ? 0 : 1 + ((1ll << 31) - 1 - plane_bytes) / stride_bytes;
+                if (per < 1) return fail("one frame of a convolution input exceeds 2 GiB");
+                for (int f0 = 0; f0 < frames; f0 += (int)per) {
+                    I2VConvParams q = p;
+                    q.N = frames - f0 < per ? frames - f0 : (int)per;
+                    q.src += (int64_t)f0 * p.src_nstride; q.dst += (int64_t)f0 * p.dst_nstride;
+                    if (q.add0) q.add0 += (int64_t)f0 * p.add0_nstride;
+                    if (q.add1) q.add1 += (int64_t)f0 * p.add1_nstride;
+                    if (q.mask) q.mask += (int64_t)f0 * p.mask_nstride;
+                    q.src_span_bytes = (int32_t)((int64_t)(q.N - 1) * stride_bytes + plane_bytes);
+                    CHECK_BE(k_conv(q, s));
+                }
             } break;
             case L_POOLF: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool_fwd(p, s)); } break;
             case L_POOLB: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool_bwd(p, s)); } break;

@@ -47,8 +47,6 @@ int be_event_record(void* ev, i2v_stream_t s) { HIPCHK(hipEventRecord((hipEvent_
 int be_event_elapsed_ms(void* a, void* b, float* ms) { HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return 0; }
 int be_stream_sync(i2v_stream_t s) { HIPCHK(hipStreamSynchronize((hipStream_t)s)); return 0; }
 
-__device__ __attribute__((aligned(16))) float i2v_zero[4] = {0.f, 0.f, 0.f, 0.f};   // source of zero operands
-
 __constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};
 __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
 
@@ -77,6 +75,7 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 // 2: tap-uniform chunks (every 16-row K chunk shares one spatial tap: channel count % 16 == 0)
 template <int BD, int BP, int WD, int WP, int MODE>
 __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
+#if defined(__HIP_DEVICE_COMPILE__)      // buffer-resource types and LDS-DMA builtins exist only in the device pass
     constexpr int KC = I2V_KC;
     constexpr int TD = BD / WD / 32, TP = BP / WP / 32;
     // one LDS array: operand staging [2][KC][BD] + [2][KC][BP], re-used by the epilogue as a
@@ -103,28 +102,48 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
 
     constexpr bool PW = MODE == 1;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    // ---- operand staging: global -> LDS by DMA (`global_load_lds`), no VGPR round trip, no ds_write ----
-    // A wave-instruction deposits 64 lanes x {16,4} bytes at a wave-uniform LDS base + lane*size, so the
-    // LDS images stay linear ([k][BD] / [k][BP]) and the gather lives in the per-lane GLOBAL address.
-    // Lanes that must contribute zeros (padding taps, K tail, pixel tail) read `i2v_zero` instead.
+    // ---- operand staging: global -> LDS by buffer DMA (`buffer_load ... lds`) -------------------------
+    // No VGPR round trip and no ds_write.  A wave-instruction deposits 64 lanes x {16,4} bytes at a
+    // wave-uniform LDS base + lane*size, so the LDS images stay linear ([k][BD] / [k][BP]) and the im2col
+    // gather lives in the per-lane 32-bit buffer offset.  Lanes that must contribute zeros (padding taps,
+    // K tail, pixel tail) get an out-of-range offset: the buffer range check makes the DMA write 0.0 for
+    // them (probed on gfx950: tools/bufdma_test.cpp), so the steady-state cost per chunk is a handful of
+    // VALU instructions instead of 64-bit pointer arithmetic and pointer selects per load.
     // Wave w issues instructions w, w+4, ...; with that assignment a lane always serves ONE pixel column.
-    const float* const zsrc = i2v_zero;
-    // weights: NA instructions of 256 floats
-    constexpr int NA = KC * BD / 256, NAQ = (NA + 3) / 4;
-    // activations: PW -> 16-byte pieces (256 floats / instruction), gather modes -> 4-byte (64 floats)
-    constexpr int BPER = PW ? 256 : 64;
+    constexpr unsigned OOB = 0x80000000u;                     // >= num_records (spans are kept < 2 GiB)
+    const int wv = __builtin_amdgcn_readfirstlane(wave);      // scalar copy: LDS bases / M0 stay in SGPRs
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.wp, 0, p.Kpad * p.Cdpad * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_span_bytes, 0x00020000);
+    constexpr int NA = KC * BD / 256, NAQ = (NA + 3) / 4;     // weights: instructions of 256 floats
+    constexpr int BPER = PW ? 256 : 64;                       // activations: 16-byte or 4-byte pieces
     constexpr int NB = KC * BP / BPER, NBQ = (NB + 3) / 4;
     const int bcol = PW ? (lane * 4) % BP : (BP >= 64 ? ((wave * 64) % BP) + lane : lane % BP);
     const int64_t ppix = px0 + bcol;
     const bool pvalid = ppix < P;
     const int64_t pn = pvalid ? ppix / HWg : 0;
     const int prem = (int)(ppix - pn * HWg);
-    int h0 = 0, w0 = 0;
-    const float* srcn = p.src + pn * p.src_nstride;
-    if (PW) srcn += prem;
-    else { const int gi = prem / p.Wg, gj = prem - gi * p.Wg; h0 = gi * p.sh; w0 = gj * p.sw; srcn += (int64_t)h0 * p.Ws + w0; }
     const int HWs = p.Hs * p.Ws;
-    const float* const wbase = p.wp + cd0;
+    int h0 = 0, w0 = 0;
+    unsigned xoff;                                            // byte offset of this lane's pixel in `src`
+    if (PW) xoff = (unsigned)((pn * p.src_nstride + prem) * 4);
+    else {
+        const int gi = prem / p.Wg, gj = prem - gi * p.Wg;
+        h0 = gi * p.sh; w0 = gj * p.sw;
+        xoff = (unsigned)((pn * p.src_nstride + (int64_t)h0 * p.Ws + w0) * 4);
+    }
+    if (!pvalid) xoff = OOB;
+    unsigned aoff[NAQ];
+#pragma unroll
+    for (int q = 0; q < NAQ; ++q) {
+        const int f = (wave + 4 * q) * 256 + lane * 4;
+        aoff[q] = (unsigned)(((f / BD) * p.Cdpad + f % BD + cd0) * 4);
+    }
+    unsigned boff[PW ? NBQ : 1];                              // PW: + row inside the chunk (lane dependent)
+    if (PW) {
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) boff[q] = pvalid ? xoff + (unsigned)((((wave + 4 * q) * 256 + lane * 4) / BP) * HWs * 4) : OOB;
+    }
 
 #define I2V_ISSUE_CHUNK(k0_, buf_)                                                                        \
     {                                                                                                     \
@@ -132,44 +151,42 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         float* const abuf = &As[buf_][0][0];                                                              \
         float* const bbuf = &Bs[buf_][0][0];                                                              \
         _Pragma("unroll") for (int q = 0; q < NAQ; ++q) {                                                 \
-            const int ins = wave + 4 * q;                                                                 \
-            if (NA % 4 == 0 || ins < NA) {                                                                \
-                const int f = ins * 256 + lane * 4;                                                       \
-                __builtin_amdgcn_global_load_lds(wbase + (int64_t)(k0 + f / BD) * p.Cdpad + f % BD,       \
-                                                 (lds_ptr_t)(abuf + ins * 256), 16, 0, 0);                \
-            }                                                                                             \
+            const int ins = wv + 4 * q;                                                                   \
+            if (NA % 4 == 0 || ins < NA)                                                                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(abuf + ins * 256), 16, aoff[q], \
+                                                         k0 * p.Cdpad * 4, 0, 0);                         \
         }                                                                                                 \
         if (PW) {                                                                                         \
             _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                             \
-                const int ins = wave + 4 * q;                                                             \
+                const int ins = wv + 4 * q;                                                               \
                 if (NB % 4 == 0 || ins < NB) {                                                            \
-                    const int k = k0 + (ins * 256 + lane * 4) / BP;                                       \
-                    const bool ok = pvalid && k < p.K;                                                    \
-                    __builtin_amdgcn_global_load_lds(ok ? srcn + (int64_t)k * HWs : zsrc,                 \
-                                                     (lds_ptr_t)(bbuf + ins * 256), 16, 0, 0);            \
+                    unsigned v = boff[q];                                                                 \
+                    if (k0 + KC > p.K)       /* K tail (uniform test): rows >= K contribute zeros */      \
+                        v = (k0 + ((wave + 4 * q) * 256 + lane * 4) / BP < p.K) ? v : OOB;                \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 256), 16, v,  \
+                                                             k0 * HWs * 4, 0, 0);                         \
                 }                                                                                         \
             }                                                                                             \
         } else if (MODE == 2) {                                                                           \
             const I2VKEntry e = load_kentry(p.ktab, k0);                                                  \
             const int hs = h0 + e.dh, ws = w0 + e.dw;                                                     \
             const bool ok = pvalid && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;     \
-            const float* const bsrc = srcn + e.chan_off + e.dh * p.Ws + e.dw;                             \
+            const unsigned v = ok ? xoff + (unsigned)((e.chan_off + e.dh * p.Ws + e.dw) * 4) : OOB;       \
             _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                             \
-                const int ins = wave + 4 * q;                                                             \
+                const int ins = wv + 4 * q;                                                               \
                 if (NB % 4 == 0 || ins < NB)                                                              \
-                    __builtin_amdgcn_global_load_lds(ok ? bsrc + (int64_t)((ins * 64) / BP) * HWs : zsrc, \
-                                                     (lds_ptr_t)(bbuf + ins * 64), 4, 0, 0);              \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 64), 4, v,    \
+                                                             ((ins * 64) / BP) * HWs * 4, 0, 0);          \
             }                                                                                             \
         } else {                                                                                          \
             _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                             \
-                const int ins = wave + 4 * q;                                                             \
+                const int ins = wv + 4 * q;                                                               \
                 if (NB % 4 == 0 || ins < NB) {                                                            \
                     const I2VKEntry e = load_kentry(p.ktab, k0 + (ins * 64) / BP);                        \
                     const int hs = h0 + e.dh, ws = w0 + e.dw;                                             \
-                    const bool ok = pvalid && e.valid && (unsigned)hs < (unsigned)p.Hs &&                 \
-                                    (unsigned)ws < (unsigned)p.Ws;                                        \
-                    __builtin_amdgcn_global_load_lds(ok ? srcn + (e.chan_off + e.dh * p.Ws + e.dw) : zsrc,\
-                                                     (lds_ptr_t)(bbuf + ins * 64), 4, 0, 0);              \
+                    const bool ok = pvalid && e.valid && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws; \
+                    const unsigned v = ok ? xoff + (unsigned)((e.chan_off + e.dh * p.Ws + e.dw) * 4) : OOB; \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 64), 4, v, 0, 0, 0); \
                 }                                                                                         \
             }                                                                                             \
         }                                                                                                 \
@@ -333,6 +350,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
             }
         }
     }
+#endif
 }
 
 template <int BD, int BP, int WD, int WP>

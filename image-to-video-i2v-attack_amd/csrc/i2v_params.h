@@ -20,6 +20,8 @@ struct I2VKEntry {
 // p enumerates (n, i, j) over an N x Hg x Wg grid.
 struct I2VConvParams {
     const float* src;  int64_t src_nstride;  int32_t Hs, Ws;
+    int32_t Cs;             // channels of the source view
+    int32_t src_span_bytes; // bytes spanned by the N frames of the source view (< 2 GiB per launch; set by the executor)
     const float* wp;   const I2VKEntry* ktab; int32_t K, Kpad, Cd, Cdpad;   // K real rows, Kpad padded
     int32_t N, Hg, Wg, sh, sw;
     float* dst;        int64_t dst_nstride;  int32_t Ho, Wo, osh, osw, oh0, ow0;

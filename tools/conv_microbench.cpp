@@ -11,7 +11,7 @@
 int main(int argc, char** argv) {
     int N = argc > 1 ? atoi(argv[1]) : 128, Cin = argc > 2 ? atoi(argv[2]) : 256, Cout = argc > 3 ? atoi(argv[3]) : 256;
     int H = argc > 4 ? atoi(argv[4]) : 14, k = argc > 5 ? atoi(argv[5]) : 3, iters = argc > 6 ? atoi(argv[6]) : 20;
-    int pad = k / 2, K = k * k * Cin, Kpad = (K + 15) / 16 * 16, Cdpad = (Cout + 127) / 128 * 128;
+    int pad = k / 2, K = k * k * Cin, Kpad = (K + I2V_KC - 1) / I2V_KC * I2V_KC, Cdpad = (Cout + 127) / 128 * 128;
     std::vector<float> wp((size_t)Kpad * Cdpad), src((size_t)N * Cin * H * H);
     std::vector<I2VKEntry> kt(Kpad, I2VKEntry{0, 0, 0, 0});
     for (auto& v : wp) v = (rand() % 2001 - 1000) * 1e-4f;
@@ -25,12 +25,13 @@ int main(int argc, char** argv) {
     hipMemcpy(ds, src.data(), src.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dk, kt.data(), kt.size() * sizeof(I2VKEntry), hipMemcpyHostToDevice);
     I2VConvParams p; memset((void*)&p, 0, sizeof p);
-    p.src = ds; p.src_nstride = (int64_t)Cin * H * H; p.Hs = p.Ws = H;
+    p.src = ds; p.src_nstride = (int64_t)Cin * H * H; p.Hs = p.Ws = H; p.Cs = Cin;
+    p.src_span_bytes = (int32_t)((int64_t)N * Cin * H * H * 4);
     p.wp = dw; p.ktab = dk; p.K = K; p.Kpad = Kpad; p.Cd = Cout; p.Cdpad = Cdpad;
     p.N = N; p.Hg = p.Wg = H; p.sh = p.sw = 1;
     p.dst = dd; p.dst_nstride = (int64_t)Cout * H * H; p.Ho = p.Wo = H; p.osh = p.osw = 1;
     p.add0_stride = 1; p.relu = 1;
-    p.pointwise = (k == 1 && (H * H) % 4 == 0); p.tap_uniform = (Cin % 16 == 0);
+    p.pointwise = (k == 1 && (H * H) % 4 == 0); p.tap_uniform = (Cin % I2V_KC == 0);
     p.vec_epilogue = ((H * H) % 4 == 0);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 3; ++i) k_conv(p, nullptr);
