@@ -783,7 +783,7 @@ extern "C" int i2v_compose_f32(const float* u, const float* delta, float* x, int
 }
 
 extern "C" size_t i2v_cossim_scratch_bytes(int64_t D, int frames) {
-    return (size_t)frames * cos_nblk(D) * 4 * sizeof(double);
+    return ((size_t)frames * cos_nblk(D) * 4 + 2) * sizeof(double);
 }
 
 extern "C" int i2v_cossim_fwd_bwd_f32(const float* a, int64_t a_stride, const float* b, int64_t b_stride,
@@ -799,15 +799,37 @@ extern "C" int i2v_cossim_fwd_bwd_f32(const float* a, int64_t a_stride, const fl
     return 0;
 }
 
+static void std_params(I2VStdParams& p, const float* a, int64_t a_stride, int64_t D, int frames, void* scratch) {
+    memset(&p, 0, sizeof p);
+    p.a = a; p.a_nstride = a_stride; p.D = D; p.N = frames; p.nblk = cos_nblk(D);
+    // scratch layout: [2] sums, then the per-block partials
+    p.sums = (double*)scratch; p.partial = (double*)scratch + 2;
+}
+
+extern "C" int i2v_std_reduce_f32(const float* a, int64_t a_stride, int64_t D, int frames, void* scratch, void* stream) {
+    if (!a || !scratch || D <= 0 || frames <= 0) return fail("i2v_std_reduce_f32: bad argument");
+    I2VStdParams p; std_params(p, a, a_stride, D, frames, scratch);
+    CHECK_BE(k_std_reduce(p, stream));
+    return 0;
+}
+
+extern "C" int i2v_std_grad_f32(const float* a, int64_t a_stride, int64_t D, int frames, int64_t total_count,
+                                int mask_relu, int accumulate, float* std_out, float* grad, int64_t grad_stride,
+                                void* scratch, void* stream) {
+    if (!a || !std_out || !grad || !scratch || D <= 0 || frames <= 0 || total_count < 2) return fail("i2v_std_grad_f32: bad argument");
+    I2VStdParams p; std_params(p, a, a_stride, D, frames, scratch);
+    p.total_count = (double)total_count; p.std_out = std_out; p.grad = grad; p.grad_nstride = grad_stride;
+    p.mask_relu = mask_relu; p.accumulate = accumulate;
+    CHECK_BE(k_std_grad(p, stream));
+    return 0;
+}
+
 extern "C" int i2v_std_fwd_bwd_f32(const float* a, int64_t a_stride, int64_t D, int frames, int mask_relu,
                                    int accumulate, float* std_out, float* grad, int64_t grad_stride,
                                    void* scratch, void* stream) {
-    if (!a || !std_out || !grad || !scratch || D <= 0 || frames <= 0) return fail("i2v_std_fwd_bwd_f32: bad argument");
-    I2VStdParams p; memset(&p, 0, sizeof p);
-    p.a = a; p.a_nstride = a_stride; p.D = D; p.N = frames; p.partial = (double*)scratch; p.nblk = cos_nblk(D);
-    p.std_out = std_out; p.grad = grad; p.grad_nstride = grad_stride; p.mask_relu = mask_relu; p.accumulate = accumulate;
-    CHECK_BE(k_std(p, stream));
-    return 0;
+    if (i2v_std_reduce_f32(a, a_stride, D, frames, scratch, stream)) return 1;
+    return i2v_std_grad_f32(a, a_stride, D, frames, (int64_t)frames * D, mask_relu, accumulate, std_out, grad,
+                            grad_stride, scratch, stream);
 }
 
 extern "C" int i2v_adam_step_f32(float* delta, float* m, float* v, const float* gx, const float* u,

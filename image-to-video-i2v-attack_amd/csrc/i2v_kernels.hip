@@ -374,8 +374,11 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
 static int conv_pick(const I2VConvParams& p) {
     static const char* force = getenv("I2V_FORCE_CFG");        // developer knob (tools/conv_microbench.cpp)
     if (force && *force) return atoi(force);
+    // ineff: relative cost per unit of tile area measured with tools/conv_microbench.cpp (small tiles pay
+    // more operand traffic per MFMA); a launch that cannot fill the CUs' block slots also loses the overlap
+    // between co-resident blocks.
     static const struct { int BD, BP, occ; double ineff; } C[5] = {
-        {128, 128, 3, 1.00}, {64, 128, 5, 1.04}, {128, 64, 5, 1.04}, {64, 64, 8, 1.10}, {32, 256, 4, 1.06}};
+        {128, 128, 3, 1.00}, {64, 128, 5, 1.05}, {128, 64, 5, 1.04}, {64, 64, 8, 1.10}, {32, 256, 4, 1.08}};
     const double P = (double)p.N * p.Hg * p.Wg;
     const int nchunks = p.Kpad / I2V_KC;
     int best = 0; double best_t = 1e300;
@@ -384,8 +387,10 @@ static int conv_pick(const I2VConvParams& p) {
         if (C[i].BD == 32 && p.Cd > 32) continue;
         const double blocks = ceil(p.Cd / (double)C[i].BD) * ceil(P / C[i].BP);
         const double rounds = ceil(blocks / 256.0);
-        const double mfma = (double)nchunks * (C[i].BD / 32) * (C[i].BP / 32) / 4 * 8 * 64 * C[i].ineff;
-        const double overhead = 2500.0 + (C[i].BD * C[i].BP / 256) * 14.0;
+        const double fill = blocks / (256.0 * C[i].occ);
+        const double mfma = (double)nchunks * (C[i].BD / 32) * (C[i].BP / 32) / 4 * 8 * 64 * C[i].ineff *
+                            (1.0 + 0.15 * (fill < 1.0 ? 1.0 - fill : 0.0));
+        const double overhead = 1500.0 + (C[i].BD * C[i].BP / 256) * 10.0;
         const double t = rounds * mfma + ceil(rounds / C[i].occ) * overhead;
         if (t < best_t) { best_t = t; best = i; }
     }
@@ -599,8 +604,7 @@ __global__ void __launch_bounds__(256) std_reduce_kernel(const I2VStdParams p) {
     }
 }
 
-__global__ void __launch_bounds__(256) std_grad_kernel(const I2VStdParams p) {
-    const int n = blockIdx.y;
+__global__ void __launch_bounds__(256) std_finish_kernel(const I2VStdParams p) {
     __shared__ double red[2][4];
     double s = 0, ss = 0;
     const int np = p.N * p.nblk;
@@ -608,9 +612,16 @@ __global__ void __launch_bounds__(256) std_grad_kernel(const I2VStdParams p) {
     s = wave_sum_d(s); ss = wave_sum_d(ss);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; }
     __syncthreads();
-    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    const double cnt = (double)p.N * (double)p.D;
+    if (threadIdx.x == 0) {
+        p.sums[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        p.sums[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+__global__ void __launch_bounds__(256) std_grad_kernel(const I2VStdParams p) {
+    const int n = blockIdx.y;
+    const double s = p.sums[0], ss = p.sums[1];
+    const double cnt = p.total_count;
     const double mu = s / cnt;
     const double var = fmax((ss - cnt * mu * mu) / (cnt - 1.0), 0.0);
     const double sd = sqrt(var);
@@ -626,9 +637,15 @@ __global__ void __launch_bounds__(256) std_grad_kernel(const I2VStdParams p) {
     }
 }
 
-int k_std(const I2VStdParams& p, i2v_stream_t s) {
+int k_std_reduce(const I2VStdParams& p, i2v_stream_t s) {
     hipLaunchKernelGGL(std_reduce_kernel, dim3(p.nblk, p.N), dim3(256), 0, (hipStream_t)s, p);
     LAUNCH_CHECK("std_reduce");
+    hipLaunchKernelGGL(std_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("std_finish");
+    return 0;
+}
+
+int k_std_grad(const I2VStdParams& p, i2v_stream_t s) {
     int gblk = (int)((p.D + 2047) / 2048); if (gblk > 64) gblk = 64;
     hipLaunchKernelGGL(std_grad_kernel, dim3(gblk, p.N), dim3(256), 0, (hipStream_t)s, p);
     LAUNCH_CHECK("std_grad");

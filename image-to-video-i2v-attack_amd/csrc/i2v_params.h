@@ -72,6 +72,8 @@ struct I2VCosParams {
 struct I2VStdParams {                          // Dispersion-Reduction loss: unbiased std of a tensor
     const float* a;    int64_t a_nstride; int64_t D; int32_t N;
     double* partial;   int32_t nblk;         // [N*nblk][2] (sum, sumsq)
+    double* sums;                            // [2] (sum, sumsq) over the LOCAL frames -- all-reduced by the host
+    double total_count;                      // element count behind `sums` when the gradient is formed (global)
     float* std_out;                          // [1]
     float* grad;       int64_t grad_nstride;
     int32_t mask_relu, accumulate;

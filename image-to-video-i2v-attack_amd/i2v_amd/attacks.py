@@ -145,7 +145,7 @@ class _ImageGuided(Attack):
                 net.forward(xadv)                                       # :334
                 for k in range(len(net.hooks)):
                     if mode == "std":
-                        net.stdloss(k, vals[i, l], scratch, N)          # :218
+                        net.stdloss(k, vals[i, l], scratch, N, self._std_exchange())   # :218
                     elif aens:
                         net.cossim(k, init[n][k], vals[i, l], scratch, N, coef_dev=self.coeffs, coef_index=l,
                                    coef_host=1.0 / L)                   # TPAMI_attack.py:289-291
@@ -182,6 +182,9 @@ class _ImageGuided(Attack):
     def _exchange(self, feat_sum, weighted_row):
         pass
 
+    def _std_exchange(self):
+        return None
+
     def forward(self, videos, labels, video_names):
         return self._run(videos, video_names)
 
@@ -203,11 +206,28 @@ class ImageGuidedStd_Adam(_ImageGuided):
     _mode = "std"
 
     def __init__(self, model_name_lists, depth, step_size, epsilon=16 / 255, steps=10, *, engine=None,
-                 graph_builder=None, weight_seed=0):
+                 graph_builder=None, weight_seed=0, process_group=None, distributed=None):
         super().__init__("ImageGuidedStd_Adam")
         self.epsilon, self.steps, self.step_size, self.depth = epsilon, steps, step_size, depth
         self.model_name = model_name_lists[0]
         self._setup(model_name_lists[:1], [[depth]], engine, graph_builder, weight_seed)
+        self._pg, self._dist = process_group, distributed
+
+    def _std_exchange(self):
+        """Clip-sharded runs: the std couples every frame of the GLOBAL batch (image_attacks.py:218), so the
+        local (sum, sum of squares, count) are all-reduced once per step -- 3 doubles over RCCL."""
+        import torch.distributed as dist
+        on = self._dist if self._dist is not None else (dist.is_available() and dist.is_initialized()
+                                                          and dist.get_world_size(self._pg) > 1)
+        if not on:
+            return None
+
+        def exchange(sums, count):
+            packed = torch.cat([sums, torch.tensor([float(count)], dtype=torch.float64, device=sums.device)])
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self._pg)
+            sums.copy_(packed[:2])
+            return int(round(packed[2].item()))
+        return exchange
 
 
 class ImageGuidedFML2_Adam_MultiModels(_ImageGuided):

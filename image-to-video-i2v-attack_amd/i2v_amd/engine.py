@@ -187,11 +187,19 @@ class Net:
             hi.post_relu, 0, C.c_void_p(cos_out.data_ptr()), C.c_void_p(hi.grad), hi.grad_stride,
             C.c_void_p(scratch.data_ptr()), self.eng.stream()))
 
-    def stdloss(self, i: int, std_out: torch.Tensor, scratch: torch.Tensor, frames: int):
+    def stdloss(self, i: int, std_out: torch.Tensor, scratch: torch.Tensor, frames: int, exchange=None):
+        """Unbiased std of hook i over ALL frames and its gradient.  `exchange(sums, count)` -- given the
+        (2,) float64 device tensor of local (sum, sum of squares) and the local element count -- may
+        all-reduce the sums in place and return the global count (clip-sharded runs)."""
         hi = self.hooks[i]
         capi = self.eng.capi
-        _lib.check(capi, capi.i2v_std_fwd_bwd_f32(
-            C.c_void_p(hi.act), hi.act_stride, hi.D, frames, hi.post_relu, 0, C.c_void_p(std_out.data_ptr()),
+        _lib.check(capi, capi.i2v_std_reduce_f32(C.c_void_p(hi.act), hi.act_stride, hi.D, frames,
+                                                 C.c_void_p(scratch.data_ptr()), self.eng.stream()))
+        total = frames * hi.D
+        if exchange is not None:
+            total = exchange(scratch[:16].view(torch.float64), total)
+        _lib.check(capi, capi.i2v_std_grad_f32(
+            C.c_void_p(hi.act), hi.act_stride, hi.D, frames, total, hi.post_relu, 0, C.c_void_p(std_out.data_ptr()),
             C.c_void_p(hi.grad), hi.grad_stride, C.c_void_p(scratch.data_ptr()), self.eng.stream()))
 
     def scratch_bytes(self, frames: int) -> int:

@@ -52,6 +52,8 @@ _PROTOS = {
     "i2v_cossim_scratch_bytes": ([_L, _I], C.c_size_t),
     "i2v_cossim_fwd_bwd_f32": ([_P, _L, _P, _L, _L, _I, _P, _I, _F, _I, _I, _P, _P, _L, _P, _P], _I),
     "i2v_std_fwd_bwd_f32": ([_P, _L, _L, _I, _I, _I, _P, _P, _L, _P, _P], _I),
+    "i2v_std_reduce_f32": ([_P, _L, _L, _I, _P, _P], _I),
+    "i2v_std_grad_f32": ([_P, _L, _L, _I, _L, _I, _I, _P, _P, _L, _P, _P], _I),
     "i2v_adam_step_f32": ([_P, _P, _P, _P, _P, _L, _I, _F, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P], _I),
     "i2v_sign_step_f32": ([_P, _P, _P, _L, _L, _F, _F, _P], _I),
     "i2v_sign_step_delta_f32": ([_P, _P, _L, _F, _P], _I),

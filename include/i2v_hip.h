@@ -115,6 +115,13 @@ int i2v_cossim_fwd_bwd_f32(const float* a, int64_t a_stride, const float* b, int
 int i2v_std_fwd_bwd_f32(const float* a, int64_t a_stride, int64_t D, int frames, int mask_relu,
                         int accumulate, float* std_out, float* grad, int64_t grad_stride,
                         void* scratch, void* stream);
+/* The same in two halves for clip-sharded runs: `reduce` leaves (sum, sum of squares) of the LOCAL
+ * frames as two doubles at the start of `scratch` (device); the host all-reduces them, and `grad`
+ * forms std and gradient from the (global) sums over `total_count` elements. */
+int i2v_std_reduce_f32(const float* a, int64_t a_stride, int64_t D, int frames, void* scratch, void* stream);
+int i2v_std_grad_f32(const float* a, int64_t a_stride, int64_t D, int frames, int64_t total_count,
+                     int mask_relu, int accumulate, float* std_out, float* grad, int64_t grad_stride,
+                     void* scratch, void* stream);
 /* Compose backward + `torch.optim.Adam.step` on delta (image_attacks.py:306,351-353):
  *   g = gx/std[c] where -eps<=delta<=eps and 0<=u+clamp(delta)<=1 (inclusive), else 0
  *   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; delta -= lr/(1-b1^t) * m/(sqrt(v)/sqrt(1-b2^t)+1e-8)

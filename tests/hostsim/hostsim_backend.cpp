@@ -154,12 +154,17 @@ int k_cos(const I2VCosParams& p, i2v_stream_t) {
     return 0;
 }
 
-int k_std(const I2VStdParams& p, i2v_stream_t) {
-    double s = 0, ss = 0; double cnt = (double)p.N * p.D;
-    for (int n = 0; n < p.N; ++n) { const float* a = p.a + (size_t)n * p.a_nstride; for (int64_t i = 0; i < p.D; ++i) s += a[i]; }
-    double mu = s / cnt;
-    for (int n = 0; n < p.N; ++n) { const float* a = p.a + (size_t)n * p.a_nstride; for (int64_t i = 0; i < p.D; ++i) ss += (a[i] - mu) * (a[i] - mu); }
-    double sd = sqrt(ss / (cnt - 1));
+int k_std_reduce(const I2VStdParams& p, i2v_stream_t) {
+    double s = 0, ss = 0;
+    for (int n = 0; n < p.N; ++n) { const float* a = p.a + (size_t)n * p.a_nstride; for (int64_t i = 0; i < p.D; ++i) { s += a[i]; ss += (double)a[i] * a[i]; } }
+    p.sums[0] = s; p.sums[1] = ss;
+    return 0;
+}
+
+int k_std_grad(const I2VStdParams& p, i2v_stream_t) {
+    double cnt = p.total_count, mu = p.sums[0] / cnt;
+    double var = (p.sums[1] - cnt * mu * mu) / (cnt - 1); if (var < 0) var = 0;
+    double sd = sqrt(var);
     p.std_out[0] = (float)sd;
     for (int n = 0; n < p.N; ++n) {
         const float* a = p.a + (size_t)n * p.a_nstride; float* g = p.grad + (size_t)n * p.grad_nstride;

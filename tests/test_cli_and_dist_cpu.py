@@ -85,3 +85,36 @@ def test_aens_two_ranks_match_single_device(tmp_path):
     np.testing.assert_allclose(r0["costs"], fx["cost_saved"], rtol=2e-4)
     adv = np.concatenate([r0["adv"], r1["adv"]])
     assert np.abs(adv - fx["adv"]).mean() < 5e-3
+
+
+def _dr_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from i2v_amd import attacks, graphs
+    from oracle.make_golden import make_clip, normalise
+    vid = normalise(make_clip(77, 2, 2, 64), torch.float32)
+    atk = attacks.ImageGuidedStd_Adam(["resnet"], depth=2, step_size=0.005, steps=3, engine=hostsim_engine(),
+                                      graph_builder=graphs.build_tiny)
+    adv = atk(vid[rank:rank + 1], torch.zeros(1, dtype=torch.long), [f"c{rank}"])
+    np.savez(os.path.join(out_dir, f"dr{rank}.npz"), adv=adv.numpy(), costs=atk.last_costs)
+    dist.destroy_process_group()
+
+
+def test_dr_two_ranks_match_single_device(tmp_path):
+    """Dispersion-Reduction couples all frames of the batch through one std (image_attacks.py:218):
+    2 ranks x 1 clip with the 3-double all-reduce == the oracle on both clips at once."""
+    from oracle import restate
+    from oracle.make_golden import make_clip, normalise
+    from i2v_amd import graphs, weights
+    vid = normalise(make_clip(77, 2, 2, 64), torch.float32)
+    g = graphs.build_tiny("resnet", (64, 64))
+    net = restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hooks[2]], dtype=torch.float64)
+    ref = restate.run_attack([net], vid.double(), steps=3, step_size=0.005, mode="std")
+    port = 31500 + os.getpid() % 2000
+    mp.start_processes(_dr_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = np.load(tmp_path / "dr0.npz"), np.load(tmp_path / "dr1.npz")
+    np.testing.assert_allclose(r0["costs"], ref["costs"], rtol=2e-4)
+    np.testing.assert_array_equal(r0["costs"], r1["costs"])
+    adv = np.concatenate([r0["adv"], r1["adv"]])
+    assert np.abs(adv - ref["adv"].float().numpy()).mean() < 5e-3
