@@ -118,3 +118,36 @@ def test_dr_two_ranks_match_single_device(tmp_path):
     np.testing.assert_array_equal(r0["costs"], r1["costs"])
     adv = np.concatenate([r0["adv"], r1["adv"]])
     assert np.abs(adv - ref["adv"].float().numpy()).mean() < 5e-3
+
+
+def label_reader(name):
+    """Model factory for the evaluator test: 'reads' the label planted in the clip."""
+    class M(torch.nn.Module):
+        def forward(self, x):
+            idx = x[:, 0, 0, 0, 0].round().long() + (1 if name == "off_by_one" else 0)
+            return torch.nn.functional.one_hot(idx.clamp(0, 9), 10).float()
+    return M()
+
+
+def test_evaluator_contract(tmp_path, monkeypatch):
+    """reference.py contract: discovers `*adv*` files, label from the file name, top-1 per model,
+    `top1_acc_all_models.json` + `results_all_models_prediction.csv`."""
+    monkeypatch.setenv("I2V_OPT_PATH", str(tmp_path))
+    d = tmp_path / "run"
+    d.mkdir()
+    for label in (3, 0, 7, 5):
+        clip = np.zeros((3, 2, 4, 4), np.float32)
+        clip[0, 0, 0, 0] = label if label != 7 else 2          # clip 7 is "fooled"
+        np.save(d / f"{label}-adv.npy", clip)
+    (d / "loss_info_1.json").write_text("{}")
+    import importlib
+    import reference as ev
+    importlib.reload(ev)
+    acc = ev.main(["--adv_path", "run", "--models", "exact,off_by_one", "--model_factory",
+                   "tests.test_cli_and_dist_cpu:label_reader", "--batch_size", "3"])
+    assert acc == {"exact": 75.0, "off_by_one": 0.0}
+    assert json.load(open(d / "top1_acc_all_models.json")) == acc
+    rows = (d / "results_all_models_prediction.csv").read_text().strip().split("\n")
+    assert rows[0] == "gt_label,exact-pre,off_by_one-pre" and len(rows) == 5
+    assert rows[1:] == ["0,0,1", "3,3,4", "5,5,6", "7,2,3"]
+    assert ev.main(["--adv_path", "run", "--models", "i3d_resnet50"])["i3d_resnet50"] >= 0.0     # built-in proxy runs

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Run ON THE GPU BOX (gpurun -- 'bash tools/profile.sh r1'): rocprofv3 passes over the bench command.
+# Kernel-trace/stats and each PMC group are separate runs (never combine --pmc with sys/hip traces).
+TAG=${1:-r1}
+R=$PWD
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing"
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- $CMD > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- $CMD > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- $CMD > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/mfma -o m --output-format csv -- $CMD > $OUT/mfma.log 2>&1
+cd $R
+tail -1 $OUT/stats.log | cut -c1-200
+ls $OUT/*/
