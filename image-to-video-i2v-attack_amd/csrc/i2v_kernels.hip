@@ -433,17 +433,19 @@ __global__ void pool_fwd_kernel(const I2VPoolParams p) {
 }
 
 // gather form (no atomics): an input element collects from the <= ceil(k/stride)^2 windows holding it
-// whose stored arg-max points back at it
-__global__ void pool_bwd_kernel(const I2VPoolParams p) {
-    const int64_t total = (int64_t)p.N * p.C * p.Hs * p.Ws;
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int w = idx % p.Ws; int64_t r = idx / p.Ws;
-        const int h = r % p.Hs; r /= p.Hs;
-        const int c = r % p.C; const int64_t n = r / p.C;
+// whose stored arg-max points back at it.  One block per (frame, channel) plane, 32-bit index math.
+__global__ void __launch_bounds__(256) pool_bwd_kernel(const I2VPoolParams p) {
+    const int plane = blockIdx.x;                       // n * C + c
+    const int n = plane / p.C, c = plane - n * p.C;
+    const float* x = p.x + (int64_t)n * p.x_nstride + (int64_t)c * p.Hs * p.Ws;
+    const float* gy = p.y + (int64_t)n * p.y_nstride + (int64_t)c * p.Ho * p.Wo;
+    const uint8_t* ix = p.idx + (int64_t)plane * p.Ho * p.Wo;
+    float* gx = p.gx + (int64_t)n * p.gx_nstride + (int64_t)c * p.Hs * p.Ws;
+    const int HW = p.Hs * p.Ws;
+    for (int e = threadIdx.x; e < HW; e += 256) {
+        const int h = e / p.Ws, w = e - h * p.Ws;
         float g = 0.f;
-        if (!p.mask_relu || p.x[n * p.x_nstride + ((int64_t)c * p.Hs + h) * p.Ws + w] > 0.f) {
-            const float* gy = p.y + n * p.y_nstride + (int64_t)c * p.Ho * p.Wo;
-            const uint8_t* ix = p.idx + (n * p.C + c) * (int64_t)p.Ho * p.Wo;
+        if (!p.mask_relu || x[e] > 0.f) {
             int ho_lo = h + p.pad - p.k + 1; ho_lo = ho_lo <= 0 ? 0 : (ho_lo + p.stride - 1) / p.stride;
             const int ho_hi = min((h + p.pad) / p.stride, p.Ho - 1);
             int wo_lo = w + p.pad - p.k + 1; wo_lo = wo_lo <= 0 ? 0 : (wo_lo + p.stride - 1) / p.stride;
@@ -454,7 +456,7 @@ __global__ void pool_bwd_kernel(const I2VPoolParams p) {
                     if (ix[ho * p.Wo + wo] == me) g += gy[ho * p.Wo + wo];
                 }
         }
-        p.gx[n * p.gx_nstride + ((int64_t)c * p.Hs + h) * p.Ws + w] = g;
+        gx[e] = g;
     }
 }
 
@@ -470,7 +472,7 @@ int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t s) {
     LAUNCH_CHECK("pool_fwd"); return 0;
 }
 int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s) {
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(stream_grid((int64_t)p.N * p.C * p.Hs * p.Ws, 256)), dim3(256), 0, (hipStream_t)s, p);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)(p.N * p.C)), dim3(256), 0, (hipStream_t)s, p);
     LAUNCH_CHECK("pool_bwd"); return 0;
 }
 
