@@ -667,7 +667,9 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int frames, cons
                 if (l.kind == L_IMGGRAD) { p.dst = gx; if (accumulate) { p.add1 = gx; p.add1_nstride = p.dst_nstride; } }
                 if (frames * p.Hg * p.Wg == 0) break;
                 p.vec_epilogue = (p.blk <= 1 && p.osh == 1 && p.osw == 1 && p.oh0 == 0 && p.ow0 == 0 && p.Hg == p.Ho &&
-                                  p.Wg == p.Wo && (p.Ho * p.Wo) % 4 == 0 && p.add0_stride == 1 && p.dst_nstride % 4 == 0 &&
+                                  p.Wg == p.Wo && (p.Ho * p.Wo) % 4 == 0 && p.dst_nstride % 4 == 0 &&
+                                  (p.add0_stride == 1 || (p.add0_stride == 2 && p.Wo % 4 == 0 && p.add0_W * 2 == p.Wo &&
+                                                          p.add0_W % 2 == 0 && (p.add0_H * p.add0_W) % 2 == 0)) &&
                                   p.add0_nstride % 4 == 0 && p.add1_nstride % 4 == 0 && p.mask_nstride % 4 == 0 &&
                                   (((uintptr_t)p.dst | (uintptr_t)p.add0 | (uintptr_t)p.add1 | (uintptr_t)p.mask) & 15) == 0)
                                      ? 1 : 0;

@@ -73,7 +73,9 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 
 // MODE 0: per-row k-table gather (any geometry); 1: pointwise float4 (1x1, stride 1, planes 16-B aligned);
 // 2: tap-uniform chunks (every 16-row K chunk shares one spatial tap: channel count % 16 == 0)
-template <int BD, int BP, int WD, int WP, int MODE>
+// PREF (single-pass tiles only): the epilogue's addend / gate tiles are fetched into registers BEFORE the
+// K loop, so for the low-K, HBM-bound layers the read traffic overlaps the matrix work instead of following it.
+template <int BD, int BP, int WD, int WP, int MODE, bool PREF>
 __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-resource types and LDS-DMA builtins exist only in the device pass
     constexpr int KC = I2V_KC;
@@ -192,6 +194,29 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         }                                                                                                 \
     }
 
+    // ---- epilogue operand prefetch ----
+    constexpr int E_C4 = BP / 4, E_RSTEP = 1024 / BP, E_NQ = WD * 32 / E_RSTEP;
+    static_assert(!PREF || TD == 1, "PREF needs a single epilogue pass");
+    float4 pre0[PREF ? E_NQ : 1], pre1[PREF ? E_NQ : 1], pregate[PREF ? E_NQ : 1];
+    if (PREF) {
+        const int e_c4 = t % E_C4, e_rbase = t / E_C4;
+        const int64_t e_pp = px0 + (int64_t)e_c4 * 4;
+        const bool e_ok = e_pp < P;
+        const int64_t e_n = e_ok ? e_pp / HWg : 0;
+        const int64_t e_poff = e_pp - e_n * HWg;
+        const int e_HoWo = p.Ho * p.Wo;
+#pragma unroll
+        for (int q = 0; q < E_NQ; ++q) {
+            const int row = e_rbase + q * E_RSTEP;
+            const int cd = cd0 + (row >> 5) * (BD / WD) + (row & 31);
+            const bool ok = e_ok && cd < p.Cd;
+            const int64_t o = (int64_t)cd * e_HoWo + e_poff;
+            pre0[q] = (ok && p.add0) ? *reinterpret_cast<const float4*>(p.add0 + e_n * p.add0_nstride + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pre1[q] = (ok && p.add1) ? *reinterpret_cast<const float4*>(p.add1 + e_n * p.add1_nstride + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pregate[q] = (ok && p.mask) ? *reinterpret_cast<const float4*>(p.mask + e_n * p.mask_nstride + o) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+    }
+
     f32x16 acc[TD][TP];
 #pragma unroll
     for (int a = 0; a < TD; ++a)
@@ -258,17 +283,31 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
                     float4 v = *reinterpret_cast<const float4*>(&Cs[row][c4 * 4]);
                     const int64_t o = (int64_t)cd * HoWo + poff;
                     if (p.shift) { const float sh = p.shift[cd]; v.x += sh; v.y += sh; v.z += sh; v.w += sh; }
-                    if (p.add0) {
-                        const float4 a = *reinterpret_cast<const float4*>(p.add0 + n * p.add0_nstride + o);
-                        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-                    }
-                    if (p.add1) {
-                        const float4 a = *reinterpret_cast<const float4*>(p.add1 + n * p.add1_nstride + o);
-                        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                    if (PREF) {
+                        v.x += pre0[q].x; v.y += pre0[q].y; v.z += pre0[q].z; v.w += pre0[q].w;
+                        v.x += pre1[q].x; v.y += pre1[q].y; v.z += pre1[q].z; v.w += pre1[q].w;
+                    } else {
+                        if (p.add0 && p.add0_stride == 1) {
+                            const float4 a = *reinterpret_cast<const float4*>(p.add0 + n * p.add0_nstride + o);
+                            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                        } else if (p.add0) {
+                            // compact stride-2 addend (input-gradient of a 1x1/2 shortcut): defined at even
+                            // (h, w) only; the 4 pixels start at a multiple of 4, so elements 0 and 2 receive
+                            const int oh = (int)(poff / p.Wo), ow = (int)(poff - (int64_t)oh * p.Wo);
+                            if (!(oh & 1) && (oh >> 1) < p.add0_H) {
+                                const float2 a = *reinterpret_cast<const float2*>(
+                                    p.add0 + n * p.add0_nstride + (int64_t)cd * p.add0_H * p.add0_W + (oh >> 1) * p.add0_W + (ow >> 1));
+                                v.x += a.x; v.z += a.y;
+                            }
+                        }
+                        if (p.add1) {
+                            const float4 a = *reinterpret_cast<const float4*>(p.add1 + n * p.add1_nstride + o);
+                            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                        }
                     }
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (p.mask) {
-                        const float4 m = *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
+                    if (PREF || p.mask) {
+                        const float4 m = PREF ? pregate[q] : *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
                         if (!(m.x > 0.f)) v.x = 0.f;
                         if (!(m.y > 0.f)) v.y = 0.f;
                         if (!(m.z > 0.f)) v.z = 0.f;
@@ -353,6 +392,12 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
 #endif
 }
 
+// Low-K layers with epilogue operands are HBM-bound (their FLOP/byte is below the machine balance): they
+// run on 64x64 tiles with the epilogue operands prefetched under the K loop.
+static bool conv_wants_prefetch(const I2VConvParams& p) {
+    return p.vec_epilogue && p.add0_stride == 1 && (p.add0 || p.add1 || p.mask) && p.Kpad <= 256 && (p.pointwise || p.tap_uniform) && p.Cd > 32;
+}
+
 template <int BD, int BP, int WD, int WP>
 static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     const int64_t P = (int64_t)p.N * p.Hg * p.Wg;
@@ -361,9 +406,14 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     const int64_t grid = n_px * n_cd;
     if (grid <= 0) return 0;
     if (grid > 0x7fffffff) { snprintf(g_be_err, sizeof g_be_err, "conv grid too large"); g_be_has_err = true; return 1; }
-    if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
-    else if (p.tap_uniform) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
-    else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 0>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+    if (BD == 64 && BP == 64 && conv_wants_prefetch(p)) {
+        if constexpr (BD == 64 && BP == 64) {
+            if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 1, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+            else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+        }
+    } else if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 1, false>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+    else if (p.tap_uniform) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2, false>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+    else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 0, false>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
     LAUNCH_CHECK("conv_igemm");
     return 0;
 }
@@ -374,6 +424,7 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
 static int conv_pick(const I2VConvParams& p) {
     static const char* force = getenv("I2V_FORCE_CFG");        // developer knob (tools/conv_microbench.cpp)
     if (force && *force) return atoi(force);
+    if (conv_wants_prefetch(p)) return 3;
     // ineff: relative cost per unit of tile area measured with tools/conv_microbench.cpp (small tiles pay
     // more operand traffic per MFMA); a launch that cannot fill the CUs' block slots also loses the overlap
     // between co-resident blocks.
