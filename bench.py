@@ -44,6 +44,20 @@ def synthetic_clips(b, seed0=1000):
     return torch.cat(clips)
 
 
+def measured_traffic():
+    """HBM bytes per conv_igemm launch from the rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
+    correction + WRITE_SIZE, separate --pmc runs of this same command: tools/profile.sh ->
+    profiles/r1_conv_traffic.json).  PMC collection cannot run inside the timed process, so the
+    committed measurement is reported; null when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r1_conv_traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+        return {"bytes_per_launch": round(t["hbm_bytes_per_launch"]), "unit": "B", "source": "profiles/r1_conv_traffic.json"}
+    except Exception:
+        return None
+
+
 def cpu_baseline():
     """The CPU oracle (a port of the reference path; `oracle/restate.py`) on a bounded sample of
     the same workload: ResNet-50 layer3, one 32-frame 224^2 clip (BASELINE configs[0]), clean pass + 3
@@ -171,7 +185,7 @@ def main():
         ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
         out["roofline"] = {"kernel": "conv_igemm (fp32 MFMA implicit GEMM, fwd + dgrad)", "bound": "mfma",
                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": measured_traffic(),
                            "launches": c["launches"], "avg_launch_us": round(1e3 * c["ms"] / c["launches"], 2),
                            "avg_gflop_per_launch": round(c["flops"] / c["launches"] / 1e9, 3),
                            "device_ms_by_kernel": {k: round(v["ms"], 2) for k, v in kt.items()},
