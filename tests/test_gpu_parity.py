@@ -299,3 +299,37 @@ def test_full_size_properties_resnet50(eng):
     assert torch.equal(adv, adv2)
     sub = atk(vid[:, :, 8:12].contiguous(), torch.zeros(1, dtype=torch.long), ["w"]).cpu()
     assert torch.equal(sub, adv[:, :, 8:12])
+
+
+def test_ensemble_full_size_and_frame_slicing(eng):
+    """Full-size shapes of the other backbones (BASELINE configs[2]-style ensemble on the reference's own
+    model list, image_main.py:73-79): AlexNet 11x11/4, SqueezeNet ceil-mode pools and Fire concat, VGG
+    224^2 planes, ResNet-101 layer2 -- 2 steps, invariants + bit-reproducibility.  Then VGG on 192 frames:
+    its first activation buffer (64x224^2 per frame) spans 2.4 GiB, so the convolution launches are
+    sliced over frames (32-bit buffer offsets); frames must not notice."""
+    gen = torch.Generator().manual_seed(2000)
+    u8 = torch.randint(0, 256, (1, 3, 32, 224, 224), generator=gen, dtype=torch.uint8)
+    vid = gu.videos_of({"clip_u8": u8.numpy()})
+    depths = {"resnet": 2, "vgg": 3, "squeezenet": 2, "alexnet": 3}
+    atk = attacks.ImageGuidedFML2_Adam_MultiModels(["resnet", "vgg", "squeezenet", "alexnet"], depths=depths, steps=2)
+    adv = atk(vid, torch.zeros(1, dtype=torch.long), ["v"]).cpu()
+    costs = atk.last_costs.copy()
+    assert abs(costs[0] - 4 * 32) < 0.5 and costs[1] < costs[0]
+    mean = torch.tensor(gu.MEAN).view(1, 3, 1, 1, 1)
+    std = torch.tensor(gu.STD).view(1, 3, 1, 1, 1)
+    un = adv * std + mean
+    assert (un - u8.float() / 255).abs().max() <= 16 / 255 + 1e-6 and un.min() >= -1e-6 and un.max() <= 1 + 1e-6
+    assert torch.equal(adv, atk(vid, torch.zeros(1, dtype=torch.long), ["v"]).cpu())
+    del atk
+    torch.cuda.empty_cache()
+    g = graphs.build("vgg", (224, 224))
+    sd = weights.synthetic_state_dict(g, 0)
+    big = eng.build_net(g, sd, [g.hooks[2]], 192)
+    small = eng.build_net(g, sd, [g.hooks[2]], 2)
+    x = restate.flatten_frames(vid).contiguous()[:2]
+    xb = torch.zeros(192, 3, 224, 224, device="cuda:0")
+    xb[0], xb[191] = x[0], x[1]
+    big.forward(xb)
+    small.forward(dev(x))
+    fb, fs = big.read_tensor(g.hooks[2], 192), small.read_tensor(g.hooks[2], 2)
+    assert torch.equal(fb[0], fs[0]) and torch.equal(fb[191], fs[1])
