@@ -193,25 +193,27 @@ def test_net_forward_backward_match_oracle(eng, model, depths, hw):
     assert torch.allclose(net.read_tensor(hooks[-1], 2).cpu().double(), feats[-1][:2], rtol=1e-4, atol=1e-5)
 
 
-def test_resnet50_full_size_layers(eng):
-    """Real ResNet-50 shapes (224^2, hook layer3) on 2 frames: every conv configuration of
-    SURVEY.md 8(a4) against the oracle's ATen ops."""
-    g = graphs.build("resnet50", (224, 224))
+@pytest.mark.parametrize("model,depths", [("resnet50", [3]), ("vgg", [3]), ("alexnet", [2, 4]), ("squeezenet", [2, 4])])
+def test_full_size_layers(eng, model, depths):
+    """Real shapes (224^2) on 2 frames: every conv configuration of SURVEY.md 8(a4) (ResNet-50 to
+    layer3), VGG-16 to features[20], AlexNet 11x11/4 + 5x5 + 3x3, SqueezeNet ceil-mode pools and Fire
+    concat -- every activation and the input gradient against the oracle's ATen ops."""
+    g = graphs.build(model, (224, 224))
     sd = weights.synthetic_state_dict(g, 0)
-    hooks = [g.hooks[3]]
+    hooks = [g.hooks[d] for d in depths]
     N = 2
     net = eng.build_net(g, sd, hooks, N)
     onet = restate.OracleNet(g, sd, hooks, dtype=torch.float32)
     x = gu.videos_of({"clip_u8": torch.randint(0, 256, (1, 3, N, 224, 224), generator=torch.Generator().manual_seed(1),
                                                dtype=torch.uint8).numpy()})
     x = restate.flatten_frames(x).contiguous()
-    feats = onet.forward(x)
+    onet.forward(x)
     net.forward(dev(x))
     for nd in net.graph.nodes:
         got = net.read_tensor(nd.dst, N).cpu()
         ref = onet.tensor(nd.dst)
         assert (got - ref).abs().max() <= 2e-4 * ref.abs().max() + 1e-5, nd
-    # gradient comparison with the oracle gated by the DEVICE's activations: 10.5M activations per
+    # gradient comparison with the oracle gated by the DEVICE's activations: millions of activations per
     # frame, a handful within fp32 noise of zero would otherwise gate differently (SURVEY.md 0.5)
     onet.adopt_activations({nd.dst: net.read_tensor(nd.dst, N).cpu() for nd in net.graph.nodes})
     feats = [onet.tensor(h) for h in hooks]
@@ -221,6 +223,56 @@ def test_resnet50_full_size_layers(eng):
     net.backward(gx)
     ref = onet.backward(hg)
     assert (gx.cpu() - ref).abs().max() <= 2e-4 * ref.abs().max()
+
+
+def _one_conv_graph(cin, cout, k, stride, pad, hw, relu, residual):
+    """input(3) -> 3x3 conv to `cin` channels -> the convolution under test [-> hook]."""
+    g = graphs.Graph("unit", (hw, hw))
+    x = g.new_tensor(3, hw, hw, False, "input")
+    g.input = x
+    a = g.conv(x, cin, 3, 1, 1, "a.weight", bias="a.bias", relu=True, name="a")
+    res = None
+    if residual and stride == 1 and 2 * pad == k - 1 and cin == cout:
+        res = a
+    b = g.conv(a, cout, k, stride, pad, "b.weight", bn="b.bn", relu=relu, residual=res, name="b")
+    g.hooks[1] = b
+    return g
+
+
+def test_conv_property_based(eng):
+    """Randomised geometry (hypothesis-style sweep with a fixed seed so the GPU box needs no database):
+    odd planes (HW % 4 != 0 -> scalar epilogue), channel counts that are not multiples of 16/32 (K tails,
+    padded Cd rows, per-row k-table mode), strides 1-3, kernels 1-5, every tile configuration."""
+    import random
+    rnd = random.Random(1234)
+    for case in range(40):
+        k = rnd.choice([1, 1, 3, 3, 5, 2])
+        stride = rnd.choice([1, 1, 2, 3])
+        pad = rnd.choice([0, k // 2])
+        cin = rnd.choice([3, 8, 16, 24, 32, 48, 64, 96, 130])
+        cout = rnd.choice([4, 16, 31, 32, 64, 80, 128, 200])
+        hw = rnd.choice([7, 12, 13, 16, 28, 30])
+        if hw + 2 * pad < k:
+            continue
+        N = rnd.choice([1, 3, 5])
+        relu, residual = rnd.random() < 0.7, rnd.random() < 0.5
+        g = _one_conv_graph(cin, cout, k, stride, pad, hw, relu, residual)
+        sd = weights.synthetic_state_dict(g, case)
+        net = eng.build_net(g, sd, [g.hooks[1]], N)
+        onet = restate.OracleNet(g, sd, [g.hooks[1]], dtype=torch.float64)
+        x = torch.randn(N, 3, hw, hw, generator=torch.Generator().manual_seed(case))
+        feats = onet.forward(x.double())
+        net.forward(dev(x))
+        tag = (case, cin, cout, k, stride, pad, hw, N, relu, residual)
+        for nd in net.graph.nodes:
+            got, ref = net.read_tensor(nd.dst, N).cpu().double(), onet.tensor(nd.dst)
+            assert (got - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-6, tag
+        hg = [torch.randn_like(f) for f in feats]
+        write_hook_grads(net, feats, hg, N)
+        gx = torch.empty(N, 3, hw, hw, device="cuda:0")
+        net.backward(gx)
+        ref = onet.backward(hg)
+        assert (gx.cpu().double() - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-7, tag
 
 
 # ------------------------------------------------------------------ attack loops
