@@ -462,52 +462,87 @@ int k_conv(const I2VConvParams& p, i2v_stream_t s) {
 // =============================================================================================
 // max pooling (window-relative arg-max byte saved by forward: first maximum in scan order, as ATen)
 // =============================================================================================
-__global__ void pool_fwd_kernel(const I2VPoolParams p) {
-    const int64_t total = (int64_t)p.N * p.C * p.Ho * p.Wo;
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int wo = idx % p.Wo; int64_t r = idx / p.Wo;
-        const int ho = r % p.Ho; r /= p.Ho;
-        const int c = r % p.C; const int64_t n = r / p.C;
-        const float* pl = p.x + n * p.x_nstride + (int64_t)c * p.Hs * p.Ws;
+// Both pooling kernels: one block per (frame, channel) plane and band of output rows; the band's input
+// rows (fwd) / arg-max bytes and upstream gradients (bwd) are staged in LDS with coalesced loads, so the
+// kernels stream at HBM rate instead of issuing k*k strided global loads per element.  32-bit index math.
+#define POOL_LDS_FLOATS 8192
+__global__ void __launch_bounds__(256) pool_fwd_kernel(const I2VPoolParams p, const int band_rows) {
+    __shared__ float xs[POOL_LDS_FLOATS];
+    const int plane = blockIdx.x, n = plane / p.C, c = plane - n * p.C;
+    const int ho0 = blockIdx.y * band_rows, ho1 = min(ho0 + band_rows, p.Ho);
+    const int h_lo = max(ho0 * p.stride - p.pad, 0), h_hi = min((ho1 - 1) * p.stride - p.pad + p.k, p.Hs);   // [h_lo, h_hi)
+    const float* x = p.x + (int64_t)n * p.x_nstride + (int64_t)c * p.Hs * p.Ws;
+    const int cnt = (h_hi - h_lo) * p.Ws;
+    const float* xb = x + h_lo * p.Ws;
+    if (((p.Ws & 3) == 0) && ((((uintptr_t)xb) & 15) == 0)) {
+        for (int e = threadIdx.x * 4; e < cnt; e += 1024) *reinterpret_cast<float4*>(&xs[e]) = *reinterpret_cast<const float4*>(xb + e);
+    } else {
+        for (int e = threadIdx.x; e < cnt; e += 256) xs[e] = xb[e];
+    }
+    __syncthreads();
+    float* y = p.y + (int64_t)n * p.y_nstride + (int64_t)c * p.Ho * p.Wo;
+    uint8_t* ix = p.idx + (int64_t)plane * p.Ho * p.Wo;
+    const int nout = (ho1 - ho0) * p.Wo;
+    for (int e = threadIdx.x; e < nout; e += 256) {
+        const int ho = ho0 + e / p.Wo, wo = e % p.Wo;
         int best = -1; float bv = 0.f;
         for (int kr = 0; kr < p.k; ++kr) {
             const int h = ho * p.stride - p.pad + kr; if (h < 0 || h >= p.Hs) continue;
             for (int ks = 0; ks < p.k; ++ks) {
                 const int w = wo * p.stride - p.pad + ks; if (w < 0 || w >= p.Ws) continue;
-                const float v = pl[h * p.Ws + w];
-                if (best < 0 || v > bv || v != v) { bv = v; best = kr * p.k + ks; }    // first maximum wins
+                const float v = xs[(h - h_lo) * p.Ws + w];
+                if (best < 0 || v > bv || v != v) { bv = v; best = kr * p.k + ks; }    // first maximum wins (ATen)
             }
         }
-        p.y[n * p.y_nstride + ((int64_t)c * p.Ho + ho) * p.Wo + wo] = bv;
-        p.idx[idx] = (uint8_t)best;
+        y[ho * p.Wo + wo] = bv;
+        ix[ho * p.Wo + wo] = (uint8_t)best;
     }
 }
 
-// gather form (no atomics): an input element collects from the <= ceil(k/stride)^2 windows holding it
-// whose stored arg-max points back at it.  One block per (frame, channel) plane, 32-bit index math.
-__global__ void __launch_bounds__(256) pool_bwd_kernel(const I2VPoolParams p) {
-    const int plane = blockIdx.x;                       // n * C + c
-    const int n = plane / p.C, c = plane - n * p.C;
-    const float* x = p.x + (int64_t)n * p.x_nstride + (int64_t)c * p.Hs * p.Ws;
+// gather form (no atomics): an input element collects from the <= ceil(k/stride)^2 windows holding it whose
+// stored arg-max points back at it
+__global__ void __launch_bounds__(256) pool_bwd_kernel(const I2VPoolParams p, const int band_rows) {
+    __shared__ float gs[POOL_LDS_FLOATS / 2];
+    __shared__ uint8_t is[POOL_LDS_FLOATS / 2];
+    const int plane = blockIdx.x, n = plane / p.C, c = plane - n * p.C;
+    const int h0 = blockIdx.y * band_rows, h1 = min(h0 + band_rows, p.Hs);           // input rows of this band
+    int ho_lo = h0 + p.pad - p.k + 1; ho_lo = ho_lo <= 0 ? 0 : (ho_lo + p.stride - 1) / p.stride;
+    const int ho_hi = min((h1 - 1 + p.pad) / p.stride, p.Ho - 1);                    // output rows [ho_lo, ho_hi]
     const float* gy = p.y + (int64_t)n * p.y_nstride + (int64_t)c * p.Ho * p.Wo;
     const uint8_t* ix = p.idx + (int64_t)plane * p.Ho * p.Wo;
+    const int cnt = (ho_hi - ho_lo + 1) * p.Wo;
+    for (int e = threadIdx.x; e < cnt; e += 256) { gs[e] = gy[ho_lo * p.Wo + e]; is[e] = ix[ho_lo * p.Wo + e]; }
+    __syncthreads();
+    const float* x = p.x + (int64_t)n * p.x_nstride + (int64_t)c * p.Hs * p.Ws;
     float* gx = p.gx + (int64_t)n * p.gx_nstride + (int64_t)c * p.Hs * p.Ws;
-    const int HW = p.Hs * p.Ws;
-    for (int e = threadIdx.x; e < HW; e += 256) {
-        const int h = e / p.Ws, w = e - h * p.Ws;
-        float g = 0.f;
-        if (!p.mask_relu || x[e] > 0.f) {
-            int ho_lo = h + p.pad - p.k + 1; ho_lo = ho_lo <= 0 ? 0 : (ho_lo + p.stride - 1) / p.stride;
-            const int ho_hi = min((h + p.pad) / p.stride, p.Ho - 1);
-            int wo_lo = w + p.pad - p.k + 1; wo_lo = wo_lo <= 0 ? 0 : (wo_lo + p.stride - 1) / p.stride;
-            const int wo_hi = min((w + p.pad) / p.stride, p.Wo - 1);
-            for (int ho = ho_lo; ho <= ho_hi; ++ho)
-                for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-                    const int me = (h - (ho * p.stride - p.pad)) * p.k + (w - (wo * p.stride - p.pad));
-                    if (ix[ho * p.Wo + wo] == me) g += gy[ho * p.Wo + wo];
-                }
+    const int nin = (h1 - h0) * p.Ws;
+    const bool vec = ((p.Ws & 3) == 0) && ((((uintptr_t)(x + h0 * p.Ws) | (uintptr_t)(gx + h0 * p.Ws)) & 15) == 0);
+    for (int e4 = threadIdx.x * (vec ? 4 : 1); e4 < nin; e4 += 256 * (vec ? 4 : 1)) {
+        float xv[4], gv[4];
+        if (vec) { const float4 t4 = *reinterpret_cast<const float4*>(x + h0 * p.Ws + e4); xv[0] = t4.x; xv[1] = t4.y; xv[2] = t4.z; xv[3] = t4.w; }
+        else xv[0] = x[h0 * p.Ws + e4];
+        const int h = h0 + e4 / p.Ws, wb = e4 % p.Ws;
+        int a_lo = h + p.pad - p.k + 1; a_lo = a_lo <= 0 ? 0 : (a_lo + p.stride - 1) / p.stride;
+        const int a_hi = min((h + p.pad) / p.stride, p.Ho - 1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!vec && u > 0) break;
+            const int w = wb + u;
+            float g = 0.f;
+            if (!p.mask_relu || xv[u] > 0.f) {
+                int b_lo = w + p.pad - p.k + 1; b_lo = b_lo <= 0 ? 0 : (b_lo + p.stride - 1) / p.stride;
+                const int b_hi = min((w + p.pad) / p.stride, p.Wo - 1);
+                for (int ho = a_lo; ho <= a_hi; ++ho)
+                    for (int wo = b_lo; wo <= b_hi; ++wo) {
+                        const int me = (h - (ho * p.stride - p.pad)) * p.k + (w - (wo * p.stride - p.pad));
+                        const int li = (ho - ho_lo) * p.Wo + wo;
+                        if (is[li] == me) g += gs[li];
+                    }
+            }
+            gv[u] = g;
         }
-        gx[e] = g;
+        if (vec) *reinterpret_cast<float4*>(gx + h0 * p.Ws + e4) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        else gx[h0 * p.Ws + e4] = gv[0];
     }
 }
 
@@ -518,12 +553,25 @@ static unsigned stream_grid(int64_t total, int per_block) {
     return (unsigned)b;
 }
 
+static int pool_fail(const char* m) { snprintf(g_be_err, sizeof g_be_err, "%s", m); g_be_has_err = true; return 1; }
+
 int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t s) {
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3(stream_grid((int64_t)p.N * p.C * p.Ho * p.Wo, 256)), dim3(256), 0, (hipStream_t)s, p);
+    // band of output rows whose input rows fit the LDS buffer
+    int band = (POOL_LDS_FLOATS / p.Ws - p.k) / p.stride + 1;
+    if (band < 1) return pool_fail("max-pool row too wide for the LDS band");
+    if (band > p.Ho) band = p.Ho;
+    dim3 grid((unsigned)(p.N * p.C), (unsigned)((p.Ho + band - 1) / band));
+    hipLaunchKernelGGL(pool_fwd_kernel, grid, dim3(256), 0, (hipStream_t)s, p, band);
     LAUNCH_CHECK("pool_fwd"); return 0;
 }
 int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s) {
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)(p.N * p.C)), dim3(256), 0, (hipStream_t)s, p);
+    // band of input rows whose covering output rows fit the LDS buffers
+    int out_rows = (POOL_LDS_FLOATS / 2) / p.Wo;
+    int band = (out_rows - 1) * p.stride - p.k + 1; if (out_rows >= p.Ho) band = p.Hs;
+    if (band < 1) return pool_fail("max-pool row too wide for the LDS band");
+    if (band > p.Hs) band = p.Hs;
+    dim3 grid((unsigned)(p.N * p.C), (unsigned)((p.Hs + band - 1) / band));
+    hipLaunchKernelGGL(pool_bwd_kernel, grid, dim3(256), 0, (hipStream_t)s, p, band);
     LAUNCH_CHECK("pool_bwd"); return 0;
 }
 
