@@ -82,10 +82,14 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     constexpr int TD = BD / WD / 32, TP = BP / WP / 32;
     // one LDS array: operand staging [2][KC][BD] + [2][KC][BP], re-used by the epilogue as a
     // [WD*32][BP] transpose buffer
-    constexpr int STAGE_FLOATS = 2 * KC * (BD + BP), EPI_FLOATS = WD * 32 * BP;
+#ifndef I2V_STAGES
+#define I2V_STAGES 2        // LDS operand buffers (3 measured no faster: tools/conv_microbench.cpp -DI2V_STAGES=3): chunk c is consumed while chunks c+1 .. c+STAGES-1 are in flight
+#endif
+    constexpr int NST = I2V_STAGES;
+    constexpr int STAGE_FLOATS = NST * KC * (BD + BP), EPI_FLOATS = WD * 32 * BP;
     __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS];
     float (*As)[KC][BD] = reinterpret_cast<float (*)[KC][BD]>(smem);
-    float (*Bs)[KC][BP] = reinterpret_cast<float (*)[KC][BP]>(smem + 2 * KC * BD);
+    float (*Bs)[KC][BP] = reinterpret_cast<float (*)[KC][BP]>(smem + NST * KC * BD);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wd = wave / WP, wpx = wave % WP;
@@ -227,14 +231,22 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
 
     const int nchunks = p.Kpad / KC;
     const int l31 = lane & 31, lk = lane >> 5;
-    if (nchunks > 0) I2V_ISSUE_CHUNK(0, 0);
+    // DMA pipeline, NST buffers deep: at the top of iteration c the wave waits only for ITS OWN loads of
+    // chunk c (a counted vmcnt leaves the younger chunks in flight), the raw barrier then covers the other
+    // waves' loads of chunk c and tells that every wave is done reading the buffer chunk c+NST-1 overwrites.
+    // `__syncthreads()` is avoided on purpose: its fence would drain vmcnt to 0.
+    constexpr bool UNIFORM = (NA % 4 == 0) && (NB % 4 == 0);           // every wave issues the same number of DMAs
+    constexpr int NL = NAQ + NBQ;                                       // DMA instructions per wave per chunk
+#pragma unroll
+    for (int c0 = 0; c0 < NST - 1; ++c0)
+        if (c0 < nchunks) I2V_ISSUE_CHUNK(c0 * KC, c0);
+    int buf = 0, nbuf = NST - 1;
     for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        // chunk c has landed (this wave's DMA: vmcnt(0); the other waves': barrier) and every wave is done
-        // reading the other buffer, which the next chunk's DMA may now overwrite under this chunk's MFMAs
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (c + 1 < nchunks) I2V_ISSUE_CHUNK((c + 1) * KC, buf ^ 1);
+        if (UNIFORM && NST == 3 && c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (c + NST - 1 < nchunks) I2V_ISSUE_CHUNK((c + NST - 1) * KC, nbuf);
         constexpr int KS = KC / 2;                         // k-steps per chunk (2 K rows per 32x32x2 MFMA)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -249,6 +261,8 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
                 for (int j = 0; j < TP; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
+        buf = buf + 1 == NST ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
     }
 #undef I2V_ISSUE_CHUNK
 
