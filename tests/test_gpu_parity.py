@@ -385,3 +385,47 @@ def test_ensemble_full_size_and_frame_slicing(eng):
     small.forward(dev(x))
     fb, fs = big.read_tensor(g.hooks[2], 192), small.read_tensor(g.hooks[2], 2)
     assert torch.equal(fb[0], fs[0]) and torch.equal(fb[191], fs[1])
+
+
+def test_aens_full_size_one_step(eng):
+    """Adaptive ENS at full size: two hooks per backbone (the shallower hooked tensor also feeds deeper
+    layers -> side-buffer hook gradient merged by addmask), device-side coefficients."""
+    gen = torch.Generator().manual_seed(2001)
+    u8 = torch.randint(0, 256, (1, 3, 8, 224, 224), generator=gen, dtype=torch.uint8)
+    vid = gu.videos_of({"clip_u8": u8.numpy()})
+    names = ["resnet", "vgg", "squeezenet", "alexnet"]
+    atk = attacks.AENS_I2V_MF(names, depths={n: [2, 3] for n in names}, step_size=0.005, steps=2, momentum=0.5)
+    adv, used, costs = atk(vid, torch.zeros(1, dtype=torch.long), ["v"])
+    w = np.stack(atk.weights)
+    assert w.shape == (2, 8) and np.allclose(w.sum(1), 1, atol=1e-5) and np.allclose(w[0], 1 / 8, atol=1e-6)
+    assert abs(costs[0] - 8.0 * (1 / 8)) < 0.05 and costs[1] < costs[0]       # mean_l coeff_l * sum_frames cos ~ 8 * 1/8
+    adv2, _, costs2 = attacks.AENS_I2V_MF(names, depths={n: [2, 3] for n in names}, step_size=0.005, steps=2,
+                                          momentum=0.5)(vid, torch.zeros(1, dtype=torch.long), ["v"])
+    assert torch.equal(adv, adv2) and np.array_equal(costs, costs2)
+
+
+def test_proxy_fooling_rate_parity(eng, tmp_path, monkeypatch):
+    """The metric's second half on what is available offline: adversarial clips from the CPU oracle and
+    from the HIP path, scored by the SAME evaluator code (reference.py contract) with its built-in proxy
+    video models, must give the same top-1 / fooling rate (north_star: within +-0.5 %)."""
+    import reference as ev
+    monkeypatch.setenv("I2V_OPT_PATH", str(tmp_path))
+    g = graphs.build_tiny("resnet", (64, 64))
+    sd = weights.synthetic_state_dict(g, 0)
+    onet = restate.OracleNet(g, sd, [g.hooks[3]])
+    atk = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=3, step_size=0.005, steps=6, graph_builder=graphs.build_tiny)
+    for d in ("oracle", "hip", "clean"):
+        (tmp_path / d).mkdir()
+    for label in range(10):
+        u8 = torch.randint(0, 256, (1, 3, 4, 64, 64), generator=torch.Generator().manual_seed(300 + label), dtype=torch.uint8)
+        vid = gu.videos_of({"clip_u8": u8.numpy()})
+        np.save(tmp_path / "clean" / f"{label}-ori.npy", vid[0].numpy())
+        np.save(tmp_path / "oracle" / f"{label}-adv.npy", restate.run_attack([onet], vid, steps=6, step_size=0.005)["adv"][0].contiguous().numpy())
+        np.save(tmp_path / "hip" / f"{label}-adv.npy", atk(vid, torch.zeros(1, dtype=torch.long), [str(label)])[0].cpu().numpy())
+    common = ["--models", "i3d_resnet50,slowfast_resnet50,tpn_resnet50", "--clean_dir", str(tmp_path / "clean")]
+    a = ev.main(["--adv_path", "oracle"] + common)
+    b = ev.main(["--adv_path", "hip"] + common)
+    for k in a:
+        assert abs(a[k] - b[k]) <= 0.5, (a, b)
+    assert (tmp_path / "hip" / "results_all_models_prediction.csv").read_text() == \
+        (tmp_path / "oracle" / "results_all_models_prediction.csv").read_text()
