@@ -283,6 +283,13 @@ extern "C" int i2v_net_create(i2v_handle h, int* net) {
     return 0;
 }
 
+extern "C" int i2v_net_destroy(i2v_handle h, int net) {
+    Net* n = get_net(h, net); if (!n) return 1;
+    free_net(n);
+    h->nets[net] = nullptr;          // ids are never reused
+    return 0;
+}
+
 extern "C" int i2v_net_add_buffer(i2v_handle h, int net, int C, int H, int W, int* buf) {
     Net* n = get_net(h, net); if (!n) return 1;
     if (n->planned) return fail("net already planned");

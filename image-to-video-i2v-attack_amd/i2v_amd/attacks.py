@@ -88,6 +88,8 @@ class _ImageGuided(Attack):
         key = (hw, )
         if self._nets is not None and self._net_key == key and self._max_frames >= frames:
             return self._nets
+        for old in (self._nets or []):          # re-planning for a larger batch / other resolution
+            old.close()
         nets = []
         for m, ds in zip(self.model_names, self._depths):
             g = self._builder(m, hw)

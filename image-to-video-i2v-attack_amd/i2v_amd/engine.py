@@ -155,6 +155,12 @@ class Net:
         hi.shape = (ts.C, ts.H, ts.W)
         return hi
 
+    def close(self):
+        """Release the arena and packed weights now (they also go when the engine is destroyed)."""
+        if self.id is not None and self.eng.h:
+            self.eng.capi.i2v_net_destroy(self.eng.h, self.id)
+        self.id = None
+
     def workspace_bytes(self) -> int:
         return self.eng.capi.i2v_net_workspace_bytes(self.eng.h, self.id)
 

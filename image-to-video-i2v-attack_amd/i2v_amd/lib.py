@@ -33,6 +33,7 @@ _PROTOS = {
     "i2v_abi_version": ([], _I),
     "i2v_backend": ([], C.c_char_p),
     "i2v_net_create": ([_P, C.POINTER(_I)], _I),
+    "i2v_net_destroy": ([_P, _I], _I),
     "i2v_net_add_buffer": ([_P, _I, _I, _I, _I, C.POINTER(_I)], _I),
     "i2v_net_add_tensor": ([_P, _I, _I, _I, _I, _I, C.POINTER(_I)], _I),
     "i2v_net_set_input": ([_P, _I, _I], _I),

@@ -51,6 +51,8 @@ typedef struct {
 } i2v_pool_desc;
 
 int i2v_net_create(i2v_handle h, int* net);
+/* Frees the backbone's packed weights and arena (net ids are not reused). */
+int i2v_net_destroy(i2v_handle h, int net);
 int i2v_net_add_buffer(i2v_handle h, int net, int C, int H, int W, int* buf);
 int i2v_net_add_tensor(i2v_handle h, int net, int buf, int c_off, int C, int post_relu, int* tensor);
 int i2v_net_set_input(i2v_handle h, int net, int tensor);

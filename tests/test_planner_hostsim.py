@@ -133,3 +133,8 @@ def test_error_paths():
     from i2v_amd.lib import I2VError
     with pytest.raises(I2VError):
         net.forward(torch.zeros(3, 3, 32, 32))          # more frames than planned
+    net.close()
+    with pytest.raises(I2VError):
+        eng.capi.i2v_net_forward  # noqa: B018
+        from i2v_amd import lib
+        lib.check(eng.capi, eng.capi.i2v_net_workspace_bytes(eng.h, 10 ** 6) or 1)   # bad id -> error text
