@@ -242,8 +242,13 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         if (c0 < nchunks) I2V_ISSUE_CHUNK(c0 * KC, c0);
     int buf = 0, nbuf = NST - 1;
     for (int c = 0; c < nchunks; ++c) {
-        if (UNIFORM && NST == 3 && c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this wave's DMA of chunk c: everything but the youngest min(NST-2, chunks left) chunks must be back
+        if (UNIFORM && NST >= 3) {
+            const int ahead = nchunks - 1 - c;                   // chunks issued after c that may stay in flight
+            if (NST >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (c + NST - 1 < nchunks) I2V_ISSUE_CHUNK((c + NST - 1) * KC, nbuf);
