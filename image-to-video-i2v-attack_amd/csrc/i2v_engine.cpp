@@ -658,12 +658,13 @@ static TimedLaunch* timing_begin(i2v_ctx* h, int kind, double flops, i2v_stream_
 }
 
 static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int frames, const float* x, float* gx, int accumulate,
-                    i2v_stream_t s) {
+                    i2v_stream_t s, bool backward_pass) {
     for (Launch& l : L) {
         double flops = 0.0;
         if (l.kind == L_CONV) flops = 2.0 * frames * l.conv.Hg * l.conv.Wg * (double)l.conv.Cd * l.conv.K;
         else if (l.kind == L_IMGGRAD) flops = l.alg_flops_per_frame * frames;
-        TimedLaunch* tl = timing_begin(h, (int)l.kind, flops, s);
+        // timing kinds: 0 conv fwd, 1 image gradient, 2 pool fwd, 3 pool bwd, 4 addmask, 5 conv input-gradient
+        TimedLaunch* tl = timing_begin(h, (l.kind == L_CONV && backward_pass) ? 5 : (int)l.kind, flops, s);
         if (tl && (l.kind == L_CONV || l.kind == L_IMGGRAD)) { tl->Cd = l.conv.Cd; tl->K = l.conv.K; tl->HWg = l.conv.Hg * l.conv.Wg; tl->frames = frames; tl->pw = l.conv.pointwise; }
         struct Stop { TimedLaunch* t; i2v_stream_t s; ~Stop() { if (t) be_event_record(t->stop, s); } } stop{tl, s};
         switch (l.kind) {
@@ -710,14 +711,14 @@ extern "C" int i2v_net_forward(i2v_handle h, int net, const float* x, int frames
     if (frames <= 0 || frames > n->maxN) return fail("frames=%d outside 1..%d", frames, n->maxN);
     if (!x) return fail("null input");
     n->frames = frames;
-    return run_list(h, *n, n->fwd, frames, x, nullptr, 0, stream);
+    return run_list(h, *n, n->fwd, frames, x, nullptr, 0, stream, false);
 }
 
 extern "C" int i2v_net_backward(i2v_handle h, int net, float* gx, int accumulate, void* stream) {
     Net* n = get_net(h, net); if (!n) return 1;
     if (!n->planned || n->frames <= 0) return fail("backward before forward");
     if (!gx) return fail("null gradient output");
-    return run_list(h, *n, n->bwd, n->frames, nullptr, gx, accumulate, stream);
+    return run_list(h, *n, n->bwd, n->frames, nullptr, gx, accumulate, stream, true);
 }
 
 extern "C" int i2v_timing_enable(i2v_handle h, int enable) {
@@ -726,10 +727,10 @@ extern "C" int i2v_timing_enable(i2v_handle h, int enable) {
     return 0;
 }
 
-// kinds: 0 conv_igemm (MFMA), 1 first-layer image gradient, 2 pool fwd, 3 pool bwd, 4 addmask
+// kinds: 0 conv_igemm forward, 1 first-layer image gradient, 2 pool fwd, 3 pool bwd, 4 addmask, 5 conv_igemm dgrad
 extern "C" int i2v_timing_collect(i2v_handle h, double* ms_by_kind, double* flops_by_kind, int64_t* launches_by_kind,
                                   int n_kinds) {
-    if (!h || !ms_by_kind || !flops_by_kind || !launches_by_kind || n_kinds < 5) return fail("i2v_timing_collect: bad argument");
+    if (!h || !ms_by_kind || !flops_by_kind || !launches_by_kind || n_kinds < 6) return fail("i2v_timing_collect: bad argument");
     for (int i = 0; i < n_kinds; ++i) { ms_by_kind[i] = 0; flops_by_kind[i] = 0; launches_by_kind[i] = 0; }
     if (h->timed_used) CHECK_BE(be_stream_sync(h->timed_stream));
     const char* dump_path = getenv("I2V_TIMING_DUMP");      // debug: one line per launch

@@ -52,7 +52,7 @@ class Engine:
         return Net(self, graph, state_dict, list(hook_tensors), max_frames)
 
     # ---- measurement ----
-    KINDS = ("conv_igemm", "conv_igemm_imggrad", "pool_fwd", "pool_bwd", "addmask")
+    KINDS = ("conv_igemm_fwd", "conv_igemm_imggrad", "pool_fwd", "pool_bwd", "addmask", "conv_igemm_dgrad")
 
     def timing_enable(self, on=True):
         _lib.check(self.capi, self.capi.i2v_timing_enable(self.h, 1 if on else 0))

@@ -85,8 +85,9 @@ int i2v_net_read_tensor(i2v_handle h, int net, int tensor, int which, float* out
 
 /* ---- measurement (bench.py `roofline`) ---------------------------------------------------
  * When enabled, every backbone launch is bracketed by a HIP event pair on its own stream;
- * `i2v_timing_collect` synchronises that stream and returns, per kernel kind (0 conv_igemm,
- * 1 first-layer image gradient, 2 pool fwd, 3 pool bwd, 4 addmask), the summed device time,
+ * `i2v_timing_collect` synchronises that stream and returns, per kernel kind (0 conv_igemm forward,
+ * 1 first-layer image gradient, 2 pool fwd, 3 pool bwd, 4 addmask, 5 conv_igemm input-gradient; n_kinds >= 6),
+ * the summed device time,
  * the summed ALGORITHMIC flops (2*pixels*Cout*Cin*kh*kw per convolution launch) and the launch
  * count since the last collect. */
 int i2v_timing_enable(i2v_handle h, int enable);
