@@ -122,8 +122,9 @@ class MIFGSM(BIM):
 
 class ILAF(object):
     """`image_attacks.py:498-629`: fine-tunes an existing adversarial clip along the feature
-    direction of a white-box VIDEO model.  The model, its hooks and the loss stay in PyTorch (the
-    3-D backbones are gluoncv's); compose and the sign update run in the library.
+    direction of a white-box VIDEO model.  The model, its hooks, the differentiable compose and the
+    loss stay in PyTorch (the 3-D backbones are gluoncv's, SURVEY.md 8(f) N2, and autograd has to see
+    the path from `modifier` to the features); the sign update runs in the library.
     The reference's return value applies reshape(b,f,c,h,w).permute(0,2,1,3,4) to a tensor that is
     already (b,c,f,h,w) (`:627-628`); that scramble is reproduced for drop-in fidelity."""
 
