@@ -780,6 +780,12 @@ extern "C" int i2v_net_read_tensor(i2v_handle h, int net, int tensor, int which,
 // ---------------------------------------------------------------------------------------------
 // loop kernels
 // ---------------------------------------------------------------------------------------------
+extern "C" int i2v_clip_from_u8_f32(const uint8_t* frames, float* video, int b, int t, int hh, int w, void* stream) {
+    if (!frames || !video || b <= 0 || t <= 0 || hh <= 0 || w <= 0) return fail("i2v_clip_from_u8_f32: bad argument");
+    CHECK_BE(k_clip_from_u8(frames, video, b, t, hh, w, stream));
+    return 0;
+}
+
 extern "C" int i2v_frames_from_video_f32(const float* video, float* x, float* u, int b, int f, int hh, int w,
                                          void* stream) {
     if (!video || !x || !u || b <= 0 || f <= 0 || hh <= 0 || w <= 0) return fail("i2v_frames_from_video_f32: bad argument");

@@ -29,6 +29,7 @@ int k_addmask(const I2VAddMaskParams& p, i2v_stream_t s);
 int k_cos(const I2VCosParams& p, i2v_stream_t s);
 int k_std_reduce(const I2VStdParams& p, i2v_stream_t s);   // -> p.sums[0..1]
 int k_std_grad(const I2VStdParams& p, i2v_stream_t s);     // p.sums, p.total_count -> std_out, grad
+int k_clip_from_u8(const uint8_t* frames, float* video, int b, int t, int h, int w, i2v_stream_t s);
 int k_frames_from_video(const float* video, float* x, float* u, int b, int f, int h, int w, i2v_stream_t s);
 int k_compose(const float* u, const float* delta, float* x, int b, int f, int h, int w, float eps,
               int video_layout, i2v_stream_t s);

@@ -775,6 +775,19 @@ int k_std_grad(const I2VStdParams& p, i2v_stream_t s) {
 // =============================================================================================
 // frame flatten + un-normalise, compose, Adam (+ compose backward), sign steps, AENS weights
 // =============================================================================================
+// decoded uint8 frames (b, t, h, w, 3) -> normalised clip (b, 3, t, h, w): ClipToTensor (/255) + Normalize
+// ((x - mean)/std), the tail of the reference's loader (datasets.py:88-93), fused with the layout change
+__global__ void clip_from_u8_kernel(const uint8_t* __restrict__ frames, float* __restrict__ video, int b, int t, int hw) {
+    const int64_t total = (int64_t)b * 3 * t * hw;
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int i = o % hw; int64_t r = o / hw;
+        const int ti = r % t; r /= t;
+        const int c = r % 3; const int64_t bi = r / 3;
+        const float v = __fdiv_rn((float)frames[((bi * t + ti) * hw + i) * 3 + c], 255.f);
+        video[o] = __fdiv_rn(__fsub_rn(v, c_mean[c]), c_std[c]);
+    }
+}
+
 __global__ void frames_from_video_kernel(const float* __restrict__ video, float* __restrict__ x, float* __restrict__ u,
                                          int b, int f, int hw) {
     const int64_t total = (int64_t)b * 3 * f * hw;
@@ -870,6 +883,11 @@ __global__ void aens_reduce_kernel(const float* cosv, const float* coeffs, int L
     if (threadIdx.x == 0) { feat_sum[l] = (float)s; weighted[l] = coeffs[l] * (float)s; }
 }
 
+int k_clip_from_u8(const uint8_t* frames, float* video, int b, int t, int h, int w, i2v_stream_t s) {
+    const int64_t total = (int64_t)b * 3 * t * h * w;
+    hipLaunchKernelGGL(clip_from_u8_kernel, dim3(stream_grid(total, 1024)), dim3(256), 0, (hipStream_t)s, frames, video, b, t, h * w);
+    LAUNCH_CHECK("clip_from_u8"); return 0;
+}
 int k_frames_from_video(const float* video, float* x, float* u, int b, int f, int h, int w, i2v_stream_t s) {
     const int64_t total = (int64_t)b * 3 * f * h * w;
     hipLaunchKernelGGL(frames_from_video_kernel, dim3(stream_grid(total, 1024)), dim3(256), 0, (hipStream_t)s, video, x, u, b, f, h * w);

@@ -64,6 +64,14 @@ class Engine:
         return {k: dict(ms=ms[i], flops=fl[i], launches=cnt[i]) for i, k in enumerate(self.KINDS)}
 
     # ---- loop kernels (thin, typed wrappers) ----
+    def clip_from_u8(self, frames_u8: torch.Tensor) -> torch.Tensor:
+        """(b,t,h,w,3) uint8 decoded frames on the device -> normalised (b,3,t,h,w) float32 clip."""
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and frames_u8.shape[-1] == 3
+        b, t, h, w, _ = frames_u8.shape
+        out = torch.empty(b, 3, t, h, w, dtype=torch.float32, device=frames_u8.device)
+        _lib.check(self.capi, self.capi.i2v_clip_from_u8_f32(C.c_void_p(frames_u8.data_ptr()), _ptr(out), b, t, h, w, self.stream()))
+        return out
+
     def frames_from_video(self, video, x, u):
         b, c, f, h, w = video.shape
         _lib.check(self.capi, self.capi.i2v_frames_from_video_f32(_ptr(video), _ptr(x), _ptr(u), b, f, h, w, self.stream()))

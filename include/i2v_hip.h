@@ -95,6 +95,10 @@ int i2v_timing_collect(i2v_handle h, double* ms_by_kind, double* flops_by_kind,
                        int64_t* launches_by_kind, int n_kinds);
 
 /* ---- loop kernels ------------------------------------------------------------------------ */
+/* Decoded, resized and cropped uint8 frames (b,t,h,w,3) -> normalised clip (b,3,t,h,w): the tail of
+ * the reference's loader, `ClipToTensor` (/255) + `Normalize(mean,std)` (datasets.py:88-93), fused
+ * with the layout change (decoding/resizing stay on the host). */
+int i2v_clip_from_u8_f32(const uint8_t* frames, float* video, int b, int t, int h, int w, void* stream);
 /* videos (b,3,f,h,w) normalised -> frames x:(b*f,3,h,w), frame n = b_idx*f + f_idx
  * (image_attacks.py:300-301) and u = x*std + mean (`_transform_video(...,'back')`, :62,308). */
 int i2v_frames_from_video_f32(const float* video, float* x, float* u, int b, int f, int h, int w,

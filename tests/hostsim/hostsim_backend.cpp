@@ -177,6 +177,16 @@ int k_std_grad(const I2VStdParams& p, i2v_stream_t) {
     return 0;
 }
 
+int k_clip_from_u8(const uint8_t* frames, float* video, int b, int t, int h, int w, i2v_stream_t) {
+    size_t hw = (size_t)h * w;
+    for (int bi = 0; bi < b; ++bi) for (int c = 0; c < 3; ++c) for (int ti = 0; ti < t; ++ti) for (size_t i = 0; i < hw; ++i) {
+        volatile float v = (float)frames[(((size_t)bi * t + ti) * hw + i) * 3 + c] / 255.f;
+        volatile float d = v - MEAN[c];
+        video[(((size_t)bi * 3 + c) * t + ti) * hw + i] = d / STD[c];
+    }
+    return 0;
+}
+
 int k_frames_from_video(const float* video, float* x, float* u, int b, int f, int h, int w, i2v_stream_t) {
     size_t hw = (size_t)h * w;
     for (int bi = 0; bi < b; ++bi) for (int c = 0; c < 3; ++c) for (int fi = 0; fi < f; ++fi)

@@ -54,6 +54,14 @@ def test_frames_compose_bit_exact(eng):
     assert torch.equal(outv.cpu(), restate.unflatten_frames(ref, 2, 5).contiguous())
 
 
+def test_clip_from_u8_bit_exact(eng):
+    u8 = torch.randint(0, 256, (2, 4, 9, 10, 3), generator=torch.Generator().manual_seed(4), dtype=torch.uint8)
+    got = eng.clip_from_u8(u8.to("cuda:0")).cpu()
+    mean = torch.tensor(gu.MEAN).view(1, 3, 1, 1, 1)
+    std = torch.tensor(gu.STD).view(1, 3, 1, 1, 1)
+    assert torch.equal(got, (u8.permute(0, 4, 1, 2, 3).float() / 255 - mean) / std)
+
+
 def test_adam_step_matches_torch_optim(eng):
     """Compose-backward + Adam against restate (itself bit-equal to torch.optim.Adam)."""
     gen = torch.Generator().manual_seed(6)

@@ -138,3 +138,14 @@ def test_error_paths():
         eng.capi.i2v_net_forward  # noqa: B018
         from i2v_amd import lib
         lib.check(eng.capi, eng.capi.i2v_net_workspace_bytes(eng.h, 10 ** 6) or 1)   # bad id -> error text
+
+
+def test_clip_from_u8_matches_loader_tail():
+    """ClipToTensor + Normalize + THWC->CTHW (the tail of /root/reference/datasets.py:88-93)."""
+    eng = hostsim_engine()
+    u8 = torch.randint(0, 256, (2, 3, 5, 6, 3), generator=torch.Generator().manual_seed(4), dtype=torch.uint8)
+    got = eng.clip_from_u8(u8)
+    mean = torch.tensor(gu.MEAN).view(1, 3, 1, 1, 1)
+    std = torch.tensor(gu.STD).view(1, 3, 1, 1, 1)
+    ref = (u8.permute(0, 4, 1, 2, 3).float() / 255 - mean) / std
+    assert torch.equal(got, ref)
