@@ -56,21 +56,24 @@ struct Packed {               // one implicit-GEMM operand set
 };
 
 struct Node {
-    int type;                 // 0 conv, 1 maxpool
+    int type;                 // 0 conv, 1 maxpool, 2 avgpool
     i2v_conv_desc cd; i2v_pool_desc pd;
     std::vector<float> w;     // [cout][cin][kh][kw] with scale folded
     std::vector<float> shift;
-    float* shift_d = nullptr;
+    std::vector<float> pre_scale, pre_shift;      // pre-activation conv (DenseNet): per input channel
+    float* shift_d = nullptr; float* pre_scale_d = nullptr; float* pre_shift_d = nullptr;   // *_d padded to Kpad
+    bool preact() const { return !pre_scale.empty(); }
     Packed fwd; std::vector<Packed> bwd;
     Packed img; int img_blk = 0, img_sh = 1;      // input-gradient of the first conv (class-packed)
     size_t idx_off = 0;                           // maxpool: arg-max bytes, arena offset in floats
 };
 
-enum Kind { L_CONV, L_IMGGRAD, L_POOLF, L_POOLB, L_ADDMASK };   // L_IMGGRAD: conv_igemm with class-packed Cd
+enum Kind { L_CONV, L_IMGGRAD, L_POOLF, L_POOLB, L_ADDMASK, L_CONVB_UNUSED, L_AVGF, L_AVGB, L_MEMSET };   // L_IMGGRAD: conv_igemm with class-packed Cd
 struct Launch {
     Kind kind;
     I2VConvParams conv; I2VPoolParams pool; I2VAddMaskParams am;
     bool src_is_input = false;     // conv: src pointer patched with the caller's x
+    float* ms_ptr = nullptr; size_t ms_floats_per_frame = 0;   // L_MEMSET
     double alg_flops_per_frame = 0; // L_IMGGRAD: algorithmic (not class-padded) flops
 };
 
@@ -167,7 +170,7 @@ static int pack_bwd(Net& n, Node& nd) {
                         kt[k] = I2VKEntry{co * db.H * db.W, dh, dw, 1};
                         for (int ci = 0; ci < c.cin; ++ci)
                             wp[(size_t)k * P.Cdpad + ci] =
-                                nd.w[(((size_t)co * c.cin + ci) * c.kh + r) * c.kw + s];
+                                nd.w[(((size_t)co * c.cin + ci) * c.kh + r) * c.kw + s] * (nd.preact() ? nd.pre_scale[ci] : 1.f);
                     }
                     ++t;
                 }
@@ -344,6 +347,29 @@ extern "C" int i2v_net_add_conv(i2v_handle h, int net, const i2v_conv_desc* d, c
     return 0;
 }
 
+extern "C" int i2v_net_add_conv_preact(i2v_handle h, int net, const i2v_conv_desc* d, const float* weight,
+                                       const float* scale, const float* shift, const float* pre_scale,
+                                       const float* pre_shift) {
+    if (!d || !pre_scale || !pre_shift) return fail("i2v_net_add_conv_preact: null argument");
+    if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->residual >= 0)
+        return fail("pre-activation is supported on plain 1x1/stride-1 convolutions only");
+    if (i2v_net_add_conv(h, net, d, weight, scale, shift)) return 1;
+    Net* n = get_net(h, net);
+    if (n->tens[d->src].post_relu) return fail("pre-activation input must not be a ReLU output");
+    Node& nd = n->nodes.back();
+    nd.pre_scale.assign(pre_scale, pre_scale + d->cin);
+    nd.pre_shift.assign(pre_shift, pre_shift + d->cin);
+    return 0;
+}
+
+extern "C" int i2v_net_add_avgpool(i2v_handle h, int net, const i2v_pool_desc* d) {
+    if (i2v_net_add_maxpool(h, net, d)) return 1;
+    Net* n = get_net(h, net);
+    if (d->pad != 0) return fail("average pooling with padding is not supported");
+    n->nodes.back().type = 2;
+    return 0;
+}
+
 extern "C" int i2v_net_add_maxpool(i2v_handle h, int net, const i2v_pool_desc* d) {
     Net* n = get_net(h, net); if (!n) return 1;
     if (n->planned) return fail("net already planned");
@@ -375,6 +401,7 @@ struct Planner {
     std::vector<int> left; std::vector<std::vector<Addend>> pending;
     std::vector<float*> hook_tmp;      // per hook: temp gradient buffer or null (direct)
     std::vector<View> galias; std::vector<char> has_alias;   // residual gradient that is just a view
+    std::vector<char> accum;                                 // per buffer: gradient accumulates (dense blocks)
     std::string err;
 
     float* base() const { return dry ? (float*)nullptr : n.arena; }
@@ -501,9 +528,20 @@ struct Planner {
     bool run() {
         const int NT = (int)n.tens.size();
         left.assign(NT, 0); pending.assign(NT, {}); galias.assign(NT, View{}); has_alias.assign(NT, 0);
+        // Buffers read through a pre-activation conv (DenseNet concatenation buffers) ACCUMULATE their
+        // gradient: zeroed at the start of the backward pass, every reader adds into its view.  They stay
+        // outside the single-finaliser protocol (`left` / `pending`) of all other tensors.
+        accum.assign(n.bufs.size(), 0);
+        for (const Node& nd : n.nodes) if (nd.type == 0 && nd.preact()) accum[n.tens[nd.cd.src].buf] = 1;
         for (const Node& nd : n.nodes) {
-            if (nd.type == 0) { left[nd.cd.src]++; if (nd.cd.residual >= 0) left[nd.cd.residual]++; }
-            else left[nd.pd.src]++;
+            if (nd.type == 0) {
+                if (accum[n.tens[nd.cd.src].buf] && !nd.preact()) { err = "a dense (accumulating) buffer may only be read by pre-activation convs"; return false; }
+                if (!nd.preact()) left[nd.cd.src]++;
+                if (nd.cd.residual >= 0) left[nd.cd.residual]++;
+            } else {
+                if (accum[n.tens[nd.pd.src].buf]) { err = "pooling directly from a dense (accumulating) buffer is not supported"; return false; }
+                left[nd.pd.src]++;
+            }
         }
         // ---------------- forward ----------------
         for (const Node& nd : n.nodes) {
@@ -522,9 +560,10 @@ struct Planner {
                 if (c.residual >= 0) { View r = view(c.residual, false); p.add0 = r.p; p.add0_nstride = r.nstride; p.add0_stride = 1; }
                 p.pointwise = (c.kh == 1 && c.kw == 1 && c.stride == 1 && c.pad == 0 && (sb.H * sb.W) % 4 == 0 &&
                                c.src != n.input) ? 1 : 0;
+                if (nd.preact()) { p.pre_scale = nd.pre_scale_d; p.pre_shift = nd.pre_shift_d; }
             } else {
                 const i2v_pool_desc& q = nd.pd;
-                l.kind = L_POOLF; memset(&l.pool, 0, sizeof l.pool);
+                l.kind = nd.type == 2 ? L_AVGF : L_POOLF; memset(&l.pool, 0, sizeof l.pool);
                 View s = view(q.src, false), d = view(q.dst, false);
                 if (q.src == n.input) { err = "maxpool directly on the input is not supported"; return false; }
                 l.pool.x = s.p; l.pool.x_nstride = s.nstride; l.pool.C = s.C; l.pool.Hs = s.H; l.pool.Ws = s.W;
@@ -543,14 +582,28 @@ struct Planner {
                 int srcs[2] = {nd.type == 0 ? nd.cd.src : nd.pd.src, nd.type == 0 ? nd.cd.residual : -1};
                 for (int s : srcs) if (s >= 0 && overlaps(n.tens[s], n.tens[t])) consumed = true;
             }
-            if (consumed) { View g = view(t, true); hook_tmp[hk] = temp(N * g.C * g.H * g.W); }
+            if (consumed || accum[n.tens[t].buf]) { View g = view(t, true); hook_tmp[hk] = temp(N * g.C * g.H * g.W); }
         }
         // ---------------- backward ----------------
+        for (size_t b = 0; b < n.bufs.size(); ++b)
+            if (accum[b]) {
+                Launch l; l.kind = L_MEMSET;
+                l.ms_ptr = base() + n.bufs[b].grad_off; l.ms_floats_per_frame = (size_t)n.bufs[b].C * n.bufs[b].H * n.bufs[b].W;
+                emit(n.bwd, l);
+            }
+        for (size_t hk = 0; hk < n.hooks.size(); ++hk)          // hook gradients of dense buffers: G += H right away
+            if (accum[n.tens[n.hooks[hk]].buf]) {
+                const int t = n.hooks[hk];
+                View g = view(t, true);
+                std::vector<Addend> adds = {Addend{g.p, g.nstride, 1, g.H, g.W},
+                                            Addend{hook_tmp[hk], (int64_t)g.C * g.H * g.W, 1, g.H, g.W}};
+                emit_addmask(g, adds, t);
+            }
         for (int i = (int)n.nodes.size() - 1; i >= 0; --i) {
             const Node& nd = n.nodes[i];
             int dst = nd.type == 0 ? nd.cd.dst : nd.pd.dst;
             for (size_t hk = 0; hk < n.hooks.size(); ++hk)
-                if (n.hooks[hk] == dst && hook_tmp[hk]) {
+                if (n.hooks[hk] == dst && hook_tmp[hk] && !accum[n.tens[dst].buf]) {
                     View g = view(dst, true);
                     std::vector<Addend> adds = {Addend{g.p, g.nstride, 1, g.H, g.W},
                                                 Addend{hook_tmp[hk], (int64_t)g.C * g.H * g.W, 1, g.H, g.W}};
@@ -570,12 +623,24 @@ struct Planner {
                     p.osh = p.osw = nd.img_blk; p.blk = nd.img_blk;
                     l.alg_flops_per_frame = 2.0 * dz.H * dz.W * c.cout * c.cin * c.kh * c.kw;
                     emit(n.bwd, l);
+                } else if (nd.preact()) {
+                    // G(view) += W'^T dz gated by the pre-activation sign; W' carries the BN scale per input channel
+                    View g = view(c.src, true), x = view(c.src, false);
+                    Launch l; l.kind = L_CONV; conv_common(l.conv, nd.bwd[0]);
+                    I2VConvParams& p = l.conv;
+                    p.src = dz.p; p.src_nstride = dz.nstride; p.Hs = dz.H; p.Ws = dz.W; p.Cs = dz.C;
+                    p.Hg = g.H; p.Wg = g.W; p.sh = p.sw = 1;
+                    p.dst = g.p; p.dst_nstride = g.nstride; p.Ho = g.H; p.Wo = g.W; p.osh = p.osw = 1;
+                    p.add1 = g.p; p.add1_nstride = g.nstride;
+                    p.mask = x.p; p.mask_nstride = x.nstride; p.gate_scale = nd.pre_scale_d; p.gate_shift = nd.pre_shift_d;
+                    p.pointwise = ((dz.H * dz.W) % 4 == 0) ? 1 : 0;
+                    emit(n.bwd, l);
                 } else if (!contribute_conv(c.src, nd, dz)) return false;
             } else {
                 const i2v_pool_desc& q = nd.pd;
                 left[q.src]--;
                 if (left[q.src] > 0 || !pending[q.src].empty()) { err = "maxpool input with several consumers is not supported"; return false; }
-                Launch l; l.kind = L_POOLB; memset(&l.pool, 0, sizeof l.pool);
+                Launch l; l.kind = nd.type == 2 ? L_AVGB : L_POOLB; memset(&l.pool, 0, sizeof l.pool);
                 View x = view(q.src, false), gx = view(q.src, true);
                 l.pool.x = x.p; l.pool.x_nstride = x.nstride; l.pool.C = x.C; l.pool.Hs = x.H; l.pool.Ws = x.W;
                 l.pool.y = dz.p; l.pool.y_nstride = dz.nstride; l.pool.Ho = dz.H; l.pool.Wo = dz.W;
@@ -608,6 +673,11 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
         if (nd.type != 0) continue;
         if (upload(n, nd.shift, &nd.shift_d)) return 1;
         if (pack_fwd(n, nd)) return 1;
+        if (nd.preact()) {          // operand-side affine, padded to Kpad with zeros (relu(0*x+0) = 0 for the K tail)
+            std::vector<float> ps(nd.fwd.Kpad > nd.fwd.Cdpad ? nd.fwd.Kpad : nd.fwd.Cdpad, 0.f), pt(ps.size(), 0.f);
+            for (int c = 0; c < nd.cd.cin; ++c) { ps[c] = nd.pre_scale[c]; pt[c] = nd.pre_shift[c]; }
+            if (upload(n, ps, &nd.pre_scale_d) || upload(n, pt, &nd.pre_shift_d)) return 1;
+        }
         if (nd.cd.src == n.input) { if (pack_img(n, nd)) return 1; }
         else if (pack_bwd(n, nd)) return 1;
     }
@@ -664,7 +734,8 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int frames, cons
         if (l.kind == L_CONV) flops = 2.0 * frames * l.conv.Hg * l.conv.Wg * (double)l.conv.Cd * l.conv.K;
         else if (l.kind == L_IMGGRAD) flops = l.alg_flops_per_frame * frames;
         // timing kinds: 0 conv fwd, 1 image gradient, 2 pool fwd, 3 pool bwd, 4 addmask, 5 conv input-gradient
-        TimedLaunch* tl = timing_begin(h, (l.kind == L_CONV && backward_pass) ? 5 : (int)l.kind, flops, s);
+        const int tkind = (l.kind == L_CONV && backward_pass) ? 5 : l.kind == L_AVGF ? 2 : l.kind == L_AVGB ? 3 : l.kind == L_MEMSET ? 4 : (int)l.kind;
+        TimedLaunch* tl = timing_begin(h, tkind, flops, s);
         if (tl && (l.kind == L_CONV || l.kind == L_IMGGRAD)) { tl->Cd = l.conv.Cd; tl->K = l.conv.K; tl->HWg = l.conv.Hg * l.conv.Wg; tl->frames = frames; tl->pw = l.conv.pointwise; }
         struct Stop { TimedLaunch* t; i2v_stream_t s; ~Stop() { if (t) be_event_record(t->stop, s); } } stop{tl, s};
         switch (l.kind) {
@@ -698,6 +769,10 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int frames, cons
                 }
             } break;
             case L_POOLF: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool_fwd(p, s)); } break;
+            case L_AVGF: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_avgpool_fwd(p, s)); } break;
+            case L_AVGB: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_avgpool_bwd(p, s)); } break;
+            case L_MEMSET: CHECK_BE(be_memset0(l.ms_ptr, l.ms_floats_per_frame * frames * sizeof(float), s)); break;
+            case L_CONVB_UNUSED: break;
             case L_POOLB: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool_bwd(p, s)); } break;
             case L_ADDMASK: { I2VAddMaskParams p = l.am; p.N = frames; CHECK_BE(k_addmask(p, s)); } break;
         }

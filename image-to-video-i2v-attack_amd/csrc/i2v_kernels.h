@@ -25,6 +25,8 @@ int  be_stream_sync(i2v_stream_t s);                                            
 int k_conv(const I2VConvParams& p, i2v_stream_t s);
 int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s);
+int k_avgpool_fwd(const I2VPoolParams& p, i2v_stream_t s);
+int k_avgpool_bwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_addmask(const I2VAddMaskParams& p, i2v_stream_t s);
 int k_cos(const I2VCosParams& p, i2v_stream_t s);
 int k_std_reduce(const I2VStdParams& p, i2v_stream_t s);   // -> p.sums[0..1]

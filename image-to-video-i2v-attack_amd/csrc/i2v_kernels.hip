@@ -75,7 +75,9 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 // 2: tap-uniform chunks (every 16-row K chunk shares one spatial tap: channel count % 16 == 0)
 // PREF (single-pass tiles only): the epilogue's addend / gate tiles are fetched into registers BEFORE the
 // K loop, so for the low-K, HBM-bound layers the read traffic overlaps the matrix work instead of following it.
-template <int BD, int BP, int WD, int WP, int MODE, bool PREF>
+// PRE: the B operand is relu(x * pre_scale[k] + pre_shift[k]) (DenseNet norm->relu->1x1 conv), applied when the
+// fragment is read from LDS; k == input channel for the 1x1 convolutions this is used on.
+template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false>
 __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-resource types and LDS-DMA builtins exist only in the device pass
     constexpr int KC = I2V_KC;
@@ -260,6 +262,14 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
             for (int i = 0; i < TD; ++i) fa[i] = As[buf][2 * s + lk][wd * (BD / WD) + i * 32 + l31];
 #pragma unroll
             for (int j = 0; j < TP; ++j) fb[j] = Bs[buf][2 * s + lk][wpx * (BP / WP) + j * 32 + l31];
+            if (PRE) {
+                typedef const __attribute__((address_space(4))) float* cfp;       // scalar (SMEM) loads
+                const int kr = c * KC + 2 * s;
+                const float sc = lk ? ((cfp)p.pre_scale)[kr + 1] : ((cfp)p.pre_scale)[kr];
+                const float sh = lk ? ((cfp)p.pre_shift)[kr + 1] : ((cfp)p.pre_shift)[kr];
+#pragma unroll
+                for (int j = 0; j < TP; ++j) fb[j] = fmaxf(fmaf(fb[j], sc, sh), 0.f);
+            }
 #pragma unroll
             for (int i = 0; i < TD; ++i)
 #pragma unroll
@@ -301,6 +311,14 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
                     if (cd >= p.Cd) continue;
                     float4 v = *reinterpret_cast<const float4*>(&Cs[row][c4 * 4]);
                     const int64_t o = (int64_t)cd * HoWo + poff;
+                    if (p.gate_scale) {      // pre-activation gate on THIS contribution, before the (accumulating) adds
+                        const float4 m = *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
+                        const float gs = p.gate_scale[cd], gt = p.gate_shift[cd];
+                        if (!(fmaf(m.x, gs, gt) > 0.f)) v.x = 0.f;
+                        if (!(fmaf(m.y, gs, gt) > 0.f)) v.y = 0.f;
+                        if (!(fmaf(m.z, gs, gt) > 0.f)) v.z = 0.f;
+                        if (!(fmaf(m.w, gs, gt) > 0.f)) v.w = 0.f;
+                    }
                     if (p.shift) { const float sh = p.shift[cd]; v.x += sh; v.y += sh; v.z += sh; v.w += sh; }
                     if (PREF) {
                         v.x += pre0[q].x; v.y += pre0[q].y; v.z += pre0[q].z; v.w += pre0[q].w;
@@ -325,7 +343,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
                         }
                     }
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (PREF || p.mask) {
+                    if (PREF || (p.mask && !p.gate_scale)) {
                         const float4 m = PREF ? pregate[q] : *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
                         if (!(m.x > 0.f)) v.x = 0.f;
                         if (!(m.y > 0.f)) v.y = 0.f;
@@ -399,11 +417,12 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
                 const int cd = cd0 + wd * (BD / WD) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (cd >= p.Cd) continue;
                 float v = acc[i][j][r];
+                if (p.gate_scale && !(fmaf(mk[(int64_t)cd * HoWo], p.gate_scale[cd], p.gate_shift[cd]) > 0.f)) v = 0.f;
                 if (p.shift) v += p.shift[cd];
                 if (a0) v += a0[(int64_t)cd * a0_plane];
                 if (a1) v += a1[(int64_t)cd * HoWo];
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (mk && !(mk[(int64_t)cd * HoWo] > 0.f)) v = 0.f;
+                if (mk && !p.gate_scale && !(mk[(int64_t)cd * HoWo] > 0.f)) v = 0.f;
                 dstn[(int64_t)cd * HoWo] = v;
             }
         }
@@ -414,7 +433,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
 // Low-K layers with epilogue operands are HBM-bound (their FLOP/byte is below the machine balance): they
 // run on 64x64 tiles with the epilogue operands prefetched under the K loop.
 static bool conv_wants_prefetch(const I2VConvParams& p) {
-    return p.vec_epilogue && p.add0_stride == 1 && (p.add0 || p.add1 || p.mask) && p.Kpad <= 256 && (p.pointwise || p.tap_uniform) && p.Cd > 32;
+    return p.vec_epilogue && !p.gate_scale && !p.pre_scale && p.add0_stride == 1 && (p.add0 || p.add1 || p.mask) && p.Kpad <= 256 && (p.pointwise || p.tap_uniform) && p.Cd > 32;
 }
 
 template <int BD, int BP, int WD, int WP>
@@ -425,7 +444,13 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     const int64_t grid = n_px * n_cd;
     if (grid <= 0) return 0;
     if (grid > 0x7fffffff) { snprintf(g_be_err, sizeof g_be_err, "conv grid too large"); g_be_has_err = true; return 1; }
-    if (BD == 64 && BP == 64 && conv_wants_prefetch(p)) {
+    if (p.pre_scale) {
+        if constexpr ((BD == 64 && BP == 64) || (BD == 128 && BP == 128)) {
+            if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 1, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+            else if (p.tap_uniform) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+            else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 0, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+        }
+    } else if (BD == 64 && BP == 64 && conv_wants_prefetch(p)) {
         if constexpr (BD == 64 && BP == 64) {
             if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 1, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
             else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
@@ -444,6 +469,10 @@ static int conv_pick(const I2VConvParams& p) {
     static const char* force = getenv("I2V_FORCE_CFG");        // developer knob (tools/conv_microbench.cpp)
     if (force && *force) return atoi(force);
     if (conv_wants_prefetch(p)) return 3;
+    if (p.pre_scale) {              // pre-activation variants exist for the 128x128 and 64x64 tiles only
+        const double blocks128 = ceil(p.Cd / 128.0) * ceil((double)p.N * p.Hg * p.Wg / 128.0);
+        return (p.Cd > 64 && blocks128 >= 256.0 * 6) ? 0 : 3;
+    }
     // ineff: relative cost per unit of tile area measured with tools/conv_microbench.cpp (small tiles pay
     // more operand traffic per MFMA); a launch that cannot fill the CUs' block slots also loses the overlap
     // between co-resident blocks.
@@ -565,6 +594,35 @@ __global__ void __launch_bounds__(256) pool_bwd_kernel(const I2VPoolParams p, co
     }
 }
 
+__global__ void avgpool_fwd_kernel(const I2VPoolParams p) {
+    const int64_t total = (int64_t)p.N * p.C * p.Ho * p.Wo;
+    const float inv = 1.f / (float)(p.k * p.k);
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int wo = idx % p.Wo; int64_t r = idx / p.Wo;
+        const int ho = r % p.Ho; r /= p.Ho;
+        const int c = r % p.C; const int64_t n = r / p.C;
+        const float* pl = p.x + n * p.x_nstride + (int64_t)c * p.Hs * p.Ws;
+        float s = 0.f;
+        for (int kr = 0; kr < p.k; ++kr)
+            for (int ks = 0; ks < p.k; ++ks) s += pl[(ho * p.stride + kr) * p.Ws + wo * p.stride + ks];
+        p.y[n * p.y_nstride + ((int64_t)c * p.Ho + ho) * p.Wo + wo] = s * inv;
+    }
+}
+
+__global__ void avgpool_bwd_kernel(const I2VPoolParams p) {
+    const int64_t total = (int64_t)p.N * p.C * p.Hs * p.Ws;
+    const float inv = 1.f / (float)(p.k * p.k);
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int w = idx % p.Ws; int64_t r = idx / p.Ws;
+        const int h = r % p.Hs; r /= p.Hs;
+        const int c = r % p.C; const int64_t n = r / p.C;
+        const int ho = h / p.stride, wo = w / p.stride;
+        const bool in = (h - ho * p.stride) < p.k && (w - wo * p.stride) < p.k && ho < p.Ho && wo < p.Wo;
+        p.gx[n * p.gx_nstride + ((int64_t)c * p.Hs + h) * p.Ws + w] =
+            in ? p.y[n * p.y_nstride + ((int64_t)c * p.Ho + ho) * p.Wo + wo] * inv : 0.f;
+    }
+}
+
 static unsigned stream_grid(int64_t total, int per_block) {
     int64_t b = (total + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -592,6 +650,15 @@ int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s) {
     dim3 grid((unsigned)(p.N * p.C), (unsigned)((p.Hs + band - 1) / band));
     hipLaunchKernelGGL(pool_bwd_kernel, grid, dim3(256), 0, (hipStream_t)s, p, band);
     LAUNCH_CHECK("pool_bwd"); return 0;
+}
+
+int k_avgpool_fwd(const I2VPoolParams& p, i2v_stream_t s) {
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(stream_grid((int64_t)p.N * p.C * p.Ho * p.Wo, 256)), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("avgpool_fwd"); return 0;
+}
+int k_avgpool_bwd(const I2VPoolParams& p, i2v_stream_t s) {
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(stream_grid((int64_t)p.N * p.C * p.Hs * p.Ws, 256)), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("avgpool_bwd"); return 0;
 }
 
 // =============================================================================================

@@ -29,6 +29,12 @@ struct I2VConvParams {
     const float* add0; int64_t add0_nstride; int32_t add0_stride, add0_H, add0_W;  // stride s>1: compact addend
     const float* add1; int64_t add1_nstride;
     const float* mask; int64_t mask_nstride;
+    // DenseNet pre-activation (norm -> relu -> 1x1 conv), pointwise launches only:
+    //   forward:  the B operand is relu(src * pre_scale[k] + pre_shift[k])        (arrays of Kpad floats, 0-padded)
+    //   backward: the gate is (mask * gate_scale[cd] + gate_shift[cd] > 0) instead of (mask > 0) and it gates the
+    //             accumulator BEFORE the addends (the gradient of a dense buffer accumulates: add1 == dst)
+    const float* pre_scale; const float* pre_shift;
+    const float* gate_scale; const float* gate_shift;
     int32_t relu;
     int32_t pointwise;  // 1: 1x1 / stride 1 / no padding, planes 16-byte aligned -> vector path
     int32_t tap_uniform; // 1: K rows are (tap-major, channel-minor) with channels % I2V_KC == 0, so every
@@ -48,7 +54,7 @@ struct I2VPoolParams {
     float* gx;         int64_t gx_nstride;                           // bwd only
     uint8_t* idx;      // [N][C][Ho][Wo] window-relative arg-max (r*k+s), written by fwd, read by bwd
     int32_t N, k, stride, pad, mask_relu;
-};
+};   // average pooling reuses it: fwd x -> y, bwd y (upstream gradient) -> gx
 
 // out = (a0 + a1 + a2) gated by (mask > 0); planes of HW elements, C channels, N frames
 struct I2VAddMaskParams {

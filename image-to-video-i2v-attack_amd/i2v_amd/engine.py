@@ -11,7 +11,7 @@ import torch
 
 from . import lib as _lib
 from .graphs import Graph
-from .weights import fold_affine
+from .weights import fold_affine, fold_pre_affine
 
 
 def _ptr(t: torch.Tensor):
@@ -142,10 +142,17 @@ class Net:
                 d = _lib.ConvDesc(self.ten_id[nd.src], self.ten_id[nd.dst], nd.cin, nd.cout, nd.kh, nd.kw,
                                   nd.stride, nd.pad, 1 if nd.relu else 0,
                                   -1 if nd.residual is None else self.ten_id[nd.residual])
-                _lib.check(capi, capi.i2v_net_add_conv(h, self.id, C.byref(d), _ptr(w), _ptr(scale), _ptr(shift)))
+                if nd.pre_bn:
+                    ps, pt = fold_pre_affine(nd, sd)
+                    ps, pt = ps.contiguous(), pt.contiguous()
+                    _lib.check(capi, capi.i2v_net_add_conv_preact(h, self.id, C.byref(d), _ptr(w), _ptr(scale), _ptr(shift),
+                                                                  _ptr(ps), _ptr(pt)))
+                else:
+                    _lib.check(capi, capi.i2v_net_add_conv(h, self.id, C.byref(d), _ptr(w), _ptr(scale), _ptr(shift)))
             else:
                 d = _lib.PoolDesc(self.ten_id[nd.src], self.ten_id[nd.dst], nd.k, nd.stride, nd.pad)
-                _lib.check(capi, capi.i2v_net_add_maxpool(h, self.id, C.byref(d)))
+                add = capi.i2v_net_add_avgpool if nd.op == "avgpool" else capi.i2v_net_add_maxpool
+                _lib.check(capi, add(h, self.id, C.byref(d)))
         hooks = (C.c_int * len(hook_tensors))(*[self.ten_id[t] for t in hook_tensors])
         _lib.check(capi, capi.i2v_net_plan(h, self.id, hooks, len(hook_tensors), max_frames))
         self.hook_tensors = hook_tensors

@@ -49,6 +49,7 @@ class ConvNode:
     bn: Optional[str]           # state_dict prefix of the BatchNorm2d that follows (ResNet)
     relu: bool                  # ReLU applied after (bias/bn [+ residual])
     residual: Optional[int] = None   # tensor added before the ReLU (Bottleneck identity)
+    pre_bn: Optional[str] = None     # DenseNet pre-activation: relu(BatchNorm(x)) applied to the conv INPUT
     op: str = "conv"
 
 
@@ -85,16 +86,17 @@ class Graph:
         return len(self.tensors) - 1
 
     def conv(self, src, cout, k, stride, pad, weight, bias=None, bn=None, relu=True,
-             residual=None, name="", dst_buf=None, dst_c_off=0) -> int:
+             residual=None, name="", dst_buf=None, dst_c_off=0, pre_bn=None) -> int:
         s = self.tensors[src]
         Ho = (s.H + 2 * pad - k) // stride + 1
         Wo = (s.W + 2 * pad - k) // stride + 1
         dst = self.new_tensor(cout, Ho, Wo, relu, name, dst_buf, dst_c_off)
+        assert pre_bn is None or (k == 1 and stride == 1 and pad == 0), "pre-activation only on 1x1 convs"
         self.nodes.append(ConvNode(src, dst, s.C, cout, k, k, stride, pad, weight, bias, bn,
-                                   relu, residual))
+                                   relu, residual, pre_bn))
         return dst
 
-    def maxpool(self, src, k, stride, pad=0, ceil_mode=False, name="") -> int:
+    def maxpool(self, src, k, stride, pad=0, ceil_mode=False, name="", dst_buf=None, dst_c_off=0, op="maxpool") -> int:
         s = self.tensors[src]
 
         def out(n):
@@ -105,9 +107,12 @@ class Graph:
             else:
                 o = (n + 2 * pad - k) // stride + 1
             return o
-        dst = self.new_tensor(s.C, out(s.H), out(s.W), False, name)
-        self.nodes.append(PoolNode(src, dst, k, stride, pad, ceil_mode))
+        dst = self.new_tensor(s.C, out(s.H), out(s.W), False, name, dst_buf, dst_c_off)
+        self.nodes.append(PoolNode(src, dst, k, stride, pad, ceil_mode, op))
         return dst
+
+    def avgpool(self, src, k, stride, name="", dst_buf=None, dst_c_off=0) -> int:
+        return self.maxpool(src, k, stride, 0, False, name, dst_buf, dst_c_off, op="avgpool")
 
     # -- analysis -------------------------------------------------------------
     def truncated(self, hook_tensors: List[int]) -> "Graph":
@@ -149,6 +154,9 @@ class Graph:
             if nd.bn:
                 for s in ("weight", "bias", "running_mean", "running_var"):
                     out[f"{nd.bn}.{s}"] = (nd.cout,)
+            if nd.pre_bn:
+                for s in ("weight", "bias", "running_mean", "running_var"):
+                    out[f"{nd.pre_bn}.{s}"] = (nd.cin,)
         return out
 
 
@@ -282,6 +290,47 @@ def squeezenet(width_div=1, in_hw=(224, 224), arch="squeezenet1_1") -> Graph:
 
 
 # ---------------------------------------------------------------------------
+# DenseNet-BC (torchvision `densenet121` / `densenet161`) -- extension, see `build`
+# ---------------------------------------------------------------------------
+def densenet(growth=32, block_config=(6, 12, 24, 16), init_features=64, bn_size=4, in_hw=(224, 224),
+             arch="densenet121") -> Graph:
+    """Hook d = output of `features.denseblock{d}` (the raw concatenation, not a ReLU output) -- the
+    only hint the reference gives for DenseNet (`image_attacks.py:98-99`).  A dense block is ONE buffer:
+    layer l reads its first C_l channels through BN+ReLU (pre-activation, folded into the 1x1 conv's
+    operand read) and appends `growth` channels."""
+    g = Graph(arch, in_hw)
+    x = g.new_tensor(3, in_hw[0], in_hw[1], False, "input")
+    g.input = x
+    x = g.conv(x, init_features, 7, 2, 3, "features.conv0.weight", bn="features.norm0", relu=True, name="features.relu0")
+    C = init_features
+    pending_pool = ("max", x)
+    for bi, nlayers in enumerate(block_config):
+        total = C + nlayers * growth
+        cb = g.new_buffer(total)
+        kind, src = pending_pool
+        if kind == "max":
+            v = g.maxpool(src, 3, 2, 1, name="features.pool0", dst_buf=cb, dst_c_off=0)
+        else:
+            v = g.avgpool(src, 2, 2, name=f"features.transition{bi}.pool", dst_buf=cb, dst_c_off=0)
+        H, W = g.tensors[v].H, g.tensors[v].W
+        for li in range(nlayers):
+            p = f"features.denseblock{bi + 1}.denselayer{li + 1}"
+            view = g.new_tensor(C, H, W, False, f"{p}.in", buf=cb, c_off=0)
+            a = g.conv(view, bn_size * growth, 1, 1, 0, f"{p}.conv1.weight", bn=f"{p}.norm2", relu=True,
+                       name=f"{p}.relu2", pre_bn=f"{p}.norm1")
+            g.conv(a, growth, 3, 1, 1, f"{p}.conv2.weight", relu=False, name=f"{p}.conv2", dst_buf=cb, dst_c_off=C)
+            C += growth
+        full = g.new_tensor(C, H, W, False, f"features.denseblock{bi + 1}", buf=cb, c_off=0)
+        g.hooks[bi + 1] = full
+        if bi != len(block_config) - 1:
+            p = f"features.transition{bi + 1}"
+            t = g.conv(full, C // 2, 1, 1, 0, f"{p}.conv.weight", relu=False, name=f"{p}.conv", pre_bn=f"{p}.norm")
+            C //= 2
+            pending_pool = ("avg", t)
+    return g
+
+
+# ---------------------------------------------------------------------------
 # name -> graph, following the reference's `get_model` vocabulary
 # ---------------------------------------------------------------------------
 def build(model_name: str, in_hw=(224, 224)) -> Graph:
@@ -298,6 +347,10 @@ def build(model_name: str, in_hw=(224, 224)) -> Graph:
         return alexnet(1, in_hw)
     if model_name == "squeezenet":
         return squeezenet(1, in_hw)
+    if model_name == "densenet121":     # extension (BASELINE.json configs[2] names it); see `densenet`
+        return densenet(32, (6, 12, 24, 16), 64, 4, in_hw, "densenet121")
+    if model_name == "densenet161":
+        return densenet(48, (6, 12, 36, 24), 96, 4, in_hw, "densenet161")
     if model_name == "densenet":
         # The reference constructs densenet161 (`image_attacks.py:96-97`) but no attack class
         # has a densenet branch in `_find_target_layer` (`:260-271`): the hook lookup returns
@@ -318,4 +371,6 @@ def build_tiny(model_name: str, in_hw=(64, 64)) -> Graph:
         return alexnet(8, in_hw, "alexnet_tiny")
     if model_name == "squeezenet":
         return squeezenet(4, in_hw, "squeezenet_tiny")
+    if model_name in ("densenet121", "densenet161"):
+        return densenet(8, (2, 3, 2, 2), 16, 2, in_hw, "densenet_tiny")
     return build(model_name, in_hw)

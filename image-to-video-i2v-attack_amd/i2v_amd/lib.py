@@ -39,6 +39,8 @@ _PROTOS = {
     "i2v_net_set_input": ([_P, _I, _I], _I),
     "i2v_net_add_conv": ([_P, _I, C.POINTER(ConvDesc), _P, _P, _P], _I),
     "i2v_net_add_maxpool": ([_P, _I, C.POINTER(PoolDesc)], _I),
+    "i2v_net_add_conv_preact": ([_P, _I, C.POINTER(ConvDesc), _P, _P, _P, _P, _P], _I),
+    "i2v_net_add_avgpool": ([_P, _I, C.POINTER(PoolDesc)], _I),
     "i2v_net_plan": ([_P, _I, C.POINTER(_I), _I, _I], _I),
     "i2v_net_workspace_bytes": ([_P, _I], C.c_size_t),
     "i2v_net_forward": ([_P, _I, _P, _I, _P], _I),

@@ -42,6 +42,12 @@ def synthetic_state_dict(graph: Graph, seed: int = 0) -> Dict[str, torch.Tensor]
             sd[nd.bn + ".bias"] = torch.randn(nd.cout, generator=g) * 0.1
             sd[nd.bn + ".running_mean"] = torch.randn(nd.cout, generator=g) * 0.1
             sd[nd.bn + ".running_var"] = torch.rand(nd.cout, generator=g) + 0.5
+        if nd.pre_bn:
+            g = _gen(seed, nd.pre_bn)
+            sd[nd.pre_bn + ".weight"] = torch.rand(nd.cin, generator=g) + 0.5
+            sd[nd.pre_bn + ".bias"] = torch.randn(nd.cin, generator=g) * 0.1
+            sd[nd.pre_bn + ".running_mean"] = torch.randn(nd.cin, generator=g) * 0.1
+            sd[nd.pre_bn + ".running_var"] = torch.rand(nd.cin, generator=g) + 0.5
     return sd
 
 
@@ -77,3 +83,14 @@ def fold_affine(nd, sd):
     s = torch.ones(nd.cout)
     t = sd[nd.bias].float() if nd.bias else torch.zeros(nd.cout)
     return s, t
+
+
+def fold_pre_affine(nd, sd):
+    """(scale, shift) of the eval-mode BatchNorm in FRONT of a pre-activation conv: the conv reads
+    relu(x*scale + shift) (torchvision `_DenseLayer`: norm1 -> relu1 -> conv1)."""
+    g = sd[nd.pre_bn + ".weight"].double()
+    b = sd[nd.pre_bn + ".bias"].double()
+    m = sd[nd.pre_bn + ".running_mean"].double()
+    v = sd[nd.pre_bn + ".running_var"].double()
+    s = g / torch.sqrt(v + BN_EPS)
+    return s.float(), (b - m * s).float()

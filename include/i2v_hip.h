@@ -62,6 +62,14 @@ int i2v_net_set_input(i2v_handle h, int net, int tensor);
 int i2v_net_add_conv(i2v_handle h, int net, const i2v_conv_desc* d, const float* weight,
                      const float* scale, const float* shift);
 int i2v_net_add_maxpool(i2v_handle h, int net, const i2v_pool_desc* d);
+/* DenseNet extension (not a backbone the reference can hook; BASELINE.json configs[2] names DenseNet-121):
+ * a 1x1/stride-1 convolution that reads relu(x*pre_scale + pre_shift) -- torchvision `_DenseLayer`
+ * norm1->relu1->conv1 and `_Transition` norm->relu->conv (host arrays of `cin` floats) -- and average
+ * pooling.  The gradient of a tensor read this way ACCUMULATES over its readers (dense connectivity). */
+int i2v_net_add_conv_preact(i2v_handle h, int net, const i2v_conv_desc* d, const float* weight,
+                            const float* scale, const float* shift, const float* pre_scale,
+                            const float* pre_shift);
+int i2v_net_add_avgpool(i2v_handle h, int net, const i2v_pool_desc* d);
 /* Freeze the graph: pack weights for forward and input-gradient, plan both passes for up to
  * `max_frames` frames and allocate the arena.  `hook_tensors` are the hooked layer outputs in
  * the order the reference's forward hooks fire (image_attacks.py:281-283). */

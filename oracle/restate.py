@@ -63,6 +63,9 @@ class OracleNet:
             src = self._view(self.buf, nd.src, N)
             if nd.op == "conv":
                 bias = self.sd[nd.bias] if nd.bias else None
+                if nd.pre_bn:       # DenseNet pre-activation: norm -> relu -> conv
+                    src = F.relu(F.batch_norm(src, self.sd[nd.pre_bn + ".running_mean"], self.sd[nd.pre_bn + ".running_var"],
+                                              self.sd[nd.pre_bn + ".weight"], self.sd[nd.pre_bn + ".bias"], False, 0.1, BN_EPS))
                 y = F.conv2d(src, self.sd[nd.weight], bias, nd.stride, nd.pad)
                 if nd.bn:
                     y = F.batch_norm(y, self.sd[nd.bn + ".running_mean"],
@@ -72,6 +75,8 @@ class OracleNet:
                     y = y + self._view(self.buf, nd.residual, N)
                 if nd.relu:
                     y = F.relu(y)
+            elif nd.op == "avgpool":
+                y = F.avg_pool2d(src, nd.k, nd.stride)
             else:
                 y, idx = F.max_pool2d(src, nd.k, nd.stride, nd.pad, ceil_mode=nd.ceil_mode,
                                       return_indices=True)
@@ -81,6 +86,9 @@ class OracleNet:
 
     def tensor(self, tid):
         return self._view(self.buf, tid)
+
+    def grad_of(self, tid):
+        return self._view(self.last_grads, tid)
 
     def adopt_activations(self, acts: Dict[int, torch.Tensor]):
         """Replace the stored activations (tensor id -> value) by externally computed ones and
@@ -118,13 +126,24 @@ class OracleNet:
                     dz = dz * inv.view(1, -1, 1, 1)
                 gx = torch.nn.grad.conv2d_input(src.shape, self.sd[nd.weight], dz.contiguous(),
                                                 nd.stride, nd.pad)
+                if nd.pre_bn:       # back through relu(BN(x)): gate on the pre-activation, times the BN scale
+                    inv = self.sd[nd.pre_bn + ".weight"] / torch.sqrt(self.sd[nd.pre_bn + ".running_var"] + BN_EPS)
+                    sh = self.sd[nd.pre_bn + ".bias"] - self.sd[nd.pre_bn + ".running_mean"] * inv
+                    pre = src * inv.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+                    gx = gx * (pre > 0).to(self.dtype) * inv.view(1, -1, 1, 1)
                 self._view(gb, nd.src, N).add_(gx)
+            elif nd.op == "avgpool":
+                gx = gd.repeat_interleave(nd.k, 2).repeat_interleave(nd.k, 3) / (nd.k * nd.k)
+                full = torch.zeros_like(src)
+                full[:, :, :gx.shape[2], :gx.shape[3]] = gx
+                self._view(gb, nd.src, N).add_(full)
             else:
                 idx = self.pool_idx[i]
                 C = src.shape[1]
                 gx = torch.zeros(N, C, src.shape[2] * src.shape[3], dtype=self.dtype)
                 gx.scatter_add_(2, idx.reshape(N, C, -1), gd.reshape(N, C, -1))
                 self._view(gb, nd.src, N).add_(gx.view_as(src))
+        self.last_grads = gb          # buffer id -> gradient (tests read intermediate gradients from it)
         return self._view(gb, g.input, N).clone()
 
 

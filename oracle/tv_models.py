@@ -147,6 +147,60 @@ class SqueezeNet11(nn.Module):
         return torch.flatten(self.classifier(self.features(x)), 1)
 
 
+class _DenseLayer(nn.Module):
+    def __init__(self, cin, growth, bn_size):
+        super().__init__()
+        self.norm1 = nn.BatchNorm2d(cin)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(cin, bn_size * growth, 1, bias=False)
+        self.norm2 = nn.BatchNorm2d(bn_size * growth)
+        self.relu2 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(bn_size * growth, growth, 3, padding=1, bias=False)
+
+    def forward(self, feats):
+        x = torch.cat(feats, 1)
+        return self.conv2(self.relu2(self.norm2(self.conv1(self.relu1(self.norm1(x))))))
+
+
+class _DenseBlock(nn.ModuleDict):
+    def __init__(self, nlayers, cin, bn_size, growth):
+        super().__init__()
+        for i in range(nlayers):
+            self.add_module(f"denselayer{i + 1}", _DenseLayer(cin + i * growth, growth, bn_size))
+
+    def forward(self, x):
+        feats = [x]
+        for _, layer in self.items():
+            feats.append(layer(feats))
+        return torch.cat(feats, 1)
+
+
+class DenseNet(nn.Module):
+    """torchvision DenseNet-BC: features.{conv0,norm0,relu0,pool0,denseblock{i},transition{i},norm5}."""
+
+    def __init__(self, growth=32, block_config=(6, 12, 24, 16), init_features=64, bn_size=4, num_classes=10):
+        super().__init__()
+        from collections import OrderedDict
+        self.features = nn.Sequential(OrderedDict([
+            ("conv0", nn.Conv2d(3, init_features, 7, 2, 3, bias=False)), ("norm0", nn.BatchNorm2d(init_features)),
+            ("relu0", nn.ReLU(inplace=True)), ("pool0", nn.MaxPool2d(3, 2, 1))]))
+        c = init_features
+        for i, n in enumerate(block_config):
+            self.features.add_module(f"denseblock{i + 1}", _DenseBlock(n, c, bn_size, growth))
+            c += n * growth
+            if i != len(block_config) - 1:
+                self.features.add_module(f"transition{i + 1}", nn.Sequential(OrderedDict([
+                    ("norm", nn.BatchNorm2d(c)), ("relu", nn.ReLU(inplace=True)),
+                    ("conv", nn.Conv2d(c, c // 2, 1, bias=False)), ("pool", nn.AvgPool2d(2, 2))])))
+                c //= 2
+        self.features.add_module("norm5", nn.BatchNorm2d(c))
+        self.classifier = nn.Linear(c, num_classes)
+
+    def forward(self, x):
+        f = torch.relu(self.features(x))
+        return self.classifier(torch.flatten(nn.functional.adaptive_avg_pool2d(f, (1, 1)), 1))
+
+
 def make(model_name: str, tiny: bool) -> nn.Module:
     """Same vocabulary as the reference's `get_model` (`image_attacks.py:84-108`); the
     tiny variants mirror `i2v_amd.graphs.build_tiny` parameter for parameter."""
@@ -163,6 +217,10 @@ def make(model_name: str, tiny: bool) -> nn.Module:
         return AlexNet((8, 24, 48, 32, 32)) if tiny else AlexNet(num_classes=1000)
     if model_name in ("squeezenet", "squeezenet1_1"):
         return SqueezeNet11(4) if tiny else SqueezeNet11(1, 1000)
+    if model_name == "densenet121":
+        return DenseNet(8, (2, 3, 2, 2), 16, 2) if tiny else DenseNet(32, (6, 12, 24, 16), 64, 4, 1000)
+    if model_name == "densenet161":
+        return DenseNet(8, (2, 3, 2, 2), 16, 2) if tiny else DenseNet(48, (6, 12, 36, 24), 96, 4, 1000)
     raise KeyError(model_name)
 
 

@@ -48,8 +48,9 @@ int k_conv(const I2VConvParams& p, i2v_stream_t) {
                         if (!e.valid) continue;
                         int hs = i * p.sh + e.dh, ws = j * p.sw + e.dw;
                         if (hs < 0 || hs >= p.Hs || ws < 0 || ws >= p.Ws) continue;
-                        acc += p.wp[(size_t)k * p.Cdpad + cd] *
-                               p.src[(size_t)n * p.src_nstride + e.chan_off + (size_t)hs * p.Ws + ws];
+                        float xv = p.src[(size_t)n * p.src_nstride + e.chan_off + (size_t)hs * p.Ws + ws];
+                        if (p.pre_scale) { xv = xv * p.pre_scale[k] + p.pre_shift[k]; xv = xv > 0.f ? xv : 0.f; }
+                        acc += p.wp[(size_t)k * p.Cdpad + cd] * xv;
                     }
                     if (p.blk > 1) {            // class-packed Cd (image gradient)
                         int Creal = p.Cd / (p.blk * p.blk), cls = cd / Creal, c = cd % Creal;
@@ -66,6 +67,10 @@ int k_conv(const I2VConvParams& p, i2v_stream_t) {
                     }
                     size_t oidx = (size_t)cd * p.Ho * p.Wo + (size_t)oh * p.Wo + ow;
                     float v = acc;
+                    if (p.gate_scale) {     // pre-activation gate: applies to THIS contribution only, before the adds
+                        float m = p.mask[(size_t)n * p.mask_nstride + oidx] * p.gate_scale[cd] + p.gate_shift[cd];
+                        if (!(m > 0.f)) v = 0.f;
+                    }
                     if (p.shift) v += p.shift[cd];
                     if (p.add0) {
                         if (p.add0_stride == 1) v += p.add0[(size_t)n * p.add0_nstride + oidx];
@@ -76,7 +81,7 @@ int k_conv(const I2VConvParams& p, i2v_stream_t) {
                     }
                     if (p.add1) v += p.add1[(size_t)n * p.add1_nstride + oidx];
                     if (p.relu) v = v > 0.f ? v : 0.f;
-                    if (p.mask && !(p.mask[(size_t)n * p.mask_nstride + oidx] > 0.f)) v = 0.f;
+                    if (p.mask && !p.gate_scale && !(p.mask[(size_t)n * p.mask_nstride + oidx] > 0.f)) v = 0.f;
                     p.dst[(size_t)n * p.dst_nstride + oidx] = v;
                 }
             }
@@ -120,6 +125,26 @@ int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t) {
                 }
             if (p.mask_relu) for (int i = 0; i < p.Hs * p.Ws; ++i) if (!(pl[i] > 0.f)) g[i] = 0.f;
         }
+    return 0;
+}
+
+int k_avgpool_fwd(const I2VPoolParams& p, i2v_stream_t) {
+    for (int n = 0; n < p.N; ++n) for (int c = 0; c < p.C; ++c) for (int ho = 0; ho < p.Ho; ++ho) for (int wo = 0; wo < p.Wo; ++wo) {
+        float s = 0.f;
+        for (int r = 0; r < p.k; ++r) for (int q = 0; q < p.k; ++q)
+            s += p.x[(size_t)n * p.x_nstride + ((size_t)c * p.Hs + ho * p.stride + r) * p.Ws + wo * p.stride + q];
+        p.y[(size_t)n * p.y_nstride + ((size_t)c * p.Ho + ho) * p.Wo + wo] = s / (p.k * p.k);
+    }
+    return 0;
+}
+
+int k_avgpool_bwd(const I2VPoolParams& p, i2v_stream_t) {
+    for (int n = 0; n < p.N; ++n) for (int c = 0; c < p.C; ++c) for (int h = 0; h < p.Hs; ++h) for (int w = 0; w < p.Ws; ++w) {
+        int ho = h / p.stride, wo = w / p.stride;
+        bool in = (h - ho * p.stride) < p.k && (w - wo * p.stride) < p.k && ho < p.Ho && wo < p.Wo;
+        p.gx[(size_t)n * p.gx_nstride + ((size_t)c * p.Hs + h) * p.Ws + w] =
+            in ? p.y[(size_t)n * p.y_nstride + ((size_t)c * p.Ho + ho) * p.Wo + wo] / (p.k * p.k) : 0.f;
+    }
     return 0;
 }
 

@@ -144,7 +144,8 @@ def test_cossim_fwd_bwd(eng, D, N, stride_pad):
 # ------------------------------------------------------------------ backbone forward / backward
 CASES = [("resnet", [3], 64), ("resnet", [2, 3], 64), ("resnet", [1], 32), ("vgg", [2], 32), ("vgg", [3], 32),
          ("alexnet", [3], 64), ("alexnet", [2, 4], 64), ("squeezenet", [2], 64), ("squeezenet", [2, 3], 64),
-         ("squeezenet", [4], 64), ("resnet", [4], 96)]
+         ("squeezenet", [4], 64), ("resnet", [4], 96), ("densenet121", [1], 64), ("densenet121", [3], 64),
+         ("densenet121", [2, 4], 96)]
 
 
 _hip = None
@@ -201,7 +202,8 @@ def test_net_forward_backward_match_oracle(eng, model, depths, hw):
     assert torch.allclose(net.read_tensor(hooks[-1], 2).cpu().double(), feats[-1][:2], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("model,depths", [("resnet50", [3]), ("vgg", [3]), ("alexnet", [2, 4]), ("squeezenet", [2, 4])])
+@pytest.mark.parametrize("model,depths", [("resnet50", [3]), ("vgg", [3]), ("alexnet", [2, 4]), ("squeezenet", [2, 4]),
+                                          ("densenet121", [2, 4])])
 def test_full_size_layers(eng, model, depths):
     """Real shapes (224^2) on 2 frames: every conv configuration of SURVEY.md 8(a4) (ResNet-50 to
     layer3), VGG-16 to features[20], AlexNet 11x11/4 + 5x5 + 3x3, SqueezeNet ceil-mode pools and Fire

@@ -14,7 +14,7 @@ from tests.hostsim_util import hostsim_engine
 
 CASES = [("resnet", [3], 64), ("resnet", [2, 3], 64), ("resnet", [1], 32), ("vgg", [2], 32), ("vgg", [3], 32),
          ("alexnet", [3], 64), ("alexnet", [2, 4], 64), ("squeezenet", [2], 64), ("squeezenet", [2, 3], 64),
-         ("squeezenet", [4], 64)]
+         ("squeezenet", [4], 64), ("densenet121", [1], 64), ("densenet121", [3], 64), ("densenet121", [2, 4], 64)]
 
 
 def write_hook_grads(net, feats, hg, N):
