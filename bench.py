@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU")
-    ap.add_argument("--workload", default="i2v", choices=["i2v", "ens", "aens"],
+    ap.add_argument("--workload", default="i2v", choices=["i2v", "ens", "aens", "config2"],
                     help="i2v = the headline metric (default); ens / aens = BASELINE configs[2]/[3]-style extras on the "
                          "reference's own model list (resnet101+vgg16+squeezenet1_1+alexnet)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -135,6 +135,10 @@ def main():
         atk = attacks.ImageGuidedFMDirection_Adam([MODEL], depth=DEPTH, step_size=0.005, steps=ATTACK_STEPS, engine=eng)
     elif args.workload == "ens":
         atk = attacks.ImageGuidedFML2_Adam_MultiModels(names4, depths={"resnet": 2, "vgg": 3, "squeezenet": 2, "alexnet": 3},
+                                                       steps=ATTACK_STEPS, engine=eng)
+    elif args.workload == "config2":      # BASELINE.json configs[2]: ResNet-50 + VGG-16 + DenseNet-121
+        names3 = ["resnet50", "vgg", "densenet121"]
+        atk = attacks.ImageGuidedFML2_Adam_MultiModels(names3, depths={"resnet50": 3, "vgg": 3, "densenet121": 3},
                                                        steps=ATTACK_STEPS, engine=eng)
     else:
         atk = attacks.AENS_I2V_MF(names4, depths={n: [2, 3] for n in names4}, step_size=0.005, steps=ATTACK_STEPS, engine=eng)
@@ -205,8 +209,9 @@ def main():
                            "device_ms_by_kernel": {k: round(v["ms"], 2) for k, v in kt.items()},
                            "wall_ms_timed_region": round(1e3 * elapsed, 2)}
     if args.workload != "i2v":
-        out["metric"] = f"adversarial frames/sec (10-step {args.workload.upper()}-I2V, resnet101+vgg16+squeezenet1_1+alexnet, 32x224^2 clips)"
-        out["config"]["workload"] = f"{args.workload} ensemble of 4 backbones (image_main.py:73-79), batch={b} clips per GPU"
+        models = "resnet50+vgg16+densenet121" if args.workload == "config2" else "resnet101+vgg16+squeezenet1_1+alexnet"
+        out["metric"] = f"adversarial frames/sec (10-step {args.workload.upper()}-I2V, {models}, 32x224^2 clips)"
+        out["config"]["workload"] = f"{args.workload} ensemble ({models}), batch={b} clips per GPU"
         for k in ("end_to_end_tflops_per_gpu", "algorithmic_gflop_per_frame"):
             out.pop(k, None)
     if rank == 0:

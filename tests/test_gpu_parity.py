@@ -439,3 +439,21 @@ def test_proxy_fooling_rate_parity(eng, tmp_path, monkeypatch):
         assert abs(a[k] - b[k]) <= 0.5, (a, b)
     assert (tmp_path / "hip" / "results_all_models_prediction.csv").read_text() == \
         (tmp_path / "oracle" / "results_all_models_prediction.csv").read_text()
+
+
+def test_config2_ensemble_resnet50_vgg16_densenet121(eng):
+    """BASELINE.json configs[2] model set at full size (1 clip x 8 frames, 2 steps): invariants,
+    bit-reproducibility, and agreement of the first-step cost with L*N (cos = 1 at delta_0)."""
+    gen = torch.Generator().manual_seed(2002)
+    u8 = torch.randint(0, 256, (1, 3, 8, 224, 224), generator=gen, dtype=torch.uint8)
+    vid = gu.videos_of({"clip_u8": u8.numpy()})
+    names = ["resnet50", "vgg", "densenet121"]
+    mk = lambda: attacks.ImageGuidedFML2_Adam_MultiModels(names, depths={n: 3 for n in names}, steps=2)   # noqa: E731
+    atk = mk()
+    adv = atk(vid, torch.zeros(1, dtype=torch.long), ["v"]).cpu()
+    assert abs(atk.last_costs[0] - 3 * 8) < 0.1 and atk.last_costs[1] < atk.last_costs[0]
+    mean = torch.tensor(gu.MEAN).view(1, 3, 1, 1, 1)
+    std = torch.tensor(gu.STD).view(1, 3, 1, 1, 1)
+    un = adv * std + mean
+    assert (un - u8.float() / 255).abs().max() <= 16 / 255 + 1e-6 and un.min() >= -1e-6 and un.max() <= 1 + 1e-6
+    assert torch.equal(adv, mk()(vid, torch.zeros(1, dtype=torch.long), ["v"]).cpu())
