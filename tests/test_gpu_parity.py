@@ -457,3 +457,34 @@ def test_config2_ensemble_resnet50_vgg16_densenet121(eng):
     un = adv * std + mean
     assert (un - u8.float() / 255).abs().max() <= 16 / 255 + 1e-6 and un.min() >= -1e-6 and un.max() <= 1 + 1e-6
     assert torch.equal(adv, mk()(vid, torch.zeros(1, dtype=torch.long), ["v"]).cpu())
+
+
+def test_rccl_exchange_paths_single_rank(eng):
+    """The collectives of the clip-sharded runs on the real backend (RCCL through torch.distributed
+    'nccl'), with a 1-rank group: AENS' 2L-float all-reduce and DR's 3-double all-reduce must leave the
+    single-device results untouched.  (Two-rank semantics are covered by the gloo tests on CPU.)"""
+    import os
+    import torch.distributed as dist
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        fx = gu.load("aens_2x2_f64")
+        kw = dict(depths=fx["depth"], step_size=fx["lr"], steps=fx["steps"], graph_builder=graphs.build_tiny, **fx["kw"])
+        vid = gu.videos_of(fx)
+        lab = torch.zeros(fx["b"], dtype=torch.long)
+        a0 = attacks.AENS_I2V_MF(fx["models"], **kw)
+        adv0, _, c0 = a0(vid, lab, ["c"] * fx["b"])
+        a1 = attacks.AENS_I2V_MF(fx["models"], distributed=True, **kw)
+        adv1, _, c1 = a1(vid, lab, ["c"] * fx["b"])
+        assert torch.equal(adv0, adv1) and np.array_equal(c0, c1) and np.array_equal(np.stack(a0.weights), np.stack(a1.weights))
+        d0 = attacks.ImageGuidedStd_Adam(["resnet"], depth=2, step_size=0.005, steps=3, graph_builder=graphs.build_tiny)
+        d1 = attacks.ImageGuidedStd_Adam(["resnet"], depth=2, step_size=0.005, steps=3, graph_builder=graphs.build_tiny,
+                                         distributed=True)
+        assert torch.equal(d0(vid, lab, ["c"]), d1(vid, lab, ["c"])) and np.array_equal(d0.last_costs, d1.last_costs)
+    finally:
+        if created:
+            dist.destroy_process_group()
