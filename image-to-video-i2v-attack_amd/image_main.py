@@ -10,6 +10,8 @@ Differences: `OPT_PATH` comes from `$I2V_OPT_PATH` (the reference hard-codes an 
 import argparse
 import json
 import os
+import queue
+import threading
 
 import numpy as np
 import torch
@@ -77,18 +79,58 @@ def main(argv=None):
     left = (args.batch_index - 1) * nums_contained
     right = args.batch_index * nums_contained
     attack_method = build_attack(args)
-    for step, (val_batch, val_label, video_names) in enumerate(
-            clips.batches(args.batch_size, args.anno, args.clip_dir, args.frames, args.hw, args.num_clips)):
-        if not (left <= step < right):
-            continue
-        if args.resume and all(os.path.exists(os.path.join(args.adv_path, f"{l.item()}-adv.npy")) for l in val_label):
-            continue
+
+    # I/O off the critical path: clips are produced by a reader thread one batch ahead (synthetic generation
+    # or np.load), results are copied to pinned host memory asynchronously and written by a writer thread,
+    # so the GPU goes straight from one batch to the next (the reference loads, attacks and np.saves serially,
+    # image_main.py:82-92).
+    todo = queue.Queue(maxsize=2)
+    done = queue.Queue(maxsize=4)
+
+    def reader():
+        for step, item in enumerate(clips.batches(args.batch_size, args.anno, args.clip_dir, args.frames, args.hw, args.num_clips)):
+            if not (left <= step < right):
+                continue
+            if args.resume and all(os.path.exists(os.path.join(args.adv_path, f"{l.item()}-adv.npy")) for l in item[1]):
+                continue
+            batch = item[0].pin_memory() if torch.cuda.is_available() else item[0]
+            todo.put((step, batch, item[1], item[2]))
+        todo.put(None)
+
+    def writer():
+        while True:
+            item = done.get()
+            if item is None:
+                return
+            labels, host, event = item
+            if event is not None:
+                event.synchronize()
+            for ind, label in enumerate(labels):
+                np.save(os.path.join(args.adv_path, "{}-adv".format(label.item())), host[ind].numpy())
+
+    threads = [threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)]
+    for t in threads:
+        t.start()
+    while True:
+        item = todo.get()
+        if item is None:
+            break
+        step, val_batch, val_label, video_names = item
         print("Running {}, {}/{}".format(args.attack_method, step + 1, total))
         adv_batches = attack_method(val_batch, val_label, video_names)
         if isinstance(adv_batches, tuple):                             # AENS returns (adv, time, costs)
             adv_batches = adv_batches[0]
-        for ind, label in enumerate(val_label):
-            np.save(os.path.join(args.adv_path, "{}-adv".format(label.item())), adv_batches[ind].detach().cpu().numpy())
+        adv_batches = adv_batches.detach()
+        if adv_batches.is_cuda:
+            host = torch.empty(adv_batches.shape, dtype=adv_batches.dtype, pin_memory=True)
+            host.copy_(adv_batches, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+        else:
+            host, event = adv_batches.contiguous(), None
+        done.put((val_label, host, event))
+    done.put(None)
+    threads[1].join()
     with open(os.path.join(args.adv_path, "loss_info_{}.json".format(args.batch_index)), "w") as opt:
         json.dump(attack_method.loss_info, opt)
 
