@@ -128,6 +128,11 @@ def main():
         torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
 
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.LIB) and rank == 0:      # normally built by __graft_entry__.build(); a no-op otherwise
+        ge.build()
+    if dist is not None:
+        dist.barrier()
     from i2v_amd import attacks, graphs
     eng = attacks.get_engine(dev)
     names4 = ["resnet", "vgg", "squeezenet", "alexnet"]
