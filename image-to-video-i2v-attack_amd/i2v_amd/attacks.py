@@ -224,11 +224,16 @@ class ImageGuidedStd_Adam(_ImageGuided):
         if not on:
             return None
 
+        counts = self.__dict__.setdefault("_global_counts", {})
+
         def exchange(sums, count):
-            packed = torch.cat([sums, torch.tensor([float(count)], dtype=torch.float64, device=sums.device)])
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self._pg)
-            sums.copy_(packed[:2])
-            return int(round(packed[2].item()))
+            # the element count is fixed per (hook, local count): all-reduced once, then no host sync per step
+            if count not in counts:
+                c = torch.tensor([float(count)], dtype=torch.float64, device=sums.device)
+                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self._pg)
+                counts[count] = int(round(c.item()))
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self._pg)
+            return counts[count]
         return exchange
 
 
