@@ -657,6 +657,8 @@ struct Planner {
 
 }  // namespace
 
+static int autotune(Net& n);
+
 extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int n_hooks, int max_frames) {
     Net* np = get_net(h, net); if (!np) return 1;
     Net& n = *np;
@@ -702,6 +704,7 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
     Planner real{n, false, off, N};
     if (!real.run()) return fail("plan: %s", real.err.c_str());
     n.hook_tmp = real.hook_tmp;
+    if (autotune(n)) return 1;
     n.planned = true;
     return 0;
 }
@@ -714,6 +717,75 @@ extern "C" size_t i2v_net_workspace_bytes(i2v_handle h, int net) {
 // ---------------------------------------------------------------------------------------------
 // execution
 // ---------------------------------------------------------------------------------------------
+// One convolution launch (possibly sliced over frames: 32-bit buffer offsets keep a launch's source span < 2 GiB)
+static int conv_run(const Launch& l, int frames, const float* x, float* gx, int accumulate, i2v_stream_t s) {
+    I2VConvParams p = l.conv;
+    if (l.src_is_input) p.src = x;
+    if (l.kind == L_IMGGRAD) { p.dst = gx; if (accumulate) { p.add1 = gx; p.add1_nstride = p.dst_nstride; } }
+    p.vec_epilogue = (p.blk <= 1 && p.osh == 1 && p.osw == 1 && p.oh0 == 0 && p.ow0 == 0 && p.Hg == p.Ho &&
+                      p.Wg == p.Wo && (p.Ho * p.Wo) % 4 == 0 && p.dst_nstride % 4 == 0 &&
+                      (p.add0_stride == 1 || (p.add0_stride == 2 && p.Wo % 4 == 0 && p.add0_W * 2 == p.Wo &&
+                                              p.add0_W % 2 == 0 && (p.add0_H * p.add0_W) % 2 == 0)) &&
+                      p.add0_nstride % 4 == 0 && p.add1_nstride % 4 == 0 && p.mask_nstride % 4 == 0 &&
+                      (((uintptr_t)p.dst | (uintptr_t)p.add0 | (uintptr_t)p.add1 | (uintptr_t)p.mask) & 15) == 0)
+                         ? 1 : 0;
+    const int64_t plane_bytes = (int64_t)p.Cs * p.Hs * p.Ws * 4, stride_bytes = p.src_nstride * 4;
+    int64_t per = plane_bytes >= (1ll << 31) ? 0 : 1 + ((1ll << 31) - 1 - plane_bytes) / stride_bytes;
+    if (per < 1) return fail("one frame of a convolution input exceeds 2 GiB");
+    for (int f0 = 0; f0 < frames; f0 += (int)per) {
+        I2VConvParams q = p;
+        q.N = frames - f0 < per ? frames - f0 : (int)per;
+        q.src += (int64_t)f0 * p.src_nstride; q.dst += (int64_t)f0 * p.dst_nstride;
+        if (q.add0) q.add0 += (int64_t)f0 * p.add0_nstride;
+        if (q.add1) q.add1 += (int64_t)f0 * p.add1_nstride;
+        if (q.mask) q.mask += (int64_t)f0 * p.mask_nstride;
+        q.src_span_bytes = (int32_t)((int64_t)(q.N - 1) * stride_bytes + plane_bytes);
+        CHECK_BE(k_conv(q, s));
+    }
+    return 0;
+}
+
+// Plan-time autotuning ("measure, don't guess"): every convolution launch of both passes is timed with each
+// valid tile configuration on the planned shapes (max_frames) and the fastest is pinned.  Tile choice never
+// changes results: each output element is the same k-ordered fmaf chain whatever the tile.
+static int autotune(Net& n) {
+    const char* off = getenv("I2V_AUTOTUNE");
+    if (off && off[0] == '0') return 0;
+    const Buffer& ib = n.bufs[n.tens[n.input].buf];
+    const size_t img = (size_t)n.maxN * ib.C * ib.H * ib.W;
+    float* scratch = (float*)be_malloc(2 * img * sizeof(float));     // stand-ins for the caller's x and gx
+    if (!scratch) return fail("autotune scratch allocation failed");
+    CHECK_BE(be_memset0(scratch, 2 * img * sizeof(float), nullptr));
+    void* e0 = be_event_create(); void* e1 = be_event_create();
+    int rc = 0;
+    for (std::vector<Launch>* L : {&n.fwd, &n.bwd})
+        for (Launch& l : *L) {
+            if (l.kind != L_CONV && l.kind != L_IMGGRAD) continue;
+            if (n.maxN * l.conv.Hg * l.conv.Wg == 0) continue;
+            int cand[8]; I2VConvParams probe = l.conv; probe.N = n.maxN;
+            const int nc = k_conv_candidates(probe, cand);
+            if (nc <= 1) { if (nc == 1) l.conv.cfg = cand[0] + 1; continue; }
+            float best = 1e30f; int best_c = -1;
+            for (int ci = 0; ci < nc && !rc; ++ci) {
+                l.conv.cfg = cand[ci] + 1;
+                rc |= conv_run(l, n.maxN, scratch, scratch + img, 0, nullptr);              // warm-up
+                be_event_record(e0, nullptr);
+                for (int r = 0; r < 2 && !rc; ++r) rc |= conv_run(l, n.maxN, scratch, scratch + img, 0, nullptr);
+                be_event_record(e1, nullptr);
+                if (rc || be_stream_sync(nullptr)) { rc = 1; break; }
+                float ms = 0.f; be_event_elapsed_ms(e0, e1, &ms);
+                if (ms < best) { best = ms; best_c = cand[ci]; }
+            }
+            l.conv.cfg = best_c >= 0 ? best_c + 1 : 0;
+            if (rc) break;
+        }
+    be_event_destroy(e0); be_event_destroy(e1); be_free(scratch);
+    if (rc) return g_err.empty() ? fail("autotune failed") : 1;
+    // the probes scribbled over activations and gradients; start from a clean arena like a fresh plan
+    CHECK_BE(be_memset0(n.arena, n.arena_floats * sizeof(float), nullptr));
+    return 0;
+}
+
 static TimedLaunch* timing_begin(i2v_ctx* h, int kind, double flops, i2v_stream_t s) {
     if (!h->timing) return nullptr;
     if (h->timed_used == h->timed.size()) {
@@ -741,32 +813,8 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int frames, cons
         switch (l.kind) {
             case L_CONV:
             case L_IMGGRAD: {
-                I2VConvParams p = l.conv;
-                if (l.src_is_input) p.src = x;
-                if (l.kind == L_IMGGRAD) { p.dst = gx; if (accumulate) { p.add1 = gx; p.add1_nstride = p.dst_nstride; } }
-                if (frames * p.Hg * p.Wg == 0) break;
-                p.vec_epilogue = (p.blk <= 1 && p.osh == 1 && p.osw == 1 && p.oh0 == 0 && p.ow0 == 0 && p.Hg == p.Ho &&
-                                  p.Wg == p.Wo && (p.Ho * p.Wo) % 4 == 0 && p.dst_nstride % 4 == 0 &&
-                                  (p.add0_stride == 1 || (p.add0_stride == 2 && p.Wo % 4 == 0 && p.add0_W * 2 == p.Wo &&
-                                                          p.add0_W % 2 == 0 && (p.add0_H * p.add0_W) % 2 == 0)) &&
-                                  p.add0_nstride % 4 == 0 && p.add1_nstride % 4 == 0 && p.mask_nstride % 4 == 0 &&
-                                  (((uintptr_t)p.dst | (uintptr_t)p.add0 | (uintptr_t)p.add1 | (uintptr_t)p.mask) & 15) == 0)
-                                     ? 1 : 0;
-                // the source is addressed through a buffer descriptor with 32-bit offsets: keep the span of
-                // one launch below 2 GiB by walking the frames in slices
-                const int64_t plane_bytes = (int64_t)p.Cs * p.Hs * p.Ws * 4, stride_bytes = p.src_nstride * 4;
-                int64_t per = plane_bytes >= (1ll << 31) ? 0 : 1 + ((1ll << 31) - 1 - plane_bytes) / stride_bytes;
-                if (per < 1) return fail("one frame of a convolution input exceeds 2 GiB");
-                for (int f0 = 0; f0 < frames; f0 += (int)per) {
-                    I2VConvParams q = p;
-                    q.N = frames - f0 < per ? frames - f0 : (int)per;
-                    q.src += (int64_t)f0 * p.src_nstride; q.dst += (int64_t)f0 * p.dst_nstride;
-                    if (q.add0) q.add0 += (int64_t)f0 * p.add0_nstride;
-                    if (q.add1) q.add1 += (int64_t)f0 * p.add1_nstride;
-                    if (q.mask) q.mask += (int64_t)f0 * p.mask_nstride;
-                    q.src_span_bytes = (int32_t)((int64_t)(q.N - 1) * stride_bytes + plane_bytes);
-                    CHECK_BE(k_conv(q, s));
-                }
+                if (frames * l.conv.Hg * l.conv.Wg == 0) break;
+                if (conv_run(l, frames, x, gx, accumulate, s)) return 1;
             } break;
             case L_POOLF: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool_fwd(p, s)); } break;
             case L_AVGF: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_avgpool_fwd(p, s)); } break;

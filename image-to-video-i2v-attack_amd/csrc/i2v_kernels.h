@@ -23,6 +23,7 @@ int  be_event_elapsed_ms(void* start, void* stop, float* ms);           // both 
 int  be_stream_sync(i2v_stream_t s);                                                       // last backend error or null
 
 int k_conv(const I2VConvParams& p, i2v_stream_t s);
+int k_conv_candidates(const I2VConvParams& p, int* out);   // tile configurations valid for p (ids 0..4), returns count
 int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_avgpool_fwd(const I2VPoolParams& p, i2v_stream_t s);

@@ -496,9 +496,23 @@ static int conv_pick(const I2VConvParams& p) {
     return best;
 }
 
+// Tile configurations a launch may use (the engine's plan-time autotuner times each of them on the real
+// shapes and pins the fastest through I2VConvParams::cfg; `conv_pick` is the model used without it).
+int k_conv_candidates(const I2VConvParams& p, int* out) {
+    int n = 0;
+    if (p.pre_scale) { if (p.Cd > 64) out[n++] = 0; out[n++] = 3; return n; }
+    static const int BD[5] = {128, 64, 128, 64, 32};
+    for (int i = 0; i < 5; ++i) {
+        if (BD[i] > 32 && p.Cd <= BD[i] / 2) continue;
+        if (BD[i] == 32 && p.Cd > 32) continue;
+        out[n++] = i;
+    }
+    return n;
+}
+
 int k_conv(const I2VConvParams& p, i2v_stream_t s) {
     hipStream_t st = (hipStream_t)s;
-    switch (conv_pick(p)) {
+    switch (p.cfg > 0 ? p.cfg - 1 : conv_pick(p)) {
         case 0: return launch_conv_cfg<128, 128, 2, 2>(p, st);
         case 1: return launch_conv_cfg<64, 128, 2, 2>(p, st);
         case 2: return launch_conv_cfg<128, 64, 2, 2>(p, st);
