@@ -450,7 +450,7 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
             else if (p.tap_uniform) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
             else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 0, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
         }
-    } else if (BD == 64 && BP == 64 && conv_wants_prefetch(p)) {
+    } else if (BD == 64 && BP == 64 && conv_wants_prefetch(p) && !(p.cfg > 0 && ((p.cfg - 1) & 8))) {
         if constexpr (BD == 64 && BP == 64) {
             if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 1, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
             else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
@@ -507,12 +507,13 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
         if (BD[i] == 32 && p.Cd > 32) continue;
         out[n++] = i;
     }
+    if (conv_wants_prefetch(p)) out[n++] = 3 | 8;       // 64x64 WITHOUT the epilogue-operand prefetch
     return n;
 }
 
 int k_conv(const I2VConvParams& p, i2v_stream_t s) {
     hipStream_t st = (hipStream_t)s;
-    switch (p.cfg > 0 ? p.cfg - 1 : conv_pick(p)) {
+    switch (p.cfg > 0 ? ((p.cfg - 1) & 7) : conv_pick(p)) {
         case 0: return launch_conv_cfg<128, 128, 2, 2>(p, st);
         case 1: return launch_conv_cfg<64, 128, 2, 2>(p, st);
         case 2: return launch_conv_cfg<128, 64, 2, 2>(p, st);

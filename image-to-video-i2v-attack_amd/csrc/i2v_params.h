@@ -46,7 +46,7 @@ struct I2VConvParams {
     // 1: output is dense over the pixel grid (osh=osw=1, Hg x Wg == Ho x Wo, plane % 4 == 0, every
     // plane 16-byte aligned, plain addends): the epilogue may use 16-byte accesses along W
     int32_t vec_epilogue;
-    int32_t cfg;            // 0: pick the tile configuration with the cost model; c+1: use configuration c (autotuned)
+    int32_t cfg;            // 0: pick the tile configuration with the cost model; c+1: use configuration c (autotuned; bit 3 of c = no epilogue-operand prefetch)
 };
 
 struct I2VPoolParams {
