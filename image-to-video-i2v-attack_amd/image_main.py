@@ -41,9 +41,8 @@ def arg_parse(argv=None):
     parser.add_argument("--direction_image_model", type=str, default="resnet",
                         help="resnet, densenet, squeezenet, vgg, alexnet (resnet50 added)")
     # additions (not in the reference)
-    parser.add_argument("--anno", type=str, default=os.environ.get("I2V_ANNO", os.path.join(os.path.dirname(
-        os.path.abspath(__file__)), "kinetics400_attack_samples.csv")),
-                        help="sample list csv `path,gt_label,clip_index` (kinetics400_attack_samples.csv)")
+    parser.add_argument("--anno", type=str, default=os.environ.get("I2V_ANNO", ""),
+                        help="sample list csv `path,gt_label,clip_index` (the reference's kinetics400_attack_samples.csv, utils.py:29); without it 400 synthetic names with labels 0..399 are used")
     parser.add_argument("--clip_dir", type=str, default="", help="directory of {label}-ori.npy clips")
     parser.add_argument("--num_clips", type=int, default=400, help="use only the first N rows of the sample list")
     parser.add_argument("--frames", type=int, default=32)

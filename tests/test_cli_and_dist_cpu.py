@@ -48,6 +48,15 @@ def test_image_main_file_contract(tiny_engine, tmp_path, monkeypatch):
         image_main.main(["--num_clips", "1"])
 
 
+def test_sample_list_fixture():
+    """The reference's sample list (data fixture): 400 rows, one clip per class, labels 0..399."""
+    from i2v_amd import clips
+    rows = clips.sample_list(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kinetics400_attack_samples.csv"))
+    assert len(rows) == 400 and sorted(l for _, l in rows) == list(range(400))
+    assert rows[0] == ("abseiling/YqTT34PsD5c_000003_000013.mp4", 0)
+    assert clips.sample_list(None, 7)[6] == ("synthetic/006.mp4", 6)
+
+
 def test_run_image_guided_plan():
     import run_image_guided
     jobs = run_image_guided.plan("0", 1)
