@@ -46,33 +46,36 @@ static int fail(const char* fmt, ...) {
 
 namespace {
 
-struct Buffer { int C, H, W; size_t act_off = 0, grad_off = 0; bool is_input = false; };
+struct Buffer { int C, H, W; int T = 1; size_t act_off = 0, grad_off = 0; bool is_input = false; };   // T: frames per clip (video networks)
 struct Tensor { int buf, c_off, C; bool post_relu; };
 
 struct Packed {               // one implicit-GEMM operand set
     float* wp = nullptr; I2VKEntry* ktab = nullptr;
     int K = 0, Kpad = 0, Cd = 0, Cdpad = 0, tap_uniform = 0;
     int ph = 0, pw = 0, Hg = 0, Wg = 0;
+    int pt = 0, Tg = 1;       // temporal parity class / grid frames per clip (video networks)
 };
 
 struct Node {
     int type;                 // 0 conv, 1 maxpool, 2 avgpool
-    i2v_conv_desc cd; i2v_pool_desc pd;
-    std::vector<float> w;     // [cout][cin][kh][kw] with scale folded
+    i2v_conv3d_desc cd; i2v_pool3d_desc pd;        // image nodes are stored as kt = 1 video nodes
+    std::vector<float> w;     // [cout][cin][kt][kh][kw] with scale folded
     std::vector<float> shift;
     std::vector<float> pre_scale, pre_shift;      // pre-activation conv (DenseNet): per input channel
     float* shift_d = nullptr; float* pre_scale_d = nullptr; float* pre_shift_d = nullptr;   // *_d padded to Kpad
     bool preact() const { return !pre_scale.empty(); }
     Packed fwd; std::vector<Packed> bwd;
-    Packed img; int img_blk = 0, img_sh = 1;      // input-gradient of the first conv (class-packed)
+    Packed img; int img_blk = 0, img_sh = 1, img_blkt = 1;   // input-gradient of the first conv (class-packed)
     size_t idx_off = 0;                           // maxpool: arg-max bytes, arena offset in floats
 };
 
-enum Kind { L_CONV, L_IMGGRAD, L_POOLF, L_POOLB, L_ADDMASK, L_CONVB_UNUSED, L_AVGF, L_AVGB, L_MEMSET };   // L_IMGGRAD: conv_igemm with class-packed Cd
+enum Kind { L_CONV, L_IMGGRAD, L_POOLF, L_POOLB, L_ADDMASK, L_CONVB_UNUSED, L_AVGF, L_AVGB, L_MEMSET, L_POOL3F, L_POOL3B };   // L_IMGGRAD: conv_igemm with class-packed Cd
 struct Launch {
     Kind kind;
     I2VConvParams conv; I2VPoolParams pool; I2VAddMaskParams am;
+    int T = 1;                     // frames per clip of the launch's iteration space (conv launches: conv.Tg)
     bool src_is_input = false;     // conv: src pointer patched with the caller's x
+    bool img_accumulate = false;   // L_IMGGRAD of a second convolution reading the input (two-pathway stems): gx += ...
     float* ms_ptr = nullptr; size_t ms_floats_per_frame = 0;   // L_MEMSET
     double alg_flops_per_frame = 0; // L_IMGGRAD: algorithmic (not class-padded) flops
 };
@@ -85,6 +88,7 @@ struct Net {
     float* arena = nullptr; size_t arena_floats = 0; std::vector<void*> dev_allocs;
     std::vector<Launch> fwd, bwd;
     int frames = 0;
+    int Tin() const { return bufs[tens[input].buf].T; }     // frames per clip of the input
     size_t weight_bytes = 0;
     std::vector<float*> hook_tmp;  // per hook: separate gradient buffer when the hooked tensor is also consumed
 };
@@ -123,54 +127,62 @@ static int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b
 static int posmod(int a, int b) { int m = a % b; return m < 0 ? m + b : m; }
 
 static int pack_fwd(Net& n, Node& nd) {
-    const i2v_conv_desc& c = nd.cd;
+    const i2v_conv3d_desc& c = nd.cd;
     const Buffer& sb = n.bufs[n.tens[c.src].buf];
-    int K = c.kh * c.kw * c.cin;
+    int K = c.kt * c.kh * c.kw * c.cin;
     Packed& P = nd.fwd;
     P.K = K; P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cout; P.Cdpad = (int)align_up(c.cout, 128);
     P.tap_uniform = (c.cin % I2V_KC == 0) ? 1 : 0;
     std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
     std::vector<I2VKEntry> kt(P.Kpad, I2VKEntry{0, 0, 0, 0});
-    for (int r = 0; r < c.kh; ++r)
-        for (int s = 0; s < c.kw; ++s)
-            for (int ci = 0; ci < c.cin; ++ci) {
-                int k = (r * c.kw + s) * c.cin + ci;
-                kt[k] = I2VKEntry{ci * sb.H * sb.W, r - c.pad, s - c.pad, 1};
-                for (int co = 0; co < c.cout; ++co)
-                    wp[(size_t)k * P.Cdpad + co] = nd.w[(((size_t)co * c.cin + ci) * c.kh + r) * c.kw + s];
-            }
+    for (int q = 0; q < c.kt; ++q)
+        for (int r = 0; r < c.kh; ++r)
+            for (int s = 0; s < c.kw; ++s)
+                for (int ci = 0; ci < c.cin; ++ci) {
+                    int k = ((q * c.kh + r) * c.kw + s) * c.cin + ci;
+                    kt[k] = I2VKEntry{ci * sb.H * sb.W, r - c.pad, s - c.pad, 1 + 2 * (q * c.dil_t - c.pad_t)};
+                    for (int co = 0; co < c.cout; ++co)
+                        wp[(size_t)k * P.Cdpad + co] = nd.w[((((size_t)co * c.cin + ci) * c.kt + q) * c.kh + r) * c.kw + s];
+                }
     if (upload(n, wp, &P.wp)) return 1;
     return upload(n, kt, &P.ktab);
 }
 
+// Input-gradient operands, one per stride-parity class (pt, ph, pw): the source positions congruent to the
+// class modulo the stride receive exactly the taps with (class + pad - tap) % stride == 0.
 static int pack_bwd(Net& n, Node& nd) {
-    const i2v_conv_desc& c = nd.cd;
+    const i2v_conv3d_desc& c = nd.cd;
     const Buffer& sb = n.bufs[n.tens[c.src].buf];
     const Buffer& db = n.bufs[n.tens[c.dst].buf];
-    int st = c.stride;
+    int st = c.stride, stt = c.stride_t;
+    for (int pt = 0; pt < stt; ++pt)
     for (int ph = 0; ph < st; ++ph)
         for (int pw = 0; pw < st; ++pw) {
             Packed P;
-            P.ph = ph; P.pw = pw;
+            P.pt = pt; P.ph = ph; P.pw = pw;
+            P.Tg = (sb.T - pt + stt - 1) / stt;
             P.Hg = (sb.H - ph + st - 1) / st; P.Wg = (sb.W - pw + st - 1) / st;
-            std::vector<int> tr, ts;
+            std::vector<int> tq, tr, ts;
+            for (int q = 0; q < c.kt; ++q) if (posmod(pt + c.pad_t - q * c.dil_t, stt) == 0) tq.push_back(q);
             for (int r = 0; r < c.kh; ++r) if (posmod(ph + c.pad - r, st) == 0) tr.push_back(r);
             for (int s = 0; s < c.kw; ++s) if (posmod(pw + c.pad - s, st) == 0) ts.push_back(s);
-            int K = (int)(tr.size() * ts.size()) * c.cout;
+            int K = (int)(tq.size() * tr.size() * ts.size()) * c.cout;
             P.K = K; P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cin; P.Cdpad = (int)align_up(c.cin, 128);
             P.tap_uniform = (c.cout % I2V_KC == 0) ? 1 : 0;
             std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
             std::vector<I2VKEntry> kt(P.Kpad ? P.Kpad : 1, I2VKEntry{0, 0, 0, 0});
             int t = 0;
+            for (int q : tq)
             for (int r : tr)
                 for (int s : ts) {
+                    int dt = floordiv(pt + c.pad_t - q * c.dil_t, stt);
                     int dh = floordiv(ph + c.pad - r, st), dw = floordiv(pw + c.pad - s, st);
                     for (int co = 0; co < c.cout; ++co) {
                         int k = t * c.cout + co;
-                        kt[k] = I2VKEntry{co * db.H * db.W, dh, dw, 1};
+                        kt[k] = I2VKEntry{co * db.H * db.W, dh, dw, 1 + 2 * dt};
                         for (int ci = 0; ci < c.cin; ++ci)
                             wp[(size_t)k * P.Cdpad + ci] =
-                                nd.w[(((size_t)co * c.cin + ci) * c.kh + r) * c.kw + s] * (nd.preact() ? nd.pre_scale[ci] : 1.f);
+                                nd.w[((((size_t)co * c.cin + ci) * c.kt + q) * c.kh + r) * c.kw + s] * (nd.preact() ? nd.pre_scale[ci] : 1.f);
                     }
                     ++t;
                 }
@@ -186,46 +198,56 @@ static int pack_bwd(Net& n, Node& nd) {
 // pairs form the Cd axis: out[(ph,pw),ci][i][j] = sum_{co,dh,dw} w'[(co,dh,dw)][(ph,pw),ci] *
 // dz[co][i*m + dh][j*m + dw], m = B/stride, with zero weights where a class has no such tap.
 static int pack_img(Net& n, Node& nd) {
-    const i2v_conv_desc& c = nd.cd;
+    const i2v_conv3d_desc& c = nd.cd;
     const Buffer& sb = n.bufs[n.tens[c.src].buf];
     const Buffer& db = n.bufs[n.tens[c.dst].buf];
     const int st = c.stride, B = st == 1 ? 2 : st, m = B / st;
-    int dh_lo = 1 << 30, dh_hi = -(1 << 30), dw_lo = 1 << 30, dw_hi = -(1 << 30);
+    const int stt = c.stride_t, Bt = stt;                  // temporal classes: one per stride residue (1 for images)
+    int dt_lo = 1 << 30, dt_hi = -(1 << 30), dh_lo = 1 << 30, dh_hi = -(1 << 30), dw_lo = 1 << 30, dw_hi = -(1 << 30);
+    for (int ct = 0; ct < Bt; ++ct)
+        for (int q = 0; q < c.kt; ++q)
+            if (posmod(ct + c.pad_t - q * c.dil_t, stt) == 0) { int d = floordiv(ct + c.pad_t - q * c.dil_t, stt); dt_lo = d < dt_lo ? d : dt_lo; dt_hi = d > dt_hi ? d : dt_hi; }
     for (int ph = 0; ph < B; ++ph)
         for (int r = 0; r < c.kh; ++r)
             if (posmod(ph + c.pad - r, st) == 0) { int d = floordiv(ph + c.pad - r, st); dh_lo = d < dh_lo ? d : dh_lo; dh_hi = d > dh_hi ? d : dh_hi; }
     for (int pw = 0; pw < B; ++pw)
         for (int s = 0; s < c.kw; ++s)
             if (posmod(pw + c.pad - s, st) == 0) { int d = floordiv(pw + c.pad - s, st); dw_lo = d < dw_lo ? d : dw_lo; dw_hi = d > dw_hi ? d : dw_hi; }
-    const int TH = dh_hi - dh_lo + 1, TW = dw_hi - dw_lo + 1;
+    const int TT = dt_hi - dt_lo + 1, TH = dh_hi - dh_lo + 1, TW = dw_hi - dw_lo + 1;
     Packed& P = nd.img;
-    P.K = TH * TW * c.cout; P.Kpad = (int)align_up(P.K, I2V_KC);
-    P.Cd = B * B * c.cin; P.Cdpad = (int)align_up(P.Cd, 128);
+    P.K = TT * TH * TW * c.cout; P.Kpad = (int)align_up(P.K, I2V_KC);
+    P.Cd = Bt * B * B * c.cin; P.Cdpad = (int)align_up(P.Cd, 128);
     P.tap_uniform = (c.cout % I2V_KC == 0) ? 1 : 0;
-    P.Hg = (sb.H + B - 1) / B; P.Wg = (sb.W + B - 1) / B;
-    nd.img_blk = B; nd.img_sh = m;
+    P.Tg = (sb.T + Bt - 1) / Bt; P.Hg = (sb.H + B - 1) / B; P.Wg = (sb.W + B - 1) / B;
+    nd.img_blk = B; nd.img_sh = m; nd.img_blkt = Bt;
     std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
     std::vector<I2VKEntry> kt(P.Kpad, I2VKEntry{0, 0, 0, 0});
     // K order = (tap, channel): chunk-uniform taps (MODE 2).  (Channel-major order would cut the L2
     // over-fetch of the 16 taps but needs the per-row table path, which measured 1.7x slower.)
+    for (int tt = 0; tt < TT; ++tt)
     for (int th = 0; th < TH; ++th)
         for (int tw = 0; tw < TW; ++tw)
             for (int co = 0; co < c.cout; ++co)
-                kt[(th * TW + tw) * c.cout + co] = I2VKEntry{co * db.H * db.W, th + dh_lo, tw + dw_lo, 1};
-    for (int ph = 0; ph < B; ++ph)
-        for (int pw = 0; pw < B; ++pw)
-            for (int r = 0; r < c.kh; ++r) {
-                if (posmod(ph + c.pad - r, st)) continue;
-                const int th = floordiv(ph + c.pad - r, st) - dh_lo;
-                for (int s = 0; s < c.kw; ++s) {
-                    if (posmod(pw + c.pad - s, st)) continue;
-                    const int tw = floordiv(pw + c.pad - s, st) - dw_lo;
-                    for (int co = 0; co < c.cout; ++co)
-                        for (int ci = 0; ci < c.cin; ++ci)
-                            wp[(size_t)((th * TW + tw) * c.cout + co) * P.Cdpad + (ph * B + pw) * c.cin + ci] =
-                                nd.w[(((size_t)co * c.cin + ci) * c.kh + r) * c.kw + s];
+                kt[((tt * TH + th) * TW + tw) * c.cout + co] = I2VKEntry{co * db.H * db.W, th + dh_lo, tw + dw_lo, 1 + 2 * (tt + dt_lo)};
+    for (int ct = 0; ct < Bt; ++ct)
+    for (int q = 0; q < c.kt; ++q) {
+        if (posmod(ct + c.pad_t - q * c.dil_t, stt)) continue;
+        const int tt = floordiv(ct + c.pad_t - q * c.dil_t, stt) - dt_lo;
+        for (int ph = 0; ph < B; ++ph)
+            for (int pw = 0; pw < B; ++pw)
+                for (int r = 0; r < c.kh; ++r) {
+                    if (posmod(ph + c.pad - r, st)) continue;
+                    const int th = floordiv(ph + c.pad - r, st) - dh_lo;
+                    for (int s = 0; s < c.kw; ++s) {
+                        if (posmod(pw + c.pad - s, st)) continue;
+                        const int tw = floordiv(pw + c.pad - s, st) - dw_lo;
+                        for (int co = 0; co < c.cout; ++co)
+                            for (int ci = 0; ci < c.cin; ++ci)
+                                wp[(size_t)(((tt * TH + th) * TW + tw) * c.cout + co) * P.Cdpad + ((ct * B + ph) * B + pw) * c.cin + ci] =
+                                    nd.w[((((size_t)co * c.cin + ci) * c.kt + q) * c.kh + r) * c.kw + s];
+                    }
                 }
-            }
+    }
     if (upload(n, wp, &P.wp)) return 1;
     return upload(n, kt, &P.ktab);
 }
@@ -233,7 +255,7 @@ static int pack_img(Net& n, Node& nd) {
 // ---------------------------------------------------------------------------------------------
 // views
 // ---------------------------------------------------------------------------------------------
-struct View { float* p; int64_t nstride; int C, H, W; };
+struct View { float* p; int64_t nstride; int C, H, W; int T = 1; };
 
 static View view_of(Net& n, int t, bool grad) {
     const Tensor& T = n.tens[t];
@@ -242,7 +264,7 @@ static View view_of(Net& n, int t, bool grad) {
     View v;
     v.p = n.arena + off + (size_t)T.c_off * B.H * B.W;
     v.nstride = (int64_t)B.C * B.H * B.W;
-    v.C = T.C; v.H = B.H; v.W = B.W;
+    v.C = T.C; v.H = B.H; v.W = B.W; v.T = B.T;
     return v;
 }
 
@@ -293,13 +315,18 @@ extern "C" int i2v_net_destroy(i2v_handle h, int net) {
     return 0;
 }
 
-extern "C" int i2v_net_add_buffer(i2v_handle h, int net, int C, int H, int W, int* buf) {
+extern "C" int i2v_net_add_buffer3d(i2v_handle h, int net, int C, int T, int H, int W, int* buf) {
     Net* n = get_net(h, net); if (!n) return 1;
     if (n->planned) return fail("net already planned");
-    if (C <= 0 || H <= 0 || W <= 0) return fail("bad buffer shape %dx%dx%d", C, H, W);
-    n->bufs.push_back(Buffer{C, H, W});
+    if (C <= 0 || T <= 0 || H <= 0 || W <= 0 || !buf) return fail("bad buffer shape %dx%dx%dx%d", C, T, H, W);
+    Buffer b{C, H, W}; b.T = T;
+    n->bufs.push_back(b);
     *buf = (int)n->bufs.size() - 1;
     return 0;
+}
+
+extern "C" int i2v_net_add_buffer(i2v_handle h, int net, int C, int H, int W, int* buf) {
+    return i2v_net_add_buffer3d(h, net, C, 1, H, W, buf);
 }
 
 extern "C" int i2v_net_add_tensor(i2v_handle h, int net, int buf, int c_off, int C, int post_relu, int* tensor) {
@@ -311,6 +338,13 @@ extern "C" int i2v_net_add_tensor(i2v_handle h, int net, int buf, int c_off, int
     return 0;
 }
 
+extern "C" int i2v_net_tensor_frames(i2v_handle h, int net, int tensor, int* T) {
+    Net* n = get_net(h, net); if (!n) return 1;
+    if (tensor < 0 || tensor >= (int)n->tens.size() || !T) return fail("bad tensor id");
+    *T = n->bufs[n->tens[tensor].buf].T;
+    return 0;
+}
+
 extern "C" int i2v_net_set_input(i2v_handle h, int net, int tensor) {
     Net* n = get_net(h, net); if (!n) return 1;
     if (tensor < 0 || tensor >= (int)n->tens.size()) return fail("bad tensor id");
@@ -319,8 +353,8 @@ extern "C" int i2v_net_set_input(i2v_handle h, int net, int tensor) {
     return 0;
 }
 
-extern "C" int i2v_net_add_conv(i2v_handle h, int net, const i2v_conv_desc* d, const float* weight,
-                                const float* scale, const float* shift) {
+extern "C" int i2v_net_add_conv3d(i2v_handle h, int net, const i2v_conv3d_desc* d, const float* weight,
+                                  const float* scale, const float* shift) {
     Net* n = get_net(h, net); if (!n) return 1;
     if (n->planned) return fail("net already planned");
     if (!d || !weight || !scale || !shift) return fail("i2v_net_add_conv: null argument");
@@ -330,21 +364,31 @@ extern "C" int i2v_net_add_conv(i2v_handle h, int net, const i2v_conv_desc* d, c
     const Tensor& S = n->tens[d->src]; const Tensor& D = n->tens[d->dst];
     const Buffer& sb = n->bufs[S.buf]; const Buffer& db = n->bufs[D.buf];
     if (S.C != d->cin || D.C != d->cout) return fail("conv channel mismatch");
-    if (d->stride < 1 || d->kh < 1 || d->kw < 1 || d->pad < 0) return fail("bad conv geometry");
+    if (d->stride < 1 || d->kh < 1 || d->kw < 1 || d->pad < 0 || d->kt < 1 || d->stride_t < 1 || d->pad_t < 0 || d->dil_t < 1)
+        return fail("bad conv geometry");
     int Ho = (sb.H + 2 * d->pad - d->kh) / d->stride + 1, Wo = (sb.W + 2 * d->pad - d->kw) / d->stride + 1;
+    int To = (sb.T + 2 * d->pad_t - d->dil_t * (d->kt - 1) - 1) / d->stride_t + 1;
     if (Ho != db.H || Wo != db.W) return fail("conv output %dx%d does not match buffer %dx%d", Ho, Wo, db.H, db.W);
+    if (To != db.T) return fail("conv output has %d frames per clip, buffer has %d", To, db.T);
     if (d->residual >= 0) {
         const Tensor& R = n->tens[d->residual]; const Buffer& rb = n->bufs[R.buf];
-        if (R.C != d->cout || rb.H != db.H || rb.W != db.W) return fail("residual shape mismatch");
+        if (R.C != d->cout || rb.H != db.H || rb.W != db.W || rb.T != db.T) return fail("residual shape mismatch");
     }
     Node nd; nd.type = 0; nd.cd = *d; memset(&nd.pd, 0, sizeof nd.pd);
-    size_t per = (size_t)d->cin * d->kh * d->kw;
+    size_t per = (size_t)d->cin * d->kt * d->kh * d->kw;
     nd.w.resize((size_t)d->cout * per);
     for (int co = 0; co < d->cout; ++co)
         for (size_t i = 0; i < per; ++i) nd.w[co * per + i] = weight[co * per + i] * scale[co];
     nd.shift.assign(shift, shift + d->cout);
     n->nodes.push_back(std::move(nd));
     return 0;
+}
+
+extern "C" int i2v_net_add_conv(i2v_handle h, int net, const i2v_conv_desc* d, const float* weight,
+                                const float* scale, const float* shift) {
+    if (!d) return fail("i2v_net_add_conv: null argument");
+    i2v_conv3d_desc q{d->src, d->dst, d->cin, d->cout, 1, d->kh, d->kw, 1, d->stride, 0, d->pad, 1, d->relu, d->residual};
+    return i2v_net_add_conv3d(h, net, &q, weight, scale, shift);
 }
 
 extern "C" int i2v_net_add_conv_preact(i2v_handle h, int net, const i2v_conv_desc* d, const float* weight,
@@ -362,22 +406,31 @@ extern "C" int i2v_net_add_conv_preact(i2v_handle h, int net, const i2v_conv_des
     return 0;
 }
 
-extern "C" int i2v_net_add_avgpool(i2v_handle h, int net, const i2v_pool_desc* d) {
-    if (i2v_net_add_maxpool(h, net, d)) return 1;
-    Net* n = get_net(h, net);
-    if (d->pad != 0) return fail("average pooling with padding is not supported");
-    n->nodes.back().type = 2;
-    return 0;
-}
-
-extern "C" int i2v_net_add_maxpool(i2v_handle h, int net, const i2v_pool_desc* d) {
+extern "C" int i2v_net_add_maxpool3d(i2v_handle h, int net, const i2v_pool3d_desc* d) {
     Net* n = get_net(h, net); if (!n) return 1;
     if (n->planned) return fail("net already planned");
     int nt = (int)n->tens.size();
     if (!d || d->src < 0 || d->src >= nt || d->dst < 0 || d->dst >= nt) return fail("bad pool desc");
     if (n->tens[d->src].C != n->tens[d->dst].C) return fail("pool channel mismatch");
+    if (d->kt < 1 || d->k < 1 || d->stride_t < 1 || d->stride < 1 || d->pad_t < 0 || d->pad < 0) return fail("bad pool geometry");
+    const Buffer& sb = n->bufs[n->tens[d->src].buf]; const Buffer& db = n->bufs[n->tens[d->dst].buf];
+    if ((sb.T + 2 * d->pad_t - d->kt) / d->stride_t + 1 != db.T) return fail("pool output frames per clip do not match the buffer");
     Node nd; nd.type = 1; nd.pd = *d; memset(&nd.cd, 0, sizeof nd.cd);
     n->nodes.push_back(std::move(nd));
+    return 0;
+}
+
+extern "C" int i2v_net_add_maxpool(i2v_handle h, int net, const i2v_pool_desc* d) {
+    if (!d) return fail("bad pool desc");
+    i2v_pool3d_desc q{d->src, d->dst, 1, d->k, 1, d->stride, 0, d->pad};
+    return i2v_net_add_maxpool3d(h, net, &q);
+}
+
+extern "C" int i2v_net_add_avgpool(i2v_handle h, int net, const i2v_pool_desc* d) {
+    if (i2v_net_add_maxpool(h, net, d)) return 1;
+    Net* n = get_net(h, net);
+    if (d->pad != 0) return fail("average pooling with padding is not supported");
+    n->nodes.back().type = 2;
     return 0;
 }
 
@@ -388,6 +441,7 @@ static void conv_common(I2VConvParams& p, const Packed& P) {
     memset(&p, 0, sizeof p);
     p.wp = P.wp; p.ktab = P.ktab; p.K = P.K; p.Kpad = P.Kpad; p.tap_uniform = P.tap_uniform; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
     p.add0_stride = 1;
+    p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1; p.ot0 = 0;
 }
 
 static bool overlaps(const Tensor& a, const Tensor& b) {
@@ -405,6 +459,7 @@ struct Planner {
     std::string err;
 
     float* base() const { return dry ? (float*)nullptr : n.arena; }
+    size_t nf(int T) const { return N / (size_t)n.Tin() * (size_t)T; }      // frames of a tensor with T frames per clip
     size_t carve(size_t floats) { size_t o = off; off = align_up(off + floats, 64); return o; }
     float* temp(size_t floats) { return base() + carve(floats); }
 
@@ -412,7 +467,7 @@ struct Planner {
         if (grad && has_alias[t]) return galias[t];
         const Tensor& T = n.tens[t]; const Buffer& B = n.bufs[T.buf];
         View v; v.p = base() + (grad ? B.grad_off : B.act_off) + (size_t)T.c_off * B.H * B.W;
-        v.nstride = (int64_t)B.C * B.H * B.W; v.C = T.C; v.H = B.H; v.W = B.W;
+        v.nstride = (int64_t)B.C * B.H * B.W; v.C = T.C; v.H = B.H; v.W = B.W; v.T = B.T;
         return v;
     }
     void emit(std::vector<Launch>& L, const Launch& l) { if (!dry) L.push_back(l); }
@@ -422,7 +477,7 @@ struct Planner {
         l.am.out = out.p; l.am.out_nstride = out.nstride;
         for (size_t i = 0; i < adds.size() && i < 3; ++i) { l.am.a[i] = adds[i].p; l.am.a_nstride[i] = adds[i].nstride; }
         if (n.tens[t].post_relu) { View a = view(t, false); l.am.mask = a.p; l.am.mask_nstride = a.nstride; }
-        l.am.N = 0; l.am.C = out.C; l.am.HW = out.H * out.W;
+        l.am.N = 0; l.am.C = out.C; l.am.HW = out.H * out.W; l.T = out.T;
         emit(n.bwd, l);
     }
 
@@ -434,8 +489,8 @@ struct Planner {
             size_t a = P.size() - 1, b = P.size() - 2;
             if (P[a].stride != 1 || P[b].stride != 1) { err = "cannot fold compact addends"; return false; }
             View g = view(t, true);
-            View tv = g; tv.p = temp(N * g.C * g.H * g.W); tv.nstride = (int64_t)g.C * g.H * g.W;
-            Launch l; memset(&l.am, 0, sizeof l.am); l.kind = L_ADDMASK;
+            View tv = g; tv.p = temp(nf(g.T) * g.C * g.H * g.W); tv.nstride = (int64_t)g.C * g.H * g.W;
+            Launch l; memset(&l.am, 0, sizeof l.am); l.kind = L_ADDMASK; l.T = g.T;
             l.am.out = tv.p; l.am.out_nstride = tv.nstride;
             l.am.a[0] = P[a].p; l.am.a_nstride[0] = P[a].nstride;
             l.am.a[1] = P[b].p; l.am.a_nstride[1] = P[b].nstride;
@@ -448,17 +503,21 @@ struct Planner {
     }
 
     void conv_launches(const Node& nd, View dz, View out, bool raw, int t, bool compact) {
-        const i2v_conv_desc& c = nd.cd;
+        const i2v_conv3d_desc& c = nd.cd;
         for (const Packed& P : nd.bwd) {
-            if (compact && (P.ph || P.pw)) continue;
-            if (P.Hg <= 0 || P.Wg <= 0) continue;
+            if (compact && (P.ph || P.pw || P.pt)) continue;
+            if (P.Hg <= 0 || P.Wg <= 0 || P.Tg <= 0) continue;
             Launch l; l.kind = L_CONV; conv_common(l.conv, P);
             I2VConvParams& p = l.conv;
             p.src = dz.p; p.src_nstride = dz.nstride; p.Hs = dz.H; p.Ws = dz.W; p.Cs = dz.C;
             p.Hg = P.Hg; p.Wg = P.Wg; p.sh = 1; p.sw = 1;
+            p.Tg = P.Tg; p.Ts = dz.T; p.st = 1; l.T = P.Tg;
             p.dst = out.p; p.dst_nstride = out.nstride;
-            if (compact) { p.Ho = P.Hg; p.Wo = P.Wg; p.osh = p.osw = 1; p.oh0 = p.ow0 = 0; }
-            else { p.Ho = out.H; p.Wo = out.W; p.osh = p.osw = c.stride; p.oh0 = P.ph; p.ow0 = P.pw; }
+            if (compact) { p.Ho = P.Hg; p.Wo = P.Wg; p.osh = p.osw = 1; p.oh0 = p.ow0 = 0; p.To = P.Tg; }
+            else {
+                p.Ho = out.H; p.Wo = out.W; p.osh = p.osw = c.stride; p.oh0 = P.ph; p.ow0 = P.pw;
+                p.To = out.T; p.ost = c.stride_t; p.ot0 = P.pt;
+            }
             if (!raw) {
                 for (const Addend& a : pending[t]) {
                     if (a.stride != 1 || p.add0 == nullptr) {
@@ -468,8 +527,8 @@ struct Planner {
                 }
                 if (n.tens[t].post_relu) { View a = view(t, false); p.mask = a.p; p.mask_nstride = a.nstride; }
             }
-            p.pointwise = (c.kh == 1 && c.kw == 1 && c.stride == 1 && c.pad == 0 && (dz.H * dz.W) % 4 == 0 &&
-                           !compact) ? 1 : 0;
+            p.pointwise = (c.kt == 1 && c.stride_t == 1 && c.pad_t == 0 && c.kh == 1 && c.kw == 1 && c.stride == 1 &&
+                           c.pad == 0 && (dz.H * dz.W) % 4 == 0 && !compact) ? 1 : 0;
             emit(n.bwd, l);
         }
     }
@@ -479,17 +538,17 @@ struct Planner {
     bool contribute_conv(int t, const Node& nd, View dz) {
         left[t]--;
         View g = view(t, true);
-        const i2v_conv_desc& c = nd.cd;
+        const i2v_conv3d_desc& c = nd.cd;
         if (left[t] > 0) {
-            bool compact = (c.kh == 1 && c.kw == 1 && c.stride > 1 && c.pad == 0);
+            bool compact = (c.kt == 1 && c.stride_t == 1 && c.pad_t == 0 && c.kh == 1 && c.kw == 1 && c.stride > 1 && c.pad == 0);
             if (compact) {
                 const Packed& P = nd.bwd[0];
-                View tv; tv.C = g.C; tv.H = P.Hg; tv.W = P.Wg; tv.nstride = (int64_t)g.C * P.Hg * P.Wg;
-                tv.p = temp(N * tv.nstride);
+                View tv; tv.C = g.C; tv.H = P.Hg; tv.W = P.Wg; tv.T = g.T; tv.nstride = (int64_t)g.C * P.Hg * P.Wg;
+                tv.p = temp(nf(g.T) * tv.nstride);
                 conv_launches(nd, dz, tv, true, t, true);
                 pending[t].push_back(Addend{tv.p, tv.nstride, c.stride, P.Hg, P.Wg});
             } else {
-                View tv = g; tv.nstride = (int64_t)g.C * g.H * g.W; tv.p = temp(N * tv.nstride);
+                View tv = g; tv.nstride = (int64_t)g.C * g.H * g.W; tv.p = temp(nf(g.T) * tv.nstride);
                 conv_launches(nd, dz, tv, true, t, false);
                 pending[t].push_back(Addend{tv.p, tv.nstride, 1, g.H, g.W});
             }
@@ -543,11 +602,21 @@ struct Planner {
                 left[nd.pd.src]++;
             }
         }
+        // A ReLU output that is only ever read through a wider concatenation view which is NOT declared post-ReLU
+        // (SlowFast: max-pooled slow features ++ ReLU'd lateral features) is gated in place before its producer's
+        // input-gradient runs; the covering view's finaliser cannot do it.
+        std::vector<char> need_gate(NT, 0);
+        for (int t = 0; t < NT; ++t) {
+            if (!n.tens[t].post_relu || left[t] > 0 || is_hook(t)) continue;
+            for (int u = 0; u < NT; ++u)
+                if (u != t && left[u] > 0 && !n.tens[u].post_relu && overlaps(n.tens[u], n.tens[t])) need_gate[t] = 1;
+        }
+        int img_seen = 0;
         // ---------------- forward ----------------
         for (const Node& nd : n.nodes) {
             Launch l;
             if (nd.type == 0) {
-                const i2v_conv_desc& c = nd.cd;
+                const i2v_conv3d_desc& c = nd.cd;
                 l.kind = L_CONV; conv_common(l.conv, nd.fwd);
                 I2VConvParams& p = l.conv;
                 View d = view(c.dst, false);
@@ -556,20 +625,25 @@ struct Planner {
                 else { View s = view(c.src, false); p.src = s.p; p.src_nstride = s.nstride; }
                 p.Hs = sb.H; p.Ws = sb.W; p.Cs = c.cin; p.Hg = d.H; p.Wg = d.W; p.sh = p.sw = c.stride;
                 p.dst = d.p; p.dst_nstride = d.nstride; p.Ho = d.H; p.Wo = d.W; p.osh = p.osw = 1;
+                p.Tg = p.To = d.T; p.Ts = sb.T; p.st = c.stride_t; l.T = d.T;
                 p.shift = nd.shift_d; p.relu = c.relu;
                 if (c.residual >= 0) { View r = view(c.residual, false); p.add0 = r.p; p.add0_nstride = r.nstride; p.add0_stride = 1; }
-                p.pointwise = (c.kh == 1 && c.kw == 1 && c.stride == 1 && c.pad == 0 && (sb.H * sb.W) % 4 == 0 &&
-                               c.src != n.input) ? 1 : 0;
+                p.pointwise = (c.kt == 1 && c.stride_t == 1 && c.pad_t == 0 && c.kh == 1 && c.kw == 1 && c.stride == 1 &&
+                               c.pad == 0 && (sb.H * sb.W) % 4 == 0 && c.src != n.input) ? 1 : 0;
                 if (nd.preact()) { p.pre_scale = nd.pre_scale_d; p.pre_shift = nd.pre_shift_d; }
             } else {
-                const i2v_pool_desc& q = nd.pd;
-                l.kind = nd.type == 2 ? L_AVGF : L_POOLF; memset(&l.pool, 0, sizeof l.pool);
+                const i2v_pool3d_desc& q = nd.pd;
+                const bool vid = q.kt != 1 || q.stride_t != 1 || q.pad_t != 0;
+                if (vid && nd.type == 2) { err = "average pooling over time is not supported"; return false; }
+                l.kind = nd.type == 2 ? L_AVGF : vid ? L_POOL3F : L_POOLF; memset(&l.pool, 0, sizeof l.pool);
                 View s = view(q.src, false), d = view(q.dst, false);
                 if (q.src == n.input) { err = "maxpool directly on the input is not supported"; return false; }
                 l.pool.x = s.p; l.pool.x_nstride = s.nstride; l.pool.C = s.C; l.pool.Hs = s.H; l.pool.Ws = s.W;
                 l.pool.y = d.p; l.pool.y_nstride = d.nstride; l.pool.Ho = d.H; l.pool.Wo = d.W;
                 l.pool.k = q.k; l.pool.stride = q.stride; l.pool.pad = q.pad;
+                l.pool.kt = q.kt; l.pool.stride_t = q.stride_t; l.pool.pad_t = q.pad_t; l.pool.Ts = s.T; l.pool.To = d.T;
                 l.pool.idx = (uint8_t*)(base() + nd.idx_off);
+                l.T = d.T;
             }
             emit(n.fwd, l);
         }
@@ -582,13 +656,14 @@ struct Planner {
                 int srcs[2] = {nd.type == 0 ? nd.cd.src : nd.pd.src, nd.type == 0 ? nd.cd.residual : -1};
                 for (int s : srcs) if (s >= 0 && overlaps(n.tens[s], n.tens[t])) consumed = true;
             }
-            if (consumed || accum[n.tens[t].buf]) { View g = view(t, true); hook_tmp[hk] = temp(N * g.C * g.H * g.W); }
+            if (consumed || accum[n.tens[t].buf]) { View g = view(t, true); hook_tmp[hk] = temp(nf(g.T) * g.C * g.H * g.W); }
         }
         // ---------------- backward ----------------
         for (size_t b = 0; b < n.bufs.size(); ++b)
             if (accum[b]) {
                 Launch l; l.kind = L_MEMSET;
                 l.ms_ptr = base() + n.bufs[b].grad_off; l.ms_floats_per_frame = (size_t)n.bufs[b].C * n.bufs[b].H * n.bufs[b].W;
+                l.T = n.bufs[b].T;
                 emit(n.bwd, l);
             }
         for (size_t hk = 0; hk < n.hooks.size(); ++hk)          // hook gradients of dense buffers: G += H right away
@@ -610,18 +685,21 @@ struct Planner {
                     emit_addmask(g, adds, dst);
                 }
             View dz = view(dst, true);
+            if (need_gate[dst]) emit_addmask(dz, {Addend{dz.p, dz.nstride, 1, dz.H, dz.W}}, dst);
             if (nd.type == 0) {
-                const i2v_conv_desc& c = nd.cd;
+                const i2v_conv3d_desc& c = nd.cd;
                 if (c.residual >= 0 && !contribute_alias(c.residual, dz)) return false;
                 if (c.src == n.input) {
                     Launch l; l.kind = L_IMGGRAD; conv_common(l.conv, nd.img);
+                    l.img_accumulate = img_seen++ > 0;
                     const Buffer& ib = n.bufs[n.tens[n.input].buf];
                     I2VConvParams& p = l.conv;
                     p.src = dz.p; p.src_nstride = dz.nstride; p.Hs = dz.H; p.Ws = dz.W; p.Cs = dz.C;
                     p.Hg = nd.img.Hg; p.Wg = nd.img.Wg; p.sh = p.sw = nd.img_sh;
                     p.dst = nullptr; p.dst_nstride = (int64_t)ib.C * ib.H * ib.W; p.Ho = ib.H; p.Wo = ib.W;
                     p.osh = p.osw = nd.img_blk; p.blk = nd.img_blk;
-                    l.alg_flops_per_frame = 2.0 * dz.H * dz.W * c.cout * c.cin * c.kh * c.kw;
+                    p.blkt = nd.img_blkt; p.Tg = nd.img.Tg; p.Ts = dz.T; p.st = 1; p.To = ib.T; p.ost = nd.img_blkt; l.T = nd.img.Tg;
+                    l.alg_flops_per_frame = 2.0 * dz.T * dz.H * dz.W * c.cout * c.cin * c.kt * c.kh * c.kw / nd.img.Tg;   // per grid frame
                     emit(n.bwd, l);
                 } else if (nd.preact()) {
                     // G(view) += W'^T dz gated by the pre-activation sign; W' carries the BN scale per input channel
@@ -631,23 +709,27 @@ struct Planner {
                     p.src = dz.p; p.src_nstride = dz.nstride; p.Hs = dz.H; p.Ws = dz.W; p.Cs = dz.C;
                     p.Hg = g.H; p.Wg = g.W; p.sh = p.sw = 1;
                     p.dst = g.p; p.dst_nstride = g.nstride; p.Ho = g.H; p.Wo = g.W; p.osh = p.osw = 1;
+                    p.Tg = p.Ts = p.To = g.T; l.T = g.T;
                     p.add1 = g.p; p.add1_nstride = g.nstride;
                     p.mask = x.p; p.mask_nstride = x.nstride; p.gate_scale = nd.pre_scale_d; p.gate_shift = nd.pre_shift_d;
                     p.pointwise = ((dz.H * dz.W) % 4 == 0) ? 1 : 0;
                     emit(n.bwd, l);
                 } else if (!contribute_conv(c.src, nd, dz)) return false;
             } else {
-                const i2v_pool_desc& q = nd.pd;
+                const i2v_pool3d_desc& q = nd.pd;
+                const bool vid = q.kt != 1 || q.stride_t != 1 || q.pad_t != 0;
                 left[q.src]--;
                 if (left[q.src] > 0 || !pending[q.src].empty()) { err = "maxpool input with several consumers is not supported"; return false; }
-                Launch l; l.kind = nd.type == 2 ? L_AVGB : L_POOLB; memset(&l.pool, 0, sizeof l.pool);
+                Launch l; l.kind = nd.type == 2 ? L_AVGB : vid ? L_POOL3B : L_POOLB; memset(&l.pool, 0, sizeof l.pool);
                 View x = view(q.src, false), gx = view(q.src, true);
                 l.pool.x = x.p; l.pool.x_nstride = x.nstride; l.pool.C = x.C; l.pool.Hs = x.H; l.pool.Ws = x.W;
                 l.pool.y = dz.p; l.pool.y_nstride = dz.nstride; l.pool.Ho = dz.H; l.pool.Wo = dz.W;
                 l.pool.gx = gx.p; l.pool.gx_nstride = gx.nstride;
                 l.pool.k = q.k; l.pool.stride = q.stride; l.pool.pad = q.pad;
                 l.pool.mask_relu = n.tens[q.src].post_relu ? 1 : 0;
+                l.pool.kt = q.kt; l.pool.stride_t = q.stride_t; l.pool.pad_t = q.pad_t; l.pool.Ts = x.T; l.pool.To = dz.T;
                 l.pool.idx = (uint8_t*)(base() + nd.idx_off);
+                l.T = dz.T;
                 emit(n.bwd, l);
             }
         }
@@ -670,6 +752,8 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
     n.hooks.assign(hook_tensors, hook_tensors + n_hooks);
     n.maxN = max_frames;
     const size_t N = (size_t)max_frames;
+    const int Tin = n.Tin();
+    if (max_frames % Tin) return fail("max_frames=%d is not a multiple of the input's %d frames per clip", max_frames, Tin);
 
     for (Node& nd : n.nodes) {
         if (nd.type != 0) continue;
@@ -686,14 +770,14 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
     size_t off = 0;
     for (Buffer& b : n.bufs) {
         if (b.is_input) continue;
-        size_t sz = N * b.C * b.H * b.W;
+        size_t sz = N / Tin * b.T * b.C * b.H * b.W;
         b.act_off = off; off = align_up(off + sz, 64);
         b.grad_off = off; off = align_up(off + sz, 64);
     }
     for (Node& nd : n.nodes)
         if (nd.type == 1) {
             const Buffer& db = n.bufs[n.tens[nd.pd.dst].buf];
-            nd.idx_off = off; off = align_up(off + (N * n.tens[nd.pd.dst].C * db.H * db.W + 3) / 4, 64);
+            nd.idx_off = off; off = align_up(off + (N / Tin * db.T * n.tens[nd.pd.dst].C * db.H * db.W + 3) / 4, 64);
         }
     Planner dry{n, true, off, N};
     if (!dry.run()) return fail("plan: %s", dry.err.c_str());
@@ -717,29 +801,34 @@ extern "C" size_t i2v_net_workspace_bytes(i2v_handle h, int net) {
 // ---------------------------------------------------------------------------------------------
 // execution
 // ---------------------------------------------------------------------------------------------
-// One convolution launch (possibly sliced over frames: 32-bit buffer offsets keep a launch's source span < 2 GiB)
+// One convolution launch over `frames` grid frames (= clips * Tg), possibly sliced over whole clips: 32-bit
+// buffer offsets keep a launch's source span < 2 GiB
 static int conv_run(const Launch& l, int frames, const float* x, float* gx, int accumulate, i2v_stream_t s) {
     I2VConvParams p = l.conv;
     if (l.src_is_input) p.src = x;
-    if (l.kind == L_IMGGRAD) { p.dst = gx; if (accumulate) { p.add1 = gx; p.add1_nstride = p.dst_nstride; } }
+    if (l.kind == L_IMGGRAD) { p.dst = gx; if (accumulate || l.img_accumulate) { p.add1 = gx; p.add1_nstride = p.dst_nstride; } }
     p.vec_epilogue = (p.blk <= 1 && p.osh == 1 && p.osw == 1 && p.oh0 == 0 && p.ow0 == 0 && p.Hg == p.Ho &&
-                      p.Wg == p.Wo && (p.Ho * p.Wo) % 4 == 0 && p.dst_nstride % 4 == 0 &&
+                      p.Wg == p.Wo && p.Tg == p.To && p.ost == 1 && p.ot0 == 0 &&
+                      (p.Ho * p.Wo) % 4 == 0 && p.dst_nstride % 4 == 0 &&
                       (p.add0_stride == 1 || (p.add0_stride == 2 && p.Wo % 4 == 0 && p.add0_W * 2 == p.Wo &&
                                               p.add0_W % 2 == 0 && (p.add0_H * p.add0_W) % 2 == 0)) &&
                       p.add0_nstride % 4 == 0 && p.add1_nstride % 4 == 0 && p.mask_nstride % 4 == 0 &&
                       (((uintptr_t)p.dst | (uintptr_t)p.add0 | (uintptr_t)p.add1 | (uintptr_t)p.mask) & 15) == 0)
                          ? 1 : 0;
+    const int clips = frames / p.Tg;
     const int64_t plane_bytes = (int64_t)p.Cs * p.Hs * p.Ws * 4, stride_bytes = p.src_nstride * 4;
-    int64_t per = plane_bytes >= (1ll << 31) ? 0 : 1 + ((1ll << 31) - 1 - plane_bytes) / stride_bytes;
-    if (per < 1) return fail("one frame of a convolution input exceeds 2 GiB");
-    for (int f0 = 0; f0 < frames; f0 += (int)per) {
+    const int64_t clip_bytes = (int64_t)(p.Ts - 1) * stride_bytes + plane_bytes;        // span of one clip's source frames
+    int64_t per = clip_bytes >= (1ll << 31) ? 0 : 1 + ((1ll << 31) - 1 - clip_bytes) / (stride_bytes * p.Ts);
+    if (per < 1) return fail("one clip of a convolution input exceeds 2 GiB");
+    for (int c0 = 0; c0 < clips; c0 += (int)per) {
         I2VConvParams q = p;
-        q.N = frames - f0 < per ? frames - f0 : (int)per;
-        q.src += (int64_t)f0 * p.src_nstride; q.dst += (int64_t)f0 * p.dst_nstride;
-        if (q.add0) q.add0 += (int64_t)f0 * p.add0_nstride;
-        if (q.add1) q.add1 += (int64_t)f0 * p.add1_nstride;
-        if (q.mask) q.mask += (int64_t)f0 * p.mask_nstride;
-        q.src_span_bytes = (int32_t)((int64_t)(q.N - 1) * stride_bytes + plane_bytes);
+        const int nc = clips - c0 < per ? clips - c0 : (int)per;
+        q.N = nc * p.Tg;
+        q.src += (int64_t)c0 * p.Ts * p.src_nstride; q.dst += (int64_t)c0 * p.To * p.dst_nstride;
+        if (q.add0) q.add0 += (int64_t)c0 * p.To * p.add0_nstride;
+        if (q.add1) q.add1 += (int64_t)c0 * p.To * p.add1_nstride;
+        if (q.mask) q.mask += (int64_t)c0 * p.To * p.mask_nstride;
+        q.src_span_bytes = (int32_t)((int64_t)(nc * p.Ts - 1) * stride_bytes + plane_bytes);
         CHECK_BE(k_conv(q, s));
     }
     return 0;
@@ -761,16 +850,17 @@ static int autotune(Net& n) {
     for (std::vector<Launch>* L : {&n.fwd, &n.bwd})
         for (Launch& l : *L) {
             if (l.kind != L_CONV && l.kind != L_IMGGRAD) continue;
-            if (n.maxN * l.conv.Hg * l.conv.Wg == 0) continue;
-            int cand[8]; I2VConvParams probe = l.conv; probe.N = n.maxN;
+            const int lf = n.maxN / n.Tin() * l.conv.Tg;        // grid frames of this launch at the planned size
+            if (lf * l.conv.Hg * l.conv.Wg == 0) continue;
+            int cand[8]; I2VConvParams probe = l.conv; probe.N = lf;
             const int nc = k_conv_candidates(probe, cand);
             if (nc <= 1) { if (nc == 1) l.conv.cfg = cand[0] + 1; continue; }
             float best = 1e30f; int best_c = -1;
             for (int ci = 0; ci < nc && !rc; ++ci) {
                 l.conv.cfg = cand[ci] + 1;
-                rc |= conv_run(l, n.maxN, scratch, scratch + img, 0, nullptr);              // warm-up
+                rc |= conv_run(l, lf, scratch, scratch + img, 0, nullptr);                  // warm-up
                 be_event_record(e0, nullptr);
-                for (int r = 0; r < 2 && !rc; ++r) rc |= conv_run(l, n.maxN, scratch, scratch + img, 0, nullptr);
+                for (int r = 0; r < 2 && !rc; ++r) rc |= conv_run(l, lf, scratch, scratch + img, 0, nullptr);
                 be_event_record(e1, nullptr);
                 if (rc || be_stream_sync(nullptr)) { rc = 1; break; }
                 float ms = 0.f; be_event_elapsed_ms(e0, e1, &ms);
@@ -799,14 +889,17 @@ static TimedLaunch* timing_begin(i2v_ctx* h, int kind, double flops, i2v_stream_
     return t;
 }
 
-static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int frames, const float* x, float* gx, int accumulate,
+static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, const float* x, float* gx, int accumulate,
                     i2v_stream_t s, bool backward_pass) {
+    const int clips = in_frames / n.Tin();
     for (Launch& l : L) {
+        const int frames = clips * l.T;                  // frames this launch iterates over
         double flops = 0.0;
         if (l.kind == L_CONV) flops = 2.0 * frames * l.conv.Hg * l.conv.Wg * (double)l.conv.Cd * l.conv.K;
         else if (l.kind == L_IMGGRAD) flops = l.alg_flops_per_frame * frames;
         // timing kinds: 0 conv fwd, 1 image gradient, 2 pool fwd, 3 pool bwd, 4 addmask, 5 conv input-gradient
-        const int tkind = (l.kind == L_CONV && backward_pass) ? 5 : l.kind == L_AVGF ? 2 : l.kind == L_AVGB ? 3 : l.kind == L_MEMSET ? 4 : (int)l.kind;
+        const int tkind = (l.kind == L_CONV && backward_pass) ? 5 : (l.kind == L_AVGF || l.kind == L_POOL3F) ? 2
+                          : (l.kind == L_AVGB || l.kind == L_POOL3B) ? 3 : l.kind == L_MEMSET ? 4 : (int)l.kind;
         TimedLaunch* tl = timing_begin(h, tkind, flops, s);
         if (tl && (l.kind == L_CONV || l.kind == L_IMGGRAD)) { tl->Cd = l.conv.Cd; tl->K = l.conv.K; tl->HWg = l.conv.Hg * l.conv.Wg; tl->frames = frames; tl->pw = l.conv.pointwise; }
         struct Stop { TimedLaunch* t; i2v_stream_t s; ~Stop() { if (t) be_event_record(t->stop, s); } } stop{tl, s};
@@ -817,6 +910,8 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int frames, cons
                 if (conv_run(l, frames, x, gx, accumulate, s)) return 1;
             } break;
             case L_POOLF: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool_fwd(p, s)); } break;
+            case L_POOL3F: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool3d_fwd(p, s)); } break;
+            case L_POOL3B: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool3d_bwd(p, s)); } break;
             case L_AVGF: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_avgpool_fwd(p, s)); } break;
             case L_AVGB: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_avgpool_bwd(p, s)); } break;
             case L_MEMSET: CHECK_BE(be_memset0(l.ms_ptr, l.ms_floats_per_frame * frames * sizeof(float), s)); break;
@@ -832,6 +927,7 @@ extern "C" int i2v_net_forward(i2v_handle h, int net, const float* x, int frames
     Net* n = get_net(h, net); if (!n) return 1;
     if (!n->planned) return fail("net not planned");
     if (frames <= 0 || frames > n->maxN) return fail("frames=%d outside 1..%d", frames, n->maxN);
+    if (frames % n->Tin()) return fail("frames=%d is not a multiple of the input's %d frames per clip", frames, n->Tin());
     if (!x) return fail("null input");
     n->frames = frames;
     return run_list(h, *n, n->fwd, frames, x, nullptr, 0, stream, false);
@@ -893,8 +989,8 @@ extern "C" int i2v_net_read_tensor(i2v_handle h, int net, int tensor, int which,
     Net* n = get_net(h, net); if (!n) return 1;
     if (!n->planned) return fail("net not planned");
     if (tensor < 0 || tensor >= (int)n->tens.size() || tensor == n->input) return fail("bad tensor id");
-    if (frames <= 0 || frames > n->maxN) return fail("bad frame count");
     View v = view_of(*n, tensor, which != 0);
+    if (frames <= 0 || frames > n->maxN / n->Tin() * v.T) return fail("bad frame count");
     size_t row = (size_t)v.C * v.H * v.W * sizeof(float);
     CHECK_BE(be_d2d_2d(out, row, v.p, (size_t)v.nstride * sizeof(float), row, frames, stream));
     return 0;
@@ -994,6 +1090,40 @@ extern "C" int i2v_sign_step_f32(float* adv, const float* u, const float* grad, 
 extern "C" int i2v_sign_step_delta_f32(float* delta, const float* grad, int64_t nel, float step, void* stream) {
     if (!delta || !grad || nel <= 0) return fail("i2v_sign_step_delta_f32: bad argument");
     CHECK_BE(k_sign_delta(delta, grad, nel, step, stream));
+    return 0;
+}
+
+extern "C" int i2v_sign_step_delta_gx_f32(float* delta, const float* gx, const float* u, int64_t nel, float eps,
+                                          float step, void* stream) {
+    if (!delta || !gx || !u || nel <= 0) return fail("i2v_sign_step_delta_gx_f32: bad argument");
+    CHECK_BE(k_sign_delta_gx(delta, gx, u, nel, eps, step, stream));
+    return 0;
+}
+
+static void ilaf_params(I2VIlafParams& p, const float* a, int64_t a_stride, const float* ori, const float* adv0,
+                        int64_t D, int frames, void* scratch) {
+    memset(&p, 0, sizeof p);
+    p.a = a; p.a_nstride = a_stride; p.ori = ori; p.adv0 = adv0; p.D = D; p.N = frames; p.nblk = cos_nblk(D);
+    p.sums = (double*)scratch; p.partial = (double*)scratch + 2;        // same layout as the std kernels
+}
+
+extern "C" int i2v_ilaf_reduce_f32(const float* a, int64_t a_stride, const float* ori, const float* adv0, int64_t D,
+                                   int frames, void* scratch, void* stream) {
+    if (!a || !ori || !adv0 || !scratch || D <= 0 || frames <= 0) return fail("i2v_ilaf_reduce_f32: bad argument");
+    I2VIlafParams p; ilaf_params(p, a, a_stride, ori, adv0, D, frames, scratch);
+    CHECK_BE(k_ilaf_reduce(p, stream));
+    return 0;
+}
+
+extern "C" int i2v_ilaf_grad_f32(const float* a, int64_t a_stride, const float* ori, const float* adv0, int64_t D,
+                                 int frames, double init_norm, int mask_relu, int accumulate, float* loss_out,
+                                 float* grad, int64_t grad_stride, void* scratch, void* stream) {
+    if (!a || !ori || !adv0 || !scratch || !loss_out || !grad || D <= 0 || frames <= 0 || !(init_norm > 0.0))
+        return fail("i2v_ilaf_grad_f32: bad argument");
+    I2VIlafParams p; ilaf_params(p, a, a_stride, ori, adv0, D, frames, scratch);
+    p.init_norm = init_norm; p.mask_relu = mask_relu; p.accumulate = accumulate; p.loss_out = loss_out;
+    p.grad = grad; p.grad_nstride = grad_stride;
+    CHECK_BE(k_ilaf_grad(p, stream));
     return 0;
 }
 

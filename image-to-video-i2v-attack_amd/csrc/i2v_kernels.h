@@ -26,12 +26,16 @@ int k_conv(const I2VConvParams& p, i2v_stream_t s);
 int k_conv_candidates(const I2VConvParams& p, int* out);   // tile configurations valid for p (ids 0..4), returns count
 int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s);
+int k_pool3d_fwd(const I2VPoolParams& p, i2v_stream_t s);  // video max pooling (kt/stride_t/pad_t honoured)
+int k_pool3d_bwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_avgpool_fwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_avgpool_bwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_addmask(const I2VAddMaskParams& p, i2v_stream_t s);
 int k_cos(const I2VCosParams& p, i2v_stream_t s);
 int k_std_reduce(const I2VStdParams& p, i2v_stream_t s);   // -> p.sums[0..1]
 int k_std_grad(const I2VStdParams& p, i2v_stream_t s);     // p.sums, p.total_count -> std_out, grad
+int k_ilaf_reduce(const I2VIlafParams& p, i2v_stream_t s); // -> p.sums[0..1]
+int k_ilaf_grad(const I2VIlafParams& p, i2v_stream_t s);   // p.sums, p.init_norm -> loss_out, grad
 int k_clip_from_u8(const uint8_t* frames, float* video, int b, int t, int h, int w, i2v_stream_t s);
 int k_frames_from_video(const float* video, float* x, float* u, int b, int f, int h, int w, i2v_stream_t s);
 int k_compose(const float* u, const float* delta, float* x, int b, int f, int h, int w, float eps,
@@ -42,6 +46,8 @@ int k_adam(float* delta, float* m, float* v, const float* gx, const float* u, in
 int k_sign_bim(float* adv, const float* u, const float* grad, int64_t n, int64_t chan_stride,
                float step, float eps, i2v_stream_t s);
 int k_sign_delta(float* delta, const float* grad, int64_t n, float step, i2v_stream_t s);
+int k_sign_delta_gx(float* delta, const float* gx, const float* u, int64_t n, float eps, float step,
+                    i2v_stream_t s);   // delta -= step * sign(d cost / d delta) from the gradient w.r.t. the composed frames
 int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t s);
 int k_aens_reduce(const float* cos, const float* coeffs, int L, int frames, float* feat_sum,
                   float* weighted, i2v_stream_t s);

@@ -132,13 +132,20 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     const int64_t pn = pvalid ? ppix / HWg : 0;
     const int prem = (int)(ppix - pn * HWg);
     const int HWs = p.Hs * p.Ws;
-    int h0 = 0, w0 = 0;
+    int h0 = 0, w0 = 0, t0 = 0;
+    int64_t pns = pn;                                         // source frame of this lane's pixel
+    if (p.Tg > 1 || p.Ts > 1) {                               // video: grid frame (clip, tg) reads frames tg*st + dt
+        const int64_t clip = pn / p.Tg;
+        t0 = (int)(pn - clip * p.Tg) * p.st;
+        pns = clip * p.Ts + t0;
+    }
+    const int nstr = (int)p.src_nstride;                      // a launch's source span is < 2 GiB
     unsigned xoff;                                            // byte offset of this lane's pixel in `src`
-    if (PW) xoff = (unsigned)((pn * p.src_nstride + prem) * 4);
+    if (PW) xoff = (unsigned)((pns * p.src_nstride + prem) * 4);
     else {
         const int gi = prem / p.Wg, gj = prem - gi * p.Wg;
         h0 = gi * p.sh; w0 = gj * p.sw;
-        xoff = (unsigned)((pn * p.src_nstride + (int64_t)h0 * p.Ws + w0) * 4);
+        xoff = (unsigned)((pns * p.src_nstride + (int64_t)h0 * p.Ws + w0) * 4);
     }
     if (!pvalid) xoff = OOB;
     unsigned aoff[NAQ];
@@ -177,9 +184,10 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
             }                                                                                             \
         } else if (MODE == 2) {                                                                           \
             const I2VKEntry e = load_kentry(p.ktab, k0);                                                  \
-            const int hs = h0 + e.dh, ws = w0 + e.dw;                                                     \
-            const bool ok = pvalid && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;     \
-            const unsigned v = ok ? xoff + (unsigned)((e.chan_off + e.dh * p.Ws + e.dw) * 4) : OOB;       \
+            const int hs = h0 + e.dh, ws = w0 + e.dw, dtk = e.valid >> 1;                                 \
+            const bool ok = pvalid && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws &&   \
+                            (unsigned)(t0 + dtk) < (unsigned)p.Ts;                                        \
+            const unsigned v = ok ? xoff + (unsigned)((e.chan_off + dtk * nstr + e.dh * p.Ws + e.dw) * 4) : OOB; \
             _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                             \
                 const int ins = wv + 4 * q;                                                               \
                 if (NB % 4 == 0 || ins < NB)                                                              \
@@ -191,9 +199,10 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
                 const int ins = wv + 4 * q;                                                               \
                 if (NB % 4 == 0 || ins < NB) {                                                            \
                     const I2VKEntry e = load_kentry(p.ktab, k0 + (ins * 64) / BP);                        \
-                    const int hs = h0 + e.dh, ws = w0 + e.dw;                                             \
-                    const bool ok = pvalid && e.valid && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws; \
-                    const unsigned v = ok ? xoff + (unsigned)((e.chan_off + e.dh * p.Ws + e.dw) * 4) : OOB; \
+                    const int hs = h0 + e.dh, ws = w0 + e.dw, dtk = e.valid >> 1;                         \
+                    const bool ok = pvalid && (e.valid & 1) && (unsigned)hs < (unsigned)p.Hs &&           \
+                                    (unsigned)ws < (unsigned)p.Ws && (unsigned)(t0 + dtk) < (unsigned)p.Ts; \
+                    const unsigned v = ok ? xoff + (unsigned)((e.chan_off + dtk * nstr + e.dh * p.Ws + e.dw) * 4) : OOB; \
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 64), 4, v, 0, 0, 0); \
                 }                                                                                         \
             }                                                                                             \
@@ -358,23 +367,27 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     }
     if (p.blk > 1) {
         // class-packed Cd (image gradient): cd = (ph*blk + pw)*Creal + c -> channel c at (gi*osh+ph, gj*osw+pw)
-        const int Creal = p.Cd / (p.blk * p.blk);
+        const int Creal = p.Cd / (p.blkt * p.blk * p.blk), bb = p.blk * p.blk;
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int64_t pp = px0 + wpx * (BP / WP) + j * 32 + l31;
             if (pp >= P) continue;
-            const int64_t n = pp / HWg;
-            const int rem = (int)(pp - n * HWg);
+            const int64_t ng = pp / HWg;
+            const int rem = (int)(pp - ng * HWg);
             const int gi = rem / p.Wg, gj = rem - gi * p.Wg;
+            const int64_t clip = ng / p.Tg;
+            const int otb = (int)(ng - clip * p.Tg) * p.ost + p.ot0;
 #pragma unroll
             for (int i = 0; i < TD; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cd = cd0 + wd * (BD / WD) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                     if (cd >= p.Cd) continue;
-                    const int cls = cd / Creal, c = cd - cls * Creal;
+                    const int cls3 = cd / Creal, c = cd - cls3 * Creal;
+                    const int ct = cls3 / bb, cls = cls3 - ct * bb;
                     const int oh = gi * p.osh + cls / p.blk + p.oh0, ow = gj * p.osw + cls % p.blk + p.ow0;
-                    if (oh >= p.Ho || ow >= p.Wo) continue;
+                    if (oh >= p.Ho || ow >= p.Wo || otb + ct >= p.To) continue;
+                    const int64_t n = clip * p.To + otb + ct;
                     const int64_t o = (int64_t)c * HoWo + oh * p.Wo + ow;
                     float v = acc[i][j][r];
                     if (p.shift) v += p.shift[c];
@@ -390,11 +403,18 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     for (int j = 0; j < TP; ++j) {
         const int64_t pp = px0 + wpx * (BP / WP) + j * 32 + l31;
         if (pp >= P) continue;
-        const int64_t n = pp / HWg;
-        const int rem = (int)(pp - n * HWg);
+        const int64_t ng = pp / HWg;
+        const int rem = (int)(pp - ng * HWg);
         const int gi = rem / p.Wg, gj = rem - gi * p.Wg;
         const int oh = gi * p.osh + p.oh0, ow = gj * p.osw + p.ow0;
         if (oh >= p.Ho || ow >= p.Wo) continue;
+        int64_t n = ng;                                          // destination frame
+        if (p.Tg > 1 || p.To > 1) {
+            const int64_t clip = ng / p.Tg;
+            const int ot = (int)(ng - clip * p.Tg) * p.ost + p.ot0;
+            if (ot >= p.To) continue;
+            n = clip * p.To + ot;
+        }
         const int opix = oh * p.Wo + ow;
         float* dstn = p.dst + n * p.dst_nstride + opix;
         const float* a0 = nullptr; int a0_plane = HoWo;
@@ -667,6 +687,73 @@ int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s) {
     LAUNCH_CHECK("pool_bwd"); return 0;
 }
 
+// ---- video max pooling (frame-major clips; window kt x k x k).  Small tensors on this path (the pools of an
+// inflated ResNet stem): one thread per element, arg-max byte (q*k + r)*k + s, gather-form backward. ----
+__global__ void pool3d_fwd_kernel(const I2VPoolParams p) {
+    const int64_t total = (int64_t)p.N * p.C * p.Ho * p.Wo;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int wo = idx % p.Wo; int64_t r = idx / p.Wo;
+        const int ho = r % p.Ho; r /= p.Ho;
+        const int c = r % p.C; const int64_t n = r / p.C;
+        const int64_t clip = n / p.To; const int to = (int)(n - clip * p.To);
+        int best = -1; float bv = 0.f;
+        for (int q = 0; q < p.kt; ++q) {
+            const int ts = to * p.stride_t - p.pad_t + q; if (ts < 0 || ts >= p.Ts) continue;
+            const float* pl = p.x + (clip * p.Ts + ts) * p.x_nstride + (int64_t)c * p.Hs * p.Ws;
+            for (int kr = 0; kr < p.k; ++kr) {
+                const int h = ho * p.stride - p.pad + kr; if (h < 0 || h >= p.Hs) continue;
+                for (int ks = 0; ks < p.k; ++ks) {
+                    const int w = wo * p.stride - p.pad + ks; if (w < 0 || w >= p.Ws) continue;
+                    const float v = pl[h * p.Ws + w];
+                    if (best < 0 || v > bv || v != v) { bv = v; best = (q * p.k + kr) * p.k + ks; }   // first maximum wins (ATen)
+                }
+            }
+        }
+        p.y[n * p.y_nstride + ((int64_t)c * p.Ho + ho) * p.Wo + wo] = bv;
+        p.idx[idx] = (uint8_t)best;
+    }
+}
+
+__global__ void pool3d_bwd_kernel(const I2VPoolParams p) {
+    const int64_t clips = p.N / p.To, total = clips * p.Ts * p.C * p.Hs * p.Ws;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int w = idx % p.Ws; int64_t r = idx / p.Ws;
+        const int h = r % p.Hs; r /= p.Hs;
+        const int c = r % p.C; const int64_t ns = r / p.C;
+        const int64_t clip = ns / p.Ts; const int ts = (int)(ns - clip * p.Ts);
+        const int64_t xo = ns * p.x_nstride + ((int64_t)c * p.Hs + h) * p.Ws + w;
+        float g = 0.f;
+        if (!p.mask_relu || p.x[xo] > 0.f) {
+            int t_lo = ts + p.pad_t - p.kt + 1; t_lo = t_lo <= 0 ? 0 : (t_lo + p.stride_t - 1) / p.stride_t;
+            const int t_hi = min((ts + p.pad_t) / p.stride_t, p.To - 1);
+            int a_lo = h + p.pad - p.k + 1; a_lo = a_lo <= 0 ? 0 : (a_lo + p.stride - 1) / p.stride;
+            const int a_hi = min((h + p.pad) / p.stride, p.Ho - 1);
+            int b_lo = w + p.pad - p.k + 1; b_lo = b_lo <= 0 ? 0 : (b_lo + p.stride - 1) / p.stride;
+            const int b_hi = min((w + p.pad) / p.stride, p.Wo - 1);
+            for (int to = t_lo; to <= t_hi; ++to)
+                for (int ho = a_lo; ho <= a_hi; ++ho)
+                    for (int wo = b_lo; wo <= b_hi; ++wo) {
+                        const int me = ((ts - (to * p.stride_t - p.pad_t)) * p.k + (h - (ho * p.stride - p.pad))) * p.k +
+                                       (w - (wo * p.stride - p.pad));
+                        const int64_t no = clip * p.To + to;
+                        if (p.idx[((no * p.C + c) * p.Ho + ho) * p.Wo + wo] == me)
+                            g += p.y[no * p.y_nstride + ((int64_t)c * p.Ho + ho) * p.Wo + wo];
+                    }
+        }
+        p.gx[ns * p.gx_nstride + ((int64_t)c * p.Hs + h) * p.Ws + w] = g;
+    }
+}
+
+int k_pool3d_fwd(const I2VPoolParams& p, i2v_stream_t s) {
+    if (p.kt * p.k * p.k > 256) return pool_fail("video max-pool window larger than 256 taps");
+    hipLaunchKernelGGL(pool3d_fwd_kernel, dim3(stream_grid((int64_t)p.N * p.C * p.Ho * p.Wo, 256)), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("pool3d_fwd"); return 0;
+}
+int k_pool3d_bwd(const I2VPoolParams& p, i2v_stream_t s) {
+    hipLaunchKernelGGL(pool3d_bwd_kernel, dim3(stream_grid((int64_t)(p.N / p.To) * p.Ts * p.C * p.Hs * p.Ws, 256)), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("pool3d_bwd"); return 0;
+}
+
 int k_avgpool_fwd(const I2VPoolParams& p, i2v_stream_t s) {
     hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(stream_grid((int64_t)p.N * p.C * p.Ho * p.Wo, 256)), dim3(256), 0, (hipStream_t)s, p);
     LAUNCH_CHECK("avgpool_fwd"); return 0;
@@ -855,6 +942,80 @@ int k_std_grad(const I2VStdParams& p, i2v_stream_t s) {
 }
 
 // =============================================================================================
+// ILAF loss (image_attacks.py:579-611) over one hooked tensor: whole-tensor norms, so reduce -> finish -> grad
+// =============================================================================================
+__global__ void __launch_bounds__(256) ilaf_reduce_kernel(const I2VIlafParams p) {
+    const int blk = blockIdx.x, n = blockIdx.y;
+    const int64_t chunk = (p.D + p.nblk - 1) / p.nblk;
+    const int64_t lo = blk * chunk, hi = (lo + chunk < p.D) ? lo + chunk : p.D;
+    const float* a = p.a + (int64_t)n * p.a_nstride;
+    const float* o = p.ori + (int64_t)n * p.D;
+    const float* a0 = p.adv0 + (int64_t)n * p.D;
+    double dd = 0, dq = 0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const float ov = o[i];
+        const double d = (double)__fsub_rn(a[i], ov), d0 = (double)__fsub_rn(a0[i], ov);    // fp32 differences, as torch
+        dd += d * d; dq += d * d0;
+    }
+    __shared__ double red[2][4];
+    dd = wave_sum_d(dd); dq = wave_sum_d(dq);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = dd; red[1][threadIdx.x >> 6] = dq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* out = p.partial + ((int64_t)n * p.nblk + blk) * 2;
+        out[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        out[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+__global__ void __launch_bounds__(256) ilaf_finish_kernel(const I2VIlafParams p) {
+    __shared__ double red[2][4];
+    double s = 0, q = 0;
+    const int np = p.N * p.nblk;
+    for (int i = threadIdx.x; i < np; i += 256) { s += p.partial[2 * i]; q += p.partial[2 * i + 1]; }
+    s = wave_sum_d(s); q = wave_sum_d(q);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        p.sums[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        p.sums[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// loss = -(0.5 s/n0 + q/(n0 s)),  s = |d|, q = <d0, d>;   d loss/d a = -((0.5/s - q/s^3) d + d0/s) / n0
+__global__ void __launch_bounds__(256) ilaf_grad_kernel(const I2VIlafParams p) {
+    const int n = blockIdx.y;
+    const double s = sqrt(p.sums[0]), q = p.sums[1], n0 = p.init_norm;
+    if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) p.loss_out[0] = (float)(-(0.5 * s / n0 + q / (n0 * s)));
+    const double cd = -(0.5 / s - q / (s * s * s)) / n0, c0 = -1.0 / (s * n0);
+    const float* a = p.a + (int64_t)n * p.a_nstride;
+    const float* o = p.ori + (int64_t)n * p.D;
+    const float* a0 = p.adv0 + (int64_t)n * p.D;
+    float* g = p.grad + (int64_t)n * p.grad_nstride;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < p.D; i += (int64_t)gridDim.x * 256) {
+        const float av = a[i], ov = o[i];
+        float v = (float)(cd * (double)__fsub_rn(av, ov) + c0 * (double)__fsub_rn(a0[i], ov));
+        if (p.mask_relu && !(av > 0.f)) v = 0.f;
+        g[i] = p.accumulate ? g[i] + v : v;
+    }
+}
+
+int k_ilaf_reduce(const I2VIlafParams& p, i2v_stream_t s) {
+    hipLaunchKernelGGL(ilaf_reduce_kernel, dim3(p.nblk, p.N), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("ilaf_reduce");
+    hipLaunchKernelGGL(ilaf_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("ilaf_finish");
+    return 0;
+}
+
+int k_ilaf_grad(const I2VIlafParams& p, i2v_stream_t s) {
+    int gblk = (int)((p.D + 2047) / 2048); if (gblk > 64) gblk = 64;
+    hipLaunchKernelGGL(ilaf_grad_kernel, dim3(gblk, p.N), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("ilaf_grad");
+    return 0;
+}
+
+// =============================================================================================
 // frame flatten + un-normalise, compose, Adam (+ compose backward), sign steps, AENS weights
 // =============================================================================================
 // decoded uint8 frames (b, t, h, w, 3) -> normalised clip (b, 3, t, h, w): ClipToTensor (/255) + Normalize
@@ -939,6 +1100,19 @@ __global__ void sign_delta_kernel(float* __restrict__ delta, const float* __rest
     }
 }
 
+// ILAF update from the gradient w.r.t. the composed frames: the compose backward only gates (inclusive clamp
+// masks) and scales by 1/std > 0, so sign(d cost / d delta) = pass ? sign(gx) : 0   (image_attacks.py:589-617)
+__global__ void sign_delta_gx_kernel(float* __restrict__ delta, const float* __restrict__ gx, const float* __restrict__ u,
+                                     int64_t n, float eps, float step) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = delta[i];
+        const float s = u[i] + fminf(fmaxf(d, -eps), eps);
+        const bool pass = d >= -eps && d <= eps && s >= 0.f && s <= 1.f;
+        const float g = pass ? gx[i] : 0.f;
+        delta[i] = __fsub_rn(d, __fmul_rn(step, g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f)));
+    }
+}
+
 __global__ void aens_coeffs_kernel(const float* prev, float* coeffs, float momentum, int L) {
     // one wave: softmax(softmax(prev) + momentum*coeffs)
     const int l = threadIdx.x;
@@ -993,6 +1167,10 @@ int k_sign_bim(float* adv, const float* u, const float* grad, int64_t n, int64_t
 int k_sign_delta(float* delta, const float* grad, int64_t n, float step, i2v_stream_t s) {
     hipLaunchKernelGGL(sign_delta_kernel, dim3(stream_grid(n, 1024)), dim3(256), 0, (hipStream_t)s, delta, grad, n, step);
     LAUNCH_CHECK("sign_delta"); return 0;
+}
+int k_sign_delta_gx(float* delta, const float* gx, const float* u, int64_t n, float eps, float step, i2v_stream_t s) {
+    hipLaunchKernelGGL(sign_delta_gx_kernel, dim3(stream_grid(n, 1024)), dim3(256), 0, (hipStream_t)s, delta, gx, u, n, eps, step);
+    LAUNCH_CHECK("sign_delta_gx"); return 0;
 }
 int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t s) {
     hipLaunchKernelGGL(aens_coeffs_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, prev, coeffs, momentum, L);

@@ -10,7 +10,8 @@
 struct I2VKEntry {
     int32_t chan_off;      // element offset of the source channel plane (c * Hs * Ws)
     int32_t dh, dw;        // tap offset in source coordinates
-    int32_t valid;         // 0 for padding rows
+    int32_t valid;         // bit 0: 0 for padding rows; bits 1..31: signed temporal tap offset dt (source frames,
+                           // video networks only; the kernel adds dt * src_nstride to chan_off)
 };
 
 // Implicit-GEMM convolution, forward and input-gradient alike:
@@ -18,6 +19,12 @@ struct I2VKEntry {
 //   v = acc + shift[cd] + add0[..] + add1[..];  relu -> max(v,0);  mask -> (mask[..] > 0 ? v : 0)
 //   dst[n][cd][i*osh + oh0][j*osw + ow0] = v
 // p enumerates (n, i, j) over an N x Hg x Wg grid.
+//
+// Video (3-D) networks keep every activation FRAME-MAJOR: a (clips, C, T, H, W) tensor is stored as
+// clips*T frames of (C, H, W), so spatial and pointwise convolutions are the image kernels unchanged and a
+// temporal tap is a whole-frame offset.  Grid frame n = clip*Tg + tg reads source frame clip*Ts + tg*st + dt_k
+// (taps outside [0, Ts) contribute zeros) and writes destination frame clip*To + tg*ost + ot0.
+// Image networks have Tg = Ts = To = st = ost = 1, ot0 = 0.
 struct I2VConvParams {
     const float* src;  int64_t src_nstride;  int32_t Hs, Ws;
     int32_t Cs;             // channels of the source view
@@ -43,6 +50,8 @@ struct I2VConvParams {
     // stored to channel c at (i*osh + ph, j*osw + pw).  Used for the gradient w.r.t. the 3-channel image,
     // where 3 output channels alone would waste 29/32 of every MFMA.
     int32_t blk;
+    int32_t blkt;           // temporal classes in front of the blk*blk spatial ones (video stem); 1 otherwise
+    int32_t Tg, Ts, To, st, ost, ot0;   // frames per clip of grid / source / destination, temporal strides (see above)
     // 1: output is dense over the pixel grid (osh=osw=1, Hg x Wg == Ho x Wo, plane % 4 == 0, every
     // plane 16-byte aligned, plain addends): the epilogue may use 16-byte accesses along W
     int32_t vec_epilogue;
@@ -55,6 +64,8 @@ struct I2VPoolParams {
     float* gx;         int64_t gx_nstride;                           // bwd only
     uint8_t* idx;      // [N][C][Ho][Wo] window-relative arg-max (r*k+s), written by fwd, read by bwd
     int32_t N, k, stride, pad, mask_relu;
+    // video pooling (k_pool3d_*): window kt x k x k over frame-major clips; N counts OUTPUT frames (clips*To)
+    int32_t kt, stride_t, pad_t, Ts, To;
 };   // average pooling reuses it: fwd x -> y, bwd y (upstream gradient) -> gx
 
 // out = (a0 + a1 + a2) gated by (mask > 0); planes of HW elements, C channels, N frames
@@ -73,6 +84,20 @@ struct I2VCosParams {
     float* cos_out;                          // [N]
     float* grad;       int64_t grad_nstride;
     const float* coef_dev; int32_t coef_index; float coef_host;
+    int32_t mask_relu, accumulate;
+};
+
+// ILAF loss over a whole hooked tensor (image_attacks.py:579-611): d = a - ori, d0 = adv0 - ori,
+//   loss = -(0.5 * |d| / |d0| + <d0/|d0|, d/|d|>);  sums = (sum d*d, sum d*d0) in double
+struct I2VIlafParams {
+    const float* a;    int64_t a_nstride;
+    const float* ori;  const float* adv0;    // dense [N][D] copies of the clean / initial adversarial features
+    int64_t D;         int32_t N;
+    double* partial;   int32_t nblk;         // [N*nblk][2]
+    double* sums;                            // [2]
+    double init_norm;                        // |d0|
+    float* loss_out;                         // [1]
+    float* grad;       int64_t grad_nstride;
     int32_t mask_relu, accumulate;
 };
 

@@ -90,6 +90,10 @@ class Engine:
         _lib.check(self.capi, self.capi.i2v_sign_step_f32(_ptr(adv), _ptr(u), _ptr(grad), adv.numel(), chan_stride,
                                                           step, eps, self.stream()))
 
+    def sign_step_delta_gx(self, delta, gx, u, eps, step):
+        _lib.check(self.capi, self.capi.i2v_sign_step_delta_gx_f32(_ptr(delta), _ptr(gx), _ptr(u), delta.numel(), eps, step,
+                                                                   self.stream()))
+
     def sign_step_delta(self, delta, grad, step):
         _lib.check(self.capi, self.capi.i2v_sign_step_delta_f32(_ptr(delta), _ptr(grad), delta.numel(), step, self.stream()))
 
@@ -102,7 +106,7 @@ class Engine:
 
 
 class HookInfo:
-    __slots__ = ("act", "act_stride", "grad", "grad_stride", "D", "post_relu", "shape")
+    __slots__ = ("act", "act_stride", "grad", "grad_stride", "D", "post_relu", "shape", "T")
 
 
 class Net:
@@ -127,7 +131,10 @@ class Net:
             ts = g.tensors[t]
             if ts.buf not in self.buf_id:
                 out = C.c_int()
-                _lib.check(capi, capi.i2v_net_add_buffer(h, self.id, g.buffers[ts.buf], ts.H, ts.W, C.byref(out)))
+                if g.video:
+                    _lib.check(capi, capi.i2v_net_add_buffer3d(h, self.id, g.buffers[ts.buf], ts.T, ts.H, ts.W, C.byref(out)))
+                else:
+                    _lib.check(capi, capi.i2v_net_add_buffer(h, self.id, g.buffers[ts.buf], ts.H, ts.W, C.byref(out)))
                 self.buf_id[ts.buf] = out.value
             out = C.c_int()
             _lib.check(capi, capi.i2v_net_add_tensor(h, self.id, self.buf_id[ts.buf], ts.c_off, ts.C,
@@ -139,6 +146,12 @@ class Net:
                 w = sd[nd.weight].float().contiguous()
                 scale, shift = fold_affine(nd, sd)
                 scale, shift = scale.contiguous(), shift.contiguous()
+                if g.video:
+                    d = _lib.Conv3dDesc(self.ten_id[nd.src], self.ten_id[nd.dst], nd.cin, nd.cout, nd.kt, nd.kh, nd.kw,
+                                        nd.stride_t, nd.stride, nd.pad_t, nd.pad, nd.dil_t, 1 if nd.relu else 0,
+                                        -1 if nd.residual is None else self.ten_id[nd.residual])
+                    _lib.check(capi, capi.i2v_net_add_conv3d(h, self.id, C.byref(d), _ptr(w), _ptr(scale), _ptr(shift)))
+                    continue
                 d = _lib.ConvDesc(self.ten_id[nd.src], self.ten_id[nd.dst], nd.cin, nd.cout, nd.kh, nd.kw,
                                   nd.stride, nd.pad, 1 if nd.relu else 0,
                                   -1 if nd.residual is None else self.ten_id[nd.residual])
@@ -149,6 +162,9 @@ class Net:
                                                                   _ptr(ps), _ptr(pt)))
                 else:
                     _lib.check(capi, capi.i2v_net_add_conv(h, self.id, C.byref(d), _ptr(w), _ptr(scale), _ptr(shift)))
+            elif g.video:
+                d = _lib.Pool3dDesc(self.ten_id[nd.src], self.ten_id[nd.dst], nd.kt, nd.k, nd.stride_t, nd.stride, nd.pad_t, nd.pad)
+                _lib.check(capi, capi.i2v_net_add_maxpool3d(h, self.id, C.byref(d)))
             else:
                 d = _lib.PoolDesc(self.ten_id[nd.src], self.ten_id[nd.dst], nd.k, nd.stride, nd.pad)
                 add = capi.i2v_net_add_avgpool if nd.op == "avgpool" else capi.i2v_net_add_maxpool
@@ -168,6 +184,7 @@ class Net:
         hi.D, hi.post_relu = D.value, pr.value
         ts = self.graph.tensors[self.hook_tensors[i]]
         hi.shape = (ts.C, ts.H, ts.W)
+        hi.T = ts.T                     # frames per clip at the hook (video backbones)
         return hi
 
     def close(self):
@@ -222,6 +239,27 @@ class Net:
         _lib.check(capi, capi.i2v_std_grad_f32(
             C.c_void_p(hi.act), hi.act_stride, hi.D, frames, total, hi.post_relu, 0, C.c_void_p(std_out.data_ptr()),
             C.c_void_p(hi.grad), hi.grad_stride, C.c_void_p(scratch.data_ptr()), self.eng.stream()))
+
+    def hook_frames(self, i: int, in_frames: int) -> int:
+        """Frames hook i holds when `in_frames` input frames were run (video backbones change the clip length)."""
+        return in_frames // self.graph.tensors[self.graph.input].T * self.hooks[i].T
+
+    def ilaf_reduce(self, i: int, ori: torch.Tensor, adv0: torch.Tensor, scratch: torch.Tensor, frames: int, act=None):
+        """(sum d*d, sum d*d0) of hook i against the dense clean / initial-adversarial feature copies, left as two
+        doubles at the start of `scratch`.  `act` overrides the activation (used once to measure |d0|)."""
+        hi = self.hooks[i]
+        capi = self.eng.capi
+        a, a_s = (C.c_void_p(hi.act), hi.act_stride) if act is None else (_ptr(act), hi.D)
+        _lib.check(capi, capi.i2v_ilaf_reduce_f32(a, a_s, _ptr(ori), _ptr(adv0), hi.D, frames,
+                                                  C.c_void_p(scratch.data_ptr()), self.eng.stream()))
+
+    def ilaf_grad(self, i: int, ori, adv0, init_norm: float, loss_out: torch.Tensor, scratch: torch.Tensor, frames: int):
+        hi = self.hooks[i]
+        capi = self.eng.capi
+        _lib.check(capi, capi.i2v_ilaf_grad_f32(C.c_void_p(hi.act), hi.act_stride, _ptr(ori), _ptr(adv0), hi.D, frames,
+                                                init_norm, hi.post_relu, 0, C.c_void_p(loss_out.data_ptr()),
+                                                C.c_void_p(hi.grad), hi.grad_stride, C.c_void_p(scratch.data_ptr()),
+                                                self.eng.stream()))
 
     def scratch_bytes(self, frames: int) -> int:
         return max(self.eng.capi.i2v_cossim_scratch_bytes(hi.D, frames) for hi in self.hooks)

@@ -32,6 +32,7 @@ class TensorSpec:
     c_off: int          # channel offset inside the buffer
     post_relu: bool     # values are outputs of a ReLU (gradient mask = value > 0)
     name: str = ""
+    T: int = 1          # frames per clip (video backbones; 1 for image backbones)
 
 
 @dataclass
@@ -51,6 +52,11 @@ class ConvNode:
     residual: Optional[int] = None   # tensor added before the ReLU (Bottleneck identity)
     pre_bn: Optional[str] = None     # DenseNet pre-activation: relu(BatchNorm(x)) applied to the conv INPUT
     op: str = "conv"
+    # video backbones: temporal extent of the kernel (output frame t reads input frames t*stride_t - pad_t + q*dil_t)
+    kt: int = 1
+    stride_t: int = 1
+    pad_t: int = 0
+    dil_t: int = 1
 
 
 @dataclass
@@ -62,6 +68,9 @@ class PoolNode:
     pad: int
     ceil_mode: bool
     op: str = "maxpool"
+    kt: int = 1
+    stride_t: int = 1
+    pad_t: int = 0
 
 
 @dataclass
@@ -73,16 +82,17 @@ class Graph:
     nodes: list = field(default_factory=list)
     hooks: Dict[int, int] = field(default_factory=dict)       # depth (1..4) -> tensor id
     input: int = 0
+    video: bool = False                                       # 3-D backbone: conv weights are (cout,cin,kt,kh,kw)
 
     # -- construction helpers -------------------------------------------------
     def new_buffer(self, C: int) -> int:
         self.buffers.append(C)
         return len(self.buffers) - 1
 
-    def new_tensor(self, C, H, W, post_relu, name="", buf=None, c_off=0) -> int:
+    def new_tensor(self, C, H, W, post_relu, name="", buf=None, c_off=0, T=1) -> int:
         if buf is None:
             buf = self.new_buffer(C)
-        self.tensors.append(TensorSpec(C, H, W, buf, c_off, post_relu, name))
+        self.tensors.append(TensorSpec(C, H, W, buf, c_off, post_relu, name, T))
         return len(self.tensors) - 1
 
     def conv(self, src, cout, k, stride, pad, weight, bias=None, bn=None, relu=True,
@@ -114,6 +124,27 @@ class Graph:
     def avgpool(self, src, k, stride, name="", dst_buf=None, dst_c_off=0) -> int:
         return self.maxpool(src, k, stride, 0, False, name, dst_buf, dst_c_off, op="avgpool")
 
+    def conv3d(self, src, cout, k, stride, pad, weight, bn=None, relu=True, residual=None, name="",
+               dst_buf=None, dst_c_off=0, dil_t=1) -> int:
+        """k / stride / pad are (temporal, spatial) pairs, as in `nn.Conv3d((kt,k,k), (st,s,s), (pt,p,p))`."""
+        (kt, ks), (st, ss), (pt, ps) = k, stride, pad
+        s = self.tensors[src]
+        To = (s.T + 2 * pt - dil_t * (kt - 1) - 1) // st + 1
+        Ho = (s.H + 2 * ps - ks) // ss + 1
+        Wo = (s.W + 2 * ps - ks) // ss + 1
+        dst = self.new_tensor(cout, Ho, Wo, relu, name, dst_buf, dst_c_off, T=To)
+        self.nodes.append(ConvNode(src, dst, s.C, cout, ks, ks, ss, ps, weight, None, bn, relu, residual, None,
+                                   "conv", kt, st, pt, dil_t))
+        return dst
+
+    def maxpool3d(self, src, k, stride, pad=(0, 0), name="") -> int:
+        (kt, ks), (st, ss), (pt, ps) = k, stride, pad
+        s = self.tensors[src]
+        dst = self.new_tensor(s.C, (s.H + 2 * ps - ks) // ss + 1, (s.W + 2 * ps - ks) // ss + 1, False, name,
+                              T=(s.T + 2 * pt - kt) // st + 1)
+        self.nodes.append(PoolNode(src, dst, ks, ss, ps, False, "maxpool", kt, st, pt))
+        return dst
+
     # -- analysis -------------------------------------------------------------
     def truncated(self, hook_tensors: List[int]) -> "Graph":
         """Copy of the graph holding only the nodes some hook tensor depends on."""
@@ -131,15 +162,16 @@ class Graph:
                 if getattr(nd, "residual", None) is not None:
                     needed.add(nd.residual)
         g = Graph(self.arch, self.in_hw, self.tensors, self.buffers,
-                  [n for n, k in zip(self.nodes, keep) if k], dict(self.hooks), self.input)
+                  [n for n, k in zip(self.nodes, keep) if k], dict(self.hooks), self.input, self.video)
         return g
 
     def macs_per_frame(self) -> int:
+        """Multiply-adds of one forward pass per input frame (image backbones) / per input CLIP (video)."""
         tot = 0
         for nd in self.nodes:
             if nd.op == "conv":
                 d = self.tensors[nd.dst]
-                tot += d.H * d.W * nd.cout * nd.cin * nd.kh * nd.kw
+                tot += d.T * d.H * d.W * nd.cout * nd.cin * nd.kt * nd.kh * nd.kw
         return tot
 
     def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
@@ -148,7 +180,7 @@ class Graph:
         for nd in self.nodes:
             if nd.op != "conv":
                 continue
-            out[nd.weight] = (nd.cout, nd.cin, nd.kh, nd.kw)
+            out[nd.weight] = (nd.cout, nd.cin, nd.kt, nd.kh, nd.kw) if self.video else (nd.cout, nd.cin, nd.kh, nd.kw)
             if nd.bias:
                 out[nd.bias] = (nd.cout,)
             if nd.bn:
@@ -328,6 +360,127 @@ def densenet(growth=32, block_config=(6, 12, 24, 16), init_features=64, bn_size=
             C //= 2
             pending_pool = ("avg", t)
     return g
+
+
+# ---------------------------------------------------------------------------
+# Video backbones: the white-box models ILAF fine-tunes against (`image_attacks.py:513-519`).
+# The reference takes them from gluoncv 0.10.4 (`image_fine_tune_attack.py:63`, configs `utils.py:9-14`), which is
+# not vendored and not installed; the graphs below restate the PUBLIC architectures (I3D: Carreira & Zisserman /
+# Wang et al. "3x1x1" inflation; SlowFast: Feichtenhofer et al.) up to the hooked stage.  Parity with gluoncv's
+# exact module layout and checkpoints is therefore UNPINNED; what is pinned is the arithmetic of every node
+# against `torch.nn.functional.conv3d / max_pool3d` (oracle/video_models.py).  Not built: the non-local blocks of
+# the `i3d_nl5_*` configs and TPN.
+# ---------------------------------------------------------------------------
+def i3d_resnet(layers=(3, 4, 6, 3), width=64, in_thw=(32, 224, 224), arch="i3d_resnet50",
+               inflate=((1, 1, 1), (1, 0, 1, 0), (1, 0, 1, 0, 1, 0), (0, 1, 0))) -> Graph:
+    """Inflated Bottleneck ResNet: stem 5x7x7 / (2,2,2), max-pool 1x3x3 / (2,2,2), pool2 2x1x1 after the first
+    stage, `inflate[stage][block] == 1` turns that block's first 1x1x1 convolution into 3x1x1.  `hooks[d]` is the
+    output of stage d; the reference hooks `res_layers._modules['1']`, i.e. d = 2 (`image_attacks.py:514`)."""
+    T, H, W = in_thw
+    g = Graph(arch, (H, W), video=True)
+    x = g.new_tensor(3, H, W, False, "input", T=T)
+    g.input = x
+    x = g.conv3d(x, width, (5, 7), (2, 2), (2, 3), "conv1.weight", bn="bn1", name="stem")
+    x = g.maxpool3d(x, (1, 3), (2, 2), (0, 1), name="maxpool")
+    inplanes = width
+    for li, nblocks in enumerate(layers):
+        planes = width * (2 ** li)
+        for b in range(nblocks):
+            stride = 2 if (b == 0 and li > 0) else 1
+            p = f"res_layers.{li}.{b}"
+            infl = inflate[li][b % len(inflate[li])] if li < len(inflate) else 0
+            a = g.conv3d(x, planes, (3, 1) if infl else (1, 1), (1, 1), (1, 0) if infl else (0, 0),
+                         f"{p}.conv1.weight", bn=f"{p}.bn1", name=f"{p}.conv1")
+            a = g.conv3d(a, planes, (1, 3), (1, stride), (0, 1), f"{p}.conv2.weight", bn=f"{p}.bn2", name=f"{p}.conv2")
+            if stride != 1 or inplanes != planes * 4:
+                idt = g.conv3d(x, planes * 4, (1, 1), (1, stride), (0, 0), f"{p}.downsample.0.weight",
+                               bn=f"{p}.downsample.1", relu=False, name=f"{p}.downsample")
+            else:
+                idt = x
+            x = g.conv3d(a, planes * 4, (1, 1), (1, 1), (0, 0), f"{p}.conv3.weight", bn=f"{p}.bn3", residual=idt,
+                         name=f"{p}.out")
+            inplanes = planes * 4
+        g.hooks[li + 1] = x
+        if li == 0:
+            x = g.maxpool3d(x, (2, 1), (2, 1), (0, 0), name="pool2")
+    return g
+
+
+def slowfast_res2(width=64, in_thw=(32, 224, 224), arch="slowfast_resnet50", slow_stride=8, fast_stride=1,
+                  beta_inv=8, fusion_ratio=2, fusion_kernel=5, blocks=3) -> Graph:
+    """SlowFast up to its `res2` stages, the two tensors the reference hooks (`image_attacks.py:515-516`):
+    hooks[1] = slow_res2, hooks[2] = fast_res2, in the order their forward hooks fire (the fast pathway runs first).
+    The pathway inputs `x[:, :, ::stride]` are expressed as temporal stride / dilation of the stem convolutions,
+    so both stems read the same frame tensor."""
+    T, H, W = in_thw
+    alpha = slow_stride // fast_stride
+    fw = width // beta_inv
+    g = Graph(arch, (H, W), video=True)
+    x = g.new_tensor(3, H, W, False, "input", T=T)
+    g.input = x
+    # fast pathway: conv 5x7x7 over every `fast_stride`-th frame
+    f = g.conv3d(x, fw, (5, 7), (fast_stride, 2), (2 * fast_stride, 3), "fast_conv1.weight", bn="fast_bn1",
+                 name="fast_stem", dil_t=fast_stride)
+    f = g.maxpool3d(f, (1, 3), (1, 2), (0, 1), name="fast_maxpool")
+    # slow pathway: conv 1x7x7 over every `slow_stride`-th frame, concatenated with the lateral connection
+    ft = g.tensors[f]
+    cat = g.new_buffer(width + fw * fusion_ratio)
+    s = g.conv3d(x, width, (1, 7), (slow_stride, 2), (0, 3), "slow_conv1.weight", bn="slow_bn1", name="slow_stem")
+    st = g.tensors[s]
+    sp_t = g.new_tensor(width, ft.H, ft.W, False, "slow_maxpool", buf=cat, c_off=0, T=st.T)
+    g.nodes.append(PoolNode(s, sp_t, 3, 2, 1, False, "maxpool", 1, 1, 0))
+    lat_t = g.new_tensor(fw * fusion_ratio, ft.H, ft.W, True, "lateral_p1", buf=cat, c_off=width, T=st.T)
+    g.nodes.append(ConvNode(f, lat_t, fw, fw * fusion_ratio, 1, 1, 1, 0, "lateral_p1.0.weight", None, "lateral_p1.1",
+                            True, None, None, "conv", fusion_kernel, alpha, fusion_kernel // 2, 1))
+    assert (ft.T + 2 * (fusion_kernel // 2) - fusion_kernel) // alpha + 1 == st.T, "pathway frame counts disagree"
+    xs = g.new_tensor(width + fw * fusion_ratio, ft.H, ft.W, False, "slow_cat", buf=cat, c_off=0, T=st.T)
+
+    def stage(x, inplanes, planes, prefix, head_t):
+        for b in range(blocks):
+            p = f"{prefix}.{b}"
+            a = g.conv3d(x, planes, (head_t, 1), (1, 1), (head_t // 2, 0), f"{p}.conv1.weight", bn=f"{p}.bn1", name=f"{p}.conv1")
+            a = g.conv3d(a, planes, (1, 3), (1, 1), (0, 1), f"{p}.conv2.weight", bn=f"{p}.bn2", name=f"{p}.conv2")
+            if inplanes != planes * 4:
+                idt = g.conv3d(x, planes * 4, (1, 1), (1, 1), (0, 0), f"{p}.downsample.0.weight",
+                               bn=f"{p}.downsample.1", relu=False, name=f"{p}.downsample")
+            else:
+                idt = x
+            x = g.conv3d(a, planes * 4, (1, 1), (1, 1), (0, 0), f"{p}.conv3.weight", bn=f"{p}.bn3", residual=idt,
+                         name=f"{p}.out")
+            inplanes = planes * 4
+        return x
+    fr = stage(f, fw, fw, "fast_res2", 3)
+    sr = stage(xs, width + fw * fusion_ratio, width, "slow_res2", 1)
+    g.hooks[1] = fr
+    g.hooks[2] = sr
+    return g
+
+
+def build_video(model_type: str, in_thw=(32, 224, 224)) -> Graph:
+    """`model_type` follows `image_fine_tune_attack.py:53` / `utils.py:9-14`."""
+    if model_type == "i3d_resnet50":
+        return i3d_resnet((3, 4, 6, 3), 64, in_thw, "i3d_resnet50")
+    if model_type == "i3d_resnet101":
+        return i3d_resnet((3, 4, 23, 3), 64, in_thw, "i3d_resnet101")
+    if model_type == "slowfast_resnet50":
+        return slowfast_res2(64, in_thw, "slowfast_resnet50")
+    if model_type == "slowfast_resnet101":          # res2 is identical for the 50- and 101-layer variants
+        return slowfast_res2(64, in_thw, "slowfast_resnet101")
+    raise KeyError(f"video backbone {model_type!r} is not built (TPN and the non-local i3d_nl5 blocks are out of scope)")
+
+
+def build_video_tiny(model_type: str, in_thw=(8, 32, 32)) -> Graph:
+    if "i3d" in model_type:
+        return i3d_resnet((2, 2, 1, 1), 8, in_thw, "i3d_tiny", inflate=((1, 1), (1, 0), (1,), (0,)))
+    return slowfast_res2(16, in_thw, "slowfast_tiny", slow_stride=4, fast_stride=1, beta_inv=4, blocks=2)
+
+
+def video_hooks(g: Graph, model_type: str) -> List[int]:
+    """Hooked tensors (`image_attacks.py:513-519`).  ILAF's loss is a plain sum over the hooked layers, each paired
+    with its own clean feature, so the order is immaterial."""
+    if "i3d" in model_type:
+        return [g.hooks[2]]
+    return [g.hooks[1], g.hooks[2]]
 
 
 # ---------------------------------------------------------------------------

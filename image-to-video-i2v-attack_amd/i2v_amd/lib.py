@@ -21,6 +21,16 @@ class PoolDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("src", "dst", "k", "stride", "pad")]
 
 
+class Conv3dDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("src", "dst", "cin", "cout", "kt", "kh", "kw", "stride_t", "stride", "pad_t", "pad", "dil_t",
+                 "relu", "residual")]
+
+
+class Pool3dDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("src", "dst", "kt", "k", "stride_t", "stride", "pad_t", "pad")]
+
+
 class I2VError(RuntimeError):
     pass
 
@@ -41,6 +51,10 @@ _PROTOS = {
     "i2v_net_add_maxpool": ([_P, _I, C.POINTER(PoolDesc)], _I),
     "i2v_net_add_conv_preact": ([_P, _I, C.POINTER(ConvDesc), _P, _P, _P, _P, _P], _I),
     "i2v_net_add_avgpool": ([_P, _I, C.POINTER(PoolDesc)], _I),
+    "i2v_net_add_buffer3d": ([_P, _I, _I, _I, _I, _I, C.POINTER(_I)], _I),
+    "i2v_net_add_conv3d": ([_P, _I, C.POINTER(Conv3dDesc), _P, _P, _P], _I),
+    "i2v_net_add_maxpool3d": ([_P, _I, C.POINTER(Pool3dDesc)], _I),
+    "i2v_net_tensor_frames": ([_P, _I, _I, C.POINTER(_I)], _I),
     "i2v_net_plan": ([_P, _I, C.POINTER(_I), _I, _I], _I),
     "i2v_net_workspace_bytes": ([_P, _I], C.c_size_t),
     "i2v_net_forward": ([_P, _I, _P, _I, _P], _I),
@@ -61,6 +75,9 @@ _PROTOS = {
     "i2v_adam_step_f32": ([_P, _P, _P, _P, _P, _L, _I, _F, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P], _I),
     "i2v_sign_step_f32": ([_P, _P, _P, _L, _L, _F, _F, _P], _I),
     "i2v_sign_step_delta_f32": ([_P, _P, _L, _F, _P], _I),
+    "i2v_sign_step_delta_gx_f32": ([_P, _P, _P, _L, _F, _F, _P], _I),
+    "i2v_ilaf_reduce_f32": ([_P, _L, _P, _P, _L, _I, _P, _P], _I),
+    "i2v_ilaf_grad_f32": ([_P, _L, _P, _P, _L, _I, C.c_double, _I, _I, _P, _P, _L, _P, _P], _I),
     "i2v_aens_coeffs_f32": ([_P, _P, _F, _I, _P], _I),
     "i2v_aens_reduce_f32": ([_P, _P, _I, _I, _P, _P, _P], _I),
 }

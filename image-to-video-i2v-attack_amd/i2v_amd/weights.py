@@ -31,9 +31,10 @@ def synthetic_state_dict(graph: Graph, seed: int = 0) -> Dict[str, torch.Tensor]
     for nd in graph.nodes:
         if nd.op != "conv":
             continue
-        fan_out = nd.cout * nd.kh * nd.kw
+        fan_out = nd.cout * nd.kt * nd.kh * nd.kw
         std = (2.0 / fan_out) ** 0.5
-        sd[nd.weight] = torch.randn(nd.cout, nd.cin, nd.kh, nd.kw, generator=_gen(seed, nd.weight)) * std
+        shape = (nd.cout, nd.cin, nd.kt, nd.kh, nd.kw) if graph.video else (nd.cout, nd.cin, nd.kh, nd.kw)
+        sd[nd.weight] = torch.randn(*shape, generator=_gen(seed, nd.weight)) * std
         if nd.bias:
             sd[nd.bias] = torch.randn(nd.cout, generator=_gen(seed, nd.bias)) * 0.05
         if nd.bn:

@@ -70,6 +70,31 @@ int i2v_net_add_conv_preact(i2v_handle h, int net, const i2v_conv_desc* d, const
                             const float* scale, const float* shift, const float* pre_scale,
                             const float* pre_shift);
 int i2v_net_add_avgpool(i2v_handle h, int net, const i2v_pool_desc* d);
+/* ---- video (3-D) backbones: the white-box model of ILAF (image_attacks.py:513-519,553-611) -------------
+ * A (clips, C, T, H, W) activation is held FRAME-MAJOR -- clips*T frames of (C, H, W) -- so the input is the
+ * same (b*f, 3, h, w) frame tensor the image path uses (i2v_frames_from_video_f32), spatial (1 x k x k) and
+ * pointwise convolutions ARE the image kernels, and a temporal tap is a whole-frame offset.  `T` is the number
+ * of frames per clip at that depth.  A network mixes these calls freely with the 2-D ones (2-D == T of the
+ * source, kt 1).  Frame counts passed to plan/forward are INPUT frames (a multiple of the input's T).
+ *   conv3d: weight host [cout][cin][kt][kh][kw]; output frame t reads input frames t*stride_t - pad_t + q*dil_t
+ *           (dil_t > 1 with stride_t == dil_t is a convolution over every dil_t-th input frame, SlowFast's
+ *           `x[:, :, ::stride]` pathway inputs). */
+typedef struct {
+    int32_t src, dst;
+    int32_t cin, cout, kt, kh, kw;
+    int32_t stride_t, stride, pad_t, pad, dil_t;
+    int32_t relu, residual;
+} i2v_conv3d_desc;
+typedef struct {
+    int32_t src, dst;
+    int32_t kt, k, stride_t, stride, pad_t, pad;
+} i2v_pool3d_desc;
+int i2v_net_add_buffer3d(i2v_handle h, int net, int C, int T, int H, int W, int* buf);
+int i2v_net_add_conv3d(i2v_handle h, int net, const i2v_conv3d_desc* d, const float* weight,
+                       const float* scale, const float* shift);
+int i2v_net_add_maxpool3d(i2v_handle h, int net, const i2v_pool3d_desc* d);
+/* Frames per clip of a tensor (1 for image networks). */
+int i2v_net_tensor_frames(i2v_handle h, int net, int tensor, int* T);
 /* Freeze the graph: pack weights for forward and input-gradient, plan both passes for up to
  * `max_frames` frames and allocate the arena.  `hook_tensors` are the hooked layer outputs in
  * the order the reference's forward hooks fire (image_attacks.py:281-283). */
@@ -152,6 +177,22 @@ int i2v_sign_step_f32(float* adv, const float* u, const float* grad, int64_t n, 
                       float step, float eps, void* stream);
 /* ILAF update `modifier -= step*sign(grad)` (image_attacks.py:617). */
 int i2v_sign_step_delta_f32(float* delta, const float* grad, int64_t n, float step, void* stream);
+/* The same from the gradient w.r.t. the COMPOSED frames (what i2v_net_backward produces): the compose
+ * backward only gates (inclusive clamp masks, image_attacks.py:589) and scales by 1/std > 0, so
+ * delta -= step * (pass ? sign(gx) : 0). */
+int i2v_sign_step_delta_gx_f32(float* delta, const float* gx, const float* u, int64_t n, float eps,
+                               float step, void* stream);
+/* ILAF loss over one hooked tensor and its gradient (image_attacks.py:595-611):
+ *   d = a - ori, d0 = adv0 - ori (fp32), s = |d|, n0 = |d0| over the WHOLE tensor (all frames),
+ *   loss = -(0.5*s/n0 + <d0/n0, d/s>),  grad (+)= d loss / d a  [gated by a>0 if mask_relu]
+ * `ori`/`adv0` are dense (frames, D) copies of the clean / initial adversarial features.  `reduce` leaves
+ * (sum d*d, sum d*d0) as two doubles at the start of `scratch` (so n0 = sqrt(first) when a == adv0);
+ * `grad` consumes them.  Scratch size as for the cosine kernel. */
+int i2v_ilaf_reduce_f32(const float* a, int64_t a_stride, const float* ori, const float* adv0, int64_t D,
+                        int frames, void* scratch, void* stream);
+int i2v_ilaf_grad_f32(const float* a, int64_t a_stride, const float* ori, const float* adv0, int64_t D,
+                      int frames, double init_norm, int mask_relu, int accumulate, float* loss_out,
+                      float* grad, int64_t grad_stride, void* scratch, void* stream);
 /* Adaptive ENS-I2V re-weighting `coeffs = softmax(softmax(prev) + momentum*coeffs)`
  * (TPAMI_attack.py:265), L <= 64, in place on device. */
 int i2v_aens_coeffs_f32(const float* prev, float* coeffs, float momentum, int L, void* stream);

@@ -1,0 +1,137 @@
+"""TEST INFRASTRUCTURE -- torch restatement of the video backbones ILAF hooks.
+
+The reference obtains I3D / SlowFast from gluoncv 0.10.4 (`/root/reference/image_fine_tune_attack.py:63`,
+configs `utils.py:9-14`); gluoncv is not vendored and not installed, so `i2v_amd.graphs.i3d_resnet` /
+`slowfast_res2` restate the public architectures and this file is their plain-PyTorch counterpart
+(`nn.Conv3d`, `nn.BatchNorm3d`, `nn.MaxPool3d`, autograd).  PARITY UNPINNED against gluoncv's own module
+layout; what IS pinned here is that the HIP engine computes exactly these modules (tests/test_video_*).
+
+The modules expose the attribute names the reference's `ILAF._find_target_layer` looks up
+(`image_attacks.py:513-519`): `res_layers._modules['1']` for I3D, `_modules['slow_res2'/'fast_res2']` for
+SlowFast, so the UNMODIFIED reference class runs on them (oracle/make_golden.py).  `state_dict()` keys are the
+graph IR's weight keys.
+"""
+import torch
+import torch.nn as nn
+
+
+class Bottleneck3d(nn.Module):
+    def __init__(self, inplanes, planes, stride=1, head_t=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv3d(inplanes, planes, (head_t, 1, 1), padding=(head_t // 2, 0, 0), bias=False)
+        self.bn1 = nn.BatchNorm3d(planes)
+        self.conv2 = nn.Conv3d(planes, planes, (1, 3, 3), stride=(1, stride, stride), padding=(0, 1, 1), bias=False)
+        self.bn2 = nn.BatchNorm3d(planes)
+        self.conv3 = nn.Conv3d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm3d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idt)
+
+
+def _stage(inplanes, planes, blocks, stride, head_t_of):
+    layers = []
+    for b in range(blocks):
+        s = stride if b == 0 else 1
+        ds = None
+        if s != 1 or inplanes != planes * 4:
+            ds = nn.Sequential(nn.Conv3d(inplanes, planes * 4, 1, stride=(1, s, s), bias=False), nn.BatchNorm3d(planes * 4))
+        layers.append(Bottleneck3d(inplanes, planes, s, head_t_of(b), ds))
+        inplanes = planes * 4
+    return nn.Sequential(*layers), inplanes
+
+
+class I3DResNet(nn.Module):
+    def __init__(self, layers=(3, 4, 6, 3), width=64, inflate=((1, 1, 1), (1, 0, 1, 0), (1, 0, 1, 0, 1, 0), (0, 1, 0))):
+        super().__init__()
+        self.conv1 = nn.Conv3d(3, width, (5, 7, 7), stride=(2, 2, 2), padding=(2, 3, 3), bias=False)
+        self.bn1 = nn.BatchNorm3d(width)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool3d((1, 3, 3), stride=(2, 2, 2), padding=(0, 1, 1))
+        self.pool2 = nn.MaxPool3d((2, 1, 1), stride=(2, 1, 1))
+        stages, inplanes = [], width
+        for li, nb in enumerate(layers):
+            infl = inflate[li]
+            st, inplanes = _stage(inplanes, width * 2 ** li, nb, 1 if li == 0 else 2,
+                                  lambda b, infl=infl: 3 if infl[b % len(infl)] else 1)
+            stages.append(st)
+        self.res_layers = nn.Sequential(*stages)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        for i, st in enumerate(self.res_layers):
+            x = st(x)
+            if i == 0:
+                x = self.pool2(x)
+        return x
+
+
+class SlowFastRes2(nn.Module):
+    """SlowFast stems + lateral connection + the two res2 stages (the part ILAF's hooks depend on)."""
+
+    def __init__(self, width=64, slow_stride=8, fast_stride=1, beta_inv=8, fusion_ratio=2, fusion_kernel=5, blocks=3):
+        super().__init__()
+        fw = width // beta_inv
+        self.slow_stride, self.fast_stride = slow_stride, fast_stride
+        self.fast_conv1 = nn.Conv3d(3, fw, (5, 7, 7), stride=(1, 2, 2), padding=(2, 3, 3), bias=False)
+        self.fast_bn1 = nn.BatchNorm3d(fw)
+        self.fast_maxpool = nn.MaxPool3d((1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+        self.slow_conv1 = nn.Conv3d(3, width, (1, 7, 7), stride=(1, 2, 2), padding=(0, 3, 3), bias=False)
+        self.slow_bn1 = nn.BatchNorm3d(width)
+        self.slow_maxpool = nn.MaxPool3d((1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+        self.relu = nn.ReLU(inplace=True)
+        alpha = slow_stride // fast_stride
+        self.lateral_p1 = nn.Sequential(
+            nn.Conv3d(fw, fw * fusion_ratio, (fusion_kernel, 1, 1), stride=(alpha, 1, 1), padding=(fusion_kernel // 2, 0, 0), bias=False),
+            nn.BatchNorm3d(fw * fusion_ratio), nn.ReLU(inplace=True))
+        self.fast_res2, _ = _stage(fw, fw, blocks, 1, lambda b: 3)
+        self.slow_res2, _ = _stage(width + fw * fusion_ratio, width, blocks, 1, lambda b: 1)
+
+    def forward(self, x):
+        fast_in, slow_in = x[:, :, ::self.fast_stride], x[:, :, ::self.slow_stride]
+        f = self.fast_maxpool(self.relu(self.fast_bn1(self.fast_conv1(fast_in))))
+        lat = self.lateral_p1(f)
+        fr = self.fast_res2(f)
+        s = self.slow_maxpool(self.relu(self.slow_bn1(self.slow_conv1(slow_in))))
+        sr = self.slow_res2(torch.cat([s, lat], dim=1))
+        return sr, fr
+
+
+def make(model_type: str, tiny: bool) -> nn.Module:
+    """Counterpart of `i2v_amd.graphs.build_video` / `build_video_tiny`."""
+    if "i3d" in model_type:
+        if tiny:
+            return I3DResNet((2, 2, 1, 1), 8, inflate=((1, 1), (1, 0), (1,), (0,)))
+        return I3DResNet((3, 4, 23, 3) if "101" in model_type else (3, 4, 6, 3))
+    if tiny:
+        return SlowFastRes2(16, slow_stride=4, fast_stride=1, beta_inv=4, blocks=2)
+    return SlowFastRes2()
+
+
+def load_weights(model: nn.Module, sd: dict) -> nn.Module:
+    """Load a graph-IR state_dict (only the stages the graph reaches carry keys; the rest keep their init)."""
+    own = model.state_dict()
+    for k, v in sd.items():
+        assert k in own and tuple(own[k].shape) == tuple(v.shape), (k, tuple(v.shape), tuple(own[k].shape) if k in own else None)
+        own[k] = v.clone()
+    model.load_state_dict(own)
+    return model.eval()
+
+
+def hook_modules(model: nn.Module, model_type: str):
+    """The modules the reference hooks (`image_attacks.py:513-519`), fast before slow to match `graphs.video_hooks`."""
+    if "i3d" in model_type:
+        return [model.res_layers._modules["1"]]
+    return [model._modules["fast_res2"], model._modules["slow_res2"]]
+
+
+def to_frames(t: torch.Tensor) -> torch.Tensor:
+    """(b, C, T, H, W) -> the engine's frame-major (b*T, C, H, W)."""
+    b, c, tt, h, w = t.shape
+    return t.permute(0, 2, 1, 3, 4).reshape(b * tt, c, h, w).contiguous()

@@ -38,7 +38,10 @@ int cos_nblk(int64_t D) { return (int)std::min<int64_t>(64, std::max<int64_t>(1,
 int k_conv_candidates(const I2VConvParams&, int* out) { out[0] = 0; return 1; }
 
 int k_conv(const I2VConvParams& p, i2v_stream_t) {
-    for (int n = 0; n < p.N; ++n)
+    for (int ng = 0; ng < p.N; ++ng) {
+        // grid frame (clip, tg) reads source frame clip*Ts + tg*st + dt and writes frame clip*To + tg*ost + ot0 (+ class)
+        const int clip = ng / p.Tg, tg = ng % p.Tg, t0 = tg * p.st;
+        const size_t nsrc = (size_t)clip * p.Ts + t0;
         for (int i = 0; i < p.Hg; ++i)
             for (int j = 0; j < p.Wg; ++j) {
                 int oh = i * p.osh + p.oh0, ow = j * p.osw + p.ow0;
@@ -47,17 +50,21 @@ int k_conv(const I2VConvParams& p, i2v_stream_t) {
                     float acc = 0.f;
                     for (int k = 0; k < p.Kpad; ++k) {
                         const I2VKEntry& e = p.ktab[k];
-                        if (!e.valid) continue;
+                        if (!(e.valid & 1)) continue;
+                        const int dt = e.valid >> 1;
                         int hs = i * p.sh + e.dh, ws = j * p.sw + e.dw;
-                        if (hs < 0 || hs >= p.Hs || ws < 0 || ws >= p.Ws) continue;
-                        float xv = p.src[(size_t)n * p.src_nstride + e.chan_off + (size_t)hs * p.Ws + ws];
+                        if (hs < 0 || hs >= p.Hs || ws < 0 || ws >= p.Ws || t0 + dt < 0 || t0 + dt >= p.Ts) continue;
+                        float xv = p.src[(int64_t)(nsrc + dt) * p.src_nstride + e.chan_off + (size_t)hs * p.Ws + ws];
                         if (p.pre_scale) { xv = xv * p.pre_scale[k] + p.pre_shift[k]; xv = xv > 0.f ? xv : 0.f; }
                         acc += p.wp[(size_t)k * p.Cdpad + cd] * xv;
                     }
                     if (p.blk > 1) {            // class-packed Cd (image gradient)
-                        int Creal = p.Cd / (p.blk * p.blk), cls = cd / Creal, c = cd % Creal;
+                        int Creal = p.Cd / (p.blkt * p.blk * p.blk), cls3 = cd / Creal, c = cd % Creal;
+                        int ct = cls3 / (p.blk * p.blk), cls = cls3 % (p.blk * p.blk);
                         int bh = i * p.osh + cls / p.blk + p.oh0, bw = j * p.osw + cls % p.blk + p.ow0;
-                        if (bh >= p.Ho || bw >= p.Wo) continue;
+                        int ot = tg * p.ost + p.ot0 + ct;
+                        if (bh >= p.Ho || bw >= p.Wo || ot >= p.To) continue;
+                        size_t n = (size_t)clip * p.To + ot;
                         size_t o = (size_t)c * p.Ho * p.Wo + (size_t)bh * p.Wo + bw;
                         float v = acc;
                         if (p.shift) v += p.shift[c];
@@ -67,6 +74,9 @@ int k_conv(const I2VConvParams& p, i2v_stream_t) {
                         p.dst[(size_t)n * p.dst_nstride + o] = v;
                         continue;
                     }
+                    const int ot = tg * p.ost + p.ot0;
+                    if (ot >= p.To) continue;
+                    const size_t n = (size_t)clip * p.To + ot;
                     size_t oidx = (size_t)cd * p.Ho * p.Wo + (size_t)oh * p.Wo + ow;
                     float v = acc;
                     if (p.gate_scale) {     // pre-activation gate: applies to THIS contribution only, before the adds
@@ -87,6 +97,7 @@ int k_conv(const I2VConvParams& p, i2v_stream_t) {
                     p.dst[(size_t)n * p.dst_nstride + oidx] = v;
                 }
             }
+    }
     return 0;
 }
 
@@ -126,6 +137,54 @@ int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t) {
                     g[h * p.Ws + w] += p.y[(size_t)n * p.y_nstride + ((size_t)c * p.Ho + ho) * p.Wo + wo];
                 }
             if (p.mask_relu) for (int i = 0; i < p.Hs * p.Ws; ++i) if (!(pl[i] > 0.f)) g[i] = 0.f;
+        }
+    return 0;
+}
+
+int k_pool3d_fwd(const I2VPoolParams& p, i2v_stream_t) {
+    for (int n = 0; n < p.N; ++n) {
+        const int clip = n / p.To, to = n % p.To;
+        for (int c = 0; c < p.C; ++c) for (int ho = 0; ho < p.Ho; ++ho) for (int wo = 0; wo < p.Wo; ++wo) {
+            int best = -1; float bv = 0.f;
+            for (int q = 0; q < p.kt; ++q) {
+                int ts = to * p.stride_t - p.pad_t + q; if (ts < 0 || ts >= p.Ts) continue;
+                const float* pl = p.x + ((size_t)clip * p.Ts + ts) * p.x_nstride + (size_t)c * p.Hs * p.Ws;
+                for (int r = 0; r < p.k; ++r) {
+                    int h = ho * p.stride - p.pad + r; if (h < 0 || h >= p.Hs) continue;
+                    for (int s = 0; s < p.k; ++s) {
+                        int w = wo * p.stride - p.pad + s; if (w < 0 || w >= p.Ws) continue;
+                        float v = pl[h * p.Ws + w];
+                        if (best < 0 || v > bv || v != v) { bv = v; best = (q * p.k + r) * p.k + s; }
+                    }
+                }
+            }
+            p.y[(size_t)n * p.y_nstride + ((size_t)c * p.Ho + ho) * p.Wo + wo] = bv;
+            p.idx[(((size_t)n * p.C + c) * p.Ho + ho) * p.Wo + wo] = (uint8_t)best;
+        }
+    }
+    return 0;
+}
+
+int k_pool3d_bwd(const I2VPoolParams& p, i2v_stream_t) {
+    const int clips = p.N / p.To;
+    for (int ns = 0; ns < clips * p.Ts; ++ns) for (int c = 0; c < p.C; ++c) {
+        float* g = p.gx + (size_t)ns * p.gx_nstride + (size_t)c * p.Hs * p.Ws;
+        for (int i = 0; i < p.Hs * p.Ws; ++i) g[i] = 0.f;
+    }
+    for (int n = 0; n < p.N; ++n) {
+        const int clip = n / p.To, to = n % p.To;
+        for (int c = 0; c < p.C; ++c) for (int ho = 0; ho < p.Ho; ++ho) for (int wo = 0; wo < p.Wo; ++wo) {
+            int code = p.idx[(((size_t)n * p.C + c) * p.Ho + ho) * p.Wo + wo];
+            int q = code / (p.k * p.k), r = code / p.k % p.k, s = code % p.k;
+            int ts = to * p.stride_t - p.pad_t + q, h = ho * p.stride - p.pad + r, w = wo * p.stride - p.pad + s;
+            p.gx[((size_t)clip * p.Ts + ts) * p.gx_nstride + ((size_t)c * p.Hs + h) * p.Ws + w] +=
+                p.y[(size_t)n * p.y_nstride + ((size_t)c * p.Ho + ho) * p.Wo + wo];
+        }
+    }
+    if (p.mask_relu)
+        for (int ns = 0; ns < clips * p.Ts; ++ns) for (int c = 0; c < p.C; ++c) for (int i = 0; i < p.Hs * p.Ws; ++i) {
+            size_t o = (size_t)c * p.Hs * p.Ws + i;
+            if (!(p.x[(size_t)ns * p.x_nstride + o] > 0.f)) p.gx[(size_t)ns * p.gx_nstride + o] = 0.f;
         }
     return 0;
 }
@@ -197,6 +256,36 @@ int k_std_grad(const I2VStdParams& p, i2v_stream_t) {
         const float* a = p.a + (size_t)n * p.a_nstride; float* g = p.grad + (size_t)n * p.grad_nstride;
         for (int64_t i = 0; i < p.D; ++i) {
             float v = (float)((a[i] - mu) / ((cnt - 1) * sd));
+            if (p.mask_relu && !(a[i] > 0.f)) v = 0.f;
+            g[i] = p.accumulate ? g[i] + v : v;
+        }
+    }
+    return 0;
+}
+
+int k_ilaf_reduce(const I2VIlafParams& p, i2v_stream_t) {
+    double dd = 0, dq = 0;
+    for (int n = 0; n < p.N; ++n) {
+        const float* a = p.a + (size_t)n * p.a_nstride; const float* o = p.ori + (size_t)n * p.D; const float* a0 = p.adv0 + (size_t)n * p.D;
+        for (int64_t i = 0; i < p.D; ++i) {
+            volatile float d = a[i] - o[i]; volatile float d0 = a0[i] - o[i];
+            dd += (double)d * d; dq += (double)d * d0;
+        }
+    }
+    p.sums[0] = dd; p.sums[1] = dq;
+    return 0;
+}
+
+int k_ilaf_grad(const I2VIlafParams& p, i2v_stream_t) {
+    const double s = sqrt(p.sums[0]), q = p.sums[1], n0 = p.init_norm;
+    p.loss_out[0] = (float)(-(0.5 * s / n0 + q / (n0 * s)));
+    const double cd = -(0.5 / s - q / (s * s * s)) / n0, c0 = -1.0 / (s * n0);
+    for (int n = 0; n < p.N; ++n) {
+        const float* a = p.a + (size_t)n * p.a_nstride; const float* o = p.ori + (size_t)n * p.D; const float* a0 = p.adv0 + (size_t)n * p.D;
+        float* g = p.grad + (size_t)n * p.grad_nstride;
+        for (int64_t i = 0; i < p.D; ++i) {
+            volatile float d = a[i] - o[i]; volatile float d0 = a0[i] - o[i];
+            float v = (float)(cd * (double)d + c0 * (double)d0);
             if (p.mask_relu && !(a[i] > 0.f)) v = 0.f;
             g[i] = p.accumulate ? g[i] + v : v;
         }
@@ -286,6 +375,17 @@ int k_sign_delta(float* delta, const float* grad, int64_t n, float step, i2v_str
     for (int64_t i = 0; i < n; ++i) {
         float g = grad[i];
         delta[i] -= step * (g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f));
+    }
+    return 0;
+}
+
+int k_sign_delta_gx(float* delta, const float* gx, const float* u, int64_t n, float eps, float step, i2v_stream_t) {
+    for (int64_t i = 0; i < n; ++i) {
+        float d = delta[i];
+        float s = u[i] + std::min(std::max(d, -eps), eps);
+        bool pass = d >= -eps && d <= eps && s >= 0.f && s <= 1.f;
+        float g = pass ? gx[i] : 0.f;
+        delta[i] = d - step * (g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f));
     }
     return 0;
 }

@@ -22,8 +22,8 @@ def write_hook_grads(net, feats, hg, N):
     i2v_cossim_fwd_bwd_f32 does on the device)."""
     for i, hi in enumerate(net.hooks):
         gate = (feats[i] > 0).to(hg[i].dtype) if hi.post_relu else torch.ones_like(feats[i])
-        flat = (hg[i] * gate).float().reshape(N, -1).contiguous()
-        for n in range(N):
+        flat = (hg[i] * gate).float().reshape(hg[i].shape[0], -1).contiguous()
+        for n in range(flat.shape[0]):
             ctypes.memmove(hi.grad + 4 * n * hi.grad_stride, flat[n].data_ptr(), 4 * hi.D)
 
 
