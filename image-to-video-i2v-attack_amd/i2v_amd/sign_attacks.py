@@ -1,16 +1,22 @@
 """White-box sign-step attacks (`/root/reference/base_attacks.py:236-340`) and ILAF's update
 (`image_attacks.py:498-629`).
 
-What is in scope here is the UPDATE RULE: un-normalise, `+ step*sign(g)`,
-project to +-eps, clamp to [0,1], re-normalise -- one fused HIP kernel (`i2v_sign_step_f32`).  The
-attacked VIDEO model (gluoncv I3D/SlowFast/TPN in the reference) is not part of this hot path: it
-is whatever differentiable torch module the caller passes, exactly as in the reference, and its
-forward/backward run in PyTorch.
+BIM / MI-FGSM / FGSM: the UPDATE RULE -- un-normalise, `+ step*sign(g)`, project to +-eps,
+clamp to [0,1], re-normalise -- is one fused HIP kernel (`i2v_sign_step_f32`); the attacked classifier is whatever
+differentiable torch module the caller passes, exactly as in the reference, and its cross-entropy gradient comes
+from PyTorch.
+
+ILAF (a18) has two paths.  Given an `i2v_amd.video.VideoModel` (I3D / SlowFast graph IR) the WHOLE loop runs in
+`libi2v_hip.so`: compose, 3-D forward to the hooked stage, ILAF loss + gradient, input gradient, masked sign step.
+Given any other torch module (the reference's calling convention; e.g. a gluoncv model the IR does not cover) the
+model runs in PyTorch and only the sign step is native.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
 from .attacks import get_engine
+from .video import VideoModel
 
 MEAN = [0.485, 0.456, 0.406]
 STD = [0.229, 0.224, 0.225]
@@ -122,9 +128,9 @@ class MIFGSM(BIM):
 
 class ILAF(object):
     """`image_attacks.py:498-629`: fine-tunes an existing adversarial clip along the feature
-    direction of a white-box VIDEO model.  The model, its hooks, the differentiable compose and the
-    loss stay in PyTorch (the 3-D backbones are gluoncv's, SURVEY.md 8(f) N2, and autograd has to see
-    the path from `modifier` to the features); the sign update runs in the library.
+    direction of a white-box VIDEO model.  `model` is a `VideoModel` (native path, `_native`) or a torch
+    module (then the model, its hooks, the differentiable compose and the loss stay in PyTorch and the sign
+    update runs in the library).
     The reference's return value applies reshape(b,f,c,h,w).permute(0,2,1,3,4) to a tensor that is
     already (b,c,f,h,w) (`:627-628`); that scramble is reproduced for drop-in fidelity."""
 
@@ -136,6 +142,9 @@ class ILAF(object):
         self.mean, self.std = MEAN, STD
         self._engine = engine
         self.activations = {"value": []}
+        self._net = self._net_key = None
+        if isinstance(model, VideoModel):
+            return                                      # native path: hooks are tensors of the graph IR
         layers = hook_layers if hook_layers is not None else self._find_target_layer()
         for layer in (layers if isinstance(layers, list) else [layers]):
             layer.register_forward_hook(lambda mod, inp, out: self.activations["value"].append(out))
@@ -156,7 +165,64 @@ class ILAF(object):
     def __call__(self, *a, **k):
         return self.forward(*a, **k)
 
+    def _native(self, videos, ori_videos, video_names):
+        """The whole of `image_attacks.py:534-629` behind the C ABI.  Activations are frame-major (b*T, C, H, W); the
+        loss only needs whole-tensor norms and a dot product, so no layout change is ever materialised."""
+        eng = self._engine or get_engine()
+        dev = eng.device
+        kw = dict(dtype=torch.float32, device=dev)
+        videos = videos.detach().to(**kw).contiguous()
+        ori = ori_videos.detach().to(**kw).contiguous()
+        b, c, f, h, w = videos.shape
+        N, eps = b * f, float(self.epsilon)
+        key = (f, h, w)
+        if self._net is None or self._net_key != key or self._net.max_frames < N:
+            if self._net is not None:
+                self._net.close()
+            g = self.model.graph_for((f, h, w))
+            self._net = eng.build_net(g, self.model.state_dict_for(g), self.model.hook_tensors(g), N)
+            self._net_key = key
+        net = self._net
+        L = len(net.hooks)
+        x, u_adv, u_ori = (torch.empty(N, 3, h, w, **kw) for _ in range(3))
+        eng.frames_from_video(ori, x, u_ori)                                     # :572 `_transform_video_ILAF(..,'back')`
+        net.forward(x)                                                          # :545-549 clean features
+        nf = [net.hook_frames(i, N) for i in range(L)]
+        ori_f = [net.save_hook(i, nf[i]) for i in range(L)]
+        eng.frames_from_video(videos, x, u_adv)
+        net.forward(x)                                                          # :555-559 features of the given adversarial clip
+        adv_f = [net.save_hook(i, nf[i]) for i in range(L)]
+        scratch = torch.empty((max(net.scratch_bytes(n) for n in nf) + 64) // 4, **kw)
+        sums = torch.empty(L, 2, dtype=torch.float64, device=dev)
+        for i in range(L):                                                      # :563-567 |adv0 - ori| per layer
+            net.ilaf_reduce(i, ori_f[i], adv_f[i], scratch, nf[i], act=adv_f[i])
+            sums[i].copy_(scratch[:4].view(torch.float64))
+        init_norms = [float(v) ** 0.5 for v in sums[:, 0].cpu()]                # the loop's only pre-loop read-back
+        modifier = torch.sub(u_adv, u_ori)                                      # :574-575 existing perturbation
+        gx = torch.empty_like(x)
+        loss = torch.zeros(L, **kw)
+        costs = torch.zeros(self.steps, **kw)
+        for i in range(self.steps):
+            eng.compose(u_ori, modifier, x, b, f, eps)                          # :585-588
+            net.forward(x)                                                      # :591
+            for k in range(L):                                                  # :599-610
+                net.ilaf_reduce(k, ori_f[k], adv_f[k], scratch, nf[k])
+                net.ilaf_grad(k, ori_f[k], adv_f[k], init_norms[k], loss[k:k + 1], scratch, nf[k])
+            net.backward(gx)                                                    # :613-614 (input gradient only)
+            eng.sign_step_delta_gx(modifier, gx, u_ori, eps, self.step_size)    # :617
+            costs[i] = loss.sum()                                               # :611, stays on the device
+        self.last_costs = costs.cpu().numpy()
+        for i in range(self.steps):
+            for name in video_names:
+                self.loss_info.setdefault(name, {})[i] = {"cost": str(np.asarray(self.last_costs[i], dtype=np.float32))}
+        out = torch.empty(b, 3, f, h, w, **kw)
+        eng.compose(u_ori, modifier, out, b, f, eps, video_layout=True)         # :625-626
+        self._modifier = modifier
+        return out.reshape(b, f, c, h, w).permute(0, 2, 1, 3, 4)                # :627-628 (sic, see class docstring)
+
     def forward(self, videos, ori_videos, labels, video_names):
+        if isinstance(self.model, VideoModel):
+            return self._native(videos, ori_videos, video_names)
         dev = next(self.model.parameters()).device
         eng = self._engine or get_engine(str(dev) if dev.type == "cuda" else None)
         videos, ori = videos.to(dev).float().contiguous(), ori_videos.to(dev).float().contiguous()

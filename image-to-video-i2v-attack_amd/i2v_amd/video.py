@@ -1,0 +1,49 @@
+"""White-box VIDEO backbones for ILAF (`/root/reference/image_attacks.py:498-629`).
+
+The reference builds them with `gluoncv.torch.model_zoo.get_model(cfg)` (`image_fine_tune_attack.py:58-66`) and
+hands the torch module to `ILAF(model, model_type)`.  gluoncv is neither vendored nor installed, so the native path
+takes a `VideoModel` instead: the graph IR of the backbone up to the hooked stage (`graphs.build_video`) plus its
+weights.  `ILAF` still accepts an arbitrary torch module (then the model runs in PyTorch and only the update rule is
+native); handing it a `VideoModel` makes the whole loop -- compose, 3-D forward to the hooks, ILAF loss, input
+gradient, sign step -- run in `libi2v_hip.so`.
+"""
+from typing import Optional
+
+from . import graphs as _graphs
+from . import weights as _weights
+
+
+class VideoModel(object):
+    """`model_type` as in `image_fine_tune_attack.py:53` ('i3d_resnet50', 'i3d_resnet101', 'slowfast_resnet50',
+    'slowfast_resnet101').  Weights: `$I2V_WEIGHTS_DIR/<arch>.pth` in the graph's key layout if present, else the
+    seeded synthetic initialiser (`weights.load_state_dict`)."""
+
+    def __init__(self, model_type: str, in_thw=(32, 224, 224), weight_seed: int = 0, tiny: bool = False,
+                 state_dict: Optional[dict] = None):
+        self.model_type = model_type
+        self.in_thw = tuple(in_thw)
+        self.tiny = tiny
+        self.weight_seed = weight_seed
+        self._sd = state_dict
+        self.training = False
+        self.graph_for(self.in_thw)          # unknown names fail at construction, like get_model(cfg)
+
+    def graph_for(self, thw):
+        build = _graphs.build_video_tiny if self.tiny else _graphs.build_video
+        return build(self.model_type, tuple(thw))
+
+    def state_dict_for(self, graph):
+        return self._sd if self._sd is not None else _weights.load_state_dict(graph, self.weight_seed)
+
+    def hook_tensors(self, graph):
+        return _graphs.video_hooks(graph, self.model_type)
+
+    # the reference calls these on the torch module (`image_fine_tune_attack.py:67`, base_attacks.py:227-229)
+    def cuda(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        return self

@@ -124,6 +124,54 @@ def run_sign_step(clip_seed=77):
     return dict(clip_u8=u8.numpy(), steps=4, eps=16 / 255, **out)
 
 
+def make_ilaf_inputs(seed, b, thw, lo, hi, amp):
+    """Clean clip with pixels in [lo, hi] + an existing adversarial version of it within +-amp/255 (both
+    uint8-quantised).  The f64 cases keep away from 0/255 and from eps so that no clamp mask is decided by the last
+    bit (they pin the loss/gradient semantics against an fp32 engine); the f32 case uses the full range and runs
+    into both clamps (the masks are the same fp32 operations on both sides)."""
+    gen = torch.Generator().manual_seed(seed)
+    ori = torch.randint(lo, hi + 1, (b, 3, *thw), generator=gen, dtype=torch.uint8)
+    noise = torch.randint(-amp, amp + 1, ori.shape, generator=gen)
+    adv = (ori.long() + noise).clamp(0, 255).to(torch.uint8)
+    return ori, adv
+
+
+def run_ilaf(model_type, prec, steps, b, thw, seed, lo, hi, amp, wseed=0):
+    """The reference's `ILAF` (`image_attacks.py:498-629`) on the tiny I3D / SlowFast modules of
+    oracle/video_models.py (gluoncv's own models are not installed)."""
+    from i2v_amd import graphs, weights
+    from oracle import video_models
+    dtype = torch.float64 if prec == "f64" else torch.float32
+    ia = ref_shim.import_reference("image_attacks")
+    g = graphs.build_video_tiny(model_type, thw)
+    model = video_models.load_weights(video_models.make(model_type, True), weights.synthetic_state_dict(g, wseed)).to(dtype)
+    ori_u8, adv_u8 = make_ilaf_inputs(seed, b, thw, lo, hi, amp)
+    ori, adv = normalise(ori_u8, dtype), normalise(adv_u8, dtype)
+    grads = []
+    orig = torch.autograd.grad
+
+    def grad_tap(*a, **k):
+        r = orig(*a, **k)
+        grads.append(r[0].detach().clone())
+        return r
+    torch.autograd.grad = grad_tap
+    try:
+        with ref_shim.quiet():
+            atk = ia.ILAF(model, model_type, step_size=0.005, steps=steps)
+            out = atk(adv.clone(), ori.clone(), torch.zeros(b, dtype=torch.long), ["v"])
+    finally:
+        torch.autograd.grad = orig
+    return dict(model_type=model_type, prec=prec, steps=steps, b=b, thw=np.array(thw), seed=seed, wseed=wseed,
+                ori_u8=ori_u8.numpy(), adv_u8=adv_u8.numpy(), cost_str=costs_of(atk, "v", steps),
+                grad0=grads[0].numpy().astype(np.float32), out=out.detach().numpy().astype(np.float32))
+
+
+ILAF_CASES = {
+    "ilaf_i3d_f64": ("i3d_resnet50", "f64", 4, 1, (8, 32, 32), 2001, 16, 239, 10),
+    "ilaf_i3d_f32": ("i3d_resnet50", "f32", 4, 1, (8, 32, 32), 2002, 0, 255, 15),
+    "ilaf_slowfast_f64": ("slowfast_resnet50", "f64", 3, 2, (8, 32, 32), 2003, 16, 239, 10),
+}
+
 CASES = {
     # name: (kind, prec, models, depth(s), steps, lr, b, f, hw, clip_seed)
     "i2v_resnet_d3_f64": ("i2v", "f64", ["resnet"], 3, 4, 0.005, 1, 3, 64, 1001),
@@ -153,7 +201,16 @@ def main():
     print("aens_coefce_f64", fix["cost_str"][-1])
     np.savez_compressed(os.path.join(OUT, "sign_step.npz"), **run_sign_step())
     print("sign_step ok")
+    make_ilaf()
+
+
+def make_ilaf():
+    for name, args in ILAF_CASES.items():
+        fix = run_ilaf(*args)
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **fix)
+        print(name, os.path.getsize(path) // 1024, "KiB", fix["cost_str"])
 
 
 if __name__ == "__main__":
-    main()
+    make_ilaf() if sys.argv[1:] == ["ilaf"] else main()

@@ -322,6 +322,47 @@ def run_attack(nets: Sequence[OracleNet], videos: torch.Tensor, *, steps: int, s
     return out
 
 
+def run_ilaf(model, hook_modules, videos, ori_videos, *, steps, step_size=0.005, eps=16 / 255):
+    """Restatement of `ILAF.forward` (`/root/reference/image_attacks.py:534-629`) for a torch video model whose
+    hooked modules are `hook_modules`: whole-tensor norms, `-(0.5*|d|/|d0| + <d0/|d0|, d/|d|>)` summed over the
+    hooked layers, gradient w.r.t. the perturbation through the clamped compose, `modifier -= step*sign(grad)`.
+    Returns (output in the reference's scrambled layout, costs[steps], first-step gradient, final modifier)."""
+    feats = []
+    handles = [m.register_forward_hook(lambda mod, i, o: feats.append(o)) for m in hook_modules]
+    dtype = videos.dtype
+    mean = torch.tensor(MEAN, dtype=dtype).view(1, 3, 1, 1, 1)
+    std = torch.tensor(STD, dtype=dtype).view(1, 3, 1, 1, 1)
+    b, c, f, h, w = videos.shape
+    try:
+        with torch.no_grad():
+            feats.clear(); model(ori_videos); ori_f = list(feats)
+            feats.clear(); model(videos); adv_f = list(feats)
+        d0 = [a - o for a, o in zip(adv_f, ori_f)]
+        n0 = [torch.norm(d, p=2) for d in d0]
+        dir0 = [d / n for d, n in zip(d0, n0)]
+        ori_u = ori_videos.clone().mul_(std).add_(mean)
+        modifier = videos.clone().mul_(std).add_(mean) - ori_u                 # `torch.Tensor(t)` aliases t: dtype kept (:574-575)
+        costs, grad0 = [], None
+        for _ in range(steps):
+            modifier.requires_grad_(True)
+            x = (torch.clamp(ori_u + torch.clamp(modifier, -eps, eps), 0, 1) - mean) / std
+            feats.clear(); model(x)
+            loss = 0
+            for k, a in enumerate(feats):
+                d = a - ori_f[k]
+                nrm = torch.norm(d, p=2)
+                loss = loss - (0.5 * nrm / n0[k] + (dir0[k] * (d / nrm)).sum())
+            g = torch.autograd.grad(loss, modifier)[0]
+            grad0 = g.detach().clone() if grad0 is None else grad0
+            modifier = sign_step_ilaf(modifier.detach(), g, step_size)
+            costs.append(float(loss.detach()))
+        out = (torch.clamp(ori_u + torch.clamp(modifier, -eps, eps), 0, 1) - mean) / std
+        return out.reshape(b, f, c, h, w).permute(0, 2, 1, 3, 4), np.array(costs), grad0, modifier
+    finally:
+        for hd in handles:
+            hd.remove()
+
+
 def cost_strings(costs: np.ndarray) -> List[str]:
     """`str(cost.detach().cpu().numpy())` of a float32 scalar (`image_attacks.py:358`)."""
     return [str(np.float32(c)) for c in costs]

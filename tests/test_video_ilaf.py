@@ -1,0 +1,91 @@
+"""CPU: ILAF on video backbones.  (1) The oracle's restatement of the loop against what the UNMODIFIED reference
+class produced on the same torch modules (fixtures `ilaf_*.npz`, oracle/make_golden.py).  (2) The native path
+(`ILAF(VideoModel)`, whole loop behind the C ABI, host simulation backend here) against the same fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from i2v_amd import graphs, sign_attacks, video, weights
+from oracle import restate, video_models as vm
+from tests import golden_util as gu
+from tests.hostsim_util import hostsim_engine
+
+FIX = ["ilaf_i3d_f64", "ilaf_i3d_f32", "ilaf_slowfast_f64"]
+
+
+def load(name):
+    z = np.load(gu.GOLDEN + "/" + name + ".npz")
+    fx = {k: z[k] for k in z.files}
+    fx["model_type"], fx["prec"] = str(fx["model_type"]), str(fx["prec"])
+    fx["steps"], fx["b"], fx["wseed"] = int(fx["steps"]), int(fx["b"]), int(fx["wseed"])
+    fx["thw"] = tuple(int(v) for v in fx["thw"])
+    fx["cost"] = np.array([float(s) for s in fx["cost_str"]])
+    return fx
+
+
+def clips(fx, dtype=torch.float32):
+    return gu.videos_of({"clip_u8": fx["adv_u8"]}, dtype), gu.videos_of({"clip_u8": fx["ori_u8"]}, dtype)
+
+
+@pytest.mark.parametrize("name", FIX)
+def test_restatement_matches_reference_class(name):
+    fx = load(name)
+    dtype = torch.float64 if fx["prec"] == "f64" else torch.float32
+    g = graphs.build_video_tiny(fx["model_type"], fx["thw"])
+    model = vm.load_weights(vm.make(fx["model_type"], True), weights.synthetic_state_dict(g, fx["wseed"])).to(dtype)
+    adv, ori = clips(fx, dtype)
+    # the reference hooks in ITS order; the loss is a sum over layers, so the order is immaterial
+    out, costs, grad0, _ = restate.run_ilaf(model, vm.hook_modules(model, fx["model_type"]), adv, ori, steps=fx["steps"])
+    tol = 1e-9 if fx["prec"] == "f64" else 2e-3
+    np.testing.assert_allclose(costs, fx["cost"], rtol=tol)
+    if fx["prec"] == "f64":
+        assert np.abs(grad0.numpy() - fx["grad0"]).max() <= 1e-6 * np.abs(fx["grad0"]).max()
+        assert np.abs(out.numpy() - fx["out"]).max() < 1e-6
+    else:
+        assert np.abs(out.numpy() - fx["out"]).mean() < 5e-3
+
+
+@pytest.mark.parametrize("name", FIX)
+def test_native_ilaf_against_reference_fixture(name):
+    fx = load(name)
+    adv, ori = clips(fx)
+    model = video.VideoModel(fx["model_type"], fx["thw"], weight_seed=fx["wseed"], tiny=True)
+    atk = sign_attacks.ILAF(model, fx["model_type"], step_size=0.005, steps=fx["steps"], engine=hostsim_engine())
+    out = atk(adv.clone(), ori.clone(), torch.zeros(fx["b"], dtype=torch.long), ["v"])
+    assert out.shape == fx["out"].shape
+    rtol = 2e-4 if fx["prec"] == "f64" else 5e-3          # fp32 engine vs f64 / f32 reference trajectories
+    np.testing.assert_allclose(atk.last_costs, fx["cost"], rtol=rtol)
+    assert atk.loss_info["v"][0]["cost"] == str(np.float32(atk.last_costs[0]))
+    assert list(atk.loss_info["v"].keys()) == list(range(fx["steps"]))
+    assert np.abs(out.numpy() - fx["out"]).mean() < 5e-3
+    # box / L_inf invariants in the reference's (scrambled) output layout: undo it first
+    b, c, f, h, w = out.shape
+    un = out.permute(0, 2, 1, 3, 4).reshape(b, c, f, h, w) * torch.tensor(gu.STD).view(1, 3, 1, 1, 1) + torch.tensor(gu.MEAN).view(1, 3, 1, 1, 1)
+    clean = torch.from_numpy(fx["ori_u8"]).float() / 255
+    assert (un - clean).abs().max() <= 16 / 255 + 1e-6 and un.min() >= -1e-6 and un.max() <= 1 + 1e-6
+
+
+@pytest.mark.parametrize("name", ["ilaf_i3d_f64", "ilaf_i3d_f32"])
+def test_native_first_step_follows_reference_gradient_sign(name):
+    fx = load(name)
+    adv, ori = clips(fx)
+    model = video.VideoModel(fx["model_type"], fx["thw"], weight_seed=fx["wseed"], tiny=True)
+    atk = sign_attacks.ILAF(model, fx["model_type"], step_size=0.005, steps=1, engine=hostsim_engine())
+    atk(adv.clone(), ori.clone(), torch.zeros(1, dtype=torch.long), ["v"])
+    std = torch.tensor(gu.STD).view(1, 3, 1, 1, 1)
+    mean = torch.tensor(gu.MEAN).view(1, 3, 1, 1, 1)
+    m0 = (adv * std + mean) - (ori * std + mean)                         # (b,3,f,h,w)
+    m1 = atk._modifier.reshape(1, fx["thw"][0], 3, *fx["thw"][1:]).permute(0, 2, 1, 3, 4)
+    moved = torch.sign(m0 - m1).numpy()                                   # = sign of the gradient the engine saw
+    g = fx["grad0"]
+    big = np.abs(g) > 2e-2 * np.abs(g).max()
+    assert (moved[big] == np.sign(g[big])).mean() > 0.995
+    assert (moved[g == 0] == 0).all()                                     # clamp-masked pixels do not move
+    assert (moved[:, :, -1] == 0).all()                                   # T=8: the last frame is never read (stride 2 twice)
+
+
+def test_video_model_errors():
+    with pytest.raises(KeyError):
+        video.VideoModel("tpn_resnet50")
+    m = video.VideoModel("i3d_resnet50", (8, 32, 32), tiny=True)
+    assert m.cuda() is m and m.eval() is m
