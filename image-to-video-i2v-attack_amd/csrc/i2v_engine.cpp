@@ -54,6 +54,7 @@ struct Packed {               // one implicit-GEMM operand set
     int K = 0, Kpad = 0, Cd = 0, Cdpad = 0, tap_uniform = 0;
     int ph = 0, pw = 0, Hg = 0, Wg = 0;
     int pt = 0, Tg = 1;       // temporal parity class / grid frames per clip (video networks)
+    int has_dt = 0;           // some k-table row carries a temporal tap offset
 };
 
 struct Node {
@@ -144,6 +145,7 @@ static int pack_fwd(Net& n, Node& nd) {
                     for (int co = 0; co < c.cout; ++co)
                         wp[(size_t)k * P.Cdpad + co] = nd.w[((((size_t)co * c.cin + ci) * c.kt + q) * c.kh + r) * c.kw + s];
                 }
+    for (const I2VKEntry& e : kt) if (e.valid >> 1) P.has_dt = 1;
     if (upload(n, wp, &P.wp)) return 1;
     return upload(n, kt, &P.ktab);
 }
@@ -186,6 +188,7 @@ static int pack_bwd(Net& n, Node& nd) {
                     }
                     ++t;
                 }
+            for (const I2VKEntry& e : kt) if (e.valid >> 1) P.has_dt = 1;
             if (upload(n, wp, &P.wp)) return 1;
             if (upload(n, kt, &P.ktab)) return 1;
             nd.bwd.push_back(P);
@@ -248,6 +251,7 @@ static int pack_img(Net& n, Node& nd) {
                     }
                 }
     }
+    for (const I2VKEntry& e : kt) if (e.valid >> 1) P.has_dt = 1;
     if (upload(n, wp, &P.wp)) return 1;
     return upload(n, kt, &P.ktab);
 }
@@ -442,6 +446,7 @@ static void conv_common(I2VConvParams& p, const Packed& P) {
     p.wp = P.wp; p.ktab = P.ktab; p.K = P.K; p.Kpad = P.Kpad; p.tap_uniform = P.tap_uniform; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
     p.add0_stride = 1;
     p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1; p.ot0 = 0;
+    p.temporal = P.has_dt;      // conv_run adds the frame-mapping half of the condition
 }
 
 static bool overlaps(const Tensor& a, const Tensor& b) {
@@ -815,6 +820,7 @@ static int conv_run(const Launch& l, int frames, const float* x, float* gx, int 
                       p.add0_nstride % 4 == 0 && p.add1_nstride % 4 == 0 && p.mask_nstride % 4 == 0 &&
                       (((uintptr_t)p.dst | (uintptr_t)p.add0 | (uintptr_t)p.add1 | (uintptr_t)p.mask) & 15) == 0)
                          ? 1 : 0;
+    if (!(p.Tg == p.Ts && p.Ts == p.To && p.st == 1 && p.ost == 1 && p.ot0 == 0 && p.blkt == 1)) p.temporal = 1;
     const int clips = frames / p.Tg;
     const int64_t plane_bytes = (int64_t)p.Cs * p.Hs * p.Ws * 4, stride_bytes = p.src_nstride * 4;
     const int64_t clip_bytes = (int64_t)(p.Ts - 1) * stride_bytes + plane_bytes;        // span of one clip's source frames

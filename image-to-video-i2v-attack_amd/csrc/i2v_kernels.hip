@@ -77,7 +77,9 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 // K loop, so for the low-K, HBM-bound layers the read traffic overlaps the matrix work instead of following it.
 // PRE: the B operand is relu(x * pre_scale[k] + pre_shift[k]) (DenseNet norm->relu->1x1 conv), applied when the
 // fragment is read from LDS; k == input channel for the 1x1 convolutions this is used on.
-template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false>
+// VID: the launch has temporal taps or a non-identity frame mapping (video networks, I2VConvParams::temporal);
+// image launches -- and the spatial / pointwise convolutions of video networks -- compile without any of it.
+template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false>
 __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-resource types and LDS-DMA builtins exist only in the device pass
     constexpr int KC = I2V_KC;
@@ -134,7 +136,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     const int HWs = p.Hs * p.Ws;
     int h0 = 0, w0 = 0, t0 = 0;
     int64_t pns = pn;                                         // source frame of this lane's pixel
-    if (p.Tg > 1 || p.Ts > 1) {                               // video: grid frame (clip, tg) reads frames tg*st + dt
+    if (VID) {                                                // grid frame (clip, tg) reads source frames tg*st + dt
         const int64_t clip = pn / p.Tg;
         t0 = (int)(pn - clip * p.Tg) * p.st;
         pns = clip * p.Ts + t0;
@@ -184,9 +186,9 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
             }                                                                                             \
         } else if (MODE == 2) {                                                                           \
             const I2VKEntry e = load_kentry(p.ktab, k0);                                                  \
-            const int hs = h0 + e.dh, ws = w0 + e.dw, dtk = e.valid >> 1;                                 \
+            const int hs = h0 + e.dh, ws = w0 + e.dw, dtk = VID ? (e.valid >> 1) : 0;                     \
             const bool ok = pvalid && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws &&   \
-                            (unsigned)(t0 + dtk) < (unsigned)p.Ts;                                        \
+                            (!VID || (unsigned)(t0 + dtk) < (unsigned)p.Ts);                              \
             const unsigned v = ok ? xoff + (unsigned)((e.chan_off + dtk * nstr + e.dh * p.Ws + e.dw) * 4) : OOB; \
             _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                             \
                 const int ins = wv + 4 * q;                                                               \
@@ -199,9 +201,9 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
                 const int ins = wv + 4 * q;                                                               \
                 if (NB % 4 == 0 || ins < NB) {                                                            \
                     const I2VKEntry e = load_kentry(p.ktab, k0 + (ins * 64) / BP);                        \
-                    const int hs = h0 + e.dh, ws = w0 + e.dw, dtk = e.valid >> 1;                         \
+                    const int hs = h0 + e.dh, ws = w0 + e.dw, dtk = VID ? (e.valid >> 1) : 0;             \
                     const bool ok = pvalid && (e.valid & 1) && (unsigned)hs < (unsigned)p.Hs &&           \
-                                    (unsigned)ws < (unsigned)p.Ws && (unsigned)(t0 + dtk) < (unsigned)p.Ts; \
+                                    (unsigned)ws < (unsigned)p.Ws && (!VID || (unsigned)(t0 + dtk) < (unsigned)p.Ts); \
                     const unsigned v = ok ? xoff + (unsigned)((e.chan_off + dtk * nstr + e.dh * p.Ws + e.dw) * 4) : OOB; \
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 64), 4, v, 0, 0, 0); \
                 }                                                                                         \
@@ -367,7 +369,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     }
     if (p.blk > 1) {
         // class-packed Cd (image gradient): cd = (ph*blk + pw)*Creal + c -> channel c at (gi*osh+ph, gj*osw+pw)
-        const int Creal = p.Cd / (p.blkt * p.blk * p.blk), bb = p.blk * p.blk;
+        const int bb = p.blk * p.blk, Creal = p.Cd / ((VID ? p.blkt : 1) * bb);
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int64_t pp = px0 + wpx * (BP / WP) + j * 32 + l31;
@@ -375,8 +377,8 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
             const int64_t ng = pp / HWg;
             const int rem = (int)(pp - ng * HWg);
             const int gi = rem / p.Wg, gj = rem - gi * p.Wg;
-            const int64_t clip = ng / p.Tg;
-            const int otb = (int)(ng - clip * p.Tg) * p.ost + p.ot0;
+            const int64_t clip = VID ? ng / p.Tg : ng;
+            const int otb = VID ? (int)(ng - clip * p.Tg) * p.ost + p.ot0 : 0;
 #pragma unroll
             for (int i = 0; i < TD; ++i)
 #pragma unroll
@@ -384,10 +386,10 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
                     const int cd = cd0 + wd * (BD / WD) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                     if (cd >= p.Cd) continue;
                     const int cls3 = cd / Creal, c = cd - cls3 * Creal;
-                    const int ct = cls3 / bb, cls = cls3 - ct * bb;
+                    const int ct = VID ? cls3 / bb : 0, cls = cls3 - ct * bb;
                     const int oh = gi * p.osh + cls / p.blk + p.oh0, ow = gj * p.osw + cls % p.blk + p.ow0;
-                    if (oh >= p.Ho || ow >= p.Wo || otb + ct >= p.To) continue;
-                    const int64_t n = clip * p.To + otb + ct;
+                    if (oh >= p.Ho || ow >= p.Wo || (VID && otb + ct >= p.To)) continue;
+                    const int64_t n = VID ? clip * p.To + otb + ct : ng;
                     const int64_t o = (int64_t)c * HoWo + oh * p.Wo + ow;
                     float v = acc[i][j][r];
                     if (p.shift) v += p.shift[c];
@@ -409,7 +411,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         const int oh = gi * p.osh + p.oh0, ow = gj * p.osw + p.ow0;
         if (oh >= p.Ho || ow >= p.Wo) continue;
         int64_t n = ng;                                          // destination frame
-        if (p.Tg > 1 || p.To > 1) {
+        if (VID) {
             const int64_t clip = ng / p.Tg;
             const int ot = (int)(ng - clip * p.Tg) * p.ost + p.ot0;
             if (ot >= p.To) continue;
@@ -465,6 +467,7 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     if (grid <= 0) return 0;
     if (grid > 0x7fffffff) { snprintf(g_be_err, sizeof g_be_err, "conv grid too large"); g_be_has_err = true; return 1; }
     if (p.pre_scale) {
+        if (p.temporal) { snprintf(g_be_err, sizeof g_be_err, "pre-activation convolutions have no temporal variant"); g_be_has_err = true; return 1; }
         if constexpr ((BD == 64 && BP == 64) || (BD == 128 && BP == 128)) {
             if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 1, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
             else if (p.tap_uniform) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
@@ -473,10 +476,13 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     } else if (BD == 64 && BP == 64 && conv_wants_prefetch(p) && !(p.cfg > 0 && ((p.cfg - 1) & 8))) {
         if constexpr (BD == 64 && BP == 64) {
             if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 1, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+            else if (p.temporal) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2, true, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
             else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
         }
     } else if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 1, false>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+    else if (p.tap_uniform && p.temporal) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2, false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
     else if (p.tap_uniform) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2, false>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+    else if (p.temporal) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 0, false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
     else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 0, false>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
     LAUNCH_CHECK("conv_igemm");
     return 0;

@@ -38,6 +38,14 @@ int cos_nblk(int64_t D) { return (int)std::min<int64_t>(64, std::max<int64_t>(1,
 int k_conv_candidates(const I2VConvParams&, int* out) { out[0] = 0; return 1; }
 
 int k_conv(const I2VConvParams& p, i2v_stream_t) {
+    if (!p.temporal) {      // image variant of the kernel: the temporal fields are ignored (a launch that needs them
+        I2VConvParams q = p; // but is not flagged must therefore FAIL the planner tests, as it would on the GPU)
+        q.temporal = 1; q.Tg = q.Ts = q.To = q.st = q.ost = 1; q.ot0 = 0; q.blkt = 1;
+        std::vector<I2VKEntry> kt(p.ktab, p.ktab + (p.Kpad ? p.Kpad : 0));
+        for (auto& e : kt) e.valid &= 1;
+        q.ktab = kt.data();
+        return k_conv(q, nullptr);
+    }
     for (int ng = 0; ng < p.N; ++ng) {
         // grid frame (clip, tg) reads source frame clip*Ts + tg*st + dt and writes frame clip*To + tg*ost + ot0 (+ class)
         const int clip = ng / p.Tg, tg = ng % p.Tg, t0 = tg * p.st;

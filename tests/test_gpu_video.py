@@ -1,0 +1,219 @@
+"""GPU (-m gpu): the video (3-D) path on the hand-written HIP kernels, through the C ABI -- temporal taps / strides /
+dilation in `conv_igemm`, the class-packed stem gradient with temporal classes, `pool3d_*`, `ilaf_*`, the masked sign
+step -- against PyTorch's `conv3d`/autograd on the CPU (float64) and against what the reference's ILAF class produced
+(fixtures `ilaf_*.npz`).
+
+Tolerances: activations rtol 1e-4 / atol 1e-5 (fp32 engine vs f64 oracle); input gradients max-abs <= 1e-4 * max|g| at
+test sizes; at full size (~10^8 ReLU gates, a few decided by the last bit) relative L2 error <= 5e-3;
+ILAF cost trajectories rtol 2e-4 (f64 fixtures) / 5e-3 (f32 fixture, whose own reference run is chaotic in the last bits).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from i2v_amd import attacks, graphs, sign_attacks, video, weights  # noqa: E402
+from oracle import restate, video_models as vm  # noqa: E402
+from tests import golden_util as gu  # noqa: E402
+from tests.test_video_hostsim import GEOM, capture  # noqa: E402
+from tests.test_video_ilaf import FIX, clips, load  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    e = attacks.get_engine("cuda:0")
+    assert e.capi.i2v_backend() == b"hip:gfx950"
+    return e
+
+
+def dev(t):
+    return t.to("cuda:0").contiguous()
+
+
+def write_hook_grads(net, feats, hg):
+    """d(cost)/d(hook), gated by the hook's own ReLU (what i2v_ilaf_grad_f32 does), into the library's views."""
+    for i, hi in enumerate(net.hooks):
+        gate = (feats[i] > 0).to(hg[i].dtype) if hi.post_relu else torch.ones_like(feats[i])
+        flat = dev((hg[i] * gate).float().reshape(hg[i].shape[0], -1))
+        torch.cuda.synchronize()
+        for n in range(flat.shape[0]):          # frame stride of the view may exceed D (concatenation buffers)
+            d2d(hi.grad + 4 * n * hi.grad_stride, flat[n].data_ptr(), 4 * hi.D)
+
+
+_hip = None
+
+
+def d2d(dst_ptr, src_ptr, nbytes):
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert _hip.hipMemcpy(ctypes.c_void_p(dst_ptr), ctypes.c_void_p(src_ptr), nbytes, 3) == 0   # hipMemcpyDeviceToDevice
+
+
+def run_backbone(eng, model_type, thw, b, tiny, seed=1):
+    g = (graphs.build_video_tiny if tiny else graphs.build_video)(model_type, thw)
+    sd = weights.synthetic_state_dict(g, seed)
+    hooks = graphs.video_hooks(g, model_type)
+    T = thw[0]
+    net = eng.build_net(g, sd, hooks, b * T)
+    model = vm.load_weights(vm.make(model_type, tiny), sd).double()
+    torch.manual_seed(5)
+    x = torch.randn(b, 3, *thw, dtype=torch.float64, requires_grad=True)
+    feats = capture(model, vm.hook_modules(model, model_type), x)
+    net.forward(dev(vm.to_frames(x.detach()).float()))
+    ffeat = [vm.to_frames(f.detach()) for f in feats]
+    for i, f in enumerate(ffeat):
+        got = net.save_hook(i, f.shape[0]).cpu().double()
+        assert torch.allclose(got, f, rtol=1e-4, atol=1e-5 * float(f.abs().max())), (i, float((got - f).abs().max()))
+    hg = [torch.randn_like(f) for f in feats]
+    ref = vm.to_frames(torch.autograd.grad(sum((f * h).sum() for f, h in zip(feats, hg)), x)[0])
+    write_hook_grads(net, ffeat, [vm.to_frames(h) for h in hg])
+    gx = torch.empty(b * T, 3, thw[1], thw[2], device="cuda:0")
+    net.backward(gx)
+    gx = gx.cpu().double()
+    net.close()
+    return gx, ref
+
+
+@pytest.mark.parametrize("model_type,thw", [("i3d_resnet50", (8, 32, 32)), ("slowfast_resnet50", (8, 32, 32)),
+                                            ("i3d_resnet50", (16, 24, 40)), ("slowfast_resnet50", (16, 40, 24))])
+def test_video_backbone_tiny(eng, model_type, thw):
+    gx, ref = run_backbone(eng, model_type, thw, 2, True)
+    assert (gx - ref).abs().max() <= 1e-4 * ref.abs().max()
+
+
+@pytest.mark.parametrize("model_type", ["i3d_resnet50", "slowfast_resnet50"])
+def test_video_backbone_full_size(eng, model_type):
+    """One 32 x 224 x 224 clip through the real-width backbone to the hooked stage and back."""
+    gx, ref = run_backbone(eng, model_type, (32, 224, 224), 1, False)
+    # fp32 engine vs f64 oracle over ~10^8 ReLU gates and 3x3 arg-max windows: the handful decided by the last bit
+    # flip, each moving a cone of the input gradient -- hence an L2 criterion here and the tight max-abs one at test sizes
+    rel = float((gx - ref).norm() / ref.norm())
+    assert rel < 5e-3, rel
+    assert (gx - ref).abs().max() <= 5e-2 * ref.abs().max()
+
+
+@pytest.mark.parametrize("case", GEOM)
+@pytest.mark.parametrize("as_stem", [False, True])
+@pytest.mark.parametrize("wide", [False, True])
+def test_conv3d_geometry(eng, case, as_stem, wide):
+    """The 3-D taps through every kernel mode: `wide` multiplies the channel counts by 16 so that the chunk-uniform
+    (MODE 2) loader and larger tiles are used; otherwise the per-row table path runs."""
+    cin, cout, k, s, p, dil, T, H = case
+    if wide:
+        cin, cout = cin * 16, cout * 16
+    g = graphs.Graph("geom", (H, H + 3), video=True)
+    x = g.new_tensor(3, H, H + 3, False, "input", T=T)
+    g.input = x
+    if as_stem:
+        y = g.conv3d(x, cout, k, s, p, "c.weight", bn="c_bn", relu=True, dil_t=dil)
+    else:
+        a = g.conv3d(x, cin, (1, 1), (1, 1), (0, 0), "a.weight", bn="a_bn", relu=True)
+        y = g.conv3d(a, cout, k, s, p, "c.weight", bn="c_bn", relu=True, dil_t=dil)
+    g.hooks[1] = y
+    sd = weights.synthetic_state_dict(g, 2)
+    b = 3
+    net = eng.build_net(g, sd, [y], b * T)
+    torch.manual_seed(sum(k) + T)
+    xv = torch.randn(b, 3, T, H, H + 3, dtype=torch.float64, requires_grad=True)
+
+    def bn(t, pre):
+        return F.batch_norm(t, sd[pre + ".running_mean"].double(), sd[pre + ".running_var"].double(),
+                            sd[pre + ".weight"].double(), sd[pre + ".bias"].double(), False, 0.0, 1e-5)
+    h = xv if as_stem else F.relu(bn(F.conv3d(xv, sd["a.weight"].double()), "a_bn"))
+    yv = F.relu(bn(F.conv3d(h, sd["c.weight"].double(), None, (s[0], s[1], s[1]), (p[0], p[1], p[1]), (dil, 1, 1)), "c_bn"))
+    net.forward(dev(vm.to_frames(xv.detach()).float()))
+    fy = vm.to_frames(yv.detach())
+    assert torch.allclose(net.save_hook(0, fy.shape[0]).cpu().double(), fy, rtol=1e-4, atol=1e-5)
+    hg = torch.randn_like(yv)
+    ref = vm.to_frames(torch.autograd.grad((yv * hg).sum(), xv)[0])
+    write_hook_grads(net, [fy], [vm.to_frames(hg)])
+    gx = torch.empty(b * T, 3, H, H + 3, device="cuda:0")
+    net.backward(gx)
+    assert (gx.cpu().double() - ref).abs().max() <= 1e-4 * ref.abs().max()
+    net.close()
+
+
+def test_ilaf_kernels(eng):
+    g = graphs.build_video_tiny("i3d_resnet50", (8, 32, 32))
+    net = eng.build_net(g, weights.synthetic_state_dict(g, 0), graphs.video_hooks(g, "i3d"), 16)
+    torch.manual_seed(0)
+    net.forward(dev(torch.rand(16, 3, 32, 32)))
+    hi, n = net.hooks[0], net.hook_frames(0, 16)
+    a = net.save_hook(0, n)
+    ori = (a + 0.3 * torch.randn_like(a)).contiguous()
+    adv0 = (a + 0.2 * torch.randn_like(a)).contiguous()
+    scratch = torch.zeros(net.scratch_bytes(n) // 4 + 8, device="cuda:0")
+    net.ilaf_reduce(0, ori, adv0, scratch, n, act=adv0)
+    n0 = float(scratch[:4].view(torch.float64)[0]) ** 0.5
+    assert abs(n0 - float((adv0 - ori).double().norm())) < 1e-6 * n0
+    loss = torch.zeros(1, device="cuda:0")
+    net.ilaf_reduce(0, ori, adv0, scratch, n)
+    net.ilaf_grad(0, ori, adv0, n0, loss, scratch, n)
+    ad = a.cpu().double().requires_grad_(True)
+    d, d0 = ad - ori.cpu().double(), (adv0 - ori).cpu().double()
+    ref_loss = -(0.5 * d.norm() / d0.norm() + (d0 / d0.norm() * d / d.norm()).sum())
+    gref = torch.autograd.grad(ref_loss, ad)[0] * (a.cpu() > 0)
+    assert abs(float(loss) - float(ref_loss.detach())) < 1e-5 * abs(float(ref_loss.detach()))
+    got = torch.empty_like(a)
+    torch.cuda.synchronize()
+    for f in range(n):
+        d2d(got[f].data_ptr(), hi.grad + 4 * f * hi.grad_stride, 4 * hi.D)
+    assert (got.cpu().double() - gref).abs().max() < 1e-5 * gref.abs().max()
+    # masked sign step: bit-exact
+    u = torch.rand(2, 3, 50, 50)
+    delta = (torch.rand(2, 3, 50, 50) - 0.5) * 0.2
+    gx = torch.randn(2, 3, 50, 50)
+    gx[0, 0, 0, :5] = 0.0
+    eps, step = 16 / 255, 0.005
+    s = u + delta.clamp(-eps, eps)
+    mask = (delta >= -eps) & (delta <= eps) & (s >= 0) & (s <= 1)
+    want = delta - step * torch.sign(gx) * mask
+    dd = dev(delta)
+    eng.sign_step_delta_gx(dd, dev(gx), dev(u), eps, step)
+    assert torch.equal(dd.cpu(), want)
+    net.close()
+
+
+@pytest.mark.parametrize("name", FIX)
+def test_native_ilaf_against_reference_fixture(eng, name):
+    fx = load(name)
+    adv, ori = clips(fx)
+    model = video.VideoModel(fx["model_type"], fx["thw"], weight_seed=fx["wseed"], tiny=True)
+    atk = sign_attacks.ILAF(model, fx["model_type"], step_size=0.005, steps=fx["steps"])
+    out = atk(adv.clone(), ori.clone(), torch.zeros(fx["b"], dtype=torch.long), ["v"]).cpu()
+    np.testing.assert_allclose(atk.last_costs, fx["cost"], rtol=2e-4 if fx["prec"] == "f64" else 5e-3)
+    assert np.abs(out.numpy() - fx["out"]).mean() < 5e-3
+    b, c, f, h, w = out.shape
+    un = out.permute(0, 2, 1, 3, 4).reshape(b, c, f, h, w) * torch.tensor(gu.STD).view(1, 3, 1, 1, 1) + torch.tensor(gu.MEAN).view(1, 3, 1, 1, 1)
+    clean = torch.from_numpy(fx["ori_u8"]).float() / 255
+    assert (un - clean).abs().max() <= 16 / 255 + 1e-6 and un.min() >= -1e-6 and un.max() <= 1 + 1e-6
+    # bit-reproducible: the same call again gives the same clip
+    atk2 = sign_attacks.ILAF(model, fx["model_type"], step_size=0.005, steps=fx["steps"])
+    assert torch.equal(atk2(adv.clone(), ori.clone(), torch.zeros(fx["b"], dtype=torch.long), ["v"]).cpu(), out)
+
+
+def test_native_ilaf_full_size_against_oracle(eng):
+    """BASELINE.json configs[4] shape (1 clip of 32 x 224 x 224 per call), 2 steps, SlowFast res2 hooks: the native
+    loop against the oracle's restatement run on the torch module (CPU, float32)."""
+    mt, thw = "slowfast_resnet50", (32, 224, 224)
+    gen = torch.Generator().manual_seed(11)
+    ori_u8 = torch.randint(0, 256, (1, 3, *thw), generator=gen, dtype=torch.uint8)
+    adv_u8 = (ori_u8.long() + torch.randint(-10, 11, ori_u8.shape, generator=gen)).clamp(0, 255).to(torch.uint8)
+    ori, adv = gu.videos_of({"clip_u8": ori_u8.numpy()}), gu.videos_of({"clip_u8": adv_u8.numpy()})
+    model = video.VideoModel(mt, thw)
+    atk = sign_attacks.ILAF(model, mt, step_size=0.005, steps=2)
+    out = atk(adv.clone(), ori.clone(), torch.zeros(1, dtype=torch.long), ["v"]).cpu()
+    g = graphs.build_video(mt, thw)
+    tm = vm.load_weights(vm.make(mt, False), weights.synthetic_state_dict(g, 0))
+    ref, costs, _, _ = restate.run_ilaf(tm, vm.hook_modules(tm, mt), adv, ori, steps=2)
+    np.testing.assert_allclose(atk.last_costs, costs, rtol=2e-3)
+    assert abs(atk.last_costs[0] + 1.5 * 2) < 1e-4          # two hooked layers, each -(0.5 + 1) at the start
+    assert float((out - ref).abs().mean()) < 2e-3
+    assert float((out != ref).float().mean()) < 0.05        # sign steps: pixels differ only where |g| ~ 0
