@@ -107,7 +107,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU")
-    ap.add_argument("--workload", default="i2v", choices=["i2v", "ens", "aens", "config2"],
+    ap.add_argument("--white_model", default="slowfast_resnet50", help="--workload ilaf: video backbone (graphs.build_video)")
+    ap.add_argument("--workload", default="i2v", choices=["i2v", "ens", "aens", "config2", "ilaf"],
                     help="i2v = the headline metric (default); ens / aens = BASELINE configs[2]/[3]-style extras on the "
                          "reference's own model list (resnet101+vgg16+squeezenet1_1+alexnet)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -145,12 +146,23 @@ def main():
         names3 = ["resnet50", "vgg", "densenet121"]
         atk = attacks.ImageGuidedFML2_Adam_MultiModels(names3, depths={"resnet50": 3, "vgg": 3, "densenet121": 3},
                                                        steps=ATTACK_STEPS, engine=eng)
+    elif args.workload == "ilaf":         # BASELINE.json configs[4]: ILAF fine-tuning, 60 steps (image_attacks.py:502), 1 clip per call
+        from i2v_amd import sign_attacks, video
+        atk = sign_attacks.ILAF(video.VideoModel(args.white_model, (FRAMES, HW, HW)), args.white_model, engine=eng)
     else:
         atk = attacks.AENS_I2V_MF(names4, depths={n: [2, 3] for n in names4}, step_size=0.005, steps=ATTACK_STEPS, engine=eng)
-    b = args.clips
+    b = 1 if args.workload == "ilaf" and args.clips == CLIPS_PER_GPU else args.clips
     videos = synthetic_clips(b, seed0=1000 + rank * b).to(dev)         # resident in HBM before timing
     labels = torch.zeros(b, dtype=torch.long)
     names = [f"clip{rank * b + i}" for i in range(b)]
+    if args.workload == "ilaf":           # (existing adversarial clip, clean clip): the clean clip + a +-10/255 perturbation
+        gen = torch.Generator().manual_seed(77 + rank)
+        std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1, 1)
+        noise = (torch.randint(-10, 11, videos.shape, generator=gen).float() / 255 / std).to(dev)
+        ori = videos
+        _ilaf = atk
+        atk = lambda v, l, n: _ilaf(v, ori, l, n)
+        videos = (ori + noise).contiguous()
 
     for _ in range(max(args.warmup, 0)):
         atk(videos, labels, names)
@@ -206,14 +218,25 @@ def main():
         ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
         out["roofline"] = {"kernel": "conv_igemm (fp32 MFMA implicit GEMM, fwd + dgrad)", "bound": "mfma",
                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": measured_traffic(),
+                           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                           "traffic": measured_traffic() if args.workload == "i2v" and b == CLIPS_PER_GPU else None,
                            "launches": c["launches"], "avg_launch_us": round(1e3 * c["ms"] / c["launches"], 2),
                            "avg_gflop_per_launch": round(c["flops"] / c["launches"] / 1e9, 3),
                            "achieved_by_pass": {"forward": tf(kt["conv_igemm_fwd"]), "input_grad": tf(kt["conv_igemm_dgrad"]),
                                                 "image_grad": tf(kt["conv_igemm_imggrad"])},
                            "device_ms_by_kernel": {k: round(v["ms"], 2) for k, v in kt.items()},
                            "wall_ms_timed_region": round(1e3 * elapsed, 2)}
-    if args.workload != "i2v":
+    if args.workload == "ilaf":
+        vg = _ilaf.model.graph_for((FRAMES, HW, HW))
+        vmac = vg.truncated(_ilaf.model.hook_tensors(vg)).macs_per_frame()          # per clip
+        out["metric"] = f"adversarial frames/sec ({_ilaf.steps}-step ILAF, {args.white_model} white-box, 32x224^2 clips)"
+        out["config"] = {"workload": f"ILAF fine-tune (BASELINE.json configs[4]): {b} clip(s) per call per GPU, {_ilaf.steps} sign "
+                                     f"steps of 0.005, eps=16/255, hooks of {args.white_model} (synthetic weights)",
+                         "frames_per_gpu": b * FRAMES, "attack_steps": _ilaf.steps,
+                         "parallelism": f"one clip stream per GPU x {world}, replicas only"}
+        out["algorithmic_gflop_per_frame"] = round((4 * _ilaf.steps + 4) * vmac / FRAMES / 1e9, 2)
+        out["end_to_end_tflops_per_gpu"] = round(value / world * (4 * _ilaf.steps + 4) * vmac / FRAMES / 1e12, 2)
+    elif args.workload != "i2v":
         models = "resnet50+vgg16+densenet121" if args.workload == "config2" else "resnet101+vgg16+squeezenet1_1+alexnet"
         out["metric"] = f"adversarial frames/sec (10-step {args.workload.upper()}-I2V, {models}, 32x224^2 clips)"
         out["config"]["workload"] = f"{args.workload} ensemble ({models}), batch={b} clips per GPU"

@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Drop-in for `/root/reference/image_fine_tune_attack.py`: ILAF fine-tuning of pre-generated adversarial clips
+against a white-box video model.  Same flags and defaults (`:40-54`), same inputs -- `--used_adv/{id}-adv.npy` with
+its clean partner `--used_ori/{id}-ori.npy` (`:16-37`) -- same artefact `--opt_path/{label}-adv.npy` (`:80-82`),
+one clip per call (`:73-79`).
+
+Differences: the white-box model is an `i2v_amd.video.VideoModel` (graph IR + weights; the reference builds a gluoncv
+module from a YACS config, `:58-66`), so `--white_model` is one of the names `graphs.build_video` knows and the whole
+ILAF loop runs in `libi2v_hip.so`; under `torchrun` the file list is dealt round-robin over the ranks (replicas only,
+no collective); `--steps` / `--step_size` expose ILAF's constructor defaults (60, 0.005; `image_attacks.py:502`);
+`--resume` skips clips whose output exists."""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+import image_attacks
+from i2v_amd.video import VideoModel
+
+
+class AdvDataset(object):
+    """`image_fine_tune_attack.py:16-37`."""
+
+    def __init__(self, used_adv_path, used_ori_path):
+        self.used_adv_path, self.used_ori_path = used_adv_path, used_ori_path
+        self.files = sorted(f for f in os.listdir(used_adv_path) if "adv" in f)
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, idx):
+        file = self.files[idx]
+        vid_id = file.split("-")[0]
+        vid = torch.from_numpy(np.load(os.path.join(self.used_adv_path, file)))[None]
+        ori_vid = torch.from_numpy(np.load(os.path.join(self.used_ori_path, "{}-ori.npy".format(vid_id))))[None]
+        label = torch.from_numpy(np.array([int(vid_id)]).astype(np.int32)).long()
+        return vid, ori_vid, label
+
+
+def arg_parse(argv=None):
+    parser = argparse.ArgumentParser(description="")
+    parser.add_argument("--gpu", type=str, default="0", help="gpu device.")
+    parser.add_argument("--batch_size", type=int, default=4, metavar="N")
+    parser.add_argument("--attack_method", type=str, default="ILAF", help="")
+    parser.add_argument("--opt_path", type=str, default="")
+    parser.add_argument("--used_adv", type=str, default="", help="")
+    parser.add_argument("--used_ori", type=str, default="", help="")
+    parser.add_argument("--white_model", type=str, default="i3d_resnet101",
+                        help="i3d_resnet50 | i3d_resnet101 | slowfast_resnet50 | slowfast_resnet101")
+    parser.add_argument("--dataset", type=str, default="Kinetics-400", help="Kinetics-400 | UCF-101")
+    # additions (not in the reference)
+    parser.add_argument("--steps", type=int, default=60)
+    parser.add_argument("--step_size", type=float, default=0.005)
+    parser.add_argument("--resume", action="store_true")
+    return parser.parse_args(argv)
+
+
+def main(argv=None, model_kwargs=None):
+    args = arg_parse(argv)
+    if "LOCAL_RANK" not in os.environ:
+        os.environ["LOCAL_RANK"] = args.gpu.split(",")[0]
+    print(args)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dataset = AdvDataset(args.used_adv, args.used_ori)
+    model = None
+    attack_method = None
+    os.makedirs(args.opt_path, exist_ok=True)
+    for step in range(rank, len(dataset), world):
+        print("Running {}, {}/{}".format(args.attack_method, step + 1, len(dataset)))
+        val_batch, ori_batch, val_label = dataset[step]
+        if args.resume and all(os.path.exists(os.path.join(args.opt_path, "{}-adv.npy".format(l.item()))) for l in val_label):
+            continue
+        if attack_method is None:                      # the clip shape decides the plan: build on first use
+            model = VideoModel(args.white_model, tuple(val_batch.shape[2:]), **(model_kwargs or {}))
+            attack_method = getattr(image_attacks, args.attack_method)(model, args.white_model, step_size=args.step_size,
+                                                                       steps=args.steps)
+        adv_batches = attack_method(val_batch, ori_batch, val_label, ["..."])
+        for ind, label in enumerate(val_label):
+            np.save(os.path.join(args.opt_path, "{}-adv".format(label.item())), adv_batches[ind].detach().cpu().numpy())
+    return attack_method
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,35 @@ def test_image_main_file_contract(tiny_engine, tmp_path, monkeypatch):
         image_main.main(["--num_clips", "1"])
 
 
+def test_image_fine_tune_attack_file_contract(tiny_engine, tmp_path):
+    """`{id}-adv.npy` + `{id}-ori.npy` in, `{label}-adv.npy` out (/root/reference/image_fine_tune_attack.py:16-37,73-82),
+    ILAF running natively on a (tiny) I3D graph."""
+    import image_fine_tune_attack as ift
+    adv_dir, ori_dir, out_dir = tmp_path / "adv", tmp_path / "ori", tmp_path / "out"
+    adv_dir.mkdir(); ori_dir.mkdir()
+    gen = torch.Generator().manual_seed(1)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1, 1)
+    for vid in (3, 17):
+        u8 = torch.randint(16, 240, (3, 8, 32, 32), generator=gen)
+        ori = (u8.float() / 255 - mean) / std
+        adv = ((u8 + torch.randint(-8, 9, u8.shape, generator=gen)).float() / 255 - mean) / std
+        np.save(ori_dir / f"{vid}-ori.npy", ori.numpy())
+        np.save(adv_dir / f"{vid}-adv.npy", adv.numpy())
+    argv = ["--used_adv", str(adv_dir), "--used_ori", str(ori_dir), "--opt_path", str(out_dir), "--white_model", "i3d_resnet50",
+            "--steps", "2"]
+    atk = ift.main(argv, model_kwargs=dict(tiny=True))
+    assert sorted(os.listdir(out_dir)) == ["17-adv.npy", "3-adv.npy"]
+    out = np.load(out_dir / "3-adv.npy")
+    assert out.dtype == np.float32 and out.shape == (3, 8, 32, 32)
+    assert list(atk.loss_info["..."].keys()) == [0, 1] and abs(float(atk.loss_info["..."][0]["cost"]) + 1.5) < 1e-4
+    before = os.path.getmtime(out_dir / "3-adv.npy")
+    assert ift.main(argv + ["--resume"], model_kwargs=dict(tiny=True)) is None      # nothing left to do
+    assert os.path.getmtime(out_dir / "3-adv.npy") == before
+    with pytest.raises(KeyError):
+        ift.main(argv[:-2] + ["--white_model", "tpn_resnet101"])
+
+
 def test_sample_list_fixture():
     """The reference's sample list (data fixture): 400 rows, one clip per class, labels 0..399."""
     from i2v_amd import clips
