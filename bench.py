@@ -168,7 +168,10 @@ def main():
         atk(videos, labels, names)
     torch.cuda.synchronize()
     timing = not args.no_kernel_timing
-    if timing:
+    # ILAF on one clip is ~3000 launches of ~30 us per call: bracketing each with an event pair costs ~20 %, so its
+    # per-kernel times come from ONE extra call after the timed region instead of from inside it
+    timing_outside = timing and args.workload == "ilaf"
+    if timing and not timing_outside:
         eng.timing_enable(True)
         atk(videos, labels, names)          # pre-create the event pool outside the timed region
         eng.timing_collect()
@@ -189,6 +192,10 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    if timing_outside:
+        eng.timing_enable(True)
+        atk(videos, labels, names); eng.timing_collect()      # event pool
+        atk(videos, labels, names)
     kt = eng.timing_collect() if timing else None
     if timing:
         eng.timing_enable(False)
@@ -226,6 +233,8 @@ def main():
                                                 "image_grad": tf(kt["conv_igemm_imggrad"])},
                            "device_ms_by_kernel": {k: round(v["ms"], 2) for k, v in kt.items()},
                            "wall_ms_timed_region": round(1e3 * elapsed, 2)}
+        if timing_outside:
+            out["roofline"]["note"] = "per-kernel times from one extra instrumented call after the timed region"
     if args.workload == "ilaf":
         vg = _ilaf.model.graph_for((FRAMES, HW, HW))
         vmac = vg.truncated(_ilaf.model.hook_tensors(vg)).macs_per_frame()          # per clip
