@@ -14,9 +14,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "i2v_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static thread_local char g_be_err[256];
 static thread_local bool g_be_has_err = false;
@@ -79,18 +82,23 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 // fragment is read from LDS; k == input channel for the 1x1 convolutions this is used on.
 // VID: the launch has temporal taps or a non-identity frame mapping (video networks, I2VConvParams::temporal);
 // image launches -- and the spatial / pointwise convolutions of video networks -- compile without any of it.
-template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false>
+// MF16: 16x16x4 MFMA fragments instead of 32x32x2 (same peak rate): for launches with <= 16 output rows -- the
+// class-packed image gradient (12 rows), 8/16-channel layers -- a 32-row tile would be mostly padding.
+template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false>
 __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-resource types and LDS-DMA builtins exist only in the device pass
     constexpr int KC = I2V_KC;
-    constexpr int TD = BD / WD / 32, TP = BP / WP / 32;
+    constexpr int FR = MF16 ? 16 : 32;                       // fragment edge
+    constexpr int NR = MF16 ? 4 : 16;                        // accumulator registers per fragment
+    constexpr int TD = BD / WD / FR, TP = BP / WP / FR;
+    static_assert(!(MF16 && (PRE || PREF)), "no pre-activation / prefetch variants of the 16x16 tile");
     // one LDS array: operand staging [2][KC][BD] + [2][KC][BP], re-used by the epilogue as a
     // [WD*32][BP] transpose buffer
 #ifndef I2V_STAGES
 #define I2V_STAGES 2        // LDS operand buffers (3 measured no faster: tools/conv_microbench.cpp -DI2V_STAGES=3): chunk c is consumed while chunks c+1 .. c+STAGES-1 are in flight
 #endif
     constexpr int NST = I2V_STAGES;
-    constexpr int STAGE_FLOATS = NST * KC * (BD + BP), EPI_FLOATS = WD * 32 * BP;
+    constexpr int STAGE_FLOATS = NST * KC * (BD + BP), EPI_FLOATS = WD * FR * BP;
     __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS];
     float (*As)[KC][BD] = reinterpret_cast<float (*)[KC][BD]>(smem);
     float (*Bs)[KC][BP] = reinterpret_cast<float (*)[KC][BP]>(smem + NST * KC * BD);
@@ -212,7 +220,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     }
 
     // ---- epilogue operand prefetch ----
-    constexpr int E_C4 = BP / 4, E_RSTEP = 1024 / BP, E_NQ = WD * 32 / E_RSTEP;
+    constexpr int E_C4 = BP / 4, E_RSTEP = 1024 / BP, E_NQ = WD * FR / E_RSTEP;
     static_assert(!PREF || TD == 1, "PREF needs a single epilogue pass");
     float4 pre0[PREF ? E_NQ : 1], pre1[PREF ? E_NQ : 1], pregate[PREF ? E_NQ : 1];
     if (PREF) {
@@ -234,16 +242,20 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         }
     }
 
-    f32x16 acc[TD][TP];
+    typedef typename std::conditional<MF16, f32x4, f32x16>::type acc_t;
+    acc_t acc[TD][TP];
 #pragma unroll
     for (int a = 0; a < TD; ++a)
 #pragma unroll
         for (int b = 0; b < TP; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < NR; ++r) acc[a][b][r] = 0.f;
 
     const int nchunks = p.Kpad / KC;
-    const int l31 = lane & 31, lk = lane >> 5;
+    // fragment coordinates of this lane: column (pixel) inside a fragment, K row inside a k-step, and the
+    // accumulator register -> fragment row map  (32x32x2: row = (r&3) + 8(r>>2) + 4(l>>5);  16x16x4: row = 4(l>>4) + r)
+    const int l31 = MF16 ? (lane & 15) : (lane & 31), lk = MF16 ? (lane >> 4) : (lane >> 5);
+#define I2V_FROW(r) (MF16 ? 4 * lk + (r) : ((r) & 3) + 8 * ((r) >> 2) + 4 * lk)
     // DMA pipeline, NST buffers deep: at the top of iteration c the wave waits only for ITS OWN loads of
     // chunk c (a counted vmcnt leaves the younger chunks in flight), the raw barrier then covers the other
     // waves' loads of chunk c and tells that every wave is done reading the buffer chunk c+NST-1 overwrites.
@@ -265,14 +277,15 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (c + NST - 1 < nchunks) I2V_ISSUE_CHUNK((c + NST - 1) * KC, nbuf);
-        constexpr int KS = KC / 2;                         // k-steps per chunk (2 K rows per 32x32x2 MFMA)
+        constexpr int KR = MF16 ? 4 : 2;                   // K rows per MFMA (32x32x2 / 16x16x4)
+        constexpr int KS = KC / KR;                        // k-steps per chunk
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             float fa[TD], fb[TP];
 #pragma unroll
-            for (int i = 0; i < TD; ++i) fa[i] = As[buf][2 * s + lk][wd * (BD / WD) + i * 32 + l31];
+            for (int i = 0; i < TD; ++i) fa[i] = As[buf][KR * s + lk][wd * (BD / WD) + i * FR + l31];
 #pragma unroll
-            for (int j = 0; j < TP; ++j) fb[j] = Bs[buf][2 * s + lk][wpx * (BP / WP) + j * 32 + l31];
+            for (int j = 0; j < TP; ++j) fb[j] = Bs[buf][KR * s + lk][wpx * (BP / WP) + j * FR + l31];
             if (PRE) {
                 typedef const __attribute__((address_space(4))) float* cfp;       // scalar (SMEM) loads
                 const int kr = c * KC + 2 * s;
@@ -284,8 +297,10 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
 #pragma unroll
             for (int i = 0; i < TD; ++i)
 #pragma unroll
-                for (int j = 0; j < TP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TP; ++j) {
+                    if constexpr (MF16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
         }
         buf = buf + 1 == NST ? 0 : buf + 1;
         nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
@@ -298,7 +313,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         // Dense output (grid == output plane, plane % 4 == 0): transpose the accumulators through LDS so
         // that each lane owns 4 consecutive pixels of one channel; addends, gate and result then move as
         // 16-byte accesses, 512 contiguous bytes per channel row.
-        constexpr int C4 = BP / 4, RSTEP = 1024 / BP, NQ = WD * 32 / RSTEP;
+        constexpr int C4 = BP / 4, RSTEP = 1024 / BP, NQ = WD * FR / RSTEP;
         const int c4 = t % C4, rbase = t / C4;
         const int64_t pp = px0 + (int64_t)c4 * 4;
         const bool pok = pp < P;
@@ -311,14 +326,14 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
 #pragma unroll
             for (int j = 0; j < TP; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    Cs[wd * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk][wpx * (BP / WP) + j * 32 + l31] = acc[i][j][r];
+                for (int r = 0; r < NR; ++r)
+                    Cs[wd * FR + I2V_FROW(r)][wpx * (BP / WP) + j * FR + l31] = acc[i][j][r];
             __syncthreads();
             if (pok) {
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const int row = rbase + q * RSTEP;
-                    const int cd = cd0 + (row >> 5) * (BD / WD) + i * 32 + (row & 31);
+                    const int cd = cd0 + (row / FR) * (BD / WD) + i * FR + (row % FR);
                     if (cd >= p.Cd) continue;
                     float4 v = *reinterpret_cast<const float4*>(&Cs[row][c4 * 4]);
                     const int64_t o = (int64_t)cd * HoWo + poff;
@@ -372,7 +387,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         const int bb = p.blk * p.blk, Creal = p.Cd / ((VID ? p.blkt : 1) * bb);
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
-            const int64_t pp = px0 + wpx * (BP / WP) + j * 32 + l31;
+            const int64_t pp = px0 + wpx * (BP / WP) + j * FR + l31;
             if (pp >= P) continue;
             const int64_t ng = pp / HWg;
             const int rem = (int)(pp - ng * HWg);
@@ -382,8 +397,8 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
 #pragma unroll
             for (int i = 0; i < TD; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int cd = cd0 + wd * (BD / WD) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                for (int r = 0; r < NR; ++r) {
+                    const int cd = cd0 + wd * (BD / WD) + i * FR + I2V_FROW(r);
                     if (cd >= p.Cd) continue;
                     const int cls3 = cd / Creal, c = cd - cls3 * Creal;
                     const int ct = VID ? cls3 / bb : 0, cls = cls3 - ct * bb;
@@ -403,7 +418,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     }
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
-        const int64_t pp = px0 + wpx * (BP / WP) + j * 32 + l31;
+        const int64_t pp = px0 + wpx * (BP / WP) + j * FR + l31;
         if (pp >= P) continue;
         const int64_t ng = pp / HWg;
         const int rem = (int)(pp - ng * HWg);
@@ -435,8 +450,8 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
 #pragma unroll
         for (int i = 0; i < TD; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cd = cd0 + wd * (BD / WD) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            for (int r = 0; r < NR; ++r) {
+                const int cd = cd0 + wd * (BD / WD) + i * FR + I2V_FROW(r);
                 if (cd >= p.Cd) continue;
                 float v = acc[i][j][r];
                 if (p.gate_scale && !(fmaf(mk[(int64_t)cd * HoWo], p.gate_scale[cd], p.gate_shift[cd]) > 0.f)) v = 0.f;
@@ -449,6 +464,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
             }
         }
     }
+#undef I2V_FROW
 #endif
 }
 
@@ -458,7 +474,7 @@ static bool conv_wants_prefetch(const I2VConvParams& p) {
     return p.vec_epilogue && !p.gate_scale && !p.pre_scale && p.add0_stride == 1 && (p.add0 || p.add1 || p.mask) && p.Kpad <= 256 && (p.pointwise || p.tap_uniform) && p.Cd > 32;
 }
 
-template <int BD, int BP, int WD, int WP>
+template <int BD, int BP, int WD, int WP, bool MF16 = false>
 static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     const int64_t P = (int64_t)p.N * p.Hg * p.Wg;
     const int n_cd = (p.Cd + BD - 1) / BD;
@@ -466,7 +482,14 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     const int64_t grid = n_px * n_cd;
     if (grid <= 0) return 0;
     if (grid > 0x7fffffff) { snprintf(g_be_err, sizeof g_be_err, "conv grid too large"); g_be_has_err = true; return 1; }
-    if (p.pre_scale) {
+    if constexpr (MF16) {
+        if (p.pre_scale) { snprintf(g_be_err, sizeof g_be_err, "pre-activation convolutions have no 16-row variant"); g_be_has_err = true; return 1; }
+        if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 1, false, false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+        else if (p.tap_uniform && p.temporal) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2, false, false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+        else if (p.tap_uniform) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 2, false, false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+        else if (p.temporal) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 0, false, false, true, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+        else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 0, false, false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+    } else if (p.pre_scale) {
         if (p.temporal) { snprintf(g_be_err, sizeof g_be_err, "pre-activation convolutions have no temporal variant"); g_be_has_err = true; return 1; }
         if constexpr ((BD == 64 && BP == 64) || (BD == 128 && BP == 128)) {
             if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 1, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
@@ -494,6 +517,7 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
 static int conv_pick(const I2VConvParams& p) {
     static const char* force = getenv("I2V_FORCE_CFG");        // developer knob (tools/conv_microbench.cpp)
     if (force && *force) return atoi(force);
+    if (p.Cd <= 16 && !p.pre_scale) return 5;        // 16-row fragments: no padding rows to speak of
     if (conv_wants_prefetch(p)) return 3;
     if (p.pre_scale) {              // pre-activation variants exist for the 128x128 and 64x64 tiles only
         const double blocks128 = ceil(p.Cd / 128.0) * ceil((double)p.N * p.Hg * p.Wg / 128.0);
@@ -534,6 +558,7 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
         out[n++] = i;
     }
     if (conv_wants_prefetch(p)) out[n++] = 3 | 8;       // 64x64 WITHOUT the epilogue-operand prefetch
+    if (p.Cd <= 16) out[n++] = 5;                        // 16x256 tile on 16x16x4 MFMA fragments
     return n;
 }
 
@@ -544,6 +569,7 @@ int k_conv(const I2VConvParams& p, i2v_stream_t s) {
         case 1: return launch_conv_cfg<64, 128, 2, 2>(p, st);
         case 2: return launch_conv_cfg<128, 64, 2, 2>(p, st);
         case 3: return launch_conv_cfg<64, 64, 2, 2>(p, st);
+        case 5: return launch_conv_cfg<16, 256, 1, 4, true>(p, st);
         default: return launch_conv_cfg<32, 256, 1, 4>(p, st);
     }
 }
