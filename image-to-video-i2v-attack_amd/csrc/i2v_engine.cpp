@@ -67,6 +67,7 @@ struct Node {
     bool preact() const { return !pre_scale.empty(); }
     Packed fwd; std::vector<Packed> bwd;
     Packed img; int img_blk = 0, img_sh = 1, img_blkt = 1;   // input-gradient of the first conv (class-packed)
+    int img_ost = 1, img_ot0 = 0;                            // its temporal output stride / offset
     size_t idx_off = 0;                           // maxpool: arg-max bytes, arena offset in floats
 };
 
@@ -78,6 +79,7 @@ struct Launch {
     bool src_is_input = false;     // conv: src pointer patched with the caller's x
     bool img_accumulate = false;   // L_IMGGRAD of a second convolution reading the input (two-pathway stems): gx += ...
     float* ms_ptr = nullptr; size_t ms_floats_per_frame = 0;   // L_MEMSET
+    bool ms_gx = false;            // L_MEMSET of the caller's gradient output (skipped when accumulating)
     double alg_flops_per_frame = 0; // L_IMGGRAD: algorithmic (not class-padded) flops
 };
 
@@ -205,9 +207,21 @@ static int pack_img(Net& n, Node& nd) {
     const Buffer& sb = n.bufs[n.tens[c.src].buf];
     const Buffer& db = n.bufs[n.tens[c.dst].buf];
     const int st = c.stride, B = st == 1 ? 2 : st, m = B / st;
-    const int stt = c.stride_t, Bt = stt;                  // temporal classes: one per stride residue (1 for images)
+    const int stt = c.stride_t;
+    // temporal classes: one per stride residue (1 for images).  A stem that samples every stt-th frame with a
+    // kernel that reaches no other residue (SlowFast's slow pathway: kt = 1) has taps in ONE class only: then
+    // only that class is packed (grid = the sampled frames, output stride stt) and the frames in between are
+    // zero-filled by a memset instead of being computed as stt - 1 classes of zero weights.
+    int with_taps = 0, only = 0;
+    for (int ct = 0; ct < stt; ++ct) {
+        bool any = false;
+        for (int q = 0; q < c.kt; ++q) if (posmod(ct + c.pad_t - q * c.dil_t, stt) == 0) any = true;
+        if (any) { with_taps++; only = ct; }
+    }
+    const bool sparse = stt > 1 && with_taps == 1;
+    const int Bt = sparse ? 1 : stt, ct0 = sparse ? only : 0;
     int dt_lo = 1 << 30, dt_hi = -(1 << 30), dh_lo = 1 << 30, dh_hi = -(1 << 30), dw_lo = 1 << 30, dw_hi = -(1 << 30);
-    for (int ct = 0; ct < Bt; ++ct)
+    for (int ct = ct0; ct < ct0 + Bt; ++ct)
         for (int q = 0; q < c.kt; ++q)
             if (posmod(ct + c.pad_t - q * c.dil_t, stt) == 0) { int d = floordiv(ct + c.pad_t - q * c.dil_t, stt); dt_lo = d < dt_lo ? d : dt_lo; dt_hi = d > dt_hi ? d : dt_hi; }
     for (int ph = 0; ph < B; ++ph)
@@ -221,8 +235,8 @@ static int pack_img(Net& n, Node& nd) {
     P.K = TT * TH * TW * c.cout; P.Kpad = (int)align_up(P.K, I2V_KC);
     P.Cd = Bt * B * B * c.cin; P.Cdpad = (int)align_up(P.Cd, 128);
     P.tap_uniform = (c.cout % I2V_KC == 0) ? 1 : 0;
-    P.Tg = (sb.T + Bt - 1) / Bt; P.Hg = (sb.H + B - 1) / B; P.Wg = (sb.W + B - 1) / B;
-    nd.img_blk = B; nd.img_sh = m; nd.img_blkt = Bt;
+    P.Tg = sparse ? (sb.T - ct0 + stt - 1) / stt : (sb.T + Bt - 1) / Bt; P.Hg = (sb.H + B - 1) / B; P.Wg = (sb.W + B - 1) / B;
+    nd.img_blk = B; nd.img_sh = m; nd.img_blkt = Bt; nd.img_ost = sparse ? stt : Bt; nd.img_ot0 = ct0;
     std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
     std::vector<I2VKEntry> kt(P.Kpad, I2VKEntry{0, 0, 0, 0});
     // K order = (tap, channel): chunk-uniform taps (MODE 2).  (Channel-major order would cut the L2
@@ -232,8 +246,9 @@ static int pack_img(Net& n, Node& nd) {
         for (int tw = 0; tw < TW; ++tw)
             for (int co = 0; co < c.cout; ++co)
                 kt[((tt * TH + th) * TW + tw) * c.cout + co] = I2VKEntry{co * db.H * db.W, th + dh_lo, tw + dw_lo, 1 + 2 * (tt + dt_lo)};
-    for (int ct = 0; ct < Bt; ++ct)
+    for (int cc = 0; cc < Bt; ++cc)
     for (int q = 0; q < c.kt; ++q) {
+        const int ct = ct0 + cc;
         if (posmod(ct + c.pad_t - q * c.dil_t, stt)) continue;
         const int tt = floordiv(ct + c.pad_t - q * c.dil_t, stt) - dt_lo;
         for (int ph = 0; ph < B; ++ph)
@@ -246,7 +261,7 @@ static int pack_img(Net& n, Node& nd) {
                         const int tw = floordiv(pw + c.pad - s, st) - dw_lo;
                         for (int co = 0; co < c.cout; ++co)
                             for (int ci = 0; ci < c.cin; ++ci)
-                                wp[(size_t)(((tt * TH + th) * TW + tw) * c.cout + co) * P.Cdpad + ((ct * B + ph) * B + pw) * c.cin + ci] =
+                                wp[(size_t)(((tt * TH + th) * TW + tw) * c.cout + co) * P.Cdpad + ((cc * B + ph) * B + pw) * c.cin + ci] =
                                     nd.w[((((size_t)co * c.cin + ci) * c.kt + q) * c.kh + r) * c.kw + s];
                     }
                 }
@@ -664,6 +679,13 @@ struct Planner {
             if (consumed || accum[n.tens[t].buf]) { View g = view(t, true); hook_tmp[hk] = temp(nf(g.T) * g.C * g.H * g.W); }
         }
         // ---------------- backward ----------------
+        for (const Node& nd : n.nodes)
+            if (nd.type == 0 && nd.cd.src == n.input && nd.img_ost != nd.img_blkt) {     // a stem gradient that skips frames
+                const Buffer& ib = n.bufs[n.tens[n.input].buf];
+                Launch l; l.kind = L_MEMSET; l.ms_gx = true; l.ms_floats_per_frame = (size_t)ib.C * ib.H * ib.W; l.T = ib.T;
+                emit(n.bwd, l);
+                break;
+            }
         for (size_t b = 0; b < n.bufs.size(); ++b)
             if (accum[b]) {
                 Launch l; l.kind = L_MEMSET;
@@ -703,7 +725,7 @@ struct Planner {
                     p.Hg = nd.img.Hg; p.Wg = nd.img.Wg; p.sh = p.sw = nd.img_sh;
                     p.dst = nullptr; p.dst_nstride = (int64_t)ib.C * ib.H * ib.W; p.Ho = ib.H; p.Wo = ib.W;
                     p.osh = p.osw = nd.img_blk; p.blk = nd.img_blk;
-                    p.blkt = nd.img_blkt; p.Tg = nd.img.Tg; p.Ts = dz.T; p.st = 1; p.To = ib.T; p.ost = nd.img_blkt; l.T = nd.img.Tg;
+                    p.blkt = nd.img_blkt; p.Tg = nd.img.Tg; p.Ts = dz.T; p.st = 1; p.To = ib.T; p.ost = nd.img_ost; p.ot0 = nd.img_ot0; l.T = nd.img.Tg;
                     l.alg_flops_per_frame = 2.0 * dz.T * dz.H * dz.W * c.cout * c.cin * c.kt * c.kh * c.kw / nd.img.Tg;   // per grid frame
                     emit(n.bwd, l);
                 } else if (nd.preact()) {
@@ -916,11 +938,27 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
                 if (conv_run(l, frames, x, gx, accumulate, s)) return 1;
             } break;
             case L_POOLF: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool_fwd(p, s)); } break;
-            case L_POOL3F: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool3d_fwd(p, s)); } break;
-            case L_POOL3B: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool3d_bwd(p, s)); } break;
+            // A 1 x k x k window with temporal stride st over Ts = st*To frames is the image pooling kernel on every
+            // st-th frame (frame stride * st); its backward leaves the skipped frames zero.
+            case L_POOL3F: {
+                I2VPoolParams p = l.pool; p.N = frames;
+                if (p.kt == 1 && p.pad_t == 0 && p.Ts == p.stride_t * p.To) { p.x_nstride *= p.stride_t; CHECK_BE(k_pool_fwd(p, s)); }
+                else CHECK_BE(k_pool3d_fwd(p, s));
+            } break;
+            case L_POOL3B: {
+                I2VPoolParams p = l.pool; p.N = frames;
+                if (p.kt == 1 && p.pad_t == 0 && p.Ts == p.stride_t * p.To && p.gx_nstride == (int64_t)p.C * p.Hs * p.Ws) {
+                    CHECK_BE(be_memset0(p.gx, (size_t)frames * p.stride_t * p.gx_nstride * sizeof(float), s));
+                    p.x_nstride *= p.stride_t; p.gx_nstride *= p.stride_t;
+                    CHECK_BE(k_pool_bwd(p, s));
+                } else CHECK_BE(k_pool3d_bwd(p, s));
+            } break;
             case L_AVGF: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_avgpool_fwd(p, s)); } break;
             case L_AVGB: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_avgpool_bwd(p, s)); } break;
-            case L_MEMSET: CHECK_BE(be_memset0(l.ms_ptr, l.ms_floats_per_frame * frames * sizeof(float), s)); break;
+            case L_MEMSET:
+                if (!l.ms_gx) CHECK_BE(be_memset0(l.ms_ptr, l.ms_floats_per_frame * frames * sizeof(float), s));
+                else if (!accumulate) CHECK_BE(be_memset0(gx, l.ms_floats_per_frame * frames * sizeof(float), s));
+                break;
             case L_CONVB_UNUSED: break;
             case L_POOLB: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool_bwd(p, s)); } break;
             case L_ADDMASK: { I2VAddMaskParams p = l.am; p.N = frames; CHECK_BE(k_addmask(p, s)); } break;

@@ -77,6 +77,32 @@ def test_image_fine_tune_attack_file_contract(tiny_engine, tmp_path):
         ift.main(argv[:-2] + ["--white_model", "tpn_resnet101"])
 
 
+def test_image_fine_tune_attack_rank_sharding(tiny_engine, tmp_path, monkeypatch):
+    """ILAF shards as replicas only: under torchrun the clip files are dealt round-robin over the
+    ranks, no collective; the union over ranks is every clip exactly once and equals the single-process result."""
+    import image_fine_tune_attack as ift
+    adv_dir, ori_dir = tmp_path / "adv", tmp_path / "ori"
+    adv_dir.mkdir(); ori_dir.mkdir()
+    gen = torch.Generator().manual_seed(2)
+    for vid in (1, 4, 9):
+        ori = torch.rand(3, 8, 32, 32, generator=gen)
+        np.save(ori_dir / f"{vid}-ori.npy", ori.numpy())
+        np.save(adv_dir / f"{vid}-adv.npy", (ori + 0.05 * torch.randn(3, 8, 32, 32, generator=gen)).numpy())
+    base = ["--used_adv", str(adv_dir), "--used_ori", str(ori_dir), "--white_model", "slowfast_resnet50", "--steps", "1"]
+    ift.main(base + ["--opt_path", str(tmp_path / "single")], model_kwargs=dict(tiny=True))
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    done = []
+    for rank in (0, 1):
+        monkeypatch.setenv("RANK", str(rank))
+        out = tmp_path / f"r{rank}"
+        ift.main(base + ["--opt_path", str(out)], model_kwargs=dict(tiny=True))
+        done.append(sorted(os.listdir(out)))
+    assert done == [["1-adv.npy", "9-adv.npy"], ["4-adv.npy"]]
+    for rank, files in enumerate(done):
+        for f in files:
+            assert np.array_equal(np.load(tmp_path / f"r{rank}" / f), np.load(tmp_path / "single" / f))
+
+
 def test_sample_list_fixture():
     """The reference's sample list (data fixture): 400 rows, one clip per class, labels 0..399."""
     from i2v_amd import clips
