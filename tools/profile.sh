@@ -11,6 +11,8 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- $CMD 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- $CMD > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/mfma -o m --output-format csv -- $CMD > $OUT/mfma.log 2>&1
+# second workload: ILAF on the SlowFast graph (BASELINE.json configs[4]) -- kernel stats only
+rocprofv3 --kernel-trace --stats -d $OUT/ilaf -o i --output-format csv -- python3 $R/bench.py --workload ilaf --steps 2 --warmup 1 --no-kernel-timing > $OUT/ilaf.log 2>&1
 cd $R
 tail -1 $OUT/stats.log | cut -c1-200
 ls $OUT/*/

@@ -20,6 +20,10 @@ def find(sub, suffix):
 
 
 shutil.copy(find("stats", "kernel_stats.csv"), f"profiles/{tag}_kernel_stats.csv")
+try:
+    shutil.copy(find("ilaf", "kernel_stats.csv"), f"profiles/{tag}_ilaf_kernel_stats.csv")
+except FileNotFoundError:
+    pass
 
 
 def short(name):
