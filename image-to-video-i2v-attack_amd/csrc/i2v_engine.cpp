@@ -138,11 +138,16 @@ static int pack_fwd(Net& n, Node& nd) {
     P.tap_uniform = (c.cin % I2V_KC == 0) ? 1 : 0;
     std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
     std::vector<I2VKEntry> kt(P.Kpad, I2VKEntry{0, 0, 0, 0});
+    // K order: (16-channel chunk, tap, channel in chunk) when the channel count allows -- each 16-row chunk keeps a
+    // single tap (MODE 2) and consecutive chunks re-read the same 16 channels at the next tap, a few KB apart in
+    // the cache instead of a full channel sweep apart -- else (tap, channel).
+    const int NT = c.kt * c.kh * c.kw;
     for (int q = 0; q < c.kt; ++q)
         for (int r = 0; r < c.kh; ++r)
             for (int s = 0; s < c.kw; ++s)
                 for (int ci = 0; ci < c.cin; ++ci) {
-                    int k = ((q * c.kh + r) * c.kw + s) * c.cin + ci;
+                    const int tap = (q * c.kh + r) * c.kw + s;
+                    int k = P.tap_uniform ? ((ci / I2V_KC) * NT + tap) * I2V_KC + ci % I2V_KC : tap * c.cin + ci;
                     kt[k] = I2VKEntry{ci * sb.H * sb.W, r - c.pad, s - c.pad, 1 + 2 * (q * c.dil_t - c.pad_t)};
                     for (int co = 0; co < c.cout; ++co)
                         wp[(size_t)k * P.Cdpad + co] = nd.w[((((size_t)co * c.cin + ci) * c.kt + q) * c.kh + r) * c.kw + s];
@@ -176,13 +181,14 @@ static int pack_bwd(Net& n, Node& nd) {
             std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
             std::vector<I2VKEntry> kt(P.Kpad ? P.Kpad : 1, I2VKEntry{0, 0, 0, 0});
             int t = 0;
+            const int NTc = (int)(tq.size() * tr.size() * ts.size());
             for (int q : tq)
             for (int r : tr)
                 for (int s : ts) {
                     int dt = floordiv(pt + c.pad_t - q * c.dil_t, stt);
                     int dh = floordiv(ph + c.pad - r, st), dw = floordiv(pw + c.pad - s, st);
                     for (int co = 0; co < c.cout; ++co) {
-                        int k = t * c.cout + co;
+                        int k = P.tap_uniform ? ((co / I2V_KC) * NTc + t) * I2V_KC + co % I2V_KC : t * c.cout + co;
                         kt[k] = I2VKEntry{co * db.H * db.W, dh, dw, 1 + 2 * dt};
                         for (int ci = 0; ci < c.cin; ++ci)
                             wp[(size_t)k * P.Cdpad + ci] =
@@ -239,13 +245,19 @@ static int pack_img(Net& n, Node& nd) {
     nd.img_blk = B; nd.img_sh = m; nd.img_blkt = Bt; nd.img_ost = sparse ? stt : Bt; nd.img_ot0 = ct0;
     std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
     std::vector<I2VKEntry> kt(P.Kpad, I2VKEntry{0, 0, 0, 0});
-    // K order = (tap, channel): chunk-uniform taps (MODE 2).  (Channel-major order would cut the L2
-    // over-fetch of the 16 taps but needs the per-row table path, which measured 1.7x slower.)
+    // K order = (16-channel chunk, tap, channel in chunk) when the channel count allows: every 16-row K chunk
+    // still has ONE tap (MODE 2), and a block sweeps all taps of 16 channels before moving on, so the taps'
+    // overlapping reads of `dz` are a few KB apart instead of a full 64-channel sweep apart (the co-resident
+    // blocks' halos then fit the L2).  Otherwise (tap, channel).
+    const int NT = TT * TH * TW;
+    auto krow = [&](int tap, int co) {
+        return P.tap_uniform ? ((co / I2V_KC) * NT + tap) * I2V_KC + co % I2V_KC : tap * c.cout + co;
+    };
     for (int tt = 0; tt < TT; ++tt)
     for (int th = 0; th < TH; ++th)
         for (int tw = 0; tw < TW; ++tw)
             for (int co = 0; co < c.cout; ++co)
-                kt[((tt * TH + th) * TW + tw) * c.cout + co] = I2VKEntry{co * db.H * db.W, th + dh_lo, tw + dw_lo, 1 + 2 * (tt + dt_lo)};
+                kt[krow((tt * TH + th) * TW + tw, co)] = I2VKEntry{co * db.H * db.W, th + dh_lo, tw + dw_lo, 1 + 2 * (tt + dt_lo)};
     for (int cc = 0; cc < Bt; ++cc)
     for (int q = 0; q < c.kt; ++q) {
         const int ct = ct0 + cc;
@@ -261,7 +273,7 @@ static int pack_img(Net& n, Node& nd) {
                         const int tw = floordiv(pw + c.pad - s, st) - dw_lo;
                         for (int co = 0; co < c.cout; ++co)
                             for (int ci = 0; ci < c.cin; ++ci)
-                                wp[(size_t)(((tt * TH + th) * TW + tw) * c.cout + co) * P.Cdpad + ((cc * B + ph) * B + pw) * c.cin + ci] =
+                                wp[(size_t)krow((tt * TH + th) * TW + tw, co) * P.Cdpad + ((cc * B + ph) * B + pw) * c.cin + ci] =
                                     nd.w[((((size_t)co * c.cin + ci) * c.kt + q) * c.kh + r) * c.kw + s];
                     }
                 }
