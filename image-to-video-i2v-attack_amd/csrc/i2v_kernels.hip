@@ -515,8 +515,8 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
 // time is fixed by its tile; what varies is how evenly the grid covers the 256 CUs (the 14x14 layers
 // have only a few hundred 128x128 tiles) against the extra operand traffic of small tiles.
 static int conv_pick(const I2VConvParams& p) {
-    static const char* force = getenv("I2V_FORCE_CFG");        // developer knob (tools/conv_microbench.cpp)
-    if (force && *force) return atoi(force);
+    const char* force = getenv("I2V_FORCE_CFG");     // developer / test knob (only consulted for launches the autotuner did not pin)
+    if (force && *force) { const int f = atoi(force); return (p.pre_scale && f != 0 && f != 3) ? 3 : f; }
     if (p.Cd <= 16 && !p.pre_scale) return 5;        // 16-row fragments: no padding rows to speak of
     if (conv_wants_prefetch(p)) return 3;
     if (p.pre_scale) {              // pre-activation variants exist for the 128x128 and 64x64 tiles only

@@ -217,3 +217,33 @@ def test_native_ilaf_full_size_against_oracle(eng):
     assert abs(atk.last_costs[0] + 1.5 * 2) < 1e-4          # two hooked layers, each -(0.5 + 1) at the start
     assert float((out - ref).abs().mean()) < 2e-3
     assert float((out != ref).float().mean()) < 0.05        # sign steps: pixels differ only where |g| ~ 0
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+def test_every_tile_configuration(eng, cfg, monkeypatch):
+    """Each of the six block-tile configurations of conv_igemm -- 128x128, 64x128, 128x64, 64x64, 32x256 and the
+    16x256 tile on 16x16x4 MFMA fragments -- forced onto EVERY launch (autotuner off), image and video graphs: the tile
+    must never change results beyond fp32 rounding, whichever one the autotuner happens to pick elsewhere."""
+    monkeypatch.setenv("I2V_AUTOTUNE", "0")
+    monkeypatch.setenv("I2V_FORCE_CFG", str(cfg))
+    for mt in ("i3d_resnet50", "slowfast_resnet50"):
+        gx, ref = run_backbone(eng, mt, (8, 32, 32), 2, True)
+        assert (gx - ref).abs().max() <= 1e-4 * ref.abs().max()
+    for model, depth in (("resnet", 3), ("squeezenet", 2), ("densenet121", 2)):
+        g = graphs.build_tiny(model, (64, 64))
+        sd = weights.synthetic_state_dict(g, 3)
+        hooks = [g.hooks[depth]]
+        net = eng.build_net(g, sd, hooks, 3)
+        onet = restate.OracleNet(g, sd, hooks, dtype=torch.float64)
+        torch.manual_seed(cfg)
+        x = torch.randn(3, 3, 64, 64)
+        feats = onet.forward(x.double())
+        net.forward(dev(x))
+        assert torch.allclose(net.save_hook(0, 3).cpu().double(), feats[0], rtol=1e-4, atol=1e-5)
+        hg = [torch.randn_like(f) for f in feats]
+        write_hook_grads(net, feats, hg)
+        gx = torch.empty(3, 3, 64, 64, device="cuda:0")
+        net.backward(gx)
+        ref = onet.backward(hg)
+        assert (gx.cpu().double() - ref).abs().max() <= 1e-4 * ref.abs().max()
+        net.close()
