@@ -1,0 +1,87 @@
+#!/usr/bin/env python
+"""Drop-in for `/root/reference/attack.py` restricted to `--attack_type image`: white-box FGSM / BIM / MIFGSM
+(`base_attacks.py:236-340`) on a video classifier, writing the pairs ILAF fine-tunes --
+`{model}-{method}-{step}-{prefix}/{label}-adv.npy` and `{label}-ori.npy` (`:102-108`).
+
+Kept: the flags that drive this path and their defaults (`--gpu --batch_size --model --attack_method --attack_type
+--step --file_prefix`, `:15-34`; the other flags of the reference parameterise `video_attacks.py`, which is outside
+the hot path, and are accepted and ignored), the per-batch call `attack_method(val_batch, val_label)` and both
+artefacts per clip.  The update rule runs in `libi2v_hip.so` (`i2v_sign_step_f32`); the classifier and its
+cross-entropy gradient are PyTorch, exactly as in the reference -- gluoncv's Kinetics-400 models are not vendored, so
+the classifier comes from a factory like the evaluator's (`reference.py`): `--model_factory pkg.module:function`,
+a callable `name -> torch.nn.Module` on normalised (b,3,f,h,w) clips; default `reference:proxy`.
+`OPT_PATH` is `$I2V_OPT_PATH`; clips come from `i2v_amd.clips` (synthetic or `--clip_dir`)."""
+import argparse
+import importlib
+import os
+
+import numpy as np
+import torch
+
+import base_attacks
+from i2v_amd import clips
+
+OPT_PATH = os.environ.get("I2V_OPT_PATH", "")
+IGNORED = ["--sf_frame", "--cf_frame", "--kernlen", "--nsig", "--kernel_mode", "--augmentation_weight", "--gamma",
+           "--momentum_weight", "--move_type"]
+IGNORED_FLAGS = ["--iterative_momentum", "--frame_conv", "--frame_momentum", "--no_iterative_momentum", "--weight_add",
+                 "--iterative_first", "--translation_invariant", "--temporal_augmentation", "--TI_First", "--noise",
+                 "--shuffle_grads"]
+
+
+def arg_parse(argv=None):
+    parser = argparse.ArgumentParser(description="")
+    parser.add_argument("--gpu", type=str, default="0", help="gpu device.")
+    parser.add_argument("--batch_size", type=int, default=4, metavar="N")
+    parser.add_argument("--model", type=str, default="i3d_resnet101")
+    parser.add_argument("--attack_method", type=str, default="TemporalAugmentationMomentum", help="FGSM | BIM | MIFGSM")
+    parser.add_argument("--attack_type", type=str, default="image", help="image | video")
+    parser.add_argument("--step", type=int, default=10, metavar="N")
+    parser.add_argument("--file_prefix", type=str, default="")
+    for f in IGNORED:
+        parser.add_argument(f, default=None, help="video_attacks.py parameter (out of scope, ignored)")
+    for f in IGNORED_FLAGS:
+        parser.add_argument(f, action="store_true", default=False, help="video_attacks.py switch (out of scope, ignored)")
+    # additions (not in the reference)
+    parser.add_argument("--model_factory", type=str, default="reference:proxy")
+    parser.add_argument("--num_classes", type=int, default=400)
+    parser.add_argument("--anno", type=str, default=os.environ.get("I2V_ANNO", ""))
+    parser.add_argument("--clip_dir", type=str, default="")
+    parser.add_argument("--num_clips", type=int, default=400)
+    parser.add_argument("--frames", type=int, default=32)
+    parser.add_argument("--hw", type=int, default=224)
+    args = parser.parse_args(argv)
+    args.adv_path = os.path.join(OPT_PATH, "{}-{}-{}-{}".format(args.model, args.attack_method, args.step, args.file_prefix))
+    os.makedirs(args.adv_path, exist_ok=True)
+    return args
+
+
+def main(argv=None):
+    args = arg_parse(argv)
+    if "LOCAL_RANK" not in os.environ:
+        os.environ["LOCAL_RANK"] = args.gpu.split(",")[0]
+    print(args)
+    if args.attack_type != "image":
+        raise NotImplementedError("--attack_type video drives video_attacks.py, which is outside this build's hot path")
+    mod, fn = args.model_factory.split(":")
+    dev = torch.device(f"cuda:{os.environ['LOCAL_RANK']}" if torch.cuda.is_available() else "cpu")
+    model = getattr(importlib.import_module(mod), fn)(args.model).to(dev)
+    attack_method = getattr(base_attacks, args.attack_method)(model, steps=args.step)   # AttributeError for the default name, as in the reference (:22)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    total = clips.num_batches(args.batch_size, args.anno, args.clip_dir, args.num_clips)
+    for step, (val_batch, val_label, _) in enumerate(clips.batches(args.batch_size, args.anno, args.clip_dir, args.frames,
+                                                                    args.hw, args.num_clips)):
+        if step % world != rank:
+            continue
+        print("Running {}, {}/{}".format(args.attack_method, step + 1, total))
+        val_batch, val_label = val_batch.to(dev), val_label.to(dev)
+        adv_batches = attack_method(val_batch, val_label % args.num_classes)
+        val_batch = val_batch.detach()
+        for ind, label in enumerate(val_label):
+            np.save(os.path.join(args.adv_path, "{}-adv".format(label.item())), adv_batches[ind].cpu().numpy())
+            np.save(os.path.join(args.adv_path, "{}-ori".format(label.item())), val_batch[ind].cpu().numpy())
+    return args.adv_path
+
+
+if __name__ == "__main__":
+    main()

@@ -77,6 +77,31 @@ def test_image_fine_tune_attack_file_contract(tiny_engine, tmp_path):
         ift.main(argv[:-2] + ["--white_model", "tpn_resnet101"])
 
 
+def test_attack_cli_feeds_fine_tune(tiny_engine, tmp_path, monkeypatch):
+    """`attack.py --attack_type image` writes `{label}-adv.npy` + `{label}-ori.npy` (/root/reference/attack.py:102-108)
+    within eps of each other, and `image_fine_tune_attack.py` consumes exactly that directory."""
+    monkeypatch.setenv("I2V_OPT_PATH", str(tmp_path))
+    import importlib
+    import attack as attack_cli
+    importlib.reload(attack_cli)
+    out = attack_cli.main(["--attack_method", "BIM", "--step", "2", "--model", "i3d_resnet50", "--num_clips", "2", "--batch_size", "1",
+                           "--frames", "32", "--hw", "16", "--file_prefix", "t", "--kernlen", "15", "--noise"])
+    assert out == str(tmp_path / "i3d_resnet50-BIM-2-t")
+    assert sorted(os.listdir(out)) == ["0-adv.npy", "0-ori.npy", "1-adv.npy", "1-ori.npy"]
+    adv, ori = np.load(os.path.join(out, "1-adv.npy")), np.load(os.path.join(out, "1-ori.npy"))
+    assert adv.shape == ori.shape == (3, 32, 16, 16) and adv.dtype == np.float32
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(3, 1, 1, 1)
+    assert 0 < np.abs((adv - ori) * std).max() <= 16 / 255 + 1e-6
+    with pytest.raises(AttributeError):
+        attack_cli.main(["--num_clips", "1", "--frames", "32", "--hw", "16"])          # the reference's default method name does not exist
+    with pytest.raises(NotImplementedError):
+        attack_cli.main(["--attack_type", "video", "--attack_method", "BIM"])
+    import image_fine_tune_attack as ift
+    ift.main(["--used_adv", out, "--used_ori", out, "--opt_path", str(tmp_path / "ft"), "--white_model", "slowfast_resnet50",
+              "--steps", "1"], model_kwargs=dict(tiny=True))
+    assert sorted(os.listdir(tmp_path / "ft")) == ["0-adv.npy", "1-adv.npy"]
+
+
 def test_image_fine_tune_attack_rank_sharding(tiny_engine, tmp_path, monkeypatch):
     """ILAF shards as replicas only: under torchrun the clip files are dealt round-robin over the
     ranks, no collective; the union over ranks is every clip exactly once and equals the single-process result."""
