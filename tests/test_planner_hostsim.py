@@ -101,6 +101,28 @@ def test_ens_and_aens_against_golden():
         assert cost_saved.dtype == np.float64 and used_time >= 0
 
 
+def test_aens_coefficients_persist_across_calls():
+    """`self.coeffs` lives on the attack object and carries over to the next call (TPAMI_attack.py:165,265): two calls
+    of the product class against the oracle run twice with the coefficients handed on (the oracle itself is pinned to
+    the reference for this in tests/test_oracle_vs_reference.py)."""
+    fx = dict(models=["resnet", "squeezenet"], depth={"resnet": [2, 3], "squeezenet": [2, 3]}, hw=64, wseed=0)
+    vid = gu.videos_of({"clip_u8": torch.randint(0, 256, (1, 3, 2, 64, 64), generator=torch.Generator().manual_seed(41),
+                                                 dtype=torch.uint8).numpy()})
+    atk = attacks.AENS_I2V_MF(fx["models"], depths=fx["depth"], step_size=0.005, momentum=1.0, steps=2,
+                              engine=hostsim_engine(), graph_builder=graphs.build_tiny)
+    nets = [restate.OracleNet(g, sd, h, dtype=torch.float64) for g, sd, h in gu.hook_lists(fx)]
+    coeffs = torch.ones(4, dtype=torch.float64)
+    first = []
+    for call in range(2):
+        atk(vid.clone(), torch.zeros(1, dtype=torch.long), ["v"])
+        first.append(np.stack(atk.weights)[0].copy())
+        o = restate.run_attack(nets, vid.double(), steps=2, step_size=0.005, mode="aens", coeffs=coeffs, momentum=1.0)
+        coeffs = o["coeffs"]
+        np.testing.assert_allclose(np.stack(atk.weights)[-2:], np.stack(o["weights"]), rtol=1e-4)
+        np.testing.assert_allclose(atk.coeffs.numpy(), coeffs.float().numpy(), rtol=1e-4)
+    assert not np.allclose(first[0], first[1])      # the second call did not start from ones
+
+
 def test_teacher_forced_first_step_matches_reference_gradient():
     """First step from delta_0: the sign of the gradient handed to Adam against the reference's
     (f64-backbone fixture => the reference value is accurate)."""
