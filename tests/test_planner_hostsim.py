@@ -120,7 +120,7 @@ def test_aens_coefficients_persist_across_calls():
         coeffs = o["coeffs"]
         np.testing.assert_allclose(np.stack(atk.weights)[-2:], np.stack(o["weights"]), rtol=1e-4)
         np.testing.assert_allclose(atk.coeffs.numpy(), coeffs.float().numpy(), rtol=1e-4)
-    assert not np.allclose(first[0], first[1])      # the second call did not start from ones
+    assert np.abs(first[0] - first[1]).max() > 0     # the second call did not start from ones (uniform 0.25)
 
 
 def test_teacher_forced_first_step_matches_reference_gradient():
