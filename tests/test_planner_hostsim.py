@@ -108,7 +108,7 @@ def test_aens_coefficients_persist_across_calls():
     fx = dict(models=["resnet", "squeezenet"], depth={"resnet": [2, 3], "squeezenet": [2, 3]}, hw=64, wseed=0)
     vid = gu.videos_of({"clip_u8": torch.randint(0, 256, (1, 3, 2, 64, 64), generator=torch.Generator().manual_seed(41),
                                                  dtype=torch.uint8).numpy()})
-    atk = attacks.AENS_I2V_MF(fx["models"], depths=fx["depth"], step_size=0.005, momentum=1.0, steps=2,
+    atk = attacks.AENS_I2V_MF(fx["models"], depths=fx["depth"], step_size=0.02, momentum=1.0, steps=4,
                               engine=hostsim_engine(), graph_builder=graphs.build_tiny)
     nets = [restate.OracleNet(g, sd, h, dtype=torch.float64) for g, sd, h in gu.hook_lists(fx)]
     coeffs = torch.ones(4, dtype=torch.float64)
@@ -116,10 +116,10 @@ def test_aens_coefficients_persist_across_calls():
     for call in range(2):
         atk(vid.clone(), torch.zeros(1, dtype=torch.long), ["v"])
         first.append(np.stack(atk.weights)[0].copy())
-        o = restate.run_attack(nets, vid.double(), steps=2, step_size=0.005, mode="aens", coeffs=coeffs, momentum=1.0)
+        o = restate.run_attack(nets, vid.double(), steps=4, step_size=0.02, mode="aens", coeffs=coeffs, momentum=1.0)
         coeffs = o["coeffs"]
-        np.testing.assert_allclose(np.stack(atk.weights)[-2:], np.stack(o["weights"]), rtol=1e-4)
-        np.testing.assert_allclose(atk.coeffs.numpy(), coeffs.float().numpy(), rtol=1e-4)
+        np.testing.assert_allclose(np.stack(atk.weights), np.stack(o["weights"]), rtol=1e-3)     # fp32 engine vs f64 oracle, lr 0.02
+        np.testing.assert_allclose(atk.coeffs.numpy(), coeffs.float().numpy(), rtol=1e-3)
     assert np.abs(first[0] - first[1]).max() > 0     # the second call did not start from ones (uniform 0.25)
 
 
