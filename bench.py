@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU")
     ap.add_argument("--white_model", default="slowfast_resnet50", help="--workload ilaf: video backbone (graphs.build_video)")
+    ap.add_argument("--streams", type=int, default=2, help="--workload ilaf: clips in flight on separate HIP streams (one clip per call each)")
     ap.add_argument("--workload", default="i2v", choices=["i2v", "ens", "aens", "config2", "ilaf"],
                     help="i2v = the headline metric (default); ens / aens = BASELINE configs[2]/[3]-style extras on the "
                          "reference's own model list (resnet101+vgg16+squeezenet1_1+alexnet)")
@@ -161,8 +162,30 @@ def main():
         noise = (torch.randint(-10, 11, videos.shape, generator=gen).float() / 255 / std).to(dev)
         ori = videos
         _ilaf = atk
-        atk = lambda v, l, n: _ilaf(v, ori, l, n)
         videos = (ori + noise).contiguous()
+        # `--streams` clip streams: each worker thread owns an ILAF object (its own planned net) and a HIP stream and
+        # works on its own clip pair; a step = one ILAF call on every stream (sign_attacks.run_concurrent).
+        import threading
+        lanes = [(_ilaf, videos, ori, torch.cuda.Stream(device=dev))]
+        for k in range(1, max(1, args.streams)):
+            o2 = synthetic_clips(b, seed0=5000 + rank * 64 + k * b).to(dev)
+            n2 = (torch.randint(-10, 11, o2.shape, generator=gen).float() / 255 / std).to(dev)
+            lanes.append((sign_attacks.ILAF(video.VideoModel(args.white_model, (FRAMES, HW, HW)), args.white_model, engine=eng),
+                          (o2 + n2).contiguous(), o2, torch.cuda.Stream(device=dev)))
+
+        def lane_calls(lane, reps):
+            a, v, o, st = lane
+            with torch.cuda.stream(st):
+                for _ in range(reps):
+                    a(v, o, labels, names)
+                st.synchronize()
+
+        def atk(v, l, n, reps=1):
+            ths = [threading.Thread(target=lane_calls, args=(ln, reps)) for ln in lanes]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
 
     for _ in range(max(args.warmup, 0)):
         atk(videos, labels, names)
@@ -183,8 +206,11 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        atk(videos, labels, names)
+    if args.workload == "ilaf":
+        atk(videos, labels, names, reps=args.steps)       # every stream runs `steps` calls back to back
+    else:
+        for _ in range(args.steps):
+            atk(videos, labels, names)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -192,15 +218,16 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    if timing_outside:
+    if timing_outside:                      # one stream, instrumented
         eng.timing_enable(True)
-        atk(videos, labels, names); eng.timing_collect()      # event pool
-        atk(videos, labels, names)
+        _ilaf(videos, ori, labels, names); eng.timing_collect()      # event pool
+        _ilaf(videos, ori, labels, names)
     kt = eng.timing_collect() if timing else None
     if timing:
         eng.timing_enable(False)
 
-    frames_total = args.steps * b * FRAMES * world
+    n_lanes = len(lanes) if args.workload == "ilaf" else 1
+    frames_total = args.steps * b * FRAMES * world * n_lanes
     value = frames_total / elapsed
     g = graphs.build(MODEL, (HW, HW)).truncated([graphs.build(MODEL, (HW, HW)).hooks[DEPTH]])
     mac = g.macs_per_frame()
@@ -239,10 +266,11 @@ def main():
         vg = _ilaf.model.graph_for((FRAMES, HW, HW))
         vmac = vg.truncated(_ilaf.model.hook_tensors(vg)).macs_per_frame()          # per clip
         out["metric"] = f"adversarial frames/sec ({_ilaf.steps}-step ILAF, {args.white_model} white-box, 32x224^2 clips)"
-        out["config"] = {"workload": f"ILAF fine-tune (BASELINE.json configs[4]): {b} clip(s) per call per GPU, {_ilaf.steps} sign "
-                                     f"steps of 0.005, eps=16/255, hooks of {args.white_model} (synthetic weights)",
-                         "frames_per_gpu": b * FRAMES, "attack_steps": _ilaf.steps,
-                         "parallelism": f"one clip stream per GPU x {world}, replicas only"}
+        out["config"] = {"workload": f"ILAF fine-tune (BASELINE.json configs[4]): {b} clip(s) per call, {n_lanes} calls in flight per GPU "
+                                     f"on separate HIP streams, {_ilaf.steps} sign steps of 0.005, eps=16/255, hooks of "
+                                     f"{args.white_model} (synthetic weights)",
+                         "frames_per_gpu": b * FRAMES * n_lanes, "attack_steps": _ilaf.steps, "streams": n_lanes,
+                         "parallelism": f"{n_lanes} clip stream(s) per GPU x {world} GPU(s), replicas only"}
         out["algorithmic_gflop_per_frame"] = round((4 * _ilaf.steps + 4) * vmac / FRAMES / 1e9, 2)
         out["end_to_end_tflops_per_gpu"] = round(value / world * (4 * _ilaf.steps + 4) * vmac / FRAMES / 1e12, 2)
     elif args.workload != "i2v":

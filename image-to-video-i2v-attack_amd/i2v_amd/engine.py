@@ -5,6 +5,7 @@ PyTorch is used for device memory and streams only (`tensor.data_ptr()`,
 `torch.cuda.current_stream().cuda_stream`); all arithmetic happens behind the C ABI.
 """
 import ctypes as C
+import threading
 from typing import List, Sequence
 
 import torch
@@ -29,6 +30,7 @@ class Engine:
         if capi is None and self.device.type != "cuda":
             raise _lib.I2VError("the I2V engine needs a ROCm device; there is no CPU path")
         self.h = C.c_void_p()
+        self.plan_lock = threading.Lock()      # net creation / planning / destruction touch the handle's net table
         idx = self.device.index or 0
         _lib.check(self.capi, self.capi.i2v_create(idx, C.byref(self.h)))
 
@@ -49,7 +51,10 @@ class Engine:
             pass
 
     def build_net(self, graph: Graph, state_dict, hook_tensors: Sequence[int], max_frames: int) -> "Net":
-        return Net(self, graph, state_dict, list(hook_tensors), max_frames)
+        """Thread-safe (concurrent clip streams plan their own nets); execution of DIFFERENT nets on different
+        streams needs no lock -- a planned net owns its arena, the library keeps no other mutable state."""
+        with self.plan_lock:
+            return Net(self, graph, state_dict, list(hook_tensors), max_frames)
 
     # ---- measurement ----
     KINDS = ("conv_igemm_fwd", "conv_igemm_imggrad", "pool_fwd", "pool_bwd", "addmask", "conv_igemm_dgrad")
@@ -190,7 +195,8 @@ class Net:
     def close(self):
         """Release the arena and packed weights now (they also go when the engine is destroyed)."""
         if self.id is not None and self.eng.h:
-            self.eng.capi.i2v_net_destroy(self.eng.h, self.id)
+            with self.eng.plan_lock:
+                self.eng.capi.i2v_net_destroy(self.eng.h, self.id)
         self.id = None
 
     def workspace_bytes(self) -> int:

@@ -126,6 +126,58 @@ class MIFGSM(BIM):
         return grad
 
 
+def run_concurrent(make_attack, items, streams=2, device=None, on_result=None):
+    """Run `attack(*item)` for every item of the iterable `items` on `streams` concurrent clip streams.  Returns
+    (results in item order, attack objects); with `on_result(index, item, result)` given, results are handed to it
+    as they finish (serialised) instead of being kept, and items are pulled lazily.
+
+    ILAF handles ONE clip per call (`image_fine_tune_attack.py:73-79`; its loss couples the whole batch, so clips
+    cannot be batched), and one 32-frame clip leaves most of an MI355X idle between its ~3000 short launches.  Each
+    worker thread owns an attack object (its own planned net and buffers) and a HIP stream, so launches of
+    different clips overlap on the device: +45..55 % clips/s with 2 streams, nothing more with 4
+    (tools/ilaf_streams_probe.py).  Per-clip results are bit-identical to the sequential run."""
+    import threading
+    it = enumerate(items)
+    pull, push = threading.Lock(), threading.Lock()
+    results, errors = {}, []
+    n = max(1, streams)
+    attacks_ = [make_attack() for _ in range(n)]
+    use_cuda = torch.cuda.is_available() and (device is None or torch.device(device).type == "cuda")
+
+    def worker(atk):
+        ctx = torch.cuda.stream(torch.cuda.Stream(device=device)) if use_cuda else None
+        try:
+            if ctx is not None:
+                ctx.__enter__()
+            while not errors:
+                with pull:
+                    nxt = next(it, None)
+                if nxt is None:
+                    break
+                i, item = nxt
+                res = atk(*item)
+                if ctx is not None:
+                    torch.cuda.current_stream().synchronize()
+                with push:
+                    if on_result is not None:
+                        on_result(i, item, res)
+                    else:
+                        results[i] = res
+        except BaseException as e:       # surfaced by the caller
+            errors.append(e)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+    threads = [threading.Thread(target=worker, args=(a,)) for a in attacks_]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return [results[i] for i in sorted(results)], attacks_
+
+
 class ILAF(object):
     """`image_attacks.py:498-629`: fine-tunes an existing adversarial clip along the feature
     direction of a white-box VIDEO model.  `model` is a `VideoModel` (native path, `_native`) or a torch

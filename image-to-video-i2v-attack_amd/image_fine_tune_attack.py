@@ -8,7 +8,8 @@ Differences: the white-box model is an `i2v_amd.video.VideoModel` (graph IR + we
 module from a YACS config, `:58-66`), so `--white_model` is one of the names `graphs.build_video` knows and the whole
 ILAF loop runs in `libi2v_hip.so`; under `torchrun` the file list is dealt round-robin over the ranks (replicas only,
 no collective); `--steps` / `--step_size` expose ILAF's constructor defaults (60, 0.005; `image_attacks.py:502`);
-`--resume` skips clips whose output exists."""
+`--resume` skips clips whose output exists; `--streams N` (default 2) keeps N clips in flight on separate HIP streams
+(`sign_attacks.run_concurrent`: one clip per call as in the reference, but a single clip cannot fill the GPU)."""
 import argparse
 import os
 
@@ -16,6 +17,7 @@ import numpy as np
 import torch
 
 import image_attacks
+from i2v_amd.sign_attacks import run_concurrent
 from i2v_amd.video import VideoModel
 
 
@@ -53,6 +55,7 @@ def arg_parse(argv=None):
     parser.add_argument("--steps", type=int, default=60)
     parser.add_argument("--step_size", type=float, default=0.005)
     parser.add_argument("--resume", action="store_true")
+    parser.add_argument("--streams", type=int, default=2, help="clips in flight on separate HIP streams")
     return parser.parse_args(argv)
 
 
@@ -63,22 +66,31 @@ def main(argv=None, model_kwargs=None):
     print(args)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     dataset = AdvDataset(args.used_adv, args.used_ori)
-    model = None
-    attack_method = None
     os.makedirs(args.opt_path, exist_ok=True)
+    todo = []
     for step in range(rank, len(dataset), world):
-        print("Running {}, {}/{}".format(args.attack_method, step + 1, len(dataset)))
-        val_batch, ori_batch, val_label = dataset[step]
-        if args.resume and all(os.path.exists(os.path.join(args.opt_path, "{}-adv.npy".format(l.item()))) for l in val_label):
+        vid_id = dataset.files[step].split("-")[0]
+        if args.resume and os.path.exists(os.path.join(args.opt_path, "{}-adv.npy".format(int(vid_id)))):
             continue
-        if attack_method is None:                      # the clip shape decides the plan: build on first use
-            model = VideoModel(args.white_model, tuple(val_batch.shape[2:]), **(model_kwargs or {}))
-            attack_method = getattr(image_attacks, args.attack_method)(model, args.white_model, step_size=args.step_size,
-                                                                       steps=args.steps)
-        adv_batches = attack_method(val_batch, ori_batch, val_label, ["..."])
-        for ind, label in enumerate(val_label):
+        todo.append(step)
+    if not todo:
+        return None
+    shape = tuple(dataset[todo[0]][0].shape[2:])            # the clip shape decides the plan
+
+    def make_attack():
+        model = VideoModel(args.white_model, shape, **(model_kwargs or {}))
+        return getattr(image_attacks, args.attack_method)(model, args.white_model, step_size=args.step_size, steps=args.steps)
+
+    def items():
+        for step in todo:
+            print("Running {}, {}/{}".format(args.attack_method, step + 1, len(dataset)))
+            val_batch, ori_batch, val_label = dataset[step]
+            yield val_batch, ori_batch, val_label, ["..."]
+    def save(_i, item, adv_batches):
+        for ind, label in enumerate(item[2]):
             np.save(os.path.join(args.opt_path, "{}-adv".format(label.item())), adv_batches[ind].detach().cpu().numpy())
-    return attack_method
+    _, attacks_ = run_concurrent(make_attack, items(), args.streams, on_result=save)
+    return attacks_[0]
 
 
 if __name__ == "__main__":

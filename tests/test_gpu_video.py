@@ -247,3 +247,23 @@ def test_every_tile_configuration(eng, cfg, monkeypatch):
         ref = onet.backward(hg)
         assert (gx.cpu().double() - ref).abs().max() <= 1e-4 * ref.abs().max()
         net.close()
+
+
+def test_concurrent_clip_streams_bit_identical(eng):
+    """Two ILAF calls in flight on separate HIP streams (own nets, own buffers) must give, clip by clip, exactly the
+    bytes the sequential run gives -- the library keeps no shared mutable state between planned nets."""
+    from i2v_amd.sign_attacks import run_concurrent
+    fx = load("ilaf_slowfast_f64")
+    adv, ori = clips(fx)
+    gen = torch.Generator().manual_seed(3)
+    items = [(adv + 0.02 * torch.randn(adv.shape, generator=gen), ori, torch.zeros(fx["b"], dtype=torch.long), [f"c{k}"]) for k in range(6)]
+
+    def make():
+        return sign_attacks.ILAF(video.VideoModel(fx["model_type"], fx["thw"], weight_seed=fx["wseed"], tiny=True),
+                                 fx["model_type"], step_size=0.005, steps=4)
+    seq = make()
+    want = [seq(*it).cpu().clone() for it in items]
+    got, workers = run_concurrent(make, items, streams=3)
+    assert len(workers) == 3
+    for g, w in zip(got, want):
+        assert torch.equal(g.cpu(), w)

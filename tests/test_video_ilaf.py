@@ -89,3 +89,34 @@ def test_video_model_errors():
         video.VideoModel("tpn_resnet50")
     m = video.VideoModel("i3d_resnet50", (8, 32, 32), tiny=True)
     assert m.cuda() is m and m.eval() is m
+
+
+def test_concurrent_clip_streams_match_sequential():
+    """`run_concurrent`: worker threads with their own attack objects (own planned nets) give, clip by clip, exactly
+    what one attack object gives sequentially; results come back in item order, or through the callback."""
+    from i2v_amd.sign_attacks import run_concurrent
+    eng = hostsim_engine()
+    fx = load("ilaf_i3d_f32")
+    adv, ori = clips(fx)
+    gen = torch.Generator().manual_seed(3)
+    items = []
+    for k in range(5):
+        noise = 0.02 * torch.randn(adv.shape, generator=gen)
+        items.append((adv + noise, ori, torch.zeros(1, dtype=torch.long), [f"clip{k}"]))
+
+    def make():
+        return sign_attacks.ILAF(video.VideoModel(fx["model_type"], fx["thw"], weight_seed=fx["wseed"], tiny=True),
+                                 fx["model_type"], step_size=0.005, steps=2, engine=eng)
+    seq = make()
+    want = [seq(*it).clone() for it in items]
+    got, workers = run_concurrent(make, items, streams=3, device="cpu")
+    assert len(workers) == 3 and len(got) == 5
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    names = sorted(n for a in workers for n in a.loss_info)
+    assert names == [f"clip{k}" for k in range(5)]
+    seen = {}
+    run_concurrent(make, iter(items), streams=2, device="cpu", on_result=lambda i, item, res: seen.__setitem__(i, res))
+    assert sorted(seen) == list(range(5)) and all(torch.equal(seen[i], want[i]) for i in range(5))
+    with pytest.raises(ZeroDivisionError):
+        run_concurrent(make, items, streams=2, device="cpu", on_result=lambda i, item, res: 1 / 0)
