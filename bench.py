@@ -175,6 +175,7 @@ def main():
 
         def lane_calls(lane, reps):
             a, v, o, st = lane
+            torch.cuda.set_device(dev)                    # per-thread state (a new thread starts on device 0)
             with torch.cuda.stream(st):
                 for _ in range(reps):
                     a(v, o, labels, names)

@@ -142,12 +142,18 @@ def run_concurrent(make_attack, items, streams=2, device=None, on_result=None):
     results, errors = {}, []
     n = max(1, streams)
     attacks_ = [make_attack() for _ in range(n)]
-    use_cuda = torch.cuda.is_available() and (device is None or torch.device(device).type == "cuda")
+    if device is None:                   # the engine's device: a new thread starts on device 0, not on the caller's
+        eng = getattr(attacks_[0], "_engine", None) or get_engine()
+        device = eng.device
+    device = torch.device(device)
+    use_cuda = device.type == "cuda" and torch.cuda.is_available()
 
     def worker(atk):
-        ctx = torch.cuda.stream(torch.cuda.Stream(device=device)) if use_cuda else None
+        ctx = None
         try:
-            if ctx is not None:
+            if use_cuda:
+                torch.cuda.set_device(device)            # per-thread state, for torch and for the HIP runtime underneath
+                ctx = torch.cuda.stream(torch.cuda.Stream(device=device))
                 ctx.__enter__()
             while not errors:
                 with pull:
