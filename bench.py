@@ -188,10 +188,17 @@ def main():
             for t in ths:
                 t.join()
 
+    timing = not args.no_kernel_timing
+    # The attack classes cut an I2V / ENS batch into two concurrently executed clip lanes by default (attacks.py,
+    # +4 % frames/s).  Under concurrency a launch's event-measured duration is no longer its own, so the timed,
+    # per-launch-instrumented region runs ONE lane (the roofline then means what it says and agrees with rocprofv3);
+    # the product-default configuration is timed afterwards, un-instrumented, and reported as `product_default`.
+    lanes_capable = args.workload in ("i2v", "ens", "config2")
+    if lanes_capable and timing:
+        atk.clip_lanes = 1
     for _ in range(max(args.warmup, 0)):
         atk(videos, labels, names)
     torch.cuda.synchronize()
-    timing = not args.no_kernel_timing
     # ILAF on one clip is ~3000 launches of ~30 us per call: bracketing each with an event pair costs ~20 %, so its
     # per-kernel times come from ONE extra call after the timed region instead of from inside it
     timing_outside = timing and args.workload == "ilaf"
@@ -226,6 +233,24 @@ def main():
     kt = eng.timing_collect() if timing else None
     if timing:
         eng.timing_enable(False)
+    product_default = None
+    if lanes_capable and timing:
+        atk.clip_lanes = None                 # product default: $I2V_CLIP_LANES or 2
+        atk(videos, labels, names)            # plans the lanes' nets, warms up
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            atk(videos, labels, names)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t1
+        barrier()
+        if dist is not None:
+            tt = torch.tensor([el2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el2 = float(tt.item())
+        product_default = {"clip_lanes": atk._lane_count(b), "value": round(args.steps * b * FRAMES * world / el2, 2),
+                           "unit": "adversarial frames/s", "ms_per_step": round(1e3 * el2 / args.steps, 3),
+                           "note": "same K steps, no per-launch events, batch cut into concurrent clip lanes (bit-identical output)"}
 
     n_lanes = len(lanes) if args.workload == "ilaf" else 1
     frames_total = args.steps * b * FRAMES * world * n_lanes
@@ -280,6 +305,8 @@ def main():
         out["config"]["workload"] = f"{args.workload} ensemble ({models}), batch={b} clips per GPU"
         for k in ("end_to_end_tflops_per_gpu", "algorithmic_gflop_per_frame"):
             out.pop(k, None)
+    if product_default is not None:
+        out["product_default"] = product_default
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.workload == "i2v":
             out["cpu_baseline"] = cpu_baseline()

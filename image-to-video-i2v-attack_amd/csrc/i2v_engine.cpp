@@ -24,6 +24,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -101,10 +103,12 @@ struct Net {
 // `chain`: the launch follows the previous timed launch back to back on the same stream (same launch list), so its
 // start IS that launch's stop event -- one event record per launch instead of two (the records cost ~2 us of stream
 // time each, 4 % of the headline bench when every launch carried a pair).
-struct TimedLaunch { void* start; void* stop; int kind; double flops; int Cd, K, HWg, frames, pw; bool chain; };
+struct TimedLaunch { void* start; void* stop; int kind; double flops; int Cd, K, HWg, frames, pw; void* chain_from; };
 struct i2v_ctx {
     int device; std::vector<Net*> nets;
-    bool timing = false; std::vector<TimedLaunch> timed; size_t timed_used = 0; i2v_stream_t timed_stream = nullptr;
+    // nets may be executed from several threads on several streams (clip lanes): entries are handed out under a lock,
+    // live in a deque (stable addresses) and chain to an explicit event, never to "the previous entry"
+    bool timing = false; std::deque<TimedLaunch> timed; size_t timed_used = 0; std::mutex timing_mu;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -919,24 +923,28 @@ static int autotune(Net& n) {
     return 0;
 }
 
-static TimedLaunch* timing_begin(i2v_ctx* h, int kind, double flops, i2v_stream_t s, bool chain) {
+static TimedLaunch* timing_begin(i2v_ctx* h, int kind, double flops, i2v_stream_t s, TimedLaunch* prev) {
     if (!h->timing) return nullptr;
-    if (h->timed_used == h->timed.size()) {
-        TimedLaunch t{be_event_create(), be_event_create(), 0, 0.0};
-        if (!t.start || !t.stop) return nullptr;
-        h->timed.push_back(t);
+    TimedLaunch* t;
+    {
+        std::lock_guard<std::mutex> lock(h->timing_mu);
+        if (h->timed_used == h->timed.size()) {
+            TimedLaunch fresh{be_event_create(), be_event_create(), 0, 0.0};
+            if (!fresh.start || !fresh.stop) return nullptr;
+            h->timed.push_back(fresh);
+        }
+        t = &h->timed[h->timed_used++];
     }
-    TimedLaunch* t = &h->timed[h->timed_used++];
-    t->kind = kind; t->flops = flops; h->timed_stream = s; t->Cd = t->K = t->HWg = t->frames = t->pw = 0;
-    t->chain = chain && h->timed_used > 1;
-    if (!t->chain) be_event_record(t->start, s);
+    t->kind = kind; t->flops = flops; t->Cd = t->K = t->HWg = t->frames = t->pw = 0;
+    t->chain_from = prev ? prev->stop : nullptr;
+    if (!t->chain_from) be_event_record(t->start, s);
     return t;
 }
 
 static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, const float* x, float* gx, int accumulate,
                     i2v_stream_t s, bool backward_pass) {
     const int clips = in_frames / n.Tin();
-    bool chained = false;                                // the first launch of the list records its own start event
+    TimedLaunch* prev_timed = nullptr;                   // the first launch of the list records its own start event
     for (Launch& l : L) {
         const int frames = clips * l.T;                  // frames this launch iterates over
         double flops = 0.0;
@@ -945,8 +953,8 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
         // timing kinds: 0 conv fwd, 1 image gradient, 2 pool fwd, 3 pool bwd, 4 addmask, 5 conv input-gradient
         const int tkind = (l.kind == L_CONV && backward_pass) ? 5 : (l.kind == L_AVGF || l.kind == L_POOL3F) ? 2
                           : (l.kind == L_AVGB || l.kind == L_POOL3B) ? 3 : l.kind == L_MEMSET ? 4 : (int)l.kind;
-        TimedLaunch* tl = timing_begin(h, tkind, flops, s, chained);
-        chained = true;
+        TimedLaunch* tl = timing_begin(h, tkind, flops, s, prev_timed);
+        prev_timed = tl;
         if (tl && (l.kind == L_CONV || l.kind == L_IMGGRAD)) { tl->Cd = l.conv.Cd; tl->K = l.conv.K; tl->HWg = l.conv.Hg * l.conv.Wg; tl->frames = frames; tl->pw = l.conv.pointwise; }
         struct Stop { TimedLaunch* t; i2v_stream_t s; ~Stop() { if (t) be_event_record(t->stop, s); } } stop{tl, s};
         switch (l.kind) {
@@ -1013,12 +1021,12 @@ extern "C" int i2v_timing_collect(i2v_handle h, double* ms_by_kind, double* flop
                                   int n_kinds) {
     if (!h || !ms_by_kind || !flops_by_kind || !launches_by_kind || n_kinds < 6) return fail("i2v_timing_collect: bad argument");
     for (int i = 0; i < n_kinds; ++i) { ms_by_kind[i] = 0; flops_by_kind[i] = 0; launches_by_kind[i] = 0; }
-    if (h->timed_used) CHECK_BE(be_stream_sync(h->timed_stream));
+    if (h->timed_used) CHECK_BE(be_device_sync());
     const char* dump_path = getenv("I2V_TIMING_DUMP");      // debug: one line per launch
     FILE* dump = dump_path ? fopen(dump_path, "a") : nullptr;
     for (size_t i = 0; i < h->timed_used; ++i) {
         float ms = 0.f;
-        CHECK_BE(be_event_elapsed_ms(h->timed[i].chain ? h->timed[i - 1].stop : h->timed[i].start, h->timed[i].stop, &ms));
+        CHECK_BE(be_event_elapsed_ms(h->timed[i].chain_from ? h->timed[i].chain_from : h->timed[i].start, h->timed[i].stop, &ms));
         int k = h->timed[i].kind;
         if (dump) fprintf(dump, "%d %d %d %d %d %d %.4f %.3f\n", k, h->timed[i].Cd, h->timed[i].K, h->timed[i].HWg,
                           h->timed[i].frames, h->timed[i].pw, ms, h->timed[i].flops * 1e-9);

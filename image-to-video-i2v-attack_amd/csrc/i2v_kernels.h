@@ -20,7 +20,8 @@ void* be_event_create();
 void be_event_destroy(void* ev);
 int  be_event_record(void* ev, i2v_stream_t s);
 int  be_event_elapsed_ms(void* start, void* stop, float* ms);           // both must have completed
-int  be_stream_sync(i2v_stream_t s);                                                       // last backend error or null
+int  be_stream_sync(i2v_stream_t s);
+int  be_device_sync();                                                       // last backend error or null
 
 int k_conv(const I2VConvParams& p, i2v_stream_t s);
 int k_conv_candidates(const I2VConvParams& p, int* out);   // tile configurations valid for p (ids 0..4), returns count

@@ -49,6 +49,7 @@ void be_event_destroy(void* ev) { (void)hipEventDestroy((hipEvent_t)ev); }
 int be_event_record(void* ev, i2v_stream_t s) { HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)s)); return 0; }
 int be_event_elapsed_ms(void* a, void* b, float* ms) { HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return 0; }
 int be_stream_sync(i2v_stream_t s) { HIPCHK(hipStreamSynchronize((hipStream_t)s)); return 0; }
+int be_device_sync() { HIPCHK(hipDeviceSynchronize()); return 0; }
 
 __constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};
 __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};

@@ -363,6 +363,24 @@ def test_full_size_properties_resnet50(eng):
     assert torch.equal(sub, adv[:, :, 8:12])
 
 
+def test_clip_lanes_full_size_bit_identical(eng):
+    """BASELINE configs[1] shape (4 clips x 32 x 224^2, ResNet-50 layer3, 10 steps): the default two concurrent clip
+    lanes against a single lane -- same bytes out, since frames are independent and no kernel's summation order depends
+    on the batch."""
+    vid = torch.cat([gu.videos_of({"clip_u8": torch.randint(0, 256, (1, 3, 32, 224, 224), generator=torch.Generator().manual_seed(1000 + i),
+                                                           dtype=torch.uint8).numpy()}) for i in range(4)])
+    names = [f"c{i}" for i in range(4)]
+    two = attacks.ImageGuidedFMDirection_Adam(["resnet50"], depth=3, step_size=0.005, steps=10)
+    assert two._lane_count(4) == 2
+    got = two(vid, torch.zeros(4, dtype=torch.long), names).cpu()
+    one = attacks.ImageGuidedFMDirection_Adam(["resnet50"], depth=3, step_size=0.005, steps=10)
+    one.clip_lanes = 1
+    ref = one(vid, torch.zeros(4, dtype=torch.long), names).cpu()
+    assert torch.equal(got, ref)
+    np.testing.assert_allclose(two.last_costs, one.last_costs, rtol=1e-6)
+    assert torch.equal(two(vid, torch.zeros(4, dtype=torch.long), names).cpu(), ref)
+
+
 def test_ensemble_full_size_and_frame_slicing(eng):
     """Full-size shapes of the other backbones (BASELINE configs[2]-style ensemble on the reference's own
     model list, image_main.py:73-79): AlexNet 11x11/4, SqueezeNet ceil-mode pools and Fire concat, VGG

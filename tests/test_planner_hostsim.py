@@ -123,6 +123,33 @@ def test_aens_coefficients_persist_across_calls():
     assert np.abs(first[0] - first[1]).max() > 0     # the second call did not start from ones (uniform 0.25)
 
 
+def test_clip_lanes_are_bit_identical():
+    """Frames are independent in I2V / ENS-I2V, so cutting the batch into concurrently executed lanes of whole clips
+    (own nets, own threads / streams) must not change a single bit of the perturbed clips; the batch cost is the sum of
+    the lanes' costs."""
+    gen = torch.Generator().manual_seed(8)
+    vid = gu.videos_of({"clip_u8": torch.randint(0, 256, (3, 3, 2, 64, 64), generator=gen, dtype=torch.uint8).numpy()})
+    names = ["a", "b", "c"]
+    for cls, kw in ((attacks.ImageGuidedFMDirection_Adam, dict(model_name_lists=["resnet"], depth=2, step_size=0.005, steps=3)),
+                    (attacks.ImageGuidedFML2_Adam_MultiModels, dict(model_name_lists=["resnet", "alexnet"],
+                                                                    depths={"resnet": 2, "alexnet": 3}, steps=2))):
+        one = cls(engine=hostsim_engine(), graph_builder=graphs.build_tiny, **kw)
+        assert one._lane_count(3) == 1                      # host simulation: lanes are opt-in
+        ref = one(vid, torch.zeros(3, dtype=torch.long), names)
+        two = cls(engine=hostsim_engine(), graph_builder=graphs.build_tiny, **kw)
+        two.clip_lanes = 2
+        got = two(vid, torch.zeros(3, dtype=torch.long), names)
+        assert torch.equal(got, ref) and torch.equal(two._delta, one._delta)
+        np.testing.assert_allclose(two.last_costs, one.last_costs, rtol=1e-6)
+        assert list(two.loss_info) == names and two.loss_info["c"][0]["cost"] == str(two.last_costs[0])
+        assert len(two._lanes) == 2 and two._lanes[0]._nets[0].max_frames == 2 and two._lanes[1]._nets[0].max_frames == 4
+        again = two(vid, torch.zeros(3, dtype=torch.long), names)      # lanes and their nets are reused
+        assert torch.equal(again, ref)
+    dr = attacks.ImageGuidedStd_Adam(["resnet"], depth=2, step_size=0.005, steps=1, engine=hostsim_engine(), graph_builder=graphs.build_tiny)
+    dr.clip_lanes = 2
+    assert dr._lane_count(3) == 1                           # DR couples the whole batch: never split
+
+
 def test_teacher_forced_first_step_matches_reference_gradient():
     """First step from delta_0: the sign of the gradient handed to Adam against the reference's
     (f64-backbone fixture => the reference value is accurate)."""
