@@ -29,6 +29,7 @@
 #include <string>
 #include <vector>
 
+#define I2V_MAX_NETS 4096
 static thread_local std::string g_err;
 
 static int fail(const char* fmt, ...) {
@@ -318,6 +319,7 @@ extern "C" int i2v_create(int device, i2v_handle* out) {
     if (be_set_device(device)) return fail("i2v_create: cannot select device %d: %s", device,
                                            be_error() ? be_error() : "?");
     *out = new i2v_ctx(); (*out)->device = device;
+    (*out)->nets.reserve(I2V_MAX_NETS);     // the table never reallocates: other threads may be executing planned nets while one is added
     return 0;
 }
 
@@ -341,6 +343,7 @@ extern "C" int i2v_destroy(i2v_handle h) {
 // ---------------------------------------------------------------------------------------------
 extern "C" int i2v_net_create(i2v_handle h, int* net) {
     if (!h || !net) return fail("i2v_net_create: null argument");
+    if (h->nets.size() >= I2V_MAX_NETS) return fail("more than %d backbones created on one handle", I2V_MAX_NETS);
     h->nets.push_back(new Net());
     *net = (int)h->nets.size() - 1;
     return 0;

@@ -12,6 +12,10 @@
  *    asynchronously on it, nothing synchronises the host;
  *  - the library owns only what hangs off the opaque handle: packed weights, the plan and the
  *    activation/gradient arena of each backbone.  One handle per (process, device).
+ *  - threads: describing / planning / destroying backbones must be serialised by the caller (the Python mirror
+ *    holds a lock); DIFFERENT planned backbones may be executed concurrently from different threads on different
+ *    streams (a planned backbone owns its arena; the library has no other mutable state; errors are per thread).
+ *    One backbone must not be executed by two threads at once.
  */
 #ifndef I2V_HIP_H
 #define I2V_HIP_H
