@@ -248,7 +248,7 @@ def main():
             tt = torch.tensor([el2], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el2 = float(tt.item())
-        product_default = {"clip_lanes": atk._lane_count(b), "value": round(args.steps * b * FRAMES * world / el2, 2),
+        product_default = {"clip_lanes": atk._lane_count(b, FRAMES), "value": round(args.steps * b * FRAMES * world / el2, 2),
                            "unit": "adversarial frames/s", "ms_per_step": round(1e3 * el2 / args.steps, 3),
                            "note": "same K steps, no per-launch events, batch cut into concurrent clip lanes (bit-identical output)"}
 

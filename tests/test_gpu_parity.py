@@ -371,7 +371,7 @@ def test_clip_lanes_full_size_bit_identical(eng):
                                                            dtype=torch.uint8).numpy()}) for i in range(4)])
     names = [f"c{i}" for i in range(4)]
     two = attacks.ImageGuidedFMDirection_Adam(["resnet50"], depth=3, step_size=0.005, steps=10)
-    assert two._lane_count(4) == 2
+    assert two._lane_count(4, 32) == 2
     got = two(vid, torch.zeros(4, dtype=torch.long), names).cpu()
     one = attacks.ImageGuidedFMDirection_Adam(["resnet50"], depth=3, step_size=0.005, steps=10)
     one.clip_lanes = 1
@@ -379,6 +379,9 @@ def test_clip_lanes_full_size_bit_identical(eng):
     assert torch.equal(got, ref)
     np.testing.assert_allclose(two.last_costs, one.last_costs, rtol=1e-6)
     assert torch.equal(two(vid, torch.zeros(4, dtype=torch.long), names).cpu(), ref)
+    # one clip (the reference CLI's default batch): the two lanes take its frames 0..15 and 16..31
+    assert two._lane_count(1, 32) == 2
+    assert torch.equal(two(vid[:1], torch.zeros(1, dtype=torch.long), names[:1]).cpu(), ref[:1])
 
 
 def test_ensemble_full_size_and_frame_slicing(eng):

@@ -145,6 +145,16 @@ def test_clip_lanes_are_bit_identical():
         assert len(two._lanes) == 2 and two._lanes[0]._nets[0].max_frames == 2 and two._lanes[1]._nets[0].max_frames == 4
         again = two(vid, torch.zeros(3, dtype=torch.long), names)      # lanes and their nets are reused
         assert torch.equal(again, ref)
+    # a single clip is cut along its frames
+    long_clip = gu.videos_of({"clip_u8": torch.randint(0, 256, (1, 3, 16, 32, 32), generator=gen, dtype=torch.uint8).numpy()})
+    one = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=2, step_size=0.005, steps=2, engine=hostsim_engine(), graph_builder=graphs.build_tiny)
+    ref = one(long_clip, torch.zeros(1, dtype=torch.long), ["v"])
+    two = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=2, step_size=0.005, steps=2, engine=hostsim_engine(), graph_builder=graphs.build_tiny)
+    two.clip_lanes = 2
+    assert two._lane_count(1, 16) == 2 and two._lane_count(1, 8) == 1
+    got = two(long_clip, torch.zeros(1, dtype=torch.long), ["v"])
+    assert got.shape == ref.shape and torch.equal(got, ref) and torch.equal(two._delta, one._delta)
+    np.testing.assert_allclose(two.last_costs, one.last_costs, rtol=1e-6)
     dr = attacks.ImageGuidedStd_Adam(["resnet"], depth=2, step_size=0.005, steps=1, engine=hostsim_engine(), graph_builder=graphs.build_tiny)
     dr.clip_lanes = 2
     assert dr._lane_count(3) == 1                           # DR couples the whole batch: never split
