@@ -384,6 +384,25 @@ def test_clip_lanes_full_size_bit_identical(eng):
     assert torch.equal(two(vid[:1], torch.zeros(1, dtype=torch.long), names[:1]).cpu(), ref[:1])
 
 
+def test_clip_lanes_ensemble_and_odd_split(eng):
+    """ENS-I2V (four backbones, gradient accumulation) with 3 clips -> lanes of 1 and 2 clips; and a 24-frame single
+    clip -> frame lanes of 12 + 12: same bytes as one lane."""
+    gen = torch.Generator().manual_seed(31)
+    vid = gu.videos_of({"clip_u8": torch.randint(0, 256, (3, 3, 4, 64, 64), generator=gen, dtype=torch.uint8).numpy()})
+    depths = {"resnet": 2, "vgg": 3, "squeezenet": 2, "alexnet": 3}
+    kw = dict(model_name_lists=list(depths), depths=depths, steps=3, graph_builder=graphs.build_tiny)
+    two = attacks.ImageGuidedFML2_Adam_MultiModels(**kw)
+    one = attacks.ImageGuidedFML2_Adam_MultiModels(**kw)
+    one.clip_lanes = 1
+    names = ["a", "b", "c"]
+    assert two._lane_count(3, 4) == 2
+    assert torch.equal(two(vid, torch.zeros(3, dtype=torch.long), names), one(vid, torch.zeros(3, dtype=torch.long), names))
+    np.testing.assert_allclose(two.last_costs, one.last_costs, rtol=1e-6)
+    clip = gu.videos_of({"clip_u8": torch.randint(0, 256, (1, 3, 24, 64, 64), generator=gen, dtype=torch.uint8).numpy()})
+    assert two._lane_count(1, 24) == 2
+    assert torch.equal(two(clip, torch.zeros(1, dtype=torch.long), ["v"]), one(clip, torch.zeros(1, dtype=torch.long), ["v"]))
+
+
 def test_ensemble_full_size_and_frame_slicing(eng):
     """Full-size shapes of the other backbones (BASELINE configs[2]-style ensemble on the reference's own
     model list, image_main.py:73-79): AlexNet 11x11/4, SqueezeNet ceil-mode pools and Fire concat, VGG
