@@ -776,6 +776,7 @@ struct Planner {
                 l.pool.gx = gx.p; l.pool.gx_nstride = gx.nstride;
                 l.pool.k = q.k; l.pool.stride = q.stride; l.pool.pad = q.pad;
                 l.pool.mask_relu = n.tens[q.src].post_relu ? 1 : 0;
+                if (l.pool.mask_relu && nd.type == 1) { View ya = view(q.dst, false); l.pool.yact = ya.p; l.pool.yact_nstride = ya.nstride; }
                 l.pool.kt = q.kt; l.pool.stride_t = q.stride_t; l.pool.pad_t = q.pad_t; l.pool.Ts = x.T; l.pool.To = dz.T;
                 l.pool.idx = (uint8_t*)(base() + nd.idx_off);
                 l.T = dz.T;

@@ -616,7 +616,9 @@ __global__ void __launch_bounds__(256) pool_fwd_kernel(const I2VPoolParams p, co
 }
 
 // gather form (no atomics): an input element collects from the <= ceil(k/stride)^2 windows holding it whose
-// stored arg-max points back at it
+// stored arg-max points back at it.  The ReLU gate of the pooled tensor (x > 0) is taken from the pooled OUTPUT:
+// an element only receives gradient from a window whose maximum it is, and then x equals that window's y -- so the
+// full-resolution activation (4x the bytes of y) is not read at all.
 __global__ void __launch_bounds__(256) pool_bwd_kernel(const I2VPoolParams p, const int band_rows) {
     __shared__ float gs[POOL_LDS_FLOATS / 2];
     __shared__ uint8_t is[POOL_LDS_FLOATS / 2];
@@ -625,18 +627,26 @@ __global__ void __launch_bounds__(256) pool_bwd_kernel(const I2VPoolParams p, co
     int ho_lo = h0 + p.pad - p.k + 1; ho_lo = ho_lo <= 0 ? 0 : (ho_lo + p.stride - 1) / p.stride;
     const int ho_hi = min((h1 - 1 + p.pad) / p.stride, p.Ho - 1);                    // output rows [ho_lo, ho_hi]
     const float* gy = p.y + (int64_t)n * p.y_nstride + (int64_t)c * p.Ho * p.Wo;
+    const float* yv = p.yact ? p.yact + (int64_t)n * p.yact_nstride + (int64_t)c * p.Ho * p.Wo : nullptr;
     const uint8_t* ix = p.idx + (int64_t)plane * p.Ho * p.Wo;
     const int cnt = (ho_hi - ho_lo + 1) * p.Wo;
-    for (int e = threadIdx.x; e < cnt; e += 256) { gs[e] = gy[ho_lo * p.Wo + e]; is[e] = ix[ho_lo * p.Wo + e]; }
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        float g = gy[ho_lo * p.Wo + e];
+        if (yv && !(yv[ho_lo * p.Wo + e] > 0.f)) g = 0.f;       // gate folded into the staged upstream gradient
+        gs[e] = g; is[e] = ix[ho_lo * p.Wo + e];
+    }
     __syncthreads();
     const float* x = p.x + (int64_t)n * p.x_nstride + (int64_t)c * p.Hs * p.Ws;
     float* gx = p.gx + (int64_t)n * p.gx_nstride + (int64_t)c * p.Hs * p.Ws;
     const int nin = (h1 - h0) * p.Ws;
+    const bool gate_x = p.mask_relu && !yv;                      // no pooled activation supplied: gate on x itself
     const bool vec = ((p.Ws & 3) == 0) && ((((uintptr_t)(x + h0 * p.Ws) | (uintptr_t)(gx + h0 * p.Ws)) & 15) == 0);
     for (int e4 = threadIdx.x * (vec ? 4 : 1); e4 < nin; e4 += 256 * (vec ? 4 : 1)) {
-        float xv[4], gv[4];
-        if (vec) { const float4 t4 = *reinterpret_cast<const float4*>(x + h0 * p.Ws + e4); xv[0] = t4.x; xv[1] = t4.y; xv[2] = t4.z; xv[3] = t4.w; }
-        else xv[0] = x[h0 * p.Ws + e4];
+        float xv[4] = {1.f, 1.f, 1.f, 1.f}, gv[4];
+        if (gate_x) {
+            if (vec) { const float4 t4 = *reinterpret_cast<const float4*>(x + h0 * p.Ws + e4); xv[0] = t4.x; xv[1] = t4.y; xv[2] = t4.z; xv[3] = t4.w; }
+            else xv[0] = x[h0 * p.Ws + e4];
+        }
         const int h = h0 + e4 / p.Ws, wb = e4 % p.Ws;
         int a_lo = h + p.pad - p.k + 1; a_lo = a_lo <= 0 ? 0 : (a_lo + p.stride - 1) / p.stride;
         const int a_hi = min((h + p.pad) / p.stride, p.Ho - 1);
@@ -645,7 +655,7 @@ __global__ void __launch_bounds__(256) pool_bwd_kernel(const I2VPoolParams p, co
             if (!vec && u > 0) break;
             const int w = wb + u;
             float g = 0.f;
-            if (!p.mask_relu || xv[u] > 0.f) {
+            if (!gate_x || xv[u] > 0.f) {
                 int b_lo = w + p.pad - p.k + 1; b_lo = b_lo <= 0 ? 0 : (b_lo + p.stride - 1) / p.stride;
                 const int b_hi = min((w + p.pad) / p.stride, p.Wo - 1);
                 for (int ho = a_lo; ho <= a_hi; ++ho)

@@ -65,6 +65,8 @@ struct I2VPoolParams {
     const float* x;    int64_t x_nstride;    int32_t C, Hs, Ws;
     float* y;          int64_t y_nstride;    int32_t Ho, Wo;       // fwd: output; bwd: upstream grad
     float* gx;         int64_t gx_nstride;                           // bwd only
+    const float* yact; int64_t yact_nstride;                         // bwd, optional: the pooled ACTIVATION (forward output); with
+                                                                     // mask_relu the gate x > 0 is then evaluated as y > 0 on it
     uint8_t* idx;      // [N][C][Ho][Wo] window-relative arg-max (r*k+s), written by fwd, read by bwd
     int32_t N, k, stride, pad, mask_relu;
     // video pooling (k_pool3d_*): window kt x k x k over frame-major clips; N counts OUTPUT frames (clips*To)
