@@ -839,6 +839,9 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
     if (!real.run()) return fail("plan: %s", real.err.c_str());
     n.hook_tmp = real.hook_tmp;
     if (autotune(n)) return 1;
+    // planning works on the null stream (uploads, arena clears, tuning probes); the caller may execute the net on any
+    // stream, including non-blocking ones that do not order against it
+    CHECK_BE(be_stream_sync(nullptr));
     n.planned = true;
     return 0;
 }
