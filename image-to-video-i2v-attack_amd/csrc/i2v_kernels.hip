@@ -620,13 +620,17 @@ __global__ void __launch_bounds__(256) pool_fwd_kernel(const I2VPoolParams p, co
 // stored arg-max points back at it.  The ReLU gate of the pooled tensor (x > 0) is taken from the pooled OUTPUT:
 // an element only receives gradient from a window whose maximum it is, and then x equals that window's y -- so the
 // full-resolution activation (4x the bytes of y) is not read at all.
+// KK/SS/PP: window, stride and padding as compile-time constants for the common geometries (the index divisions become
+// shifts); KK == 0 reads them from the parameters.
+template <int KK, int SS, int PP>
 __global__ void __launch_bounds__(256) pool_bwd_kernel(const I2VPoolParams p, const int band_rows) {
+    const int pk = KK ? KK : p.k, pstride = KK ? SS : p.stride, ppad = KK ? PP : p.pad;
     __shared__ float gs[POOL_LDS_FLOATS / 2];
     __shared__ uint8_t is[POOL_LDS_FLOATS / 2];
     const int plane = blockIdx.x, n = plane / p.C, c = plane - n * p.C;
     const int h0 = blockIdx.y * band_rows, h1 = min(h0 + band_rows, p.Hs);           // input rows of this band
-    int ho_lo = h0 + p.pad - p.k + 1; ho_lo = ho_lo <= 0 ? 0 : (ho_lo + p.stride - 1) / p.stride;
-    const int ho_hi = min((h1 - 1 + p.pad) / p.stride, p.Ho - 1);                    // output rows [ho_lo, ho_hi]
+    int ho_lo = h0 + ppad - pk + 1; ho_lo = ho_lo <= 0 ? 0 : (ho_lo + pstride - 1) / pstride;
+    const int ho_hi = min((h1 - 1 + ppad) / pstride, p.Ho - 1);                    // output rows [ho_lo, ho_hi]
     const float* gy = p.y + (int64_t)n * p.y_nstride + (int64_t)c * p.Ho * p.Wo;
     const float* yv = p.yact ? p.yact + (int64_t)n * p.yact_nstride + (int64_t)c * p.Ho * p.Wo : nullptr;
     const uint8_t* ix = p.idx + (int64_t)plane * p.Ho * p.Wo;
@@ -649,19 +653,19 @@ __global__ void __launch_bounds__(256) pool_bwd_kernel(const I2VPoolParams p, co
             else xv[0] = x[h0 * p.Ws + e4];
         }
         const int h = h0 + e4 / p.Ws, wb = e4 % p.Ws;
-        int a_lo = h + p.pad - p.k + 1; a_lo = a_lo <= 0 ? 0 : (a_lo + p.stride - 1) / p.stride;
-        const int a_hi = min((h + p.pad) / p.stride, p.Ho - 1);
+        int a_lo = h + ppad - pk + 1; a_lo = a_lo <= 0 ? 0 : (a_lo + pstride - 1) / pstride;
+        const int a_hi = min((h + ppad) / pstride, p.Ho - 1);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (!vec && u > 0) break;
             const int w = wb + u;
             float g = 0.f;
             if (!gate_x || xv[u] > 0.f) {
-                int b_lo = w + p.pad - p.k + 1; b_lo = b_lo <= 0 ? 0 : (b_lo + p.stride - 1) / p.stride;
-                const int b_hi = min((w + p.pad) / p.stride, p.Wo - 1);
+                int b_lo = w + ppad - pk + 1; b_lo = b_lo <= 0 ? 0 : (b_lo + pstride - 1) / pstride;
+                const int b_hi = min((w + ppad) / pstride, p.Wo - 1);
                 for (int ho = a_lo; ho <= a_hi; ++ho)
                     for (int wo = b_lo; wo <= b_hi; ++wo) {
-                        const int me = (h - (ho * p.stride - p.pad)) * p.k + (w - (wo * p.stride - p.pad));
+                        const int me = (h - (ho * pstride - ppad)) * pk + (w - (wo * pstride - ppad));
                         const int li = (ho - ho_lo) * p.Wo + wo;
                         if (is[li] == me) g += gs[li];
                     }
@@ -727,7 +731,10 @@ int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s) {
     if (band < 1) return pool_fail("max-pool row too wide for the LDS band");
     if (band > p.Hs) band = p.Hs;
     dim3 grid((unsigned)(p.N * p.C), (unsigned)((p.Hs + band - 1) / band));
-    hipLaunchKernelGGL(pool_bwd_kernel, grid, dim3(256), 0, (hipStream_t)s, p, band);
+    if (p.k == 3 && p.stride == 2 && p.pad == 1) hipLaunchKernelGGL((pool_bwd_kernel<3, 2, 1>), grid, dim3(256), 0, (hipStream_t)s, p, band);
+    else if (p.k == 2 && p.stride == 2 && p.pad == 0) hipLaunchKernelGGL((pool_bwd_kernel<2, 2, 0>), grid, dim3(256), 0, (hipStream_t)s, p, band);
+    else if (p.k == 3 && p.stride == 2 && p.pad == 0) hipLaunchKernelGGL((pool_bwd_kernel<3, 2, 0>), grid, dim3(256), 0, (hipStream_t)s, p, band);
+    else hipLaunchKernelGGL((pool_bwd_kernel<0, 0, 0>), grid, dim3(256), 0, (hipStream_t)s, p, band);
     LAUNCH_CHECK("pool_bwd"); return 0;
 }
 

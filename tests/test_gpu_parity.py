@@ -285,6 +285,34 @@ def test_conv_property_based(eng):
         assert (gx.cpu().double() - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-7, tag
 
 
+@pytest.mark.parametrize("k,stride,pad", [(3, 1, 1), (5, 3, 2), (2, 1, 0), (3, 2, 1), (4, 4, 0)])
+def test_maxpool_geometries(eng, k, stride, pad):
+    """Max-pooling windows beyond the three the backbones use (those have compile-time specialisations of pool_bwd;
+    everything else runs the generic instantiation): conv -> pool -> conv, forward and input gradient vs the oracle."""
+    g = graphs.Graph("poolgeom", (29, 26))
+    x = g.new_tensor(3, 29, 26, False, "input")
+    g.input = x
+    a = g.conv(x, 12, 3, 1, 1, "a.weight", bn="a_bn", relu=True)
+    pl = g.maxpool(a, k, stride, pad)
+    y = g.conv(pl, 8, 3, 1, 1, "c.weight", bn="c_bn", relu=True)
+    g.hooks[1] = y
+    sd = weights.synthetic_state_dict(g, k * 10 + stride)
+    N = 3
+    net = eng.build_net(g, sd, [y], N)
+    onet = restate.OracleNet(g, sd, [y], dtype=torch.float64)
+    xin = torch.randn(N, 3, 29, 26, generator=torch.Generator().manual_seed(k))
+    feats = onet.forward(xin.double())
+    net.forward(dev(xin))
+    assert torch.allclose(net.read_tensor(pl, N).cpu().double(), onet.tensor(pl), rtol=1e-5, atol=1e-6)
+    hg = [torch.randn_like(f) for f in feats]
+    write_hook_grads(net, feats, hg, N)
+    gx = torch.empty(N, 3, 29, 26, device="cuda:0")
+    net.backward(gx)
+    ref = onet.backward(hg)
+    assert (gx.cpu().double() - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-7
+    net.close()
+
+
 # ------------------------------------------------------------------ attack loops
 MODE = {"i2v": attacks.ImageGuidedFMDirection_Adam, "std": attacks.ImageGuidedStd_Adam}
 
