@@ -53,7 +53,7 @@ def measured_traffic():
     try:
         with open(path) as fh:
             t = json.load(fh)
-        return {"bytes_per_launch": round(t["hbm_bytes_per_launch"]), "unit": "B", "source": "profiles/r1_conv_traffic.json"}
+        return round(t["hbm_bytes_per_launch"])
     except Exception:
         return None
 
@@ -280,6 +280,7 @@ def main():
                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                            "traffic": measured_traffic() if args.workload == "i2v" and b == CLIPS_PER_GPU else None,
+                           "traffic_unit": "B per launch (rocprofv3 PMC passes: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_conv_traffic.json)",
                            "launches": c["launches"], "avg_launch_us": round(1e3 * c["ms"] / c["launches"], 2),
                            "avg_gflop_per_launch": round(c["flops"] / c["launches"] / 1e9, 3),
                            "achieved_by_pass": {"forward": tf(kt["conv_igemm_fwd"]), "input_grad": tf(kt["conv_igemm_dgrad"]),
