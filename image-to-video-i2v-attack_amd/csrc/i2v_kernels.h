@@ -24,7 +24,7 @@ int  be_stream_sync(i2v_stream_t s);
 int  be_device_sync();                                                       // last backend error or null
 
 int k_conv(const I2VConvParams& p, i2v_stream_t s);
-int k_conv_candidates(const I2VConvParams& p, int* out);   // tile configurations valid for p (ids 0..4), returns count
+int k_conv_candidates(const I2VConvParams& p, int* out);   // tile configurations valid for p (ids 0..5, +8 = no epilogue prefetch), returns count
 int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_pool3d_fwd(const I2VPoolParams& p, i2v_stream_t s);  // video max pooling (kt/stride_t/pad_t honoured)
