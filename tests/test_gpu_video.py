@@ -267,3 +267,28 @@ def test_concurrent_clip_streams_bit_identical(eng):
     assert len(workers) == 3
     for g, w in zip(got, want):
         assert torch.equal(g.cpu(), w)
+
+
+def test_tile_configurations_are_bit_identical(eng, monkeypatch):
+    """The plan-time autotuner picks tiles by timing, so two plans of the same net may use different tiles (and the clip
+    lanes plan one net each): results must not depend on the pick.  They do not -- an fp32 MFMA, 32x32x2 or 16x16x4, is a
+    sequential fma chain along K, so every output element is the same chain whatever the tile: features and input gradient
+    of all six configurations are compared bit for bit."""
+    monkeypatch.setenv("I2V_AUTOTUNE", "0")
+    g = graphs.build_tiny("resnet", (64, 64))              # width 8: many launches with <= 16 output rows, image gradient Cd = 12
+    sd = weights.synthetic_state_dict(g, 0)
+    x = dev(torch.randn(6, 3, 64, 64, generator=torch.Generator().manual_seed(0)))
+    outs = []
+    for cfg in range(6):
+        monkeypatch.setenv("I2V_FORCE_CFG", str(cfg))
+        net = eng.build_net(g, sd, [g.hooks[3]], 6)
+        net.forward(x)
+        f = net.save_hook(0, 6).cpu()
+        hg = torch.randn(f.shape, generator=torch.Generator().manual_seed(1))
+        write_hook_grads(net, [f], [hg])
+        gx = torch.empty(6, 3, 64, 64, device="cuda:0")
+        net.backward(gx)
+        outs.append((f, gx.cpu()))
+        net.close()
+    for f, gx in outs[1:]:
+        assert torch.equal(f, outs[0][0]) and torch.equal(gx, outs[0][1])
