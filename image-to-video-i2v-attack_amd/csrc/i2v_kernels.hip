@@ -1124,7 +1124,9 @@ __global__ void adam_kernel(float* __restrict__ delta, float* __restrict__ m, fl
         const float g = pass ? __fdiv_rn(gx[i], c_std[c]) : 0.f;
         const float mm = fmaf(w1, __fsub_rn(g, m[i]), m[i]);                  // lerp_(g, 1-b1)
         const float vv = __fadd_rn(__fmul_rn(v[i], beta2), __fmul_rn(__fmul_rn(w2, g), g));   // mul_, addcmul_
-        const float den = __fadd_rn(__fdiv_rn(__fsqrt_rn(vv), bc2_sqrt), adam_eps);
+        // sqrtf, not __fsqrt_rn: on ROCm 7 the intrinsic is NOT correctly rounded for small arguments (166 290 of 2^20
+        // values in [1e-13, 1e-11] differ from the IEEE result), sqrtf is (hipcc's default correctly-rounded divide/sqrt)
+        const float den = __fadd_rn(__fdiv_rn(sqrtf(vv), bc2_sqrt), adam_eps);
         delta[i] = __fadd_rn(d, __fmul_rn(-step_size, __fdiv_rn(mm, den)));   // addcdiv_
         m[i] = mm; v[i] = vv;
     }

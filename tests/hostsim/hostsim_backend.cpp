@@ -64,8 +64,8 @@ int k_conv(const I2VConvParams& p, i2v_stream_t) {
                         int hs = i * p.sh + e.dh, ws = j * p.sw + e.dw;
                         if (hs < 0 || hs >= p.Hs || ws < 0 || ws >= p.Ws || t0 + dt < 0 || t0 + dt >= p.Ts) continue;
                         float xv = p.src[(int64_t)(nsrc + dt) * p.src_nstride + e.chan_off + (size_t)hs * p.Ws + ws];
-                        if (p.pre_scale) { xv = xv * p.pre_scale[k] + p.pre_shift[k]; xv = xv > 0.f ? xv : 0.f; }
-                        acc += p.wp[(size_t)k * p.Cdpad + cd] * xv;
+                        if (p.pre_scale) { xv = fmaf(xv, p.pre_scale[k], p.pre_shift[k]); xv = xv > 0.f ? xv : 0.f; }
+                        acc = fmaf(p.wp[(size_t)k * p.Cdpad + cd], xv, acc);      // one fused multiply-add per K row, in packed-K order: what an fp32 MFMA chain computes
                     }
                     if (p.blk > 1) {            // class-packed Cd (image gradient)
                         int Creal = p.Cd / (p.blkt * p.blk * p.blk), cls3 = cd / Creal, c = cd % Creal;
@@ -89,7 +89,7 @@ int k_conv(const I2VConvParams& p, i2v_stream_t) {
                     size_t oidx = (size_t)cd * p.Ho * p.Wo + (size_t)oh * p.Wo + ow;
                     float v = acc;
                     if (p.gate_scale) {     // pre-activation gate: applies to THIS contribution only, before the adds
-                        float m = p.mask[(size_t)n * p.mask_nstride + oidx] * p.gate_scale[cd] + p.gate_shift[cd];
+                        float m = fmaf(p.mask[(size_t)n * p.mask_nstride + oidx], p.gate_scale[cd], p.gate_shift[cd]);
                         if (!(m > 0.f)) v = 0.f;
                     }
                     if (p.shift) v += p.shift[cd];
@@ -230,18 +230,77 @@ int k_addmask(const I2VAddMaskParams& p, i2v_stream_t) {
     return 0;
 }
 
+// Cosine similarity: the SAME reduction tree as the device kernels (cos_reduce_kernel / cos_grad_kernel) -- per-thread fp32
+// partial sums over the float4-strided slices of a block, 64-lane shuffle-down trees, four wave results combined as
+// (r0+r1)+(r2+r3), then the per-block partials summed in double over a 64-lane tree -- so that a whole attack run on this
+// backend is bit-identical to the run on the GPU (tests/test_gpu_video.py).  volatile keeps the host compiler from
+// re-associating or contracting.
+static float tree64(const float* v) {          // lane 0 of: for o in 32,16,..,1: v[l] += v[l+o]
+    volatile float t[64];
+    for (int l = 0; l < 64; ++l) t[l] = v[l];
+    for (int o = 32; o > 0; o >>= 1) for (int l = 0; l < o; ++l) t[l] = t[l] + t[l + o];
+    return t[0];
+}
+static double tree64d(const double* v) {
+    volatile double t[64];
+    for (int l = 0; l < 64; ++l) t[l] = v[l];
+    for (int o = 32; o > 0; o >>= 1) for (int l = 0; l < o; ++l) t[l] = t[l] + t[l + o];
+    return t[0];
+}
+
 int k_cos(const I2VCosParams& p, i2v_stream_t) {
-    float coef = p.coef_host * (p.coef_dev ? p.coef_dev[p.coef_index] : 1.f);
+    const bool vec = ((p.a_nstride | p.b_nstride) & 3) == 0;      // device also requires 16-byte aligned bases (always true there)
+    std::vector<float> part((size_t)p.N * p.nblk * 4, 0.f);
     for (int n = 0; n < p.N; ++n) {
         const float* a = p.a + (size_t)n * p.a_nstride; const float* b = p.b + (size_t)n * p.b_nstride;
-        double dot = 0, aa = 0, bb = 0;
-        for (int64_t i = 0; i < p.D; ++i) { dot += (double)a[i] * b[i]; aa += (double)a[i] * a[i]; bb += (double)b[i] * b[i]; }
-        double n1 = std::max(sqrt(aa), 1e-8), n2 = std::max(sqrt(bb), 1e-8);
-        double cs = dot / (n1 * n2);
+        for (int blk = 0; blk < p.nblk; ++blk) {
+            const int64_t chunk = ((p.D + p.nblk - 1) / p.nblk + 3) & ~(int64_t)3;
+            const int64_t lo = blk * chunk, hi = (lo + chunk < p.D) ? lo + chunk : p.D;
+            float dot[256], aa[256], bb[256];
+            for (int t = 0; t < 256; ++t) {
+                volatile float d = 0.f, x2 = 0.f, y2 = 0.f;
+                auto one = [&](int64_t i) {
+                    volatile float m;
+                    m = a[i] * b[i]; d = d + m; m = a[i] * a[i]; x2 = x2 + m; m = b[i] * b[i]; y2 = y2 + m;
+                };
+                if (vec) {
+                    const int64_t hi4 = lo + ((hi - lo) & ~(int64_t)3);
+                    for (int64_t i = lo + t * 4; i < hi4; i += 1024) {
+                        volatile float s, m;
+                        s = a[i] * b[i]; m = a[i + 1] * b[i + 1]; s = s + m; m = a[i + 2] * b[i + 2]; s = s + m; m = a[i + 3] * b[i + 3]; s = s + m; d = d + s;
+                        s = a[i] * a[i]; m = a[i + 1] * a[i + 1]; s = s + m; m = a[i + 2] * a[i + 2]; s = s + m; m = a[i + 3] * a[i + 3]; s = s + m; x2 = x2 + s;
+                        s = b[i] * b[i]; m = b[i + 1] * b[i + 1]; s = s + m; m = b[i + 2] * b[i + 2]; s = s + m; m = b[i + 3] * b[i + 3]; s = s + m; y2 = y2 + s;
+                    }
+                    for (int64_t i = hi4 + t; i < hi; i += 256) one(i);
+                } else {
+                    for (int64_t i = lo + t; i < hi; i += 256) one(i);
+                }
+                dot[t] = d; aa[t] = x2; bb[t] = y2;
+            }
+            float* o = &part[((size_t)n * p.nblk + blk) * 4];
+            volatile float r[3][4];
+            for (int w = 0; w < 4; ++w) { r[0][w] = tree64(dot + 64 * w); r[1][w] = tree64(aa + 64 * w); r[2][w] = tree64(bb + 64 * w); }
+            for (int q = 0; q < 3; ++q) { volatile float u = r[q][0] + r[q][1], v = r[q][2] + r[q][3]; o[q] = u + v; }
+        }
+    }
+    for (int n = 0; n < p.N; ++n) {
+        double d[64] = {0}, x[64] = {0}, y[64] = {0};
+        for (int t = 0; t < 64 && t < p.nblk; ++t) { const float* o = &part[((size_t)n * p.nblk + t) * 4]; d[t] = o[0]; x[t] = o[1]; y[t] = o[2]; }
+        const double fd = tree64d(d), fx = tree64d(x), fy = tree64d(y);
+        const double n1 = std::max(sqrt(fx), 1e-8), n2 = std::max(sqrt(fy), 1e-8);
+        volatile double nn = n1 * n2;
+        const double cs = fd / nn;
         p.cos_out[n] = (float)cs;
+        double coef = (double)p.coef_host;
+        if (p.coef_dev) coef *= (double)p.coef_dev[p.coef_index];
+        volatile double c1 = coef / nn;
+        volatile double c2a = coef * cs, n11 = n1 * n1;
+        volatile double c2 = c2a / n11;
+        const float* a = p.a + (size_t)n * p.a_nstride; const float* b = p.b + (size_t)n * p.b_nstride;
         float* g = p.grad + (size_t)n * p.grad_nstride;
         for (int64_t i = 0; i < p.D; ++i) {
-            float v = (float)(coef * (b[i] / (n1 * n2) - cs * a[i] / (n1 * n1)));
+            volatile double t1 = c1 * (double)b[i], t2 = c2 * (double)a[i];
+            float v = (float)(t1 - t2);
             if (p.mask_relu && !(a[i] > 0.f)) v = 0.f;
             g[i] = p.accumulate ? g[i] + v : v;
         }

@@ -292,3 +292,70 @@ def test_tile_configurations_are_bit_identical(eng, monkeypatch):
         net.close()
     for f, gx in outs[1:]:
         assert torch.equal(f, outs[0][0]) and torch.equal(gx, outs[0][1])
+
+
+@pytest.mark.parametrize("name,hw,depths", [("resnet", 64, [2, 3]), ("vgg", 32, [3]), ("squeezenet", 64, [2, 3]), ("alexnet", 64, [3]),
+                                            ("densenet121", 64, [2]), ("i3d_resnet50", (8, 32, 32), None),
+                                            ("slowfast_resnet50", (8, 32, 32), None)])
+def test_hip_kernels_bit_exact_against_scalar_restatement(eng, name, hw, depths):
+    """The strongest statement about the kernels: run the SAME planned launch lists on the gfx950 kernels and on their
+    scalar host restatement (tests/hostsim/hostsim_backend.cpp: the literal definition of every launch-parameter struct,
+    one fmaf per K row in packed-K order) and compare every activation and the input gradient BIT FOR BIT.  Holds because
+    an fp32 MFMA is a sequential fused-multiply-add chain along K and the epilogues apply the same fp32 operations in the
+    same order; the cosine / ILAF reductions (fp64 partial sums in a different order) are not part of this test."""
+    from tests.hostsim_util import hostsim_engine
+    cpu = hostsim_engine()
+    video = not isinstance(hw, int)
+    if video:
+        g = graphs.build_video_tiny(name, hw)
+        hooks = graphs.video_hooks(g, name)
+        frames, shape = 2 * hw[0], (hw[1], hw[2])
+    else:
+        g = graphs.build_tiny(name, (hw, hw))
+        hooks = [g.hooks[d] for d in depths]
+        frames, shape = 3, (hw, hw)
+    sd = weights.synthetic_state_dict(g, 0)
+    x = torch.randn(frames, 3, *shape, generator=torch.Generator().manual_seed(0))
+    ng, nc = eng.build_net(g, sd, hooks, frames), cpu.build_net(g, sd, hooks, frames)
+    ng.forward(dev(x))
+    nc.forward(x)
+    for nd in ng.graph.nodes:
+        nf = frames // g.tensors[g.input].T * g.tensors[nd.dst].T
+        assert torch.equal(ng.read_tensor(nd.dst, nf).cpu(), nc.read_tensor(nd.dst, nf)), nd
+    feats = [nc.save_hook(i, nc.hook_frames(i, frames)) for i in range(len(hooks))]
+    hg = [torch.randn(f.shape, generator=torch.Generator().manual_seed(1 + i)) for i, f in enumerate(feats)]
+    write_hook_grads(ng, feats, hg)
+    from tests.test_planner_hostsim import write_hook_grads as write_cpu
+    write_cpu(nc, feats, hg, None)
+    gg, gc = torch.empty(frames, 3, *shape, device="cuda:0"), torch.empty(frames, 3, *shape)
+    ng.backward(gg)
+    nc.backward(gc)
+    assert torch.equal(gg.cpu(), gc)
+    ng.close()
+    nc.close()
+
+
+@pytest.mark.parametrize("models,depths,steps", [(["resnet"], 3, 10), (["vgg"], 2, 4), (["resnet", "vgg", "squeezenet", "alexnet"],
+                                                                                 {"resnet": 2, "vgg": 3, "squeezenet": 2, "alexnet": 3}, 3)])
+def test_whole_attack_bit_exact_against_scalar_restatement(eng, models, depths, steps):
+    """The complete I2V / ENS-I2V loop -- un-normalise, compose, backbone forward, cosine loss, input gradient, Adam, final
+    compose -- on the MI355X against the scalar host restatement of every kernel (same planner, same launch lists): the
+    perturbed clip must come out BIT-IDENTICAL after `steps` chaotic iterations, which only happens if every kernel
+    computes exactly its definition (the host cosine kernel replays the device's reduction tree)."""
+    from tests.hostsim_util import hostsim_engine
+    gen = torch.Generator().manual_seed(77)
+    vid = gu.videos_of({"clip_u8": torch.randint(0, 256, (2, 3, 3, 64, 64), generator=gen, dtype=torch.uint8).numpy()})
+
+    def make(engine):
+        if len(models) == 1:
+            return attacks.ImageGuidedFMDirection_Adam(models, depth=depths, step_size=0.005, steps=steps, engine=engine,
+                                                       graph_builder=graphs.build_tiny)
+        return attacks.ImageGuidedFML2_Adam_MultiModels(models, depths=depths, steps=steps, engine=engine, graph_builder=graphs.build_tiny)
+    on_gpu, on_cpu = make(eng), make(hostsim_engine())
+    on_gpu.clip_lanes = 1
+    a = on_gpu(vid, torch.zeros(2, dtype=torch.long), ["a", "b"]).cpu()
+    b = on_cpu(vid, torch.zeros(2, dtype=torch.long), ["a", "b"])
+    assert torch.equal(a, b)
+    assert torch.equal(on_gpu._delta.cpu(), on_cpu._delta)
+    np.testing.assert_allclose(on_gpu.last_costs, on_cpu.last_costs, rtol=1e-6)      # the batch cost is summed by torch on either side
+    assert float((a - vid).abs().max()) > 0.02                                       # and the attack did move the clip

@@ -41,8 +41,8 @@ def test_forward_backward_match_oracle(model, depths, hw):
     feats = onet.forward(x.double())
     net.forward(x)
     for nd in net.graph.nodes:                       # every activation the truncated graph produces
-        got = net.read_tensor(nd.dst, N).double()
-        assert torch.allclose(got, onet.tensor(nd.dst), rtol=1e-4, atol=1e-5), nd
+        got, want = net.read_tensor(nd.dst, N).double(), onet.tensor(nd.dst)
+        assert torch.allclose(got, want, rtol=1e-4, atol=max(1e-5, 1e-6 * float(want.abs().max()))), nd   # fp32 vs f64
     hg = [torch.randn_like(f) for f in feats]        # well-conditioned random hook gradients
     write_hook_grads(net, feats, hg, N)
     gx = torch.empty(N, 3, hw, hw)
