@@ -197,9 +197,12 @@ def cosine_fwd_bwd(a: torch.Tensor, b: torch.Tensor):
 
 
 class AdamState:
-    """`torch.optim.Adam([delta], lr)` with defaults betas=(0.9,0.999), eps=1e-8
-    (`image_attacks.py:306`), single-tensor path of torch/optim/adam.py: lerp_ for m,
-    mul_+addcmul_ for v, host-side bias corrections in double."""
+    """`torch.optim.Adam([delta], lr)` with defaults betas=(0.9,0.999), eps=1e-8 (`image_attacks.py:306`), single-tensor path
+    of torch/optim/adam.py -- `lerp_` for m, `mul_` + `addcmul_` for v, `sqrt / bc2_sqrt + eps`, `addcdiv_`, host-side bias
+    corrections in double -- written as SEPARATE single-rounding operations (lerp = one fused multiply-add).  torch's own CPU
+    kernels are not a bit-level reference: ATen's vectorised `addcmul` / `addcdiv` contract to FMA on some hosts and not on
+    others, an ulp of difference; this formulation is host-independent and is what the HIP kernel and its scalar restatement
+    compute bit for bit."""
 
     def __init__(self, like, lr, beta1=0.9, beta2=0.999, eps=1e-8):
         self.m = torch.zeros_like(like)
@@ -209,13 +212,18 @@ class AdamState:
 
     def step(self, delta, grad):
         self.t += 1
-        self.m.lerp_(grad, 1 - self.b1)
-        self.v.mul_(self.b2).addcmul_(grad, grad, value=1 - self.b2)
+        w1, w2 = 1 - self.b1, 1 - self.b2
+        if delta.dtype == torch.float32:        # fma(w1, g - m, m): the product of two floats is exact in double
+            w1f = float(np.float32(w1))
+            self.m = (self.m.double() + (grad - self.m).double() * w1f).float()
+        else:
+            self.m = self.m + (grad - self.m) * w1
+        self.v = self.v * self.b2 + (grad * w2) * grad
         bc1 = 1 - self.b1 ** self.t
         bc2 = 1 - self.b2 ** self.t
         step_size = self.lr / bc1
-        denom = (self.v.sqrt() / (bc2 ** 0.5)).add_(self.eps)
-        delta.addcdiv_(self.m, denom, value=-step_size)
+        denom = self.v.sqrt() / (bc2 ** 0.5) + self.eps
+        delta.add_((self.m / denom) * (-step_size))
 
 
 def sign_step_bim(adv_norm, u, grad, step_size, eps):
