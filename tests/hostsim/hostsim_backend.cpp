@@ -308,22 +308,55 @@ int k_cos(const I2VCosParams& p, i2v_stream_t) {
     return 0;
 }
 
+// Whole-tensor reductions (DR loss, ILAF loss): the device kernels' trees replayed -- per-thread double sums over a block's
+// slice with stride 256, 64-lane shuffle-down trees, (r0+r1)+(r2+r3), then the block partials summed the same way.
+static void block_sums2(const std::vector<double>& t0, const std::vector<double>& t1, double* o0, double* o1) {
+    volatile double r0[4], r1[4];
+    for (int w = 0; w < 4; ++w) { r0[w] = tree64d(t0.data() + 64 * w); r1[w] = tree64d(t1.data() + 64 * w); }
+    volatile double a = r0[0] + r0[1], b = r0[2] + r0[3]; *o0 = a + b;
+    volatile double c = r1[0] + r1[1], d = r1[2] + r1[3]; *o1 = c + d;
+}
+static void finish_sums2(const std::vector<double>& partial, int np, double* sums) {
+    std::vector<double> t0(256, 0.0), t1(256, 0.0);
+    for (int t = 0; t < 256; ++t) {
+        volatile double s = 0, q = 0;
+        for (int i = t; i < np; i += 256) { s = s + partial[2 * i]; q = q + partial[2 * i + 1]; }
+        t0[t] = s; t1[t] = q;
+    }
+    block_sums2(t0, t1, &sums[0], &sums[1]);
+}
+
 int k_std_reduce(const I2VStdParams& p, i2v_stream_t) {
-    double s = 0, ss = 0;
-    for (int n = 0; n < p.N; ++n) { const float* a = p.a + (size_t)n * p.a_nstride; for (int64_t i = 0; i < p.D; ++i) { s += a[i]; ss += (double)a[i] * a[i]; } }
-    p.sums[0] = s; p.sums[1] = ss;
+    std::vector<double> partial((size_t)p.N * p.nblk * 2);
+    for (int n = 0; n < p.N; ++n) for (int blk = 0; blk < p.nblk; ++blk) {
+        const int64_t chunk = (p.D + p.nblk - 1) / p.nblk, lo = blk * chunk, hi = (lo + chunk < p.D) ? lo + chunk : p.D;
+        const float* a = p.a + (size_t)n * p.a_nstride;
+        std::vector<double> t0(256), t1(256);
+        for (int t = 0; t < 256; ++t) {
+            volatile double s = 0, ss = 0;
+            for (int64_t i = lo + t; i < hi; i += 256) { const double v = a[i]; volatile double v2 = v * v; s = s + v; ss = ss + v2; }
+            t0[t] = s; t1[t] = ss;
+        }
+        block_sums2(t0, t1, &partial[((size_t)n * p.nblk + blk) * 2], &partial[((size_t)n * p.nblk + blk) * 2 + 1]);
+    }
+    finish_sums2(partial, p.N * p.nblk, p.sums);
     return 0;
 }
 
 int k_std_grad(const I2VStdParams& p, i2v_stream_t) {
-    double cnt = p.total_count, mu = p.sums[0] / cnt;
-    double var = (p.sums[1] - cnt * mu * mu) / (cnt - 1); if (var < 0) var = 0;
-    double sd = sqrt(var);
+    const double s = p.sums[0], ss = p.sums[1], cnt = p.total_count;
+    volatile double mu = s / cnt;
+    volatile double cm = cnt * mu, cmm = cm * mu, num = ss - cmm, var0 = num / (cnt - 1.0);
+    const double var = var0 > 0.0 ? var0 : 0.0;
+    const double sd = sqrt(var);
     p.std_out[0] = (float)sd;
+    volatile double den = (cnt - 1.0) * sd;
+    volatile double inv = 1.0 / den;
     for (int n = 0; n < p.N; ++n) {
         const float* a = p.a + (size_t)n * p.a_nstride; float* g = p.grad + (size_t)n * p.grad_nstride;
         for (int64_t i = 0; i < p.D; ++i) {
-            float v = (float)((a[i] - mu) / ((cnt - 1) * sd));
+            volatile double c = (double)a[i] - mu, r = c * inv;
+            float v = (float)r;
             if (p.mask_relu && !(a[i] > 0.f)) v = 0.f;
             g[i] = p.accumulate ? g[i] + v : v;
         }
@@ -332,28 +365,44 @@ int k_std_grad(const I2VStdParams& p, i2v_stream_t) {
 }
 
 int k_ilaf_reduce(const I2VIlafParams& p, i2v_stream_t) {
-    double dd = 0, dq = 0;
-    for (int n = 0; n < p.N; ++n) {
+    std::vector<double> partial((size_t)p.N * p.nblk * 2);
+    for (int n = 0; n < p.N; ++n) for (int blk = 0; blk < p.nblk; ++blk) {
+        const int64_t chunk = (p.D + p.nblk - 1) / p.nblk, lo = blk * chunk, hi = (lo + chunk < p.D) ? lo + chunk : p.D;
         const float* a = p.a + (size_t)n * p.a_nstride; const float* o = p.ori + (size_t)n * p.D; const float* a0 = p.adv0 + (size_t)n * p.D;
-        for (int64_t i = 0; i < p.D; ++i) {
-            volatile float d = a[i] - o[i]; volatile float d0 = a0[i] - o[i];
-            dd += (double)d * d; dq += (double)d * d0;
+        std::vector<double> t0(256), t1(256);
+        for (int t = 0; t < 256; ++t) {
+            volatile double dd = 0, dq = 0;
+            for (int64_t i = lo + t; i < hi; i += 256) {
+                volatile float df = a[i] - o[i], d0f = a0[i] - o[i];
+                const double d = df, d0 = d0f;
+                volatile double m1 = d * d, m2 = d * d0;
+                dd = dd + m1; dq = dq + m2;
+            }
+            t0[t] = dd; t1[t] = dq;
         }
+        block_sums2(t0, t1, &partial[((size_t)n * p.nblk + blk) * 2], &partial[((size_t)n * p.nblk + blk) * 2 + 1]);
     }
-    p.sums[0] = dd; p.sums[1] = dq;
+    finish_sums2(partial, p.N * p.nblk, p.sums);
     return 0;
 }
 
 int k_ilaf_grad(const I2VIlafParams& p, i2v_stream_t) {
     const double s = sqrt(p.sums[0]), q = p.sums[1], n0 = p.init_norm;
-    p.loss_out[0] = (float)(-(0.5 * s / n0 + q / (n0 * s)));
-    const double cd = -(0.5 / s - q / (s * s * s)) / n0, c0 = -1.0 / (s * n0);
+    {
+        volatile double t1 = 0.5 * s, t2 = t1 / n0, t3 = n0 * s, t4 = q / t3, t5 = t2 + t4;
+        p.loss_out[0] = (float)(-t5);
+    }
+    volatile double h = 0.5 / s, ss = s * s, sss = ss * s, qs = q / sss, hd = h - qs, nhd = -hd;
+    volatile double cd = nhd / n0;
+    volatile double sn = s * n0;
+    volatile double c0 = -1.0 / sn;
     for (int n = 0; n < p.N; ++n) {
         const float* a = p.a + (size_t)n * p.a_nstride; const float* o = p.ori + (size_t)n * p.D; const float* a0 = p.adv0 + (size_t)n * p.D;
         float* g = p.grad + (size_t)n * p.grad_nstride;
         for (int64_t i = 0; i < p.D; ++i) {
-            volatile float d = a[i] - o[i]; volatile float d0 = a0[i] - o[i];
-            float v = (float)(cd * (double)d + c0 * (double)d0);
+            volatile float df = a[i] - o[i], d0f = a0[i] - o[i];
+            volatile double t1 = cd * (double)df, t2 = c0 * (double)d0f, r = t1 + t2;
+            float v = (float)r;
             if (p.mask_relu && !(a[i] > 0.f)) v = 0.f;
             g[i] = p.accumulate ? g[i] + v : v;
         }

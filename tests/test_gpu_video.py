@@ -359,3 +359,28 @@ def test_whole_attack_bit_exact_against_scalar_restatement(eng, models, depths, 
     assert torch.equal(on_gpu._delta.cpu(), on_cpu._delta)
     np.testing.assert_allclose(on_gpu.last_costs, on_cpu.last_costs, rtol=1e-6)      # the batch cost is summed by torch on either side
     assert float((a - vid).abs().max()) > 0.02                                       # and the attack did move the clip
+
+
+def test_dr_and_ilaf_loops_bit_exact_against_scalar_restatement(eng):
+    """The same for the whole-tensor losses: the Dispersion-Reduction attack (unbiased std over the batch) and the native
+    ILAF loop on the I3D and SlowFast graphs -- the host kernels replay the device's double-precision reduction trees."""
+    from tests.hostsim_util import hostsim_engine
+    cpu = hostsim_engine()
+    gen = torch.Generator().manual_seed(78)
+    vid = gu.videos_of({"clip_u8": torch.randint(0, 256, (2, 3, 3, 64, 64), generator=gen, dtype=torch.uint8).numpy()})
+    runs = []
+    for engine in (eng, cpu):
+        dr = attacks.ImageGuidedStd_Adam(["resnet"], depth=2, step_size=0.005, steps=5, engine=engine, graph_builder=graphs.build_tiny)
+        runs.append((dr(vid, torch.zeros(2, dtype=torch.long), ["a", "b"]).cpu(), dr.last_costs))
+    assert torch.equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])              # the std itself comes out of the kernels: bit-equal too
+    for name in ("ilaf_i3d_f32", "ilaf_slowfast_f64"):
+        fx = load(name)
+        adv, ori = clips(fx)
+        outs = []
+        for engine in (eng, cpu):
+            model = video.VideoModel(fx["model_type"], fx["thw"], weight_seed=fx["wseed"], tiny=True)
+            atk = sign_attacks.ILAF(model, fx["model_type"], step_size=0.005, steps=6, engine=engine)
+            outs.append((atk(adv.clone(), ori.clone(), torch.zeros(fx["b"], dtype=torch.long), ["v"]).cpu(), atk.last_costs))
+        assert torch.equal(outs[0][0], outs[1][0])
+        np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-6)  # per-layer losses are bit-equal, their sum is torch's
