@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")"
 cp libi2v_hostsim.so /tmp/libi2v_hostsim.keep 2>/dev/null || true
-g++ -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -o libi2v_hostsim.so \
+g++ -O1 -g -ffp-contract=off -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -o libi2v_hostsim.so \
     ../../image-to-video-i2v-attack_amd/csrc/i2v_engine.cpp hostsim_backend.cpp
 cd ../..
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 \

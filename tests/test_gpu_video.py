@@ -384,3 +384,31 @@ def test_dr_and_ilaf_loops_bit_exact_against_scalar_restatement(eng):
             outs.append((atk(adv.clone(), ori.clone(), torch.zeros(fx["b"], dtype=torch.long), ["v"]).cpu(), atk.last_costs))
         assert torch.equal(outs[0][0], outs[1][0])
         np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-6)  # per-layer losses are bit-equal, their sum is torch's
+
+
+def test_full_size_resnet50_bit_exact_against_scalar_restatement(eng):
+    """The headline backbone at its real size -- ResNet-50 to layer3 on a 224 x 224 frame, 43 convolutions, 3.28 GMAC --
+    forward and input gradient against the scalar restatement, bit for bit (about 25 s of scalar host work).  Together with
+    frame independence (test_full_size_properties_resnet50, the clip-lane tests) this covers the 128-frame bench workload."""
+    from tests.hostsim_util import hostsim_engine
+    from tests.test_planner_hostsim import write_hook_grads as write_cpu
+    cpu = hostsim_engine()
+    g = graphs.build("resnet50", (224, 224))
+    sd = weights.synthetic_state_dict(g, 0)
+    hooks = [g.hooks[3]]
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    ng, nc = eng.build_net(g, sd, hooks, 1), cpu.build_net(g, sd, hooks, 1)
+    ng.forward(dev(x))
+    nc.forward(x)
+    for nd in ng.graph.nodes:
+        assert torch.equal(ng.read_tensor(nd.dst, 1).cpu(), nc.read_tensor(nd.dst, 1)), nd
+    f = nc.save_hook(0, 1)
+    hg = torch.randn(f.shape, generator=torch.Generator().manual_seed(1))
+    write_hook_grads(ng, [f], [hg])
+    write_cpu(nc, [f], [hg], None)
+    gg, gc = torch.empty(1, 3, 224, 224, device="cuda:0"), torch.empty(1, 3, 224, 224)
+    ng.backward(gg)
+    nc.backward(gc)
+    assert torch.equal(gg.cpu(), gc) and float(gc.abs().max()) > 0
+    ng.close()
+    nc.close()
