@@ -139,19 +139,19 @@ def main():
     eng = attacks.get_engine(dev)
     names4 = ["resnet", "vgg", "squeezenet", "alexnet"]
     if args.workload == "i2v":
-        atk = attacks.ImageGuidedFMDirection_Adam([MODEL], depth=DEPTH, step_size=0.005, steps=ATTACK_STEPS, engine=eng)
+        atk = attacks.ImageGuidedFMDirection_Adam([MODEL], depth=DEPTH, step_size=0.005, steps=ATTACK_STEPS, engine=eng, weight_seed=0)
     elif args.workload == "ens":
         atk = attacks.ImageGuidedFML2_Adam_MultiModels(names4, depths={"resnet": 2, "vgg": 3, "squeezenet": 2, "alexnet": 3},
-                                                       steps=ATTACK_STEPS, engine=eng)
+                                                       steps=ATTACK_STEPS, engine=eng, weight_seed=0)
     elif args.workload == "config2":      # BASELINE.json configs[2]: ResNet-50 + VGG-16 + DenseNet-121
         names3 = ["resnet50", "vgg", "densenet121"]
         atk = attacks.ImageGuidedFML2_Adam_MultiModels(names3, depths={"resnet50": 3, "vgg": 3, "densenet121": 3},
-                                                       steps=ATTACK_STEPS, engine=eng)
+                                                       steps=ATTACK_STEPS, engine=eng, weight_seed=0)
     elif args.workload == "ilaf":         # BASELINE.json configs[4]: ILAF fine-tuning, 60 steps (image_attacks.py:502), 1 clip per call
         from i2v_amd import sign_attacks, video
-        atk = sign_attacks.ILAF(video.VideoModel(args.white_model, (FRAMES, HW, HW)), args.white_model, engine=eng)
+        atk = sign_attacks.ILAF(video.VideoModel(args.white_model, (FRAMES, HW, HW), weight_seed=0), args.white_model, engine=eng)
     else:
-        atk = attacks.AENS_I2V_MF(names4, depths={n: [2, 3] for n in names4}, step_size=0.005, steps=ATTACK_STEPS, engine=eng)
+        atk = attacks.AENS_I2V_MF(names4, depths={n: [2, 3] for n in names4}, step_size=0.005, steps=ATTACK_STEPS, engine=eng, weight_seed=0)
     b = 1 if args.workload == "ilaf" and args.clips == CLIPS_PER_GPU else args.clips
     videos = synthetic_clips(b, seed0=1000 + rank * b).to(dev)         # resident in HBM before timing
     labels = torch.zeros(b, dtype=torch.long)
@@ -170,7 +170,7 @@ def main():
         for k in range(1, max(1, args.streams)):
             o2 = synthetic_clips(b, seed0=5000 + rank * 64 + k * b).to(dev)
             n2 = (torch.randint(-10, 11, o2.shape, generator=gen).float() / 255 / std).to(dev)
-            lanes.append((sign_attacks.ILAF(video.VideoModel(args.white_model, (FRAMES, HW, HW)), args.white_model, engine=eng),
+            lanes.append((sign_attacks.ILAF(video.VideoModel(args.white_model, (FRAMES, HW, HW), weight_seed=0), args.white_model, engine=eng),
                           (o2 + n2).contiguous(), o2, torch.cuda.Stream(device=dev)))
 
         def lane_calls(lane, reps):

@@ -726,13 +726,20 @@ struct Planner {
         for (int i = (int)n.nodes.size() - 1; i >= 0; --i) {
             const Node& nd = n.nodes[i];
             int dst = nd.type == 0 ? nd.cd.dst : nd.pd.dst;
-            for (size_t hk = 0; hk < n.hooks.size(); ++hk)
-                if (n.hooks[hk] == dst && hook_tmp[hk] && !accum[n.tens[dst].buf]) {
+            // a hook gradient kept in a side buffer joins the gradient of every node output the hooked view COVERS:
+            // the hooked tensor itself, or -- a hooked concatenation (SqueezeNet Fire output = expand1x1 ++ expand3x3,
+            // TPAMI_attack.py:195-197) -- each branch's channel slice of it
+            for (size_t hk = 0; hk < n.hooks.size(); ++hk) {
+                const Tensor& HT = n.tens[n.hooks[hk]]; const Tensor& DT = n.tens[dst];
+                const bool covers = HT.buf == DT.buf && HT.c_off <= DT.c_off && DT.c_off + DT.C <= HT.c_off + HT.C;
+                if (covers && hook_tmp[hk] && !accum[DT.buf]) {
                     View g = view(dst, true);
+                    const int64_t hD = (int64_t)HT.C * g.H * g.W;
                     std::vector<Addend> adds = {Addend{g.p, g.nstride, 1, g.H, g.W},
-                                                Addend{hook_tmp[hk], (int64_t)g.C * g.H * g.W, 1, g.H, g.W}};
+                                                Addend{hook_tmp[hk] + (size_t)(DT.c_off - HT.c_off) * g.H * g.W, hD, 1, g.H, g.W}};
                     emit_addmask(g, adds, dst);
                 }
+            }
             View dz = view(dst, true);
             if (need_gate[dst]) emit_addmask(dz, {Addend{dz.p, dz.nstride, 1, dz.H, dz.W}}, dst);
             if (nd.type == 0) {

@@ -717,6 +717,7 @@ static int pool_fail(const char* m) { snprintf(g_be_err, sizeof g_be_err, "%s", 
 
 int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t s) {
     // band of output rows whose input rows fit the LDS buffer
+    if (POOL_FWD_LDS_FLOATS / p.Ws < p.k) return pool_fail("max-pool row too wide for the LDS band");     // (a negative numerator would truncate towards 0 below)
     int band = (POOL_FWD_LDS_FLOATS / p.Ws - p.k) / p.stride + 1;
     if (band < 1) return pool_fail("max-pool row too wide for the LDS band");
     if (band > p.Ho) band = p.Ho;
@@ -727,6 +728,7 @@ int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t s) {
 int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s) {
     // band of input rows whose covering output rows fit the LDS buffers
     int out_rows = (POOL_LDS_FLOATS / 2) / p.Wo;
+    if (out_rows < 1) return pool_fail("max-pool row too wide for the LDS band");
     int band = (out_rows - 1) * p.stride - p.k + 1; if (out_rows >= p.Ho) band = p.Hs;
     if (band < 1) return pool_fail("max-pool row too wide for the LDS band");
     if (band > p.Hs) band = p.Hs;

@@ -63,9 +63,12 @@ class _ImageGuided(Attack):
     _mode = "i2v"
 
     def _setup(self, model_names: Sequence[str], depths_per_model: List[List[int]], engine, graph_builder,
-               weight_seed):
+               weight_seed, whole_module: Optional[List[bool]] = None):
         self.model_names = list(model_names)
         self._depths = depths_per_model
+        # per model: hook the whole module (list depths of the adaptive attack, TPAMI_attack.py:176-200) instead of
+        # the scalar-depth lookup's tensor -- the two differ for SqueezeNet (Fire output vs its 3x3 branch)
+        self._whole = list(whole_module) if whole_module is not None else [False] * len(self.model_names)
         self._engine = engine
         self._builder = graph_builder or _graphs.build
         self._wseed = weight_seed
@@ -93,10 +96,10 @@ class _ImageGuided(Attack):
         for old in (self._nets or []):          # re-planning for a larger batch / other resolution
             old.close()
         nets = []
-        for m, ds in zip(self.model_names, self._depths):
+        for m, ds, whole in zip(self.model_names, self._depths, self._whole):
             g = self._builder(m, hw)
             sd = _weights.load_state_dict(g, self._wseed)
-            nets.append(self.engine.build_net(g, sd, [g.hooks[d] for d in ds], frames))
+            nets.append(self.engine.build_net(g, sd, [g.hook_for(d, whole) for d in ds], frames))
         self._nets, self._net_key, self._max_frames = nets, key, frames
         return nets
 
@@ -104,7 +107,10 @@ class _ImageGuided(Attack):
     def _begin(self, L, dev):
         pass
 
-    def _run(self, videos: torch.Tensor, video_names):
+    def _run(self, videos: torch.Tensor, video_names, state=None, steps=None):
+        """`state` / `steps` serve teacher forcing only (`forced_step`): start from a given (delta, exp_avg,
+        exp_avg_sq) after `t` Adam steps -- and, for the adaptive attack, given coefficients -- and run `steps`
+        iterations instead of `self.steps`."""
         eng = self.engine
         dev = eng.device
         videos = videos.detach().to(device=dev, dtype=torch.float32).contiguous()
@@ -112,8 +118,9 @@ class _ImageGuided(Attack):
         N = b * f
         nets = self._get_nets(N, (h, w))
         L = sum(len(n.hooks) for n in nets)
-        steps, eps = self.steps, float(self.epsilon)
+        steps, eps = (self.steps if steps is None else int(steps)), float(self.epsilon)
         mode = self._mode
+        t0 = 0
         kw = dict(dtype=torch.float32, device=dev)
         x = torch.empty(N, 3, h, w, **kw)
         u = torch.empty_like(x)
@@ -123,6 +130,11 @@ class _ImageGuided(Attack):
         v = torch.zeros_like(delta)
         gx = torch.empty_like(delta)
         xadv = torch.empty_like(delta)
+        if state is not None:
+            delta.copy_(state["delta"].reshape(delta.shape))
+            m.copy_(state["m"].reshape(delta.shape))
+            v.copy_(state["v"].reshape(delta.shape))
+            t0 = int(state["t"])
         scratch = torch.empty(max(n.scratch_bytes(N) for n in nets), dtype=torch.uint8, device=dev)
         init = []
         if mode != "std":
@@ -141,7 +153,10 @@ class _ImageGuided(Attack):
         begin = time.time()
         for i in range(steps):
             if aens:
-                eng.aens_coeffs(prev, self.coeffs, float(self.momentum))   # :265
+                if state is not None and i == 0 and state.get("coeffs") is not None:
+                    self.coeffs.copy_(state["coeffs"].to(dev))             # forced coefficients of this step
+                else:
+                    eng.aens_coeffs(prev, self.coeffs, float(self.momentum))   # :265
                 wts[i].copy_(self.coeffs)
             eng.compose(u, delta, xadv, b, f, eps)                      # image_attacks.py:331-332
             l = 0
@@ -161,7 +176,7 @@ class _ImageGuided(Attack):
                 eng.aens_reduce(vals[i], self.coeffs, feat_sum, weighted[i])
                 self._exchange(feat_sum, weighted[i])
                 prev = (weighted[i] if self.coef_CE else feat_sum).clone()   # TPAMI_attack.py:293-297
-            eng.adam_step(delta, m, v, gx, u, eps, float(self.step_size), i + 1)   # :351-353
+            eng.adam_step(delta, m, v, gx, u, eps, float(self.step_size), t0 + i + 1)   # :351-353
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         self.used_time = time.time() - begin
@@ -180,8 +195,22 @@ class _ImageGuided(Attack):
                 self.loss_info[vid_name] = {}
             for i in range(steps):
                 self.loss_info[vid_name][i] = {"cost": str(costs[i])}
-        self._delta = delta
+        self._delta, self._m, self._v = delta, m, v
+        self._gx = gx                        # d cost / d composed frames of the LAST iteration (before the compose backward)
+        if aens:
+            self._prev = prev                # previous_cs_loss after the last iteration (TPAMI_attack.py:293-297)
         return out
+
+    def forced_step(self, videos, delta, m, v, t, coeffs=None):
+        """Teacher forcing (tests / diagnostics): ONE iteration of the loop from the optimiser state `(delta, m, v)`
+        reached after `t` Adam steps (`image_attacks.py:325-358`, `TPAMI_attack.py:258-312`), always in one lane.
+        Returns `(delta', m', v', cost)`.  `coeffs` forces the adaptive attack's layer weights for this iteration."""
+        saved = dict(self.loss_info)
+        try:
+            self._run(videos, [], state=dict(delta=delta, m=m, v=v, t=t, coeffs=coeffs), steps=1)
+        finally:
+            self.loss_info = saved
+        return self._delta, self._m, self._v, float(self.last_costs[0])
 
     def _exchange(self, feat_sum, weighted_row):
         pass
@@ -220,6 +249,8 @@ class _ImageGuided(Attack):
                 lane = copy.copy(self)
                 lane._nets, lane._net_key, lane.loss_info, lane._lanes = None, None, {}, []
                 self._lanes.append(lane)
+        for lane in self._lanes:                        # the caller may have changed these between calls (legal on the
+            lane.steps, lane.step_size, lane.epsilon = self.steps, self.step_size, self.epsilon    # reference classes)
         by_frames = b == 1                              # one clip: the lanes take frame ranges of it
         total = f if by_frames else b
         cuts = [(total * k) // n_lanes for k in range(n_lanes + 1)]
@@ -278,7 +309,7 @@ class ImageGuidedFMDirection_Adam(_ImageGuided):
     """The I2V attack (`/root/reference/image_attacks.py:236-364`)."""
 
     def __init__(self, model_name_lists, depth, step_size, epsilon=16 / 255, steps=10, *, engine=None,
-                 graph_builder=None, weight_seed=0):
+                 graph_builder=None, weight_seed=None):
         super().__init__("ImageGuidedFMDirection_Adam")
         self.epsilon, self.steps, self.step_size, self.depth = epsilon, steps, step_size, depth
         self.model_name = model_name_lists[0]
@@ -291,7 +322,7 @@ class ImageGuidedStd_Adam(_ImageGuided):
     _mode = "std"
 
     def __init__(self, model_name_lists, depth, step_size, epsilon=16 / 255, steps=10, *, engine=None,
-                 graph_builder=None, weight_seed=0, process_group=None, distributed=None):
+                 graph_builder=None, weight_seed=None, process_group=None, distributed=None):
         super().__init__("ImageGuidedStd_Adam")
         self.epsilon, self.steps, self.step_size, self.depth = epsilon, steps, step_size, depth
         self.model_name = model_name_lists[0]
@@ -325,7 +356,7 @@ class ImageGuidedFML2_Adam_MultiModels(_ImageGuided):
     cost = sum over models and frames; lr is hard-wired to 0.005 (`:376`)."""
 
     def __init__(self, model_name_lists, depths, epsilon=16 / 255, steps=60, *, engine=None, graph_builder=None,
-                 weight_seed=0):
+                 weight_seed=None):
         super().__init__("ImageGuidedFML2_Adam_MultiModels")
         self.epsilon, self.steps, self.step_size, self.depths = epsilon, steps, 0.005, depths
         self._setup(model_name_lists, [[depths[m]] for m in model_name_lists], engine, graph_builder, weight_seed)
@@ -341,14 +372,15 @@ class AENS_I2V_MF(_ImageGuided):
     _mode = "aens"
 
     def __init__(self, model_name_lists, depths, step_size, momentum=0, coef_CE=False, epsilon=16 / 255, steps=60,
-                 *, engine=None, graph_builder=None, weight_seed=0, process_group=None, distributed=None):
+                 *, engine=None, graph_builder=None, weight_seed=None, process_group=None, distributed=None):
         super().__init__("AENS_I2V_MF")
         self.epsilon, self.steps, self.step_size, self.depths = epsilon, steps, step_size, depths
         self.momentum, self.coef_CE = momentum, coef_CE
         self.coeffs = None
         self.weights = []
         per_model = [list(depths[m]) if isinstance(depths[m], (list, tuple)) else [depths[m]] for m in model_name_lists]
-        self._setup(model_name_lists, per_model, engine, graph_builder, weight_seed)
+        whole = [isinstance(depths[m], (list, tuple)) for m in model_name_lists]
+        self._setup(model_name_lists, per_model, engine, graph_builder, weight_seed, whole)
         self._pg = process_group
         self._dist = distributed
 

@@ -81,6 +81,10 @@ class Graph:
     buffers: List[int] = field(default_factory=list)          # channel width per buffer
     nodes: list = field(default_factory=list)
     hooks: Dict[int, int] = field(default_factory=dict)       # depth (1..4) -> tensor id
+    # depth -> tensor id of the WHOLE hooked module's output where that differs from `hooks[depth]`: the list-depth
+    # lookup of the adaptive attack hooks the Fire module itself (TPAMI_attack.py:195-197), i.e. cat(expand1x1,
+    # expand3x3), while the scalar-depth lookup takes `.expand3x3_activation` only (:199, image_attacks.py:269-271)
+    hooks_module: Dict[int, int] = field(default_factory=dict)
     input: int = 0
     video: bool = False                                       # 3-D backbone: conv weights are (cout,cin,kt,kh,kw)
 
@@ -162,8 +166,16 @@ class Graph:
                 if getattr(nd, "residual", None) is not None:
                     needed.add(nd.residual)
         g = Graph(self.arch, self.in_hw, self.tensors, self.buffers,
-                  [n for n, k in zip(self.nodes, keep) if k], dict(self.hooks), self.input, self.video)
+                  [n for n, k in zip(self.nodes, keep) if k], dict(self.hooks), dict(self.hooks_module), self.input,
+                  self.video)
         return g
+
+    def hook_for(self, depth: int, whole_module: bool = False) -> int:
+        """Hooked tensor of `depth`; `whole_module` selects the list-depth lookup of `AENS_I2V_MF`
+        (`/root/reference/TPAMI_attack.py:176-200`), which differs from the scalar one for SqueezeNet only."""
+        if depth not in self.hooks:
+            raise KeyError(depth)
+        return self.hooks_module.get(depth, self.hooks[depth]) if whole_module else self.hooks[depth]
 
     def macs_per_frame(self) -> int:
         """Multiply-adds of one forward pass per input frame (image backbones) / per input CLIP (video)."""
@@ -318,6 +330,7 @@ def squeezenet(width_div=1, in_hw=(224, 224), arch="squeezenet1_1") -> Graph:
         x = g.new_tensor(e1 + e3, st.H, st.W, True, f"{p}.cat", buf=cat_buf, c_off=0)
         if idx in hook_of:
             g.hooks[hook_of[idx]] = t3
+            g.hooks_module[hook_of[idx]] = x
     return g
 
 

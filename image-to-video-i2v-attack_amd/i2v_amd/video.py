@@ -15,10 +15,11 @@ from . import weights as _weights
 
 class VideoModel(object):
     """`model_type` as in `image_fine_tune_attack.py:53` ('i3d_resnet50', 'i3d_resnet101', 'slowfast_resnet50',
-    'slowfast_resnet101').  Weights: `$I2V_WEIGHTS_DIR/<arch>.pth` in the graph's key layout if present, else the
-    seeded synthetic initialiser (`weights.load_state_dict`)."""
+    'slowfast_resnet101').  Weights: `state_dict` (graph key layout; `weights.convert_gluoncv_state_dict` maps a gluoncv
+    checkpoint onto it), else `$I2V_WEIGHTS_DIR/<arch>.pth`, else -- only with an explicit `weight_seed` or
+    `I2V_SYNTHETIC_WEIGHTS=1` -- the seeded synthetic initialiser (`weights.load_state_dict`)."""
 
-    def __init__(self, model_type: str, in_thw=(32, 224, 224), weight_seed: int = 0, tiny: bool = False,
+    def __init__(self, model_type: str, in_thw=(32, 224, 224), weight_seed: Optional[int] = None, tiny: bool = False,
                  state_dict: Optional[dict] = None):
         self.model_type = model_type
         self.in_thw = tuple(in_thw)

@@ -5,7 +5,8 @@ The reference downloads ImageNet checkpoints with `models.<arch>(pretrained=True
 seeded synthetic initialiser: Kaiming-normal(fan_out) convolutions and
 randomised BatchNorm statistics, so that BN folding is actually exercised.  A real checkpoint
 (`torch.save(model.state_dict())` of the torchvision model) is picked up from
-`$I2V_WEIGHTS_DIR/<arch>.pth` when present.
+`$I2V_WEIGHTS_DIR/<arch>.pth` when present; without one the synthetic initialiser must be asked
+for explicitly (`load_state_dict`).
 """
 import os
 import zlib
@@ -52,12 +53,30 @@ def synthetic_state_dict(graph: Graph, seed: int = 0) -> Dict[str, torch.Tensor]
     return sd
 
 
-def load_state_dict(graph: Graph, seed: int = 0) -> Dict[str, torch.Tensor]:
-    """Real checkpoint if `$I2V_WEIGHTS_DIR/<arch>.pth` exists, else the seeded initialiser."""
+class MissingWeights(FileNotFoundError):
+    pass
+
+
+#: arch -> where its weights came from in this process ("<path>" or "synthetic(seed=N)"); printed once per arch
+SOURCES: Dict[str, str] = {}
+
+
+def synthetic_allowed() -> bool:
+    return os.environ.get("I2V_SYNTHETIC_WEIGHTS", "") not in ("", "0")
+
+
+def load_state_dict(graph: Graph, seed=None) -> Dict[str, torch.Tensor]:
+    """`$I2V_WEIGHTS_DIR/<arch>.pth` (a torchvision-layout `state_dict`; extra keys such as `layer4.*`, `fc.*`,
+    `num_batches_tracked` are ignored) when it exists.  Otherwise the seeded synthetic initialiser -- but only when
+    the caller asked for it: an explicit integer `seed` (tests, bench) or `I2V_SYNTHETIC_WEIGHTS=1`.  The reference
+    attacks ImageNet-pretrained backbones (`pretrained=True`, image_attacks.py:88-101); silently perturbing clips
+    against random weights would produce valid-looking but meaningless `*-adv.npy` files, so that case raises."""
     root = os.environ.get("I2V_WEIGHTS_DIR", "")
     path = os.path.join(root, graph.arch + ".pth") if root else ""
     if path and os.path.exists(path):
-        sd = torch.load(path, map_location="cpu")
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
+            sd = sd["state_dict"]
         shapes = graph.param_shapes()
         missing = [k for k in shapes if k not in sd]
         if missing:
@@ -65,8 +84,27 @@ def load_state_dict(graph: Graph, seed: int = 0) -> Dict[str, torch.Tensor]:
         for k, shp in shapes.items():
             if tuple(sd[k].shape) != tuple(shp):
                 raise ValueError(f"{path}: {k} has shape {tuple(sd[k].shape)}, expected {shp}")
+        _note(graph.arch, path)
         return {k: sd[k].float().contiguous() for k in shapes}
+    if seed is None:
+        if not synthetic_allowed():
+            raise MissingWeights(
+                f"no pretrained weights for {graph.arch!r}: put the torchvision state_dict at "
+                f"$I2V_WEIGHTS_DIR/{graph.arch}.pth (I2V_WEIGHTS_DIR={root!r}), or opt in to seeded SYNTHETIC weights "
+                "with I2V_SYNTHETIC_WEIGHTS=1 / --synthetic_weights / an explicit weight_seed")
+        seed = 0
+    _note(graph.arch, f"synthetic(seed={seed})")
     return synthetic_state_dict(graph, seed)
+
+
+def _note(arch: str, source: str):
+    if SOURCES.get(arch) != source:
+        SOURCES[arch] = source
+        if source.startswith("synthetic") and os.environ.get("I2V_QUIET_WEIGHTS", "") in ("", "0"):
+            import sys
+            print(f"[i2v_amd] WARNING: backbone {arch} runs on {source} weights, not an ImageNet checkpoint", file=sys.stderr)
+        elif not source.startswith("synthetic"):
+            print(f"[i2v_amd] backbone {arch}: weights from {source}")
 
 
 def fold_affine(nd, sd):

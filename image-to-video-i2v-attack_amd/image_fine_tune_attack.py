@@ -55,8 +55,14 @@ def arg_parse(argv=None):
     parser.add_argument("--steps", type=int, default=60)
     parser.add_argument("--step_size", type=float, default=0.005)
     parser.add_argument("--resume", action="store_true")
+    parser.add_argument("--synthetic_weights", action="store_true",
+                        help="run on the seeded synthetic initialiser when no checkpoint lies under $I2V_WEIGHTS_DIR "
+                             "(same as I2V_SYNTHETIC_WEIGHTS=1); without it a missing checkpoint is an error")
     parser.add_argument("--streams", type=int, default=2, help="clips in flight on separate HIP streams")
-    return parser.parse_args(argv)
+    args = parser.parse_args(argv)
+    if args.synthetic_weights:
+        os.environ["I2V_SYNTHETIC_WEIGHTS"] = "1"
+    return args
 
 
 def main(argv=None, model_kwargs=None):

@@ -48,7 +48,12 @@ def arg_parse(argv=None):
     parser.add_argument("--frames", type=int, default=32)
     parser.add_argument("--hw", type=int, default=224)
     parser.add_argument("--resume", action="store_true")
+    parser.add_argument("--synthetic_weights", action="store_true",
+                        help="run on the seeded synthetic initialiser when no checkpoint lies under $I2V_WEIGHTS_DIR "
+                             "(same as I2V_SYNTHETIC_WEIGHTS=1); without it a missing checkpoint is an error")
     args = parser.parse_args(argv)
+    if args.synthetic_weights:
+        os.environ["I2V_SYNTHETIC_WEIGHTS"] = "1"
     args.adv_path = os.path.join(OPT_PATH, "{}-{}-{}-{}".format("Image", args.attack_method, args.step, args.file_prefix))
     os.makedirs(args.adv_path, exist_ok=True)
     return args
@@ -78,6 +83,11 @@ def main(argv=None):
     left = (args.batch_index - 1) * nums_contained
     right = args.batch_index * nums_contained
     attack_method = build_attack(args)
+    cuda = torch.cuda.is_available()
+    if cuda:
+        from i2v_amd import attacks as _attacks
+        device = torch.device(_attacks.default_device())
+        torch.cuda.set_device(device)          # events, pinned copies and the attack's stream all live on THIS rank's device
 
     # I/O off the critical path: clips are produced by a reader thread one batch ahead (synthetic generation
     # or np.load), results are copied to pinned host memory asynchronously and written by a writer thread,
@@ -87,12 +97,14 @@ def main(argv=None):
     done = queue.Queue(maxsize=4)
 
     def reader():
+        if cuda:
+            torch.cuda.set_device(device)      # per-thread state: pin_memory() would otherwise create a context on device 0
         for step, item in enumerate(clips.batches(args.batch_size, args.anno, args.clip_dir, args.frames, args.hw, args.num_clips)):
             if not (left <= step < right):
                 continue
             if args.resume and all(os.path.exists(os.path.join(args.adv_path, f"{l.item()}-adv.npy")) for l in item[1]):
                 continue
-            batch = item[0].pin_memory() if torch.cuda.is_available() else item[0]
+            batch = item[0].pin_memory() if cuda else item[0]
             todo.put((step, batch, item[1], item[2]))
         todo.put(None)
 
@@ -124,7 +136,7 @@ def main(argv=None):
             host = torch.empty(adv_batches.shape, dtype=adv_batches.dtype, pin_memory=True)
             host.copy_(adv_batches, non_blocking=True)
             event = torch.cuda.Event()
-            event.record()
+            event.record(torch.cuda.current_stream(adv_batches.device))
         else:
             host, event = adv_batches.contiguous(), None
         done.put((val_label, host, event))

@@ -49,7 +49,7 @@ def costs_of(atk, name, steps):
     return np.array([atk.loss_info[name][i]["cost"] for i in range(steps)])
 
 
-def run_image_attack(kind, prec, models, depth, steps, lr, b, f, hw, clip_seed, wseed=0, **kw):
+def run_image_attack(kind, prec, models, depth, steps, lr, b, f, hw, clip_seed, wseed=0, per_step=False, **kw):
     dtype = torch.float64 if prec == "f64" else torch.float32
     ref_shim.FACTORY.tiny, ref_shim.FACTORY.seed = True, wseed
     ref_shim.FACTORY.in_hw, ref_shim.FACTORY.dtype = (hw, hw), dtype
@@ -88,6 +88,16 @@ def run_image_attack(kind, prec, models, depth, steps, lr, b, f, hw, clip_seed, 
                delta_last=tap.deltas[-1].numpy().astype(np.float32),
                adv=adv.detach().numpy().astype(np.float32),
                kw=repr({k: v for k, v in kw.items()}), **extra)
+    if per_step:
+        # teacher-forcing checkpoints: the state AFTER every Adam step (image_attacks.py:351-353) and the gradient
+        # that step consumed; delta/exp_avg/exp_avg_sq are float32 in the reference whatever the backbone precision
+        # (`torch.Tensor(...)`, :304), the gradient is stored at its float32 value as Adam saw it
+        fix.update(tf_delta=np.stack([t.numpy() for t in tap.deltas]).astype(np.float32),
+                   tf_m=np.stack([t.numpy() for t in tap.ms]).astype(np.float32),
+                   tf_v=np.stack([t.numpy() for t in tap.vs]).astype(np.float32),
+                   tf_grad=np.stack([t.numpy() for t in tap.grads]).astype(np.float32))
+        for k in ("delta_first", "delta_last", "grad0"):
+            fix.pop(k)
     return fix
 
 
@@ -187,6 +197,16 @@ CASES = {
 }
 AENS_KW = {"aens_2x2_f64": dict(momentum=0.5, coef_CE=False)}
 
+# teacher-forcing fixtures (per-step delta / exp_avg / exp_avg_sq / gradient): 48x48 frames keep them < 1 MB each
+TF_CASES = {
+    "tf_i2v_resnet_d3_f64": ("i2v", "f64", ["resnet"], 3, 5, 0.005, 1, 2, 48, 1101),
+    "tf_ens_f64": ("ens", "f64", ["resnet", "vgg", "squeezenet"], {"resnet": 2, "vgg": 3, "squeezenet": 2}, 4, 0.005, 2, 1, 48, 1102),
+    # list depths: the adaptive attack hooks the whole SqueezeNet Fire module (TPAMI_attack.py:195-197)
+    "tf_aens_f64": ("aens", "f64", ["resnet", "squeezenet", "vgg"],
+                    {"resnet": [2, 3], "squeezenet": [2, 3], "vgg": [2, 3]}, 4, 0.005, 2, 1, 48, 1103),
+}
+TF_KW = {"tf_aens_f64": dict(momentum=0.5, coef_CE=False)}
+
 
 def main():
     os.makedirs(OUT, exist_ok=True)
@@ -204,6 +224,14 @@ def main():
     make_ilaf()
 
 
+def make_tf():
+    for name, args in TF_CASES.items():
+        fix = run_image_attack(*args, per_step=True, **TF_KW.get(name, {}))
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **fix)
+        print(name, os.path.getsize(path) // 1024, "KiB", fix["cost_str"][-1])
+
+
 def make_ilaf():
     for name, args in ILAF_CASES.items():
         fix = run_ilaf(*args)
@@ -213,4 +241,10 @@ def make_ilaf():
 
 
 if __name__ == "__main__":
-    make_ilaf() if sys.argv[1:] == ["ilaf"] else main()
+    if sys.argv[1:] == ["ilaf"]:
+        make_ilaf()
+    elif sys.argv[1:] == ["tf"]:
+        make_tf()
+    else:
+        main()
+        make_tf()

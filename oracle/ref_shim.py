@@ -127,11 +127,12 @@ def import_reference(module: str):
 
 
 class AdamTap:
-    """Records delta after every `torch.optim.Adam.step` and the gradient of the first step
-    (the reference builds its optimiser inside `forward`, `image_attacks.py:306`)."""
+    """Records, around every `torch.optim.Adam.step`, the gradient the reference handed to it and delta / exp_avg /
+    exp_avg_sq after it -- the per-step checkpoints teacher-forcing tests start from (the reference builds its
+    optimiser inside `forward`, `image_attacks.py:306`)."""
 
     def __init__(self):
-        self.deltas, self.grad0 = [], None
+        self.deltas, self.grads, self.ms, self.vs, self.grad0 = [], [], [], [], None
 
     def __enter__(self):
         self._orig = torch.optim.Adam.step
@@ -141,8 +142,12 @@ class AdamTap:
             p = opt.param_groups[0]["params"][0]
             if tap.grad0 is None:
                 tap.grad0 = p.grad.detach().clone()
+            tap.grads.append(p.grad.detach().clone())
             r = tap._orig(opt, *a, **k)
             tap.deltas.append(p.detach().clone())
+            st = opt.state[p]
+            tap.ms.append(st["exp_avg"].detach().clone())
+            tap.vs.append(st["exp_avg_sq"].detach().clone())
             return r
         torch.optim.Adam.step = step
         return self

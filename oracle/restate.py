@@ -254,15 +254,18 @@ def aens_coeffs(prev, coeffs, momentum):
 def run_attack(nets: Sequence[OracleNet], videos: torch.Tensor, *, steps: int, step_size: float,
                epsilon: float = 16 / 255, mode: str = "i2v", coeffs: Optional[torch.Tensor] = None,
                momentum: float = 0.0, coef_CE: bool = False, trace: bool = False,
-               forced_deltas: Optional[Sequence[torch.Tensor]] = None):
+               forced_states: Optional[Sequence] = None, forced_coeffs: Optional[Sequence[torch.Tensor]] = None):
     """Restates `ImageGuidedFMDirection_Adam.forward` (`image_attacks.py:294-364`, one net, one
     hook), `ImageGuidedFML2_Adam_MultiModels.forward` (`:426-496`, several nets) [mode 'i2v'],
     `AENS_I2V_MF.forward` (`TPAMI_attack.py:223-320`) [mode 'aens'] and
     `ImageGuidedStd_Adam.forward` (`image_attacks.py:187-234`) [mode 'std'].
 
-    `forced_deltas[i]`, when given, replaces delta at the START of step i (teacher forcing).
+    Teacher forcing: `forced_states[i] = (delta, exp_avg, exp_avg_sq)`, when given and not None, replaces the
+    optimiser state at the START of step i (i.e. the reference's state after step i-1; the Adam step count is i
+    either way), and `forced_coeffs[i]` replaces the AENS coefficients used in step i (the self-computed ones are
+    still returned in `weights_own`).
     Returns a dict: adv (b,3,f,h,w), costs[steps] (float32), and with trace=True per-step
-    delta (after the update), first-step gradient, cos per (step, layer, frame), weights.
+    delta (after the update), per-step gradients, cos per (step, layer, frame), weights.
     """
     dt = nets[0].dtype
     b, c, f, h, w = videos.shape
@@ -275,13 +278,18 @@ def run_attack(nets: Sequence[OracleNet], videos: torch.Tensor, *, steps: int, s
     if mode != "std":
         init = [[t.clone() for t in net.forward(x)] for net in nets]   # :318-323 (raw x, not norm(u))
     L = sum(len(net.hooks) for net in nets)
-    out = {"costs": np.zeros(steps, np.float32), "deltas": [], "cos": [], "weights": [], "grad0": None}
+    out = {"costs": np.zeros(steps, np.float32), "deltas": [], "cos": [], "weights": [], "weights_own": [], "grad0": None,
+           "grads": []}
     prev = torch.ones(L, dtype=dt) if mode == "aens" else None
     for i in range(steps):
-        if forced_deltas is not None:
-            delta = forced_deltas[i].clone().to(dt)
+        if forced_states is not None and forced_states[i] is not None:
+            fd, fm, fv = forced_states[i]
+            delta, opt.m, opt.v, opt.t = fd.clone().to(dt), fm.clone().to(dt), fv.clone().to(dt), i
         if mode == "aens":
             coeffs = aens_coeffs(prev, coeffs, momentum)            # TPAMI_attack.py:265
+            out["weights_own"].append(coeffs.clone().numpy())
+            if forced_coeffs is not None and forced_coeffs[i] is not None:
+                coeffs = forced_coeffs[i].clone().to(dt)
             out["weights"].append(coeffs.clone().numpy())
         xn, mask = compose(u, delta, epsilon)
         gx = torch.zeros_like(xn)
@@ -320,6 +328,8 @@ def run_attack(nets: Sequence[OracleNet], videos: torch.Tensor, *, steps: int, s
         g = compose_backward(gx, mask)
         if i == 0 and trace:
             out["grad0"] = g.clone()
+        if trace:
+            out["grads"].append(g.clone())
         opt.step(delta, g)                                          # :351-353
         if trace:
             out["deltas"].append(delta.clone())

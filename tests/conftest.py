@@ -10,6 +10,10 @@ for p in (PKG_ROOT, ROOT):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# no ImageNet checkpoints exist offline: the suites run on the seeded synthetic initialiser, which the product only
+# uses when asked to (i2v_amd/weights.py)
+os.environ.setdefault("I2V_SYNTHETIC_WEIGHTS", "1")
+os.environ.setdefault("I2V_QUIET_WEIGHTS", "1")
 
 
 def pytest_configure(config):

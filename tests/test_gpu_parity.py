@@ -352,6 +352,16 @@ def test_first_step_against_reference_gradient(eng):
     assert (np.abs(d1 - fx["delta_first"]) < 1e-4).mean() > 0.9
 
 
+@pytest.mark.parametrize("name", ["tf_i2v_resnet_d3_f64", "tf_ens_f64", "tf_aens_f64"])
+def test_teacher_forced_steps_against_reference_states(eng, name):
+    """north_star's atol 1e-4 on EVERY step, not only the first: each iteration of the HIP loop is restarted from the
+    reference's (delta_i, exp_avg_i, exp_avg_sq_i) [and AENS coefficients] and must land on the reference's
+    delta_{i+1} / cost_i (I2V image_attacks.py:325-358, ENS :456-490, AENS TPAMI_attack.py:258-312; the fixture's
+    AENS case hooks SqueezeNet's whole Fire modules, :195-197).  Tolerances: gu.check_teacher_forced."""
+    fx = gu.load(name)
+    gu.check_teacher_forced(fx, gu.make_attack(fx, attacks), to_dev=dev)
+
+
 def test_ens_and_aens_against_golden(eng):
     fx = gu.load("ens_4models_f64")
     atk = attacks.ImageGuidedFML2_Adam_MultiModels(fx["models"], depths=fx["depth"], steps=fx["steps"],

@@ -42,6 +42,32 @@ def test_oracle_matches_reference_semantics_f64(name):
         np.testing.assert_allclose(out["costs"], fx["cost_saved"], rtol=2e-6)
 
 
+@pytest.mark.parametrize("name", ["tf_i2v_resnet_d3_f64", "tf_ens_f64", "tf_aens_f64"])
+def test_oracle_teacher_forced_steps_f64(name):
+    """Every step restarted from the reference's (delta, exp_avg, exp_avg_sq) -- and, for the adaptive attack, its
+    coefficients: the oracle's step must land on the reference's next state (image_attacks.py:325-358,
+    TPAMI_attack.py:258-312).  tf_aens_f64 hooks SqueezeNet with LIST depths, i.e. the whole Fire module."""
+    fx = gu.load(name)
+    nets = [restate.OracleNet(g, sd, hooks, dtype=torch.float64) for g, sd, hooks in gu.hook_lists(fx)]
+    S = fx["steps"]
+    states = [None] + [tuple(torch.from_numpy(fx[k][i]) for k in ("tf_delta", "tf_m", "tf_v")) for i in range(S - 1)]
+    kw = {}
+    if fx["kind"] == "aens":
+        L = sum(len(n.hooks) for n in nets)
+        kw = dict(coeffs=torch.ones(L, dtype=torch.float64), momentum=fx["kw"]["momentum"], coef_CE=fx["kw"]["coef_CE"],
+                  forced_coeffs=[torch.from_numpy(w) for w in fx["weights"]])
+    out = restate.run_attack(nets, gu.videos_of(fx, torch.float64), steps=S, step_size=fx["lr"], mode=MODE[fx["kind"]],
+                             trace=True, forced_states=states, **kw)
+    np.testing.assert_allclose(out["costs"], np.array([float(s) for s in fx["cost_str"]]), rtol=2e-6)
+    for i in range(S):
+        g, r = out["grads"][i].float().numpy(), fx["tf_grad"][i]
+        assert np.abs(g - r).max() <= 2e-6 * np.abs(r).max(), i
+        # the oracle keeps delta/Adam in float64 here, the reference in float32: agreement to float32 rounding
+        assert np.abs(out["deltas"][i].float().numpy() - fx["tf_delta"][i]).max() < 2e-6, i
+    if fx["kind"] == "aens":       # the coefficients the oracle derives itself (from the previous forced step's cosines)
+        np.testing.assert_allclose(np.stack(out["weights_own"]), fx["weights"], rtol=1e-5)
+
+
 def test_oracle_f32_contract():
     """fp32 vs fp32 reference: only summation order differs, yet single pixels diverge
     (SURVEY.md 0.5); what must hold is the parity ladder of 7.3-1."""

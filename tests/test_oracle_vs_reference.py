@@ -61,3 +61,33 @@ def test_aens_coeffs_persist_across_calls():
                             momentum=1.0)
     np.testing.assert_allclose(np.stack(o1["weights"]), w1, rtol=1e-6)
     np.testing.assert_allclose(np.stack(o2["weights"]), w2, rtol=1e-6)
+
+
+def test_aens_squeezenet_hooks_whole_fire_module_live():
+    """With LIST depths the adaptive attack hooks `features[idx]` itself -- cat(expand1x1, expand3x3) -- not the 3x3
+    branch the scalar-depth lookup takes (TPAMI_attack.py:195-199).  Gradient and output of the imported reference
+    class against the oracle on the product's graph (`Graph.hook_for(d, whole_module=True)`); the coefficient
+    weights alone would not notice the difference while cos ~ 1."""
+    ref_shim.FACTORY.tiny, ref_shim.FACTORY.seed = True, 3
+    ref_shim.FACTORY.in_hw, ref_shim.FACTORY.dtype = (64, 64), torch.float64
+    tp = ref_shim.import_reference("TPAMI_attack")
+    vid = _clip(52, 2, 2, 64, torch.float64)
+    depths = {"squeezenet": [2, 3], "alexnet": [2, 3]}
+    with ref_shim.quiet():
+        atk = tp.AENS_I2V_MF(["squeezenet", "alexnet"], depths, step_size=0.005, momentum=0.5, steps=3)
+        with ref_shim.AdamTap() as tap:
+            adv, _, cost_saved = atk(vid.clone(), torch.zeros(2, dtype=torch.long), ["a", "b"])
+    shapes = [tuple(a.shape[1:]) for a in atk.activations["value"]]          # last model's hooks: alexnet
+    fx = dict(models=["squeezenet", "alexnet"], depth=depths, hw=64, wseed=3)
+    lists = gu.hook_lists(fx)
+    g, _, hooks = lists[0]
+    e1 = g.tensors[g.hooks[2]].C
+    assert [g.tensors[h].C for h in hooks] == [2 * e1, 2 * g.tensors[g.hooks[3]].C]      # both Fire branches
+    nets = [restate.OracleNet(gg, sd, h, dtype=torch.float64) for gg, sd, h in lists]
+    out = restate.run_attack(nets, vid, steps=3, step_size=0.005, mode="aens", coeffs=torch.ones(4, dtype=torch.float64),
+                             momentum=0.5, trace=True)
+    np.testing.assert_allclose(out["costs"], cost_saved, rtol=2e-6)
+    assert (tap.grad0.double() - out["grad0"]).abs().max() <= 2e-6 * tap.grad0.abs().max()
+    assert (adv.detach() - out["adv"]).abs().max() < 5e-5
+    np.testing.assert_allclose(np.stack(out["weights"]), np.stack(atk.weights), rtol=1e-6)
+    assert len(shapes) == 2

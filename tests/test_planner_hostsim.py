@@ -101,6 +101,14 @@ def test_ens_and_aens_against_golden():
         assert cost_saved.dtype == np.float64 and used_time >= 0
 
 
+@pytest.mark.parametrize("name", ["tf_i2v_resnet_d3_f64", "tf_ens_f64", "tf_aens_f64"])
+def test_teacher_forced_steps_against_reference_states(name):
+    """The planner/executor + host-simulated kernels, restarted at every step from the reference's optimiser state
+    (gu.check_teacher_forced states the tolerances; the same check runs on the HIP kernels in test_gpu_parity.py)."""
+    fx = gu.load(name)
+    gu.check_teacher_forced(fx, gu.make_attack(fx, attacks, engine=hostsim_engine()))
+
+
 def test_aens_coefficients_persist_across_calls():
     """`self.coeffs` lives on the attack object and carries over to the next call (TPAMI_attack.py:165,265): two calls
     of the product class against the oracle run twice with the coefficients handed on (the oracle itself is pinned to
