@@ -101,7 +101,7 @@ def cpu_baseline():
                       f"extrapolated to {ATTACK_STEPS} iterations"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -111,24 +111,160 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="--workload ilaf: clips in flight on separate HIP streams (one clip per call each)")
     ap.add_argument("--workload", default="i2v", choices=["i2v", "ens", "aens", "config2", "ilaf"],
                     help="i2v = the headline metric (default); ens / aens = BASELINE configs[2]/[3]-style extras on the "
-                         "reference's own model list (resnet101+vgg16+squeezenet1_1+alexnet)")
+                         "reference's own model list (resnet101+vgg16+squeezenet1_1+alexnet); aens carries the one data-path "
+                         "collective (2L floats all-reduced per step, TPAMI_attack.py:265,293-297) inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket backbone launches with HIP events in the timed region")
-    args = ap.parse_args()
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (measurements); gloo only for functional checks of the rank plumbing")
+    ap.add_argument("--share-device", action="store_true",
+                    help="FUNCTIONAL CHECK ONLY: every rank uses device 0 (a 1-GPU box); the line is labelled a non-measurement")
+    ap.add_argument("--selftest-hostsim", action="store_true",
+                    help="FUNCTIONAL CHECK ONLY (no GPU): the rank plumbing on the CPU host simulation of the kernel backend "
+                         "(tests/hostsim, tiny backbone, gloo); the line is labelled a non-measurement")
+    return ap.parse_args(argv)
 
+
+def under_launcher():
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per device) BEFORE this process
+    touches the GPU in any way -- never re-exec a process that has initialised HIP -- wait for them, pass rank 0's
+    JSON line through.  (Under `python -m torch.distributed.run ... bench.py --gpus N` the launcher has already made
+    the ranks and this function is not used.)  A failed rank fails the run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile(mode="w+") as out0:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        bad = []
+        while any(p.poll() is None for p in procs) and not bad:
+            bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            time.sleep(0.05)
+        if bad:                                  # a dead rank leaves the others waiting in a collective: stop exactly them
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        bad = bad or [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
+        out0.seek(0)
+        sys.stdout.write(out0.read())
+        sys.stdout.flush()
+    if bad:
+        print(f"bench.py: rank(s) failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and not under_launcher():
+        return spawn_ranks(args, argv)
+    if args.selftest_hostsim:
+        return selftest_hostsim(args)
+    return run_rank(args)
+
+
+def init_ranks(args):
+    """(dist or None, rank, local_rank, world, device string, sum of rank ids); one all-reduce of the rank ids
+    proves that N ranks really are talking to each other."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):     # launched by torch.distributed.run
+    cpu = args.selftest_hostsim
+    dev_index = 0 if (args.share_device or cpu) else local_rank
+    if not cpu:
+        torch.cuda.set_device(dev_index)
+    dev = "cpu" if cpu else f"cuda:{dev_index}"
+    dist, rank_sum = None, 0
+    if world > 1 or under_launcher():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if args.dist_backend == "nccl" and not cpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank)], device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t)
+        rank_sum = int(t.item())
+        if rank_sum != world * (world - 1) // 2:
+            raise RuntimeError(f"rank-id all-reduce gave {rank_sum}, expected {world * (world - 1) // 2}")
+    return dist, rank, local_rank, world, dev, rank_sum
+
+
+def reduce_max(dist, value, dev):
+    """max over ranks of a host scalar (the slowest rank's wall time) and the list of every rank's own value."""
+    if dist is None:
+        return value, [value]
+    on = dev if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([value], device=on, dtype=torch.float64)
+    every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, t)
+    vals = [float(e.item()) for e in every]
+    return max(vals), vals
+
+
+def selftest_hostsim(args):
+    """FUNCTIONAL CHECK of the multi-rank plumbing without a GPU (CPU container, `tests/test_cli_and_dist_cpu.py`):
+    gloo ranks, each attacking its own clips on the HOST SIMULATION of the kernel backend (tests/hostsim -- test
+    infrastructure) with a tiny backbone; `--workload aens` all-reduces its 2L floats per step.  Never a
+    measurement: the line says so."""
+    from tests.hostsim_util import hostsim_engine
+    from i2v_amd import attacks, graphs
+    if os.environ.get("I2V_BENCH_SELFTEST_FAIL_RANK") == os.environ.get("RANK", "0"):     # test hook: a rank that dies early
+        return 3
+    dist, rank, _, world, dev, rank_sum = init_ranks(args)
+    eng = hostsim_engine()
+    b, f, hw = 2, 2, 32
+    kw = dict(engine=eng, graph_builder=graphs.build_tiny, weight_seed=0)
+    if args.workload == "aens":
+        atk = attacks.AENS_I2V_MF(["resnet", "vgg"], depths={"resnet": [2, 3], "vgg": [2, 3]}, step_size=0.005, steps=2, **kw)
     else:
-        dist = None
-        torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
+        atk = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=3, step_size=0.005, steps=2, **kw)
+    vids = torch.cat([synthetic_clips(1, seed0=1000 + rank * b + i)[:, :, :f, :hw, :hw] for i in range(b)]).contiguous()
+    lab = torch.zeros(b, dtype=torch.long)
+    names = [f"clip{rank * b + i}" for i in range(b)]
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        atk(vids, lab, names)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    elapsed, per_rank = reduce_max(dist, elapsed, dev)
+    extra = {}
+    if args.workload == "aens":
+        extra["aens_weights_last"] = [round(float(x), 6) for x in atk.weights[-1]]     # identical on every rank: global batch
+    line = {"metric": "SELFTEST (host simulation, not a measurement)", "value": round(args.steps * b * f * world / elapsed, 3),
+            "unit": "adversarial frames/s", "n_gpus": world, "steps": args.steps, "warmup": 0, "data": "synthetic",
+            "ranks_proved_by_allreduce": {"sum_of_rank_ids": rank_sum, "expected": world * (world - 1) // 2},
+            "per_gpu": [round(args.steps * b * f / t, 3) for t in per_rank], "config": {"workload": f"selftest {args.workload}"}, **extra}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
+def run_rank(args):
+    dist, rank, local_rank, world, dev, rank_sum = init_ranks(args)
 
     import __graft_entry__ as ge
     if not os.path.exists(ge.LIB) and rank == 0:      # normally built by __graft_entry__.build(); a no-op otherwise
@@ -153,6 +289,8 @@ def main():
     else:
         atk = attacks.AENS_I2V_MF(names4, depths={n: [2, 3] for n in names4}, step_size=0.005, steps=ATTACK_STEPS, engine=eng, weight_seed=0)
     b = 1 if args.workload == "ilaf" and args.clips == CLIPS_PER_GPU else args.clips
+    if args.workload == "aens" and world > 1:
+        out_parallelism = f"clips sharded over {world} GPUs, one all-reduce of 2L floats per attack step (RCCL)"
     videos = synthetic_clips(b, seed0=1000 + rank * b).to(dev)         # resident in HBM before timing
     labels = torch.zeros(b, dtype=torch.long)
     names = [f"clip{rank * b + i}" for i in range(b)]
@@ -222,10 +360,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    own_elapsed = elapsed
+    elapsed, per_rank_s = reduce_max(dist, elapsed, dev)
     if timing_outside:                      # one stream, instrumented
         eng.timing_enable(True)
         _ilaf(videos, ori, labels, names); eng.timing_collect()      # event pool
@@ -244,10 +380,7 @@ def main():
         torch.cuda.synchronize()
         el2 = time.perf_counter() - t1
         barrier()
-        if dist is not None:
-            tt = torch.tensor([el2], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el2 = float(tt.item())
+        el2, _ = reduce_max(dist, el2, dev)
         product_default = {"clip_lanes": atk._lane_count(b, FRAMES), "value": round(args.steps * b * FRAMES * world / el2, 2),
                            "unit": "adversarial frames/s", "ms_per_step": round(1e3 * el2 / args.steps, 3),
                            "note": "same K steps, no per-launch events, batch cut into concurrent clip lanes (bit-identical output)"}
@@ -269,7 +402,14 @@ def main():
                    "parallelism": f"clips sharded over {world} GPU(s), no collective"},
         "end_to_end_tflops_per_gpu": round(value / world * flop_per_frame / 1e12, 2),
         "algorithmic_gflop_per_frame": round(flop_per_frame / 1e9, 2),
+        # every rank's own frames/s over ITS wall time of the same K steps (`value` divides all frames by the slowest)
+        "per_gpu": [round(args.steps * b * FRAMES * n_lanes / t, 2) for t in per_rank_s],
     }
+    if dist is not None:
+        out["ranks_proved_by_allreduce"] = {"sum_of_rank_ids": rank_sum, "expected": world * (world - 1) // 2,
+                                            "backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend()}
+    if args.share_device:
+        out["metric"] = "FUNCTIONAL CHECK (all ranks share device 0, not a measurement): " + out["metric"]
     if kt is not None and kt["conv_igemm_fwd"]["launches"]:
         # every instantiation of conv_igemm: backbone fwd + dgrad, and the class-packed image gradient
         parts = ("conv_igemm_fwd", "conv_igemm_dgrad", "conv_igemm_imggrad")
@@ -301,6 +441,8 @@ def main():
         out["algorithmic_gflop_per_frame"] = round((4 * _ilaf.steps + 4) * vmac / FRAMES / 1e9, 2)
         out["end_to_end_tflops_per_gpu"] = round(value / world * (4 * _ilaf.steps + 4) * vmac / FRAMES / 1e12, 2)
     elif args.workload != "i2v":
+        if args.workload == "aens" and world > 1:
+            out["config"]["parallelism"] = out_parallelism
         models = "resnet50+vgg16+densenet121" if args.workload == "config2" else "resnet101+vgg16+squeezenet1_1+alexnet"
         out["metric"] = f"adversarial frames/sec (10-step {args.workload.upper()}-I2V, {models}, 32x224^2 clips)"
         out["config"]["workload"] = f"{args.workload} ensemble ({models}), batch={b} clips per GPU"
@@ -314,7 +456,8 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -86,6 +86,7 @@ def load_state_dict(graph: Graph, seed=None) -> Dict[str, torch.Tensor]:
                 raise ValueError(f"{path}: {k} has shape {tuple(sd[k].shape)}, expected {shp}")
         _note(graph.arch, path)
         return {k: sd[k].float().contiguous() for k in shapes}
+    explicit = seed is not None
     if seed is None:
         if not synthetic_allowed():
             raise MissingWeights(
@@ -93,14 +94,14 @@ def load_state_dict(graph: Graph, seed=None) -> Dict[str, torch.Tensor]:
                 f"$I2V_WEIGHTS_DIR/{graph.arch}.pth (I2V_WEIGHTS_DIR={root!r}), or opt in to seeded SYNTHETIC weights "
                 "with I2V_SYNTHETIC_WEIGHTS=1 / --synthetic_weights / an explicit weight_seed")
         seed = 0
-    _note(graph.arch, f"synthetic(seed={seed})")
+    _note(graph.arch, f"synthetic(seed={seed})", warn=not explicit)
     return synthetic_state_dict(graph, seed)
 
 
-def _note(arch: str, source: str):
+def _note(arch: str, source: str, warn: bool = True):
     if SOURCES.get(arch) != source:
         SOURCES[arch] = source
-        if source.startswith("synthetic") and os.environ.get("I2V_QUIET_WEIGHTS", "") in ("", "0"):
+        if source.startswith("synthetic") and warn and os.environ.get("I2V_QUIET_WEIGHTS", "") in ("", "0"):
             import sys
             print(f"[i2v_amd] WARNING: backbone {arch} runs on {source} weights, not an ImageNet checkpoint", file=sys.stderr)
         elif not source.startswith("synthetic"):

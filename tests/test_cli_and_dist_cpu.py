@@ -240,3 +240,39 @@ def test_evaluator_contract(tmp_path, monkeypatch):
     assert rows[0] == "gt_label,exact-pre,off_by_one-pre" and len(rows) == 5
     assert rows[1:] == ["0,0,1", "3,3,4", "5,5,6", "7,2,3"]
     assert ev.main(["--adv_path", "run", "--models", "i3d_resnet50"])["i3d_resnet50"] >= 0.0     # built-in proxy runs
+
+
+# ------------------------------------------------------------------ bench.py --gpus N: rank spawning
+def _bench(args, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, I2V_QUIET_WEIGHTS="1", **(env or {}))
+    for k in ("RANK", "WORLD_SIZE", "MASTER_PORT", "LOCAL_RANK"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, env=e, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, [json.loads(ln) for ln in lines], r.stderr
+
+
+def test_bench_gpus_n_spawns_n_ranks():
+    """`python bench.py --gpus 2` must BE two ranks (the flag used to be parsed and ignored): the parent
+    starts one process per device before touching the GPU, the ranks prove themselves with an all-reduce of their
+    ids, rank 0 prints ONE line with n_gpus == 2 and whole-job frames/s.  Here on the host simulation over gloo; the
+    AENS workload puts its per-step all-reduce inside the timed loop and every rank sees the same (global) weights."""
+    code, lines, err = _bench(["--gpus", "2", "--selftest-hostsim", "--steps", "1", "--workload", "aens"])
+    assert code == 0, err
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["n_gpus"] == 2 and len(out["per_gpu"]) == 2 and out["value"] > 0
+    assert out["ranks_proved_by_allreduce"] == {"sum_of_rank_ids": 1, "expected": 1}
+    assert "not a measurement" in out["metric"]
+    assert abs(sum(out["aens_weights_last"]) - 1) < 1e-5
+    code, lines, err = _bench(["--gpus", "1", "--selftest-hostsim", "--steps", "1"])
+    assert code == 0 and lines[0]["n_gpus"] == 1
+
+
+def test_bench_failed_rank_fails_the_run():
+    code, lines, err = _bench(["--gpus", "2", "--selftest-hostsim", "--steps", "1"], env={"I2V_BENCH_SELFTEST_FAIL_RANK": "1"})
+    assert code != 0 and "rank(s) failed" in err and not lines
