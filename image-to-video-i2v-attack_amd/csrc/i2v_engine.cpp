@@ -49,7 +49,8 @@ static int fail(const char* fmt, ...) {
 
 namespace {
 
-struct Buffer { int C, H, W; int T = 1; size_t act_off = 0, grad_off = 0; bool is_input = false; };   // T: frames per clip (video networks)
+struct Buffer { int C, H, W; int T = 1; size_t act_off = 0, grad_off = 0; bool is_input = false;    // T: frames per clip (video networks)
+                size_t gate_off = 0; int gate_words = 0; bool gated = false; };   // 1-bit ReLU gates: C rows of gate_words 32-bit words
 struct Tensor { int buf, c_off, C; bool post_relu; };
 
 struct Packed {               // one implicit-GEMM operand set
@@ -513,12 +514,29 @@ struct Planner {
         return v;
     }
     void emit(std::vector<Launch>& L, const Launch& l) { if (!dry) L.push_back(l); }
+    // gate rows of tensor t (null when its buffer keeps no gates)
+    uint32_t* gate_rows(int t, int* stride) const {
+        const Tensor& T = n.tens[t]; const Buffer& B = n.bufs[T.buf];
+        if (!B.gated) return nullptr;
+        *stride = B.gate_words;
+        return (uint32_t*)(base() + B.gate_off) + (size_t)T.c_off * B.gate_words;
+    }
+    // the ReLU gate of tensor t for a launch that finalises its gradient: bits when available, else the fp32 activation
+    void set_gate(I2VConvParams& p, int t) {
+        int st = 0;
+        if (uint32_t* g = gate_rows(t, &st)) { p.gate = g; p.gate_stride = st; p.gate_pix0 = 0; }
+        else { View a = view(t, false); p.mask = a.p; p.mask_nstride = a.nstride; }
+    }
 
     void emit_addmask(View out, const std::vector<Addend>& adds, int t) {
         Launch l; memset(&l.am, 0, sizeof l.am); l.kind = L_ADDMASK;
         l.am.out = out.p; l.am.out_nstride = out.nstride;
         for (size_t i = 0; i < adds.size() && i < 3; ++i) { l.am.a[i] = adds[i].p; l.am.a_nstride[i] = adds[i].nstride; }
-        if (n.tens[t].post_relu) { View a = view(t, false); l.am.mask = a.p; l.am.mask_nstride = a.nstride; }
+        if (n.tens[t].post_relu) {
+            int st = 0;
+            if (uint32_t* g = gate_rows(t, &st)) { l.am.gate = g; l.am.gate_stride = st; }
+            else { View a = view(t, false); l.am.mask = a.p; l.am.mask_nstride = a.nstride; }
+        }
         l.am.N = 0; l.am.C = out.C; l.am.HW = out.H * out.W; l.T = out.T;
         emit(n.bwd, l);
     }
@@ -567,7 +585,7 @@ struct Planner {
                         p.add0 = a.p; p.add0_nstride = a.nstride; p.add0_stride = a.stride; p.add0_H = a.H; p.add0_W = a.W;
                     } else { p.add1 = a.p; p.add1_nstride = a.nstride; }
                 }
-                if (n.tens[t].post_relu) { View a = view(t, false); p.mask = a.p; p.mask_nstride = a.nstride; }
+                if (n.tens[t].post_relu) set_gate(p, t);
             }
             p.pointwise = (c.kt == 1 && c.stride_t == 1 && c.pad_t == 0 && c.kh == 1 && c.kw == 1 && c.stride == 1 &&
                            c.pad == 0 && (dz.H * dz.W) % 4 == 0 && !compact) ? 1 : 0;
@@ -673,6 +691,7 @@ struct Planner {
                 p.pointwise = (c.kt == 1 && c.stride_t == 1 && c.pad_t == 0 && c.kh == 1 && c.kw == 1 && c.stride == 1 &&
                                c.pad == 0 && (sb.H * sb.W) % 4 == 0 && c.src != n.input) ? 1 : 0;
                 if (nd.preact()) { p.pre_scale = nd.pre_scale_d; p.pre_shift = nd.pre_shift_d; }
+                if (c.relu) { int st = 0; if (uint32_t* g = gate_rows(c.dst, &st)) { p.gate_out = g; p.gate_out_stride = st; p.gate_out_pix0 = 0; } }
             } else {
                 const i2v_pool3d_desc& q = nd.pd;
                 const bool vid = q.kt != 1 || q.stride_t != 1 || q.pad_t != 0;
@@ -831,6 +850,19 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
         b.act_off = off; off = align_up(off + sz, 64);
         b.grad_off = off; off = align_up(off + sz, 64);
     }
+    // 1-bit ReLU gates (I2VConvParams::gate*): every buffer holding the output of a ReLU convolution gets one bit per
+    // element, rows per channel; the input-gradient pass gates with these instead of re-reading fp32 activations
+    const char* gates_env = getenv("I2V_GATES");           // developer knob: I2V_GATES=0 keeps the fp32-activation gates
+    const bool use_gates = !(gates_env && gates_env[0] == '0');
+    for (const Node& nd : n.nodes)
+        if (use_gates && nd.type == 0 && nd.cd.relu) n.bufs[n.tens[nd.cd.dst].buf].gated = true;
+    for (Buffer& b : n.bufs) {
+        if (!b.gated) continue;
+        const size_t pix = N / Tin * b.T * b.H * b.W;
+        if (pix + 64 >= (1ull << 31)) return fail("gate rows of more than 2^31 bits are not supported");
+        b.gate_words = (int)((pix + 31) / 32 + 2);
+        b.gate_off = off; off = align_up(off + (size_t)b.C * b.gate_words, 64);
+    }
     for (Node& nd : n.nodes)
         if (nd.type == 1) {
             const Buffer& db = n.bufs[n.tens[nd.pd.dst].buf];
@@ -881,6 +913,10 @@ static int conv_run(const Launch& l, int frames, const float* x, float* gx, int 
     const int64_t clip_bytes = (int64_t)(p.Ts - 1) * stride_bytes + plane_bytes;        // span of one clip's source frames
     int64_t per = clip_bytes >= (1ll << 31) ? 0 : 1 + ((1ll << 31) - 1 - clip_bytes) / (stride_bytes * p.Ts);
     if (per < 1) return fail("one clip of a convolution input exceeds 2 GiB");
+    if (per < clips && (p.gate || p.gate_out)) {        // a slice must start on a 32-bit boundary of the gate rows
+        per -= per % 32;
+        if (per < 1) return fail("a sliced convolution launch cannot keep its gate rows word-aligned");
+    }
     for (int c0 = 0; c0 < clips; c0 += (int)per) {
         I2VConvParams q = p;
         const int nc = clips - c0 < per ? clips - c0 : (int)per;
@@ -889,6 +925,8 @@ static int conv_run(const Launch& l, int frames, const float* x, float* gx, int 
         if (q.add0) q.add0 += (int64_t)c0 * p.To * p.add0_nstride;
         if (q.add1) q.add1 += (int64_t)c0 * p.To * p.add1_nstride;
         if (q.mask) q.mask += (int64_t)c0 * p.To * p.mask_nstride;
+        q.gate_pix0 = p.gate_pix0 + (int32_t)((int64_t)c0 * p.To * p.Ho * p.Wo);
+        q.gate_out_pix0 = p.gate_out_pix0 + (int32_t)((int64_t)c0 * p.To * p.Ho * p.Wo);
         q.src_span_bytes = (int32_t)((int64_t)(nc * p.Ts - 1) * stride_bytes + plane_bytes);
         CHECK_BE(k_conv(q, s));
     }

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "i2v_kernels.h"
 
@@ -95,10 +96,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     static_assert(!(MF16 && (PRE || PREF)), "no pre-activation / prefetch variants of the 16x16 tile");
     // one LDS array: operand staging [2][KC][BD] + [2][KC][BP], re-used by the epilogue as a
     // [WD*32][BP] transpose buffer
-#ifndef I2V_STAGES
-#define I2V_STAGES 2        // LDS operand buffers (3 measured no faster: tools/conv_microbench.cpp -DI2V_STAGES=3): chunk c is consumed while chunks c+1 .. c+STAGES-1 are in flight
-#endif
-    constexpr int NST = I2V_STAGES;
+    constexpr int NST = 2;      // LDS operand buffers: chunk c is consumed while chunk c+1 is in flight
     constexpr int STAGE_FLOATS = NST * KC * (BD + BP), EPI_FLOATS = WD * FR * BP;
     __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS];
     float (*As)[KC][BD] = reinterpret_cast<float (*)[KC][BD]>(smem);
@@ -171,44 +169,40 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         for (int q = 0; q < NBQ; ++q) boff[q] = pvalid ? xoff + (unsigned)((((wave + 4 * q) * 256 + lane * 4) / BP) * HWs * 4) : OOB;
     }
 
-#define I2V_ISSUE_CHUNK(k0_, buf_)                                                                        \
+#ifdef X_DMAHOT
+#define X_HOT(v) ((v) & 0xFFCu)
+#define X_HOTS(v) 0
+#else
+#define X_HOT(v) (v)
+#define X_HOTS(v) (v)
+#endif
+    // One DMA instruction of this wave's share of a K chunk.  Piece j (compile-time) of the NL = NAQ + NBQ pieces a wave
+    // issues per chunk: j < NAQ is a 16-byte piece of the weight tile, the others are pieces of the activation tile.
+    // `vb_` is the per-lane byte offset of the chunk's tap (MODE 2; computed once per chunk by I2V_CHUNK_VB).
+#define I2V_ISSUE_PIECE(j_, k0_, buf_, vb_)                                                               \
     {                                                                                                     \
+        constexpr int jj = (j_);                                                                          \
         const int k0 = (k0_);                                                                             \
-        float* const abuf = &As[buf_][0][0];                                                              \
-        float* const bbuf = &Bs[buf_][0][0];                                                              \
-        _Pragma("unroll") for (int q = 0; q < NAQ; ++q) {                                                 \
-            const int ins = wv + 4 * q;                                                                   \
+        if constexpr (jj < NAQ) {                                                                         \
+            const int ins = wv + 4 * jj;                                                                  \
             if (NA % 4 == 0 || ins < NA)                                                                  \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(abuf + ins * 256), 16, aoff[q], \
-                                                         k0 * p.Cdpad * 4, 0, 0);                         \
-        }                                                                                                 \
-        if (PW) {                                                                                         \
-            _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                             \
-                const int ins = wv + 4 * q;                                                               \
-                if (NB % 4 == 0 || ins < NB) {                                                            \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(&As[buf_][0][0] + ins * 256), 16, X_HOT(aoff[jj]), \
+                                                         X_HOTS(k0 * p.Cdpad * 4), 0, 0);                 \
+        } else {                                                                                          \
+            constexpr int q = jj - NAQ;                                                                   \
+            const int ins = wv + 4 * q;                                                                   \
+            float* const bbuf = &Bs[buf_][0][0];                                                          \
+            if (NB % 4 == 0 || ins < NB) {                                                                \
+                if constexpr (PW) {                                                                       \
                     unsigned v = boff[q];                                                                 \
                     if (k0 + KC > p.K)       /* K tail (uniform test): rows >= K contribute zeros */      \
                         v = (k0 + ((wave + 4 * q) * 256 + lane * 4) / BP < p.K) ? v : OOB;                \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 256), 16, v,  \
-                                                             k0 * HWs * 4, 0, 0);                         \
-                }                                                                                         \
-            }                                                                                             \
-        } else if (MODE == 2) {                                                                           \
-            const I2VKEntry e = load_kentry(p.ktab, k0);                                                  \
-            const int hs = h0 + e.dh, ws = w0 + e.dw, dtk = VID ? (e.valid >> 1) : 0;                     \
-            const bool ok = pvalid && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws &&   \
-                            (!VID || (unsigned)(t0 + dtk) < (unsigned)p.Ts);                              \
-            const unsigned v = ok ? xoff + (unsigned)((e.chan_off + dtk * nstr + e.dh * p.Ws + e.dw) * 4) : OOB; \
-            _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                             \
-                const int ins = wv + 4 * q;                                                               \
-                if (NB % 4 == 0 || ins < NB)                                                              \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 64), 4, v,    \
-                                                             ((ins * 64) / BP) * HWs * 4, 0, 0);          \
-            }                                                                                             \
-        } else {                                                                                          \
-            _Pragma("unroll") for (int q = 0; q < NBQ; ++q) {                                             \
-                const int ins = wv + 4 * q;                                                               \
-                if (NB % 4 == 0 || ins < NB) {                                                            \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 256), 16, X_HOT(v),  \
+                                                             X_HOTS(k0 * HWs * 4), 0, 0);                 \
+                } else if constexpr (MODE == 2) {                                                         \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 64), 4, X_HOT(vb_), \
+                                                             X_HOTS(((ins * 64) / BP) * HWs * 4), 0, 0);  \
+                } else {                                                                                  \
                     const I2VKEntry e = load_kentry(p.ktab, k0 + (ins * 64) / BP);                        \
                     const int hs = h0 + e.dh, ws = w0 + e.dw, dtk = VID ? (e.valid >> 1) : 0;             \
                     const bool ok = pvalid && (e.valid & 1) && (unsigned)hs < (unsigned)p.Hs &&           \
@@ -219,11 +213,20 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
             }                                                                                             \
         }                                                                                                 \
     }
+    // MODE 2: every K row of a chunk shares ONE tap, described by the chunk's first k-table row
+#define I2V_CHUNK_VB(e_)                                                                                  \
+    ([&]() -> unsigned {                                                                                  \
+        const int hs = h0 + (e_).dh, ws = w0 + (e_).dw, dtk = VID ? ((e_).valid >> 1) : 0;                \
+        const bool ok = pvalid && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws &&       \
+                        (!VID || (unsigned)(t0 + dtk) < (unsigned)p.Ts);                                  \
+        return ok ? xoff + (unsigned)(((e_).chan_off + dtk * nstr + (e_).dh * p.Ws + (e_).dw) * 4) : OOB; \
+    }())
 
     // ---- epilogue operand prefetch ----
     constexpr int E_C4 = BP / 4, E_RSTEP = 1024 / BP, E_NQ = WD * FR / E_RSTEP;
     static_assert(!PREF || TD == 1, "PREF needs a single epilogue pass");
     float4 pre0[PREF ? E_NQ : 1], pre1[PREF ? E_NQ : 1], pregate[PREF ? E_NQ : 1];
+    unsigned pregw[PREF ? E_NQ : 1];                       // 1-bit gates: the word holding this lane's 4 bits
     if (PREF) {
         const int e_c4 = t % E_C4, e_rbase = t / E_C4;
         const int64_t e_pp = px0 + (int64_t)e_c4 * 4;
@@ -240,6 +243,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
             pre0[q] = (ok && p.add0) ? *reinterpret_cast<const float4*>(p.add0 + e_n * p.add0_nstride + o) : make_float4(0.f, 0.f, 0.f, 0.f);
             pre1[q] = (ok && p.add1) ? *reinterpret_cast<const float4*>(p.add1 + e_n * p.add1_nstride + o) : make_float4(0.f, 0.f, 0.f, 0.f);
             pregate[q] = (ok && p.mask) ? *reinterpret_cast<const float4*>(p.mask + e_n * p.mask_nstride + o) : make_float4(1.f, 1.f, 1.f, 1.f);
+            pregw[q] = (ok && p.gate) ? p.gate[(int64_t)cd * p.gate_stride + ((p.gate_pix0 + e_pp) >> 5)] : 0xffffffffu;
         }
     }
 
@@ -257,56 +261,110 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     // accumulator register -> fragment row map  (32x32x2: row = (r&3) + 8(r>>2) + 4(l>>5);  16x16x4: row = 4(l>>4) + r)
     const int l31 = MF16 ? (lane & 15) : (lane & 31), lk = MF16 ? (lane >> 4) : (lane >> 5);
 #define I2V_FROW(r) (MF16 ? 4 * lk + (r) : ((r) & 3) + 8 * ((r) >> 2) + 4 * lk)
-    // DMA pipeline, NST buffers deep: at the top of iteration c the wave waits only for ITS OWN loads of
-    // chunk c (a counted vmcnt leaves the younger chunks in flight), the raw barrier then covers the other
-    // waves' loads of chunk c and tells that every wave is done reading the buffer chunk c+NST-1 overwrites.
-    // `__syncthreads()` is avoided on purpose: its fence would drain vmcnt to 0.
-    constexpr bool UNIFORM = (NA % 4 == 0) && (NB % 4 == 0);           // every wave issues the same number of DMAs
+    // ---- main loop: two LDS buffers, ONE barrier per K chunk, software-pipelined inside the wave -------------
+    // An fp32 MFMA holds its SIMD for 64 (32x32x2) / 32 (16x16x4) cycles, so everything else a wave has to do
+    // for a chunk is issued in the shadow of its own MFMAs instead of in front of them:
+    //   top of iteration c:  s_waitcnt vmcnt(0) (this wave's DMA of chunk c, issued a whole iteration ago),
+    //                        raw s_barrier (every wave's DMA landed AND every wave finished reading the other buffer);
+    //   then the fragments of k-step 0 are read, and -- k-step by k-step -- the fragments of step s+1 are requested
+    //   before the MFMAs of step s, and the DMA instructions of chunk c+1 follow the MFMAs of steps 0, 1, ... one or
+    //   two at a time (an LDS-DMA instruction costs its wave tens of issue cycles: behind an MFMA they are free, in
+    //   front of the chunk's first MFMA they were a bubble on the matrix pipe).  The k-table row of chunk c+2 (MODE 2)
+    //   is fetched (SMEM) an iteration before it is needed, so its latency is off the path as well.
+    // `__syncthreads()` is avoided on purpose: its fence would add waits the pipeline does not need.
     constexpr int NL = NAQ + NBQ;                                       // DMA instructions per wave per chunk
-#pragma unroll
-    for (int c0 = 0; c0 < NST - 1; ++c0)
-        if (c0 < nchunks) I2V_ISSUE_CHUNK(c0 * KC, c0);
-    int buf = 0, nbuf = NST - 1;
-    for (int c = 0; c < nchunks; ++c) {
-        // this wave's DMA of chunk c: everything but the youngest min(NST-2, chunks left) chunks must be back
-        if (UNIFORM && NST >= 3) {
-            const int ahead = nchunks - 1 - c;                   // chunks issued after c that may stay in flight
-            if (NST >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
-            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr int KR = MF16 ? 4 : 2;                                    // K rows per MFMA (32x32x2 / 16x16x4)
+    constexpr int KS = KC / KR;                                         // k-steps per chunk
+    constexpr int PPS = (NL + KS - 1) / KS;                             // DMA pieces issued behind each k-step
+    I2VKEntry e_next = I2VKEntry{0, 0, 0, 0};
+    {   // prologue: chunk 0 (and the k-table row of chunk 1)
+        unsigned vb0 = OOB;
+        if constexpr (MODE == 2) {
+            const I2VKEntry e0 = load_kentry(p.ktab, 0);
+            vb0 = I2V_CHUNK_VB(e0);
+            e_next = load_kentry(p.ktab, nchunks > 1 ? KC : 0);
+        }
+        (void)vb0;
+        if (nchunks > 0) {
+            [&]<int... J>(std::integer_sequence<int, J...>) { (([&] { I2V_ISSUE_PIECE(J, 0, 0, vb0); }()), ...); }
+            (std::make_integer_sequence<int, NL>{});
+        }
+    }
+    auto chunk_body = [&](const int c, const int buf, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;                // a chunk c+1 exists: its DMA is issued here
+#ifndef X_NOBAR
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (c + NST - 1 < nchunks) I2V_ISSUE_CHUNK((c + NST - 1) * KC, nbuf);
-        constexpr int KR = MF16 ? 4 : 2;                   // K rows per MFMA (32x32x2 / 16x16x4)
-        constexpr int KS = KC / KR;                        // k-steps per chunk
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            float fa[TD], fb[TP];
-#pragma unroll
-            for (int i = 0; i < TD; ++i) fa[i] = As[buf][KR * s + lk][wd * (BD / WD) + i * FR + l31];
-#pragma unroll
-            for (int j = 0; j < TP; ++j) fb[j] = Bs[buf][KR * s + lk][wpx * (BP / WP) + j * FR + l31];
-            if (PRE) {
-                typedef const __attribute__((address_space(4))) float* cfp;       // scalar (SMEM) loads
-                const int kr = c * KC + 2 * s;
-                const float sc = lk ? ((cfp)p.pre_scale)[kr + 1] : ((cfp)p.pre_scale)[kr];
-                const float sh = lk ? ((cfp)p.pre_shift)[kr + 1] : ((cfp)p.pre_shift)[kr];
-#pragma unroll
-                for (int j = 0; j < TP; ++j) fb[j] = fmaxf(fmaf(fb[j], sc, sh), 0.f);
-            }
-#pragma unroll
-            for (int i = 0; i < TD; ++i)
-#pragma unroll
-                for (int j = 0; j < TP; ++j) {
-                    if constexpr (MF16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                }
+#endif
+        unsigned vb = OOB;
+        if constexpr (MORE && MODE == 2) {
+            vb = I2V_CHUNK_VB(e_next);                                  // tap of chunk c+1 (row fetched last iteration)
+            const int c2 = c + 2 < nchunks ? c + 2 : nchunks - 1;
+            e_next = load_kentry(p.ktab, c2 * KC);                      // prefetch the row of chunk c+2
         }
-        buf = buf + 1 == NST ? 0 : buf + 1;
-        nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+        (void)vb;
+        float fa[2][TD], fb[2][TP];
+        auto read_frags = [&](const int s, const int set) {
+#ifdef X_NOLDS
+            for (int i = 0; i < TD; ++i) { fa[set][i] = 1.0f + s; asm volatile("" : "+v"(fa[set][i])); }
+            for (int j = 0; j < TP; ++j) { fb[set][j] = 0.5f + s; asm volatile("" : "+v"(fb[set][j])); }
+            return;
+#endif
+#pragma unroll
+            for (int i = 0; i < TD; ++i) fa[set][i] = As[buf][KR * s + lk][wd * (BD / WD) + i * FR + l31];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) fb[set][j] = Bs[buf][KR * s + lk][wpx * (BP / WP) + j * FR + l31];
+        };
+        read_frags(0, 0);
+#ifdef X_PRIO
+        __builtin_amdgcn_s_setprio(X_PRIO);
+#endif
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            (([&] {
+                constexpr int s = S, set = S & 1;
+                if constexpr (s + 1 < KS) read_frags(s + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);          // keep the NEXT step's LDS reads in front of this step's MFMAs
+                if constexpr (PRE) {
+                    typedef const __attribute__((address_space(4))) float* cfp;       // scalar (SMEM) loads
+                    const int kr = c * KC + 2 * s;
+                    const float sc = lk ? ((cfp)p.pre_scale)[kr + 1] : ((cfp)p.pre_scale)[kr];
+                    const float sh = lk ? ((cfp)p.pre_shift)[kr + 1] : ((cfp)p.pre_shift)[kr];
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) fb[set][j] = fmaxf(fmaf(fb[set][j], sc, sh), 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < TD; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) {
+                        if constexpr (MF16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+                    }
+#ifdef X_NODMA
+                if constexpr (false) {
+#else
+                if constexpr (MORE) {
+#endif
+                    [&]<int... Q>(std::integer_sequence<int, Q...>) {
+                        (([&] {
+                            constexpr int jp = s * PPS + Q;
+                            if constexpr (jp < NL) I2V_ISSUE_PIECE(jp, (c + 1) * KC, buf ^ 1, vb);
+                        }()), ...);
+                    }(std::make_integer_sequence<int, PPS>{});
+                }
+            }()), ...);
+        }(std::make_integer_sequence<int, KS>{});
+#ifdef X_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+    {
+        int buf = 0;
+        for (int c = 0; c + 1 < nchunks; ++c) { chunk_body(c, buf, std::true_type{}); buf ^= 1; }
+        if (nchunks > 0) chunk_body(nchunks - 1, buf, std::false_type{});
     }
-#undef I2V_ISSUE_CHUNK
+#undef I2V_ISSUE_PIECE
+#undef I2V_CHUNK_VB
 
     // ---- epilogue: shift, addends, ReLU, gradient gate, NCHW store ----
     const int HoWo = p.Ho * p.Wo;
@@ -330,13 +388,15 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
                 for (int r = 0; r < NR; ++r)
                     Cs[wd * FR + I2V_FROW(r)][wpx * (BP / WP) + j * FR + l31] = acc[i][j][r];
             __syncthreads();
-            if (pok) {
+            {
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const int row = rbase + q * RSTEP;
                     const int cd = cd0 + (row / FR) * (BD / WD) + i * FR + (row % FR);
-                    if (cd >= p.Cd) continue;
-                    float4 v = *reinterpret_cast<const float4*>(&Cs[row][c4 * 4]);
+                    const bool valid = pok && cd < p.Cd;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (valid) {
+                    v = *reinterpret_cast<const float4*>(&Cs[row][c4 * 4]);
                     const int64_t o = (int64_t)cd * HoWo + poff;
                     if (p.gate_scale) {      // pre-activation gate on THIS contribution, before the (accumulating) adds
                         const float4 m = *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
@@ -370,7 +430,14 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
                         }
                     }
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (PREF || (p.mask && !p.gate_scale)) {
+                    if (p.gate) {            // 1-bit gates of the tensor whose gradient this is: 4 bits of one word
+                        const unsigned w = PREF ? pregw[q] : p.gate[(int64_t)cd * p.gate_stride + ((p.gate_pix0 + pp) >> 5)];
+                        const unsigned g = w >> ((unsigned)(p.gate_pix0 + pp) & 31u);
+                        if (!(g & 1u)) v.x = 0.f;
+                        if (!(g & 2u)) v.y = 0.f;
+                        if (!(g & 4u)) v.z = 0.f;
+                        if (!(g & 8u)) v.w = 0.f;
+                    } else if (PREF || (p.mask && !p.gate_scale)) {
                         const float4 m = PREF ? pregate[q] : *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
                         if (!(m.x > 0.f)) v.x = 0.f;
                         if (!(m.y > 0.f)) v.y = 0.f;
@@ -378,6 +445,20 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
                         if (!(m.w > 0.f)) v.w = 0.f;
                     }
                     *reinterpret_cast<float4*>(p.dst + n * p.dst_nstride + o) = v;
+                    }
+                    if (p.gate_out) {
+                        // this tensor's own gates: 8 consecutive lanes hold 32 consecutive pixels of one channel row
+                        // (BP/4 lanes per row, a multiple of 8); every lane takes part in the exchange, invalid ones with 0
+                        unsigned nib = valid ? ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) : 0u;
+                        nib <<= 4 * (lane & 7);
+                        // OR over the 8 lanes with DPP moves (VALU only; __shfl_xor would go through the LDS crossbar):
+                        // quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7-i of each 8)
+                        nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0xB1, 0xF, 0xF, true);
+                        nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x4E, 0xF, 0xF, true);
+                        nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x141, 0xF, 0xF, true);
+                        if (valid && (lane & 7) == 0)
+                            p.gate_out[(int64_t)cd * p.gate_out_stride + ((p.gate_out_pix0 + pp) >> 5)] = nib;
+                    }
                 }
             }
         }
@@ -419,24 +500,25 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     }
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
+        // (no early `continue`s: when the launch emits gate words, every lane of the wave takes part in the ballots)
         const int64_t pp = px0 + wpx * (BP / WP) + j * FR + l31;
-        if (pp >= P) continue;
-        const int64_t ng = pp / HWg;
-        const int rem = (int)(pp - ng * HWg);
+        const bool pin = pp < P;
+        const int64_t ng = pin ? pp / HWg : 0;
+        const int rem = (int)(pin ? pp - ng * HWg : 0);
         const int gi = rem / p.Wg, gj = rem - gi * p.Wg;
         const int oh = gi * p.osh + p.oh0, ow = gj * p.osw + p.ow0;
-        if (oh >= p.Ho || ow >= p.Wo) continue;
+        bool ok = pin && oh < p.Ho && ow < p.Wo;
         int64_t n = ng;                                          // destination frame
         if (VID) {
             const int64_t clip = ng / p.Tg;
             const int ot = (int)(ng - clip * p.Tg) * p.ost + p.ot0;
-            if (ot >= p.To) continue;
+            if (ot >= p.To) ok = false;
             n = clip * p.To + ot;
         }
         const int opix = oh * p.Wo + ow;
         float* dstn = p.dst + n * p.dst_nstride + opix;
         const float* a0 = nullptr; int a0_plane = HoWo;
-        if (p.add0) {
+        if (p.add0 && ok) {
             if (p.add0_stride == 1) a0 = p.add0 + n * p.add0_nstride + opix;
             else {
                 const int s = p.add0_stride, qh = oh / s, qw = ow / s;
@@ -448,20 +530,37 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         }
         const float* a1 = p.add1 ? p.add1 + n * p.add1_nstride + opix : nullptr;
         const float* mk = p.mask ? p.mask + n * p.mask_nstride + opix : nullptr;
+        const int64_t gidx = (int64_t)p.gate_pix0 + n * HoWo + opix;           // this element's bit in a gate row
 #pragma unroll
         for (int i = 0; i < TD; ++i) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int cd = cd0 + wd * (BD / WD) + i * FR + I2V_FROW(r);
-                if (cd >= p.Cd) continue;
-                float v = acc[i][j][r];
-                if (p.gate_scale && !(fmaf(mk[(int64_t)cd * HoWo], p.gate_scale[cd], p.gate_shift[cd]) > 0.f)) v = 0.f;
-                if (p.shift) v += p.shift[cd];
-                if (a0) v += a0[(int64_t)cd * a0_plane];
-                if (a1) v += a1[(int64_t)cd * HoWo];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (mk && !p.gate_scale && !(mk[(int64_t)cd * HoWo] > 0.f)) v = 0.f;
-                dstn[(int64_t)cd * HoWo] = v;
+                const bool okc = ok && cd < p.Cd;
+                float v = 0.f;
+                if (okc) {
+                    v = acc[i][j][r];
+                    if (p.gate_scale && !(fmaf(mk[(int64_t)cd * HoWo], p.gate_scale[cd], p.gate_shift[cd]) > 0.f)) v = 0.f;
+                    if (p.shift) v += p.shift[cd];
+                    if (a0) v += a0[(int64_t)cd * a0_plane];
+                    if (a1) v += a1[(int64_t)cd * HoWo];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.gate) { if (!((p.gate[(int64_t)cd * p.gate_stride + (gidx >> 5)] >> (gidx & 31)) & 1u)) v = 0.f; }
+                    else if (mk && !p.gate_scale && !(mk[(int64_t)cd * HoWo] > 0.f)) v = 0.f;
+                    dstn[(int64_t)cd * HoWo] = v;
+                }
+                if (p.gate_out) {
+                    // dense forward output: a fragment's FR lanes are FR consecutive pixels (aligned to FR) of channel cd,
+                    // so the ballot's FR-bit field IS that stretch of the gate row
+                    const unsigned long long bal = __ballot(okc && v > 0.f);
+                    if (l31 == 0 && pin && cd < p.Cd) {
+                        const int64_t bit0 = (int64_t)p.gate_out_pix0 + pp;
+                        if constexpr (MF16)
+                            reinterpret_cast<uint16_t*>(p.gate_out + (int64_t)cd * p.gate_out_stride)[bit0 >> 4] = (uint16_t)(bal >> (16 * lk));
+                        else
+                            p.gate_out[(int64_t)cd * p.gate_out_stride + (bit0 >> 5)] = (unsigned)(bal >> (32 * lk));
+                    }
+                }
             }
         }
     }
@@ -472,7 +571,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
 // Low-K layers with epilogue operands are HBM-bound (their FLOP/byte is below the machine balance): they
 // run on 64x64 tiles with the epilogue operands prefetched under the K loop.
 static bool conv_wants_prefetch(const I2VConvParams& p) {
-    return p.vec_epilogue && !p.gate_scale && !p.pre_scale && p.add0_stride == 1 && (p.add0 || p.add1 || p.mask) && p.Kpad <= 256 && (p.pointwise || p.tap_uniform) && p.Cd > 32;
+    return p.vec_epilogue && !p.gate_scale && !p.pre_scale && p.add0_stride == 1 && (p.add0 || p.add1 || p.mask || p.gate) && p.Kpad <= 256 && (p.pointwise || p.tap_uniform) && p.Cd > 32;
 }
 
 template <int BD, int BP, int WD, int WP, bool MF16 = false>
@@ -827,7 +926,10 @@ __global__ void addmask_kernel(const I2VAddMaskParams p) {
         if (p.a[0]) v += p.a[0][n * p.a_nstride[0] + i];
         if (p.a[1]) v += p.a[1][n * p.a_nstride[1] + i];
         if (p.a[2]) v += p.a[2][n * p.a_nstride[2] + i];
-        if (p.mask && !(p.mask[n * p.mask_nstride + i] > 0.f)) v = 0.f;
+        if (p.gate) {
+            const int64_t c = i / p.HW, bit = n * p.HW + (i - c * p.HW);
+            if (!((p.gate[c * p.gate_stride + (bit >> 5)] >> (bit & 31)) & 1u)) v = 0.f;
+        } else if (p.mask && !(p.mask[n * p.mask_nstride + i] > 0.f)) v = 0.f;
         p.out[n * p.out_nstride + i] = v;
     }
 }

@@ -36,6 +36,13 @@ struct I2VConvParams {
     const float* add0; int64_t add0_nstride; int32_t add0_stride, add0_H, add0_W;  // stride s>1: compact addend
     const float* add1; int64_t add1_nstride;
     const float* mask; int64_t mask_nstride;
+    // 1-bit ReLU gates.  A post-ReLU tensor keeps one bit per element, (value > 0), in rows of 32-bit words per
+    // CHANNEL: bit (pix0 + n*H*W + pixel) of row c, n counting the launch's frames of that tensor -- 1/32 of the
+    // bytes of re-reading the fp32 activation as its own gate.  `gate_out` (forward launches with relu, dense
+    // output) is written by the epilogue; `gate` (input-gradient launches) replaces `mask`: v = gate bit ? v : 0.
+    // Row strides in words; pix0 is a multiple of 32 (a launch sliced over clips starts mid-row).
+    uint32_t* gate_out; int32_t gate_out_stride; int32_t gate_out_pix0;
+    const uint32_t* gate; int32_t gate_stride; int32_t gate_pix0;
     // DenseNet pre-activation (norm -> relu -> 1x1 conv), pointwise launches only:
     //   forward:  the B operand is relu(src * pre_scale[k] + pre_shift[k])        (arrays of Kpad floats, 0-padded)
     //   backward: the gate is (mask * gate_scale[cd] + gate_shift[cd] > 0) instead of (mask > 0) and it gates the
@@ -78,6 +85,7 @@ struct I2VAddMaskParams {
     float* out;        int64_t out_nstride;
     const float* a[3]; int64_t a_nstride[3];
     const float* mask; int64_t mask_nstride;
+    const uint32_t* gate; int32_t gate_stride;     // 1-bit gates instead of `mask` (rows per channel, bit n*HW + i)
     int32_t N, C, HW;
 };
 

@@ -102,8 +102,17 @@ int k_conv(const I2VConvParams& p, i2v_stream_t) {
                     }
                     if (p.add1) v += p.add1[(size_t)n * p.add1_nstride + oidx];
                     if (p.relu) v = v > 0.f ? v : 0.f;
-                    if (p.mask && !p.gate_scale && !(p.mask[(size_t)n * p.mask_nstride + oidx] > 0.f)) v = 0.f;
+                    const size_t bit = (size_t)n * p.Ho * p.Wo + (size_t)oh * p.Wo + ow;     // element's bit in a gate row of channel cd
+                    if (p.gate) {
+                        const size_t b = (size_t)p.gate_pix0 + bit;
+                        if (!((p.gate[(size_t)cd * p.gate_stride + (b >> 5)] >> (b & 31)) & 1u)) v = 0.f;
+                    } else if (p.mask && !p.gate_scale && !(p.mask[(size_t)n * p.mask_nstride + oidx] > 0.f)) v = 0.f;
                     p.dst[(size_t)n * p.dst_nstride + oidx] = v;
+                    if (p.gate_out) {       // 1-bit ReLU gate of the value just stored
+                        const size_t b = (size_t)p.gate_out_pix0 + bit;
+                        uint32_t& w = p.gate_out[(size_t)cd * p.gate_out_stride + (b >> 5)];
+                        w = v > 0.f ? (w | (1u << (b & 31))) : (w & ~(1u << (b & 31)));
+                    }
                 }
             }
     }
@@ -224,7 +233,10 @@ int k_addmask(const I2VAddMaskParams& p, i2v_stream_t) {
         for (size_t i = 0; i < plane; ++i) {
             float v = 0.f;
             for (int a = 0; a < 3; ++a) if (p.a[a]) v += p.a[a][(size_t)n * p.a_nstride[a] + i];
-            if (p.mask && !(p.mask[(size_t)n * p.mask_nstride + i] > 0.f)) v = 0.f;
+            if (p.gate) {
+                const size_t c = i / p.HW, bit = (size_t)n * p.HW + (i - c * p.HW);
+                if (!((p.gate[c * p.gate_stride + (bit >> 5)] >> (bit & 31)) & 1u)) v = 0.f;
+            } else if (p.mask && !(p.mask[(size_t)n * p.mask_nstride + i] > 0.f)) v = 0.f;
             p.out[(size_t)n * p.out_nstride + i] = v;
         }
     return 0;

@@ -1,29 +1,43 @@
-// Developer tool (not part of the product or the tests): times conv_igemm on one layer shape with
-// synthetic operands so that kernel experiments do not need the whole attack loop.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -x hip tools/conv_microbench.cpp -o /tmp/cmb
-//   /tmp/cmb <frames> <Cin> <Cout> <H> <k> [iters]
-#include "../image-to-video-i2v-attack_amd/csrc/i2v_kernels.hip"
+// Developer tool (not part of the product or the tests): times conv_igemm on the ResNet-50 layer shapes with
+// synthetic operands (random data, chunk-major K order as the planner packs it) so that kernel experiments do not
+// need the whole attack loop.  Built against whichever kernel source KSRC names, so two builds (old / new kernel)
+// can be run back to back on the same device:
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++20 -x hip -DKSRC='"../image-to-video-i2v-attack_amd/csrc/i2v_kernels.hip"' tools/conv_microbench.cpp -o tools/cmb
+//   tools/cmb [frames] [iters]            all shapes x all valid tile configurations
+//   tools/cmb <frames> <Cin> <Cout> <H> <k> [iters]     one shape (I2V_FORCE_CFG picks the configuration)
+#ifndef KSRC
+#define KSRC "../image-to-video-i2v-attack_amd/csrc/i2v_kernels.hip"
+#endif
+#include KSRC
 
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
 
-int main(int argc, char** argv) {
-    int N = argc > 1 ? atoi(argv[1]) : 128, Cin = argc > 2 ? atoi(argv[2]) : 256, Cout = argc > 3 ? atoi(argv[3]) : 256;
-    int H = argc > 4 ? atoi(argv[4]) : 14, k = argc > 5 ? atoi(argv[5]) : 3, iters = argc > 6 ? atoi(argv[6]) : 20;
+struct Shape { int Cin, Cout, H, k; const char* what; };
+
+static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
+    const int Cin = sh.Cin, Cout = sh.Cout, H = sh.H, k = sh.k;
     int pad = k / 2, K = k * k * Cin, Kpad = (K + I2V_KC - 1) / I2V_KC * I2V_KC, Cdpad = (Cout + 127) / 128 * 128;
     std::vector<float> wp((size_t)Kpad * Cdpad), src((size_t)N * Cin * H * H);
     std::vector<I2VKEntry> kt(Kpad, I2VKEntry{0, 0, 0, 0});
     for (auto& v : wp) v = (rand() % 2001 - 1000) * 1e-4f;
     for (auto& v : src) v = (rand() % 2001 - 1000) * 1e-3f;
-    for (int r = 0; r < k; ++r) for (int s = 0; s < k; ++s) for (int c = 0; c < Cin; ++c)
-        kt[(r * k + s) * Cin + c] = I2VKEntry{c * H * H, r - pad, s - pad, 1};
-    float *dw, *ds, *dd; I2VKEntry* dk;
-    hipMalloc(&dw, wp.size() * 4); hipMalloc(&ds, src.size() * 4); hipMalloc(&dd, (size_t)N * Cout * H * H * 4);
+    const bool tu = Cin % I2V_KC == 0;
+    const int NT = k * k;
+    for (int r = 0; r < k; ++r) for (int s = 0; s < k; ++s) for (int c = 0; c < Cin; ++c) {
+        const int tap = r * k + s;
+        const int kk = tu ? ((c / I2V_KC) * NT + tap) * I2V_KC + c % I2V_KC : tap * Cin + c;
+        kt[kk] = I2VKEntry{c * H * H, r - pad, s - pad, 1};
+    }
+    float *dw, *ds, *dd, *da; I2VKEntry* dk;
+    const size_t outn = (size_t)N * Cout * H * H;
+    hipMalloc(&dw, wp.size() * 4); hipMalloc(&ds, src.size() * 4); hipMalloc(&dd, outn * 4); hipMalloc(&da, outn * 4);
     hipMalloc(&dk, kt.size() * sizeof(I2VKEntry));
     hipMemcpy(dw, wp.data(), wp.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(ds, src.data(), src.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dk, kt.data(), kt.size() * sizeof(I2VKEntry), hipMemcpyHostToDevice);
+    hipMemset(da, 0, outn * 4);
     I2VConvParams p; memset((void*)&p, 0, sizeof p);
     p.src = ds; p.src_nstride = (int64_t)Cin * H * H; p.Hs = p.Ws = H; p.Cs = Cin;
     p.src_span_bytes = (int32_t)((int64_t)N * Cin * H * H * 4);
@@ -31,17 +45,49 @@ int main(int argc, char** argv) {
     p.N = N; p.Hg = p.Wg = H; p.sh = p.sw = 1;
     p.dst = dd; p.dst_nstride = (int64_t)Cout * H * H; p.Ho = p.Wo = H; p.osh = p.osw = 1;
     p.add0_stride = 1; p.relu = 1;
-    p.pointwise = (k == 1 && (H * H) % 4 == 0); p.tap_uniform = (Cin % I2V_KC == 0);
+    p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1;
+    if (with_epi) { p.add0 = da; p.add0_nstride = p.dst_nstride; }      // residual-style addend (the expand convolutions)
+    p.pointwise = (k == 1 && (H * H) % 4 == 0); p.tap_uniform = tu;
     p.vec_epilogue = ((H * H) % 4 == 0);
+    p.cfg = cfg + 1;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int i = 0; i < 3; ++i) k_conv(p, nullptr);
+    for (int i = 0; i < 2; ++i) k_conv(p, nullptr);
     hipDeviceSynchronize();
     hipEventRecord(a, nullptr);
     for (int i = 0; i < iters; ++i) k_conv(p, nullptr);
     hipEventRecord(b, nullptr); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b); ms /= iters;
-    double fl = 2.0 * N * H * H * (double)Cout * K;
-    printf("N=%d Cin=%d Cout=%d H=%d k=%d cfg=%d: %.3f ms  %.1f TFLOP/s  (err=%s)\n", N, Cin, Cout, H, k, conv_pick(p), ms,
-           fl / ms * 1e-9, be_error() ? be_error() : "none");
+    hipFree(dw); hipFree(ds); hipFree(dd); hipFree(da); hipFree(dk); hipEventDestroy(a); hipEventDestroy(b);
+    if (be_error()) { printf("ERROR %s\n", be_error()); exit(1); }
+    return 2.0 * N * H * H * (double)Cout * K / ms * 1e-9;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 5) {
+        Shape sh{atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), "cli"};
+        const char* f = getenv("I2V_FORCE_CFG");
+        printf("%.1f TFLOP/s\n", run(atoi(argv[1]), sh, f ? atoi(f) : 3, argc > 6 ? atoi(argv[6]) : 20, 0));
+        return 0;
+    }
+    const int N = argc > 1 ? atoi(argv[1]) : 128, iters = argc > 2 ? atoi(argv[2]) : 10;
+    static const Shape S[] = {
+        {256, 256, 14, 3, "layer3 3x3"}, {128, 128, 28, 3, "layer2 3x3"}, {64, 64, 56, 3, "layer1 3x3"},
+        {256, 1024, 14, 1, "layer3 expand"}, {1024, 256, 14, 1, "layer3 reduce"}, {128, 512, 28, 1, "layer2 expand"},
+        {512, 128, 28, 1, "layer2 reduce"}, {64, 256, 56, 1, "layer1 expand"}, {256, 64, 56, 1, "layer1 reduce"},
+        {512, 1024, 14, 1, "layer3 down(K512)"}, {256, 512, 28, 1, "layer2 down(K256)"}, {64, 64, 56, 1, "layer1 first"}};
+    static const char* CN[5] = {"128x128", "64x128", "128x64", "64x64", "32x256"};
+    printf("%-20s %5s %5s %3s %2s |", "shape", "Cin", "Cout", "H", "k");
+    for (int c = 0; c < 4; ++c) printf(" %8s", CN[c]);
+    printf(" | +addend(64x64)\n");
+    for (const Shape& sh : S) {
+        printf("%-20s %5d %5d %3d %2d |", sh.what, sh.Cin, sh.Cout, sh.H, sh.k);
+        for (int c = 0; c < 4; ++c) {
+            const int BD = (c == 0 || c == 2) ? 128 : 64;
+            if (sh.Cout <= BD / 2) { printf(" %8s", "-"); continue; }
+            printf(" %8.1f", run(N, sh, c, iters, 0));
+        }
+        printf(" | %8.1f\n", run(N, sh, 3, iters, 1));
+        fflush(stdout);
+    }
     return 0;
 }
