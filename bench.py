@@ -26,6 +26,7 @@ for p in (os.path.join(ROOT, "image-to-video-i2v-attack_amd"), ROOT):
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32-input MFMA (= vector) peak
+PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured on a float4 copy)
 ATTACK_STEPS = 10
 CLIPS_PER_GPU = 4
 FRAMES, HW = 32, 224
@@ -44,18 +45,35 @@ def synthetic_clips(b, seed0=1000):
     return torch.cat(clips)
 
 
+def build_id():
+    """Identity of the kernel/engine SOURCES the running library was built from (the .git directory does not travel to
+    the GPU box, the sources do): sha256 over csrc/ and the ABI header, first 16 hex digits.  A PMC summary is only
+    evidence about THIS binary if it carries the same id."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "image-to-video-i2v-attack_amd", "csrc")
+    for f in sorted(os.listdir(csrc)) + [os.path.join(ROOT, "include", "i2v_hip.h")]:
+        with open(f if os.path.isabs(f) else os.path.join(csrc, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2_traffic_by_instantiation.json")
+
+
 def measured_traffic():
-    """HBM bytes per conv_igemm launch from the rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
-    correction + WRITE_SIZE, separate --pmc runs of this same command: tools/profile.sh ->
-    profiles/r1_conv_traffic.json).  PMC collection cannot run inside the timed process, so the
-    committed measurement is reported; null when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r1_conv_traffic.json")
+    """HBM bytes per conv_igemm launch from the rocprofv3 PMC passes over this same command (tools/profile.sh ->
+    tools/summarise_profile.py: 2 x FETCH_SIZE per the gfx950 correction + WRITE_SIZE, separate --pmc runs).  PMC
+    collection cannot run inside the timed process, so the committed summary is reported -- but only when it was
+    collected on a build of exactly these sources (`build_id`); otherwise null."""
     try:
-        with open(path) as fh:
+        with open(TRAFFIC_JSON) as fh:
             t = json.load(fh)
-        return round(t["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+        if t.get("build_id") != build_id():
+            return None, f"profiles/r2_traffic_by_instantiation.json is from build {t.get('build_id')}, running {build_id()}"
+        return round(t["conv_igemm"]["hbm_bytes_per_launch"]), None
+    except Exception as e:       # noqa: BLE001
+        return None, f"no PMC summary ({type(e).__name__})"
 
 
 def cpu_baseline():
@@ -413,20 +431,38 @@ def run_rank(args):
     if kt is not None and kt["conv_igemm_fwd"]["launches"]:
         # every instantiation of conv_igemm: backbone fwd + dgrad, and the class-packed image gradient
         parts = ("conv_igemm_fwd", "conv_igemm_dgrad", "conv_igemm_imggrad")
-        c = {k: sum(kt[p][k] for p in parts) for k in ("ms", "flops", "launches")}
+        c = {k: sum(kt[p][k] for p in parts) for k in kt["conv_igemm_fwd"]}
         tf = lambda d: round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2) if d["ms"] else None
         ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
+        traffic, why_not = measured_traffic() if args.workload == "i2v" and b == CLIPS_PER_GPU else (None, "not the headline workload")
+        # the launches whose algorithmic flops/byte is below the machine balance (157.3 TFLOP/s / 8 TB/s = 19.7): the
+        # low-K "expand" convolutions and their input gradients -- those are bounded by the HBM roofline, the rest by MFMA
+        hi = {k: c[k] - c["lowi_" + k] for k in ("ms", "flops", "launches", "bytes")}
         out["roofline"] = {"kernel": "conv_igemm (fp32 MFMA implicit GEMM, fwd + dgrad)", "bound": "mfma",
                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                           "traffic": measured_traffic() if args.workload == "i2v" and b == CLIPS_PER_GPU else None,
-                           "traffic_unit": "B per launch (rocprofv3 PMC passes: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_conv_traffic.json)",
-                           "launches": c["launches"], "avg_launch_us": round(1e3 * c["ms"] / c["launches"], 2),
+                           "traffic": traffic,
+                           "traffic_unit": "B per launch (rocprofv3 PMC passes of this build: 2*FETCH_SIZE + WRITE_SIZE, profiles/r2_traffic_by_instantiation.json)",
+                           "launches": int(c["launches"]), "avg_launch_us": round(1e3 * c["ms"] / c["launches"], 2),
                            "avg_gflop_per_launch": round(c["flops"] / c["launches"] / 1e9, 3),
+                           "algorithmic_bytes_per_launch": round(c["bytes"] / c["launches"]),
                            "achieved_by_pass": {"forward": tf(kt["conv_igemm_fwd"]), "input_grad": tf(kt["conv_igemm_dgrad"]),
                                                 "image_grad": tf(kt["conv_igemm_imggrad"])},
+                           "by_bound": {
+                               "mfma_bound_launches": {"launches": int(hi["launches"]), "device_ms": round(hi["ms"], 2),
+                                                       "achieved_tflops": round(hi["flops"] / (hi["ms"] * 1e-3) / 1e12, 2) if hi["ms"] else None,
+                                                       "frac_of_mfma_peak": round(hi["flops"] / (hi["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if hi["ms"] else None},
+                               "hbm_bound_launches": {"launches": int(c["lowi_launches"]), "device_ms": round(c["lowi_ms"], 2),
+                                                      "rule": "algorithmic flops/byte < 19.7 (= 157.3 TFLOP/s / 8 TB/s)",
+                                                      "achieved_gbps": round(c["lowi_bytes"] / (c["lowi_ms"] * 1e-3) / 1e9, 1) if c["lowi_ms"] else None,
+                                                      "peak_gbps": PEAK_HBM_GBPS,
+                                                      "frac_of_hbm_peak": round(c["lowi_bytes"] / (c["lowi_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if c["lowi_ms"] else None,
+                                                      "achieved_tflops": round(c["lowi_flops"] / (c["lowi_ms"] * 1e-3) / 1e12, 2) if c["lowi_ms"] else None}},
                            "device_ms_by_kernel": {k: round(v["ms"], 2) for k, v in kt.items()},
-                           "wall_ms_timed_region": round(1e3 * elapsed, 2)}
+                           "wall_ms_timed_region": round(1e3 * elapsed, 2),
+                           "build_id": build_id()}
+        if why_not:
+            out["roofline"]["traffic_note"] = why_not
         if timing_outside:
             out["roofline"]["note"] = "per-kernel times from one extra instrumented call after the timed region"
     if args.workload == "ilaf":
@@ -448,6 +484,9 @@ def run_rank(args):
         out["config"]["workload"] = f"{args.workload} ensemble ({models}), batch={b} clips per GPU"
         for k in ("end_to_end_tflops_per_gpu", "algorithmic_gflop_per_frame"):
             out.pop(k, None)
+    out["plan_ms"] = {"total": round(eng.plan_ms, 1), "plans": eng.plans,
+                      "note": "host wall time of building the planned backbones (weight packing, upload, launch lists, plan-time "
+                              "autotuning of every convolution launch); paid once per (backbone, resolution, max batch), never inside a timed region"}
     if product_default is not None:
         out["product_default"] = product_default
     if rank == 0:

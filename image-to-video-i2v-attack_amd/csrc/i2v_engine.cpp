@@ -105,7 +105,7 @@ struct Net {
 // `chain`: the launch follows the previous timed launch back to back on the same stream (same launch list), so its
 // start IS that launch's stop event -- one event record per launch instead of two (the records cost ~2 us of stream
 // time each, 4 % of the headline bench when every launch carried a pair).
-struct TimedLaunch { void* start; void* stop; int kind; double flops; int Cd, K, HWg, frames, pw; void* chain_from; };
+struct TimedLaunch { void* start; void* stop; int kind; double flops; int Cd, K, HWg, frames, pw; void* chain_from; double bytes; };
 struct i2v_ctx {
     int device; std::vector<Net*> nets;
     // nets may be executed from several threads on several streams (clip lanes): entries are handed out under a lock,
@@ -981,13 +981,13 @@ static TimedLaunch* timing_begin(i2v_ctx* h, int kind, double flops, i2v_stream_
     {
         std::lock_guard<std::mutex> lock(h->timing_mu);
         if (h->timed_used == h->timed.size()) {
-            TimedLaunch fresh{be_event_create(), be_event_create(), 0, 0.0};
+            TimedLaunch fresh{be_event_create(), be_event_create(), 0, 0.0, 0, 0, 0, 0, 0, nullptr, 0.0};
             if (!fresh.start || !fresh.stop) return nullptr;
             h->timed.push_back(fresh);
         }
         t = &h->timed[h->timed_used++];
     }
-    t->kind = kind; t->flops = flops; t->Cd = t->K = t->HWg = t->frames = t->pw = 0;
+    t->kind = kind; t->flops = flops; t->Cd = t->K = t->HWg = t->frames = t->pw = 0; t->bytes = 0.0;
     t->chain_from = prev ? prev->stop : nullptr;
     if (!t->chain_from) be_event_record(t->start, s);
     return t;
@@ -1007,7 +1007,21 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
                           : (l.kind == L_AVGB || l.kind == L_POOL3B) ? 3 : l.kind == L_MEMSET ? 4 : (int)l.kind;
         TimedLaunch* tl = timing_begin(h, tkind, flops, s, prev_timed);
         prev_timed = tl;
-        if (tl && (l.kind == L_CONV || l.kind == L_IMGGRAD)) { tl->Cd = l.conv.Cd; tl->K = l.conv.K; tl->HWg = l.conv.Hg * l.conv.Wg; tl->frames = frames; tl->pw = l.conv.pointwise; }
+        if (tl && (l.kind == L_CONV || l.kind == L_IMGGRAD)) {
+            tl->Cd = l.conv.Cd; tl->K = l.conv.K; tl->HWg = l.conv.Hg * l.conv.Wg; tl->frames = frames; tl->pw = l.conv.pointwise;
+            // ALGORITHMIC bytes of the launch: every operand once -- the source view, the packed weights, the output, each
+            // epilogue addend, and the ReLU gate (fp32 activation, or 1 bit per element) -- whatever the tiling re-reads
+            const I2VConvParams& q = l.conv;
+            const double out = (double)frames * q.Hg * q.Wg * q.Cd;
+            const double src = (double)clips * q.Ts * q.Cs * q.Hs * q.Ws;
+            double b = 4.0 * (src + (double)q.K * q.Cd + out);
+            if (q.add0) b += 4.0 * out / (q.add0_stride * q.add0_stride);
+            if (q.add1 || l.kind == L_IMGGRAD) b += (q.add1 || accumulate || l.img_accumulate) ? 4.0 * out : 0.0;
+            if (q.mask) b += 4.0 * out;
+            if (q.gate) b += out / 8.0;
+            if (q.gate_out) b += out / 8.0;
+            tl->bytes = b;
+        }
         struct Stop { TimedLaunch* t; i2v_stream_t s; ~Stop() { if (t) be_event_record(t->stop, s); } } stop{tl, s};
         switch (l.kind) {
             case L_CONV:
@@ -1069,23 +1083,40 @@ extern "C" int i2v_timing_enable(i2v_handle h, int enable) {
 }
 
 // kinds: 0 conv_igemm forward, 1 first-layer image gradient, 2 pool fwd, 3 pool bwd, 4 addmask, 5 conv_igemm dgrad
-extern "C" int i2v_timing_collect(i2v_handle h, double* ms_by_kind, double* flops_by_kind, int64_t* launches_by_kind,
-                                  int n_kinds) {
-    if (!h || !ms_by_kind || !flops_by_kind || !launches_by_kind || n_kinds < 6) return fail("i2v_timing_collect: bad argument");
-    for (int i = 0; i < n_kinds; ++i) { ms_by_kind[i] = 0; flops_by_kind[i] = 0; launches_by_kind[i] = 0; }
+// fields per kind: 0 ms, 1 algorithmic flops, 2 launches, 3 algorithmic bytes (convolution launches), and the same for the
+// LOW-INTENSITY launches alone -- flops/byte below the machine balance 157.3 TFLOP/s / 8 TB/s = 19.7, i.e. the ones the
+// HBM roofline bounds --: 4 ms, 5 bytes, 6 launches, 7 flops
+#define I2V_TIMING_FIELDS 8
+extern "C" int i2v_timing_collect_ex(i2v_handle h, double* out, int n_kinds, int n_fields) {
+    if (!h || !out || n_kinds < 6 || n_fields < I2V_TIMING_FIELDS) return fail("i2v_timing_collect_ex: bad argument");
+    for (int i = 0; i < n_kinds * n_fields; ++i) out[i] = 0.0;
     if (h->timed_used) CHECK_BE(be_device_sync());
     const char* dump_path = getenv("I2V_TIMING_DUMP");      // debug: one line per launch
     FILE* dump = dump_path ? fopen(dump_path, "a") : nullptr;
     for (size_t i = 0; i < h->timed_used; ++i) {
+        const TimedLaunch& t = h->timed[i];
         float ms = 0.f;
-        CHECK_BE(be_event_elapsed_ms(h->timed[i].chain_from ? h->timed[i].chain_from : h->timed[i].start, h->timed[i].stop, &ms));
-        int k = h->timed[i].kind;
-        if (dump) fprintf(dump, "%d %d %d %d %d %d %.4f %.3f\n", k, h->timed[i].Cd, h->timed[i].K, h->timed[i].HWg,
-                          h->timed[i].frames, h->timed[i].pw, ms, h->timed[i].flops * 1e-9);
-        ms_by_kind[k] += ms; flops_by_kind[k] += h->timed[i].flops; launches_by_kind[k] += 1;
+        CHECK_BE(be_event_elapsed_ms(t.chain_from ? t.chain_from : t.start, t.stop, &ms));
+        if (dump) fprintf(dump, "%d %d %d %d %d %d %.4f %.3f %.3f\n", t.kind, t.Cd, t.K, t.HWg, t.frames, t.pw, ms, t.flops * 1e-9, t.bytes * 1e-6);
+        if (t.kind < 0 || t.kind >= n_kinds) continue;
+        double* o = out + (size_t)t.kind * n_fields;
+        o[0] += ms; o[1] += t.flops; o[2] += 1; o[3] += t.bytes;
+        if (t.bytes > 0 && t.flops < 19.7 * t.bytes) { o[4] += ms; o[5] += t.bytes; o[6] += 1; o[7] += t.flops; }
     }
     if (dump) fclose(dump);
     h->timed_used = 0;
+    return 0;
+}
+
+extern "C" int i2v_timing_collect(i2v_handle h, double* ms_by_kind, double* flops_by_kind, int64_t* launches_by_kind,
+                                  int n_kinds) {
+    if (!h || !ms_by_kind || !flops_by_kind || !launches_by_kind || n_kinds < 6 || n_kinds > 16) return fail("i2v_timing_collect: bad argument");
+    double tmp[16 * I2V_TIMING_FIELDS];
+    if (i2v_timing_collect_ex(h, tmp, n_kinds, I2V_TIMING_FIELDS)) return 1;
+    for (int i = 0; i < n_kinds; ++i) {
+        ms_by_kind[i] = tmp[i * I2V_TIMING_FIELDS]; flops_by_kind[i] = tmp[i * I2V_TIMING_FIELDS + 1];
+        launches_by_kind[i] = (int64_t)tmp[i * I2V_TIMING_FIELDS + 2];
+    }
     return 0;
 }
 

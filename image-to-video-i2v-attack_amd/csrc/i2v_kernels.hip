@@ -169,6 +169,11 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         for (int q = 0; q < NBQ; ++q) boff[q] = pvalid ? xoff + (unsigned)((((wave + 4 * q) * 256 + lane * 4) / BP) * HWs * 4) : OOB;
     }
 
+#if defined(X_NOA_DMA) || defined(X_NOA_LDS)
+#define X_ADMA false
+#else
+#define X_ADMA true
+#endif
 #ifdef X_DMAHOT
 #define X_HOT(v) ((v) & 0xFFCu)
 #define X_HOTS(v) 0
@@ -185,7 +190,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         const int k0 = (k0_);                                                                             \
         if constexpr (jj < NAQ) {                                                                         \
             const int ins = wv + 4 * jj;                                                                  \
-            if (NA % 4 == 0 || ins < NA)                                                                  \
+            if (X_ADMA && (NA % 4 == 0 || ins < NA))                                                      \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(&As[buf_][0][0] + ins * 256), 16, X_HOT(aoff[jj]), \
                                                          X_HOTS(k0 * p.Cdpad * 4), 0, 0);                 \
         } else {                                                                                          \
@@ -286,12 +291,29 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         }
         (void)vb0;
         if (nchunks > 0) {
+#if defined(X_NODMA) || defined(X_NOA_DMA)       // ablations: both LDS buffers hold REAL operand data (same MFMA power as the full kernel)
+#undef X_ADMA
+#define X_ADMA true
+            [&]<int... J>(std::integer_sequence<int, J...>) { (([&] { I2V_ISSUE_PIECE(J, (nchunks > 1 ? KC : 0), 1, vb0); }()), ...); }
+            (std::make_integer_sequence<int, NL>{});
+#endif
             [&]<int... J>(std::integer_sequence<int, J...>) { (([&] { I2V_ISSUE_PIECE(J, 0, 0, vb0); }()), ...); }
             (std::make_integer_sequence<int, NL>{});
+#if defined(X_NOA_DMA)
+#undef X_ADMA
+#define X_ADMA false
+#endif
         }
     }
+#ifdef X_ALOAD
+    f32x4 xsink[TD][2];
+    for (int i = 0; i < TD; ++i) { xsink[i][0] = f32x4{0, 0, 0, 0}; xsink[i][1] = f32x4{0, 0, 0, 0}; }
+#endif
     auto chunk_body = [&](const int c, const int buf, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;                // a chunk c+1 exists: its DMA is issued here
+#ifdef X_ALOAD
+        for (int i = 0; i < TD; ++i) { asm volatile("" :: "v"(xsink[i][0]), "v"(xsink[i][1])); }
+#endif
 #ifndef X_NOBAR
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -311,8 +333,12 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
             for (int j = 0; j < TP; ++j) { fb[set][j] = 0.5f + s; asm volatile("" : "+v"(fb[set][j])); }
             return;
 #endif
+#ifdef X_NOA_LDS
+            for (int i = 0; i < TD; ++i) { fa[set][i] = 1.0f + s; asm volatile("" : "+v"(fa[set][i])); }
+#else
 #pragma unroll
             for (int i = 0; i < TD; ++i) fa[set][i] = As[buf][KR * s + lk][wd * (BD / WD) + i * FR + l31];
+#endif
 #pragma unroll
             for (int j = 0; j < TP; ++j) fb[set][j] = Bs[buf][KR * s + lk][wpx * (BP / WP) + j * FR + l31];
         };

@@ -6,6 +6,7 @@ PyTorch is used for device memory and streams only (`tensor.data_ptr()`,
 """
 import ctypes as C
 import threading
+import time
 from typing import List, Sequence
 
 import torch
@@ -31,6 +32,7 @@ class Engine:
             raise _lib.I2VError("the I2V engine needs a ROCm device; there is no CPU path")
         self.h = C.c_void_p()
         self.plan_lock = threading.Lock()      # net creation / planning / destruction touch the handle's net table
+        self.plan_ms, self.plans = 0.0, 0      # host wall time spent building nets (never inside a timed region of bench.py)
         idx = self.device.index or 0
         _lib.check(self.capi, self.capi.i2v_create(idx, C.byref(self.h)))
 
@@ -54,7 +56,11 @@ class Engine:
         """Thread-safe (concurrent clip streams plan their own nets); execution of DIFFERENT nets on different
         streams needs no lock -- a planned net owns its arena, the library keeps no other mutable state."""
         with self.plan_lock:
-            return Net(self, graph, state_dict, list(hook_tensors), max_frames)
+            t0 = time.perf_counter()
+            net = Net(self, graph, state_dict, list(hook_tensors), max_frames)
+            self.plan_ms += 1e3 * (time.perf_counter() - t0)      # pack + upload + plan + autotune (i2v_net_plan syncs)
+            self.plans += 1
+            return net
 
     # ---- measurement ----
     KINDS = ("conv_igemm_fwd", "conv_igemm_imggrad", "pool_fwd", "pool_bwd", "addmask", "conv_igemm_dgrad")
@@ -63,10 +69,13 @@ class Engine:
         _lib.check(self.capi, self.capi.i2v_timing_enable(self.h, 1 if on else 0))
 
     def timing_collect(self):
-        n = len(self.KINDS)
-        ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
-        _lib.check(self.capi, self.capi.i2v_timing_collect(self.h, ms, fl, cnt, n))
-        return {k: dict(ms=ms[i], flops=fl[i], launches=cnt[i]) for i, k in enumerate(self.KINDS)}
+        """Per kernel kind: device ms, algorithmic flops, launches, algorithmic bytes, and the same over the launches
+        whose flops/byte is below the machine balance (`lowi_*`: the HBM-bound ones)."""
+        n, f = len(self.KINDS), 8
+        out = (C.c_double * (n * f))()
+        _lib.check(self.capi, self.capi.i2v_timing_collect_ex(self.h, out, n, f))
+        keys = ("ms", "flops", "launches", "bytes", "lowi_ms", "lowi_bytes", "lowi_launches", "lowi_flops")
+        return {k: {key: out[i * f + j] for j, key in enumerate(keys)} for i, k in enumerate(self.KINDS)}
 
     # ---- loop kernels (thin, typed wrappers) ----
     def clip_from_u8(self, frames_u8: torch.Tensor) -> torch.Tensor:
@@ -198,6 +207,12 @@ class Net:
             with self.eng.plan_lock:
                 self.eng.capi.i2v_net_destroy(self.eng.h, self.id)
         self.id = None
+
+    def __del__(self):            # an attack object going out of scope gives its arenas back (tens of GB at full size)
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def workspace_bytes(self) -> int:
         return self.eng.capi.i2v_net_workspace_bytes(self.eng.h, self.id)

@@ -130,6 +130,11 @@ int i2v_net_read_tensor(i2v_handle h, int net, int tensor, int which, float* out
 int i2v_timing_enable(i2v_handle h, int enable);
 int i2v_timing_collect(i2v_handle h, double* ms_by_kind, double* flops_by_kind,
                        int64_t* launches_by_kind, int n_kinds);
+/* The same with the launches' ALGORITHMIC bytes (every operand of a convolution launch once: source view, packed weights,
+ * output, epilogue addends, ReLU gate) so that bench.py can state both rooflines: out[kind*n_fields + f], n_fields >= 8,
+ * f = 0 ms, 1 flops, 2 launches, 3 bytes, and over the launches whose flops/byte is below the machine balance
+ * (157.3 TFLOP/s / 8 TB/s = 19.7 -- the HBM-bound ones): 4 ms, 5 bytes, 6 launches, 7 flops. */
+int i2v_timing_collect_ex(i2v_handle h, double* out, int n_kinds, int n_fields);
 
 /* ---- loop kernels ------------------------------------------------------------------------ */
 /* Decoded, resized and cropped uint8 frames (b,t,h,w,3) -> normalised clip (b,3,t,h,w): the tail of

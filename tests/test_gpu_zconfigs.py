@@ -153,6 +153,7 @@ def test_config3_aens_shard_8clips_full_size(eng):
     finally:
         if created:
             dist.destroy_process_group()
+    del a0, a1
     adv2, _, c2 = attacks.AENS_I2V_MF(names, **kw)(vid, lab, vnames)
     assert torch.equal(adv0, adv2) and np.array_equal(c0, c2)
 

@@ -6,7 +6,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
@@ -57,14 +57,29 @@ for n in sorted(fetch, key=lambda k: -fetch[k]["_ns"]):
               "FETCH_SIZE_KB_per_launch_raw": round(f_kb / calls, 1), "WRITE_SIZE_KB_per_launch": round(w_kb / max(write.get(n, {}).get("_calls", 1), 1), 1),
               "mfma_busy_frac": round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * t * 2.4e9), 4) if t else None,
               "clock_GHz": round(m.get("GRBM_GUI_ACTIVE", 0) / 8 / t / 1e9, 3) if t else None}
-json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
+try:
+    bid = open(os.path.join(src, "build_id.txt")).read().strip()
+except OSError:
+    bid = None
+for n, v in out.items():
+    m = mfma.get(n, {})
+    wc = m.get("SQ_WAVE_CYCLES", 0)
+    if wc:
+        v["wave_cycles_waiting_frac"] = round(m.get("SQ_WAIT_ANY", 0) / wc, 3)          # parked at s_waitcnt / s_barrier
+        v["wave_cycles_issue_stalled_frac"] = round(m.get("SQ_WAIT_INST_ANY", 0) / wc, 3)  # ready but the pipe is busy
+    v["hbm_bytes_per_launch"] = round((2 * v["FETCH_SIZE_KB_per_launch_raw"] + v["WRITE_SIZE_KB_per_launch"]) * 1024)
+json.dump({"build_id": bid, "kernels": out}, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 conv = {k: v for k, v in out.items() if k.startswith("conv_igemm")}
 calls = sum(v["calls"] for v in conv.values())
 fk = sum(v["FETCH_SIZE_KB_per_launch_raw"] * v["calls"] for v in conv.values()) / calls
 wk = sum(v["WRITE_SIZE_KB_per_launch"] * v["calls"] for v in conv.values()) / calls
-json.dump({"kernel": "conv_igemm (all instantiations)", "launches": calls,
-           "fetch_bytes_per_launch_raw": fk * 1024, "fetch_bytes_per_launch_corrected_x2": 2 * fk * 1024,
-           "write_bytes_per_launch": wk * 1024, "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
-           "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE as read; "
-                   "separate --pmc passes of `bench.py --steps 2 --warmup 1`"}, open(f"profiles/{tag}_conv_traffic.json", "w"), indent=1)
+json.dump({"build_id": bid,
+           "note": "HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 tallies 128-B fetch requests at 64 B: MI355X_MICROARCH.md, HBM); "
+                   "separate --pmc passes of `bench.py --steps 2 --warmup 1 --no-kernel-timing` (plan-time autotuner probes included in the averages)",
+           "conv_igemm": {"launches": calls, "fetch_bytes_per_launch_raw": fk * 1024, "write_bytes_per_launch": wk * 1024,
+                          "hbm_bytes_per_launch": (2 * fk + wk) * 1024},
+           "by_instantiation": {k: {"calls": v["calls"], "avg_us": v["avg_us"], "hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
+                                    "hbm_gbps": round(v["hbm_bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1),
+                                    "mfma_busy_frac": v["mfma_busy_frac"]} for k, v in conv.items()}},
+          open(f"profiles/{tag}_traffic_by_instantiation.json", "w"), indent=1)
 print(json.dumps({k: out[k] for k in list(out)[:8]}, indent=1))
