@@ -108,6 +108,44 @@ def _note(arch: str, source: str, warn: bool = True):
             print(f"[i2v_amd] backbone {arch}: weights from {source}")
 
 
+def convert_gluoncv_state_dict(graph: Graph, sd: Dict[str, torch.Tensor], rules=None) -> Dict[str, torch.Tensor]:
+    """Map a gluoncv-torch video checkpoint (the reference builds its white-box models with
+    `gluoncv.torch.model_zoo.get_model(cfg)`, `image_fine_tune_attack.py:58-66`) onto the key layout of the video graph IR
+    (`graphs.i3d_resnet` / `graphs.slowfast_res2`): unwraps `{'state_dict': ...}`, strips a DataParallel `module.` prefix,
+    applies `rules` -- `(regex, replacement)` pairs, first match wins -- and then REQUIRES every parameter the graph reads
+    to be present with the right shape (everything else -- later stages, heads, `num_batches_tracked` -- is dropped).
+
+    The graph's own names follow the attributes the reference dereferences on those models (`res_layers`, `slow_res2`,
+    `fast_res2`, `image_attacks.py:513-519`) and the Bottleneck layout of gluoncv's action-recognition ResNets
+    (`conv1/bn1/conv2/bn2/conv3/bn3/downsample.{0,1}`), so the default rule set is the identity.  gluoncv is not
+    installed and cannot be fetched here: the mapping is therefore UNPINNED against a real checkpoint -- which is why a
+    key that does not land, or lands with another shape, is an error and never a silent re-initialisation."""
+    import re
+    if isinstance(sd, dict) and isinstance(sd.get("state_dict"), dict):
+        sd = sd["state_dict"]
+    rules = [(re.compile(a), b) for a, b in (rules or [])]
+    renamed = {}
+    for k, v in sd.items():
+        k = k[len("module."):] if k.startswith("module.") else k
+        for rx, rep in rules:
+            if rx.search(k):
+                k = rx.sub(rep, k)
+                break
+        renamed[k] = v
+    out, missing, wrong = {}, [], []
+    for k, shp in graph.param_shapes().items():
+        if k not in renamed:
+            missing.append(k)
+        elif tuple(renamed[k].shape) != tuple(shp):
+            wrong.append((k, tuple(renamed[k].shape), tuple(shp)))
+        else:
+            out[k] = renamed[k].float().contiguous()
+    if missing or wrong:
+        raise KeyError(f"checkpoint does not cover the {graph.arch} graph: {len(missing)} missing (e.g. {missing[:3]}), "
+                       f"{len(wrong)} with another shape (e.g. {wrong[:2]}); pass `rules=[(regex, replacement), ...]` to rename")
+    return out
+
+
 def fold_affine(nd, sd):
     """Per-output-channel (scale, shift) such that the node computes
     `y = conv(x, W) * scale + shift` -- BatchNorm in eval mode

@@ -1,0 +1,98 @@
+"""GPU (-m gpu): the drop-in CLIs END TO END on the device: `image_main.py` as the reference
+runs it -- one process per shard, `--batch_nums/--batch_index` windows (image_main.py:61-63), `{label}-adv.npy` +
+`loss_info_{i}.json` (:45,90-95) -- with the async reader / pinned-copy / writer threads on a real stream, `--resume`,
+then the evaluator (`reference.py:96-129` contract) on the directory it left behind."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "image-to-video-i2v-attack_amd")
+
+
+def run_cli(script, args, env):
+    r = subprocess.run([sys.executable, os.path.join(PKG, script)] + args, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r.stdout
+
+
+def test_image_main_shards_resume_and_evaluator_on_gpu(tmp_path):
+    assert torch.cuda.is_available()
+    env = dict(os.environ, I2V_OPT_PATH=str(tmp_path), I2V_SYNTHETIC_WEIGHTS="1", I2V_QUIET_WEIGHTS="1",
+               PYTHONPATH=os.pathsep.join([PKG, ROOT, os.environ.get("PYTHONPATH", "")]))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    # 6 clips of 8 frames x 112^2 through the real ResNet-50 (reference CLI vocabulary: --direction_image_model),
+    # batch 2; int(3 batches / 2 shards) = 1 batch per shard, as the reference's integer division leaves the last batch to nobody
+    common = ["--attack_method", "ImageGuidedFMDirection_Adam", "--step", "3", "--step_size", "0.005", "--depth", "3",
+              "--direction_image_model", "resnet50", "--num_clips", "6", "--frames", "8", "--hw", "112", "--batch_size", "2",
+              "--file_prefix", "gpu", "--batch_nums", "2", "--anno", os.path.join(ROOT, "tests", "golden", "kinetics400_attack_samples.csv")]
+    out = tmp_path / "Image-ImageGuidedFMDirection_Adam-3-gpu"
+    log2 = run_cli("image_main.py", common + ["--batch_index", "2"], env)
+    labels = [int(r.split(",")[1]) for r in open(os.path.join(ROOT, "tests", "golden", "kinetics400_attack_samples.csv")).read().strip().split("\n")[1:7]]
+    # batches of 2 over 6 clips = 3 batches; int(3 / 2) = 1 batch per shard (image_main.py:61): shard 2 = batch index 1
+    shard2 = sorted(f"{l}-adv.npy" for l in labels[2:4])
+    assert sorted(os.listdir(out)) == sorted(shard2 + ["loss_info_2.json"]), (os.listdir(out), log2[-500:])
+    run_cli("image_main.py", common + ["--batch_index", "1"], env)
+    shard1 = sorted(f"{l}-adv.npy" for l in labels[0:2])
+    assert sorted(os.listdir(out)) == sorted(shard1 + shard2 + ["loss_info_1.json", "loss_info_2.json"])
+    for f in shard1 + shard2:
+        adv = np.load(out / f)
+        assert adv.dtype == np.float32 and adv.shape == (3, 8, 112, 112) and np.isfinite(adv).all()
+        un = adv * np.array([0.229, 0.224, 0.225], np.float32).reshape(3, 1, 1, 1) + np.array([0.485, 0.456, 0.406], np.float32).reshape(3, 1, 1, 1)
+        assert un.min() >= -1e-5 and un.max() <= 1 + 1e-5
+    info = json.load(open(out / "loss_info_1.json"))
+    assert len(info) == 2 and all(list(v) == ["0", "1", "2"] for v in info.values())
+    costs = [float(v["0"]["cost"]) for v in info.values()]
+    assert all(abs(c - 2 * 8) < 0.1 for c in costs)                      # batch-total cost: 2 clips x 8 frames, cos ~ 1 at delta_0
+    # the perturbed clips equal an in-process run of the same attack (same device, deterministic kernels)
+    sys.path.insert(0, PKG)
+    from i2v_amd import attacks, clips
+    atk = attacks.ImageGuidedFMDirection_Adam(["resnet50"], depth=3, step_size=0.005, steps=3, weight_seed=0)
+    batch = next(iter(clips.batches(2, os.path.join(ROOT, "tests", "golden", "kinetics400_attack_samples.csv"), None, 8, 112, 6)))
+    ref = atk(batch[0], batch[1], batch[2]).cpu().numpy()
+    assert np.array_equal(ref[0], np.load(out / f"{labels[0]}-adv.npy")) and np.array_equal(ref[1], np.load(out / f"{labels[1]}-adv.npy"))
+    # --resume: nothing left to do in shard 1, files untouched
+    before = {f: os.path.getmtime(out / f) for f in shard1}
+    run_cli("image_main.py", common + ["--batch_index", "1", "--resume"], env)
+    assert {f: os.path.getmtime(out / f) for f in shard1} == before
+    # the evaluator on what the attack left behind (proxy video models; reference.py:96-129 file contract)
+    log = run_cli("reference.py", ["--adv_path", "Image-ImageGuidedFMDirection_Adam-3-gpu", "--models", "i3d_resnet50,slowfast_resnet50",
+                                   "--batch_size", "3"], env)
+    acc = json.load(open(out / "top1_acc_all_models.json"))
+    assert set(acc) == {"i3d_resnet50", "slowfast_resnet50"} and all(0.0 <= v <= 100.0 for v in acc.values())
+    rows = (out / "results_all_models_prediction.csv").read_text().strip().split("\n")
+    assert rows[0] == "gt_label,i3d_resnet50-pre,slowfast_resnet50-pre" and len(rows) == 5
+    assert [int(r.split(",")[0]) for r in rows[1:]] == sorted(labels[0:4]) and "fooling rate" in log
+
+
+def test_checkpoint_file_drives_the_engine(tmp_path, monkeypatch):
+    """A torchvision-layout checkpoint under $I2V_WEIGHTS_DIR (extra keys and all) must give exactly the clips the same
+    tensors give when handed over directly -- i.e. the file, not the synthetic initialiser, is what reaches the device."""
+    sys.path.insert(0, PKG)
+    from i2v_amd import attacks, graphs, weights
+    g = graphs.build_tiny("resnet", (64, 64))
+    sd = weights.synthetic_state_dict(g, 5)
+    full = dict(sd)
+    full.update({"fc.weight": torch.zeros(10, 256), "fc.bias": torch.zeros(10), "bn1.num_batches_tracked": torch.tensor(0),
+                 "layer4.0.conv1.weight": torch.zeros(64, 128, 1, 1)})
+    torch.save(full, tmp_path / f"{g.arch}.pth")
+    vid = torch.randn(2, 3, 4, 64, 64, generator=torch.Generator().manual_seed(9))
+    lab = torch.zeros(2, dtype=torch.long)
+    want = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=3, step_size=0.005, steps=3, graph_builder=graphs.build_tiny,
+                                               weight_seed=5)(vid, lab, ["a", "b"]).cpu()
+    monkeypatch.setenv("I2V_WEIGHTS_DIR", str(tmp_path))
+    monkeypatch.delenv("I2V_SYNTHETIC_WEIGHTS", raising=False)
+    got = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=3, step_size=0.005, steps=3,
+                                              graph_builder=graphs.build_tiny)(vid, lab, ["a", "b"]).cpu()
+    assert torch.equal(got, want)
+    other = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=3, step_size=0.005, steps=3, graph_builder=graphs.build_tiny,
+                                                weight_seed=6)(vid, lab, ["a", "b"]).cpu()
+    assert not torch.equal(other, want)
