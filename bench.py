@@ -52,8 +52,9 @@ def build_id():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "image-to-video-i2v-attack_amd", "csrc")
-    for f in sorted(os.listdir(csrc)) + [os.path.join(ROOT, "include", "i2v_hip.h")]:
-        with open(f if os.path.isabs(f) else os.path.join(csrc, f), "rb") as fh:
+    files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".cpp", ".h"))]
+    for f in files + [os.path.join(ROOT, "include", "i2v_hip.h")]:
+        with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 

@@ -88,11 +88,11 @@ def test_checkpoint_file_drives_the_engine(tmp_path, monkeypatch):
     lab = torch.zeros(2, dtype=torch.long)
     want = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=3, step_size=0.005, steps=3, graph_builder=graphs.build_tiny,
                                                weight_seed=5)(vid, lab, ["a", "b"]).cpu()
+    other = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=3, step_size=0.005, steps=3, graph_builder=graphs.build_tiny,
+                                                weight_seed=6)(vid, lab, ["a", "b"]).cpu()
+    assert not torch.equal(other, want)                      # the weights do matter to the result
     monkeypatch.setenv("I2V_WEIGHTS_DIR", str(tmp_path))
     monkeypatch.delenv("I2V_SYNTHETIC_WEIGHTS", raising=False)
     got = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=3, step_size=0.005, steps=3,
                                               graph_builder=graphs.build_tiny)(vid, lab, ["a", "b"]).cpu()
     assert torch.equal(got, want)
-    other = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=3, step_size=0.005, steps=3, graph_builder=graphs.build_tiny,
-                                                weight_seed=6)(vid, lab, ["a", "b"]).cpu()
-    assert not torch.equal(other, want)
