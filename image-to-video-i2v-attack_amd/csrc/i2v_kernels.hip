@@ -1212,6 +1212,36 @@ __global__ void clip_from_u8_kernel(const uint8_t* __restrict__ frames, float* _
     }
 }
 
+// Decoded uint8 frames (b, t, H, W, 3) -> bilinear resize to (rh, rw) in OpenCV's 8-bit fixed-point arithmetic (what gluoncv's
+// `video_transforms.Resize` runs on decord's numpy frames, datasets.py:88) -> centre crop (oh, ow) -> /255 -> (x - mean)/std ->
+// clip layout (b, 3, t, oh, ow): the whole validation transform of the reference's loader (datasets.py:86-93) in one pass over the
+// pixels that survive the crop.  xtab / ytab hold (source index, weight of it, weight of the next one; weights in 1/2048) per
+// RESIZED column / row, built on the host exactly as cv::resize builds them.
+//   horizontal: S = src[sx]*a0 + src[sx+1]*a1                     (int, <= 255*2048)
+//   vertical:   d = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2          (cv::VResizeLinear<uchar, int, short>)
+__global__ void clip_resize_crop_kernel(const uint8_t* __restrict__ frames, float* __restrict__ video, const int32_t* __restrict__ xtab,
+                                        const int32_t* __restrict__ ytab, int b, int t, int H, int W, int cy, int cx, int oh, int ow) {
+    const int64_t total = (int64_t)b * t * oh * ow;
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int x = o % ow; int64_t r = o / ow;
+        const int y = r % oh; r /= oh;
+        const int ti = r % t; const int64_t bi = r / t;
+        const int32_t* xe = xtab + 3 * (x + cx); const int32_t* ye = ytab + 3 * (y + cy);
+        const int sx0 = xe[0], a0 = xe[1], a1 = xe[2], sy0 = ye[0], b0 = ye[1], b1 = ye[2];
+        const int sx1 = min(sx0 + 1, W - 1), sy1 = min(sy0 + 1, H - 1);
+        const uint8_t* f = frames + (bi * t + ti) * (int64_t)H * W * 3;
+        const uint8_t* r0 = f + (int64_t)sy0 * W * 3; const uint8_t* r1 = f + (int64_t)sy1 * W * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int S0 = r0[sx0 * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
+            const int S1 = r1[sx0 * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+            const int d = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+            const float v = __fdiv_rn((float)d, 255.f);
+            video[(((bi * 3 + c) * t + ti) * oh + y) * (int64_t)ow + x] = __fdiv_rn(__fsub_rn(v, c_mean[c]), c_std[c]);
+        }
+    }
+}
+
 __global__ void frames_from_video_kernel(const float* __restrict__ video, float* __restrict__ x, float* __restrict__ u,
                                          int b, int f, int hw) {
     const int64_t total = (int64_t)b * 3 * f * hw;
@@ -1326,6 +1356,13 @@ int k_clip_from_u8(const uint8_t* frames, float* video, int b, int t, int h, int
     const int64_t total = (int64_t)b * 3 * t * h * w;
     hipLaunchKernelGGL(clip_from_u8_kernel, dim3(stream_grid(total, 1024)), dim3(256), 0, (hipStream_t)s, frames, video, b, t, h * w);
     LAUNCH_CHECK("clip_from_u8"); return 0;
+}
+int k_clip_resize_crop(const uint8_t* frames, float* video, const int32_t* xtab, const int32_t* ytab, int b, int t, int H, int W,
+                       int cy, int cx, int oh, int ow, i2v_stream_t s) {
+    const int64_t total = (int64_t)b * t * oh * ow;
+    hipLaunchKernelGGL(clip_resize_crop_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)s, frames, video, xtab, ytab,
+                       b, t, H, W, cy, cx, oh, ow);
+    LAUNCH_CHECK("clip_resize_crop"); return 0;
 }
 int k_frames_from_video(const float* video, float* x, float* u, int b, int f, int h, int w, i2v_stream_t s) {
     const int64_t total = (int64_t)b * 3 * f * h * w;

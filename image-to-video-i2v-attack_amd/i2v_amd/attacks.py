@@ -40,6 +40,19 @@ def get_engine(device: Optional[str] = None) -> Engine:
     return _ENGINES[device]
 
 
+def shutdown():
+    """Orderly end of a CLI process: wait for the device, then release every engine (planned nets, arenas, event pools)
+    while the HIP runtime is certainly still alive -- instead of leaving it to interpreter finalisation, whose order
+    against the runtime's own teardown is not defined."""
+    for dev, eng in list(_ENGINES.items()):
+        try:
+            if eng.device.type == "cuda":
+                torch.cuda.synchronize(eng.device)
+            eng.close()
+        finally:
+            _ENGINES.pop(dev, None)
+
+
 class Attack(object):
     """Base class, `/root/reference/image_attacks.py:12-82`: attack name, ImageNet mean/std,
     `__call__ -> forward`."""

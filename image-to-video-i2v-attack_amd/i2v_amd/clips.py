@@ -35,8 +35,14 @@ def sample_list(csv_path=None, n=400):
 
 
 def batches(batch_size, csv_path=None, clip_dir=None, frames=32, hw=224, n=400):
-    """Yields (val_batch (b,3,f,h,w), val_label (b,), video_names) like the reference's DataLoader."""
-    if clip_dir:
+    """Yields (val_batch (b,3,f,h,w), val_label (b,), video_names) like the reference's DataLoader.  A `clip_dir` of
+    `{label}-raw.npy` files -- DECODED uint8 frames (t,H,W,3), what decord hands the reference's loader
+    (datasets.py:226-244) -- yields uint8 batches (b,t,H,W,3) instead: the caller runs the validation transform on the
+    device (`Engine.clip_resize_crop`, datasets.py:86-93).  Raw clips of one batch must share their frame size."""
+    raw = sorted(glob.glob(os.path.join(clip_dir, "*-raw.npy"))) if clip_dir else []
+    if raw:
+        items = [(os.path.basename(p), int(os.path.basename(p).split("-")[0]), p) for p in raw]
+    elif clip_dir:
         files = sorted(glob.glob(os.path.join(clip_dir, "*-ori.npy")))
         items = [(os.path.basename(p), int(os.path.basename(p).split("-")[0]), p) for p in files]
     else:
@@ -50,7 +56,46 @@ def batches(batch_size, csv_path=None, clip_dir=None, frames=32, hw=224, n=400):
 
 def num_batches(batch_size, csv_path=None, clip_dir=None, n=400):
     if clip_dir:
-        cnt = len(glob.glob(os.path.join(clip_dir, "*-ori.npy")))
+        cnt = len(glob.glob(os.path.join(clip_dir, "*-raw.npy"))) or len(glob.glob(os.path.join(clip_dir, "*-ori.npy")))
     else:
         cnt = len(sample_list(csv_path, n))
     return (cnt + batch_size - 1) // batch_size
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# geometry of the reference's validation transform (datasets.py:86-93; gluoncv.torch.data.video_transforms), host side
+# of `Engine.clip_resize_crop`.  gluoncv and OpenCV are third-party to the reference and not installed here: restated
+# from their public sources, parity UNPINNED (oracle/restate.py:resize_center_crop_normalise is the CPU twin).
+# ---------------------------------------------------------------------------------------------------------------
+def resize_sizes(h, w, short_side):
+    """`video_transforms.Resize(size: int)`: the short side becomes `size`, the other int(size * long / short);
+    an image whose short side already is `size` is left alone."""
+    if (w <= h and w == short_side) or (h <= w and h == short_side):
+        return h, w
+    if w < h:
+        return int(short_side * h / w), short_side
+    return short_side, int(short_side * w / h)
+
+
+def center_crop_origin(h, w, ch, cw):
+    """`video_transforms.CenterCrop`: (y1, x1) = round((im - crop) / 2)."""
+    return int(round((h - ch) / 2.0)), int(round((w - cw) / 2.0))
+
+
+def resize_table(n_out, n_in):
+    """Per output index of a bilinear axis resize as cv::resize (INTER_LINEAR, 8-bit) builds it: source index,
+    weight of it and of its right/lower neighbour in INTER_RESIZE_COEF_SCALE = 2048 units (int32 (n_out, 3)).
+        fx = (float)((d + 0.5) * scale - 0.5); sx = floor(fx); fx -= sx
+        sx < 0 -> sx = 0, fx = 0;  sx >= n_in - 1 -> sx = n_in - 1, fx = 0
+        weights = saturate_cast<short>(rint((1 - fx) * 2048)), saturate_cast<short>(rint(fx * 2048))"""
+    scale = np.float64(n_in) / np.float64(n_out)
+    d = np.arange(n_out, dtype=np.float64)
+    fx = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    sx = np.floor(fx).astype(np.int64)
+    fx = (fx - sx.astype(np.float32)).astype(np.float32)
+    lo, hi = sx < 0, sx >= n_in - 1
+    fx = np.where(lo | hi, np.float32(0), fx)
+    sx = np.where(lo, 0, np.where(hi, n_in - 1, sx))
+    a1 = np.rint(fx * np.float32(2048)).astype(np.int64)
+    a0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(np.int64)
+    return np.stack([sx, a0, a1], 1).astype(np.int32)

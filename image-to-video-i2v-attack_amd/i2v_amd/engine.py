@@ -5,6 +5,7 @@ PyTorch is used for device memory and streams only (`tensor.data_ptr()`,
 `torch.cuda.current_stream().cuda_stream`); all arithmetic happens behind the C ABI.
 """
 import ctypes as C
+import sys
 import threading
 import time
 from typing import List, Sequence
@@ -48,7 +49,8 @@ class Engine:
 
     def __del__(self):
         try:
-            self.close()
+            if not sys.is_finalizing():        # at interpreter exit the HIP runtime may already be tearing down: let the OS reclaim
+                self.close()
         except Exception:
             pass
 
@@ -84,6 +86,26 @@ class Engine:
         b, t, h, w, _ = frames_u8.shape
         out = torch.empty(b, 3, t, h, w, dtype=torch.float32, device=frames_u8.device)
         _lib.check(self.capi, self.capi.i2v_clip_from_u8_f32(C.c_void_p(frames_u8.data_ptr()), _ptr(out), b, t, h, w, self.stream()))
+        return out
+
+    def clip_resize_crop(self, frames_u8: torch.Tensor, short_side=256, crop=224) -> torch.Tensor:
+        """(b,t,H,W,3) uint8 decoded frames on the device -> the reference's validation transform (datasets.py:86-93:
+        resize the short side to `short_side` with cv2-style 8-bit bilinear, centre-crop `crop`, /255, normalise) ->
+        (b,3,t,crop,crop) float32, in one kernel."""
+        from . import clips as _clips
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and frames_u8.shape[-1] == 3
+        b, t, H, W, _ = frames_u8.shape
+        rh, rw = _clips.resize_sizes(H, W, short_side)
+        cy, cx = _clips.center_crop_origin(rh, rw, crop, crop)
+        key = (H, W, rh, rw)
+        tabs = self.__dict__.setdefault("_resize_tabs", {})
+        if key not in tabs:
+            tabs[key] = tuple(torch.from_numpy(_clips.resize_table(n_out, n_in)).to(frames_u8.device) for n_out, n_in in ((rw, W), (rh, H)))
+        xt, yt = tabs[key]
+        out = torch.empty(b, 3, t, crop, crop, dtype=torch.float32, device=frames_u8.device)
+        _lib.check(self.capi, self.capi.i2v_clip_resize_crop_u8_f32(
+            C.c_void_p(frames_u8.data_ptr()), _ptr(out), C.c_void_p(xt.data_ptr()), C.c_void_p(yt.data_ptr()), b, t, H, W, rh, rw,
+            cy, cx, crop, crop, self.stream()))
         return out
 
     def frames_from_video(self, video, x, u):
@@ -210,7 +232,8 @@ class Net:
 
     def __del__(self):            # an attack object going out of scope gives its arenas back (tens of GB at full size)
         try:
-            self.close()
+            if not sys.is_finalizing():
+                self.close()
         except Exception:
             pass
 

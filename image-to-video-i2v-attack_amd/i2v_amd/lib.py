@@ -66,6 +66,7 @@ _PROTOS = {
     "i2v_timing_collect": ([_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L), _I], _I),
     "i2v_timing_collect_ex": ([_P, C.POINTER(C.c_double), _I, _I], _I),
     "i2v_clip_from_u8_f32": ([_P, _P, _I, _I, _I, _I, _P], _I),
+    "i2v_clip_resize_crop_u8_f32": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),
     "i2v_frames_from_video_f32": ([_P, _P, _P, _I, _I, _I, _I, _P], _I),
     "i2v_compose_f32": ([_P, _P, _P, _I, _I, _I, _I, _F, _I, _P], _I),
     "i2v_cossim_scratch_bytes": ([_L, _I], C.c_size_t),

@@ -128,6 +128,10 @@ def main(argv=None):
             break
         step, val_batch, val_label, video_names = item
         print("Running {}, {}/{}".format(args.attack_method, step + 1, total))
+        if val_batch.dtype == torch.uint8:          # decoded frames (b,t,H,W,3): the loader's Resize/CenterCrop/ToTensor/Normalize on the device
+            from i2v_amd import attacks as _attacks
+            eng = _attacks.get_engine()
+            val_batch = eng.clip_resize_crop(val_batch.to(eng.device, non_blocking=True).contiguous(), crop=args.hw)
         adv_batches = attack_method(val_batch, val_label, video_names)
         if isinstance(adv_batches, tuple):                             # AENS returns (adv, time, costs)
             adv_batches = adv_batches[0]
@@ -144,6 +148,11 @@ def main(argv=None):
     threads[1].join()
     with open(os.path.join(args.adv_path, "loss_info_{}.json".format(args.batch_index)), "w") as opt:
         json.dump(attack_method.loss_info, opt)
+    threads[0].join(timeout=60)
+    if cuda and __name__ == "__main__":
+        del attack_method
+        from i2v_amd import attacks as _a
+        _a.shutdown()
 
 
 if __name__ == "__main__":

@@ -141,6 +141,14 @@ int i2v_timing_collect_ex(i2v_handle h, double* out, int n_kinds, int n_fields);
  * the reference's loader, `ClipToTensor` (/255) + `Normalize(mean,std)` (datasets.py:88-93), fused
  * with the layout change (decoding/resizing stay on the host). */
 int i2v_clip_from_u8_f32(const uint8_t* frames, float* video, int b, int t, int h, int w, void* stream);
+/* The WHOLE validation transform of the reference's loader (datasets.py:86-93: `Resize(short_side, 'bilinear')` ->
+ * `CenterCrop` -> `ClipToTensor` -> `Normalize`) on decoded uint8 frames (b,t,H,W,3) in one pass: only the pixels that
+ * survive the crop are computed.  The resize is OpenCV's 8-bit bilinear (gluoncv runs cv2.resize on decord's numpy
+ * frames): xtab (rw x 3) / ytab (rh x 3) int32 DEVICE tables hold, per resized column / row, (source index, weight of
+ * it, weight of the next index) in 1/2048 units, built by the host as cv::resize builds them (i2v_amd/clips.py).
+ * Output (b,3,t,out_h,out_w), normalised. */
+int i2v_clip_resize_crop_u8_f32(const uint8_t* frames, float* video, const int32_t* xtab, const int32_t* ytab, int b, int t,
+                                int H, int W, int rh, int rw, int crop_y, int crop_x, int out_h, int out_w, void* stream);
 /* videos (b,3,f,h,w) normalised -> frames x:(b*f,3,h,w), frame n = b_idx*f + f_idx
  * (image_attacks.py:300-301) and u = x*std + mean (`_transform_video(...,'back')`, :62,308). */
 int i2v_frames_from_video_f32(const float* video, float* x, float* u, int b, int f, int h, int w,

@@ -384,3 +384,57 @@ def run_ilaf(model, hook_modules, videos, ori_videos, *, steps, step_size=0.005,
 def cost_strings(costs: np.ndarray) -> List[str]:
     """`str(cost.detach().cpu().numpy())` of a float32 scalar (`image_attacks.py:358`)."""
     return [str(np.float32(c)) for c in costs]
+
+
+# ---------------------------------------------------------------------------
+# input pipeline (SURVEY.md 8(f) N4)
+# ---------------------------------------------------------------------------
+def resize_center_crop_normalise(frames_u8: np.ndarray, short_side=256, crop=224) -> torch.Tensor:
+    """CPU twin of `i2v_clip_resize_crop_u8_f32`: the reference's validation transform (`/root/reference/datasets.py:86-93`)
+    `video_transforms.Resize(short_side, 'bilinear')` -> `CenterCrop(crop)` -> `ClipToTensor` (/255, THWC -> CTHW) ->
+    `Normalize(mean, std)` on decoded uint8 frames (b, t, H, W, 3).
+
+    The arithmetic lives in gluoncv 0.10.4 (`gluoncv/torch/data/video_transforms`: numpy frames go through `cv2.resize(img,
+    (new_w, new_h), interpolation=cv2.INTER_LINEAR)`) and OpenCV (`resize.cpp`: 8-bit bilinear in fixed point: horizontal pass
+    with 11-bit weights into int, vertical pass `(((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2`), neither vendored nor
+    installed: restated here from the public sources -- PARITY UNPINNED.  Written independently of `i2v_amd.clips` (its own
+    coordinate / weight construction, whole-frame resize then crop) so that the two restatements check each other."""
+    b, t, H, W, _ = frames_u8.shape
+    # gluoncv get_resize_sizes
+    if (W <= H and W == short_side) or (H <= W and H == short_side):
+        rh, rw = H, W
+    elif W < H:
+        rh, rw = int(short_side * H / W), short_side
+    else:
+        rh, rw = short_side, int(short_side * W / H)
+
+    def axis(n_out, n_in):
+        idx, w0, w1 = np.zeros(n_out, np.int64), np.zeros(n_out, np.int64), np.zeros(n_out, np.int64)
+        scale = float(n_in) / float(n_out)
+        for d in range(n_out):
+            fx = np.float32((d + 0.5) * scale - 0.5)
+            sx = int(math.floor(fx))
+            fx = np.float32(fx - np.float32(sx))
+            if sx < 0:
+                sx, fx = 0, np.float32(0)
+            if sx >= n_in - 1:
+                sx, fx = n_in - 1, np.float32(0)
+            idx[d] = sx
+            w0[d] = int(np.rint(np.float32(np.float32(1) - fx) * np.float32(2048)))
+            w1[d] = int(np.rint(fx * np.float32(2048)))
+        return idx, w0, w1
+    xi, xa0, xa1 = axis(rw, W)
+    yi, yb0, yb1 = axis(rh, H)
+    src = frames_u8.astype(np.int64)
+    xn = np.minimum(xi + 1, W - 1)
+    S = src[:, :, :, xi, :] * xa0[None, None, None, :, None] + src[:, :, :, xn, :] * xa1[None, None, None, :, None]   # (b,t,H,rw,3)
+    yn = np.minimum(yi + 1, H - 1)
+    S0, S1 = S[:, :, yi], S[:, :, yn]
+    d = (((yb0[None, None, :, None, None] * (S0 >> 4)) >> 16) + ((yb1[None, None, :, None, None] * (S1 >> 4)) >> 16) + 2) >> 2
+    y1, x1 = int(round((rh - crop) / 2.0)), int(round((rw - crop) / 2.0))
+    d = d[:, :, y1:y1 + crop, x1:x1 + crop]
+    v = torch.from_numpy(d.astype(np.float32)) / 255                                   # ClipToTensor
+    v = v.permute(0, 4, 1, 2, 3)
+    mean = torch.tensor(MEAN).view(1, 3, 1, 1, 1)
+    std = torch.tensor(STD).view(1, 3, 1, 1, 1)
+    return ((v - mean) / std).contiguous()                                              # Normalize: sub then div

@@ -422,6 +422,24 @@ int k_ilaf_grad(const I2VIlafParams& p, i2v_stream_t) {
     return 0;
 }
 
+int k_clip_resize_crop(const uint8_t* frames, float* video, const int32_t* xtab, const int32_t* ytab, int b, int t, int H, int W,
+                       int cy, int cx, int oh, int ow, i2v_stream_t) {
+    for (int bi = 0; bi < b; ++bi) for (int ti = 0; ti < t; ++ti) for (int y = 0; y < oh; ++y) for (int x = 0; x < ow; ++x) {
+        const int32_t* xe = xtab + 3 * (x + cx); const int32_t* ye = ytab + 3 * (y + cy);
+        const int sx0 = xe[0], sx1 = std::min(sx0 + 1, W - 1), sy0 = ye[0], sy1 = std::min(sy0 + 1, H - 1);
+        const uint8_t* f = frames + ((size_t)bi * t + ti) * H * W * 3;
+        for (int c = 0; c < 3; ++c) {
+            const int S0 = f[((size_t)sy0 * W + sx0) * 3 + c] * xe[1] + f[((size_t)sy0 * W + sx1) * 3 + c] * xe[2];
+            const int S1 = f[((size_t)sy1 * W + sx0) * 3 + c] * xe[1] + f[((size_t)sy1 * W + sx1) * 3 + c] * xe[2];
+            const int d = (((ye[1] * (S0 >> 4)) >> 16) + ((ye[2] * (S1 >> 4)) >> 16) + 2) >> 2;
+            volatile float v = (float)d / 255.f;
+            volatile float u = v - MEAN[c];
+            video[((((size_t)bi * 3 + c) * t + ti) * oh + y) * ow + x] = u / STD[c];
+        }
+    }
+    return 0;
+}
+
 int k_clip_from_u8(const uint8_t* frames, float* video, int b, int t, int h, int w, i2v_stream_t) {
     size_t hw = (size_t)h * w;
     for (int bi = 0; bi < b; ++bi) for (int c = 0; c < 3; ++c) for (int ti = 0; ti < t; ++ti) for (size_t i = 0; i < hw; ++i) {

@@ -566,3 +566,19 @@ def test_rccl_exchange_paths_single_rank(eng):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_resize_crop_normalise_bit_exact(eng):
+    """N4 on the device: decoded uint8 frames -> Resize(256, cv2-style 8-bit bilinear) -> CenterCrop(224) -> /255 ->
+    Normalize -> (b,3,t,224,224) in ONE kernel (`i2v_clip_resize_crop_u8_f32`), bit for bit against the oracle's
+    restatement of the reference loader's validation transform (datasets.py:86-93), on a Kinetics-like 340x256 clip,
+    a portrait one and an already-sized one; and straight into an attack."""
+    for H, W, t in ((256, 340, 8), (360, 300, 2), (256, 256, 2), (224, 224, 1)):
+        fr = torch.randint(0, 256, (2, t, H, W, 3), generator=torch.Generator().manual_seed(H * W), dtype=torch.uint8)
+        got = eng.clip_resize_crop(fr.to("cuda:0")).cpu()
+        assert torch.equal(got, restate.resize_center_crop_normalise(fr.numpy()))
+    fr = torch.randint(0, 256, (1, 4, 100, 130, 3), generator=torch.Generator().manual_seed(3), dtype=torch.uint8)
+    vid = eng.clip_resize_crop(fr.to("cuda:0"), short_side=72, crop=64)
+    atk = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=3, step_size=0.005, steps=2, graph_builder=graphs.build_tiny, weight_seed=0)
+    adv = atk(vid, torch.zeros(1, dtype=torch.long), ["v"])
+    assert adv.shape == (1, 3, 4, 64, 64) and atk.last_costs[1] < atk.last_costs[0]

@@ -2,6 +2,7 @@
 classes, addend/mask fusion, arena) driven through the C ABI with the scalar host backend of
 tests/hostsim/, against the oracle.  The HIP kernels themselves are checked by the -m gpu tests."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -216,3 +217,49 @@ def test_clip_from_u8_matches_loader_tail():
     std = torch.tensor(gu.STD).view(1, 3, 1, 1, 1)
     ref = (u8.permute(0, 4, 1, 2, 3).float() / 255 - mean) / std
     assert torch.equal(got, ref)
+
+
+def test_resize_crop_normalise_matches_loader_transform():
+    """`Resize(256, bilinear) -> CenterCrop(224) -> ClipToTensor -> Normalize` (datasets.py:86-93) fused into
+    one kernel (host simulation here, HIP in test_gpu_parity.py) against the oracle's independent restatement of the
+    gluoncv / OpenCV arithmetic -- bit for bit (the resize is integer fixed point) -- on landscape, portrait, already-sized
+    and square frames; and, as the only pin available offline (cv2 and gluoncv are not installed: parity unpinned), against
+    PIL's bilinear resize on an UPscale, where PIL's filter has the same two-tap support: within 1.5/255."""
+    eng = hostsim_engine()
+    for H, W in ((240, 320), (360, 300), (256, 341), (288, 288), (224, 224)):
+        fr = torch.randint(0, 256, (2, 2, H, W, 3), generator=torch.Generator().manual_seed(H + W), dtype=torch.uint8)
+        got = eng.clip_resize_crop(fr)
+        assert got.shape == (2, 3, 2, 224, 224)
+        assert torch.equal(got, restate.resize_center_crop_normalise(fr.numpy()))
+    from PIL import Image
+    yy, xx = np.mgrid[0:240, 0:320]
+    img = np.stack([(yy + xx) % 256, (2 * yy) % 256, (3 * xx) % 256], -1).astype(np.uint8)
+    mine = restate.resize_center_crop_normalise(img[None, None])[0, :, 0].permute(1, 2, 0)
+    mine = (mine * torch.tensor(restate.STD) + torch.tensor(restate.MEAN)).numpy() * 255
+    pil = np.asarray(Image.fromarray(img).resize((341, 256), Image.BILINEAR)).astype(np.float32)
+    x1 = int(round((341 - 224) / 2.0))
+    wrap = np.abs(np.diff(img.astype(np.int32), axis=0, prepend=0)).max(-1) > 8         # the test pattern's modulo jumps
+    ok = ~np.asarray(Image.fromarray((wrap * 255).astype(np.uint8)).resize((341, 256), Image.BILINEAR))[16:240, x1:x1 + 224].astype(bool)
+    assert np.abs(pil[16:240, x1:x1 + 224] - mine)[ok].max() <= 1.5
+
+
+def test_image_main_takes_decoded_frames(tmp_path, monkeypatch):
+    """`--clip_dir` with `{label}-raw.npy` decoded uint8 clips: the CLI runs the loader's transform on the engine."""
+    from i2v_amd import attacks
+    eng = hostsim_engine()
+    monkeypatch.setitem(attacks._ENGINES, attacks.default_device(), eng)
+    monkeypatch.setattr(graphs, "build", graphs.build_tiny)
+    monkeypatch.setenv("I2V_OPT_PATH", str(tmp_path / "out"))
+    raw = tmp_path / "raw"
+    raw.mkdir()
+    for label in (4, 9):
+        np.save(raw / f"{label}-raw.npy", np.random.RandomState(label).randint(0, 256, (2, 80, 100, 3)).astype(np.uint8))
+    import importlib
+    import image_main
+    importlib.reload(image_main)
+    monkeypatch.setattr(eng, "clip_resize_crop", lambda fr, short_side=256, crop=224, _f=eng.clip_resize_crop: _f(fr, short_side=72, crop=crop))
+    image_main.main(["--attack_method", "ImageGuidedFMDirection_Adam", "--step", "1", "--depth", "2", "--direction_image_model", "resnet",
+                     "--clip_dir", str(raw), "--hw", "64", "--batch_size", "2", "--file_prefix", "raw"])
+    out = tmp_path / "out" / "Image-ImageGuidedFMDirection_Adam-1-raw"
+    assert sorted(f for f in os.listdir(out) if f.endswith(".npy")) == ["4-adv.npy", "9-adv.npy"]
+    assert np.load(out / "4-adv.npy").shape == (3, 2, 64, 64)
