@@ -14,10 +14,10 @@
 #include <string.h>
 #include <vector>
 
-struct Shape { int Cin, Cout, H, k; const char* what; };
+struct Shape { int Cin, Cout, H, k; const char* what; int stride = 1; };
 
 static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
-    const int Cin = sh.Cin, Cout = sh.Cout, H = sh.H, k = sh.k;
+    const int Cin = sh.Cin, Cout = sh.Cout, H = sh.H, k = sh.k, st = sh.stride, Ho = (H + 2 * (k / 2) - k) / st + 1;
     int pad = k / 2, K = k * k * Cin, Kpad = (K + I2V_KC - 1) / I2V_KC * I2V_KC, Cdpad = (Cout + 127) / 128 * 128;
     std::vector<float> wp((size_t)Kpad * Cdpad), src((size_t)N * Cin * H * H);
     std::vector<I2VKEntry> kt(Kpad, I2VKEntry{0, 0, 0, 0});
@@ -31,7 +31,7 @@ static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
         kt[kk] = I2VKEntry{c * H * H, r - pad, s - pad, 1};
     }
     float *dw, *ds, *dd, *da; I2VKEntry* dk;
-    const size_t outn = (size_t)N * Cout * H * H;
+    const size_t outn = (size_t)N * Cout * Ho * Ho;
     hipMalloc(&dw, wp.size() * 4); hipMalloc(&ds, src.size() * 4); hipMalloc(&dd, outn * 4); hipMalloc(&da, outn * 4);
     hipMalloc(&dk, kt.size() * sizeof(I2VKEntry));
     hipMemcpy(dw, wp.data(), wp.size() * 4, hipMemcpyHostToDevice);
@@ -42,13 +42,13 @@ static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
     p.src = ds; p.src_nstride = (int64_t)Cin * H * H; p.Hs = p.Ws = H; p.Cs = Cin;
     p.src_span_bytes = (int32_t)((int64_t)N * Cin * H * H * 4);
     p.wp = dw; p.ktab = dk; p.K = K; p.Kpad = Kpad; p.Cd = Cout; p.Cdpad = Cdpad;
-    p.N = N; p.Hg = p.Wg = H; p.sh = p.sw = 1;
-    p.dst = dd; p.dst_nstride = (int64_t)Cout * H * H; p.Ho = p.Wo = H; p.osh = p.osw = 1;
+    p.N = N; p.Hg = p.Wg = Ho; p.sh = p.sw = st;
+    p.dst = dd; p.dst_nstride = (int64_t)Cout * Ho * Ho; p.Ho = p.Wo = Ho; p.osh = p.osw = 1;
     p.add0_stride = 1; p.relu = 1;
     p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1;
     if (with_epi) { p.add0 = da; p.add0_nstride = p.dst_nstride; }      // residual-style addend (the expand convolutions)
-    p.pointwise = (k == 1 && (H * H) % 4 == 0 && !getenv("CMB_NOPW")); p.tap_uniform = tu;
-    p.vec_epilogue = ((H * H) % 4 == 0);
+    p.pointwise = (k == 1 && st == 1 && (H * H) % 4 == 0 && !getenv("CMB_NOPW")); p.tap_uniform = tu;
+    p.vec_epilogue = ((Ho * Ho) % 4 == 0);
     p.cfg = cfg + 1;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 2; ++i) k_conv(p, nullptr);
@@ -59,7 +59,7 @@ static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
     float ms; hipEventElapsedTime(&ms, a, b); ms /= iters;
     hipFree(dw); hipFree(ds); hipFree(dd); hipFree(da); hipFree(dk); hipEventDestroy(a); hipEventDestroy(b);
     if (be_error()) { printf("ERROR %s\n", be_error()); exit(1); }
-    return 2.0 * N * H * H * (double)Cout * K / ms * 1e-9;
+    return 2.0 * N * Ho * Ho * (double)Cout * K / ms * 1e-9;
 }
 
 int main(int argc, char** argv) {
@@ -74,7 +74,8 @@ int main(int argc, char** argv) {
         {256, 256, 14, 3, "layer3 3x3"}, {128, 128, 28, 3, "layer2 3x3"}, {64, 64, 56, 3, "layer1 3x3"},
         {256, 1024, 14, 1, "layer3 expand"}, {1024, 256, 14, 1, "layer3 reduce"}, {128, 512, 28, 1, "layer2 expand"},
         {512, 128, 28, 1, "layer2 reduce"}, {64, 256, 56, 1, "layer1 expand"}, {256, 64, 56, 1, "layer1 reduce"},
-        {512, 1024, 14, 1, "layer3 down(K512)"}, {256, 512, 28, 1, "layer2 down(K256)"}, {64, 64, 56, 1, "layer1 first"}};
+        {512, 1024, 14, 1, "layer3 down(K512)"}, {256, 512, 28, 1, "layer2 down(K256)"}, {64, 64, 56, 1, "layer1 first"},
+        {3, 64, 224, 7, "stem 7x7/2", 2}, {3, 64, 224, 3, "vgg first 3x3", 1}};
     static const char* CN[5] = {"128x128", "64x128", "128x64", "64x64", "32x256"};
     printf("%-20s %5s %5s %3s %2s |", "shape", "Cin", "Cout", "H", "k");
     for (int c = 0; c < 4; ++c) printf(" %8s", CN[c]);
