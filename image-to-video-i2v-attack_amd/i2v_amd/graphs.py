@@ -469,6 +469,39 @@ def slowfast_res2(width=64, in_thw=(32, 224, 224), arch="slowfast_resnet50", slo
     return g
 
 
+def tpn_resnet(layers=(3, 4, 6, 3), width=64, in_thw=(32, 224, 224), arch="tpn_resnet50") -> Graph:
+    """Backbone of TPN (Yang et al., "Temporal Pyramid Network") up to `layer2`, the module the reference hooks for
+    'tpn' models (`image_attacks.py:517-518`).  TPN's backbone is a SlowOnly-style 3-D ResNet: stem 1x7x7 / (1,2,2),
+    max-pool 1x3x3 / (1,2,2), and NO temporal convolution in `layer1` / `layer2` (the 3x1x1 inflation starts at
+    `layer3`) -- up to the hook it is a per-frame 2-D ResNet, i.e. frame-major image launches.  Keys: torchvision-style
+    `conv1 / bn1 / layer{i}.{b}.conv{1,2,3} / bn{1,2,3} / downsample.{0,1}` (parity with gluoncv's module layout
+    unpinned, like the other video graphs)."""
+    T, H, W = in_thw
+    g = Graph(arch, (H, W), video=True)
+    x = g.new_tensor(3, H, W, False, "input", T=T)
+    g.input = x
+    x = g.conv3d(x, width, (1, 7), (1, 2), (0, 3), "conv1.weight", bn="bn1", name="stem")
+    x = g.maxpool3d(x, (1, 3), (1, 2), (0, 1), name="maxpool")
+    inplanes = width
+    for li, nblocks in enumerate(layers[:2]):
+        planes = width * (2 ** li)
+        for b in range(nblocks):
+            stride = 2 if (b == 0 and li > 0) else 1
+            p = f"layer{li + 1}.{b}"
+            a = g.conv3d(x, planes, (1, 1), (1, 1), (0, 0), f"{p}.conv1.weight", bn=f"{p}.bn1", name=f"{p}.conv1")
+            a = g.conv3d(a, planes, (1, 3), (1, stride), (0, 1), f"{p}.conv2.weight", bn=f"{p}.bn2", name=f"{p}.conv2")
+            if stride != 1 or inplanes != planes * 4:
+                idt = g.conv3d(x, planes * 4, (1, 1), (1, stride), (0, 0), f"{p}.downsample.0.weight",
+                               bn=f"{p}.downsample.1", relu=False, name=f"{p}.downsample")
+            else:
+                idt = x
+            x = g.conv3d(a, planes * 4, (1, 1), (1, 1), (0, 0), f"{p}.conv3.weight", bn=f"{p}.bn3", residual=idt,
+                         name=f"{p}.out")
+            inplanes = planes * 4
+        g.hooks[li + 1] = x
+    return g
+
+
 def build_video(model_type: str, in_thw=(32, 224, 224)) -> Graph:
     """`model_type` follows `image_fine_tune_attack.py:53` / `utils.py:9-14`."""
     if model_type == "i3d_resnet50":
@@ -479,10 +512,16 @@ def build_video(model_type: str, in_thw=(32, 224, 224)) -> Graph:
         return slowfast_res2(64, in_thw, "slowfast_resnet50")
     if model_type == "slowfast_resnet101":          # res2 is identical for the 50- and 101-layer variants
         return slowfast_res2(64, in_thw, "slowfast_resnet101")
-    raise KeyError(f"video backbone {model_type!r} is not built (TPN and the non-local i3d_nl5 blocks are out of scope)")
+    if model_type == "tpn_resnet50":
+        return tpn_resnet((3, 4, 6, 3), 64, in_thw, "tpn_resnet50")
+    if model_type == "tpn_resnet101":          # layer1 / layer2 are the same for the 50- and 101-layer backbones
+        return tpn_resnet((3, 4, 23, 3), 64, in_thw, "tpn_resnet101")
+    raise KeyError(f"video backbone {model_type!r} is not built (the non-local i3d_nl5 blocks are out of scope)")
 
 
 def build_video_tiny(model_type: str, in_thw=(8, 32, 32)) -> Graph:
+    if "tpn" in model_type:
+        return tpn_resnet((2, 2, 1, 1), 8, in_thw, "tpn_tiny")
     if "i3d" in model_type:
         return i3d_resnet((2, 2, 1, 1), 8, in_thw, "i3d_tiny", inflate=((1, 1), (1, 0), (1,), (0,)))
     return slowfast_res2(16, in_thw, "slowfast_tiny", slow_stride=4, fast_stride=1, beta_inv=4, blocks=2)
@@ -491,7 +530,7 @@ def build_video_tiny(model_type: str, in_thw=(8, 32, 32)) -> Graph:
 def video_hooks(g: Graph, model_type: str) -> List[int]:
     """Hooked tensors (`image_attacks.py:513-519`).  ILAF's loss is a plain sum over the hooked layers, each paired
     with its own clean feature, so the order is immaterial."""
-    if "i3d" in model_type:
+    if "i3d" in model_type or "tpn" in model_type:          # res_layers['1'] / layer2: the second stage
         return [g.hooks[2]]
     return [g.hooks[1], g.hooks[2]]
 

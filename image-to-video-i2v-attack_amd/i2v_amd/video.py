@@ -15,7 +15,7 @@ from . import weights as _weights
 
 class VideoModel(object):
     """`model_type` as in `image_fine_tune_attack.py:53` ('i3d_resnet50', 'i3d_resnet101', 'slowfast_resnet50',
-    'slowfast_resnet101').  Weights: `state_dict` (graph key layout; `weights.convert_gluoncv_state_dict` maps a gluoncv
+    'slowfast_resnet101', 'tpn_resnet50', 'tpn_resnet101').  Weights: `state_dict` (graph key layout; `weights.convert_gluoncv_state_dict` maps a gluoncv
     checkpoint onto it), else `$I2V_WEIGHTS_DIR/<arch>.pth`, else -- only with an explicit `weight_seed` or
     `I2V_SYNTHETIC_WEIGHTS=1` -- the seeded synthetic initialiser (`weights.load_state_dict`)."""
 

@@ -49,7 +49,7 @@ def arg_parse(argv=None):
     parser.add_argument("--used_adv", type=str, default="", help="")
     parser.add_argument("--used_ori", type=str, default="", help="")
     parser.add_argument("--white_model", type=str, default="i3d_resnet101",
-                        help="i3d_resnet50 | i3d_resnet101 | slowfast_resnet50 | slowfast_resnet101")
+                        help="i3d_resnet50 | i3d_resnet101 | slowfast_resnet50 | slowfast_resnet101 | tpn_resnet50 | tpn_resnet101")
     parser.add_argument("--dataset", type=str, default="Kinetics-400", help="Kinetics-400 | UCF-101")
     # additions (not in the reference)
     parser.add_argument("--steps", type=int, default=60)

@@ -103,8 +103,31 @@ class SlowFastRes2(nn.Module):
         return sr, fr
 
 
+class TPNBackbone(nn.Module):
+    """SlowOnly-style backbone of TPN up to `layer2` (+ `layer3` so that something runs behind the hook): stem 1x7x7,
+    no temporal kernels in layer1 / layer2.  `model.layer2` is what the reference hooks (`image_attacks.py:517-518`)."""
+
+    def __init__(self, layers=(3, 4, 6, 3), width=64):
+        super().__init__()
+        self.conv1 = nn.Conv3d(3, width, (1, 7, 7), stride=(1, 2, 2), padding=(0, 3, 3), bias=False)
+        self.bn1 = nn.BatchNorm3d(width)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool3d((1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+        self.layer1, c = _stage(width, width, layers[0], 1, lambda b: 1)
+        self.layer2, c = _stage(c, width * 2, layers[1], 2, lambda b: 1)
+        self.layer3, c = _stage(c, width * 4, layers[2], 2, lambda b: 3)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        return self.layer3(self.layer2(self.layer1(x)))
+
+
 def make(model_type: str, tiny: bool) -> nn.Module:
     """Counterpart of `i2v_amd.graphs.build_video` / `build_video_tiny`."""
+    if "tpn" in model_type:
+        if tiny:
+            return TPNBackbone((2, 2, 1, 1), 8)
+        return TPNBackbone((3, 4, 23, 3) if "101" in model_type else (3, 4, 6, 3))
     if "i3d" in model_type:
         if tiny:
             return I3DResNet((2, 2, 1, 1), 8, inflate=((1, 1), (1, 0), (1,), (0,)))
@@ -128,6 +151,8 @@ def hook_modules(model: nn.Module, model_type: str):
     """The modules the reference hooks (`image_attacks.py:513-519`), fast before slow to match `graphs.video_hooks`."""
     if "i3d" in model_type:
         return [model.res_layers._modules["1"]]
+    if "tpn" in model_type:
+        return [model.layer2]
     return [model._modules["fast_res2"], model._modules["slow_res2"]]
 
 

@@ -81,14 +81,14 @@ def run_backbone(eng, model_type, thw, b, tiny, seed=1):
     return gx, ref
 
 
-@pytest.mark.parametrize("model_type,thw", [("i3d_resnet50", (8, 32, 32)), ("slowfast_resnet50", (8, 32, 32)),
+@pytest.mark.parametrize("model_type,thw", [("i3d_resnet50", (8, 32, 32)), ("slowfast_resnet50", (8, 32, 32)), ("tpn_resnet50", (4, 32, 32)),
                                             ("i3d_resnet50", (16, 24, 40)), ("slowfast_resnet50", (16, 40, 24))])
 def test_video_backbone_tiny(eng, model_type, thw):
     gx, ref = run_backbone(eng, model_type, thw, 2, True)
     assert (gx - ref).abs().max() <= 1e-4 * ref.abs().max()
 
 
-@pytest.mark.parametrize("model_type", ["i3d_resnet50", "slowfast_resnet50"])
+@pytest.mark.parametrize("model_type", ["i3d_resnet50", "slowfast_resnet50", "tpn_resnet50"])
 def test_video_backbone_full_size(eng, model_type):
     """One 32 x 224 x 224 clip through the real-width backbone to the hooked stage and back."""
     gx, ref = run_backbone(eng, model_type, (32, 224, 224), 1, False)

@@ -22,7 +22,7 @@ def capture(model, mods, x):
     return feats
 
 
-@pytest.mark.parametrize("model_type,thw", [("i3d_resnet50", (8, 32, 32)), ("slowfast_resnet50", (8, 32, 32)),
+@pytest.mark.parametrize("model_type,thw", [("i3d_resnet50", (8, 32, 32)), ("slowfast_resnet50", (8, 32, 32)), ("tpn_resnet50", (4, 32, 32)),
                                             ("i3d_resnet50", (16, 24, 40))])
 def test_video_backbone_forward_backward(model_type, thw):
     eng = hostsim_engine()

@@ -10,7 +10,7 @@ from oracle import restate, video_models as vm
 from tests import golden_util as gu
 from tests.hostsim_util import hostsim_engine
 
-FIX = ["ilaf_i3d_f64", "ilaf_i3d_f32", "ilaf_slowfast_f64"]
+FIX = ["ilaf_i3d_f64", "ilaf_i3d_f32", "ilaf_slowfast_f64", "ilaf_tpn_f64"]
 
 
 def load(name):
@@ -86,7 +86,7 @@ def test_native_first_step_follows_reference_gradient_sign(name):
 
 def test_video_model_errors():
     with pytest.raises(KeyError):
-        video.VideoModel("tpn_resnet50")
+        video.VideoModel("i3d_nl5_resnet50")
     m = video.VideoModel("i3d_resnet50", (8, 32, 32), tiny=True)
     assert m.cuda() is m and m.eval() is m
 
