@@ -43,7 +43,8 @@ def arg_parse(argv=None):
     for f in IGNORED_FLAGS:
         parser.add_argument(f, action="store_true", default=False, help="video_attacks.py switch (out of scope, ignored)")
     # additions (not in the reference)
-    parser.add_argument("--model_factory", type=str, default="reference:proxy")
+    parser.add_argument("--model_factory", type=str, default="reference:proxy",
+                        help="pkg.module:function (name -> torch classifier), or 'native' for the I3D graphs with a native classifier head")
     parser.add_argument("--num_classes", type=int, default=400)
     parser.add_argument("--anno", type=str, default=os.environ.get("I2V_ANNO", ""))
     parser.add_argument("--clip_dir", type=str, default="")
@@ -63,9 +64,13 @@ def main(argv=None):
     print(args)
     if args.attack_type != "image":
         raise NotImplementedError("--attack_type video drives video_attacks.py, which is outside this build's hot path")
-    mod, fn = args.model_factory.split(":")
     dev = torch.device(f"cuda:{os.environ['LOCAL_RANK']}" if torch.cuda.is_available() else "cpu")
-    model = getattr(importlib.import_module(mod), fn)(args.model).to(dev)
+    if args.model_factory == "native":        # graph IR + classifier head: the whole white-box gradient behind the C ABI
+        from i2v_amd.video import VideoModel
+        model = VideoModel(args.model, (args.frames, args.hw, args.hw), num_classes=args.num_classes)
+    else:
+        mod, fn = args.model_factory.split(":")
+        model = getattr(importlib.import_module(mod), fn)(args.model).to(dev)
     attack_method = getattr(base_attacks, args.attack_method)(model, steps=args.step)   # AttributeError for the default name, as in the reference (:22)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     total = clips.num_batches(args.batch_size, args.anno, args.clip_dir, args.num_clips)

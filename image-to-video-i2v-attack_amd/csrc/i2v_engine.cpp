@@ -1289,6 +1289,21 @@ extern "C" int i2v_ilaf_grad_f32(const float* a, int64_t a_stride, const float* 
     return 0;
 }
 
+extern "C" size_t i2v_head_scratch_bytes(int C, int clips) { return (size_t)2 * C * clips * sizeof(float) + 64; }
+
+extern "C" int i2v_head_ce_f32(const float* a, int64_t a_stride, int C, int HW, int T, int clips, const float* W, const float* bias,
+                               int K, const int32_t* labels, float scale, int mask_relu, int accumulate, float* logits, float* loss_each,
+                               float* grad, int64_t grad_stride, void* scratch, void* stream) {
+    if (!a || !W || !labels || !logits || !loss_each || !grad || !scratch || C <= 0 || HW <= 0 || T <= 0 || clips <= 0 || K <= 0)
+        return fail("i2v_head_ce_f32: bad argument");
+    I2VHeadParams p; memset(&p, 0, sizeof p);
+    p.a = a; p.a_nstride = a_stride; p.C = C; p.HW = HW; p.T = T; p.clips = clips; p.K = K; p.W = W; p.bias = bias; p.labels = labels;
+    p.scale = scale; p.pooled = (float*)scratch; p.dpooled = (float*)scratch + (size_t)C * clips; p.logits = logits; p.loss_each = loss_each;
+    p.grad = grad; p.grad_nstride = grad_stride; p.mask_relu = mask_relu; p.accumulate = accumulate;
+    CHECK_BE(k_head_ce(p, stream));
+    return 0;
+}
+
 extern "C" int i2v_aens_coeffs_f32(const float* prev, float* coeffs, float momentum, int L, void* stream) {
     if (!prev || !coeffs || L <= 0 || L > 64) return fail("i2v_aens_coeffs_f32: bad argument");
     CHECK_BE(k_aens_coeffs(prev, coeffs, momentum, L, stream));

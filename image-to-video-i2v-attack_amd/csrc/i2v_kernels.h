@@ -37,6 +37,7 @@ int k_std_reduce(const I2VStdParams& p, i2v_stream_t s);   // -> p.sums[0..1]
 int k_std_grad(const I2VStdParams& p, i2v_stream_t s);     // p.sums, p.total_count -> std_out, grad
 int k_ilaf_reduce(const I2VIlafParams& p, i2v_stream_t s); // -> p.sums[0..1]
 int k_ilaf_grad(const I2VIlafParams& p, i2v_stream_t s);   // p.sums, p.init_norm -> loss_out, grad
+int k_head_ce(const I2VHeadParams& p, i2v_stream_t s);
 int k_clip_from_u8(const uint8_t* frames, float* video, int b, int t, int h, int w, i2v_stream_t s);
 int k_clip_resize_crop(const uint8_t* frames, float* video, const int32_t* xtab, const int32_t* ytab, int b, int t, int H, int W,
                        int cy, int cx, int oh, int ow, i2v_stream_t s);

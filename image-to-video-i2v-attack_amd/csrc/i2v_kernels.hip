@@ -1197,6 +1197,96 @@ int k_ilaf_grad(const I2VIlafParams& p, i2v_stream_t s) {
 }
 
 // =============================================================================================
+// classifier head: global average pool -> Linear -> softmax cross-entropy and its gradient (I2VHeadParams)
+// =============================================================================================
+// grid (C, clips): mean over the clip's T frames and HW pixels of one channel (double accumulation, fixed tree)
+__global__ void __launch_bounds__(256) head_pool_kernel(const I2VHeadParams p) {
+    const int c = blockIdx.x, clip = blockIdx.y;
+    const int per = p.T * p.HW;
+    double s = 0;
+    for (int i = threadIdx.x; i < per; i += 256) {
+        const int t = i / p.HW, px = i - t * p.HW;
+        s += (double)p.a[((int64_t)clip * p.T + t) * p.a_nstride + (int64_t)c * p.HW + px];
+    }
+    __shared__ double red[4];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) p.pooled[(int64_t)clip * p.C + c] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)per);
+}
+
+// grid (clips): logits, softmax, loss, d loss / d pooled
+__global__ void __launch_bounds__(256) head_logits_kernel(const I2VHeadParams p) {
+    const int clip = blockIdx.x;
+    const float* x = p.pooled + (int64_t)clip * p.C;
+    float* lg = p.logits + (int64_t)clip * p.K;
+    for (int k = threadIdx.x; k < p.K; k += 256) {
+        double acc = p.bias ? (double)p.bias[k] : 0.0;
+        const float* w = p.W + (int64_t)k * p.C;
+        for (int c = 0; c < p.C; ++c) acc += (double)w[c] * (double)x[c];
+        lg[k] = (float)acc;
+    }
+    __syncthreads();
+    __shared__ double red[4]; __shared__ double mx_s, sum_s;
+    double mx = -1e300;
+    for (int k = threadIdx.x; k < p.K; k += 256) mx = fmax(mx, (double)lg[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) mx_s = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    __syncthreads();
+    double se = 0;
+    for (int k = threadIdx.x; k < p.K; k += 256) se += exp((double)lg[k] - mx_s);
+    se = wave_sum_d(se);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sum_s = (red[0] + red[1]) + (red[2] + red[3]);
+        const int lab = p.labels[clip];
+        p.loss_each[clip] = (float)(-((double)lg[lab] - mx_s - log(sum_s)));
+    }
+    __syncthreads();
+    // d(scale * mean_clips loss) / d pooled[c] = scale/clips * sum_k W[k][c] (softmax_k - [k == label])
+    const int lab = p.labels[clip];
+    const double f = (double)p.scale / (double)p.clips;
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+        double acc = 0;
+        for (int k = 0; k < p.K; ++k) {
+            const double pk = exp((double)lg[k] - mx_s) / sum_s - (k == lab ? 1.0 : 0.0);
+            acc += (double)p.W[(int64_t)k * p.C + c] * pk;
+        }
+        p.dpooled[(int64_t)clip * p.C + c] = (float)(f * acc / (double)(p.T * p.HW));
+    }
+}
+
+// grid (blocks, frames): the pooled gradient spread back over the frame's positions, gated by the feature's ReLU
+__global__ void __launch_bounds__(256) head_grad_kernel(const I2VHeadParams p) {
+    const int n = blockIdx.y, clip = n / p.T;
+    const int64_t D = (int64_t)p.C * p.HW;
+    const float* a = p.a + (int64_t)n * p.a_nstride;
+    float* g = p.grad + (int64_t)n * p.grad_nstride;
+    const float* dp = p.dpooled + (int64_t)clip * p.C;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < D; i += (int64_t)gridDim.x * 256) {
+        float v = dp[i / p.HW];
+        if (p.mask_relu && !(a[i] > 0.f)) v = 0.f;
+        g[i] = p.accumulate ? g[i] + v : v;
+    }
+}
+
+int k_head_ce(const I2VHeadParams& p, i2v_stream_t s) {
+    hipLaunchKernelGGL(head_pool_kernel, dim3(p.C, p.clips), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("head_pool");
+    hipLaunchKernelGGL(head_logits_kernel, dim3(p.clips), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("head_logits");
+    const int64_t D = (int64_t)p.C * p.HW;
+    int gblk = (int)((D + 2047) / 2048); if (gblk > 64) gblk = 64;
+    hipLaunchKernelGGL(head_grad_kernel, dim3(gblk, p.clips * p.T), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("head_grad");
+    return 0;
+}
+
+// =============================================================================================
 // frame flatten + un-normalise, compose, Adam (+ compose backward), sign steps, AENS weights
 // =============================================================================================
 // decoded uint8 frames (b, t, h, w, 3) -> normalised clip (b, 3, t, h, w): ClipToTensor (/255) + Normalize

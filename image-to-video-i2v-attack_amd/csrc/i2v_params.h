@@ -114,6 +114,24 @@ struct I2VIlafParams {
     int32_t mask_relu, accumulate;
 };
 
+// Classifier head of a white-box video model over its last feature map (frame-major: clips*T frames of (C, HW)):
+// global average pool over (T, H, W) -> Linear(C -> K) -> softmax cross-entropy against `labels`, mean over the clips
+// (attack.py:63-96 builds the gluoncv classifier, base_attacks.py:282-284 takes `CrossEntropyLoss()(model(adv), labels)`),
+// and d(scale * loss) / d(feature):  grad[n][c][p] = scale/clips * (W^T (softmax - onehot))[clip(n)][c] / (T*HW)
+struct I2VHeadParams {
+    const float* a;    int64_t a_nstride;     // feature view, frame stride; C*HW contiguous per frame
+    int32_t C, HW, T, clips, K;
+    const float* W;    const float* bias;     // [K][C], [K]
+    const int32_t* labels;                    // [clips]
+    float scale;                              // `_targeted` of base_attacks.py:229-231 (+1 / -1)
+    float* pooled;                            // [clips][C]      (scratch)
+    float* dpooled;                           // [clips][C]      (scratch)
+    float* logits;                            // [clips][K]      (output: the model's prediction)
+    float* loss_each;                         // [clips]         (-log softmax[label]; the host averages)
+    float* grad;       int64_t grad_nstride;
+    int32_t mask_relu, accumulate;
+};
+
 struct I2VStdParams {                          // Dispersion-Reduction loss: unbiased std of a tensor
     const float* a;    int64_t a_nstride; int64_t D; int32_t N;
     double* partial;   int32_t nblk;         // [N*nblk][2] (sum, sumsq)

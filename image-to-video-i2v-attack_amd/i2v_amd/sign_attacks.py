@@ -2,9 +2,10 @@
 (`image_attacks.py:498-629`).
 
 BIM / MI-FGSM / FGSM: the UPDATE RULE -- un-normalise, `+ step*sign(g)`, project to +-eps,
-clamp to [0,1], re-normalise -- is one fused HIP kernel (`i2v_sign_step_f32`); the attacked classifier is whatever
-differentiable torch module the caller passes, exactly as in the reference, and its cross-entropy gradient comes
-from PyTorch.
+clamp to [0,1], re-normalise -- is one fused HIP kernel (`i2v_sign_step_f32`).  The attacked classifier is either a
+`VideoModel(..., num_classes=K)` -- then the cross-entropy gradient is native too: 3-D backbone to its last stage,
+global-pool / fc / softmax-CE head (`i2v_head_ce_f32`), input gradient -- or, as in the reference, whatever
+differentiable torch module the caller passes, whose gradient then comes from PyTorch.
 
 ILAF (a18) has two paths.  Given an `i2v_amd.video.VideoModel` (I3D / SlowFast graph IR) the WHOLE loop runs in
 `libi2v_hip.so`: compose, 3-D forward to the hooked stage, ILAF loss + gradient, input gradient, masked sign step.
@@ -37,7 +38,14 @@ class _SignAttack(object):
         self.model = model
         self.model_name = str(model).split("(")[0]
         self.training = model.training
-        self.device = next(model.parameters()).device
+        if isinstance(model, VideoModel):     # native classifier: graph IR + head, everything behind the C ABI (`_grad_native`)
+            if model.num_classes is None:
+                raise ValueError("a VideoModel used as a classifier needs num_classes (its head)")
+            self._engine = engine or get_engine()
+            self.device = self._engine.device
+            self._net = self._net_key = None
+        else:
+            self.device = next(model.parameters()).device
         self._targeted = 1
         self._return_type = "float"
         self.mean, self.std = MEAN, STD
@@ -54,7 +62,38 @@ class _SignAttack(object):
         std = torch.as_tensor(self.std, dtype=videos.dtype, device=videos.device)[:, None, None, None]
         return videos.clone().detach().mul_(std).add_(mean)
 
+    def _grad_native(self, adv, labels):
+        """`autograd.grad(targeted * CrossEntropyLoss()(model(adv), labels), adv)` (base_attacks.py:282-286) without
+        autograd: frames -> 3-D backbone to its last stage -> pool / fc / softmax-CE head and its gradient -> input
+        gradient, all in libi2v_hip.so.  Returns the gradient in the clip layout (b,3,f,h,w)."""
+        eng, m = self.engine, self.model
+        b, c, f, h, w = adv.shape
+        N = b * f
+        key = (f, h, w)
+        if self._net is None or self._net_key != key or self._net.max_frames < N:
+            if self._net is not None:
+                self._net.close()
+            g = m.graph_for((f, h, w))
+            self._net = eng.build_net(g, m.state_dict_for(g), m.classifier_hook(g), N)
+            self._head = tuple(t.to(eng.device) if t is not None else None for t in m.head_weights(g))
+            self._net_key = key
+        net = self._net
+        kw = dict(dtype=torch.float32, device=eng.device)
+        x, u = torch.empty(N, 3, h, w, **kw), torch.empty(N, 3, h, w, **kw)
+        eng.frames_from_video(adv.detach().to(**kw).contiguous(), x, u)
+        net.forward(x)
+        W, bias = self._head
+        logits, loss_each = torch.empty(b, W.shape[0], **kw), torch.empty(b, **kw)
+        scratch = torch.empty(eng.capi.i2v_head_scratch_bytes(W.shape[1], b), dtype=torch.uint8, device=eng.device)
+        net.head_ce(0, W, bias, labels.to(eng.device).to(torch.int32).contiguous(), N, float(self._targeted), logits, loss_each, scratch)
+        gx = torch.empty_like(x)
+        net.backward(gx)
+        self.last_logits, self.last_loss = logits, loss_each.mean()
+        return gx.view(b, f, 3, h, w).permute(0, 2, 1, 3, 4).contiguous()
+
     def _grad(self, adv, labels):
+        if isinstance(self.model, VideoModel):
+            return self._grad_native(adv, labels)
         adv.requires_grad = True
         cost = self._targeted * nn.CrossEntropyLoss()(self.model(adv), labels)
         return torch.autograd.grad(cost, adv, retain_graph=False, create_graph=False)[0]

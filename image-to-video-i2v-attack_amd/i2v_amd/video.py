@@ -20,7 +20,13 @@ class VideoModel(object):
     `I2V_SYNTHETIC_WEIGHTS=1` -- the seeded synthetic initialiser (`weights.load_state_dict`)."""
 
     def __init__(self, model_type: str, in_thw=(32, 224, 224), weight_seed: Optional[int] = None, tiny: bool = False,
-                 state_dict: Optional[dict] = None):
+                 state_dict: Optional[dict] = None, num_classes: Optional[int] = None):
+        """`num_classes`: also carry the classifier head (global average pool -> `fc`), which makes the model usable as the
+        white-box CLASSIFIER of the BIM family (`attack.py:63-96`, `base_attacks.py:261-340`) with the whole cross-entropy
+        gradient computed natively.  Only graphs that reach their last stage have one (the I3D ResNets)."""
+        self.num_classes = num_classes
+        if num_classes is not None and "i3d" not in model_type:
+            raise KeyError(f"{model_type!r}: only the I3D graphs are built to their last stage; no native classifier head")
         self.model_type = model_type
         self.in_thw = tuple(in_thw)
         self.tiny = tiny
@@ -38,6 +44,30 @@ class VideoModel(object):
 
     def hook_tensors(self, graph):
         return _graphs.video_hooks(graph, self.model_type)
+
+    # ---- classifier head (num_classes given) ----
+    def classifier_hook(self, graph):
+        """The tensor the head reads: the output of the last stage."""
+        return [graph.hooks[max(graph.hooks)]]
+
+    def head_weights(self, graph):
+        """(fc.weight (K, C), fc.bias (K,)) -- from the state_dict (gluoncv names its head `fc` as torchvision does) or,
+        under the same opt-in rules as the backbone, seeded synthetic values."""
+        import torch
+        C_ = graph.tensors[self.classifier_hook(graph)[0]].C
+        sd = self._sd or {}
+        if "fc.weight" in sd:
+            w, b = sd["fc.weight"].float(), sd.get("fc.bias")
+            if tuple(w.shape) != (self.num_classes, C_):
+                raise ValueError(f"fc.weight has shape {tuple(w.shape)}, expected {(self.num_classes, C_)}")
+            return w.contiguous(), (b.float().contiguous() if b is not None else None)
+        if self._sd is not None:
+            raise KeyError("state_dict has no fc.weight for the classifier head")
+        if self.weight_seed is None and not _weights.synthetic_allowed():
+            raise _weights.MissingWeights(f"no classifier-head weights for {graph.arch!r} (see weights.load_state_dict)")
+        gen = torch.Generator().manual_seed(7919 * (self.weight_seed or 0) + 13)
+        return (torch.randn(self.num_classes, C_, generator=gen) * (1.0 / C_) ** 0.5).contiguous(), \
+            (torch.randn(self.num_classes, generator=gen) * 0.01).contiguous()
 
     # the reference calls these on the torch module (`image_fine_tune_attack.py:67`, base_attacks.py:227-229)
     def cuda(self, *a, **k):

@@ -210,6 +210,16 @@ int i2v_ilaf_reduce_f32(const float* a, int64_t a_stride, const float* ori, cons
 int i2v_ilaf_grad_f32(const float* a, int64_t a_stride, const float* ori, const float* adv0, int64_t D,
                       int frames, double init_norm, int mask_relu, int accumulate, float* loss_out,
                       float* grad, int64_t grad_stride, void* scratch, void* stream);
+/* Classifier head of a white-box video model and the cross-entropy gradient the BIM family starts from
+ * (`attack.py:63-96` builds the classifier, `base_attacks.py:282-284`: `cost = targeted * CrossEntropyLoss()(model(adv), labels)`):
+ * over the hooked LAST feature map (frame-major, clips*T frames of (C, HW)): global average pool over (T,H,W) ->
+ * Linear W[K][C] + bias -> softmax cross-entropy, mean over the clips; writes the logits (clips,K), the per-clip losses,
+ * and  grad (+)= scale * d(mean loss)/d(feature)  [gated by a>0 if mask_relu] into the hook's gradient view, from where
+ * `i2v_net_backward` takes it to the input.  scratch >= i2v_head_scratch_bytes(C, clips); W / bias / labels on the device. */
+size_t i2v_head_scratch_bytes(int C, int clips);
+int i2v_head_ce_f32(const float* a, int64_t a_stride, int C, int HW, int T, int clips, const float* W, const float* bias,
+                    int K, const int32_t* labels, float scale, int mask_relu, int accumulate, float* logits, float* loss_each,
+                    float* grad, int64_t grad_stride, void* scratch, void* stream);
 /* Adaptive ENS-I2V re-weighting `coeffs = softmax(softmax(prev) + momentum*coeffs)`
  * (TPAMI_attack.py:265), L <= 64, in place on device. */
 int i2v_aens_coeffs_f32(const float* prev, float* coeffs, float momentum, int L, void* stream);

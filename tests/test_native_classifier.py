@@ -1,0 +1,129 @@
+"""The white-box CLASSIFIER path of the BIM family with everything behind the C ABI (`attack.py:63-96`,
+`base_attacks.py:261-340`): `VideoModel(..., num_classes=K)` = I3D graph to its last stage + global-pool / fc head;
+`autograd.grad(CrossEntropyLoss()(model(adv), labels), adv)` becomes forward -> `i2v_head_ce_f32` -> input-gradient.
+Checked against torch autograd in float64 on the same weights (the plain-PyTorch I3D of oracle/video_models.py + pool + fc),
+on the host simulation here and on the HIP kernels in the `gpu`-marked twin."""
+import numpy as np
+import pytest
+import torch
+
+from i2v_amd import graphs, sign_attacks, video, weights
+from oracle import video_models as vm
+
+
+def torch_classifier(model_type, thw, seed, K):
+    g = graphs.build_video_tiny(model_type, thw)
+    sd = weights.synthetic_state_dict(g, seed)
+    m = video.VideoModel(model_type, thw, weight_seed=seed, tiny=True, num_classes=K)
+    W, b = m.head_weights(g)
+    back = vm.load_weights(vm.make(model_type, True), sd).double()
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.back = back
+            self.fc = torch.nn.Linear(W.shape[1], K).double()
+            with torch.no_grad():
+                self.fc.weight.copy_(W.double()); self.fc.bias.copy_(b.double())
+
+        def forward(self, x):
+            f = self.back(x.double())
+            return self.fc(f.mean(dim=(2, 3, 4)))
+    return m, Net().eval()
+
+
+def check_gradient(eng, dev):
+    thw, K, b = (8, 32, 32), 7, 2
+    m, ref = torch_classifier("i3d_resnet50", thw, 3, K)
+    gen = torch.Generator().manual_seed(11)
+    vid = torch.randn(b, 3, *thw, generator=gen)
+    labels = torch.tensor([2, 5])
+    atk = sign_attacks.BIM(m, steps=1, engine=eng)
+    g = atk._grad(vid.to(dev), labels).cpu().double()
+    x = vid.double().requires_grad_(True)
+    logits = ref(x)
+    loss = torch.nn.CrossEntropyLoss()(logits, labels)
+    gref = torch.autograd.grad(loss, x)[0]
+    np.testing.assert_allclose(atk.last_logits.cpu().double().numpy(), logits.detach().numpy(), rtol=1e-4, atol=1e-5)
+    assert abs(float(atk.last_loss) - float(loss.detach())) < 1e-5 * max(1.0, abs(float(loss)))
+    assert (g - gref).abs().max() <= 2e-4 * gref.abs().max(), float((g - gref).abs().max() / gref.abs().max())
+    # targeted attacks flip the sign of the cost (base_attacks.py:229-231, 282)
+    atk._targeted = -1
+    g2 = atk._grad(vid.to(dev), labels).cpu().double()
+    assert torch.equal(g2, -g)
+    return m, ref, vid, labels
+
+
+def check_attacks(eng, dev):
+    """FGSM / BIM / MI-FGSM with the native classifier against the same classes driving the float64 torch module (the
+    reference's calling convention): same update kernel on both sides, so the clips agree wherever the gradient's sign is
+    not decided in the last bits."""
+    thw, K = (32, 32, 32), 5         # norm_grads asserts 32 frames, like the reference (utils.py:58-67)
+    m, ref = torch_classifier("i3d_resnet50", thw, 4, K)
+    vid = torch.randn(1, 3, *thw, generator=torch.Generator().manual_seed(12)) * 0.5
+    labels = torch.tensor([1])
+
+    class F32(torch.nn.Module):          # the torch path wants float32 in / out
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, x):
+            return self.net(x).float()
+    for cls, kw in ((sign_attacks.FGSM, {}), (sign_attacks.BIM, dict(steps=3)), (sign_attacks.MIFGSM, dict(steps=3))):
+        a = cls(m, engine=eng, **kw)(vid.to(dev), labels).cpu()
+        r = cls(F32(ref), engine=eng, **kw)(vid.clone(), labels).cpu()
+        assert a.shape == vid.shape
+        agree = float(((a - r).abs() < 1e-5).float().mean())
+        assert agree > 0.97, (cls.__name__, agree)
+        un = a * torch.tensor(sign_attacks.STD).view(1, 3, 1, 1, 1) + torch.tensor(sign_attacks.MEAN).view(1, 3, 1, 1, 1)
+        assert un.min() >= -1e-5 and un.max() <= 1 + 1e-5
+
+
+def test_native_ce_gradient_hostsim():
+    from tests.hostsim_util import hostsim_engine
+    check_gradient(hostsim_engine(), "cpu")
+
+
+def test_native_sign_attacks_hostsim():
+    from tests.hostsim_util import hostsim_engine
+    check_attacks(hostsim_engine(), "cpu")
+
+
+def test_classifier_needs_a_full_graph():
+    with pytest.raises(KeyError):
+        video.VideoModel("slowfast_resnet50", num_classes=400)
+    with pytest.raises(ValueError):
+        from tests.hostsim_util import hostsim_engine
+        sign_attacks.BIM(video.VideoModel("i3d_resnet50", (8, 32, 32), weight_seed=0, tiny=True), engine=hostsim_engine())
+
+
+@pytest.mark.gpu
+def test_native_ce_gradient_gpu():
+    from i2v_amd import attacks
+    check_gradient(attacks.get_engine("cuda:0"), "cuda:0")
+
+
+@pytest.mark.gpu
+def test_native_sign_attacks_gpu():
+    from i2v_amd import attacks
+    check_attacks(attacks.get_engine("cuda:0"), "cuda:0")
+
+
+@pytest.mark.gpu
+def test_native_classifier_full_size_i3d_r50():
+    """One 32 x 224^2 clip through the whole I3D-ResNet-50 (all four stages) + 400-way head and back: finite, non-trivial
+    gradient, reproducible, and BIM moves the clip within its eps box."""
+    from i2v_amd import attacks
+    eng = attacks.get_engine("cuda:0")
+    m = video.VideoModel("i3d_resnet50", (32, 224, 224), weight_seed=0, num_classes=400)
+    vid = torch.randn(1, 3, 32, 224, 224, generator=torch.Generator().manual_seed(1)).clamp(-2, 2)
+    atk = sign_attacks.BIM(m, steps=2, engine=eng)
+    g = atk._grad(vid.to("cuda:0"), torch.tensor([7]))
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0 and atk.last_logits.shape == (1, 400)
+    assert torch.equal(g, atk._grad(vid.to("cuda:0"), torch.tensor([7])))
+    adv = atk(vid.to("cuda:0"), torch.tensor([7])).cpu()
+    std = torch.tensor(sign_attacks.STD).view(1, 3, 1, 1, 1)
+    un = adv * std + torch.tensor(sign_attacks.MEAN).view(1, 3, 1, 1, 1)
+    assert un.min() >= -1e-5 and un.max() <= 1 + 1e-5 and not torch.equal(adv, vid)
