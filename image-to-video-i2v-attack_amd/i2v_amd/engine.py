@@ -17,8 +17,13 @@ from .graphs import Graph
 from .weights import fold_affine, fold_pre_affine
 
 
+_DEVICE_TYPES = set()       # device types of the engines alive in this process ('cuda' for libi2v_hip.so)
+
+
 def _ptr(t: torch.Tensor):
     assert t.is_contiguous() and t.dtype == torch.float32, (t.dtype, t.is_contiguous())
+    if t.device.type not in _DEVICE_TYPES:      # a host pointer handed to a HIP kernel reads garbage or faults the GPU
+        raise _lib.I2VError(f"tensor on {t.device} passed to an engine on {sorted(_DEVICE_TYPES)}: move it to the engine's device")
     return C.c_void_p(t.data_ptr())
 
 
@@ -31,6 +36,7 @@ class Engine:
         self.capi = capi if capi is not None else _lib.load()
         if capi is None and self.device.type != "cuda":
             raise _lib.I2VError("the I2V engine needs a ROCm device; there is no CPU path")
+        _DEVICE_TYPES.add(self.device.type)
         self.h = C.c_void_p()
         self.plan_lock = threading.Lock()      # net creation / planning / destruction touch the handle's net table
         self.plan_ms, self.plans = 0.0, 0      # host wall time spent building nets (never inside a timed region of bench.py)

@@ -73,7 +73,7 @@ def check_attacks(eng, dev):
             return self.net(x).float()
     for cls, kw in ((sign_attacks.FGSM, {}), (sign_attacks.BIM, dict(steps=3)), (sign_attacks.MIFGSM, dict(steps=3))):
         a = cls(m, engine=eng, **kw)(vid.to(dev), labels).cpu()
-        r = cls(F32(ref), engine=eng, **kw)(vid.clone(), labels).cpu()
+        r = cls(F32(ref).to(dev), engine=eng, **kw)(vid.clone().to(dev), labels).cpu()     # the module lives where the engine does
         assert a.shape == vid.shape
         agree = float(((a - r).abs() < 1e-5).float().mean())
         assert agree > 0.97, (cls.__name__, agree)
