@@ -64,6 +64,16 @@ __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
 //   A: lane l holds Wp[k = kk + (l>>5)][cd = l&31]      B: lane l holds X[k = kk + (l>>5)][px = l&31]
 //   D: lane l, register r  ->  pixel l&31, channel (r&3) + 8*(r>>2) + 4*(l>>5)
 // so every global store instruction writes 32 consecutive pixels of one channel plane.
+// n / d for 0 <= n < 2^31 with the precomputed (m, s) of fastdiv_magic: exact
+__device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned m, unsigned s) {
+    return (unsigned)(((unsigned long long)n * m) >> s);
+}
+static void fastdiv_magic(unsigned d, uint32_t* m, uint32_t* s) {
+    // s = 31 + ceil(log2 d), m = floor(2^s / d) + 1 (< 2^32): floor(n*m / 2^s) == floor(n / d) for every n < 2^31
+    unsigned l = 0; while ((1ull << l) < d) ++l;
+    *s = 31 + l;
+    *m = (uint32_t)(((1ull << (31 + l)) / d) + 1);
+}
 // k-table row through the constant address space: stays a scalar (SMEM) load next to the LDS-DMA traffic;
 // an ordinary VGPR-destination load there would make hipcc drain vmcnt(0) inside the pipeline.
 typedef int i2v_v4i __attribute__((ext_vector_type(4)));
@@ -138,13 +148,13 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     const int bcol = PW ? (lane * 4) % BP : (BP >= 64 ? ((wave * 64) % BP) + lane : lane % BP);
     const int64_t ppix = px0 + bcol;
     const bool pvalid = ppix < P;
-    const int64_t pn = pvalid ? ppix / HWg : 0;
+    const int64_t pn = pvalid ? fastdiv((unsigned)ppix, p.dv_hw_m, p.dv_hw_s) : 0;        // P < 2^31 (checked by k_conv)
     const int prem = (int)(ppix - pn * HWg);
     const int HWs = p.Hs * p.Ws;
     int h0 = 0, w0 = 0, t0 = 0;
     int64_t pns = pn;                                         // source frame of this lane's pixel
     if (VID) {                                                // grid frame (clip, tg) reads source frames tg*st + dt
-        const int64_t clip = pn / p.Tg;
+        const int64_t clip = fastdiv((unsigned)pn, p.dv_t_m, p.dv_t_s);
         t0 = (int)(pn - clip * p.Tg) * p.st;
         pns = clip * p.Ts + t0;
     }
@@ -152,7 +162,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     unsigned xoff;                                            // byte offset of this lane's pixel in `src`
     if (PW) xoff = (unsigned)((pns * p.src_nstride + prem) * 4);
     else {
-        const int gi = prem / p.Wg, gj = prem - gi * p.Wg;
+        const int gi = (int)fastdiv((unsigned)prem, p.dv_w_m, p.dv_w_s), gj = prem - gi * p.Wg;
         h0 = gi * p.sh; w0 = gj * p.sw;
         xoff = (unsigned)((pns * p.src_nstride + (int64_t)h0 * p.Ws + w0) * 4);
     }
@@ -236,7 +246,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         const int e_c4 = t % E_C4, e_rbase = t / E_C4;
         const int64_t e_pp = px0 + (int64_t)e_c4 * 4;
         const bool e_ok = e_pp < P;
-        const int64_t e_n = e_ok ? e_pp / HWg : 0;
+        const int64_t e_n = e_ok ? fastdiv((unsigned)e_pp, p.dv_hw_m, p.dv_hw_s) : 0;
         const int64_t e_poff = e_pp - e_n * HWg;
         const int e_HoWo = p.Ho * p.Wo;
 #pragma unroll
@@ -402,7 +412,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         const int c4 = t % C4, rbase = t / C4;
         const int64_t pp = px0 + (int64_t)c4 * 4;
         const bool pok = pp < P;
-        const int64_t n = pok ? pp / HWg : 0;
+        const int64_t n = pok ? fastdiv((unsigned)pp, p.dv_hw_m, p.dv_hw_s) : 0;
         const int64_t poff = pp - n * HWg;
         float (*Cs)[BP] = reinterpret_cast<float (*)[BP]>(smem);
 #pragma unroll
@@ -443,7 +453,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
                         } else if (p.add0) {
                             // compact stride-2 addend (input-gradient of a 1x1/2 shortcut): defined at even
                             // (h, w) only; the 4 pixels start at a multiple of 4, so elements 0 and 2 receive
-                            const int oh = (int)(poff / p.Wo), ow = (int)(poff - (int64_t)oh * p.Wo);
+                            const int oh = (int)fastdiv((unsigned)poff, p.dv_wo_m, p.dv_wo_s), ow = (int)(poff - (int64_t)oh * p.Wo);
                             if (!(oh & 1) && (oh >> 1) < p.add0_H) {
                                 const float2 a = *reinterpret_cast<const float2*>(
                                     p.add0 + n * p.add0_nstride + (int64_t)cd * p.add0_H * p.add0_W + (oh >> 1) * p.add0_W + (ow >> 1));
@@ -497,10 +507,10 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         for (int j = 0; j < TP; ++j) {
             const int64_t pp = px0 + wpx * (BP / WP) + j * FR + l31;
             if (pp >= P) continue;
-            const int64_t ng = pp / HWg;
+            const int64_t ng = fastdiv((unsigned)pp, p.dv_hw_m, p.dv_hw_s);
             const int rem = (int)(pp - ng * HWg);
-            const int gi = rem / p.Wg, gj = rem - gi * p.Wg;
-            const int64_t clip = VID ? ng / p.Tg : ng;
+            const int gi = (int)fastdiv((unsigned)rem, p.dv_w_m, p.dv_w_s), gj = rem - gi * p.Wg;
+            const int64_t clip = VID ? fastdiv((unsigned)ng, p.dv_t_m, p.dv_t_s) : ng;
             const int otb = VID ? (int)(ng - clip * p.Tg) * p.ost + p.ot0 : 0;
 #pragma unroll
             for (int i = 0; i < TD; ++i)
@@ -529,14 +539,14 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
         // (no early `continue`s: when the launch emits gate words, every lane of the wave takes part in the ballots)
         const int64_t pp = px0 + wpx * (BP / WP) + j * FR + l31;
         const bool pin = pp < P;
-        const int64_t ng = pin ? pp / HWg : 0;
+        const int64_t ng = pin ? fastdiv((unsigned)pp, p.dv_hw_m, p.dv_hw_s) : 0;
         const int rem = (int)(pin ? pp - ng * HWg : 0);
-        const int gi = rem / p.Wg, gj = rem - gi * p.Wg;
+        const int gi = (int)fastdiv((unsigned)rem, p.dv_w_m, p.dv_w_s), gj = rem - gi * p.Wg;
         const int oh = gi * p.osh + p.oh0, ow = gj * p.osw + p.ow0;
         bool ok = pin && oh < p.Ho && ow < p.Wo;
         int64_t n = ng;                                          // destination frame
         if (VID) {
-            const int64_t clip = ng / p.Tg;
+            const int64_t clip = fastdiv((unsigned)ng, p.dv_t_m, p.dv_t_s);
             const int ot = (int)(ng - clip * p.Tg) * p.ost + p.ot0;
             if (ot >= p.To) ok = false;
             n = clip * p.To + ot;
@@ -688,8 +698,14 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
     return n;
 }
 
-int k_conv(const I2VConvParams& p, i2v_stream_t s) {
+int k_conv(const I2VConvParams& p_in, i2v_stream_t s) {
     hipStream_t st = (hipStream_t)s;
+    I2VConvParams p = p_in;
+    if ((int64_t)p.N * p.Hg * p.Wg + 1024 >= (1ll << 31)) { snprintf(g_be_err, sizeof g_be_err, "conv launch of more than 2^31 grid pixels"); g_be_has_err = true; return 1; }
+    fastdiv_magic((unsigned)(p.Hg * p.Wg), &p.dv_hw_m, &p.dv_hw_s);
+    fastdiv_magic((unsigned)p.Wg, &p.dv_w_m, &p.dv_w_s);
+    fastdiv_magic((unsigned)(p.Tg > 0 ? p.Tg : 1), &p.dv_t_m, &p.dv_t_s);
+    fastdiv_magic((unsigned)(p.Wo > 0 ? p.Wo : 1), &p.dv_wo_m, &p.dv_wo_s);
     switch (p.cfg > 0 ? ((p.cfg - 1) & 7) : conv_pick(p)) {
         case 0: return launch_conv_cfg<128, 128, 2, 2>(p, st);
         case 1: return launch_conv_cfg<64, 128, 2, 2>(p, st);

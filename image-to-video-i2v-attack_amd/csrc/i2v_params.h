@@ -65,6 +65,10 @@ struct I2VConvParams {
     // 1: output is dense over the pixel grid (osh=osw=1, Hg x Wg == Ho x Wo, plane % 4 == 0, every
     // plane 16-byte aligned, plain addends): the epilogue may use 16-byte accesses along W
     int32_t vec_epilogue;
+    // exact division of a pixel index (< 2^31) by Hg*Wg, Wg, Tg and Wo as multiply-high + shift: filled in by k_conv (the
+    // hardware has no integer divide; the 64-bit software divisions of round 1 cost a block more VALU issue slots than a
+    // K = 64 tile spends on its MFMAs)
+    uint32_t dv_hw_m, dv_hw_s, dv_w_m, dv_w_s, dv_t_m, dv_t_s, dv_wo_m, dv_wo_s;
     int32_t cfg;            // 0: pick the tile configuration with the cost model; c+1: use configuration c (autotuned; bit 3 of c = no epilogue-operand prefetch)
 };
 

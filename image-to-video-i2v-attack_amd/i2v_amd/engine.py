@@ -27,6 +27,12 @@ def _ptr(t: torch.Tensor):
     return C.c_void_p(t.data_ptr())
 
 
+def _hptr(t: torch.Tensor):
+    """HOST array handed to the description calls (`i2v_net_add_conv*` take host weights / scale / shift)."""
+    assert t.is_contiguous() and t.dtype == torch.float32 and t.device.type == "cpu", (t.dtype, t.device)
+    return C.c_void_p(t.data_ptr())
+
+
 class Engine:
     """One per (process, device) -- mirrors the reference's single `.cuda()` device
     (`image_attacks.py:103`).  `capi` is injected only by the planner unit tests."""
@@ -185,14 +191,14 @@ class Net:
         _lib.check(capi, capi.i2v_net_set_input(h, self.id, self.ten_id[g.input]))
         for nd in g.nodes:
             if nd.op == "conv":
-                w = sd[nd.weight].float().contiguous()
+                w = sd[nd.weight].float().cpu().contiguous()
                 scale, shift = fold_affine(nd, sd)
                 scale, shift = scale.contiguous(), shift.contiguous()
                 if g.video:
                     d = _lib.Conv3dDesc(self.ten_id[nd.src], self.ten_id[nd.dst], nd.cin, nd.cout, nd.kt, nd.kh, nd.kw,
                                         nd.stride_t, nd.stride, nd.pad_t, nd.pad, nd.dil_t, 1 if nd.relu else 0,
                                         -1 if nd.residual is None else self.ten_id[nd.residual])
-                    _lib.check(capi, capi.i2v_net_add_conv3d(h, self.id, C.byref(d), _ptr(w), _ptr(scale), _ptr(shift)))
+                    _lib.check(capi, capi.i2v_net_add_conv3d(h, self.id, C.byref(d), _hptr(w), _hptr(scale), _hptr(shift)))
                     continue
                 d = _lib.ConvDesc(self.ten_id[nd.src], self.ten_id[nd.dst], nd.cin, nd.cout, nd.kh, nd.kw,
                                   nd.stride, nd.pad, 1 if nd.relu else 0,
@@ -200,10 +206,10 @@ class Net:
                 if nd.pre_bn:
                     ps, pt = fold_pre_affine(nd, sd)
                     ps, pt = ps.contiguous(), pt.contiguous()
-                    _lib.check(capi, capi.i2v_net_add_conv_preact(h, self.id, C.byref(d), _ptr(w), _ptr(scale), _ptr(shift),
-                                                                  _ptr(ps), _ptr(pt)))
+                    _lib.check(capi, capi.i2v_net_add_conv_preact(h, self.id, C.byref(d), _hptr(w), _hptr(scale), _hptr(shift),
+                                                                  _hptr(ps), _hptr(pt)))
                 else:
-                    _lib.check(capi, capi.i2v_net_add_conv(h, self.id, C.byref(d), _ptr(w), _ptr(scale), _ptr(shift)))
+                    _lib.check(capi, capi.i2v_net_add_conv(h, self.id, C.byref(d), _hptr(w), _hptr(scale), _hptr(shift)))
             elif g.video:
                 d = _lib.Pool3dDesc(self.ten_id[nd.src], self.ten_id[nd.dst], nd.kt, nd.k, nd.stride_t, nd.stride, nd.pad_t, nd.pad)
                 _lib.check(capi, capi.i2v_net_add_maxpool3d(h, self.id, C.byref(d)))
