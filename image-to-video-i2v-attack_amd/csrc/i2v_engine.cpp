@@ -59,6 +59,7 @@ struct Packed {               // one implicit-GEMM operand set
     int ph = 0, pw = 0, Hg = 0, Wg = 0;
     int pt = 0, Tg = 1;       // temporal parity class / grid frames per clip (video networks)
     int has_dt = 0;           // some k-table row carries a temporal tap offset
+    int quad = 0, quad_kw = 0, quad_dw0 = 0;     // "quad rows" packing (I2VConvParams::quad): quads per row run, taps per run, first tap
 };
 
 struct Node {
@@ -98,6 +99,8 @@ struct Net {
     int Tin() const { return bufs[tens[input].buf].T; }     // frames per clip of the input
     size_t weight_bytes = 0;
     std::vector<float*> hook_tmp;  // per hook: separate gradient buffer when the hooked tensor is also consumed
+    size_t in_stage_off = 0; bool stage_input = false;   // quad-row stems read up to 64 bytes around a view: the caller's frames are
+                                                         // copied into the arena (slack on both sides) before the forward pass
 };
 
 }  // namespace
@@ -145,6 +148,32 @@ static int pack_fwd(Net& n, Node& nd) {
     Packed& P = nd.fwd;
     P.K = K; P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cout; P.Cdpad = (int)align_up(c.cout, 128);
     P.tap_uniform = (c.cin % I2V_KC == 0) ? 1 : 0;
+    // "Quad rows" for narrow stems (few input channels AND few output channels: SlowFast's fast pathway, 3 -> 8): such a launch
+    // spends its time ISSUING the 4-byte im2col DMA of the per-row path (one instruction per K row and 64 pixels; 17 TFLOP/s),
+    // not in the matrix pipe.  K rows ordered (channel, frame tap, row tap, column-tap quad x 4) put four ADJACENT source pixels
+    // in consecutive rows, which the kernel (MODE 4) stages with ONE 16-byte DMA per pixel: 1.6x on that launch
+    // (tools/conv_microbench.cpp "fast stem").  Wide stems (64 output channels) are bound elsewhere and measured no gain.
+    static const bool no_quad = [] { const char* e = getenv("I2V_QUAD"); return e && e[0] == '0'; }();
+    if (!no_quad && c.cin < I2V_KC && c.cout <= 32 && c.kw >= 2 && c.kw <= 8 && !nd.preact()) {
+        const int kwq = (c.kw + 3) / 4;
+        P.K = c.cin * c.kt * c.kh * kwq * 4; P.Kpad = (int)align_up(P.K, I2V_KC); P.tap_uniform = 0;
+        P.quad = kwq; P.quad_kw = c.kw; P.quad_dw0 = -c.pad;
+        std::vector<float> wq((size_t)P.Kpad * P.Cdpad, 0.f);
+        std::vector<I2VKEntry> kq(P.Kpad, I2VKEntry{0, 0, 0, 0});
+        for (int ci = 0; ci < c.cin; ++ci)
+            for (int q = 0; q < c.kt; ++q)
+                for (int r = 0; r < c.kh; ++r)
+                    for (int s4 = 0; s4 < kwq * 4; ++s4) {
+                        const int k = (((ci * c.kt + q) * c.kh + r) * kwq) * 4 + s4;
+                        kq[k] = I2VKEntry{ci * sb.H * sb.W, r - c.pad, s4 - c.pad, (s4 < c.kw ? 1 : 0) + 2 * (q * c.dil_t - c.pad_t)};
+                        if (s4 < c.kw)
+                            for (int co = 0; co < c.cout; ++co)
+                                wq[(size_t)k * P.Cdpad + co] = nd.w[((((size_t)co * c.cin + ci) * c.kt + q) * c.kh + r) * c.kw + s4];
+                    }
+        for (const I2VKEntry& e : kq) if (e.valid >> 1) P.has_dt = 1;
+        if (upload(n, wq, &P.wp)) return 1;
+        return upload(n, kq, &P.ktab);
+    }
     std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
     std::vector<I2VKEntry> kt(P.Kpad, I2VKEntry{0, 0, 0, 0});
     // K order: (16-channel chunk, tap, channel in chunk) when the channel count allows -- each 16-row chunk keeps a
@@ -247,9 +276,15 @@ static int pack_img(Net& n, Node& nd) {
             if (posmod(pw + c.pad - s, st) == 0) { int d = floordiv(pw + c.pad - s, st); dw_lo = d < dw_lo ? d : dw_lo; dw_hi = d > dw_hi ? d : dw_hi; }
     const int TT = dt_hi - dt_lo + 1, TH = dh_hi - dh_lo + 1, TW = dw_hi - dw_lo + 1;
     Packed& P = nd.img;
-    P.K = TT * TH * TW * c.cout; P.Kpad = (int)align_up(P.K, I2V_KC);
+    // few output channels (SlowFast's fast stem: 8) cannot use the tap-uniform path; instead of the per-row path they take the
+    // "quad rows" order (channel, frame tap, row tap, column-tap quad x 4): see pack_fwd
+    static const bool no_quad = [] { const char* e = getenv("I2V_QUAD"); return e && e[0] == '0'; }();
+    const bool quad = !no_quad && c.cout % I2V_KC != 0 && TW >= 2 && TW <= 8;
+    const int TWq = quad ? (TW + 3) / 4 * 4 : TW;               // column taps per run, padded to whole quads
+    P.K = TT * TH * TWq * c.cout; P.Kpad = (int)align_up(P.K, I2V_KC);
     P.Cd = Bt * B * B * c.cin; P.Cdpad = (int)align_up(P.Cd, 128);
-    P.tap_uniform = (c.cout % I2V_KC == 0) ? 1 : 0;
+    P.tap_uniform = (!quad && c.cout % I2V_KC == 0) ? 1 : 0;
+    if (quad) { P.quad = TWq / 4; P.quad_kw = TW; P.quad_dw0 = dw_lo; }
     P.Tg = sparse ? (sb.T - ct0 + stt - 1) / stt : (sb.T + Bt - 1) / Bt; P.Hg = (sb.H + B - 1) / B; P.Wg = (sb.W + B - 1) / B;
     nd.img_blk = B; nd.img_sh = m; nd.img_blkt = Bt; nd.img_ost = sparse ? stt : Bt; nd.img_ot0 = ct0;
     std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
@@ -257,16 +292,18 @@ static int pack_img(Net& n, Node& nd) {
     // K order = (16-channel chunk, tap, channel in chunk) when the channel count allows: every 16-row K chunk
     // still has ONE tap (MODE 2), and a block sweeps all taps of 16 channels before moving on, so the taps'
     // overlapping reads of `dz` are a few KB apart instead of a full 64-channel sweep apart (the co-resident
-    // blocks' halos then fit the L2).  Otherwise (tap, channel).
+    // blocks' halos then fit the L2).  Otherwise (tap, channel) -- or the quad-row order.
     const int NT = TT * TH * TW;
-    auto krow = [&](int tap, int co) {
+    auto krow = [&](int tt, int th, int tw, int co) {
+        if (quad) return (((co * TT + tt) * TH + th) * TWq) + tw;
+        const int tap = (tt * TH + th) * TW + tw;
         return P.tap_uniform ? ((co / I2V_KC) * NT + tap) * I2V_KC + co % I2V_KC : tap * c.cout + co;
     };
     for (int tt = 0; tt < TT; ++tt)
     for (int th = 0; th < TH; ++th)
-        for (int tw = 0; tw < TW; ++tw)
+        for (int tw = 0; tw < TWq; ++tw)
             for (int co = 0; co < c.cout; ++co)
-                kt[krow((tt * TH + th) * TW + tw, co)] = I2VKEntry{co * db.H * db.W, th + dh_lo, tw + dw_lo, 1 + 2 * (tt + dt_lo)};
+                kt[krow(tt, th, tw, co)] = I2VKEntry{co * db.H * db.W, th + dh_lo, tw + dw_lo, (tw < TW ? 1 : 0) + 2 * (tt + dt_lo)};
     for (int cc = 0; cc < Bt; ++cc)
     for (int q = 0; q < c.kt; ++q) {
         const int ct = ct0 + cc;
@@ -282,7 +319,7 @@ static int pack_img(Net& n, Node& nd) {
                         const int tw = floordiv(pw + c.pad - s, st) - dw_lo;
                         for (int co = 0; co < c.cout; ++co)
                             for (int ci = 0; ci < c.cin; ++ci)
-                                wp[(size_t)krow((tt * TH + th) * TW + tw, co) * P.Cdpad + ((cc * B + ph) * B + pw) * c.cin + ci] =
+                                wp[(size_t)krow(tt, th, tw, co) * P.Cdpad + ((cc * B + ph) * B + pw) * c.cin + ci] =
                                     nd.w[((((size_t)co * c.cin + ci) * c.kt + q) * c.kh + r) * c.kw + s];
                     }
                 }
@@ -485,6 +522,7 @@ static void conv_common(I2VConvParams& p, const Packed& P) {
     p.add0_stride = 1;
     p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1; p.ot0 = 0;
     p.temporal = P.has_dt;      // conv_run adds the frame-mapping half of the condition
+    p.quad = P.quad; p.quad_kw = P.quad_kw; p.quad_dw0 = P.quad_dw0;
 }
 
 static bool overlaps(const Tensor& a, const Tensor& b) {
@@ -692,6 +730,7 @@ struct Planner {
                                c.pad == 0 && (sb.H * sb.W) % 4 == 0 && c.src != n.input) ? 1 : 0;
                 if (nd.preact()) { p.pre_scale = nd.pre_scale_d; p.pre_shift = nd.pre_shift_d; }
                 if (c.relu) { int st = 0; if (uint32_t* g = gate_rows(c.dst, &st)) { p.gate_out = g; p.gate_out_stride = st; p.gate_out_pix0 = 0; } }
+                if (nd.fwd.quad) l.alg_flops_per_frame = 2.0 * d.H * d.W * c.cout * (double)c.cin * c.kt * c.kh * c.kw;
             } else {
                 const i2v_pool3d_desc& q = nd.pd;
                 const bool vid = q.kt != 1 || q.stride_t != 1 || q.pad_t != 0;
@@ -843,7 +882,13 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
         if (nd.cd.src == n.input) { if (pack_img(n, nd)) return 1; }
         else if (pack_bwd(n, nd)) return 1;
     }
-    size_t off = 0;
+    size_t off = 64;            // 256 bytes of slack in front of the first tensor (and behind the last, below): the quad-row
+                                // staging of conv_igemm (MODE 4) reads a few pixels past either end of a source view
+    for (const Node& nd : n.nodes) if (nd.type == 0 && nd.cd.src == n.input && nd.fwd.quad) n.stage_input = true;
+    if (n.stage_input) {        // ... which the caller's frame tensor cannot promise: forward() copies it in here first
+        const Buffer& ib = n.bufs[n.tens[n.input].buf];
+        n.in_stage_off = off; off = align_up(off + N * ib.C * ib.H * ib.W, 64) + 64;
+    }
     for (Buffer& b : n.bufs) {
         if (b.is_input) continue;
         size_t sz = N / Tin * b.T * b.C * b.H * b.W;
@@ -870,7 +915,7 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
         }
     Planner dry{n, true, off, N};
     if (!dry.run()) return fail("plan: %s", dry.err.c_str());
-    n.arena_floats = dry.off;
+    n.arena_floats = dry.off + 64;
     n.arena = (float*)be_malloc(n.arena_floats * sizeof(float));
     if (!n.arena) return fail("arena allocation of %zu bytes failed", n.arena_floats * sizeof(float));
     CHECK_BE(be_memset0(n.arena, n.arena_floats * sizeof(float), nullptr));
@@ -945,6 +990,7 @@ static int autotune(Net& n) {
     if (!scratch) return fail("autotune scratch allocation failed");
     CHECK_BE(be_memset0(scratch, 2 * img * sizeof(float), nullptr));
     void* e0 = be_event_create(); void* e1 = be_event_create();
+    const float* xin = n.stage_input ? n.arena + n.in_stage_off : scratch;      // quad-row stems need slack around their source
     int rc = 0;
     for (std::vector<Launch>* L : {&n.fwd, &n.bwd})
         for (Launch& l : *L) {
@@ -957,9 +1003,9 @@ static int autotune(Net& n) {
             float best = 1e30f; int best_c = -1;
             for (int ci = 0; ci < nc && !rc; ++ci) {
                 l.conv.cfg = cand[ci] + 1;
-                rc |= conv_run(l, lf, scratch, scratch + img, 0, nullptr);                  // warm-up
+                rc |= conv_run(l, lf, xin, scratch + img, 0, nullptr);                      // warm-up
                 be_event_record(e0, nullptr);
-                for (int r = 0; r < 2 && !rc; ++r) rc |= conv_run(l, lf, scratch, scratch + img, 0, nullptr);
+                for (int r = 0; r < 2 && !rc; ++r) rc |= conv_run(l, lf, xin, scratch + img, 0, nullptr);
                 be_event_record(e1, nullptr);
                 if (rc || be_stream_sync(nullptr)) { rc = 1; break; }
                 float ms = 0.f; be_event_elapsed_ms(e0, e1, &ms);
@@ -1000,7 +1046,8 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
     for (Launch& l : L) {
         const int frames = clips * l.T;                  // frames this launch iterates over
         double flops = 0.0;
-        if (l.kind == L_CONV) flops = 2.0 * frames * l.conv.Hg * l.conv.Wg * (double)l.conv.Cd * l.conv.K;
+        if (l.kind == L_CONV && l.alg_flops_per_frame > 0) flops = l.alg_flops_per_frame * frames;     // quad-row packings pad K
+        else if (l.kind == L_CONV) flops = 2.0 * frames * l.conv.Hg * l.conv.Wg * (double)l.conv.Cd * l.conv.K;
         else if (l.kind == L_IMGGRAD) flops = l.alg_flops_per_frame * frames;
         // timing kinds: 0 conv fwd, 1 image gradient, 2 pool fwd, 3 pool bwd, 4 addmask, 5 conv input-gradient
         const int tkind = (l.kind == L_CONV && backward_pass) ? 5 : (l.kind == L_AVGF || l.kind == L_POOL3F) ? 2
@@ -1066,6 +1113,13 @@ extern "C" int i2v_net_forward(i2v_handle h, int net, const float* x, int frames
     if (frames % n->Tin()) return fail("frames=%d is not a multiple of the input's %d frames per clip", frames, n->Tin());
     if (!x) return fail("null input");
     n->frames = frames;
+    if (n->stage_input) {
+        const Buffer& ib = n->bufs[n->tens[n->input].buf];
+        const size_t bytes = (size_t)frames * ib.C * ib.H * ib.W * sizeof(float);
+        float* staged = n->arena + n->in_stage_off;
+        CHECK_BE(be_d2d_2d(staged, bytes, x, bytes, bytes, 1, stream));
+        x = staged;
+    }
     return run_list(h, *n, n->fwd, frames, x, nullptr, 0, stream, false);
 }
 

@@ -88,6 +88,11 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 
 // MODE 0: per-row k-table gather (any geometry); 1: pointwise float4 (1x1, stride 1, planes 16-B aligned);
 // 2: tap-uniform chunks (every 16-row K chunk shares one spatial tap: channel count % 16 == 0)
+// 4: "quad rows" (I2VConvParams::quad): the 3-channel stems.  K rows come in groups of four adjacent taps (dw0 .. dw0+3) of one
+//    (channel, frame, row) tap: ONE 16-byte DMA per lane stages four K rows of its pixel -- the LDS image of a chunk is
+//    [quad][pixel][4] -- instead of four 4-byte pieces with a k-table row each (MODE 0 spent its time issuing DMA
+//    instructions: 17 TFLOP/s on SlowFast's 5x7x7 stem).  Elements whose tap falls outside the row, or beyond the kernel
+//    width (zero weights), hold a neighbour's pixel and are replaced by 0 when the fragment is read.
 // PREF (single-pass tiles only): the epilogue's addend / gate tiles are fetched into registers BEFORE the
 // K loop, so for the low-K, HBM-bound layers the read traffic overlaps the matrix work instead of following it.
 // PRE: the B operand is relu(x * pre_scale[k] + pre_shift[k]) (DenseNet norm->relu->1x1 conv), applied when the
@@ -128,6 +133,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     const int64_t P = (int64_t)p.N * HWg;
 
     constexpr bool PW = MODE == 1;
+    constexpr bool QUAD = MODE == 4;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     // ---- operand staging: global -> LDS by buffer DMA (`buffer_load ... lds`) -------------------------
     // No VGPR round trip and no ds_write.  A wave-instruction deposits 64 lanes x {16,4} bytes at a
@@ -141,9 +147,13 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     const int wv = __builtin_amdgcn_readfirstlane(wave);      // scalar copy: LDS bases / M0 stay in SGPRs
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.wp, 0, p.Kpad * p.Cdpad * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_span_bytes, 0x00020000);
+    // MODE 4 reads up to 3 pixels before / 6 behind a row (masked afterwards): the resource starts 64 bytes early and ends 64
+    // late -- a lane whose 16 bytes START out of range is zero-filled as a whole, its in-range pixels included -- and every
+    // offset carries +64 (the executor keeps that slack around the staged input: Net::in_stage)
+    constexpr unsigned XB = QUAD ? 64u : 0u;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src - XB), 0, p.src_span_bytes + 2 * XB, 0x00020000);
     constexpr int NA = KC * BD / 256, NAQ = (NA + 3) / 4;     // weights: instructions of 256 floats
-    constexpr int BPER = PW ? 256 : 64;                       // activations: 16-byte or 4-byte pieces
+    constexpr int BPER = (PW || QUAD) ? 256 : 64;             // activations: 16-byte or 4-byte pieces (floats per instruction)
     constexpr int NB = KC * BP / BPER, NBQ = (NB + 3) / 4;
     const int bcol = PW ? (lane * 4) % BP : (BP >= 64 ? ((wave * 64) % BP) + lane : lane % BP);
     const int64_t ppix = px0 + bcol;
@@ -164,7 +174,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     else {
         const int gi = (int)fastdiv((unsigned)prem, p.dv_w_m, p.dv_w_s), gj = prem - gi * p.Wg;
         h0 = gi * p.sh; w0 = gj * p.sw;
-        xoff = (unsigned)((pns * p.src_nstride + (int64_t)h0 * p.Ws + w0) * 4);
+        xoff = (unsigned)((pns * p.src_nstride + (int64_t)h0 * p.Ws + w0) * 4) + XB;
     }
     if (!pvalid) xoff = OOB;
     unsigned aoff[NAQ];
@@ -214,6 +224,14 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
                         v = (k0 + ((wave + 4 * q) * 256 + lane * 4) / BP < p.K) ? v : OOB;                \
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 256), 16, X_HOT(v),  \
                                                              X_HOTS(k0 * HWs * 4), 0, 0);                 \
+                } else if constexpr (QUAD) {                                                              \
+                    /* piece = quad (ins*64)/BP of the chunk x 64 pixels; its first row's k-table entry gives   \
+                       channel plane, row / frame tap and dw0; the row run's quads alternate (quad = 1 or 2) */ \
+                    const I2VKEntry e = load_kentry(p.ktab, k0 + 4 * ((ins * 64) / BP));                  \
+                    const int hs = h0 + e.dh, dtk = VID ? (e.valid >> 1) : 0;                             \
+                    const bool ok = pvalid && (unsigned)hs < (unsigned)p.Hs && (!VID || (unsigned)(t0 + dtk) < (unsigned)p.Ts); \
+                    const unsigned v = ok ? xoff + (unsigned)((e.chan_off + dtk * nstr + e.dh * p.Ws + e.dw) * 4) : OOB; \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 256), 16, v, 0, 0, 0); \
                 } else if constexpr (MODE == 2) {                                                         \
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 64), 4, X_HOT(vb_), \
                                                              X_HOTS(((ins * 64) / BP) * HWs * 4), 0, 0);  \
@@ -292,6 +310,26 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
     constexpr int KS = KC / KR;                                         // k-steps per chunk
     constexpr int PPS = (NL + KS - 1) / KS;                             // DMA pieces issued behind each k-step
     I2VKEntry e_next = I2VKEntry{0, 0, 0, 0};
+    // MODE 4: which of this lane's B-fragment elements are real taps.  Element e of run-quad qi is dw = quad_dw0 + 4 qi + e; it
+    // counts if it lies inside the kernel (4 qi + e < quad_kw) and inside the row.  16x16x4: a lane's element is lk, k-step s
+    // is quad s of the chunk; 32x32x2: k-step s is half (s & 1) of quad s >> 1, element 2 (s & 1) + lk.  A chunk holds 4
+    // quads and the run length (1 or 2) divides 4, so run-quad = quad & (p.quad - 1): the masks do not depend on the chunk.
+    bool qok[QUAD ? TP : 1][2][MF16 ? 1 : 2];
+    if constexpr (QUAD) {
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int64_t fp = px0 + wpx * (BP / WP) + j * FR + l31;
+            const unsigned fr = fp < P ? (unsigned)fp - fastdiv((unsigned)fp, p.dv_hw_m, p.dv_hw_s) * (unsigned)HWg : 0u;
+            const int fj = (int)(fr - fastdiv(fr, p.dv_w_m, p.dv_w_s) * (unsigned)p.Wg);
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+                for (int hf = 0; hf < (MF16 ? 1 : 2); ++hf) {
+                    const int el = MF16 ? lk : 2 * hf + lk;
+                    qok[j][qi][hf] = 4 * qi + el < p.quad_kw && (unsigned)(fj * p.sw + p.quad_dw0 + 4 * qi + el) < (unsigned)p.Ws;
+                }
+        }
+    }
     {   // prologue: chunk 0 (and the k-table row of chunk 1)
         unsigned vb0 = OOB;
         if constexpr (MODE == 2) {
@@ -349,8 +387,20 @@ __global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const i
 #pragma unroll
             for (int i = 0; i < TD; ++i) fa[set][i] = As[buf][KR * s + lk][wd * (BD / WD) + i * FR + l31];
 #endif
+            if constexpr (QUAD) {       // [quad][pixel][4] image: 16x16x4 reads element lk of quad s, 32x32x2 element 2(s&1)+lk of quad s>>1
+                const float* const bq = &Bs[buf][0][0];
 #pragma unroll
-            for (int j = 0; j < TP; ++j) fb[set][j] = Bs[buf][KR * s + lk][wpx * (BP / WP) + j * FR + l31];
+                for (int j = 0; j < TP; ++j) {
+                    const int px = wpx * (BP / WP) + j * FR + l31;
+                    const int qd = MF16 ? s : (s >> 1), el = MF16 ? lk : 2 * (s & 1) + lk;
+                    const float v = bq[(qd * BP + px) * 4 + el];
+                    const bool m = ((qd & 1) && p.quad == 2) ? qok[j][1][MF16 ? 0 : (s & 1)] : qok[j][0][MF16 ? 0 : (s & 1)];
+                    fb[set][j] = m ? v : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TP; ++j) fb[set][j] = Bs[buf][KR * s + lk][wpx * (BP / WP) + j * FR + l31];
+            }
         };
         read_frags(0, 0);
 #ifdef X_PRIO
@@ -618,6 +668,13 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     const int64_t grid = n_px * n_cd;
     if (grid <= 0) return 0;
     if (grid > 0x7fffffff) { snprintf(g_be_err, sizeof g_be_err, "conv grid too large"); g_be_has_err = true; return 1; }
+    if (p.quad) {           // "quad rows" stems (MODE 4)
+        if (p.pre_scale || (p.quad != 1 && p.quad != 2)) { snprintf(g_be_err, sizeof g_be_err, "bad quad-row launch"); g_be_has_err = true; return 1; }
+        if (p.temporal) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 4, false, false, true, MF16>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+        else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 4, false, false, false, MF16>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+        LAUNCH_CHECK("conv_igemm");
+        return 0;
+    }
     if constexpr (MF16) {
         if (p.pre_scale) { snprintf(g_be_err, sizeof g_be_err, "pre-activation convolutions have no 16-row variant"); g_be_has_err = true; return 1; }
         if (p.pointwise) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 1, false, false, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);

@@ -65,6 +65,12 @@ struct I2VConvParams {
     // 1: output is dense over the pixel grid (osh=osw=1, Hg x Wg == Ho x Wo, plane % 4 == 0, every
     // plane 16-byte aligned, plain addends): the epilogue may use 16-byte accesses along W
     int32_t vec_epilogue;
+    // quad > 0: "quad rows" packing of a few-channel stem (kernel MODE 4): K rows come in groups of four that share channel,
+    // frame and row tap and differ by dw = dw0 .. dw0+3 -- four ADJACENT source pixels -- so one 16-byte DMA per lane stages
+    // four K rows of a pixel ([quad][pixel][4] LDS image) instead of four 4-byte pieces; quad = quads per row run
+    // (ceil(kw / 4), 1 or 2), quad_kw = kw (rows with dw0 + e beyond the kernel have zero weights and are masked), the tap of
+    // element e of run-quad qi is dw = quad_dw0 + 4 qi + e.  The source view needs 64 readable bytes on either side.
+    int32_t quad, quad_kw, quad_dw0;
     // exact division of a pixel index (< 2^31) by Hg*Wg, Wg, Tg and Wo as multiply-high + shift: filled in by k_conv (the
     // hardware has no integer divide; the 64-bit software divisions of round 1 cost a block more VALU issue slots than a
     // K = 64 tile spends on its MFMAs)

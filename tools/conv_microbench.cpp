@@ -18,13 +18,24 @@ struct Shape { int Cin, Cout, H, k; const char* what; int stride = 1; };
 
 static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
     const int Cin = sh.Cin, Cout = sh.Cout, H = sh.H, k = sh.k, st = sh.stride, Ho = (H + 2 * (k / 2) - k) / st + 1;
-    int pad = k / 2, K = k * k * Cin, Kpad = (K + I2V_KC - 1) / I2V_KC * I2V_KC, Cdpad = (Cout + 127) / 128 * 128;
+    int pad = k / 2; int K = k * k * Cin, Kpad = (K + I2V_KC - 1) / I2V_KC * I2V_KC, Cdpad = (Cout + 127) / 128 * 128;
     std::vector<float> wp((size_t)Kpad * Cdpad), src((size_t)N * Cin * H * H);
     std::vector<I2VKEntry> kt(Kpad, I2VKEntry{0, 0, 0, 0});
     for (auto& v : wp) v = (rand() % 2001 - 1000) * 1e-4f;
     for (auto& v : src) v = (rand() % 2001 - 1000) * 1e-3f;
     const bool tu = Cin % I2V_KC == 0;
     const int NT = k * k;
+    const bool quad = Cin < 16 && k >= 2 && k <= 8 && !getenv("CMB_NOQUAD");     // stems: rows (c, r, s-quad x 4)
+    const int kwq = (k + 3) / 4;
+    if (quad) {
+        K = Cin * k * kwq * 4; Kpad = (K + I2V_KC - 1) / I2V_KC * I2V_KC;
+        wp.assign((size_t)Kpad * Cdpad, 0.f); kt.assign(Kpad, I2VKEntry{0, 0, 0, 0});
+        for (int c = 0; c < Cin; ++c) for (int r = 0; r < k; ++r) for (int sq = 0; sq < kwq; ++sq) for (int e = 0; e < 4; ++e) {
+            const int s2 = sq * 4 + e, kk = ((c * k + r) * kwq + sq) * 4 + e;
+            kt[kk] = I2VKEntry{c * H * H, r - pad, s2 - pad, s2 < k ? 1 : 0};
+            if (s2 < k) for (int co = 0; co < Cout; ++co) wp[(size_t)kk * Cdpad + co] = (rand() % 2001 - 1000) * 1e-4f;
+        }
+    } else
     for (int r = 0; r < k; ++r) for (int s = 0; s < k; ++s) for (int c = 0; c < Cin; ++c) {
         const int tap = r * k + s;
         const int kk = tu ? ((c / I2V_KC) * NT + tap) * I2V_KC + c % I2V_KC : tap * Cin + c;
@@ -32,7 +43,7 @@ static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
     }
     float *dw, *ds, *dd, *da; I2VKEntry* dk;
     const size_t outn = (size_t)N * Cout * Ho * Ho;
-    hipMalloc(&dw, wp.size() * 4); hipMalloc(&ds, src.size() * 4); hipMalloc(&dd, outn * 4); hipMalloc(&da, outn * 4);
+    hipMalloc(&dw, wp.size() * 4); hipMalloc(&ds, src.size() * 4 + 1024); ds += 64;      /* slack around the source for the quad-row staging */ hipMalloc(&dd, outn * 4); hipMalloc(&da, outn * 4);
     hipMalloc(&dk, kt.size() * sizeof(I2VKEntry));
     hipMemcpy(dw, wp.data(), wp.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(ds, src.data(), src.size() * 4, hipMemcpyHostToDevice);
@@ -42,11 +53,13 @@ static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
     p.src = ds; p.src_nstride = (int64_t)Cin * H * H; p.Hs = p.Ws = H; p.Cs = Cin;
     p.src_span_bytes = (int32_t)((int64_t)N * Cin * H * H * 4);
     p.wp = dw; p.ktab = dk; p.K = K; p.Kpad = Kpad; p.Cd = Cout; p.Cdpad = Cdpad;
+    if (quad) { p.quad = kwq; p.quad_kw = k; p.quad_dw0 = -pad; }
     p.N = N; p.Hg = p.Wg = Ho; p.sh = p.sw = st;
     p.dst = dd; p.dst_nstride = (int64_t)Cout * Ho * Ho; p.Ho = p.Wo = Ho; p.osh = p.osw = 1;
     p.add0_stride = 1; p.relu = 1;
     p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1;
     if (with_epi) { p.add0 = da; p.add0_nstride = p.dst_nstride; }      // residual-style addend (the expand convolutions)
+    p.tap_uniform = tu;
     p.pointwise = (k == 1 && st == 1 && (H * H) % 4 == 0 && !getenv("CMB_NOPW")); p.tap_uniform = tu;
     p.vec_epilogue = ((Ho * Ho) % 4 == 0);
     p.cfg = cfg + 1;
@@ -57,9 +70,9 @@ static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
     for (int i = 0; i < iters; ++i) k_conv(p, nullptr);
     hipEventRecord(b, nullptr); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b); ms /= iters;
-    hipFree(dw); hipFree(ds); hipFree(dd); hipFree(da); hipFree(dk); hipEventDestroy(a); hipEventDestroy(b);
+    hipFree(dw); hipFree(ds - 64); hipFree(dd); hipFree(da); hipFree(dk); hipEventDestroy(a); hipEventDestroy(b);
     if (be_error()) { printf("ERROR %s\n", be_error()); exit(1); }
-    return 2.0 * N * Ho * Ho * (double)Cout * K / ms * 1e-9;
+    return 2.0 * N * Ho * Ho * (double)Cout * (k * k * Cin) / ms * 1e-9;      // algorithmic flops (not the padded quad rows)
 }
 
 int main(int argc, char** argv) {
@@ -75,7 +88,8 @@ int main(int argc, char** argv) {
         {256, 1024, 14, 1, "layer3 expand"}, {1024, 256, 14, 1, "layer3 reduce"}, {128, 512, 28, 1, "layer2 expand"},
         {512, 128, 28, 1, "layer2 reduce"}, {64, 256, 56, 1, "layer1 expand"}, {256, 64, 56, 1, "layer1 reduce"},
         {512, 1024, 14, 1, "layer3 down(K512)"}, {256, 512, 28, 1, "layer2 down(K256)"}, {64, 64, 56, 1, "layer1 first"},
-        {3, 64, 224, 7, "stem 7x7/2", 2}, {3, 64, 224, 3, "vgg first 3x3", 1}};
+        {3, 64, 224, 7, "stem 7x7/2", 2}, {3, 64, 224, 3, "vgg first 3x3", 1},
+        {15, 8, 224, 7, "fast stem 5x7x7 (as 15 ch)", 2}};
     static const char* CN[5] = {"128x128", "64x128", "128x64", "64x64", "32x256"};
     printf("%-20s %5s %5s %3s %2s |", "shape", "Cin", "Cout", "H", "k");
     for (int c = 0; c < 4; ++c) printf(" %8s", CN[c]);
@@ -87,7 +101,8 @@ int main(int argc, char** argv) {
             if (sh.Cout <= BD / 2) { printf(" %8s", "-"); continue; }
             printf(" %8.1f", run(N, sh, c, iters, 0));
         }
-        printf(" | %8.1f\n", run(N, sh, 3, iters, 1));
+        if (sh.Cout <= 16) printf(" | cfg5(16x256 MF16) %8.1f\n", run(N, sh, 5, iters, 0));
+        else printf(" | %8.1f\n", run(N, sh, 3, iters, 1));
         fflush(stdout);
     }
     return 0;
