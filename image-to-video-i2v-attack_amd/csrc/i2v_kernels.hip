@@ -101,8 +101,17 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 // image launches -- and the spatial / pointwise convolutions of video networks -- compile without any of it.
 // MF16: 16x16x4 MFMA fragments instead of 32x32x2 (same peak rate): for launches with <= 16 output rows -- the
 // class-packed image gradient (12 rows), 8/16-channel layers -- a 32-row tile would be mostly padding.
+// Residency: the 64x64 tile (one wave per SIMD per block) is compiled for 7 waves per SIMD -- 72 unified VGPRs and, which
+// the register allocator then also honours, <= 96 SGPRs (MI355X_MICROARCH.md "Residency": 98+ SGPRs admit only 6 blocks of
+// 256 threads per CU).  The launches that matter have 1568*k tiles = 6.125*k per CU: at 6 resident blocks the last 32
+// tiles wait for a second round.
+#ifndef I2V_WPE_OFF
+#define I2V_CONV_WPE __attribute__((amdgpu_waves_per_eu((BD == 64 && BP == 64 && !PREF) ? 7 : 1, (BD == 64 && BP == 64 && !PREF) ? 7 : 8)))
+#else
+#define I2V_CONV_WPE
+#endif
 template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false>
-__global__ void __launch_bounds__(256) conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
+__global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-resource types and LDS-DMA builtins exist only in the device pass
     constexpr int KC = I2V_KC;
     constexpr int FR = MF16 ? 16 : 32;                       // fragment edge
