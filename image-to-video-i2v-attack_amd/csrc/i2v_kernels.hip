@@ -106,7 +106,10 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 // 256 threads per CU).  The launches that matter have 1568*k tiles = 6.125*k per CU: at 6 resident blocks the last 32
 // tiles wait for a second round.
 #ifndef I2V_WPE_OFF
-#define I2V_CONV_WPE __attribute__((amdgpu_waves_per_eu((BD == 64 && BP == 64 && !PREF) ? 7 : 1, (BD == 64 && BP == 64 && !PREF) ? 7 : 8)))
+#ifndef I2V_PREF_WPE
+#define I2V_PREF_WPE 6
+#endif
+#define I2V_CONV_WPE __attribute__((amdgpu_waves_per_eu((BD == 64 && BP == 64) ? (PREF ? I2V_PREF_WPE : 7) : 1, (BD == 64 && BP == 64) ? (PREF ? I2V_PREF_WPE : 7) : 8)))
 #else
 #define I2V_CONV_WPE
 #endif
@@ -267,7 +270,10 @@ __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvPara
     // ---- epilogue operand prefetch ----
     constexpr int E_C4 = BP / 4, E_RSTEP = 1024 / BP, E_NQ = WD * FR / E_RSTEP;
     static_assert(!PREF || TD == 1, "PREF needs a single epilogue pass");
-    float4 pre0[PREF ? E_NQ : 1], pre1[PREF ? E_NQ : 1], pregate[PREF ? E_NQ : 1];
+    // Only the first addend and the 1-bit gate word are prefetched (20 registers): a second addend or an fp32 mask
+    // (I2V_GATES=0) is read in the epilogue itself.  Prefetching all four cost 48 more registers and one third of the
+    // resident blocks -- on launches that are HBM-bound and live on bytes in flight.
+    float4 pre0[PREF ? E_NQ : 1];
     unsigned pregw[PREF ? E_NQ : 1];                       // 1-bit gates: the word holding this lane's 4 bits
     if (PREF) {
         const int e_c4 = t % E_C4, e_rbase = t / E_C4;
@@ -283,8 +289,6 @@ __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvPara
             const bool ok = e_ok && cd < p.Cd;
             const int64_t o = (int64_t)cd * e_HoWo + e_poff;
             pre0[q] = (ok && p.add0) ? *reinterpret_cast<const float4*>(p.add0 + e_n * p.add0_nstride + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-            pre1[q] = (ok && p.add1) ? *reinterpret_cast<const float4*>(p.add1 + e_n * p.add1_nstride + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-            pregate[q] = (ok && p.mask) ? *reinterpret_cast<const float4*>(p.mask + e_n * p.mask_nstride + o) : make_float4(1.f, 1.f, 1.f, 1.f);
             pregw[q] = (ok && p.gate) ? p.gate[(int64_t)cd * p.gate_stride + ((p.gate_pix0 + e_pp) >> 5)] : 0xffffffffu;
         }
     }
@@ -504,7 +508,6 @@ __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvPara
                     if (p.shift) { const float sh = p.shift[cd]; v.x += sh; v.y += sh; v.z += sh; v.w += sh; }
                     if (PREF) {
                         v.x += pre0[q].x; v.y += pre0[q].y; v.z += pre0[q].z; v.w += pre0[q].w;
-                        v.x += pre1[q].x; v.y += pre1[q].y; v.z += pre1[q].z; v.w += pre1[q].w;
                     } else {
                         if (p.add0 && p.add0_stride == 1) {
                             const float4 a = *reinterpret_cast<const float4*>(p.add0 + n * p.add0_nstride + o);
@@ -519,10 +522,10 @@ __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvPara
                                 v.x += a.x; v.z += a.y;
                             }
                         }
-                        if (p.add1) {
-                            const float4 a = *reinterpret_cast<const float4*>(p.add1 + n * p.add1_nstride + o);
-                            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-                        }
+                    }
+                    if (p.add1) {
+                        const float4 a = *reinterpret_cast<const float4*>(p.add1 + n * p.add1_nstride + o);
+                        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
                     }
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     if (p.gate) {            // 1-bit gates of the tensor whose gradient this is: 4 bits of one word
@@ -532,8 +535,8 @@ __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvPara
                         if (!(g & 2u)) v.y = 0.f;
                         if (!(g & 4u)) v.z = 0.f;
                         if (!(g & 8u)) v.w = 0.f;
-                    } else if (PREF || (p.mask && !p.gate_scale)) {
-                        const float4 m = PREF ? pregate[q] : *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
+                    } else if (p.mask && !p.gate_scale) {
+                        const float4 m = *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
                         if (!(m.x > 0.f)) v.x = 0.f;
                         if (!(m.y > 0.f)) v.y = 0.f;
                         if (!(m.z > 0.f)) v.z = 0.f;

@@ -235,9 +235,9 @@ class _ImageGuided(Attack):
     # Frames are independent in I2V / ENS-I2V (the loss is a sum of per-frame terms, Adam is elementwise), so a batch
     # may be cut into lanes of whole clips that run CONCURRENTLY on separate HIP streams, each with its own planned
     # nets: the tails and under-filled launches of one lane overlap with the other's.  Measured on the headline
-    # workload: 674 -> 693 frames/s with 2 lanes of 2 clips (tools/i2v_streams_probe.py).  The perturbed clips are
+    # workload: 695 -> 734 frames/s with 2 lanes of 2 clips (tools/lanes_fresh.py).  The perturbed clips are
     # bit-identical to the single-lane run; only the reported batch cost is summed in a different order.
-    clip_lanes = None          # None: $I2V_CLIP_LANES (default: one clip per lane up to 4 clips, else 2) on a GPU engine, 1 on the host simulation
+    clip_lanes = None          # None: $I2V_CLIP_LANES (default 2) on a GPU engine, 1 on the host simulation
 
     def _lane_count(self, b, f=1):
         """Lanes for a batch of b clips of f frames: whole clips per lane, or -- for a single clip, the reference
@@ -246,10 +246,11 @@ class _ImageGuided(Attack):
             return 1
         n = self.clip_lanes
         if n is None:
-            # measured on the headline shape (tools/lanes_probe.py, frames/s with 1 / 2 / 3 / 4 lanes): 4 clips 673 / 706 / 630 /
-            # 718, 8 clips 717 / 737 / 735 / 734, 1 clip 495 / 504 / 499 / 488 -- one clip per lane up to 4 clips, else two lanes
-            auto = b if 2 <= b <= 4 else 2
-            n = int(os.environ.get("I2V_CLIP_LANES", str(auto))) if self.engine.device.type == "cuda" else 1
+            # Two lanes, whatever the batch.  Measured on the headline shape in fresh processes (tools/lanes_fresh.py, frames/s with
+            # 1 / 2 / 4 lanes): 695 / 734 / 630 -- the HIP runtime multiplexes a process's streams onto 4 hardware queues by
+            # default, and with 4 lane streams beside torch's own two lanes end up sharing a queue and serialise (with
+            # GPU_MAX_HW_QUEUES=8: 694 / 734 / 731, nothing gained over two).  8 clips: 717 / 737 / 734; 1 clip: 495 / 504 / 488.
+            n = int(os.environ.get("I2V_CLIP_LANES", "2")) if self.engine.device.type == "cuda" else 1
         units = b if b > 1 else f // 8            # a lane of fewer than 8 frames does not pay
         return max(1, min(int(n), units))
 
