@@ -127,7 +127,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU")
     ap.add_argument("--white_model", default="slowfast_resnet50", help="--workload ilaf: video backbone (graphs.build_video)")
-    ap.add_argument("--streams", type=int, default=2, help="--workload ilaf: clips in flight on separate HIP streams (one clip per call each)")
+    ap.add_argument("--streams", type=int, default=3, help="--workload ilaf: clips in flight on separate HIP streams (one clip per call each)")
     ap.add_argument("--workload", default="i2v", choices=["i2v", "ens", "aens", "config2", "ilaf"],
                     help="i2v = the headline metric (default); ens / aens = BASELINE configs[2]/[3]-style extras on the "
                          "reference's own model list (resnet101+vgg16+squeezenet1_1+alexnet); aens carries the one data-path "

@@ -101,18 +101,35 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 // image launches -- and the spatial / pointwise convolutions of video networks -- compile without any of it.
 // MF16: 16x16x4 MFMA fragments instead of 32x32x2 (same peak rate): for launches with <= 16 output rows -- the
 // class-packed image gradient (12 rows), 8/16-channel layers -- a 32-row tile would be mostly padding.
-// Residency: the 64x64 tile (one wave per SIMD per block) is compiled for 7 waves per SIMD -- 72 unified VGPRs and, which
-// the register allocator then also honours, <= 96 SGPRs (MI355X_MICROARCH.md "Residency": 98+ SGPRs admit only 6 blocks of
-// 256 threads per CU).  The launches that matter have 1568*k tiles = 6.125*k per CU: at 6 resident blocks the last 32
-// tiles wait for a second round.
-#ifndef I2V_WPE_OFF
+// Residency: every tile is compiled for a stated number of waves per SIMD (= resident 256-thread blocks per CU), which
+// makes the register allocator count the MFMA accumulators in the unified VGPR file and stop at the matching budget:
+//   64x64   7  (72 registers; it then also keeps <= 96 SGPRs -- MI355X_MICROARCH.md "Residency": 98+ SGPRs admit only
+//               6 blocks per CU.  The launches that matter have 1568*k tiles = 6.125*k per CU: at 6 resident blocks the
+//               last 32 tiles waited for a second round)
+//   64x64 with epilogue prefetch  6  (78 registers; 7 would spill)
+//   128x64 / 64x128  5  (82-89 registers; left alone the allocator used 84 + 32 AGPRs = 4 blocks)
+//   128x128  3  (147-154; was 147 + 64 = 2 blocks)
+// The 256-pixel tiles are bounded by LDS (4 blocks) and are left alone.  All without spills (-Rpass-analysis).
+#ifndef I2V_SMALL_WPE
+#define I2V_SMALL_WPE 7
+#endif
 #ifndef I2V_PREF_WPE
 #define I2V_PREF_WPE 6
 #endif
-#define I2V_CONV_WPE __attribute__((amdgpu_waves_per_eu((BD == 64 && BP == 64) ? (PREF ? I2V_PREF_WPE : 7) : 1, (BD == 64 && BP == 64) ? (PREF ? I2V_PREF_WPE : 7) : 8)))
-#else
-#define I2V_CONV_WPE
+#ifndef I2V_MID_WPE
+#define I2V_MID_WPE 5
 #endif
+#ifndef I2V_BIG_WPE
+#define I2V_BIG_WPE 3
+#endif
+static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi) {
+#ifdef I2V_WPE_OFF
+    return hi ? 8 : 1;
+#else
+    return (BD == 64 && BP == 64) ? (PREF ? I2V_PREF_WPE : I2V_SMALL_WPE) : BD * BP == 8192 ? I2V_MID_WPE : BD * BP == 16384 ? I2V_BIG_WPE : (hi ? 8 : 1);
+#endif
+}
+#define I2V_CONV_WPE __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(BD, BP, PREF, false), conv_waves_per_simd(BD, BP, PREF, true))))
 template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false>
 __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-resource types and LDS-DMA builtins exist only in the device pass

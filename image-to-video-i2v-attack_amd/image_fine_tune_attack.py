@@ -8,7 +8,7 @@ Differences: the white-box model is an `i2v_amd.video.VideoModel` (graph IR + we
 module from a YACS config, `:58-66`), so `--white_model` is one of the names `graphs.build_video` knows and the whole
 ILAF loop runs in `libi2v_hip.so`; under `torchrun` the file list is dealt round-robin over the ranks (replicas only,
 no collective); `--steps` / `--step_size` expose ILAF's constructor defaults (60, 0.005; `image_attacks.py:502`);
-`--resume` skips clips whose output exists; `--streams N` (default 2) keeps N clips in flight on separate HIP streams
+`--resume` skips clips whose output exists; `--streams N` (default 3) keeps N clips in flight on separate HIP streams
 (`sign_attacks.run_concurrent`: one clip per call as in the reference, but a single clip cannot fill the GPU)."""
 import argparse
 import os
@@ -58,7 +58,7 @@ def arg_parse(argv=None):
     parser.add_argument("--synthetic_weights", action="store_true",
                         help="run on the seeded synthetic initialiser when no checkpoint lies under $I2V_WEIGHTS_DIR "
                              "(same as I2V_SYNTHETIC_WEIGHTS=1); without it a missing checkpoint is an error")
-    parser.add_argument("--streams", type=int, default=2, help="clips in flight on separate HIP streams")
+    parser.add_argument("--streams", type=int, default=3, help="clips in flight on separate HIP streams")
     args = parser.parse_args(argv)
     if args.synthetic_weights:
         os.environ["I2V_SYNTHETIC_WEIGHTS"] = "1"
