@@ -110,7 +110,7 @@ struct Net {
 // time each, 4 % of the headline bench when every launch carried a pair).
 struct TimedLaunch { void* start; void* stop; int kind; double flops; int Cd, K, HWg, frames, pw; void* chain_from; double bytes; };
 struct i2v_ctx {
-    int device; std::vector<Net*> nets;
+    int device; std::vector<Net*> nets; std::mutex nets_mu;     // the table: created / destroyed under the lock, ids of destroyed nets are handed out again
     // nets may be executed from several threads on several streams (clip lanes): entries are handed out under a lock,
     // live in a deque (stable addresses) and chain to an explicit event, never to "the previous entry"
     bool timing = false; std::deque<TimedLaunch> timed; size_t timed_used = 0; std::mutex timing_mu;
@@ -381,7 +381,10 @@ extern "C" int i2v_destroy(i2v_handle h) {
 // ---------------------------------------------------------------------------------------------
 extern "C" int i2v_net_create(i2v_handle h, int* net) {
     if (!h || !net) return fail("i2v_net_create: null argument");
-    if (h->nets.size() >= I2V_MAX_NETS) return fail("more than %d backbones created on one handle", I2V_MAX_NETS);
+    std::lock_guard<std::mutex> lock(h->nets_mu);
+    for (size_t i = 0; i < h->nets.size(); ++i)       // a long run re-plans whenever its batch grows: reuse the ids it gave back
+        if (!h->nets[i]) { h->nets[i] = new Net(); *net = (int)i; return 0; }
+    if (h->nets.size() >= I2V_MAX_NETS) return fail("more than %d backbones alive on one handle", I2V_MAX_NETS);
     h->nets.push_back(new Net());
     *net = (int)h->nets.size() - 1;
     return 0;
@@ -390,7 +393,8 @@ extern "C" int i2v_net_create(i2v_handle h, int* net) {
 extern "C" int i2v_net_destroy(i2v_handle h, int net) {
     Net* n = get_net(h, net); if (!n) return 1;
     free_net(n);
-    h->nets[net] = nullptr;          // ids are never reused
+    std::lock_guard<std::mutex> lock(h->nets_mu);
+    h->nets[net] = nullptr;          // the id may be handed out again by i2v_net_create
     return 0;
 }
 

@@ -263,3 +263,21 @@ def test_image_main_takes_decoded_frames(tmp_path, monkeypatch):
     out = tmp_path / "out" / "Image-ImageGuidedFMDirection_Adam-1-raw"
     assert sorted(f for f in os.listdir(out) if f.endswith(".npy")) == ["4-adv.npy", "9-adv.npy"]
     assert np.load(out / "4-adv.npy").shape == (3, 2, 64, 64)
+
+
+def test_net_ids_are_reused():
+    """A long CLI run re-plans whenever its batch grows; the ids it gives back must be handed out again (round 1 capped
+    a handle at 4096 backbones ever created)."""
+    eng = hostsim_engine()
+    seen = set()
+    for _ in range(5000):
+        nid = ctypes.c_int(-1)
+        assert eng.capi.i2v_net_create(eng.h, ctypes.byref(nid)) == 0
+        seen.add(nid.value)
+        assert eng.capi.i2v_net_destroy(eng.h, nid.value) == 0
+    assert len(seen) <= 2
+    # and a planned net still works next to the churn
+    g = graphs.build_tiny("resnet", (32, 32))
+    net = eng.build_net(g, weights.synthetic_state_dict(g, 1), [g.hooks[1]], 2)
+    net.forward(torch.zeros(2, 3, 32, 32))
+    net.close()
