@@ -498,6 +498,12 @@ extern "C" int i2v_net_add_maxpool3d(i2v_handle h, int net, const i2v_pool3d_des
     if (d->kt < 1 || d->k < 1 || d->stride_t < 1 || d->stride < 1 || d->pad_t < 0 || d->pad < 0) return fail("bad pool geometry");
     const Buffer& sb = n->bufs[n->tens[d->src].buf]; const Buffer& db = n->bufs[n->tens[d->dst].buf];
     if ((sb.T + 2 * d->pad_t - d->kt) / d->stride_t + 1 != db.T) return fail("pool output frames per clip do not match the buffer");
+    {   // the destination plane must be what this window produces (floor, or ceil_mode's one extra row / column)
+        const int ho = (sb.H + 2 * d->pad - d->k) / d->stride + 1, hc = (sb.H + 2 * d->pad - d->k + d->stride - 1) / d->stride + 1;
+        const int wo = (sb.W + 2 * d->pad - d->k) / d->stride + 1, wc = (sb.W + 2 * d->pad - d->k + d->stride - 1) / d->stride + 1;
+        if (sb.H + 2 * d->pad < d->k || sb.W + 2 * d->pad < d->k || db.H < ho || db.H > hc || db.W < wo || db.W > wc)
+            return fail("pool output plane %dx%d does not match %dx%d pooled by k=%d stride=%d pad=%d", db.H, db.W, sb.H, sb.W, d->k, d->stride, d->pad);
+    }
     Node nd; nd.type = 1; nd.pd = *d; memset(&nd.cd, 0, sizeof nd.cd);
     n->nodes.push_back(std::move(nd));
     return 0;

@@ -281,3 +281,26 @@ def test_net_ids_are_reused():
     net = eng.build_net(g, weights.synthetic_state_dict(g, 1), [g.hooks[1]], 2)
     net.forward(torch.zeros(2, 3, 32, 32))
     net.close()
+
+
+def test_pool_output_plane_is_validated():
+    """ADVICE (round 1): the planner accepted any destination plane for a max-pool; a wrong one is an out-of-bounds write
+    in the banded kernels.  floor and ceil_mode planes are accepted, anything else is refused."""
+    from i2v_amd import lib
+    eng = hostsim_engine()
+    cap = eng.capi
+
+    def pool_into(h_out):
+        nid, b0, b1, t0, t1 = (ctypes.c_int(-1) for _ in range(5))
+        assert cap.i2v_net_create(eng.h, ctypes.byref(nid)) == 0
+        assert cap.i2v_net_add_buffer(eng.h, nid.value, 4, 14, 14, ctypes.byref(b0)) == 0
+        assert cap.i2v_net_add_buffer(eng.h, nid.value, 4, h_out, h_out, ctypes.byref(b1)) == 0
+        assert cap.i2v_net_add_tensor(eng.h, nid.value, b0.value, 0, 4, 0, ctypes.byref(t0)) == 0
+        assert cap.i2v_net_add_tensor(eng.h, nid.value, b1.value, 0, 4, 0, ctypes.byref(t1)) == 0
+        rc = cap.i2v_net_add_maxpool(eng.h, nid.value, ctypes.byref(lib.PoolDesc(t0.value, t1.value, 3, 2, 0)))
+        cap.i2v_net_destroy(eng.h, nid.value)
+        return rc
+    assert pool_into(6) == 0            # floor((14 - 3) / 2) + 1
+    assert pool_into(7) == 0            # ceil_mode
+    assert pool_into(8) != 0 and b"pool output plane" in cap.i2v_last_error()
+    assert pool_into(5) != 0
