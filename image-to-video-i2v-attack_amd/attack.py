@@ -44,7 +44,7 @@ def arg_parse(argv=None):
         parser.add_argument(f, action="store_true", default=False, help="video_attacks.py switch (out of scope, ignored)")
     # additions (not in the reference)
     parser.add_argument("--model_factory", type=str, default="reference:proxy",
-                        help="pkg.module:function (name -> torch classifier), or 'native' for the I3D graphs with a native classifier head")
+                        help="pkg.module:function (name -> torch classifier), or 'native' for the I3D / SlowFast graphs with a native classifier head")
     parser.add_argument("--num_classes", type=int, default=400)
     parser.add_argument("--anno", type=str, default=os.environ.get("I2V_ANNO", ""))
     parser.add_argument("--clip_dir", type=str, default="")

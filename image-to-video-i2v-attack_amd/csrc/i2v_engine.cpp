@@ -1355,15 +1355,49 @@ extern "C" int i2v_ilaf_grad_f32(const float* a, int64_t a_stride, const float* 
 
 extern "C" size_t i2v_head_scratch_bytes(int C, int clips) { return (size_t)2 * C * clips * sizeof(float) + 64; }
 
+static void head_feature(I2VHeadParams& p, const float* a, int64_t a_stride, int C, int HW, int T, int clips, int Ctot, int c_off, void* scratch) {
+    memset(&p, 0, sizeof p);
+    p.a = a; p.a_nstride = a_stride; p.C = C; p.HW = HW; p.T = T; p.clips = clips; p.Ctot = Ctot; p.c_off = c_off;
+    p.pooled = (float*)scratch; p.dpooled = (float*)scratch + (size_t)Ctot * clips;
+}
+
 extern "C" int i2v_head_ce_f32(const float* a, int64_t a_stride, int C, int HW, int T, int clips, const float* W, const float* bias,
                                int K, const int32_t* labels, float scale, int mask_relu, int accumulate, float* logits, float* loss_each,
                                float* grad, int64_t grad_stride, void* scratch, void* stream) {
     if (!a || !W || !labels || !logits || !loss_each || !grad || !scratch || C <= 0 || HW <= 0 || T <= 0 || clips <= 0 || K <= 0)
         return fail("i2v_head_ce_f32: bad argument");
-    I2VHeadParams p; memset(&p, 0, sizeof p);
-    p.a = a; p.a_nstride = a_stride; p.C = C; p.HW = HW; p.T = T; p.clips = clips; p.K = K; p.W = W; p.bias = bias; p.labels = labels;
-    p.scale = scale; p.pooled = (float*)scratch; p.dpooled = (float*)scratch + (size_t)C * clips; p.logits = logits; p.loss_each = loss_each;
-    p.grad = grad; p.grad_nstride = grad_stride; p.mask_relu = mask_relu; p.accumulate = accumulate;
+    I2VHeadParams p; head_feature(p, a, a_stride, C, HW, T, clips, C, 0, scratch);
+    p.K = K; p.W = W; p.bias = bias; p.labels = labels; p.scale = scale; p.logits = logits; p.loss_each = loss_each;
+    p.grad = grad; p.grad_nstride = grad_stride; p.mask_relu = mask_relu; p.accumulate = accumulate; p.phase = 7;
+    CHECK_BE(k_head_ce(p, stream));
+    return 0;
+}
+
+// The same head over SEVERAL features (SlowFast pools its two pathways separately and concatenates): pool every feature into
+// its columns of the Ctot-wide vector, then one logits / loss call, then every feature's gradient.  scratch >=
+// i2v_head_scratch_bytes(Ctot, clips), the same block in all three.
+extern "C" int i2v_head_pool_f32(const float* a, int64_t a_stride, int C, int HW, int T, int clips, int Ctot, int c_off, void* scratch,
+                                 void* stream) {
+    if (!a || !scratch || C <= 0 || HW <= 0 || T <= 0 || clips <= 0 || c_off < 0 || c_off + C > Ctot) return fail("i2v_head_pool_f32: bad argument");
+    I2VHeadParams p; head_feature(p, a, a_stride, C, HW, T, clips, Ctot, c_off, scratch); p.phase = 1;
+    CHECK_BE(k_head_ce(p, stream));
+    return 0;
+}
+
+extern "C" int i2v_head_logits_ce_f32(int Ctot, int clips, const float* W, const float* bias, int K, const int32_t* labels, float scale,
+                                      float* logits, float* loss_each, void* scratch, void* stream) {
+    if (!W || !labels || !logits || !loss_each || !scratch || Ctot <= 0 || clips <= 0 || K <= 0) return fail("i2v_head_logits_ce_f32: bad argument");
+    I2VHeadParams p; head_feature(p, nullptr, 0, Ctot, 1, 1, clips, Ctot, 0, scratch);
+    p.K = K; p.W = W; p.bias = bias; p.labels = labels; p.scale = scale; p.logits = logits; p.loss_each = loss_each; p.phase = 2;
+    CHECK_BE(k_head_ce(p, stream));
+    return 0;
+}
+
+extern "C" int i2v_head_grad_f32(const float* a, int64_t a_stride, int C, int HW, int T, int clips, int Ctot, int c_off, int mask_relu,
+                                 int accumulate, float* grad, int64_t grad_stride, void* scratch, void* stream) {
+    if (!a || !grad || !scratch || C <= 0 || HW <= 0 || T <= 0 || clips <= 0 || c_off < 0 || c_off + C > Ctot) return fail("i2v_head_grad_f32: bad argument");
+    I2VHeadParams p; head_feature(p, a, a_stride, C, HW, T, clips, Ctot, c_off, scratch);
+    p.grad = grad; p.grad_nstride = grad_stride; p.mask_relu = mask_relu; p.accumulate = accumulate; p.phase = 4;
     CHECK_BE(k_head_ce(p, stream));
     return 0;
 }

@@ -1314,18 +1314,18 @@ __global__ void __launch_bounds__(256) head_pool_kernel(const I2VHeadParams p) {
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) p.pooled[(int64_t)clip * p.C + c] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)per);
+    if (threadIdx.x == 0) p.pooled[(int64_t)clip * p.Ctot + p.c_off + c] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)per);
 }
 
 // grid (clips): logits, softmax, loss, d loss / d pooled
 __global__ void __launch_bounds__(256) head_logits_kernel(const I2VHeadParams p) {
     const int clip = blockIdx.x;
-    const float* x = p.pooled + (int64_t)clip * p.C;
+    const float* x = p.pooled + (int64_t)clip * p.Ctot;
     float* lg = p.logits + (int64_t)clip * p.K;
     for (int k = threadIdx.x; k < p.K; k += 256) {
         double acc = p.bias ? (double)p.bias[k] : 0.0;
-        const float* w = p.W + (int64_t)k * p.C;
-        for (int c = 0; c < p.C; ++c) acc += (double)w[c] * (double)x[c];
+        const float* w = p.W + (int64_t)k * p.Ctot;
+        for (int c = 0; c < p.Ctot; ++c) acc += (double)w[c] * (double)x[c];
         lg[k] = (float)acc;
     }
     __syncthreads();
@@ -1349,16 +1349,17 @@ __global__ void __launch_bounds__(256) head_logits_kernel(const I2VHeadParams p)
         p.loss_each[clip] = (float)(-((double)lg[lab] - mx_s - log(sum_s)));
     }
     __syncthreads();
-    // d(scale * mean_clips loss) / d pooled[c] = scale/clips * sum_k W[k][c] (softmax_k - [k == label])
+    // d(scale * mean_clips loss) / d pooled[c] = scale/clips * sum_k W[k][c] (softmax_k - [k == label]); the division by the
+    // feature's T*HW (the average pool's backward) happens where the gradient is spread, per feature
     const int lab = p.labels[clip];
     const double f = (double)p.scale / (double)p.clips;
-    for (int c = threadIdx.x; c < p.C; c += 256) {
+    for (int c = threadIdx.x; c < p.Ctot; c += 256) {
         double acc = 0;
         for (int k = 0; k < p.K; ++k) {
             const double pk = exp((double)lg[k] - mx_s) / sum_s - (k == lab ? 1.0 : 0.0);
-            acc += (double)p.W[(int64_t)k * p.C + c] * pk;
+            acc += (double)p.W[(int64_t)k * p.Ctot + c] * pk;
         }
-        p.dpooled[(int64_t)clip * p.C + c] = (float)(f * acc / (double)(p.T * p.HW));
+        p.dpooled[(int64_t)clip * p.Ctot + c] = (float)(f * acc);
     }
 }
 
@@ -1368,23 +1369,30 @@ __global__ void __launch_bounds__(256) head_grad_kernel(const I2VHeadParams p) {
     const int64_t D = (int64_t)p.C * p.HW;
     const float* a = p.a + (int64_t)n * p.a_nstride;
     float* g = p.grad + (int64_t)n * p.grad_nstride;
-    const float* dp = p.dpooled + (int64_t)clip * p.C;
+    const float* dp = p.dpooled + (int64_t)clip * p.Ctot + p.c_off;
+    const float cnt = (float)(p.T * p.HW);
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < D; i += (int64_t)gridDim.x * 256) {
-        float v = dp[i / p.HW];
+        float v = __fdiv_rn(dp[i / p.HW], cnt);
         if (p.mask_relu && !(a[i] > 0.f)) v = 0.f;
         g[i] = p.accumulate ? g[i] + v : v;
     }
 }
 
 int k_head_ce(const I2VHeadParams& p, i2v_stream_t s) {
-    hipLaunchKernelGGL(head_pool_kernel, dim3(p.C, p.clips), dim3(256), 0, (hipStream_t)s, p);
-    LAUNCH_CHECK("head_pool");
-    hipLaunchKernelGGL(head_logits_kernel, dim3(p.clips), dim3(256), 0, (hipStream_t)s, p);
-    LAUNCH_CHECK("head_logits");
-    const int64_t D = (int64_t)p.C * p.HW;
-    int gblk = (int)((D + 2047) / 2048); if (gblk > 64) gblk = 64;
-    hipLaunchKernelGGL(head_grad_kernel, dim3(gblk, p.clips * p.T), dim3(256), 0, (hipStream_t)s, p);
-    LAUNCH_CHECK("head_grad");
+    if (p.phase & 1) {
+        hipLaunchKernelGGL(head_pool_kernel, dim3(p.C, p.clips), dim3(256), 0, (hipStream_t)s, p);
+        LAUNCH_CHECK("head_pool");
+    }
+    if (p.phase & 2) {
+        hipLaunchKernelGGL(head_logits_kernel, dim3(p.clips), dim3(256), 0, (hipStream_t)s, p);
+        LAUNCH_CHECK("head_logits");
+    }
+    if (p.phase & 4) {
+        const int64_t D = (int64_t)p.C * p.HW;
+        int gblk = (int)((D + 2047) / 2048); if (gblk > 64) gblk = 64;
+        hipLaunchKernelGGL(head_grad_kernel, dim3(gblk, p.clips * p.T), dim3(256), 0, (hipStream_t)s, p);
+        LAUNCH_CHECK("head_grad");
+    }
     return 0;
 }
 

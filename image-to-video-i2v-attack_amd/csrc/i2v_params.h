@@ -134,12 +134,16 @@ struct I2VHeadParams {
     const float* W;    const float* bias;     // [K][C], [K]
     const int32_t* labels;                    // [clips]
     float scale;                              // `_targeted` of base_attacks.py:229-231 (+1 / -1)
-    float* pooled;                            // [clips][C]      (scratch)
-    float* dpooled;                           // [clips][C]      (scratch)
+    float* pooled;                            // [clips][Ctot]   (scratch)
+    float* dpooled;                           // [clips][Ctot]   (scratch): d(scale * mean loss) / d pooled
     float* logits;                            // [clips][K]      (output: the model's prediction)
     float* loss_each;                         // [clips]         (-log softmax[label]; the host averages)
     float* grad;       int64_t grad_nstride;
     int32_t mask_relu, accumulate;
+    // A head may read SEVERAL features (SlowFast: slow and fast pathway, pooled separately and concatenated): this feature's
+    // channels are columns [c_off, c_off + C) of the Ctot-wide pooled vector / fc weight rows.
+    int32_t Ctot, c_off;
+    int32_t phase;                            // bit 0: pool this feature, bit 1: logits + loss + dpooled, bit 2: this feature's gradient
 };
 
 struct I2VStdParams {                          // Dispersion-Reduction loss: unbiased std of a tensor

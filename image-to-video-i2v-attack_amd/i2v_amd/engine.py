@@ -317,19 +317,40 @@ class Net:
                                                 C.c_void_p(hi.grad), hi.grad_stride, C.c_void_p(scratch.data_ptr()),
                                                 self.eng.stream()))
 
-    def head_ce(self, i: int, W: torch.Tensor, bias, labels: torch.Tensor, in_frames: int, scale: float, logits: torch.Tensor,
+    def head_ce(self, i, W: torch.Tensor, bias, labels: torch.Tensor, in_frames: int, scale: float, logits: torch.Tensor,
                 loss_each: torch.Tensor, scratch: torch.Tensor):
-        """Classifier head over hook i (global average pool over the clip -> Linear -> cross-entropy, mean over clips) and
-        `scale * d loss / d feature` into the hook's gradient view (base_attacks.py:282-284)."""
-        hi = self.hooks[i]
+        """Classifier head over hook i -- or over a LIST of hooks whose pooled features are concatenated in that order
+        (SlowFast) -- : global average pool over the clip -> Linear -> cross-entropy, mean over clips, and
+        `scale * d loss / d feature` into every hook's gradient view (base_attacks.py:282-284)."""
         capi = self.eng.capi
-        C_, H_, W_ = hi.shape
         clips = in_frames // self.graph.tensors[self.graph.input].T
-        assert labels.dtype == torch.int32 and labels.numel() == clips and W.shape[1] == C_
-        _lib.check(capi, capi.i2v_head_ce_f32(
-            C.c_void_p(hi.act), hi.act_stride, C_, H_ * W_, hi.T, clips, _ptr(W), _ptr(bias) if bias is not None else C.c_void_p(0),
-            W.shape[0], C.c_void_p(labels.data_ptr()), scale, hi.post_relu, 0, _ptr(logits), _ptr(loss_each), C.c_void_p(hi.grad),
-            hi.grad_stride, C.c_void_p(scratch.data_ptr()), self.eng.stream()))
+        bias_p = _ptr(bias) if bias is not None else C.c_void_p(0)
+        assert labels.dtype == torch.int32 and labels.numel() == clips
+        if isinstance(i, int):
+            hi = self.hooks[i]
+            C_, H_, W_ = hi.shape
+            assert W.shape[1] == C_
+            _lib.check(capi, capi.i2v_head_ce_f32(
+                C.c_void_p(hi.act), hi.act_stride, C_, H_ * W_, hi.T, clips, _ptr(W), bias_p,
+                W.shape[0], C.c_void_p(labels.data_ptr()), scale, hi.post_relu, 0, _ptr(logits), _ptr(loss_each), C.c_void_p(hi.grad),
+                hi.grad_stride, C.c_void_p(scratch.data_ptr()), self.eng.stream()))
+            return
+        his = [self.hooks[k] for k in i]
+        Ctot = sum(hi.shape[0] for hi in his)
+        assert W.shape[1] == Ctot and scratch.numel() >= capi.i2v_head_scratch_bytes(Ctot, clips)
+        sp, st = C.c_void_p(scratch.data_ptr()), self.eng.stream()
+        off = 0
+        for hi in his:
+            _lib.check(capi, capi.i2v_head_pool_f32(C.c_void_p(hi.act), hi.act_stride, hi.shape[0], hi.shape[1] * hi.shape[2], hi.T, clips,
+                                                    Ctot, off, sp, st))
+            off += hi.shape[0]
+        _lib.check(capi, capi.i2v_head_logits_ce_f32(Ctot, clips, _ptr(W), bias_p, W.shape[0], C.c_void_p(labels.data_ptr()), scale,
+                                                     _ptr(logits), _ptr(loss_each), sp, st))
+        off = 0
+        for hi in his:
+            _lib.check(capi, capi.i2v_head_grad_f32(C.c_void_p(hi.act), hi.act_stride, hi.shape[0], hi.shape[1] * hi.shape[2], hi.T, clips,
+                                                    Ctot, off, hi.post_relu, 0, C.c_void_p(hi.grad), hi.grad_stride, sp, st))
+            off += hi.shape[0]
 
     def scratch_bytes(self, frames: int) -> int:
         return max(self.eng.capi.i2v_cossim_scratch_bytes(hi.D, frames) for hi in self.hooks)

@@ -87,6 +87,7 @@ class Graph:
     hooks_module: Dict[int, int] = field(default_factory=dict)
     input: int = 0
     video: bool = False                                       # 3-D backbone: conv weights are (cout,cin,kt,kh,kw)
+    classifier_feats: List[int] = field(default_factory=list)  # tensors a classifier head pools and concatenates (video graphs built to their last stage)
 
     # -- construction helpers -------------------------------------------------
     def new_buffer(self, C: int) -> int:
@@ -167,7 +168,7 @@ class Graph:
                     needed.add(nd.residual)
         g = Graph(self.arch, self.in_hw, self.tensors, self.buffers,
                   [n for n, k in zip(self.nodes, keep) if k], dict(self.hooks), dict(self.hooks_module), self.input,
-                  self.video)
+                  self.video, list(self.classifier_feats))
         return g
 
     def hook_for(self, depth: int, whole_module: bool = False) -> int:
@@ -469,6 +470,83 @@ def slowfast_res2(width=64, in_thw=(32, 224, 224), arch="slowfast_resnet50", slo
     return g
 
 
+def slowfast_resnet(layers=(3, 4, 6, 3), width=64, in_thw=(32, 224, 224), arch="slowfast_resnet50_full", slow_stride=8,
+                    fast_stride=1, beta_inv=8, fusion_ratio=2, fusion_kernel=5) -> Graph:
+    """The WHOLE SlowFast backbone (Feichtenhofer et al.; gluoncv `slowfast_4x16_resnet50/101_kinetics400`): both pathways
+    through res2..res5 with a time-strided lateral convolution (5x1x1 / (alpha,1,1), BN, ReLU) from the fast into the slow
+    pathway in front of every slow stage.  Slow pathway: temporal kernels only in res4 / res5; fast pathway: 3x1x1 in every
+    block.  hooks[1] / hooks[2] = fast_res2 / slow_res2 as in `slowfast_res2` (same weight keys, same order), and
+    `classifier_feats` = [slow_res5, fast_res5]: the head pools each over (T, H, W), concatenates them in that order and
+    applies `fc` (the classifier of the white-box sign-step attacks, `attack.py:63-96`).  Parity with gluoncv's module
+    layout unpinned, like the other video graphs."""
+    T, H, W = in_thw
+    alpha = slow_stride // fast_stride
+    fw = width // beta_inv
+    g = Graph(arch, (H, W), video=True)
+    x = g.new_tensor(3, H, W, False, "input", T=T)
+    g.input = x
+    f = g.conv3d(x, fw, (5, 7), (fast_stride, 2), (2 * fast_stride, 3), "fast_conv1.weight", bn="fast_bn1",
+                 name="fast_stem", dil_t=fast_stride)
+    f = g.maxpool3d(f, (1, 3), (1, 2), (0, 1), name="fast_maxpool")
+    ft = g.tensors[f]
+    s = g.conv3d(x, width, (1, 7), (slow_stride, 2), (0, 3), "slow_conv1.weight", bn="slow_bn1", name="slow_stem")
+    st = g.tensors[s]
+
+    def lateral(src, cat, c_off, key):
+        """fast feature -> 5x1x1 / alpha convolution + BN + ReLU into channels [c_off, ...) of the slow pathway's next input"""
+        sp = g.tensors[src]
+        t = g.new_tensor(sp.C * fusion_ratio, sp.H, sp.W, True, key, buf=cat, c_off=c_off,
+                         T=(sp.T + 2 * (fusion_kernel // 2) - fusion_kernel) // alpha + 1)
+        g.nodes.append(ConvNode(src, t, sp.C, sp.C * fusion_ratio, 1, 1, 1, 0, f"{key}.0.weight", None, f"{key}.1",
+                                True, None, None, "conv", fusion_kernel, alpha, fusion_kernel // 2, 1))
+        return t
+
+    cat = g.new_buffer(width + fw * fusion_ratio)
+    sp_t = g.new_tensor(width, ft.H, ft.W, False, "slow_maxpool", buf=cat, c_off=0, T=st.T)
+    g.nodes.append(PoolNode(s, sp_t, 3, 2, 1, False, "maxpool", 1, 1, 0))
+    lat = lateral(f, cat, width, "lateral_p1")
+    assert g.tensors[lat].T == st.T, "pathway frame counts disagree"
+    xs = g.new_tensor(width + fw * fusion_ratio, ft.H, ft.W, False, "slow_cat1", buf=cat, c_off=0, T=st.T)
+
+    def stage(x, planes, nblocks, stride, prefix, head_t, out_buf=None):
+        inplanes = g.tensors[x].C
+        for b in range(nblocks):
+            sb = stride if b == 0 else 1
+            p = f"{prefix}.{b}"
+            a = g.conv3d(x, planes, (head_t, 1), (1, 1), (head_t // 2, 0), f"{p}.conv1.weight", bn=f"{p}.bn1", name=f"{p}.conv1")
+            a = g.conv3d(a, planes, (1, 3), (1, sb), (0, 1), f"{p}.conv2.weight", bn=f"{p}.bn2", name=f"{p}.conv2")
+            if sb != 1 or inplanes != planes * 4:
+                idt = g.conv3d(x, planes * 4, (1, 1), (1, sb), (0, 0), f"{p}.downsample.0.weight",
+                               bn=f"{p}.downsample.1", relu=False, name=f"{p}.downsample")
+            else:
+                idt = x
+            last = b == nblocks - 1 and out_buf is not None
+            x = g.conv3d(a, planes * 4, (1, 1), (1, 1), (0, 0), f"{p}.conv3.weight", bn=f"{p}.bn3", residual=idt,
+                         name=f"{p}.out", dst_buf=out_buf if last else None, dst_c_off=0)
+            inplanes = planes * 4
+        return x
+
+    slow_t = (1, 1, 3, 3)                       # temporal kernel of conv1 in the slow pathway's stages
+    fr, sr = f, xs
+    for li, nb in enumerate(layers):
+        stride = 1 if li == 0 else 2
+        fr = stage(fr, fw * 2 ** li, nb, stride, f"fast_res{li + 2}", 3)
+        nxt = None
+        if li < len(layers) - 1:                # the slow stage's output lands next to the lateral it is concatenated with
+            nxt = g.new_buffer(width * 4 * 2 ** li + g.tensors[fr].C * fusion_ratio)
+        sr = stage(sr, width * 2 ** li, nb, stride, f"slow_res{li + 2}", slow_t[li], nxt)
+        if li == 0:
+            g.hooks[1], g.hooks[2] = fr, sr
+        if nxt is not None:
+            so = g.tensors[sr]
+            lt = lateral(fr, nxt, so.C, f"lateral_res{li + 2}")
+            assert (g.tensors[lt].T, g.tensors[lt].H) == (so.T, so.H), "pathway shapes disagree"
+            sr = g.new_tensor(so.C + g.tensors[lt].C, so.H, so.W, False, f"slow_cat{li + 2}", buf=nxt, c_off=0, T=so.T)
+    g.hooks[3], g.hooks[4] = sr, fr
+    g.classifier_feats = [sr, fr]
+    return g
+
+
 def tpn_resnet(layers=(3, 4, 6, 3), width=64, in_thw=(32, 224, 224), arch="tpn_resnet50") -> Graph:
     """Backbone of TPN (Yang et al., "Temporal Pyramid Network") up to `layer2`, the module the reference hooks for
     'tpn' models (`image_attacks.py:517-518`).  TPN's backbone is a SlowOnly-style 3-D ResNet: stem 1x7x7 / (1,2,2),
@@ -502,8 +580,11 @@ def tpn_resnet(layers=(3, 4, 6, 3), width=64, in_thw=(32, 224, 224), arch="tpn_r
     return g
 
 
-def build_video(model_type: str, in_thw=(32, 224, 224)) -> Graph:
-    """`model_type` follows `image_fine_tune_attack.py:53` / `utils.py:9-14`."""
+def build_video(model_type: str, in_thw=(32, 224, 224), full: bool = False) -> Graph:
+    """`model_type` follows `image_fine_tune_attack.py:53` / `utils.py:9-14`.  `full`: the graph to its last stage (what a
+    classifier head needs); the I3D graphs always are, SlowFast then gets res3..res5 and its lateral connections."""
+    if full and model_type in ("slowfast_resnet50", "slowfast_resnet101"):
+        return slowfast_resnet((3, 4, 23, 3) if "101" in model_type else (3, 4, 6, 3), 64, in_thw, model_type + "_full")
     if model_type == "i3d_resnet50":
         return i3d_resnet((3, 4, 6, 3), 64, in_thw, "i3d_resnet50")
     if model_type == "i3d_resnet101":
@@ -519,7 +600,9 @@ def build_video(model_type: str, in_thw=(32, 224, 224)) -> Graph:
     raise KeyError(f"video backbone {model_type!r} is not built (the non-local i3d_nl5 blocks are out of scope)")
 
 
-def build_video_tiny(model_type: str, in_thw=(8, 32, 32)) -> Graph:
+def build_video_tiny(model_type: str, in_thw=(8, 32, 32), full: bool = False) -> Graph:
+    if full and "slowfast" in model_type:
+        return slowfast_resnet((2, 2, 1, 1), 16, in_thw, "slowfast_tiny_full", slow_stride=4, fast_stride=1, beta_inv=4)
     if "tpn" in model_type:
         return tpn_resnet((2, 2, 1, 1), 8, in_thw, "tpn_tiny")
     if "i3d" in model_type:

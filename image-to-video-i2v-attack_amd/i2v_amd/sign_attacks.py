@@ -85,7 +85,8 @@ class _SignAttack(object):
         W, bias = self._head
         logits, loss_each = torch.empty(b, W.shape[0], **kw), torch.empty(b, **kw)
         scratch = torch.empty(eng.capi.i2v_head_scratch_bytes(W.shape[1], b), dtype=torch.uint8, device=eng.device)
-        net.head_ce(0, W, bias, labels.to(eng.device).to(torch.int32).contiguous(), N, float(self._targeted), logits, loss_each, scratch)
+        feats = 0 if len(net.hooks) == 1 else list(range(len(net.hooks)))
+        net.head_ce(feats, W, bias, labels.to(eng.device).to(torch.int32).contiguous(), N, float(self._targeted), logits, loss_each, scratch)
         gx = torch.empty_like(x)
         net.backward(gx)
         self.last_logits, self.last_loss = logits, loss_each.mean()

@@ -23,10 +23,11 @@ class VideoModel(object):
                  state_dict: Optional[dict] = None, num_classes: Optional[int] = None):
         """`num_classes`: also carry the classifier head (global average pool -> `fc`), which makes the model usable as the
         white-box CLASSIFIER of the BIM family (`attack.py:63-96`, `base_attacks.py:261-340`) with the whole cross-entropy
-        gradient computed natively.  Only graphs that reach their last stage have one (the I3D ResNets)."""
+        gradient computed natively.  Only graphs that reach their last stage have one (the I3D ResNets; SlowFast, whose graph
+        is then built through res5 with all lateral connections)."""
         self.num_classes = num_classes
-        if num_classes is not None and "i3d" not in model_type:
-            raise KeyError(f"{model_type!r}: only the I3D graphs are built to their last stage; no native classifier head")
+        if num_classes is not None and not ("i3d" in model_type or "slowfast" in model_type):
+            raise KeyError(f"{model_type!r}: only the I3D and SlowFast graphs are built to their last stage; no native classifier head")
         self.model_type = model_type
         self.in_thw = tuple(in_thw)
         self.tiny = tiny
@@ -37,7 +38,7 @@ class VideoModel(object):
 
     def graph_for(self, thw):
         build = _graphs.build_video_tiny if self.tiny else _graphs.build_video
-        return build(self.model_type, tuple(thw))
+        return build(self.model_type, tuple(thw), full=self.num_classes is not None)
 
     def state_dict_for(self, graph):
         return self._sd if self._sd is not None else _weights.load_state_dict(graph, self.weight_seed)
@@ -47,14 +48,15 @@ class VideoModel(object):
 
     # ---- classifier head (num_classes given) ----
     def classifier_hook(self, graph):
-        """The tensor the head reads: the output of the last stage."""
-        return [graph.hooks[max(graph.hooks)]]
+        """The tensors the head pools and concatenates: the output of the last stage (I3D), or of both pathways' last
+        stages, slow first (SlowFast)."""
+        return list(graph.classifier_feats) or [graph.hooks[max(graph.hooks)]]
 
     def head_weights(self, graph):
         """(fc.weight (K, C), fc.bias (K,)) -- from the state_dict (gluoncv names its head `fc` as torchvision does) or,
         under the same opt-in rules as the backbone, seeded synthetic values."""
         import torch
-        C_ = graph.tensors[self.classifier_hook(graph)[0]].C
+        C_ = sum(graph.tensors[t].C for t in self.classifier_hook(graph))
         sd = self._sd or {}
         if "fc.weight" in sd:
             w, b = sd["fc.weight"].float(), sd.get("fc.bias")

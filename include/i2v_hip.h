@@ -220,6 +220,15 @@ size_t i2v_head_scratch_bytes(int C, int clips);
 int i2v_head_ce_f32(const float* a, int64_t a_stride, int C, int HW, int T, int clips, const float* W, const float* bias,
                     int K, const int32_t* labels, float scale, int mask_relu, int accumulate, float* logits, float* loss_each,
                     float* grad, int64_t grad_stride, void* scratch, void* stream);
+/* The same head over SEVERAL features -- SlowFast pools its slow and fast pathway separately and concatenates them in front of
+ * `fc` -- in three steps sharing one scratch block (>= i2v_head_scratch_bytes(Ctot, clips)): every feature is pooled into
+ * columns [c_off, c_off + C) of the Ctot-wide vector, one call forms logits / losses / d loss / d pooled (W[K][Ctot]), and every
+ * feature's share is spread into its gradient view (divided by its own T*HW, the average pool's backward). */
+int i2v_head_pool_f32(const float* a, int64_t a_stride, int C, int HW, int T, int clips, int Ctot, int c_off, void* scratch, void* stream);
+int i2v_head_logits_ce_f32(int Ctot, int clips, const float* W, const float* bias, int K, const int32_t* labels, float scale,
+                           float* logits, float* loss_each, void* scratch, void* stream);
+int i2v_head_grad_f32(const float* a, int64_t a_stride, int C, int HW, int T, int clips, int Ctot, int c_off, int mask_relu,
+                      int accumulate, float* grad, int64_t grad_stride, void* scratch, void* stream);
 /* Adaptive ENS-I2V re-weighting `coeffs = softmax(softmax(prev) + momentum*coeffs)`
  * (TPAMI_attack.py:265), L <= 64, in place on device. */
 int i2v_aens_coeffs_f32(const float* prev, float* coeffs, float momentum, int L, void* stream);

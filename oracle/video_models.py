@@ -103,6 +103,56 @@ class SlowFastRes2(nn.Module):
         return sr, fr
 
 
+class SlowFastNet(nn.Module):
+    """The whole SlowFast backbone (both pathways through res5, lateral connections in front of every slow stage):
+    counterpart of `graphs.slowfast_resnet`; forward returns (slow_res5, fast_res5), which a classifier head pools and
+    concatenates in that order."""
+
+    def __init__(self, layers=(3, 4, 6, 3), width=64, slow_stride=8, fast_stride=1, beta_inv=8, fusion_ratio=2, fusion_kernel=5):
+        super().__init__()
+        fw = width // beta_inv
+        self.slow_stride, self.fast_stride = slow_stride, fast_stride
+        self.fast_conv1 = nn.Conv3d(3, fw, (5, 7, 7), stride=(1, 2, 2), padding=(2, 3, 3), bias=False)
+        self.fast_bn1 = nn.BatchNorm3d(fw)
+        self.fast_maxpool = nn.MaxPool3d((1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+        self.slow_conv1 = nn.Conv3d(3, width, (1, 7, 7), stride=(1, 2, 2), padding=(0, 3, 3), bias=False)
+        self.slow_bn1 = nn.BatchNorm3d(width)
+        self.slow_maxpool = nn.MaxPool3d((1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
+        self.relu = nn.ReLU(inplace=True)
+        alpha = slow_stride // fast_stride
+
+        def lateral(c):
+            return nn.Sequential(
+                nn.Conv3d(c, c * fusion_ratio, (fusion_kernel, 1, 1), stride=(alpha, 1, 1), padding=(fusion_kernel // 2, 0, 0), bias=False),
+                nn.BatchNorm3d(c * fusion_ratio), nn.ReLU(inplace=True))
+        self.lateral_p1 = lateral(fw)
+        slow_t = (1, 1, 3, 3)
+        fin, sin = fw, width + fw * fusion_ratio
+        for li, nb in enumerate(layers):
+            stride = 1 if li == 0 else 2
+            fs, fout = _stage(fin, fw * 2 ** li, nb, stride, lambda b: 3)
+            ss, sout = _stage(sin, width * 2 ** li, nb, stride, lambda b, t=slow_t[li]: t)
+            setattr(self, f"fast_res{li + 2}", fs)
+            setattr(self, f"slow_res{li + 2}", ss)
+            if li < len(layers) - 1:
+                setattr(self, f"lateral_res{li + 2}", lateral(fout))
+                sin = sout + fout * fusion_ratio
+            fin = fout
+        self.nstages = len(layers)
+
+    def forward(self, x):
+        fast_in, slow_in = x[:, :, ::self.fast_stride], x[:, :, ::self.slow_stride]
+        f = self.fast_maxpool(self.relu(self.fast_bn1(self.fast_conv1(fast_in))))
+        s = self.slow_maxpool(self.relu(self.slow_bn1(self.slow_conv1(slow_in))))
+        s = torch.cat([s, self.lateral_p1(f)], dim=1)
+        for li in range(self.nstages):
+            f = getattr(self, f"fast_res{li + 2}")(f)
+            s = getattr(self, f"slow_res{li + 2}")(s)
+            if li < self.nstages - 1:
+                s = torch.cat([s, getattr(self, f"lateral_res{li + 2}")(f)], dim=1)
+        return s, f
+
+
 class TPNBackbone(nn.Module):
     """SlowOnly-style backbone of TPN up to `layer2` (+ `layer3` so that something runs behind the hook): stem 1x7x7,
     no temporal kernels in layer1 / layer2.  `model.layer2` is what the reference hooks (`image_attacks.py:517-518`)."""
@@ -122,8 +172,12 @@ class TPNBackbone(nn.Module):
         return self.layer3(self.layer2(self.layer1(x)))
 
 
-def make(model_type: str, tiny: bool) -> nn.Module:
+def make(model_type: str, tiny: bool, full: bool = False) -> nn.Module:
     """Counterpart of `i2v_amd.graphs.build_video` / `build_video_tiny`."""
+    if full and "slowfast" in model_type:
+        if tiny:
+            return SlowFastNet((2, 2, 1, 1), 16, slow_stride=4, fast_stride=1, beta_inv=4)
+        return SlowFastNet((3, 4, 23, 3) if "101" in model_type else (3, 4, 6, 3))
     if "tpn" in model_type:
         if tiny:
             return TPNBackbone((2, 2, 1, 1), 8)

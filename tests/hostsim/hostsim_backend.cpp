@@ -424,37 +424,43 @@ int k_ilaf_grad(const I2VIlafParams& p, i2v_stream_t) {
 
 int k_head_ce(const I2VHeadParams& p, i2v_stream_t) {
     for (int clip = 0; clip < p.clips; ++clip) {
-        for (int c = 0; c < p.C; ++c) {
-            double s = 0;
-            for (int t = 0; t < p.T; ++t) for (int px = 0; px < p.HW; ++px)
-                s += (double)p.a[((size_t)clip * p.T + t) * p.a_nstride + (size_t)c * p.HW + px];
-            p.pooled[(size_t)clip * p.C + c] = (float)(s / ((double)p.T * p.HW));
-        }
-        float* lg = p.logits + (size_t)clip * p.K;
-        double mx = -1e300;
-        for (int k = 0; k < p.K; ++k) {
-            double acc = p.bias ? (double)p.bias[k] : 0.0;
-            for (int c = 0; c < p.C; ++c) acc += (double)p.W[(size_t)k * p.C + c] * (double)p.pooled[(size_t)clip * p.C + c];
-            lg[k] = (float)acc; mx = std::max(mx, (double)lg[k]);
-        }
-        double se = 0; for (int k = 0; k < p.K; ++k) se += exp((double)lg[k] - mx);
-        const int lab = p.labels[clip];
-        p.loss_each[clip] = (float)(-((double)lg[lab] - mx - log(se)));
-        const double f = (double)p.scale / (double)p.clips;
-        for (int c = 0; c < p.C; ++c) {
-            double acc = 0;
-            for (int k = 0; k < p.K; ++k) acc += (double)p.W[(size_t)k * p.C + c] * (exp((double)lg[k] - mx) / se - (k == lab ? 1.0 : 0.0));
-            p.dpooled[(size_t)clip * p.C + c] = (float)(f * acc / ((double)p.T * p.HW));
-        }
-        for (int t = 0; t < p.T; ++t) {
-            const size_t n = (size_t)clip * p.T + t;
-            for (size_t i = 0; i < (size_t)p.C * p.HW; ++i) {
-                float v = p.dpooled[(size_t)clip * p.C + i / p.HW];
-                if (p.mask_relu && !(p.a[n * p.a_nstride + i] > 0.f)) v = 0.f;
-                float* g = p.grad + n * p.grad_nstride + i;
-                *g = p.accumulate ? *g + v : v;
+        if (p.phase & 1)
+            for (int c = 0; c < p.C; ++c) {
+                double s = 0;
+                for (int t = 0; t < p.T; ++t) for (int px = 0; px < p.HW; ++px)
+                    s += (double)p.a[((size_t)clip * p.T + t) * p.a_nstride + (size_t)c * p.HW + px];
+                p.pooled[(size_t)clip * p.Ctot + p.c_off + c] = (float)(s / ((double)p.T * p.HW));
+            }
+        if (p.phase & 2) {
+            float* lg = p.logits + (size_t)clip * p.K;
+            double mx = -1e300;
+            for (int k = 0; k < p.K; ++k) {
+                double acc = p.bias ? (double)p.bias[k] : 0.0;
+                for (int c = 0; c < p.Ctot; ++c) acc += (double)p.W[(size_t)k * p.Ctot + c] * (double)p.pooled[(size_t)clip * p.Ctot + c];
+                lg[k] = (float)acc; mx = std::max(mx, (double)lg[k]);
+            }
+            double se = 0; for (int k = 0; k < p.K; ++k) se += exp((double)lg[k] - mx);
+            const int lab = p.labels[clip];
+            p.loss_each[clip] = (float)(-((double)lg[lab] - mx - log(se)));
+            const double f = (double)p.scale / (double)p.clips;
+            for (int c = 0; c < p.Ctot; ++c) {
+                double acc = 0;
+                for (int k = 0; k < p.K; ++k) acc += (double)p.W[(size_t)k * p.Ctot + c] * (exp((double)lg[k] - mx) / se - (k == lab ? 1.0 : 0.0));
+                p.dpooled[(size_t)clip * p.Ctot + c] = (float)(f * acc);
             }
         }
+        if (p.phase & 4)
+            for (int t = 0; t < p.T; ++t) {
+                const size_t n = (size_t)clip * p.T + t;
+                const float cnt = (float)(p.T * p.HW);
+                for (size_t i = 0; i < (size_t)p.C * p.HW; ++i) {
+                    volatile float q = p.dpooled[(size_t)clip * p.Ctot + p.c_off + i / p.HW] / cnt;
+                    float v = q;
+                    if (p.mask_relu && !(p.a[n * p.a_nstride + i] > 0.f)) v = 0.f;
+                    float* g = p.grad + n * p.grad_nstride + i;
+                    *g = p.accumulate ? *g + v : v;
+                }
+            }
     }
     return 0;
 }

@@ -1,5 +1,6 @@
 """The white-box CLASSIFIER path of the BIM family with everything behind the C ABI (`attack.py:63-96`,
-`base_attacks.py:261-340`): `VideoModel(..., num_classes=K)` = I3D graph to its last stage + global-pool / fc head;
+`base_attacks.py:261-340`): `VideoModel(..., num_classes=K)` = I3D or SlowFast graph to its last stage + global-pool / fc head
+(SlowFast: both pathways pooled separately and concatenated, slow first);
 `autograd.grad(CrossEntropyLoss()(model(adv), labels), adv)` becomes forward -> `i2v_head_ce_f32` -> input-gradient.
 Checked against torch autograd in float64 on the same weights (the plain-PyTorch I3D of oracle/video_models.py + pool + fc),
 on the host simulation here and on the HIP kernels in the `gpu`-marked twin."""
@@ -12,11 +13,11 @@ from oracle import video_models as vm
 
 
 def torch_classifier(model_type, thw, seed, K):
-    g = graphs.build_video_tiny(model_type, thw)
+    g = graphs.build_video_tiny(model_type, thw, full=True)
     sd = weights.synthetic_state_dict(g, seed)
     m = video.VideoModel(model_type, thw, weight_seed=seed, tiny=True, num_classes=K)
     W, b = m.head_weights(g)
-    back = vm.load_weights(vm.make(model_type, True), sd).double()
+    back = vm.load_weights(vm.make(model_type, True, full=True), sd).double()
 
     class Net(torch.nn.Module):
         def __init__(self):
@@ -28,13 +29,14 @@ def torch_classifier(model_type, thw, seed, K):
 
         def forward(self, x):
             f = self.back(x.double())
-            return self.fc(f.mean(dim=(2, 3, 4)))
+            feats = f if isinstance(f, tuple) else (f,)
+            return self.fc(torch.cat([t.mean(dim=(2, 3, 4)) for t in feats], dim=1))
     return m, Net().eval()
 
 
-def check_gradient(eng, dev):
+def check_gradient(eng, dev, model_type="i3d_resnet50"):
     thw, K, b = (8, 32, 32), 7, 2
-    m, ref = torch_classifier("i3d_resnet50", thw, 3, K)
+    m, ref = torch_classifier(model_type, thw, 3, K)
     gen = torch.Generator().manual_seed(11)
     vid = torch.randn(b, 3, *thw, generator=gen)
     labels = torch.tensor([2, 5])
@@ -54,12 +56,12 @@ def check_gradient(eng, dev):
     return m, ref, vid, labels
 
 
-def check_attacks(eng, dev):
+def check_attacks(eng, dev, model_type="i3d_resnet50"):
     """FGSM / BIM / MI-FGSM with the native classifier against the same classes driving the float64 torch module (the
     reference's calling convention): same update kernel on both sides, so the clips agree wherever the gradient's sign is
     not decided in the last bits."""
     thw, K = (32, 32, 32), 5         # norm_grads asserts 32 frames, like the reference (utils.py:58-67)
-    m, ref = torch_classifier("i3d_resnet50", thw, 4, K)
+    m, ref = torch_classifier(model_type, thw, 4, K)
     vid = torch.randn(1, 3, *thw, generator=torch.Generator().manual_seed(12)) * 0.5
     labels = torch.tensor([1])
 
@@ -81,43 +83,52 @@ def check_attacks(eng, dev):
         assert un.min() >= -1e-5 and un.max() <= 1 + 1e-5
 
 
-def test_native_ce_gradient_hostsim():
-    from tests.hostsim_util import hostsim_engine
-    check_gradient(hostsim_engine(), "cpu")
+MODELS = ["i3d_resnet50", "slowfast_resnet50"]
 
 
-def test_native_sign_attacks_hostsim():
+@pytest.mark.parametrize("model_type", MODELS)
+def test_native_ce_gradient_hostsim(model_type):
     from tests.hostsim_util import hostsim_engine
-    check_attacks(hostsim_engine(), "cpu")
+    check_gradient(hostsim_engine(), "cpu", model_type)
+
+
+@pytest.mark.parametrize("model_type", MODELS)
+def test_native_sign_attacks_hostsim(model_type):
+    from tests.hostsim_util import hostsim_engine
+    check_attacks(hostsim_engine(), "cpu", model_type)
 
 
 def test_classifier_needs_a_full_graph():
     with pytest.raises(KeyError):
-        video.VideoModel("slowfast_resnet50", num_classes=400)
+        video.VideoModel("tpn_resnet50", num_classes=400)
     with pytest.raises(ValueError):
         from tests.hostsim_util import hostsim_engine
         sign_attacks.BIM(video.VideoModel("i3d_resnet50", (8, 32, 32), weight_seed=0, tiny=True), engine=hostsim_engine())
 
 
 @pytest.mark.gpu
-def test_native_ce_gradient_gpu():
+@pytest.mark.parametrize("model_type", MODELS)
+def test_native_ce_gradient_gpu(model_type):
     from i2v_amd import attacks
-    check_gradient(attacks.get_engine("cuda:0"), "cuda:0")
+    check_gradient(attacks.get_engine("cuda:0"), "cuda:0", model_type)
 
 
 @pytest.mark.gpu
-def test_native_sign_attacks_gpu():
+@pytest.mark.parametrize("model_type", MODELS)
+def test_native_sign_attacks_gpu(model_type):
     from i2v_amd import attacks
-    check_attacks(attacks.get_engine("cuda:0"), "cuda:0")
+    check_attacks(attacks.get_engine("cuda:0"), "cuda:0", model_type)
 
 
 @pytest.mark.gpu
-def test_native_classifier_full_size_i3d_r50():
-    """One 32 x 224^2 clip through the whole I3D-ResNet-50 (all four stages) + 400-way head and back: finite, non-trivial
-    gradient, reproducible, and BIM moves the clip within its eps box."""
+@pytest.mark.parametrize("model_type", MODELS)
+def test_native_classifier_full_size(model_type):
+    """One 32 x 224^2 clip through the whole I3D-ResNet-50 / SlowFast-R50 (all four stages; SlowFast: both pathways and the four
+    lateral connections) + 400-way head and back: finite, non-trivial gradient, reproducible, and BIM moves the clip within its
+    eps box."""
     from i2v_amd import attacks
     eng = attacks.get_engine("cuda:0")
-    m = video.VideoModel("i3d_resnet50", (32, 224, 224), weight_seed=0, num_classes=400)
+    m = video.VideoModel(model_type, (32, 224, 224), weight_seed=0, num_classes=400)
     vid = torch.randn(1, 3, 32, 224, 224, generator=torch.Generator().manual_seed(1)).clamp(-2, 2)
     atk = sign_attacks.BIM(m, steps=2, engine=eng)
     g = atk._grad(vid.to("cuda:0"), torch.tensor([7]))
@@ -127,3 +138,32 @@ def test_native_classifier_full_size_i3d_r50():
     std = torch.tensor(sign_attacks.STD).view(1, 3, 1, 1, 1)
     un = adv * std + torch.tensor(sign_attacks.MEAN).view(1, 3, 1, 1, 1)
     assert un.min() >= -1e-5 and un.max() <= 1 + 1e-5 and not torch.equal(adv, vid)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_type", MODELS)
+def test_native_classifier_full_architecture_vs_torch(model_type):
+    """The FULL-depth I3D-R50 / SlowFast-R50 graphs (every stage, every lateral connection, real channel widths) + 400-way
+    head on a 32 x 64^2 clip against torch autograd in float64 on the same weights: logits, loss, and the input gradient
+    (relative L2: a handful of the ~10^7 ReLU gates / arg-max windows are decided differently in fp32)."""
+    from i2v_amd import attacks
+    eng = attacks.get_engine("cuda:0")
+    thw, K = (32, 64, 64), 400
+    m = video.VideoModel(model_type, thw, weight_seed=5, num_classes=K)
+    g = m.graph_for(thw)
+    W, b = m.head_weights(g)
+    back = vm.load_weights(vm.make(model_type, False, full=True), weights.synthetic_state_dict(g, 5)).double()
+    vid = torch.randn(1, 3, *thw, generator=torch.Generator().manual_seed(21))
+    labels = torch.tensor([123])
+    atk = sign_attacks.BIM(m, steps=1, engine=eng)
+    gx = atk._grad(vid.to("cuda:0"), labels).cpu().double()
+    x = vid.double().requires_grad_(True)
+    f = back(x)
+    feats = f if isinstance(f, tuple) else (f,)
+    logits = torch.cat([t.mean(dim=(2, 3, 4)) for t in feats], dim=1) @ W.double().t() + b.double()
+    loss = torch.nn.CrossEntropyLoss()(logits, labels)
+    gref = torch.autograd.grad(loss, x)[0]
+    np.testing.assert_allclose(atk.last_logits.cpu().double().numpy(), logits.detach().numpy(), rtol=2e-3, atol=2e-4)
+    assert abs(float(atk.last_loss) - float(loss.detach())) < 1e-4 * max(1.0, abs(float(loss.detach())))
+    rel = float((gx - gref).norm() / gref.norm())
+    assert rel < 5e-3, rel
