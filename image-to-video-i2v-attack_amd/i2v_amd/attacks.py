@@ -199,8 +199,10 @@ class _ImageGuided(Attack):
         if aens:
             costs = weighted.mean(dim=1).cpu().numpy().astype(np.float32)   # TPAMI_attack.py:291
             self.weights = [wts[i].cpu().numpy() for i in range(steps)]     # :266
+        elif mode == "std":
+            costs = vals[:steps].sum(dim=(1, 2)).cpu().numpy().astype(np.float32)   # image_attacks.py:218 (one value per step)
         else:
-            costs = vals[:steps].sum(dim=(1, 2)).cpu().numpy().astype(np.float32)   # image_attacks.py:347
+            costs, self.last_clip_costs = _canonical_costs(vals[:steps].cpu().numpy(), b, f)   # image_attacks.py:347
         self.last_costs = costs
         self.last_values = vals
         for vid_name in video_names:                                    # :355-358 (batch-total cost per name)
@@ -304,9 +306,10 @@ class _ImageGuided(Attack):
         if errors:
             raise errors[0]
         self.used_time = time.time() - begin
-        costs = self._lanes[0].last_costs.copy()
-        for lane in self._lanes[1:]:
-            costs = (costs + lane.last_costs).astype(np.float32)
+        # the lanes' per-frame loss values side by side in frame order = what one lane would have produced: the reported cost
+        # does not depend on the split either
+        vals = np.concatenate([lane.last_values[:self.steps].cpu().numpy() for lane in self._lanes], axis=2)
+        costs, self.last_clip_costs = _canonical_costs(vals, b, f)
         self.last_costs = costs
         self._delta = torch.cat([lane._delta for lane in self._lanes])      # frame order: (clip, frame) in both splits
         for vid_name in video_names:                                    # image_attacks.py:355-358 (batch-total cost per name)
@@ -320,6 +323,50 @@ class _ImageGuided(Attack):
         if n_lanes > 1:
             return self._run_lanes(videos.detach().to(device=self.engine.device, dtype=torch.float32), video_names, n_lanes)
         return self._run(videos, video_names)
+
+    def forward_grouped(self, batches):
+        """Several loader batches `(videos, labels, video_names)` in ONE engine call (the reference CLI's default is
+        `--batch_size 1`: a single 32-frame clip leaves the 14x14 layers with 1.5 blocks per CU).  Frames are independent
+        in I2V / ENS-I2V and no kernel's summation order depends on the batch, so every clip comes out bit-identical to its
+        own call; `loss_info` gets, per batch, the cost of THAT batch's frames (what its own call would have logged).
+        Returns the list of per-batch outputs.  Attacks that couple the batch (adaptive ENS, DR) run batch by batch."""
+        batches = list(batches)
+        if self._mode != "i2v" or len(batches) == 1:
+            return [self(v, l, n) for v, l, n in batches]
+        sizes = [int(v.shape[0]) for v, _, _ in batches]
+        dev = self.engine.device
+        videos = torch.cat([v.detach().to(device=dev, dtype=torch.float32) for v, _, _ in batches])
+        labels = torch.cat([torch.as_tensor(l).reshape(-1) for _, l, _ in batches])
+        names = [n for _, _, ns in batches for n in ns]
+        out = self(videos, labels, names)
+        cc, at, outs = self.last_clip_costs, 0, []
+        for (v, l, ns), nb in zip(batches, sizes):
+            cost = _sum_in_order(cc[:, at:at + nb])
+            for n in ns:
+                for i in range(self.steps):
+                    self.loss_info[n][i] = {"cost": str(cost[i])}
+            outs.append(out[at:at + nb])
+            at += nb
+        return outs
+
+
+def _sum_in_order(a):
+    """fp32 sum over the last axis, left to right (a fixed order, whatever the length)."""
+    acc = np.zeros(a.shape[:-1], np.float32)
+    for k in range(a.shape[-1]):
+        acc = (acc + a[..., k]).astype(np.float32)
+    return acc
+
+
+def _canonical_costs(vals, b, f):
+    """`cost = sum(stack(losses))` (image_attacks.py:347) from the per-frame loss values `vals` (steps, L, b*f), in an order
+    that does not depend on how the batch was executed: every clip's (L, f) values are summed on their own (numpy's
+    pairwise sum of a contiguous run of L*f floats), then the clips left to right.  Returns (costs (steps,), per-clip
+    costs (steps, b)) -- clip lanes, grouped loader batches and a plain call all log the same strings."""
+    steps, L, N = vals.shape
+    per_clip = np.ascontiguousarray(vals.reshape(steps, L, b, f).transpose(0, 2, 1, 3)).reshape(steps, b, L * f)
+    clip_costs = per_clip.sum(axis=2, dtype=np.float32)
+    return _sum_in_order(clip_costs), clip_costs
 
 
 class ImageGuidedFMDirection_Adam(_ImageGuided):

@@ -48,6 +48,9 @@ def arg_parse(argv=None):
     parser.add_argument("--frames", type=int, default=32)
     parser.add_argument("--hw", type=int, default=224)
     parser.add_argument("--resume", action="store_true")
+    parser.add_argument("--group_clips", type=int, default=4,
+                        help="attack up to this many clips of READY loader batches in one engine call (I2V / ENS-I2V only; same clips, "
+                             "same logged costs as batch-by-batch; 1 = one call per loader batch as in the reference)")
     parser.add_argument("--synthetic_weights", action="store_true",
                         help="run on the seeded synthetic initialiser when no checkpoint lies under $I2V_WEIGHTS_DIR "
                              "(same as I2V_SYNTHETIC_WEIGHTS=1); without it a missing checkpoint is an error")
@@ -93,7 +96,8 @@ def main(argv=None):
     # or np.load), results are copied to pinned host memory asynchronously and written by a writer thread,
     # so the GPU goes straight from one batch to the next (the reference loads, attacks and np.saves serially,
     # image_main.py:82-92).
-    todo = queue.Queue(maxsize=2)
+    group = max(1, args.group_clips)
+    todo = queue.Queue(maxsize=max(2, group))
     done = queue.Queue(maxsize=4)
 
     def reader():
@@ -122,28 +126,49 @@ def main(argv=None):
     threads = [threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)]
     for t in threads:
         t.start()
-    while True:
-        item = todo.get()
-        if item is None:
+    ended = False
+    while not ended:
+        # Loader batches that are READY are attacked in one engine call, up to --group_clips clips (frames are independent in
+        # I2V / ENS-I2V: every clip and every logged cost is what the batch's own call produces, `forward_grouped`); the
+        # reference's default `--batch_size 1` alone would leave the GPU a third empty.  Nothing waits for a batch that is
+        # not there yet.
+        items, nclips = [], 0
+        while nclips < group:
+            try:
+                item = todo.get() if not items else todo.get_nowait()
+            except queue.Empty:
+                break
+            if item is None:
+                ended = True
+                break
+            items.append(item)
+            nclips += int(item[1].shape[0])
+        if not items:
             break
-        step, val_batch, val_label, video_names = item
-        print("Running {}, {}/{}".format(args.attack_method, step + 1, total))
-        if val_batch.dtype == torch.uint8:          # decoded frames (b,t,H,W,3): the loader's Resize/CenterCrop/ToTensor/Normalize on the device
-            from i2v_amd import attacks as _attacks
-            eng = _attacks.get_engine()
-            val_batch = eng.clip_resize_crop(val_batch.to(eng.device, non_blocking=True).contiguous(), crop=args.hw)
-        adv_batches = attack_method(val_batch, val_label, video_names)
-        if isinstance(adv_batches, tuple):                             # AENS returns (adv, time, costs)
-            adv_batches = adv_batches[0]
-        adv_batches = adv_batches.detach()
-        if adv_batches.is_cuda:
-            host = torch.empty(adv_batches.shape, dtype=adv_batches.dtype, pin_memory=True)
-            host.copy_(adv_batches, non_blocking=True)
-            event = torch.cuda.Event()
-            event.record(torch.cuda.current_stream(adv_batches.device))
+        batches = []
+        for step, val_batch, val_label, video_names in items:
+            print("Running {}, {}/{}".format(args.attack_method, step + 1, total))
+            if val_batch.dtype == torch.uint8:          # decoded frames (b,t,H,W,3): the loader's Resize/CenterCrop/ToTensor/Normalize on the device
+                from i2v_amd import attacks as _attacks
+                eng = _attacks.get_engine()
+                val_batch = eng.clip_resize_crop(val_batch.to(eng.device, non_blocking=True).contiguous(), crop=args.hw)
+            batches.append((val_batch, val_label, video_names))
+        if len(batches) > 1 and hasattr(attack_method, "forward_grouped"):
+            outs = attack_method.forward_grouped(batches)
         else:
-            host, event = adv_batches.contiguous(), None
-        done.put((val_label, host, event))
+            outs = [attack_method(*bt) for bt in batches]
+        for (_, val_label, _), adv_batches in zip(batches, outs):
+            if isinstance(adv_batches, tuple):                             # AENS returns (adv, time, costs)
+                adv_batches = adv_batches[0]
+            adv_batches = adv_batches.detach()
+            if adv_batches.is_cuda:
+                host = torch.empty(adv_batches.shape, dtype=adv_batches.dtype, pin_memory=True)
+                host.copy_(adv_batches, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record(torch.cuda.current_stream(adv_batches.device))
+            else:
+                host, event = adv_batches.contiguous(), None
+            done.put((val_label, host, event))
     done.put(None)
     threads[1].join()
     with open(os.path.join(args.adv_path, "loss_info_{}.json".format(args.batch_index)), "w") as opt:

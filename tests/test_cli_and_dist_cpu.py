@@ -48,6 +48,29 @@ def test_image_main_file_contract(tiny_engine, tmp_path, monkeypatch):
         image_main.main(["--num_clips", "1"])
 
 
+def test_image_main_grouped_batches_are_byte_identical(tiny_engine, tmp_path, monkeypatch):
+    """`--group_clips`: ready loader batches share one engine call.  Every `{label}-adv.npy` and every logged cost string must
+    equal what one call per loader batch (`--group_clips 1`, the reference's behaviour) writes -- also with clip lanes on."""
+    import importlib
+    import image_main
+    outs = {}
+    for tag, extra, lanes in (("one", ["--group_clips", "1"], "1"), ("grp", ["--group_clips", "3"], "1"), ("grp_lanes", ["--group_clips", "4"], "2")):
+        monkeypatch.setenv("I2V_OPT_PATH", str(tmp_path / tag))
+        monkeypatch.setenv("I2V_CLIP_LANES", lanes)
+        (tmp_path / tag).mkdir()
+        importlib.reload(image_main)
+        image_main.main(["--attack_method", "ImageGuidedFMDirection_Adam", "--step", "3", "--step_size", "0.005", "--depth", "2",
+                         "--direction_image_model", "resnet", "--num_clips", "5", "--frames", "2", "--hw", "64", "--file_prefix", "t"] + extra)
+        d = tmp_path / tag / "Image-ImageGuidedFMDirection_Adam-3-t"
+        outs[tag] = ({f: np.load(d / f) for f in sorted(os.listdir(d)) if f.endswith(".npy")}, json.load(open(d / "loss_info_1.json")))
+    files, info = outs["one"]
+    assert len(files) == 5 and len(info) == 5
+    for tag in ("grp", "grp_lanes"):
+        f2, i2 = outs[tag]
+        assert sorted(f2) == sorted(files) and all(np.array_equal(f2[k], files[k]) for k in files), tag
+        assert i2 == info, tag
+
+
 def test_image_fine_tune_attack_file_contract(tiny_engine, tmp_path):
     """`{id}-adv.npy` + `{id}-ori.npy` in, `{label}-adv.npy` out (/root/reference/image_fine_tune_attack.py:16-37,73-82),
     ILAF running natively on a (tiny) I3D graph."""

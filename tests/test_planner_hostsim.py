@@ -149,7 +149,7 @@ def test_clip_lanes_are_bit_identical():
         two.clip_lanes = 2
         got = two(vid, torch.zeros(3, dtype=torch.long), names)
         assert torch.equal(got, ref) and torch.equal(two._delta, one._delta)
-        np.testing.assert_allclose(two.last_costs, one.last_costs, rtol=1e-6)
+        assert np.array_equal(two.last_costs, one.last_costs)      # canonical per-clip summation: the split does not show in the log either
         assert list(two.loss_info) == names and two.loss_info["c"][0]["cost"] == str(two.last_costs[0])
         assert len(two._lanes) == 2 and two._lanes[0]._nets[0].max_frames == 2 and two._lanes[1]._nets[0].max_frames == 4
         again = two(vid, torch.zeros(3, dtype=torch.long), names)      # lanes and their nets are reused
@@ -163,7 +163,7 @@ def test_clip_lanes_are_bit_identical():
     assert two._lane_count(1, 16) == 2 and two._lane_count(1, 8) == 1
     got = two(long_clip, torch.zeros(1, dtype=torch.long), ["v"])
     assert got.shape == ref.shape and torch.equal(got, ref) and torch.equal(two._delta, one._delta)
-    np.testing.assert_allclose(two.last_costs, one.last_costs, rtol=1e-6)
+    assert np.array_equal(two.last_costs, one.last_costs)      # canonical per-clip summation: the split does not show in the log either
     dr = attacks.ImageGuidedStd_Adam(["resnet"], depth=2, step_size=0.005, steps=1, engine=hostsim_engine(), graph_builder=graphs.build_tiny)
     dr.clip_lanes = 2
     assert dr._lane_count(3) == 1                           # DR couples the whole batch: never split
