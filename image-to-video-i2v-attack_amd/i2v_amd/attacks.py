@@ -256,18 +256,33 @@ class _ImageGuided(Attack):
         units = b if b > 1 else f // 8            # a lane of fewer than 8 frames does not pay
         return max(1, min(int(n), units))
 
-    def _run_lanes(self, videos, video_names, n_lanes):
-        eng = self.engine
-        dev = eng.device
-        cuda = dev.type == "cuda"
-        b, _, f, h, w = videos.shape
-        video_names = list(video_names)
+    def _make_lanes(self, n_lanes):
         if len(getattr(self, "_lanes", [])) != n_lanes:
             self._lanes = []
             for _ in range(n_lanes):
                 lane = copy.copy(self)
                 lane._nets, lane._net_key, lane.loss_info, lane._lanes = None, None, {}, []
                 self._lanes.append(lane)
+
+    def reserve(self, clips, frames, hw):
+        """Plan (pack, upload, autotune) now for the LARGEST batch the caller will send -- `clips` clips of `frames` frames at
+        `hw` -- so that a run whose batches grow (a CLI grouping whatever its loader has ready) never re-plans on the way."""
+        n_lanes = self._lane_count(clips, frames)
+        if n_lanes > 1:
+            self._make_lanes(n_lanes)
+            share = -(-clips // n_lanes) * frames if clips > 1 else -(-frames // n_lanes)
+            for lane in self._lanes:
+                lane._get_nets(share, tuple(hw))
+        else:
+            self._get_nets(clips * frames, tuple(hw))
+
+    def _run_lanes(self, videos, video_names, n_lanes):
+        eng = self.engine
+        dev = eng.device
+        cuda = dev.type == "cuda"
+        b, _, f, h, w = videos.shape
+        video_names = list(video_names)
+        self._make_lanes(n_lanes)
         for lane in self._lanes:                        # the caller may have changed these between calls (legal on the
             lane.steps, lane.step_size, lane.epsilon = self.steps, self.step_size, self.epsilon    # reference classes)
         by_frames = b == 1                              # one clip: the lanes take frame ranges of it

@@ -34,7 +34,7 @@ def sample_list(csv_path=None, n=400):
     return [(f"synthetic/{i:03d}.mp4", i) for i in range(n)]
 
 
-def batches(batch_size, csv_path=None, clip_dir=None, frames=32, hw=224, n=400):
+def batches(batch_size, csv_path=None, clip_dir=None, frames=32, hw=224, n=400, workers=0):
     """Yields (val_batch (b,3,f,h,w), val_label (b,), video_names) like the reference's DataLoader.  A `clip_dir` of
     `{label}-raw.npy` files -- DECODED uint8 frames (t,H,W,3), what decord hands the reference's loader
     (datasets.py:226-244) -- yields uint8 batches (b,t,H,W,3) instead: the caller runs the validation transform on the
@@ -47,11 +47,33 @@ def batches(batch_size, csv_path=None, clip_dir=None, frames=32, hw=224, n=400):
         items = [(os.path.basename(p), int(os.path.basename(p).split("-")[0]), p) for p in files]
     else:
         items = [(name, label, None) for name, label in sample_list(csv_path, n)]
-    for s in range(0, len(items), batch_size):
+    def load(s):
         chunk = items[s:s + batch_size]
         clips = [torch.from_numpy(np.load(p)) if p else synthetic_clip(s + i, frames, hw)
                  for i, (_, _, p) in enumerate(chunk)]
-        yield torch.stack(clips), torch.tensor([c[1] for c in chunk]), [c[0] for c in chunk]
+        return torch.stack(clips), torch.tensor([c[1] for c in chunk]), [c[0] for c in chunk]
+    starts = list(range(0, len(items), batch_size))
+    if workers <= 0:
+        for s in starts:
+            yield load(s)
+        return
+    # `workers` loader threads, a window of 2 x workers batches in flight, results in order (np.load and the synthetic
+    # generator release the GIL): what the reference's DataLoader workers are for
+    import collections
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(workers) as ex:
+        window = collections.deque()
+        it = iter(starts)
+        for s in it:
+            window.append(ex.submit(load, s))
+            if len(window) >= 2 * workers:
+                break
+        while window:
+            out = window.popleft().result()
+            nxt = next(it, None)
+            if nxt is not None:
+                window.append(ex.submit(load, nxt))
+            yield out
 
 
 def num_batches(batch_size, csv_path=None, clip_dir=None, n=400):

@@ -48,6 +48,7 @@ def arg_parse(argv=None):
     parser.add_argument("--frames", type=int, default=32)
     parser.add_argument("--hw", type=int, default=224)
     parser.add_argument("--resume", action="store_true")
+    parser.add_argument("--workers", type=int, default=2, help="loader threads (0: load in the reader thread itself)")
     parser.add_argument("--group_clips", type=int, default=4,
                         help="attack up to this many clips of READY loader batches in one engine call (I2V / ENS-I2V only; same clips, "
                              "same logged costs as batch-by-batch; 1 = one call per loader batch as in the reference)")
@@ -97,13 +98,16 @@ def main(argv=None):
     # so the GPU goes straight from one batch to the next (the reference loads, attacks and np.saves serially,
     # image_main.py:82-92).
     group = max(1, args.group_clips)
+    if group > args.batch_size and hasattr(attack_method, "reserve") and getattr(attack_method, "_mode", "") == "i2v":
+        attack_method.reserve(max(group, args.batch_size), args.frames, (args.hw, args.hw))     # plan once, for the largest group
     todo = queue.Queue(maxsize=max(2, group))
     done = queue.Queue(maxsize=4)
 
     def reader():
         if cuda:
             torch.cuda.set_device(device)      # per-thread state: pin_memory() would otherwise create a context on device 0
-        for step, item in enumerate(clips.batches(args.batch_size, args.anno, args.clip_dir, args.frames, args.hw, args.num_clips)):
+        for step, item in enumerate(clips.batches(args.batch_size, args.anno, args.clip_dir, args.frames, args.hw, args.num_clips,
+                                                   workers=args.workers)):
             if not (left <= step < right):
                 continue
             if args.resume and all(os.path.exists(os.path.join(args.adv_path, f"{l.item()}-adv.npy")) for l in item[1]):
