@@ -19,12 +19,13 @@ import numpy as np
 import torch
 
 import base_attacks
+import video_attacks
 from i2v_amd import clips
 
 OPT_PATH = os.environ.get("I2V_OPT_PATH", "")
-IGNORED = ["--sf_frame", "--cf_frame", "--kernlen", "--nsig", "--kernel_mode", "--augmentation_weight", "--gamma",
-           "--momentum_weight", "--move_type"]
-IGNORED_FLAGS = ["--iterative_momentum", "--frame_conv", "--frame_momentum", "--no_iterative_momentum", "--weight_add",
+# flags the reference parses but no code path reads (attack.py:24-51 there)
+IGNORED = ["--sf_frame", "--cf_frame", "--nsig", "--gamma", "--momentum_weight"]
+IGNORED_FLAGS = ["--frame_conv", "--frame_momentum", "--no_iterative_momentum", "--weight_add",
                  "--iterative_first", "--translation_invariant", "--temporal_augmentation", "--TI_First", "--noise",
                  "--shuffle_grads"]
 
@@ -38,10 +39,16 @@ def arg_parse(argv=None):
     parser.add_argument("--attack_type", type=str, default="image", help="image | video")
     parser.add_argument("--step", type=int, default=10, metavar="N")
     parser.add_argument("--file_prefix", type=str, default="")
+    # TemporalTranslation (attack.py:28,32-33,38,51,79 of the reference)
+    parser.add_argument("--kernlen", type=int, default=15, metavar="N")
+    parser.add_argument("--kernel_mode", type=str, default="gaussian")
+    parser.add_argument("--iterative_momentum", action="store_true", default=False)
+    parser.add_argument("--augmentation_weight", type=float, default=1.0)
+    parser.add_argument("--move_type", type=str, default="adj", help="adj | large | random")
     for f in IGNORED:
-        parser.add_argument(f, default=None, help="video_attacks.py parameter (out of scope, ignored)")
+        parser.add_argument(f, default=None, help="parsed by the reference, read by nothing")
     for f in IGNORED_FLAGS:
-        parser.add_argument(f, action="store_true", default=False, help="video_attacks.py switch (out of scope, ignored)")
+        parser.add_argument(f, action="store_true", default=False, help="parsed by the reference, read by nothing")
     # additions (not in the reference)
     parser.add_argument("--model_factory", type=str, default="reference:proxy",
                         help="pkg.module:function (name -> torch classifier), or 'native' for the I3D / SlowFast graphs with a native classifier head")
@@ -62,8 +69,8 @@ def main(argv=None):
     if "LOCAL_RANK" not in os.environ:
         os.environ["LOCAL_RANK"] = args.gpu.split(",")[0]
     print(args)
-    if args.attack_type != "image":
-        raise NotImplementedError("--attack_type video drives video_attacks.py, which is outside this build's hot path")
+    if args.attack_type not in ("image", "video"):
+        raise UnboundLocalError("local variable 'attack_method' referenced before assignment")      # as the reference ends up (:75-82)
     dev = torch.device(f"cuda:{os.environ['LOCAL_RANK']}" if torch.cuda.is_available() else "cpu")
     if args.model_factory == "native":        # graph IR + classifier head: the whole white-box gradient behind the C ABI
         from i2v_amd.video import VideoModel
@@ -71,7 +78,15 @@ def main(argv=None):
     else:
         mod, fn = args.model_factory.split(":")
         model = getattr(importlib.import_module(mod), fn)(args.model).to(dev)
-    attack_method = getattr(base_attacks, args.attack_method)(model, steps=args.step)   # AttributeError for the default name, as in the reference (:22)
+    if args.attack_type == "image":
+        attack_method = getattr(base_attacks, args.attack_method)(model, steps=args.step)   # AttributeError for the default name, as in the reference (:22)
+    else:
+        if args.attack_method == "TemporalTranslation":                                         # :78-79
+            spe_params = {"kernlen": args.kernlen, "momentum": args.iterative_momentum, "weight": args.augmentation_weight,
+                          "move_type": args.move_type, "kernel_mode": args.kernel_mode}
+        print("Used Params")
+        print(spe_params)                                                                       # UnboundLocalError for any other name, as there
+        attack_method = getattr(video_attacks, args.attack_method)(model, params=spe_params, steps=args.step)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     total = clips.num_batches(args.batch_size, args.anno, args.clip_dir, args.num_clips)
     for step, (val_batch, val_label, _) in enumerate(clips.batches(args.batch_size, args.anno, args.clip_dir, args.frames,

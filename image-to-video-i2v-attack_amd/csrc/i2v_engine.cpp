@@ -1402,6 +1402,14 @@ extern "C" int i2v_head_grad_f32(const float* a, int64_t a_stride, int C, int HW
     return 0;
 }
 
+extern "C" int i2v_tt_grad_mix_f32(const float* grads, float* out, const float* kernel, const int32_t* moves, int D, int64_t NC, int T, int HW,
+                                  float weight, void* stream) {
+    if (!grads || !out || !kernel || !moves || D <= 0 || D > 64 || NC <= 0 || T <= 0 || HW <= 0) return fail("i2v_tt_grad_mix_f32: bad argument");
+    const float w1 = (float)(1.0 - (double)weight);           // python: (1 - self.weight) in double, then a float32 tensor scalar
+    CHECK_BE(k_tt_grad_mix(grads, out, kernel, (const int*)moves, D, NC, T, HW, w1, weight, stream));
+    return 0;
+}
+
 extern "C" int i2v_aens_coeffs_f32(const float* prev, float* coeffs, float momentum, int L, void* stream) {
     if (!prev || !coeffs || L <= 0 || L > 64) return fail("i2v_aens_coeffs_f32: bad argument");
     CHECK_BE(k_aens_coeffs(prev, coeffs, momentum, L, stream));

@@ -1592,6 +1592,32 @@ int k_sign_delta_gx(float* delta, const float* gx, const float* u, int64_t n, fl
     hipLaunchKernelGGL(sign_delta_gx_kernel, dim3(stream_grid(n, 1024)), dim3(256), 0, (hipStream_t)s, delta, gx, u, n, eps, step);
     LAUNCH_CHECK("sign_delta_gx"); return 0;
 }
+// Temporal-translation gradient augmentation (video_attacks.py:160-175): grads (D, NC, T, HW) are the input gradients of D
+// cyclically frame-shifted copies of a clip; out = (1-w) * sum_d k[d] g_d  +  w * sum_d k[d] roll(g_d, -move_d along T), the
+// two sums as fmaf chains over d in order (the reference's 1 x D matmul), then two products and one addition as torch forms them.
+struct TTMix { float k[64]; int move[64]; };
+__global__ void __launch_bounds__(256) tt_grad_mix_kernel(const float* __restrict__ g, float* __restrict__ out, const TTMix m, const int D,
+                                                          const int64_t M, const int T, const int HW, const float w1, const float w) {
+    const int64_t per = (int64_t)T * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
+        const int64_t nc = i / per; const int r = (int)(i - nc * per); const int t = r / HW, x = r - t * HW;
+        float s = 0.f, d = 0.f;
+        for (int k = 0; k < D; ++k) {
+            const float* gk = g + (int64_t)k * M + nc * per;
+            int ts = (t + m.move[k]) % T; if (ts < 0) ts += T;
+            s = fmaf(m.k[k], gk[r], s);
+            d = fmaf(m.k[k], gk[(int64_t)ts * HW + x], d);
+        }
+        out[i] = __fadd_rn(__fmul_rn(w1, s), __fmul_rn(w, d));
+    }
+}
+int k_tt_grad_mix(const float* grads, float* out, const float* kern, const int* moves, int D, int64_t NC, int T, int HW, float w1, float w,
+                  i2v_stream_t s) {
+    TTMix m; for (int k = 0; k < D; ++k) { m.k[k] = kern[k]; m.move[k] = moves[k]; }
+    const int64_t M = NC * T * HW;
+    hipLaunchKernelGGL(tt_grad_mix_kernel, dim3(stream_grid(M, 1024)), dim3(256), 0, (hipStream_t)s, grads, out, m, D, M, T, HW, w1, w);
+    LAUNCH_CHECK("tt_grad_mix"); return 0;
+}
 int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t s) {
     hipLaunchKernelGGL(aens_coeffs_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, prev, coeffs, momentum, L);
     LAUNCH_CHECK("aens_coeffs"); return 0;

@@ -145,6 +145,18 @@ class Engine:
     def sign_step_delta(self, delta, grad, step):
         _lib.check(self.capi, self.capi.i2v_sign_step_delta_f32(_ptr(delta), _ptr(grad), delta.numel(), step, self.stream()))
 
+    def tt_grad_mix(self, grads, kernel, moves, weight):
+        """`TemporalTranslation._grad_augmentation` (video_attacks.py:160-175): grads (D, N, C, T, H, W) on the device, kernel /
+        moves host sequences of length D -> (N, C, T, H, W)."""
+        import numpy as np
+        D, N, C_, T, H, W = grads.shape
+        k = np.ascontiguousarray(np.asarray(kernel, dtype=np.float32).reshape(D))
+        mv = np.ascontiguousarray(np.asarray(moves, dtype=np.int32).reshape(D))
+        out = torch.empty(N, C_, T, H, W, dtype=torch.float32, device=grads.device)
+        _lib.check(self.capi, self.capi.i2v_tt_grad_mix_f32(_ptr(grads.contiguous()), _ptr(out), C.c_void_p(k.ctypes.data), C.c_void_p(mv.ctypes.data),
+                                                            D, N * C_, T, H * W, float(weight), self.stream()))
+        return out
+
     def aens_coeffs(self, prev, coeffs, momentum):
         _lib.check(self.capi, self.capi.i2v_aens_coeffs_f32(_ptr(prev), _ptr(coeffs), momentum, coeffs.numel(), self.stream()))
 

@@ -229,6 +229,13 @@ int i2v_head_logits_ce_f32(int Ctot, int clips, const float* W, const float* bia
                            float* logits, float* loss_each, void* scratch, void* stream);
 int i2v_head_grad_f32(const float* a, int64_t a_stride, int C, int HW, int T, int clips, int Ctot, int c_off, int mask_relu,
                       int accumulate, float* grad, int64_t grad_stride, void* scratch, void* stream);
+/* Temporal-translation attack (`video_attacks.py:14-229`, the white-box video attack `attack.py --attack_type video` runs): the
+ * gradient augmentation `_grad_augmentation` (:160-175) in one pass.  grads: (D, NC, T, HW) device floats = input gradients of the D
+ * cyclically frame-shifted copies of a clip (NC = clips * channels); kernel[D] (host: the temporal Gaussian / linear / uniform
+ * weights, :49-80), moves[D] (host: `cycle_move_list`, :46-48); out (NC, T, HW) =
+ * (1 - weight) * sum_d kernel[d] * grads[d]  +  weight * sum_d kernel[d] * roll(grads[d], -moves[d] along T). */
+int i2v_tt_grad_mix_f32(const float* grads, float* out, const float* kernel, const int32_t* moves, int D, int64_t NC, int T, int HW,
+                        float weight, void* stream);
 /* Adaptive ENS-I2V re-weighting `coeffs = softmax(softmax(prev) + momentum*coeffs)`
  * (TPAMI_attack.py:265), L <= 64, in place on device. */
 int i2v_aens_coeffs_f32(const float* prev, float* coeffs, float momentum, int L, void* stream);

@@ -9,6 +9,7 @@ only their missing third-party imports are stubbed:
   gluoncv.torch.engine.config           (utils.py:2, via base_attacks)-> stub
   torchvision.models.{resnet101,...}    (image_attacks.py:88-101)     -> oracle/tv_models.py nets
   Tensor.cuda / Module.cuda             (image_attacks.py:45,103,...) -> identity
+  numpy.math                            (video_attacks.py:69; removed in NumPy 2) -> the math module
 
 Nothing here is reference code.
 """
@@ -80,6 +81,10 @@ def install():
     tv.models = tvm
     sys.modules["torchvision"] = tv
     sys.modules["torchvision.models"] = tvm
+    import math
+    import numpy
+    if not hasattr(numpy, "math"):          # `np.math.exp` (video_attacks.py:69): the alias NumPy 2 removed
+        numpy.math = math
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self
     _installed = True
@@ -97,7 +102,7 @@ def quiet():
 
 
 _REF_MODULES = {}
-_COLLIDING = ("image_attacks", "TPAMI_attack", "base_attacks", "utils", "image_main", "run_image_guided")
+_COLLIDING = ("image_attacks", "TPAMI_attack", "base_attacks", "utils", "image_main", "run_image_guided", "video_attacks")
 
 
 def import_reference(module: str):

@@ -580,6 +580,24 @@ int k_sign_delta_gx(float* delta, const float* gx, const float* u, int64_t n, fl
     return 0;
 }
 
+int k_tt_grad_mix(const float* grads, float* out, const float* kern, const int* moves, int D, int64_t NC, int T, int HW, float w1, float w,
+                  i2v_stream_t) {
+    const int64_t per = (int64_t)T * HW, M = NC * per;
+    for (int64_t i = 0; i < M; ++i) {
+        const int64_t nc = i / per; const int r = (int)(i - nc * per); const int t = r / HW, x = r - t * HW;
+        float s = 0.f, d = 0.f;
+        for (int k = 0; k < D; ++k) {
+            const float* gk = grads + (int64_t)k * M + nc * per;
+            int ts = (t + moves[k]) % T; if (ts < 0) ts += T;
+            s = fmaf(kern[k], gk[r], s);
+            d = fmaf(kern[k], gk[(int64_t)ts * HW + x], d);
+        }
+        volatile float a = w1 * s; volatile float b = w * d;
+        out[i] = a + b;
+    }
+    return 0;
+}
+
 int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t) {
     std::vector<float> a(L), b(L);
     float mx = -INFINITY, sum = 0.f;

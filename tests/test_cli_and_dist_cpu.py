@@ -117,7 +117,7 @@ def test_attack_cli_feeds_fine_tune(tiny_engine, tmp_path, monkeypatch):
     assert 0 < np.abs((adv - ori) * std).max() <= 16 / 255 + 1e-6
     with pytest.raises(AttributeError):
         attack_cli.main(["--num_clips", "1", "--frames", "32", "--hw", "16"])          # the reference's default method name does not exist
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(UnboundLocalError):          # a video attack other than TemporalTranslation: `spe_params` is never bound (attack.py:78-82)
         attack_cli.main(["--attack_type", "video", "--attack_method", "BIM"])
     import image_fine_tune_attack as ift
     ift.main(["--used_adv", out, "--used_ori", out, "--opt_path", str(tmp_path / "ft"), "--white_model", "slowfast_resnet50",
