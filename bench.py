@@ -60,6 +60,7 @@ def build_id():
 
 
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2_traffic_by_instantiation.json")
+PMC_MFMA_BUSY = None      # MFMA-busy fraction of the conv launches from the same PMC summary (same build-id rule as the traffic)
 
 
 def measured_traffic():
@@ -72,6 +73,8 @@ def measured_traffic():
             t = json.load(fh)
         if t.get("build_id") != build_id():
             return None, f"profiles/r2_traffic_by_instantiation.json is from build {t.get('build_id')}, running {build_id()}"
+        global PMC_MFMA_BUSY
+        PMC_MFMA_BUSY = t["conv_igemm"].get("mfma_busy_frac")
         return round(t["conv_igemm"]["hbm_bytes_per_launch"]), None
     except Exception as e:       # noqa: BLE001
         return None, f"no PMC summary ({type(e).__name__})"
@@ -464,6 +467,8 @@ def run_rank(args):
                            "build_id": build_id()}
         if why_not:
             out["roofline"]["traffic_note"] = why_not
+        elif PMC_MFMA_BUSY is not None:      # same PMC summary, same build: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x time x 2.4 GHz), time-weighted
+            out["roofline"]["mfma_busy_frac_pmc"] = PMC_MFMA_BUSY
         if timing_outside:
             out["roofline"]["note"] = "per-kernel times from one extra instrumented call after the timed region"
     if args.workload == "ilaf":
