@@ -1231,6 +1231,16 @@ extern "C" int i2v_clip_resize_crop_u8_f32(const uint8_t* frames, float* video, 
     return 0;
 }
 
+extern "C" int i2v_clip_resample_crop_u8_f32(const uint8_t* frames, float* video, const int32_t* xbounds, const int32_t* xcoef, int kx,
+                                             const int32_t* ybounds, const int32_t* ycoef, int ky, int b, int t, int H, int W, int rh, int rw,
+                                             int crop_y, int crop_x, int out_h, int out_w, void* stream) {
+    if (!frames || !video || !xbounds || !xcoef || !ybounds || !ycoef || kx <= 0 || ky <= 0 || b <= 0 || t <= 0 || H <= 0 || W <= 0 || out_h <= 0 ||
+        out_w <= 0) return fail("i2v_clip_resample_crop_u8_f32: bad argument");
+    if (crop_y < 0 || crop_x < 0 || crop_y + out_h > rh || crop_x + out_w > rw) return fail("i2v_clip_resample_crop_u8_f32: crop window outside the resized frame");
+    CHECK_BE(k_clip_resample_crop(frames, video, xbounds, xcoef, kx, ybounds, ycoef, ky, b, t, H, W, crop_y, crop_x, out_h, out_w, stream));
+    return 0;
+}
+
 extern "C" int i2v_frames_from_video_f32(const float* video, float* x, float* u, int b, int f, int hh, int w,
                                          void* stream) {
     if (!video || !x || !u || b <= 0 || f <= 0 || hh <= 0 || w <= 0) return fail("i2v_frames_from_video_f32: bad argument");

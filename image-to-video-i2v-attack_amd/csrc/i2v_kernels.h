@@ -52,6 +52,8 @@ int k_sign_bim(float* adv, const float* u, const float* grad, int64_t n, int64_t
 int k_sign_delta(float* delta, const float* grad, int64_t n, float step, i2v_stream_t s);
 int k_sign_delta_gx(float* delta, const float* gx, const float* u, int64_t n, float eps, float step,
                     i2v_stream_t s);   // delta -= step * sign(d cost / d delta) from the gradient w.r.t. the composed frames
+int k_clip_resample_crop(const uint8_t* frames, float* video, const int32_t* xb, const int32_t* xk, int kx, const int32_t* yb, const int32_t* yk,
+                         int ky, int b, int t, int H, int W, int cy, int cx, int oh, int ow, i2v_stream_t s);
 int k_tt_grad_mix(const float* grads, float* out, const float* kern /*host [D]*/, const int* moves /*host [D]*/, int D, int64_t NC, int T,
                   int HW, float w1, float w, i2v_stream_t s);
 int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t s);

@@ -1442,6 +1442,39 @@ __global__ void clip_resize_crop_kernel(const uint8_t* __restrict__ frames, floa
     }
 }
 
+// The UCF-101 loader's validation transform (dataset_ucf101.py:113-126) for one output element: Pillow's antialiased BILINEAR
+// resample (libImaging/Resample.c, 8-bit path) restricted to the crop window -- horizontal pass over the rows the vertical pass
+// needs, each result rounded and clipped to 8 bits as Pillow stores its intermediate image, then the vertical pass, rounded
+// and clipped again -- followed by ToTensor (/255), Normalize and the (b,3,t,h,w) layout.  Taps and 22-bit fixed-point
+// coefficients per RESIZED column / row are built on the host as `precompute_coeffs` / `normalize_coeffs_8bpc` build them.
+__global__ void clip_resample_crop_kernel(const uint8_t* __restrict__ frames, float* __restrict__ video, const int32_t* __restrict__ xb,
+                                          const int32_t* __restrict__ xk, int kx, const int32_t* __restrict__ yb, const int32_t* __restrict__ yk,
+                                          int ky, int b, int t, int H, int W, int cy, int cx, int oh, int ow) {
+    const int64_t total = (int64_t)b * t * oh * ow;
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int x = o % ow; int64_t r = o / ow;
+        const int y = r % oh; r /= oh;
+        const int ti = r % t; const int64_t bi = r / t;
+        const int x0 = xb[2 * (x + cx)], nx = xb[2 * (x + cx) + 1], y0 = yb[2 * (y + cy)], ny = yb[2 * (y + cy) + 1];
+        const int32_t* kxr = xk + (int64_t)(x + cx) * kx; const int32_t* kyr = yk + (int64_t)(y + cy) * ky;
+        const uint8_t* f = frames + (bi * t + ti) * (int64_t)H * W * 3;
+        int v0 = 1 << 21, v1 = 1 << 21, v2 = 1 << 21;
+        for (int j = 0; j < ny; ++j) {
+            const uint8_t* row = f + ((int64_t)(y0 + j) * W + x0) * 3;
+            int h0 = 1 << 21, h1 = 1 << 21, h2 = 1 << 21;
+            for (int i = 0; i < nx; ++i) { const int k = kxr[i]; h0 += row[3 * i] * k; h1 += row[3 * i + 1] * k; h2 += row[3 * i + 2] * k; }
+            const int k = kyr[j];
+            v0 += min(max(h0 >> 22, 0), 255) * k; v1 += min(max(h1 >> 22, 0), 255) * k; v2 += min(max(h2 >> 22, 0), 255) * k;
+        }
+        const int d[3] = {min(max(v0 >> 22, 0), 255), min(max(v1 >> 22, 0), 255), min(max(v2 >> 22, 0), 255)};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = __fdiv_rn((float)d[c], 255.f);
+            video[(((bi * 3 + c) * t + ti) * oh + y) * (int64_t)ow + x] = __fdiv_rn(__fsub_rn(v, c_mean[c]), c_std[c]);
+        }
+    }
+}
+
 __global__ void frames_from_video_kernel(const float* __restrict__ video, float* __restrict__ x, float* __restrict__ u,
                                          int b, int f, int hw) {
     const int64_t total = (int64_t)b * 3 * f * hw;
@@ -1563,6 +1596,13 @@ int k_clip_resize_crop(const uint8_t* frames, float* video, const int32_t* xtab,
     hipLaunchKernelGGL(clip_resize_crop_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)s, frames, video, xtab, ytab,
                        b, t, H, W, cy, cx, oh, ow);
     LAUNCH_CHECK("clip_resize_crop"); return 0;
+}
+int k_clip_resample_crop(const uint8_t* frames, float* video, const int32_t* xb, const int32_t* xk, int kx, const int32_t* yb, const int32_t* yk,
+                         int ky, int b, int t, int H, int W, int cy, int cx, int oh, int ow, i2v_stream_t s) {
+    const int64_t total = (int64_t)b * t * oh * ow;
+    hipLaunchKernelGGL(clip_resample_crop_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)s, frames, video, xb, xk, kx, yb, yk, ky,
+                       b, t, H, W, cy, cx, oh, ow);
+    LAUNCH_CHECK("clip_resample_crop"); return 0;
 }
 int k_frames_from_video(const float* video, float* x, float* u, int b, int f, int h, int w, i2v_stream_t s) {
     const int64_t total = (int64_t)b * 3 * f * h * w;

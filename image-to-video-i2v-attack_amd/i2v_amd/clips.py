@@ -9,6 +9,7 @@
 Each item mirrors the reference's validation item `(clip, label, name)` (`datasets.py:138-150`)."""
 import csv
 import glob
+import math
 import os
 
 import numpy as np
@@ -121,3 +122,59 @@ def resize_table(n_out, n_in):
     a1 = np.rint(fx * np.float32(2048)).astype(np.int64)
     a0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(np.int64)
     return np.stack([sx, a0, a1], 1).astype(np.int32)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# geometry of the UCF-101 loader's validation transform (`dataset_ucf101.py:113-126`, `transforms_ucf101.py`):
+# Scale(224) = PIL `Image.resize(..., BILINEAR)` to short side 224, CornerCrop(224, 'c'), ToTensor (/255), Normalize.
+# Pillow IS installed here, so the restatement of its resampler (libImaging/Resample.c: antialiased two-pass convolution,
+# 8-bit path with 22-bit fixed-point coefficients) is pinned bit for bit against the library itself
+# (tests/test_pil_resample.py); host side of `Engine.clip_resample_crop`.
+# ---------------------------------------------------------------------------------------------------------------
+PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def scale_sizes(h, w, size):
+    """`transforms_ucf101.Scale(size: int)` (:271-289): the smaller edge becomes `size`, the other int(size * long / short)."""
+    if (w <= h and w == size) or (h <= w and h == size):
+        return h, w
+    if w < h:
+        return int(size * h / w), size
+    return size, int(size * w / h)
+
+
+def corner_crop_center_origin(h, w, size):
+    """`CornerCrop(size, 'c')` (:343-348): x1 = int(round((W - size) / 2.)), y1 likewise (Python 3 banker's rounding)."""
+    return int(round((h - size) / 2.0)), int(round((w - size) / 2.0))
+
+
+def pil_resample_table(n_in, n_out):
+    """Pillow's `precompute_coeffs` + `normalize_coeffs_8bpc` for the BILINEAR filter over the full axis: per output index the
+    first source index, the number of taps, and the taps as 22-bit fixed-point integers.  Returns (bounds int32 (n_out, 2),
+    coeffs int32 (n_out, ksize), ksize).  Downscaling widens the triangle filter by the scale factor (antialiasing)."""
+    scale = float(n_in) / float(n_out)
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale                         # bilinear: support 1
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((n_out, 2), np.int32)
+    coeffs = np.zeros((n_out, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(n_out):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)              # C cast: truncation
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > n_in:
+            xmax = n_in
+        xmax -= xmin
+        w = []
+        for x in range(xmax):
+            t = abs((x + xmin - center + 0.5) * ss)
+            w.append(1.0 - t if t < 1.0 else 0.0)
+        ww = sum(w)                                     # left-to-right double sum, as the C loop
+        for x in range(xmax):
+            k = w[x] / ww if ww != 0.0 else w[x]
+            coeffs[xx, x] = int(-0.5 + k * (1 << PIL_PRECISION_BITS)) if k < 0 else int(0.5 + k * (1 << PIL_PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, coeffs, ksize

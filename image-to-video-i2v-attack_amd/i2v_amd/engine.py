@@ -120,6 +120,26 @@ class Engine:
             cy, cx, crop, crop, self.stream()))
         return out
 
+    def clip_resample_crop(self, frames_u8: torch.Tensor, size=224, crop=224) -> torch.Tensor:
+        """(b,t,H,W,3) uint8 decoded frames on the device -> the UCF-101 loader's validation transform (dataset_ucf101.py:113-126:
+        PIL BILINEAR `Scale(size)`, `CornerCrop(crop, 'c')`, ToTensor, Normalize) -> (b,3,t,crop,crop) float32, in one kernel."""
+        from . import clips as _clips
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and frames_u8.shape[-1] == 3
+        b, t, H, W, _ = frames_u8.shape
+        rh, rw = _clips.scale_sizes(H, W, size)
+        cy, cx = _clips.corner_crop_center_origin(rh, rw, crop)
+        key = ("pil", H, W, rh, rw)
+        tabs = self.__dict__.setdefault("_resize_tabs", {})
+        if key not in tabs:
+            (xb, xk, kx), (yb, yk, ky) = _clips.pil_resample_table(W, rw), _clips.pil_resample_table(H, rh)
+            tabs[key] = tuple(torch.from_numpy(a).to(frames_u8.device) for a in (xb, xk, yb, yk)) + (kx, ky)
+        xb, xk, yb, yk, kx, ky = tabs[key]
+        out = torch.empty(b, 3, t, crop, crop, dtype=torch.float32, device=frames_u8.device)
+        _lib.check(self.capi, self.capi.i2v_clip_resample_crop_u8_f32(
+            C.c_void_p(frames_u8.data_ptr()), _ptr(out), C.c_void_p(xb.data_ptr()), C.c_void_p(xk.data_ptr()), kx, C.c_void_p(yb.data_ptr()),
+            C.c_void_p(yk.data_ptr()), ky, b, t, H, W, rh, rw, cy, cx, crop, crop, self.stream()))
+        return out
+
     def frames_from_video(self, video, x, u):
         b, c, f, h, w = video.shape
         _lib.check(self.capi, self.capi.i2v_frames_from_video_f32(_ptr(video), _ptr(x), _ptr(u), b, f, h, w, self.stream()))

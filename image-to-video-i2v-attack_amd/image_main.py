@@ -23,7 +23,7 @@ from i2v_amd import clips
 OPT_PATH = os.environ.get("I2V_OPT_PATH", "")
 
 
-def arg_parse(argv=None):
+def arg_parse(argv=None, ucf101=False):
     parser = argparse.ArgumentParser(description="")
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     parser.add_argument("--batch_nums", type=int, default=world)
@@ -31,7 +31,7 @@ def arg_parse(argv=None):
     parser.add_argument("--gpu", type=str, default="0", help="gpu device.")
     parser.add_argument("--batch_size", type=int, default=1, metavar="N")
     parser.add_argument("--attack_method", type=str, default="ImageGuidedAttentionMap", help="")
-    parser.add_argument("--step", type=int, default=60, metavar="N")
+    parser.add_argument("--step", type=int, default=10 if ucf101 else 60, metavar="N")      # image_main_ucf101.py:26
     parser.add_argument("--file_prefix", type=str, default="")
     parser.add_argument("--depth", type=int, default=1, help="1,2,3,4")
     parser.add_argument("--lamb", type=float, default=0.1, help="")
@@ -63,7 +63,12 @@ def arg_parse(argv=None):
     return args
 
 
-def build_attack(args):
+def build_attack(args, ucf101=False):
+    if ucf101 and args.attack_method == "ImageGuidedFML2_Adam_MultiModels":       # the UCF-101 twin passes --step on (image_main_ucf101.py:75)
+        names = ["resnet", "vgg", "squeezenet", "alexnet"]
+        return image_attacks.ImageGuidedFML2_Adam_MultiModels(names, depths={"resnet": 2, "vgg": 3, "squeezenet": 2, "alexnet": 3}, steps=args.step)
+    if ucf101 and args.attack_method == "AENS_I2V_MF":                            # ... and has no adaptive branch (:62-75)
+        return getattr(image_attacks, args.attack_method)
     if args.attack_method in ("ImageGuidedStd_Adam", "ImageGuidedFMDirection_Adam"):
         return getattr(image_attacks, args.attack_method)([args.direction_image_model], depth=args.depth,
                                                           step_size=args.step_size, steps=args.step)
@@ -77,8 +82,11 @@ def build_attack(args):
     return getattr(image_attacks, args.attack_method)          # AttributeError, as in the reference
 
 
-def main(argv=None):
-    args = arg_parse(argv)
+def main(argv=None, ucf101=False):
+    """`ucf101`: the behaviour of the reference's `image_main_ucf101.py` (drop-in module of that name): --step defaults to 10, the
+    ensemble class receives it, names are `str(val_label)` (:83), and decoded uint8 clips go through the UCF-101 loader's transform
+    (PIL `Scale(224)` + `CornerCrop`, `Engine.clip_resample_crop`) instead of the Kinetics one."""
+    args = arg_parse(argv, ucf101)
     if "LOCAL_RANK" not in os.environ:
         os.environ["LOCAL_RANK"] = args.gpu.split(",")[0]
     print(args)
@@ -86,7 +94,7 @@ def main(argv=None):
     nums_contained = int(total / args.batch_nums)                      # int(400 / batch_nums), :61
     left = (args.batch_index - 1) * nums_contained
     right = args.batch_index * nums_contained
-    attack_method = build_attack(args)
+    attack_method = build_attack(args, ucf101)
     cuda = torch.cuda.is_available()
     if cuda:
         from i2v_amd import attacks as _attacks
@@ -155,7 +163,10 @@ def main(argv=None):
             if val_batch.dtype == torch.uint8:          # decoded frames (b,t,H,W,3): the loader's Resize/CenterCrop/ToTensor/Normalize on the device
                 from i2v_amd import attacks as _attacks
                 eng = _attacks.get_engine()
-                val_batch = eng.clip_resize_crop(val_batch.to(eng.device, non_blocking=True).contiguous(), crop=args.hw)
+                raw = val_batch.to(eng.device, non_blocking=True).contiguous()
+                val_batch = eng.clip_resample_crop(raw, args.hw, args.hw) if ucf101 else eng.clip_resize_crop(raw, crop=args.hw)
+            if ucf101:
+                video_names = str(val_label)            # image_main_ucf101.py:83 -- the attack then iterates the CHARACTERS of this string
             batches.append((val_batch, val_label, video_names))
         if len(batches) > 1 and hasattr(attack_method, "forward_grouped"):
             outs = attack_method.forward_grouped(batches)

@@ -149,6 +149,14 @@ int i2v_clip_from_u8_f32(const uint8_t* frames, float* video, int b, int t, int 
  * Output (b,3,t,out_h,out_w), normalised. */
 int i2v_clip_resize_crop_u8_f32(const uint8_t* frames, float* video, const int32_t* xtab, const int32_t* ytab, int b, int t,
                                 int H, int W, int rh, int rw, int crop_y, int crop_x, int out_h, int out_w, void* stream);
+/* The UCF-101 loader's validation transform (`dataset_ucf101.py:113-126`, `transforms_ucf101.py`): Scale(size) = PIL
+ * `Image.resize(BILINEAR)` (antialiased two-pass resampler, 8-bit intermediates) -> CornerCrop(size, 'c') -> ToTensor -> Normalize,
+ * on decoded uint8 frames (b,t,H,W,3) -> (b,3,t,out_h,out_w).  xbounds/ybounds: int32 (rw|rh, 2) = first source index and tap
+ * count per RESIZED column / row; xcoef/ycoef: int32 (rw|rh, kx|ky) 22-bit fixed-point taps -- built on the host exactly as
+ * Pillow's `precompute_coeffs` / `normalize_coeffs_8bpc` (i2v_amd/clips.py:pil_resample_table; pinned bit for bit against Pillow). */
+int i2v_clip_resample_crop_u8_f32(const uint8_t* frames, float* video, const int32_t* xbounds, const int32_t* xcoef, int kx,
+                                  const int32_t* ybounds, const int32_t* ycoef, int ky, int b, int t, int H, int W, int rh, int rw,
+                                  int crop_y, int crop_x, int out_h, int out_w, void* stream);
 /* videos (b,3,f,h,w) normalised -> frames x:(b*f,3,h,w), frame n = b_idx*f + f_idx
  * (image_attacks.py:300-301) and u = x*std + mean (`_transform_video(...,'back')`, :62,308). */
 int i2v_frames_from_video_f32(const float* video, float* x, float* u, int b, int f, int h, int w,

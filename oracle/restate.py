@@ -438,3 +438,28 @@ def resize_center_crop_normalise(frames_u8: np.ndarray, short_side=256, crop=224
     mean = torch.tensor(MEAN).view(1, 3, 1, 1, 1)
     std = torch.tensor(STD).view(1, 3, 1, 1, 1)
     return ((v - mean) / std).contiguous()                                              # Normalize: sub then div
+
+
+def ucf101_transform(frames_u8: np.ndarray, size=224, crop=224) -> torch.Tensor:
+    """CPU twin of `i2v_clip_resample_crop_u8_f32`: the UCF-101 loader's validation transform
+    (`/root/reference/dataset_ucf101.py:113-126`: `Scale(224)` -> `CornerCrop(224, 'c')` -> `ToTensor()` -> `Normalize`, then
+    `torch.stack(clip, 0).permute(1, 0, 2, 3)`, :79) on decoded uint8 frames (b, t, H, W, 3).  The resampling arithmetic is
+    Pillow's, and Pillow is installed: the frames go through `PIL.Image.resize(..., BILINEAR)` ITSELF, so this oracle is pinned by
+    construction (tests/test_pil_resample.py also runs the reference's own transform classes where /root/reference exists)."""
+    from PIL import Image
+    b, t, H, W, _ = frames_u8.shape
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    out = torch.empty(b, 3, t, crop, crop)
+    for bi in range(b):
+        for ti in range(t):
+            img = Image.fromarray(frames_u8[bi, ti])
+            w, h = img.size
+            if not ((w <= h and w == size) or (h <= w and h == size)):              # transforms_ucf101.py:278-289
+                img = img.resize((size, int(size * h / w)) if w < h else (int(size * w / h), size), Image.BILINEAR)
+            iw, ih = img.size
+            x1, y1 = int(round((iw - crop) / 2.)), int(round((ih - crop) / 2.))      # :343-348
+            img = img.crop((x1, y1, x1 + crop, y1 + crop))
+            ten = torch.from_numpy(np.array(img)).permute(2, 0, 1).float().div(255)  # ToTensor, :200-213
+            out[bi, :, ti] = ten.sub(mean).div(std)                                  # Normalize: t.sub_(m).div_(s)
+    return out

@@ -465,6 +465,28 @@ int k_head_ce(const I2VHeadParams& p, i2v_stream_t) {
     return 0;
 }
 
+int k_clip_resample_crop(const uint8_t* frames, float* video, const int32_t* xb, const int32_t* xk, int kx, const int32_t* yb, const int32_t* yk,
+                         int ky, int b, int t, int H, int W, int cy, int cx, int oh, int ow, i2v_stream_t) {
+    auto clip8 = [](int v) { return std::min(std::max(v >> 22, 0), 255); };
+    for (int bi = 0; bi < b; ++bi) for (int ti = 0; ti < t; ++ti) for (int y = 0; y < oh; ++y) for (int x = 0; x < ow; ++x) {
+        const int x0 = xb[2 * (x + cx)], nx = xb[2 * (x + cx) + 1], y0 = yb[2 * (y + cy)], ny = yb[2 * (y + cy) + 1];
+        const int32_t* kxr = xk + (size_t)(x + cx) * kx; const int32_t* kyr = yk + (size_t)(y + cy) * ky;
+        const uint8_t* f = frames + ((size_t)bi * t + ti) * H * W * 3;
+        for (int c = 0; c < 3; ++c) {
+            int v = 1 << 21;
+            for (int j = 0; j < ny; ++j) {
+                int h = 1 << 21;
+                for (int i = 0; i < nx; ++i) h += f[((size_t)(y0 + j) * W + x0 + i) * 3 + c] * kxr[i];
+                v += clip8(h) * kyr[j];
+            }
+            volatile float q = (float)clip8(v) / 255.f;
+            volatile float u = q - MEAN[c];
+            video[((((size_t)bi * 3 + c) * t + ti) * oh + y) * ow + x] = u / STD[c];
+        }
+    }
+    return 0;
+}
+
 int k_clip_resize_crop(const uint8_t* frames, float* video, const int32_t* xtab, const int32_t* ytab, int b, int t, int H, int W,
                        int cy, int cx, int oh, int ow, i2v_stream_t) {
     for (int bi = 0; bi < b; ++bi) for (int ti = 0; ti < t; ++ti) for (int y = 0; y < oh; ++y) for (int x = 0; x < ow; ++x) {

@@ -71,6 +71,34 @@ def test_image_main_grouped_batches_are_byte_identical(tiny_engine, tmp_path, mo
         assert i2 == info, tag
 
 
+def test_image_main_ucf101_twin(tiny_engine, tmp_path, monkeypatch):
+    """`image_main_ucf101.py`: raw 240 x 320 uint8 clips go through the UCF-101 transform (PIL Scale + centre crop) on the engine;
+    --step defaults to 10; names are the characters of `str(val_label)` (image_main_ucf101.py:83 feeds a string to the attack)."""
+    import importlib
+    import image_main
+    import image_main_ucf101
+    from oracle import restate
+    clip_dir = tmp_path / "clips"
+    clip_dir.mkdir()
+    rng = np.random.default_rng(5)
+    raws = {}
+    for label in (4, 9):
+        raws[label] = rng.integers(0, 256, (2, 60, 80, 3), dtype=np.uint8)          # (t, H, W, 3) decoded frames
+        np.save(clip_dir / f"{label}-raw.npy", raws[label])
+    monkeypatch.setenv("I2V_OPT_PATH", str(tmp_path))
+    importlib.reload(image_main); importlib.reload(image_main_ucf101)
+    image_main_ucf101.main(["--attack_method", "ImageGuidedFMDirection_Adam", "--step_size", "0.005", "--depth", "2", "--direction_image_model", "resnet",
+                            "--clip_dir", str(clip_dir), "--hw", "48", "--file_prefix", "u", "--group_clips", "1"])
+    out = tmp_path / "Image-ImageGuidedFMDirection_Adam-10-u"                       # --step defaulted to 10
+    assert sorted(os.listdir(out)) == ["4-adv.npy", "9-adv.npy", "loss_info_1.json"]
+    adv = np.load(out / "4-adv.npy")
+    clean = restate.ucf101_transform(raws[4][None], 48, 48)[0].numpy()            # what the attack started from
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(3, 1, 1, 1)
+    assert adv.shape == clean.shape == (3, 2, 48, 48) and 0 < np.abs((adv - clean) * std).max() <= 16 / 255 + 1e-5
+    info = json.load(open(out / "loss_info_1.json"))
+    assert set(info) == set("tensor([9])") | set("tensor([4])") and list(info["t"]) == [str(i) for i in range(10)]
+
+
 def test_image_fine_tune_attack_file_contract(tiny_engine, tmp_path):
     """`{id}-adv.npy` + `{id}-ori.npy` in, `{label}-adv.npy` out (/root/reference/image_fine_tune_attack.py:16-37,73-82),
     ILAF running natively on a (tiny) I3D graph."""
