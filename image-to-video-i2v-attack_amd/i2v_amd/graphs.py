@@ -580,19 +580,25 @@ def tpn_resnet(layers=(3, 4, 6, 3), width=64, in_thw=(32, 224, 224), arch="tpn_r
     return g
 
 
+# The reference's configs name `slowfast_8x8_resnet50/101_kinetics400` (`utils.py:11-12`): gluoncv's 8x8 variant samples the slow
+# pathway every 8th and the fast pathway every 2nd frame (alpha = 4) and fuses with a 7x1x1 lateral kernel (the 4x16 variant: 16 / 2,
+# alpha = 8, kernel 5).  On the 32-frame clips of this path that is 4 slow and 16 fast frames.
+SLOWFAST_8X8 = dict(slow_stride=8, fast_stride=2, fusion_kernel=7)
+
+
 def build_video(model_type: str, in_thw=(32, 224, 224), full: bool = False) -> Graph:
     """`model_type` follows `image_fine_tune_attack.py:53` / `utils.py:9-14`.  `full`: the graph to its last stage (what a
     classifier head needs); the I3D graphs always are, SlowFast then gets res3..res5 and its lateral connections."""
     if full and model_type in ("slowfast_resnet50", "slowfast_resnet101"):
-        return slowfast_resnet((3, 4, 23, 3) if "101" in model_type else (3, 4, 6, 3), 64, in_thw, model_type + "_full")
+        return slowfast_resnet((3, 4, 23, 3) if "101" in model_type else (3, 4, 6, 3), 64, in_thw, model_type + "_full", **SLOWFAST_8X8)
     if model_type == "i3d_resnet50":
         return i3d_resnet((3, 4, 6, 3), 64, in_thw, "i3d_resnet50")
     if model_type == "i3d_resnet101":
         return i3d_resnet((3, 4, 23, 3), 64, in_thw, "i3d_resnet101")
     if model_type == "slowfast_resnet50":
-        return slowfast_res2(64, in_thw, "slowfast_resnet50")
+        return slowfast_res2(64, in_thw, "slowfast_resnet50", **SLOWFAST_8X8)
     if model_type == "slowfast_resnet101":          # res2 is identical for the 50- and 101-layer variants
-        return slowfast_res2(64, in_thw, "slowfast_resnet101")
+        return slowfast_res2(64, in_thw, "slowfast_resnet101", **SLOWFAST_8X8)
     if model_type == "tpn_resnet50":
         return tpn_resnet((3, 4, 6, 3), 64, in_thw, "tpn_resnet50")
     if model_type == "tpn_resnet101":          # layer1 / layer2 are the same for the 50- and 101-layer backbones

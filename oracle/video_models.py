@@ -177,7 +177,7 @@ def make(model_type: str, tiny: bool, full: bool = False) -> nn.Module:
     if full and "slowfast" in model_type:
         if tiny:
             return SlowFastNet((2, 2, 1, 1), 16, slow_stride=4, fast_stride=1, beta_inv=4)
-        return SlowFastNet((3, 4, 23, 3) if "101" in model_type else (3, 4, 6, 3))
+        return SlowFastNet((3, 4, 23, 3) if "101" in model_type else (3, 4, 6, 3), slow_stride=8, fast_stride=2, fusion_kernel=7)
     if "tpn" in model_type:
         if tiny:
             return TPNBackbone((2, 2, 1, 1), 8)
@@ -188,7 +188,7 @@ def make(model_type: str, tiny: bool, full: bool = False) -> nn.Module:
         return I3DResNet((3, 4, 23, 3) if "101" in model_type else (3, 4, 6, 3))
     if tiny:
         return SlowFastRes2(16, slow_stride=4, fast_stride=1, beta_inv=4, blocks=2)
-    return SlowFastRes2()
+    return SlowFastRes2(slow_stride=8, fast_stride=2, fusion_kernel=7)          # the 8x8 configuration the reference names (utils.py:11-12)
 
 
 def load_weights(model: nn.Module, sd: dict) -> nn.Module:

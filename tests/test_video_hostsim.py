@@ -63,6 +63,34 @@ def test_video_backbone_forward_backward(model_type, thw):
     net.close()
 
 
+def test_slowfast_8x8_configuration():
+    """The configuration the reference names (`utils.py:11-12`: slowfast_8x8): slow pathway every 8th frame, FAST pathway every 2nd
+    (a 5x7x7 stem with temporal stride AND dilation 2 on the quad-row path), 7x1x1 lateral kernel with stride alpha = 4 -- narrow
+    widths, against `nn.Conv3d` + autograd in float64."""
+    eng = hostsim_engine()
+    thw, b = (16, 32, 32), 2
+    g = graphs.slowfast_res2(16, thw, "slowfast_8x8_narrow", beta_inv=4, blocks=2, **graphs.SLOWFAST_8X8)
+    sd = weights.synthetic_state_dict(g, 2)
+    hooks = graphs.video_hooks(g, "slowfast_resnet50")
+    net = eng.build_net(g, sd, hooks, b * thw[0])
+    model = vm.load_weights(vm.SlowFastRes2(16, slow_stride=8, fast_stride=2, beta_inv=4, fusion_kernel=7, blocks=2), sd).double()
+    torch.manual_seed(8)
+    x = torch.randn(b, 3, *thw, dtype=torch.float64, requires_grad=True)
+    feats = capture(model, vm.hook_modules(model, "slowfast_resnet50"), x)
+    assert [tuple(f.shape[1:3]) for f in feats] == [(16, 8), (64, 2)]             # fast: 16 / 2 frames, slow: 16 / 8
+    net.forward(vm.to_frames(x.detach()).float())
+    ffeat = [vm.to_frames(f.detach()) for f in feats]
+    for i, f in enumerate(ffeat):
+        got = net.save_hook(i, f.shape[0]).double()
+        assert got.shape == f.shape and torch.allclose(got, f, rtol=1e-4, atol=1e-5), (i, (got - f).abs().max())
+    hg = [torch.randn_like(f) for f in feats]
+    ref = vm.to_frames(torch.autograd.grad(sum((f * h).sum() for f, h in zip(feats, hg)), x)[0])
+    write_hook_grads(net, ffeat, [vm.to_frames(h) for h in hg], None)
+    gx = torch.empty(b * thw[0], 3, thw[1], thw[2])
+    net.backward(gx)
+    assert (gx.double() - ref).abs().max() / ref.abs().max() < 1e-4
+
+
 GEOM = [  # cin, cout, (kt,k), (st,s), (pt,p), dil_t, T, H
     (5, 7, (3, 1), (1, 1), (1, 0), 1, 6, 9),
     (4, 6, (3, 3), (2, 2), (1, 1), 1, 7, 10),
