@@ -383,15 +383,8 @@ __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvPara
 #endif
         }
     }
-#ifdef X_ALOAD
-    f32x4 xsink[TD][2];
-    for (int i = 0; i < TD; ++i) { xsink[i][0] = f32x4{0, 0, 0, 0}; xsink[i][1] = f32x4{0, 0, 0, 0}; }
-#endif
     auto chunk_body = [&](const int c, const int buf, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;                // a chunk c+1 exists: its DMA is issued here
-#ifdef X_ALOAD
-        for (int i = 0; i < TD; ++i) { asm volatile("" :: "v"(xsink[i][0]), "v"(xsink[i][1])); }
-#endif
 #ifndef X_NOBAR
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -749,7 +742,7 @@ static int conv_pick(const I2VConvParams& p) {
     // more operand traffic per MFMA); a launch that cannot fill the CUs' block slots also loses the overlap
     // between co-resident blocks.
     static const struct { int BD, BP, occ; double ineff; } C[5] = {
-        {128, 128, 3, 1.00}, {64, 128, 5, 1.05}, {128, 64, 5, 1.04}, {64, 64, 8, 1.10}, {32, 256, 4, 1.08}};
+        {128, 128, 3, 1.00}, {64, 128, 5, 1.05}, {128, 64, 5, 1.04}, {64, 64, 7, 1.10}, {32, 256, 4, 1.08}};      // occ = resident blocks per CU (conv_waves_per_simd)
     const double P = (double)p.N * p.Hg * p.Wg;
     const int nchunks = p.Kpad / I2V_KC;
     int best = 0; double best_t = 1e300;
