@@ -130,8 +130,18 @@ static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi) {
 #endif
 }
 #define I2V_CONV_WPE __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(BD, BP, PREF, false), conv_waves_per_simd(BD, BP, PREF, true))))
+// LDS floats one tile needs: operand staging [2][KC][BD] + [2][KC][BP], re-used by the epilogue as a [WD*FR][BP] transpose buffer
+template <int BD, int BP, int WD, bool MF16>
+constexpr int conv_lds_floats() {
+    constexpr int stage = 2 * I2V_KC * (BD + BP), epi = WD * (MF16 ? 16 : 32) * BP;
+    return stage > epi ? stage : epi;
+}
+
+// One tile of the implicit GEMM.  `bid` of `nwg` blocks share `n_cd_tiles` channel tiles per pixel tile, the first pixel tile
+// starting at pixel `px_base` (a launch may be cut into regions with different tile shapes, conv_igemm_tail below).
 template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false>
-__global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
+__device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd_tiles, const int bid, const int nwg, const int64_t px_base,
+                                          float* const smem) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-resource types and LDS-DMA builtins exist only in the device pass
     constexpr int KC = I2V_KC;
     constexpr int FR = MF16 ? 16 : 32;                       // fragment edge
@@ -141,8 +151,6 @@ __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvPara
     // one LDS array: operand staging [2][KC][BD] + [2][KC][BP], re-used by the epilogue as a
     // [WD*32][BP] transpose buffer
     constexpr int NST = 2;      // LDS operand buffers: chunk c is consumed while chunk c+1 is in flight
-    constexpr int STAGE_FLOATS = NST * KC * (BD + BP), EPI_FLOATS = WD * FR * BP;
-    __shared__ __attribute__((aligned(16))) float smem[STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS];
     float (*As)[KC][BD] = reinterpret_cast<float (*)[KC][BD]>(smem);
     float (*Bs)[KC][BP] = reinterpret_cast<float (*)[KC][BP]>(smem + NST * KC * BD);
 
@@ -151,11 +159,10 @@ __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvPara
 
     // XCD-aware remap: consecutive logical tiles (same pixel tile, neighbouring channel tiles) share
     // one XCD's L2 instead of being dealt round-robin over the 8 XCDs (bijective form).
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int cd_tile = lid % n_cd_tiles;
-    const int64_t px0 = (int64_t)(lid / n_cd_tiles) * BP;
+    const int64_t px0 = px_base + (int64_t)(lid / n_cd_tiles) * BP;
     const int cd0 = cd_tile * BD;
 
     const int HWg = p.Hg * p.Wg;
@@ -676,10 +683,43 @@ __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvPara
 #endif
 }
 
+template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false>
+__global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
+    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<BD, BP, WD, MF16>()];
+    conv_tile<BD, BP, WD, WP, MODE, PREF, PRE, VID, MF16>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem);
+}
+
+// "Tail split": the first `nA` blocks compute 64x64 tiles over the pixel tiles [0, px_base_b / 64); the remaining blocks cover the
+// rest of the pixels with 16x64 tiles on 16x16x4 fragments (a quarter of the work each).  A launch of 6.125 tiles per CU leaves
+// 32 CUs with 7 tiles and 224 with 6; cut this way it is 6 tiles everywhere plus 128 quarter tiles on 128 CUs.  Every output
+// element is still the same k-ordered fmaf chain (fragment shape does not enter): results are bit-identical.
+template <int MODE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I2V_SMALL_WPE, I2V_SMALL_WPE)))
+conv_igemm_tail(const I2VConvParams p, const int n_cd_a, const int nA, const int n_cd_b, const int64_t px_base_b) {
+    constexpr int LA = conv_lds_floats<64, 64, 2, false>(), LB = conv_lds_floats<16, 64, 1, true>();
+    __shared__ __attribute__((aligned(16))) float smem[LA > LB ? LA : LB];
+    if ((int)blockIdx.x < nA) conv_tile<64, 64, 2, 2, MODE, false, false, false, false>(p, n_cd_a, blockIdx.x, nA, 0, smem);
+    else conv_tile<16, 64, 1, 4, MODE, false, false, false, true>(p, n_cd_b, (int)blockIdx.x - nA, (int)gridDim.x - nA, px_base_b, smem);
+}
+
 // Low-K layers with epilogue operands are HBM-bound (their FLOP/byte is below the machine balance): they
 // run on 64x64 tiles with the epilogue operands prefetched under the K loop.
 static bool conv_wants_prefetch(const I2VConvParams& p) {
     return p.vec_epilogue && !p.gate_scale && !p.pre_scale && p.add0_stride == 1 && (p.add0 || p.add1 || p.mask || p.gate) && p.Kpad <= 256 && (p.pointwise || p.tap_uniform) && p.Cd > 32;
+}
+
+// Tail split (conv_igemm_tail) applies to plain 64x64 image launches whose tile count leaves a small remainder over the 256 CUs:
+// returns the number of trailing PIXEL tiles to hand to quarter tiles, 0 for none.  Chosen by the autotuner (bit 5 of the
+// configuration), never by default.
+static int conv_tail_px_tiles(const I2VConvParams& p) {
+    if (p.quad || p.pre_scale || p.temporal || !(p.pointwise || p.tap_uniform) || p.Cd % 16 != 0 || p.blk > 1) return 0;
+    const int64_t P = (int64_t)p.N * p.Hg * p.Wg;
+    const int64_t n_px = (P + 63) / 64; const int n_cd = (p.Cd + 63) / 64;
+    const int64_t tiles = n_px * n_cd;
+    if (tiles < 2 * 256) return 0;
+    const int r = (int)(tiles % 256);
+    if (r == 0 || r > 104) return 0;                  // a remainder beyond ~0.4 tiles per CU is better left as whole tiles
+    return r / n_cd;
 }
 
 template <int BD, int BP, int WD, int WP, bool MF16 = false>
@@ -696,6 +736,20 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
         else hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 4, false, false, false, MF16>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
         LAUNCH_CHECK("conv_igemm");
         return 0;
+    }
+    if constexpr (BD == 64 && BP == 64 && !MF16) {
+        if (p.cfg > 0 && ((p.cfg - 1) & 32)) {
+            const int tail = conv_tail_px_tiles(p);
+            if (tail > 0 && !conv_wants_prefetch(p)) {
+                const int nA = (int)((n_px - tail) * n_cd), n_cd_b = (p.Cd + 15) / 16;
+                const int64_t nB = (int64_t)tail * n_cd_b;
+                const dim3 g((unsigned)(nA + nB));
+                if (p.pointwise) hipLaunchKernelGGL((conv_igemm_tail<1>), g, dim3(256), 0, s, p, n_cd, nA, n_cd_b, (n_px - tail) * 64);
+                else hipLaunchKernelGGL((conv_igemm_tail<2>), g, dim3(256), 0, s, p, n_cd, nA, n_cd_b, (n_px - tail) * 64);
+                LAUNCH_CHECK("conv_igemm_tail");
+                return 0;
+            }
+        }
     }
     if constexpr (MF16) {
         if (p.pre_scale) { snprintf(g_be_err, sizeof g_be_err, "pre-activation convolutions have no 16-row variant"); g_be_has_err = true; return 1; }
@@ -773,6 +827,7 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
         out[n++] = i;
     }
     if (conv_wants_prefetch(p)) out[n++] = 3 | 8;       // 64x64 WITHOUT the epilogue-operand prefetch
+    else if (conv_tail_px_tiles(p) > 0 && p.Cd > 32) out[n++] = 3 | 32;      // 64x64 with the remainder tiles cut into quarter tiles
     if (p.Cd <= 16) out[n++] = 5;                        // 16x256 tile on 16x16x4 MFMA fragments
     return n;
 }
