@@ -103,12 +103,13 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 // class-packed image gradient (12 rows), 8/16-channel layers -- a 32-row tile would be mostly padding.
 // Residency: every tile is compiled for a stated number of waves per SIMD (= resident 256-thread blocks per CU), which
 // makes the register allocator count the MFMA accumulators in the unified VGPR file and stop at the matching budget:
-//   64x64   7  (72 registers; it then also keeps <= 96 SGPRs -- MI355X_MICROARCH.md "Residency": 98+ SGPRs admit only
-//               6 blocks per CU.  The launches that matter have 1568*k tiles = 6.125*k per CU: at 6 resident blocks the
-//               last 32 tiles waited for a second round)
+//   64x64   7  (49 registers since the tile body became a device function -- 61 before --; the allocator then also keeps <= 96
+//               SGPRs -- MI355X_MICROARCH.md "Residency": 98+ SGPRs admit only 6 blocks per CU.  The launches that matter have
+//               1568*k tiles = 6.125*k per CU: at 6 resident blocks the last 32 tiles waited for a second round.  8 blocks fit
+//               as well (78 SGPRs) and measured 0.5 % slower, twice)
 //   64x64 with epilogue prefetch  6  (78 registers; 7 would spill)
-//   128x64 / 64x128  5  (82-89 registers; left alone the allocator used 84 + 32 AGPRs = 4 blocks)
-//   128x128  3  (147-154; was 147 + 64 = 2 blocks)
+//   128x64  6  (70 registers, 24 KB of LDS; +0.5 % over 5)     64x128  5  (83 registers, 32 KB)
+//   128x128  3  (147-150; left alone the allocator used 147 + 64 AGPRs = 2 blocks)
 // The 256-pixel tiles are bounded by LDS (4 blocks) and are left alone.  All without spills (-Rpass-analysis).
 #ifndef I2V_SMALL_WPE
 #define I2V_SMALL_WPE 7
@@ -119,6 +120,9 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 #ifndef I2V_MID_WPE
 #define I2V_MID_WPE 5
 #endif
+#ifndef I2V_TALL_WPE
+#define I2V_TALL_WPE 6
+#endif
 #ifndef I2V_BIG_WPE
 #define I2V_BIG_WPE 3
 #endif
@@ -126,7 +130,7 @@ static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi) {
 #ifdef I2V_WPE_OFF
     return hi ? 8 : 1;
 #else
-    return (BD == 64 && BP == 64) ? (PREF ? I2V_PREF_WPE : I2V_SMALL_WPE) : BD * BP == 8192 ? I2V_MID_WPE : BD * BP == 16384 ? I2V_BIG_WPE : (hi ? 8 : 1);
+    return (BD == 64 && BP == 64) ? (PREF ? I2V_PREF_WPE : I2V_SMALL_WPE) : (BD == 128 && BP == 64) ? I2V_TALL_WPE : BD * BP == 8192 ? I2V_MID_WPE : BD * BP == 16384 ? I2V_BIG_WPE : (hi ? 8 : 1);
 #endif
 }
 #define I2V_CONV_WPE __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(BD, BP, PREF, false), conv_waves_per_simd(BD, BP, PREF, true))))
