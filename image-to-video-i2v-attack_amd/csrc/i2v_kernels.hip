@@ -844,7 +844,8 @@ int k_conv(const I2VConvParams& p_in, i2v_stream_t s) {
     fastdiv_magic((unsigned)p.Wg, &p.dv_w_m, &p.dv_w_s);
     fastdiv_magic((unsigned)(p.Tg > 0 ? p.Tg : 1), &p.dv_t_m, &p.dv_t_s);
     fastdiv_magic((unsigned)(p.Wo > 0 ? p.Wo : 1), &p.dv_wo_m, &p.dv_wo_s);
-    switch (p.cfg > 0 ? ((p.cfg - 1) & 7) : conv_pick(p)) {
+    if (p.cfg <= 0) p.cfg = conv_pick(p) + 1;          // the model's pick -- or $I2V_FORCE_CFG, which may carry the variant bits too
+    switch ((p.cfg - 1) & 7) {
         case 0: return launch_conv_cfg<128, 128, 2, 2>(p, st);
         case 1: return launch_conv_cfg<64, 128, 2, 2>(p, st);
         case 2: return launch_conv_cfg<128, 64, 2, 2>(p, st);

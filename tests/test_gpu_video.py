@@ -294,6 +294,30 @@ def test_tile_configurations_are_bit_identical(eng, monkeypatch):
         assert torch.equal(f, outs[0][0]) and torch.equal(gx, outs[0][1])
 
 
+def test_tail_split_is_bit_identical(eng, monkeypatch):
+    """`conv_igemm_tail`: the remainder tiles of a launch as 16x64 quarter tiles in the same grid.  Forced onto every eligible launch
+    (configuration 3 | 32) of a net whose layers leave remainders of 64 / 16 pixel tiles over the 256 CUs (576 and 144+... tiles), against
+    the plain 64x64 configuration: features and input gradient bit for bit."""
+    monkeypatch.setenv("I2V_AUTOTUNE", "0")
+    g = graphs.build_tiny("resnet", (96, 96))              # width 8: layer1 has 16 / 32-channel launches over 64 x 24 x 24 = 36 864 pixels = 576 tiles
+    sd = weights.synthetic_state_dict(g, 0)
+    x = dev(torch.randn(64, 3, 96, 96, generator=torch.Generator().manual_seed(0)))
+    outs = []
+    for cfg in (3, 3 | 32):
+        monkeypatch.setenv("I2V_FORCE_CFG", str(cfg))
+        net = eng.build_net(g, sd, [g.hooks[3]], 64)
+        net.forward(x)
+        f = net.save_hook(0, 64).cpu()
+        hg = torch.randn(f.shape, generator=torch.Generator().manual_seed(1))
+        write_hook_grads(net, [f], [hg])
+        gx = torch.empty(64, 3, 96, 96, device="cuda:0")
+        net.backward(gx)
+        outs.append((f, gx.cpu()))
+        net.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].abs().max()) > 0
+
+
 @pytest.mark.parametrize("name,hw,depths", [("resnet", 64, [2, 3]), ("vgg", 32, [3]), ("squeezenet", 64, [2, 3]), ("alexnet", 64, [3]),
                                             ("densenet121", 64, [2]), ("i3d_resnet50", (8, 32, 32), None),
                                             ("slowfast_resnet50", (8, 32, 32), None)])
