@@ -111,18 +111,24 @@ def main(argv=None, ucf101=False):
     todo = queue.Queue(maxsize=max(2, group))
     done = queue.Queue(maxsize=4)
 
+    reader_error = []
+
     def reader():
-        if cuda:
-            torch.cuda.set_device(device)      # per-thread state: pin_memory() would otherwise create a context on device 0
-        for step, item in enumerate(clips.batches(args.batch_size, args.anno, args.clip_dir, args.frames, args.hw, args.num_clips,
-                                                   workers=args.workers)):
-            if not (left <= step < right):
-                continue
-            if args.resume and all(os.path.exists(os.path.join(args.adv_path, f"{l.item()}-adv.npy")) for l in item[1]):
-                continue
-            batch = item[0].pin_memory() if cuda else item[0]
-            todo.put((step, batch, item[1], item[2]))
-        todo.put(None)
+        try:
+            if cuda:
+                torch.cuda.set_device(device)      # per-thread state: pin_memory() would otherwise create a context on device 0
+            for step, item in enumerate(clips.batches(args.batch_size, args.anno, args.clip_dir, args.frames, args.hw, args.num_clips,
+                                                       workers=args.workers)):
+                if not (left <= step < right):
+                    continue
+                if args.resume and all(os.path.exists(os.path.join(args.adv_path, f"{l.item()}-adv.npy")) for l in item[1]):
+                    continue
+                batch = item[0].pin_memory() if cuda else item[0]
+                todo.put((step, batch, item[1], item[2]))
+        except BaseException as e:             # a clip that cannot be read must end the run, not leave the main loop waiting
+            reader_error.append(e)
+        finally:
+            todo.put(None)
 
     def writer():
         while True:
@@ -186,6 +192,8 @@ def main(argv=None, ucf101=False):
             done.put((val_label, host, event))
     done.put(None)
     threads[1].join()
+    if reader_error:
+        raise reader_error[0]
     with open(os.path.join(args.adv_path, "loss_info_{}.json".format(args.batch_index)), "w") as opt:
         json.dump(attack_method.loss_info, opt)
     threads[0].join(timeout=60)

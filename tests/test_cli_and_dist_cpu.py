@@ -71,6 +71,23 @@ def test_image_main_grouped_batches_are_byte_identical(tiny_engine, tmp_path, mo
         assert i2 == info, tag
 
 
+def test_image_main_reader_failure_ends_the_run(tiny_engine, tmp_path, monkeypatch):
+    """A clip file that cannot be read raises out of `main` (after the clips before it were written) instead of leaving the main
+    loop waiting on its queue."""
+    import importlib
+    import image_main
+    clip_dir = tmp_path / "clips"
+    clip_dir.mkdir()
+    np.save(clip_dir / "1-ori.npy", np.zeros((3, 2, 64, 64), np.float32))
+    (clip_dir / "2-ori.npy").write_bytes(b"not a numpy file")
+    monkeypatch.setenv("I2V_OPT_PATH", str(tmp_path))
+    importlib.reload(image_main)
+    with pytest.raises(Exception):
+        image_main.main(["--attack_method", "ImageGuidedFMDirection_Adam", "--step", "1", "--step_size", "0.005", "--depth", "2",
+                         "--direction_image_model", "resnet", "--clip_dir", str(clip_dir), "--file_prefix", "e", "--workers", "0", "--group_clips", "1"])
+    assert os.path.exists(tmp_path / "Image-ImageGuidedFMDirection_Adam-1-e" / "1-adv.npy")
+
+
 def test_image_main_ucf101_twin(tiny_engine, tmp_path, monkeypatch):
     """`image_main_ucf101.py`: raw 240 x 320 uint8 clips go through the UCF-101 transform (PIL Scale + centre crop) on the engine;
     --step defaults to 10; names are the characters of `str(val_label)` (image_main_ucf101.py:83 feeds a string to the attack)."""
