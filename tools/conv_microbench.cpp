@@ -79,7 +79,7 @@ int main(int argc, char** argv) {
     if (argc > 5) {
         Shape sh{atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), "cli"};
         const char* f = getenv("I2V_FORCE_CFG");
-        printf("%.1f TFLOP/s\n", run(atoi(argv[1]), sh, f ? atoi(f) : 3, argc > 6 ? atoi(argv[6]) : 20, 0));
+        printf("%.1f TFLOP/s\n", run(atoi(argv[1]), sh, f ? atoi(f) : 3, argc > 6 ? atoi(argv[6]) : 20, getenv("CMB_EPI") ? 1 : 0));      // CMB_EPI: with a residual addend
         return 0;
     }
     const int N = argc > 1 ? atoi(argv[1]) : 128, iters = argc > 2 ? atoi(argv[2]) : 10;
