@@ -1,0 +1,51 @@
+"""Developer soak test (GPU box) for the tail split (conv_igemm_tail): random two-layer image nets large enough that their
+64x64 launches leave a remainder over the 256 CUs, run with the plain 64x64 configuration and with the tail split forced onto
+every eligible launch (I2V_FORCE_CFG = 3 | 32, no autotuning): features and input gradient must agree BIT FOR BIT.
+    python tools/soak_tail.py <seconds> [seed]"""
+import os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "image-to-video-i2v-attack_amd")); sys.path.insert(0, ROOT)
+os.environ["I2V_AUTOTUNE"] = "0"
+import torch
+from i2v_amd import attacks, graphs, weights
+from tests.test_gpu_video import write_hook_grads
+
+budget, seed = float(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rnd = random.Random(seed)
+eng = attacks.get_engine("cuda:0")
+t_end, n, split_cases = time.time() + budget, 0, 0
+while time.time() < t_end:
+    H = rnd.choice([14, 20, 28, 33, 56]); W = rnd.choice([14, 24, 28, 40, 56])
+    c1 = rnd.choice([16, 32, 48, 64]); c2 = rnd.choice([16, 32, 64, 80, 128, 256])
+    k = rnd.choice([1, 3])
+    frames = rnd.choice([24, 40, 64, 96, 128])
+    # how many launches would be split?  (64-pixel tiles x ceil(C / 64) channel tiles, remainder over 256 in (0, 104])
+    def eligible(C):
+        t = ((frames * H * W + 63) // 64) * ((C + 63) // 64)
+        return t >= 512 and 0 < t % 256 <= 104 and (t % 256) // ((C + 63) // 64) > 0
+    split_cases += int(eligible(c1) or eligible(c2))
+    g = graphs.Graph("soak_tail", (H, W))
+    x = g.new_tensor(3, H, W, False, "input")
+    g.input = x
+    a = g.conv(x, c1, 3, 1, 1, "a.weight", bn="a_bn", relu=True)
+    b = g.conv(a, c2, k, 1, k // 2, "b.weight", bn="b_bn", relu=rnd.random() < 0.7)
+    c = g.conv(b, c1, 1, 1, 0, "c.weight", bn="c_bn", relu=True, residual=a if rnd.random() < 0.5 else None)
+    g.hooks[1] = c
+    sd = weights.synthetic_state_dict(g, n)
+    xin = torch.randn(frames, 3, H, W, generator=torch.Generator().manual_seed(n)).to("cuda:0")
+    outs = []
+    for cfg in (3, 3 | 32):
+        os.environ["I2V_FORCE_CFG"] = str(cfg)
+        net = eng.build_net(g, sd, [c], frames)
+        net.forward(xin)
+        f = net.save_hook(0, frames).cpu()
+        write_hook_grads(net, [f], [torch.randn(f.shape, generator=torch.Generator().manual_seed(n + 1))])
+        gx = torch.empty(frames, 3, H, W, device="cuda:0")
+        net.backward(gx)
+        outs.append((f, gx.cpu()))
+        net.close()
+    if not (torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])):
+        print("FAIL", dict(n=n, H=H, W=W, c1=c1, c2=c2, k=k, frames=frames))
+        sys.exit(1)
+    n += 1
+print("tail-split soak ok:", n, "nets,", split_cases, "with at least one split launch, all bit-identical")
