@@ -56,6 +56,7 @@ struct Tensor { int buf, c_off, C; bool post_relu; };
 struct Packed {               // one implicit-GEMM operand set
     float* wp = nullptr; I2VKEntry* ktab = nullptr;
     int K = 0, Kpad = 0, Cd = 0, Cdpad = 0, tap_uniform = 0;
+    int halo = 0;           // 9 for a 3x3 / stride-1 / pad-1 packing in (16-channel group, tap, channel) order (kernel MODE 5), else 0
     int ph = 0, pw = 0, Hg = 0, Wg = 0;
     int pt = 0, Tg = 1;       // temporal parity class / grid frames per clip (video networks)
     int has_dt = 0;           // some k-table row carries a temporal tap offset
@@ -148,6 +149,7 @@ static int pack_fwd(Net& n, Node& nd) {
     Packed& P = nd.fwd;
     P.K = K; P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cout; P.Cdpad = (int)align_up(c.cout, 128);
     P.tap_uniform = (c.cin % I2V_KC == 0) ? 1 : 0;
+    if (P.tap_uniform && c.kt == 1 && c.kh == 3 && c.kw == 3 && c.stride == 1 && c.stride_t == 1 && c.pad == 1 && !nd.preact()) P.halo = 9;
     // "Quad rows" for narrow stems (few input channels AND few output channels: SlowFast's fast pathway, 3 -> 8): such a launch
     // spends its time ISSUING the 4-byte im2col DMA of the per-row path (one instruction per K row and 64 pixels; 17 TFLOP/s),
     // not in the matrix pipe.  K rows ordered (channel, frame tap, row tap, column-tap quad x 4) put four ADJACENT source pixels
@@ -216,6 +218,7 @@ static int pack_bwd(Net& n, Node& nd) {
             int K = (int)(tq.size() * tr.size() * ts.size()) * c.cout;
             P.K = K; P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cin; P.Cdpad = (int)align_up(c.cin, 128);
             P.tap_uniform = (c.cout % I2V_KC == 0) ? 1 : 0;
+            if (P.tap_uniform && st == 1 && stt == 1 && c.kt == 1 && c.kh == 3 && c.kw == 3 && c.pad == 1 && !nd.preact()) P.halo = 9;
             std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
             std::vector<I2VKEntry> kt(P.Kpad ? P.Kpad : 1, I2VKEntry{0, 0, 0, 0});
             int t = 0;
@@ -533,6 +536,7 @@ static void conv_common(I2VConvParams& p, const Packed& P) {
     p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1; p.ot0 = 0;
     p.temporal = P.has_dt;      // conv_run adds the frame-mapping half of the condition
     p.quad = P.quad; p.quad_kw = P.quad_kw; p.quad_dw0 = P.quad_dw0;
+    p.halo = P.halo;
 }
 
 static bool overlaps(const Tensor& a, const Tensor& b) {

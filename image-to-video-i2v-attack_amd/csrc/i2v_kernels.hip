@@ -141,9 +141,16 @@ constexpr int conv_lds_floats() {
     return stage > epi ? stage : epi;
 }
 
+// MODE 5 ("halo") of the 64x64 tile: weights [2][KC][64] + halo rows [2][KC][64 + 2 W + 2]
+template <int HWM>
+constexpr int conv_halo_lds_floats() {
+    constexpr int stage = 2 * I2V_KC * (64 + 64 + 2 * HWM + 2), epi = 64 * 64;
+    return stage > epi ? stage : epi;
+}
+
 // One tile of the implicit GEMM.  `bid` of `nwg` blocks share `n_cd_tiles` channel tiles per pixel tile, the first pixel tile
 // starting at pixel `px_base` (a launch may be cut into regions with different tile shapes, conv_igemm_tail below).
-template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false>
+template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false, int HWM = 0>
 __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd_tiles, const int bid, const int nwg, const int64_t px_base,
                                           float* const smem) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-resource types and LDS-DMA builtins exist only in the device pass
@@ -155,6 +162,11 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     // one LDS array: operand staging [2][KC][BD] + [2][KC][BP], re-used by the epilogue as a
     // [WD*32][BP] transpose buffer
     constexpr int NST = 2;      // LDS operand buffers: chunk c is consumed while chunk c+1 is in flight
+    // MODE 5 ("halo"): a 3x3 / stride-1 / pad-1 launch on planes exactly HWM wide stages, per 16-channel group, ONE halo row per
+    // channel -- the tile's 64 pixels plus a source row and a pixel on either side -- instead of nine shifted copies of the tile
+    constexpr bool HALO = MODE == 5;
+    constexpr int HS = HALO ? BP + 2 * HWM + 2 : 1, HQ = (HS + 63) / 64;
+    static_assert(!HALO || (HWM > 0 && BD == 64 && BP == 64 && !PREF && !PRE && !VID && !MF16), "halo staging: the plain 64x64 image tile only");
     float (*As)[KC][BD] = reinterpret_cast<float (*)[KC][BD]>(smem);
     float (*Bs)[KC][BP] = reinterpret_cast<float (*)[KC][BP]>(smem + NST * KC * BD);
 
@@ -194,7 +206,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src - XB), 0, p.src_span_bytes + 2 * XB, 0x00020000);
     constexpr int NA = KC * BD / 256, NAQ = (NA + 3) / 4;     // weights: instructions of 256 floats
     constexpr int BPER = (PW || QUAD) ? 256 : 64;             // activations: 16-byte or 4-byte pieces (floats per instruction)
-    constexpr int NB = KC * BP / BPER, NBQ = (NB + 3) / 4;
+    constexpr int NB = HALO ? 0 : KC * BP / BPER, NBQ = (NB + 3) / 4;      // MODE 5 stages its activations as halo rows
     const int bcol = PW ? (lane * 4) % BP : (BP >= 64 ? ((wave * 64) % BP) + lane : lane % BP);
     const int64_t ppix = px0 + bcol;
     const bool pvalid = ppix < P;
@@ -371,7 +383,96 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
                 }
         }
     }
-    {   // prologue: chunk 0 (and the k-table row of chunk 1)
+    if constexpr (HALO) {
+        // ---- MODE 5 main loop: groups of 16 channels x 9 taps; the nine chunks of a group are unrolled (tap index compile-time) ----
+        constexpr int NT = 9, HPW = 4 * HQ, PPC = (HPW + NT - 1) / NT;       // halo DMA pieces per wave per group / per chunk
+        float* const Hb = smem + NST * KC * BD;                                // [2][KC][HS]
+        const int W_ = HWM;
+        int tsh[NT], tdh[NT], tdw[NT];                                         // per tap: shift inside a halo row, row / column offset
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const I2VKEntry e = load_kentry(p.ktab, t * KC);
+            tdh[t] = e.dh; tdw[t] = e.dw; tsh[t] = e.dh * W_ + e.dw + W_ + 1;
+        }
+        const int chan0 = load_kentry(p.ktab, 0).chan_off;
+        const int ngroups = nchunks / NT;
+        const int gstride = ngroups > 1 ? load_kentry(p.ktab, NT * KC).chan_off - chan0 : 0;
+        // this lane's fragment pixel: validity of each tap as one bit
+        const int64_t fp = px0 + wpx * (BP / WP) + l31;
+        const bool fpv = fp < P;
+        const unsigned fr = fpv ? (unsigned)fp - fastdiv((unsigned)fp, p.dv_hw_m, p.dv_hw_s) * (unsigned)HWg : 0u;
+        const int fh = (int)fastdiv(fr, p.dv_w_m, p.dv_w_s), fw = (int)fr - fh * p.Wg;
+        unsigned tmask = 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            tmask |= (fpv && (unsigned)(fh + tdh[t]) < (unsigned)p.Hs && (unsigned)(fw + tdw[t]) < (unsigned)p.Ws) ? (1u << t) : 0u;
+        const int lbase = lk * HS + wpx * (BP / WP) + l31;                    // float index of this lane's element in row (k = lk), shift 0
+        // halo element 64 q + lane of a row = flattened pixel px0 - (W + 1) + 64 q + lane, in whichever frame it lies
+        unsigned hoff[HQ];
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) {
+            const int64_t vp = px0 - (W_ + 1) + 64 * q + lane;
+            const bool ok = vp >= 0 && vp < P;
+            const int64_t vn = ok ? fastdiv((unsigned)vp, p.dv_hw_m, p.dv_hw_s) : 0;
+            hoff[q] = ok ? (unsigned)((vn * p.src_nstride + (vp - vn * HWg)) * 4) : OOB;
+        }
+        // piece idx (compile-time) of a group: channel 4 wave + idx / HQ, 64-lane piece idx % HQ of its row.  A wave's rows are
+        // written in order, so a row's last piece may run into the next row (overwritten by that row's own pieces, issued
+        // later by the same wave); only the LAST row of a wave must not overrun: that piece is cut by EXEC.
+        auto halo_piece = [&]<int IDX>(std::integral_constant<int, IDX>, const int gb, const int chan_off) {
+            constexpr int chl = IDX / HQ, q = IDX % HQ;
+            float* const dst = Hb + ((gb * KC + wv * 4 + chl) * HS + 64 * q);
+            const int so = (chan_off + (wv * 4 + chl) * HWs) * 4;
+            if constexpr (chl == 3 && q == HQ - 1) {
+                if (lane < HS - 64 * q) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)dst, 4, hoff[q], so, 0, 0);
+            } else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)dst, 4, hoff[q], so, 0, 0);
+        };
+        if (ngroups > 0) {      // prologue: the halo rows of group 0, the weight tile of chunk 0
+            [&]<int... I>(std::integer_sequence<int, I...>) { ((halo_piece(std::integral_constant<int, I>{}, 0, chan0)), ...); }
+            (std::make_integer_sequence<int, HPW>{});
+            I2V_ISSUE_PIECE(0, 0, 0, OOB);
+        }
+        int gbuf = 0;
+        for (int g = 0; g < ngroups; ++g) {
+            const bool more_g = g + 1 < ngroups;
+            const int chan_next = chan0 + (g + 1) * gstride;
+            [&]<int... T>(std::integer_sequence<int, T...>) {
+                (([&] {
+                    constexpr int t = T;
+                    const int abuf = (g + t) & 1;                              // chunk g * 9 + t: 9 is odd
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    const int hidx = lbase + gbuf * KC * HS + tsh[t];
+                    const bool ok = (tmask >> t) & 1u;
+                    float fa[2], fb[2];
+                    auto rd = [&](const int s_, const int set) {
+                        fa[set] = As[abuf][KR * s_ + lk][wd * (BD / WD) + l31];
+                        fb[set] = Hb[hidx + KR * s_ * HS];
+                    };
+                    rd(0, 0);
+                    [&]<int... S>(std::integer_sequence<int, S...>) {
+                        (([&] {
+                            constexpr int s_ = S, set = S & 1;
+                            if constexpr (s_ + 1 < KS) rd(s_ + 1, set ^ 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                            fb[set] = ok ? fb[set] : 0.f;
+                            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set], fb[set], acc[0][0], 0, 0, 0);
+                            if constexpr (s_ == 0) {                           // the weight tile of the next chunk
+                                if (t < NT - 1 || more_g) I2V_ISSUE_PIECE(0, (g * NT + t + 1) * KC, abuf ^ 1, OOB);
+                            }
+                            if constexpr (s_ >= 1 && s_ <= PPC) {              // the next group's halo rows, PPC pieces per chunk, in order
+                                constexpr int idx = t * PPC + (s_ - 1);
+                                if constexpr (idx < HPW) { if (more_g) halo_piece(std::integral_constant<int, idx>{}, gbuf ^ 1, chan_next); }
+                            }
+                        }()), ...);
+                    }(std::make_integer_sequence<int, KS>{});
+                }()), ...);
+            }(std::make_integer_sequence<int, NT>{});
+            gbuf ^= 1;
+        }
+    } else {   // prologue: chunk 0 (and the k-table row of chunk 1)
         unsigned vb0 = OOB;
         if constexpr (MODE == 2) {
             const I2VKEntry e0 = load_kentry(p.ktab, 0);
@@ -478,7 +579,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         __builtin_amdgcn_s_setprio(0);
 #endif
     };
-    {
+    if constexpr (!HALO) {
         int buf = 0;
         for (int c = 0; c + 1 < nchunks; ++c) { chunk_body(c, buf, std::true_type{}); buf ^= 1; }
         if (nchunks > 0) chunk_body(nchunks - 1, buf, std::false_type{});
@@ -693,6 +794,14 @@ __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvPara
     conv_tile<BD, BP, WD, WP, MODE, PREF, PRE, VID, MF16>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem);
 }
 
+// MODE 5 launches (halo staging of 3x3 / stride-1 convolutions on planes HWM wide)
+template <int HWM>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HWM <= 14 ? I2V_SMALL_WPE : (HWM <= 28 ? 6 : 5), HWM <= 14 ? I2V_SMALL_WPE : (HWM <= 28 ? 6 : 5))))
+conv_igemm_halo(const I2VConvParams p, const int n_cd_tiles) {
+    __shared__ __attribute__((aligned(16))) float smem[conv_halo_lds_floats<HWM>()];
+    conv_tile<64, 64, 2, 2, 5, false, false, false, false, HWM>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem);
+}
+
 // "Tail split": the first `nA` blocks compute 64x64 tiles over the pixel tiles [0, px_base_b / 64); the remaining blocks cover the
 // rest of the pixels with 16x64 tiles on 16x16x4 fragments (a quarter of the work each).  A launch of 6.125 tiles per CU leaves
 // 32 CUs with 7 tiles and 224 with 6; cut this way it is 6 tiles everywhere plus 128 quarter tiles on 128 CUs.  Every output
@@ -726,6 +835,13 @@ static int conv_tail_px_tiles(const I2VConvParams& p) {
     return r / n_cd;
 }
 
+// MODE 5 applies: the planner marked the packing (K order (16-channel group, tap, channel), 3x3 / stride 1 / pad 1), the launch is a
+// plain same-size image launch on a plane width the kernel is instantiated for, and the autotuner chose it (bit 4)
+static bool conv_halo_ok(const I2VConvParams& p) {
+    return p.halo == 9 && p.tap_uniform && !p.temporal && !p.pre_scale && !p.quad && p.blk <= 1 && p.sh == 1 && p.sw == 1 && p.Hs == p.Hg &&
+           p.Ws == p.Wg && (p.Ws == 14 || p.Ws == 28 || p.Ws == 56) && p.Kpad == p.K && (p.Kpad / I2V_KC) % 9 == 0;
+}
+
 template <int BD, int BP, int WD, int WP, bool MF16 = false>
 static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     const int64_t P = (int64_t)p.N * p.Hg * p.Wg;
@@ -742,6 +858,13 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
         return 0;
     }
     if constexpr (BD == 64 && BP == 64 && !MF16) {
+        if (p.cfg > 0 && ((p.cfg - 1) & 16) && conv_halo_ok(p)) {
+            if (p.Ws == 14) hipLaunchKernelGGL((conv_igemm_halo<14>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+            else if (p.Ws == 28) hipLaunchKernelGGL((conv_igemm_halo<28>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+            else hipLaunchKernelGGL((conv_igemm_halo<56>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+            LAUNCH_CHECK("conv_igemm_halo");
+            return 0;
+        }
         if (p.cfg > 0 && ((p.cfg - 1) & 32)) {
             const int tail = conv_tail_px_tiles(p);
             if (tail > 0 && !conv_wants_prefetch(p)) {
@@ -832,6 +955,8 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
     }
     if (conv_wants_prefetch(p)) out[n++] = 3 | 8;       // 64x64 WITHOUT the epilogue-operand prefetch
     else if (conv_tail_px_tiles(p) > 0 && p.Cd > 32) out[n++] = 3 | 32;      // 64x64 with the remainder tiles cut into quarter tiles
+    static const bool no_halo = [] { const char* e = getenv("I2V_HALO"); return e && e[0] == '0'; }();
+    if (conv_halo_ok(p) && p.Cd > 32 && !no_halo) out[n++] = 3 | 16;         // 64x64 with halo staging (MODE 5)
     if (p.Cd <= 16) out[n++] = 5;                        // 16x256 tile on 16x16x4 MFMA fragments
     return n;
 }

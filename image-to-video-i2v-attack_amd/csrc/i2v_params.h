@@ -71,6 +71,11 @@ struct I2VConvParams {
     // (ceil(kw / 4), 1 or 2), quad_kw = kw (rows with dw0 + e beyond the kernel have zero weights and are masked), the tap of
     // element e of run-quad qi is dw = quad_dw0 + 4 qi + e.  The source view needs 64 readable bytes on either side.
     int32_t quad, quad_kw, quad_dw0;
+    // halo = 9 (kernel MODE 5): a tap-uniform 3x3 / stride-1 / pad-1 launch whose K rows are ordered (16-channel group, tap, channel).
+    // The nine chunks of a group read the SAME 16 channel planes shifted by their tap, so the kernel may stage one halo row per
+    // channel and group (tile pixels + a row and a pixel on either side) instead of nine shifted copies of the tile.  Same
+    // products in the same order: results are bit-identical.
+    int32_t halo;
     // exact division of a pixel index (< 2^31) by Hg*Wg, Wg, Tg and Wo as multiply-high + shift: filled in by k_conv (the
     // hardware has no integer divide; the 64-bit software divisions of round 1 cost a block more VALU issue slots than a
     // K = 64 tile spends on its MFMAs)

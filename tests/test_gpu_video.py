@@ -294,6 +294,41 @@ def test_tile_configurations_are_bit_identical(eng, monkeypatch):
         assert torch.equal(f, outs[0][0]) and torch.equal(gx, outs[0][1])
 
 
+def test_halo_staging_is_bit_identical(eng, monkeypatch):
+    """MODE 5 (`conv_igemm_halo`): 3x3 / stride-1 layers stage one halo row per channel and 16-channel group instead of nine shifted
+    tile copies.  Forced onto every eligible launch (configuration 3 | 16; plane widths 14 / 28 / 56 are instantiated) of a VGG-style
+    stack at 56^2 -- forward AND input-gradient launches, tiles that cross frame boundaries, a pixel tail -- against the plain 64x64
+    configuration: features and input gradient bit for bit."""
+    monkeypatch.setenv("I2V_AUTOTUNE", "0")
+    g = graphs.Graph("halo_test", (56, 56))
+    x = g.new_tensor(3, 56, 56, False, "input")
+    g.input = x
+    a = g.conv(x, 32, 3, 1, 1, "a.weight", bn="a_bn", relu=True)
+    b = g.conv(a, 48, 3, 1, 1, "b.weight", bn="b_bn", relu=True)             # 56 wide, 32 -> 48 channels
+    c = g.maxpool(b, 2, 2)
+    d = g.conv(c, 64, 3, 1, 1, "d.weight", bn="d_bn", relu=True)             # 28 wide
+    e = g.conv(d, 64, 3, 1, 1, "e.weight", bn="e_bn", relu=False, residual=d)
+    f = g.maxpool(e, 2, 2)
+    h = g.conv(f, 32, 3, 1, 1, "h.weight", bn="h_bn", relu=True)             # 14 wide
+    g.hooks[1] = h
+    sd = weights.synthetic_state_dict(g, 0)
+    frames = 5                                                                  # 5 x 196 pixels: tiles straddle frames, 980 % 64 != 0
+    xin = dev(torch.randn(frames, 3, 56, 56, generator=torch.Generator().manual_seed(0)))
+    outs = []
+    for cfg in (3, 3 | 16):
+        monkeypatch.setenv("I2V_FORCE_CFG", str(cfg))
+        net = eng.build_net(g, sd, [h], frames)
+        net.forward(xin)
+        ft = net.save_hook(0, frames).cpu()
+        write_hook_grads(net, [ft], [torch.randn(ft.shape, generator=torch.Generator().manual_seed(1))])
+        gx = torch.empty(frames, 3, 56, 56, device="cuda:0")
+        net.backward(gx)
+        outs.append((ft, gx.cpu()))
+        net.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].abs().max()) > 0
+
+
 def test_tail_split_is_bit_identical(eng, monkeypatch):
     """`conv_igemm_tail`: the remainder tiles of a launch as 16x64 quarter tiles in the same grid.  Forced onto every eligible launch
     (configuration 3 | 32) of a net whose layers leave remainders of 64 / 16 pixel tiles over the 256 CUs (576 and 144+... tiles), against

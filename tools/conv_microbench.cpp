@@ -63,6 +63,7 @@ static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
     p.pointwise = (k == 1 && st == 1 && (H * H) % 4 == 0 && !getenv("CMB_NOPW")); p.tap_uniform = tu;
     p.vec_epilogue = ((Ho * Ho) % 4 == 0);
     p.cfg = cfg + 1;
+    if (tu && k == 3 && st == 1) p.halo = 9;      // the K order above is (16-channel group, tap, channel): I2V_FORCE_CFG=19 (3 | 16) runs MODE 5
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 2; ++i) k_conv(p, nullptr);
     hipDeviceSynchronize();
