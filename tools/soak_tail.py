@@ -1,7 +1,8 @@
-"""Developer soak test (GPU box) for the tail split (conv_igemm_tail): random two-layer image nets large enough that their
-64x64 launches leave a remainder over the 256 CUs, run with the plain 64x64 configuration and with the tail split forced onto
-every eligible launch (I2V_FORCE_CFG = 3 | 32, no autotuning): features and input gradient must agree BIT FOR BIT.
-    python tools/soak_tail.py <seconds> [seed]"""
+"""Developer soak test (GPU box) for the 64x64 tile's variants: random three-layer image nets run with the plain 64x64 configuration and
+with a variant forced onto every eligible launch (no autotuning): features and input gradient must agree BIT FOR BIT.
+    python tools/soak_tail.py <seconds> [seed] [tail|halo]
+  tail: the tail split (conv_igemm_tail, I2V_FORCE_CFG = 3 | 32) on nets large enough to leave a remainder over the 256 CUs;
+  halo: halo staging (conv_igemm_halo, 3 | 16) on planes 14 / 28 / 56 wide, any height, few or many frames."""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "image-to-video-i2v-attack_amd")); sys.path.insert(0, ROOT)
@@ -11,14 +12,16 @@ from i2v_amd import attacks, graphs, weights
 from tests.test_gpu_video import write_hook_grads
 
 budget, seed = float(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 0
+mode = sys.argv[3] if len(sys.argv) > 3 else "tail"
+variant = 3 | (16 if mode == "halo" else 32)
 rnd = random.Random(seed)
 eng = attacks.get_engine("cuda:0")
 t_end, n, split_cases = time.time() + budget, 0, 0
 while time.time() < t_end:
-    H = rnd.choice([14, 20, 28, 33, 56]); W = rnd.choice([14, 24, 28, 40, 56])
+    H = rnd.choice([14, 20, 28, 33, 56]); W = rnd.choice([14, 28, 56] if mode == "halo" else [14, 24, 28, 40, 56])
     c1 = rnd.choice([16, 32, 48, 64]); c2 = rnd.choice([16, 32, 64, 80, 128, 256])
     k = rnd.choice([1, 3])
-    frames = rnd.choice([24, 40, 64, 96, 128])
+    frames = rnd.choice([1, 2, 3, 5, 8, 24] if mode == "halo" else [24, 40, 64, 96, 128])
     # how many launches would be split?  (64-pixel tiles x ceil(C / 64) channel tiles, remainder over 256 in (0, 104])
     def eligible(C):
         t = ((frames * H * W + 63) // 64) * ((C + 63) // 64)
@@ -34,7 +37,7 @@ while time.time() < t_end:
     sd = weights.synthetic_state_dict(g, n)
     xin = torch.randn(frames, 3, H, W, generator=torch.Generator().manual_seed(n)).to("cuda:0")
     outs = []
-    for cfg in (3, 3 | 32):
+    for cfg in (3, variant):
         os.environ["I2V_FORCE_CFG"] = str(cfg)
         net = eng.build_net(g, sd, [c], frames)
         net.forward(xin)
@@ -48,4 +51,4 @@ while time.time() < t_end:
         print("FAIL", dict(n=n, H=H, W=W, c1=c1, c2=c2, k=k, frames=frames))
         sys.exit(1)
     n += 1
-print("tail-split soak ok:", n, "nets,", split_cases, "with at least one split launch, all bit-identical")
+print(mode, "soak ok:", n, "nets" + (", %d with at least one split launch" % split_cases if mode == "tail" else ""), "-- all bit-identical")
