@@ -96,3 +96,21 @@ def test_checkpoint_file_drives_the_engine(tmp_path, monkeypatch):
     got = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=3, step_size=0.005, steps=3,
                                               graph_builder=graphs.build_tiny)(vid, lab, ["a", "b"]).cpu()
     assert torch.equal(got, want)
+
+
+def test_bench_starts_its_own_ranks_on_the_gpu():
+    """`bench.py --gpus 2` without a launcher: the parent starts two rank processes before touching the GPU, every rank joins the
+    process group, all-reduces its rank id (the proof printed in the JSON line) and runs the timed region; rank 0 prints ONE line with
+    n_gpus == 2 and both ranks' frames/s.  FUNCTIONAL CHECK: a 1-GPU box, so both ranks share device 0 over gloo (the line says so);
+    the RCCL path itself is what `torch.distributed.run` / the driver exercises on a multi-GPU node."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(I2V_SYNTHETIC_WEIGHTS="1", I2V_QUIET_WEIGHTS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--dist-backend", "gloo", "--steps", "1",
+                        "--warmup", "0", "--clips", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["per_gpu"]) == 2 and d["value"] > 0
+    assert d["ranks_proved_by_allreduce"]["sum_of_rank_ids"] == 1 == d["ranks_proved_by_allreduce"]["expected"]
+    assert abs(sum(d["per_gpu"]) - d["value"]) <= 0.05 * d["value"]
