@@ -52,6 +52,15 @@ int be_event_elapsed_ms(void* a, void* b, float* ms) { HIPCHK(hipEventElapsedTim
 int be_stream_sync(i2v_stream_t s) { HIPCHK(hipStreamSynchronize((hipStream_t)s)); return 0; }
 int be_device_sync() { HIPCHK(hipDeviceSynchronize()); return 0; }
 
+#ifdef X_CLOCK
+__device__ unsigned long long g_xclk[1 << 20];      // diagnostic build only: per block 8 words {K-loop shader cycles, K-loop 100 MHz ticks, entry, loop start, loop end, exit (100 MHz), HW_ID, XCC_ID}
+#define X_CLOCK_ENTRY const unsigned long long xc_e = __builtin_amdgcn_s_memrealtime();
+#define X_CLOCK_EXIT(bid_) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 0 && (bid_) < (1 << 17)) { g_xclk[8 * (bid_) + 2] = xc_e; g_xclk[8 * (bid_) + 5] = __builtin_amdgcn_s_memrealtime(); \
+      g_xclk[8 * (bid_) + 6] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4); g_xclk[8 * (bid_) + 7] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20); } }
+#else
+#define X_CLOCK_ENTRY
+#define X_CLOCK_EXIT(bid_)
+#endif
 __constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};
 __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
 
@@ -333,6 +342,9 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         }
     }
 
+#ifdef X_CLOCK
+    const unsigned long long xc_t0 = __builtin_amdgcn_s_memtime(), xc_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     typedef typename std::conditional<MF16, f32x4, f32x16>::type acc_t;
     acc_t acc[TD][TP];
 #pragma unroll
@@ -586,6 +598,13 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     }
 #undef I2V_ISSUE_PIECE
 #undef I2V_CHUNK_VB
+#ifdef X_CLOCK
+    if (t == 0 && bid + (px_base ? 65536 : 0) < (1 << 17)) {      // (tail-split launches: the quarter tiles are recorded from slot 65536 on)
+        const int xb = bid + (px_base ? 65536 : 0);
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        g_xclk[8 * xb] = __builtin_amdgcn_s_memtime() - xc_t0; g_xclk[8 * xb + 1] = r1 - xc_r0; g_xclk[8 * xb + 3] = xc_r0; g_xclk[8 * xb + 4] = r1;
+    }
+#endif
 
     // ---- epilogue: shift, addends, ReLU, gradient gate, NCHW store ----
     const int HoWo = p.Ho * p.Wo;
@@ -791,7 +810,9 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
 template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false>
 __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
     __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<BD, BP, WD, MF16>()];
+    X_CLOCK_ENTRY
     conv_tile<BD, BP, WD, WP, MODE, PREF, PRE, VID, MF16>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem);
+    X_CLOCK_EXIT(blockIdx.x)
 }
 
 // MODE 5 launches (halo staging of 3x3 / stride-1 convolutions on planes HWM wide)
@@ -799,7 +820,9 @@ template <int HWM>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HWM <= 14 ? I2V_SMALL_WPE : (HWM <= 28 ? 6 : 5), HWM <= 14 ? I2V_SMALL_WPE : (HWM <= 28 ? 6 : 5))))
 conv_igemm_halo(const I2VConvParams p, const int n_cd_tiles) {
     __shared__ __attribute__((aligned(16))) float smem[conv_halo_lds_floats<HWM>()];
+    X_CLOCK_ENTRY
     conv_tile<64, 64, 2, 2, 5, false, false, false, false, HWM>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem);
+    X_CLOCK_EXIT(blockIdx.x)
 }
 
 // "Tail split": the first `nA` blocks compute 64x64 tiles over the pixel tiles [0, px_base_b / 64); the remaining blocks cover the
@@ -811,8 +834,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I2V_SM
 conv_igemm_tail(const I2VConvParams p, const int n_cd_a, const int nA, const int n_cd_b, const int64_t px_base_b) {
     constexpr int LA = conv_lds_floats<64, 64, 2, false>(), LB = conv_lds_floats<16, 64, 1, true>();
     __shared__ __attribute__((aligned(16))) float smem[LA > LB ? LA : LB];
+    X_CLOCK_ENTRY
     if ((int)blockIdx.x < nA) conv_tile<64, 64, 2, 2, MODE, false, false, false, false>(p, n_cd_a, blockIdx.x, nA, 0, smem);
     else conv_tile<16, 64, 1, 4, MODE, false, false, false, true>(p, n_cd_b, (int)blockIdx.x - nA, (int)gridDim.x - nA, px_base_b, smem);
+    X_CLOCK_EXIT((int)blockIdx.x < nA ? (int)blockIdx.x : 65536 + (int)blockIdx.x - nA)
 }
 
 // Low-K layers with epilogue operands are HBM-bound (their FLOP/byte is below the machine balance): they

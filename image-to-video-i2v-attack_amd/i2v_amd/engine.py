@@ -17,13 +17,18 @@ from .graphs import Graph
 from .weights import fold_affine, fold_pre_affine
 
 
-_DEVICE_TYPES = set()       # device types of the engines alive in this process ('cuda' for libi2v_hip.so)
+_DEVICE_TYPES = {}          # device type -> number of engines ALIVE on it in this process ('cuda' for libi2v_hip.so)
 
 
-def _ptr(t: torch.Tensor):
+def _ptr(t: torch.Tensor, eng: "Engine" = None):
+    """Device pointer of a tensor handed to the library.  With `eng` the tensor must live on that engine's device type (every
+    call that knows its engine passes it); without, on the device type of some engine that is still alive (an entry goes
+    when its last engine closes -- a host-simulation engine that once existed does not let CPU tensors through for good)."""
     assert t.is_contiguous() and t.dtype == torch.float32, (t.dtype, t.is_contiguous())
-    if t.device.type not in _DEVICE_TYPES:      # a host pointer handed to a HIP kernel reads garbage or faults the GPU
-        raise _lib.I2VError(f"tensor on {t.device} passed to an engine on {sorted(_DEVICE_TYPES)}: move it to the engine's device")
+    ok = t.device.type == eng.device.type if eng is not None else _DEVICE_TYPES.get(t.device.type, 0) > 0
+    if not ok:      # a host pointer handed to a HIP kernel reads garbage or faults the GPU
+        where = eng.device if eng is not None else sorted(k for k, v in _DEVICE_TYPES.items() if v > 0)
+        raise _lib.I2VError(f"tensor on {t.device} passed to an engine on {where}: move it to the engine's device")
     return C.c_void_p(t.data_ptr())
 
 
@@ -42,12 +47,14 @@ class Engine:
         self.capi = capi if capi is not None else _lib.load()
         if capi is None and self.device.type != "cuda":
             raise _lib.I2VError("the I2V engine needs a ROCm device; there is no CPU path")
-        _DEVICE_TYPES.add(self.device.type)
         self.h = C.c_void_p()
-        self.plan_lock = threading.Lock()      # net creation / planning / destruction touch the handle's net table
+        # net creation / planning / destruction touch the handle's net table.  Re-entrant: Net.__del__ -> close() takes it, and the
+        # cyclic GC may finalise an unreachable Net on the very thread that is inside build_net
+        self.plan_lock = threading.RLock()
         self.plan_ms, self.plans = 0.0, 0      # host wall time spent building nets (never inside a timed region of bench.py)
         idx = self.device.index or 0
         _lib.check(self.capi, self.capi.i2v_create(idx, C.byref(self.h)))
+        _DEVICE_TYPES[self.device.type] = _DEVICE_TYPES.get(self.device.type, 0) + 1
 
     def stream(self):
         if self.device.type == "cuda":
@@ -58,6 +65,7 @@ class Engine:
         if self.h:
             self.capi.i2v_destroy(self.h)
             self.h = C.c_void_p()
+            _DEVICE_TYPES[self.device.type] = max(0, _DEVICE_TYPES.get(self.device.type, 0) - 1)
 
     def __del__(self):
         try:
@@ -97,7 +105,7 @@ class Engine:
         assert frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and frames_u8.shape[-1] == 3
         b, t, h, w, _ = frames_u8.shape
         out = torch.empty(b, 3, t, h, w, dtype=torch.float32, device=frames_u8.device)
-        _lib.check(self.capi, self.capi.i2v_clip_from_u8_f32(C.c_void_p(frames_u8.data_ptr()), _ptr(out), b, t, h, w, self.stream()))
+        _lib.check(self.capi, self.capi.i2v_clip_from_u8_f32(C.c_void_p(frames_u8.data_ptr()), _ptr(out, self), b, t, h, w, self.stream()))
         return out
 
     def clip_resize_crop(self, frames_u8: torch.Tensor, short_side=256, crop=224) -> torch.Tensor:
@@ -116,7 +124,7 @@ class Engine:
         xt, yt = tabs[key]
         out = torch.empty(b, 3, t, crop, crop, dtype=torch.float32, device=frames_u8.device)
         _lib.check(self.capi, self.capi.i2v_clip_resize_crop_u8_f32(
-            C.c_void_p(frames_u8.data_ptr()), _ptr(out), C.c_void_p(xt.data_ptr()), C.c_void_p(yt.data_ptr()), b, t, H, W, rh, rw,
+            C.c_void_p(frames_u8.data_ptr()), _ptr(out, self), C.c_void_p(xt.data_ptr()), C.c_void_p(yt.data_ptr()), b, t, H, W, rh, rw,
             cy, cx, crop, crop, self.stream()))
         return out
 
@@ -136,34 +144,34 @@ class Engine:
         xb, xk, yb, yk, kx, ky = tabs[key]
         out = torch.empty(b, 3, t, crop, crop, dtype=torch.float32, device=frames_u8.device)
         _lib.check(self.capi, self.capi.i2v_clip_resample_crop_u8_f32(
-            C.c_void_p(frames_u8.data_ptr()), _ptr(out), C.c_void_p(xb.data_ptr()), C.c_void_p(xk.data_ptr()), kx, C.c_void_p(yb.data_ptr()),
+            C.c_void_p(frames_u8.data_ptr()), _ptr(out, self), C.c_void_p(xb.data_ptr()), C.c_void_p(xk.data_ptr()), kx, C.c_void_p(yb.data_ptr()),
             C.c_void_p(yk.data_ptr()), ky, b, t, H, W, rh, rw, cy, cx, crop, crop, self.stream()))
         return out
 
     def frames_from_video(self, video, x, u):
         b, c, f, h, w = video.shape
-        _lib.check(self.capi, self.capi.i2v_frames_from_video_f32(_ptr(video), _ptr(x), _ptr(u), b, f, h, w, self.stream()))
+        _lib.check(self.capi, self.capi.i2v_frames_from_video_f32(_ptr(video, self), _ptr(x, self), _ptr(u, self), b, f, h, w, self.stream()))
 
     def compose(self, u, delta, out, b, f, eps, video_layout=False):
         h, w = u.shape[-2:]
-        _lib.check(self.capi, self.capi.i2v_compose_f32(_ptr(u), _ptr(delta), _ptr(out), b, f, h, w, eps,
+        _lib.check(self.capi, self.capi.i2v_compose_f32(_ptr(u, self), _ptr(delta, self), _ptr(out, self), b, f, h, w, eps,
                                                         1 if video_layout else 0, self.stream()))
 
     def adam_step(self, delta, m, v, gx, u, eps, lr, step_t, beta1=0.9, beta2=0.999, adam_eps=1e-8):
         n, _, h, w = delta.shape
-        _lib.check(self.capi, self.capi.i2v_adam_step_f32(_ptr(delta), _ptr(m), _ptr(v), _ptr(gx), _ptr(u), n, h * w,
+        _lib.check(self.capi, self.capi.i2v_adam_step_f32(_ptr(delta, self), _ptr(m, self), _ptr(v, self), _ptr(gx, self), _ptr(u, self), n, h * w,
                                                           eps, lr, beta1, beta2, adam_eps, step_t, self.stream()))
 
     def sign_step(self, adv, u, grad, chan_stride, step, eps):
-        _lib.check(self.capi, self.capi.i2v_sign_step_f32(_ptr(adv), _ptr(u), _ptr(grad), adv.numel(), chan_stride,
+        _lib.check(self.capi, self.capi.i2v_sign_step_f32(_ptr(adv, self), _ptr(u, self), _ptr(grad, self), adv.numel(), chan_stride,
                                                           step, eps, self.stream()))
 
     def sign_step_delta_gx(self, delta, gx, u, eps, step):
-        _lib.check(self.capi, self.capi.i2v_sign_step_delta_gx_f32(_ptr(delta), _ptr(gx), _ptr(u), delta.numel(), eps, step,
+        _lib.check(self.capi, self.capi.i2v_sign_step_delta_gx_f32(_ptr(delta, self), _ptr(gx, self), _ptr(u, self), delta.numel(), eps, step,
                                                                    self.stream()))
 
     def sign_step_delta(self, delta, grad, step):
-        _lib.check(self.capi, self.capi.i2v_sign_step_delta_f32(_ptr(delta), _ptr(grad), delta.numel(), step, self.stream()))
+        _lib.check(self.capi, self.capi.i2v_sign_step_delta_f32(_ptr(delta, self), _ptr(grad, self), delta.numel(), step, self.stream()))
 
     def tt_grad_mix(self, grads, kernel, moves, weight):
         """`TemporalTranslation._grad_augmentation` (video_attacks.py:160-175): grads (D, N, C, T, H, W) on the device, kernel /
@@ -173,16 +181,16 @@ class Engine:
         k = np.ascontiguousarray(np.asarray(kernel, dtype=np.float32).reshape(D))
         mv = np.ascontiguousarray(np.asarray(moves, dtype=np.int32).reshape(D))
         out = torch.empty(N, C_, T, H, W, dtype=torch.float32, device=grads.device)
-        _lib.check(self.capi, self.capi.i2v_tt_grad_mix_f32(_ptr(grads.contiguous()), _ptr(out), C.c_void_p(k.ctypes.data), C.c_void_p(mv.ctypes.data),
+        _lib.check(self.capi, self.capi.i2v_tt_grad_mix_f32(_ptr(grads.contiguous(), self), _ptr(out, self), C.c_void_p(k.ctypes.data), C.c_void_p(mv.ctypes.data),
                                                             D, N * C_, T, H * W, float(weight), self.stream()))
         return out
 
     def aens_coeffs(self, prev, coeffs, momentum):
-        _lib.check(self.capi, self.capi.i2v_aens_coeffs_f32(_ptr(prev), _ptr(coeffs), momentum, coeffs.numel(), self.stream()))
+        _lib.check(self.capi, self.capi.i2v_aens_coeffs_f32(_ptr(prev, self), _ptr(coeffs, self), momentum, coeffs.numel(), self.stream()))
 
     def aens_reduce(self, cos, coeffs, feat_sum, weighted):
         L, n = cos.shape
-        _lib.check(self.capi, self.capi.i2v_aens_reduce_f32(_ptr(cos), _ptr(coeffs), L, n, _ptr(feat_sum), _ptr(weighted), self.stream()))
+        _lib.check(self.capi, self.capi.i2v_aens_reduce_f32(_ptr(cos, self), _ptr(coeffs, self), L, n, _ptr(feat_sum, self), _ptr(weighted, self), self.stream()))
 
 
 class HookInfo:
@@ -285,17 +293,17 @@ class Net:
         return self.eng.capi.i2v_net_workspace_bytes(self.eng.h, self.id)
 
     def forward(self, x: torch.Tensor):
-        _lib.check(self.eng.capi, self.eng.capi.i2v_net_forward(self.eng.h, self.id, _ptr(x), x.shape[0], self.eng.stream()))
+        _lib.check(self.eng.capi, self.eng.capi.i2v_net_forward(self.eng.h, self.id, _ptr(x, self.eng), x.shape[0], self.eng.stream()))
 
     def backward(self, gx: torch.Tensor, accumulate=False):
-        _lib.check(self.eng.capi, self.eng.capi.i2v_net_backward(self.eng.h, self.id, _ptr(gx), 1 if accumulate else 0,
+        _lib.check(self.eng.capi, self.eng.capi.i2v_net_backward(self.eng.h, self.id, _ptr(gx, self.eng), 1 if accumulate else 0,
                                                                  self.eng.stream()))
 
     def read_tensor(self, tid: int, frames: int, grad=False) -> torch.Tensor:
         ts = self.graph.tensors[tid]
         out = torch.empty(frames, ts.C, ts.H, ts.W, dtype=torch.float32, device=self.eng.device)
         _lib.check(self.eng.capi, self.eng.capi.i2v_net_read_tensor(self.eng.h, self.id, self.ten_id[tid], 1 if grad else 0,
-                                                                    _ptr(out), frames, self.eng.stream()))
+                                                                    _ptr(out, self.eng), frames, self.eng.stream()))
         return out
 
     def save_hook(self, i: int, frames: int) -> torch.Tensor:
@@ -308,7 +316,7 @@ class Net:
         hi = self.hooks[i]
         capi = self.eng.capi
         _lib.check(capi, capi.i2v_cossim_fwd_bwd_f32(
-            C.c_void_p(hi.act), hi.act_stride, _ptr(init), hi.D, hi.D, frames,
+            C.c_void_p(hi.act), hi.act_stride, _ptr(init, self.eng), hi.D, hi.D, frames,
             C.c_void_p(coef_dev.data_ptr()) if coef_dev is not None else C.c_void_p(0), coef_index, coef_host,
             hi.post_relu, 0, C.c_void_p(cos_out.data_ptr()), C.c_void_p(hi.grad), hi.grad_stride,
             C.c_void_p(scratch.data_ptr()), self.eng.stream()))
@@ -337,14 +345,14 @@ class Net:
         doubles at the start of `scratch`.  `act` overrides the activation (used once to measure |d0|)."""
         hi = self.hooks[i]
         capi = self.eng.capi
-        a, a_s = (C.c_void_p(hi.act), hi.act_stride) if act is None else (_ptr(act), hi.D)
-        _lib.check(capi, capi.i2v_ilaf_reduce_f32(a, a_s, _ptr(ori), _ptr(adv0), hi.D, frames,
+        a, a_s = (C.c_void_p(hi.act), hi.act_stride) if act is None else (_ptr(act, self.eng), hi.D)
+        _lib.check(capi, capi.i2v_ilaf_reduce_f32(a, a_s, _ptr(ori, self.eng), _ptr(adv0, self.eng), hi.D, frames,
                                                   C.c_void_p(scratch.data_ptr()), self.eng.stream()))
 
     def ilaf_grad(self, i: int, ori, adv0, init_norm: float, loss_out: torch.Tensor, scratch: torch.Tensor, frames: int):
         hi = self.hooks[i]
         capi = self.eng.capi
-        _lib.check(capi, capi.i2v_ilaf_grad_f32(C.c_void_p(hi.act), hi.act_stride, _ptr(ori), _ptr(adv0), hi.D, frames,
+        _lib.check(capi, capi.i2v_ilaf_grad_f32(C.c_void_p(hi.act), hi.act_stride, _ptr(ori, self.eng), _ptr(adv0, self.eng), hi.D, frames,
                                                 init_norm, hi.post_relu, 0, C.c_void_p(loss_out.data_ptr()),
                                                 C.c_void_p(hi.grad), hi.grad_stride, C.c_void_p(scratch.data_ptr()),
                                                 self.eng.stream()))
@@ -356,15 +364,15 @@ class Net:
         `scale * d loss / d feature` into every hook's gradient view (base_attacks.py:282-284)."""
         capi = self.eng.capi
         clips = in_frames // self.graph.tensors[self.graph.input].T
-        bias_p = _ptr(bias) if bias is not None else C.c_void_p(0)
+        bias_p = _ptr(bias, self.eng) if bias is not None else C.c_void_p(0)
         assert labels.dtype == torch.int32 and labels.numel() == clips
         if isinstance(i, int):
             hi = self.hooks[i]
             C_, H_, W_ = hi.shape
             assert W.shape[1] == C_
             _lib.check(capi, capi.i2v_head_ce_f32(
-                C.c_void_p(hi.act), hi.act_stride, C_, H_ * W_, hi.T, clips, _ptr(W), bias_p,
-                W.shape[0], C.c_void_p(labels.data_ptr()), scale, hi.post_relu, 0, _ptr(logits), _ptr(loss_each), C.c_void_p(hi.grad),
+                C.c_void_p(hi.act), hi.act_stride, C_, H_ * W_, hi.T, clips, _ptr(W, self.eng), bias_p,
+                W.shape[0], C.c_void_p(labels.data_ptr()), scale, hi.post_relu, 0, _ptr(logits, self.eng), _ptr(loss_each, self.eng), C.c_void_p(hi.grad),
                 hi.grad_stride, C.c_void_p(scratch.data_ptr()), self.eng.stream()))
             return
         his = [self.hooks[k] for k in i]
@@ -376,8 +384,8 @@ class Net:
             _lib.check(capi, capi.i2v_head_pool_f32(C.c_void_p(hi.act), hi.act_stride, hi.shape[0], hi.shape[1] * hi.shape[2], hi.T, clips,
                                                     Ctot, off, sp, st))
             off += hi.shape[0]
-        _lib.check(capi, capi.i2v_head_logits_ce_f32(Ctot, clips, _ptr(W), bias_p, W.shape[0], C.c_void_p(labels.data_ptr()), scale,
-                                                     _ptr(logits), _ptr(loss_each), sp, st))
+        _lib.check(capi, capi.i2v_head_logits_ce_f32(Ctot, clips, _ptr(W, self.eng), bias_p, W.shape[0], C.c_void_p(labels.data_ptr()), scale,
+                                                     _ptr(logits, self.eng), _ptr(loss_each, self.eng), sp, st))
         off = 0
         for hi in his:
             _lib.check(capi, capi.i2v_head_grad_f32(C.c_void_p(hi.act), hi.act_stride, hi.shape[0], hi.shape[1] * hi.shape[2], hi.T, clips,

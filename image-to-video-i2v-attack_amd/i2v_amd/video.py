@@ -33,6 +33,7 @@ class VideoModel(object):
         self.tiny = tiny
         self.weight_seed = weight_seed
         self._sd = state_dict
+        self._loaded = None                  # (arch, state_dict) read from $I2V_WEIGHTS_DIR or synthesised: backbone AND head
         self.training = False
         self.graph_for(self.in_thw)          # unknown names fail at construction, like get_model(cfg)
 
@@ -41,7 +42,11 @@ class VideoModel(object):
         return build(self.model_type, tuple(thw), full=self.num_classes is not None)
 
     def state_dict_for(self, graph):
-        return self._sd if self._sd is not None else _weights.load_state_dict(graph, self.weight_seed)
+        if self._sd is not None:
+            return self._sd
+        if self._loaded is None or self._loaded[0] != graph.arch:
+            self._loaded = (graph.arch, _weights.load_state_dict(graph, self.weight_seed, keep_head=self.num_classes is not None))
+        return self._loaded[1]
 
     def hook_tensors(self, graph):
         return _graphs.video_hooks(graph, self.model_type)
@@ -57,16 +62,17 @@ class VideoModel(object):
         under the same opt-in rules as the backbone, seeded synthetic values."""
         import torch
         C_ = sum(graph.tensors[t].C for t in self.classifier_hook(graph))
-        sd = self._sd or {}
+        sd = self.state_dict_for(graph)      # the SAME source as the backbone: a checkpoint's `fc.*` travels with it
         if "fc.weight" in sd:
             w, b = sd["fc.weight"].float(), sd.get("fc.bias")
             if tuple(w.shape) != (self.num_classes, C_):
                 raise ValueError(f"fc.weight has shape {tuple(w.shape)}, expected {(self.num_classes, C_)}")
             return w.contiguous(), (b.float().contiguous() if b is not None else None)
-        if self._sd is not None:
-            raise KeyError("state_dict has no fc.weight for the classifier head")
-        if self.weight_seed is None and not _weights.synthetic_allowed():
-            raise _weights.MissingWeights(f"no classifier-head weights for {graph.arch!r} (see weights.load_state_dict)")
+        source = "state_dict" if self._sd is not None else _weights.SOURCES.get(graph.arch, "")
+        if not source.startswith("synthetic"):
+            # a real backbone with a random classifier would attack a meaningless model and still write valid-looking files
+            raise KeyError(f"{source or 'the state_dict'} has no fc.weight for the classifier head of {graph.arch!r}; "
+                           "a pretrained backbone is never paired with a synthetic head")
         gen = torch.Generator().manual_seed(7919 * (self.weight_seed or 0) + 13)
         return (torch.randn(self.num_classes, C_, generator=gen) * (1.0 / C_) ** 0.5).contiguous(), \
             (torch.randn(self.num_classes, generator=gen) * 0.01).contiguous()

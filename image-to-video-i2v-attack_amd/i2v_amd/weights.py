@@ -57,6 +57,11 @@ class MissingWeights(FileNotFoundError):
     pass
 
 
+#: classifier-head parameters (torchvision and gluoncv both name the last Linear `fc`); not part of any graph's
+#: `param_shapes()`, kept next to the backbone's tensors whenever the checkpoint has them
+HEAD_KEYS = ("fc.weight", "fc.bias")
+
+
 #: arch -> where its weights came from in this process ("<path>" or "synthetic(seed=N)"); printed once per arch
 SOURCES: Dict[str, str] = {}
 
@@ -65,9 +70,9 @@ def synthetic_allowed() -> bool:
     return os.environ.get("I2V_SYNTHETIC_WEIGHTS", "") not in ("", "0")
 
 
-def load_state_dict(graph: Graph, seed=None) -> Dict[str, torch.Tensor]:
+def load_state_dict(graph: Graph, seed=None, keep_head: bool = False) -> Dict[str, torch.Tensor]:
     """`$I2V_WEIGHTS_DIR/<arch>.pth` (a torchvision-layout `state_dict`; extra keys such as `layer4.*`, `fc.*`,
-    `num_batches_tracked` are ignored) when it exists.  Otherwise the seeded synthetic initialiser -- but only when
+    `num_batches_tracked` are ignored; with `keep_head` the classifier's `fc.weight` / `fc.bias` are returned as well) when it exists.  Otherwise the seeded synthetic initialiser -- but only when
     the caller asked for it: an explicit integer `seed` (tests, bench) or `I2V_SYNTHETIC_WEIGHTS=1`.  The reference
     attacks ImageNet-pretrained backbones (`pretrained=True`, image_attacks.py:88-101); silently perturbing clips
     against random weights would produce valid-looking but meaningless `*-adv.npy` files, so that case raises."""
@@ -85,7 +90,11 @@ def load_state_dict(graph: Graph, seed=None) -> Dict[str, torch.Tensor]:
             if tuple(sd[k].shape) != tuple(shp):
                 raise ValueError(f"{path}: {k} has shape {tuple(sd[k].shape)}, expected {shp}")
         _note(graph.arch, path)
-        return {k: sd[k].float().contiguous() for k in shapes}
+        out = {k: sd[k].float().contiguous() for k in shapes}
+        for k in HEAD_KEYS if keep_head else ():      # the classifier head travels with its backbone (video.VideoModel.head_weights)
+            if k in sd:
+                out[k] = sd[k].float().contiguous()
+        return out
     explicit = seed is not None
     if seed is None:
         if not synthetic_allowed():
@@ -113,7 +122,11 @@ def convert_gluoncv_state_dict(graph: Graph, sd: Dict[str, torch.Tensor], rules=
     `gluoncv.torch.model_zoo.get_model(cfg)`, `image_fine_tune_attack.py:58-66`) onto the key layout of the video graph IR
     (`graphs.i3d_resnet` / `graphs.slowfast_res2`): unwraps `{'state_dict': ...}`, strips a DataParallel `module.` prefix,
     applies `rules` -- `(regex, replacement)` pairs, first match wins -- and then REQUIRES every parameter the graph reads
-    to be present with the right shape (everything else -- later stages, heads, `num_batches_tracked` -- is dropped).
+    to be present with the right shape.  Dropped: `num_batches_tracked`, and parameters of stages the graph does not
+    contain at all (later stages when the graph stops at a hook).  The classifier head (`fc.*`) is kept.  NOT dropped:
+    a checkpoint parameter that lives INSIDE a stage the graph builds but that the graph does not read (e.g. the
+    `res_layers.1.*` non-local block of an `i3d_nl5` checkpoint offered to a plain I3D graph) -- the checkpoint then
+    describes another network than the graph and loading it "successfully" would attack the wrong model: KeyError.
 
     The graph's own names follow the attributes the reference dereferences on those models (`res_layers`, `slow_res2`,
     `fast_res2`, `image_attacks.py:513-519`) and the Bottleneck layout of gluoncv's action-recognition ResNets
@@ -133,7 +146,8 @@ def convert_gluoncv_state_dict(graph: Graph, sd: Dict[str, torch.Tensor], rules=
                 break
         renamed[k] = v
     out, missing, wrong = {}, [], []
-    for k, shp in graph.param_shapes().items():
+    shapes = graph.param_shapes()
+    for k, shp in shapes.items():
         if k not in renamed:
             missing.append(k)
         elif tuple(renamed[k].shape) != tuple(shp):
@@ -143,7 +157,24 @@ def convert_gluoncv_state_dict(graph: Graph, sd: Dict[str, torch.Tensor], rules=
     if missing or wrong:
         raise KeyError(f"checkpoint does not cover the {graph.arch} graph: {len(missing)} missing (e.g. {missing[:3]}), "
                        f"{len(wrong)} with another shape (e.g. {wrong[:2]}); pass `rules=[(regex, replacement), ...]` to rename")
+    stages = {_stage(k) for k in shapes}
+    unread = sorted(k for k in renamed if k not in shapes and k not in HEAD_KEYS and not k.endswith("num_batches_tracked")
+                    and _stage(k) in stages)
+    if unread:
+        raise KeyError(f"checkpoint has {len(unread)} parameters inside stages the {graph.arch} graph builds but does not read "
+                       f"(e.g. {unread[:3]}): it describes a different network (non-local blocks?) than this graph")
+    for k in HEAD_KEYS:
+        if k in renamed:
+            out[k] = renamed[k].float().contiguous()
     return out
+
+
+def _stage(key: str) -> str:
+    """The stage a parameter belongs to: its first path component, plus the second when that is an index
+    (`res_layers.1.0.conv1.weight` -> `res_layers.1`, `slow_res2.0.conv1.weight` -> `slow_res2`, `first_stage.conv1.weight`
+    -> `first_stage`)."""
+    parts = key.split(".")
+    return ".".join(parts[:2]) if len(parts) > 2 and parts[1].isdigit() else parts[0]
 
 
 def fold_affine(nd, sd):

@@ -131,33 +131,50 @@ def main(argv=None, ucf101=False):
             todo.put(None)
 
     def writer():
+        failed = False
         while True:
             item = done.get()
             if item is None:
                 return
-            labels, host, event = item
-            if event is not None:
-                event.synchronize()
-            for ind, label in enumerate(labels):
-                np.save(os.path.join(args.adv_path, "{}-adv".format(label.item())), host[ind].numpy())
+            if failed:
+                continue                     # keep draining so that the main loop's done.put() never blocks
+            try:
+                labels, host, event = item
+                if event is not None:
+                    event.synchronize()
+                for ind, label in enumerate(labels):
+                    np.save(os.path.join(args.adv_path, "{}-adv".format(label.item())), host[ind].numpy())
+            except BaseException as e:       # disk full, unwritable directory: end the run with that error
+                writer_error.append(e)
+                failed = True
 
     threads = [threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)]
     for t in threads:
         t.start()
     ended = False
+    carry = None                            # a loader batch taken from the queue that would have overshot the group
+    writer_error = []
     while not ended:
+        if writer_error:
+            break
         # Loader batches that are READY are attacked in one engine call, up to --group_clips clips (frames are independent in
         # I2V / ENS-I2V: every clip and every logged cost is what the batch's own call produces, `forward_grouped`); the
         # reference's default `--batch_size 1` alone would leave the GPU a third empty.  Nothing waits for a batch that is
         # not there yet.
         items, nclips = [], 0
         while nclips < group:
-            try:
-                item = todo.get() if not items else todo.get_nowait()
-            except queue.Empty:
-                break
+            if carry is not None:
+                item, carry = carry, None
+            else:
+                try:
+                    item = todo.get() if not items else todo.get_nowait()
+                except queue.Empty:
+                    break
             if item is None:
                 ended = True
+                break
+            if items and nclips + int(item[1].shape[0]) > max(group, args.batch_size):
+                carry = item                # the plan was reserved for `group` clips: never collect more (a larger group would re-plan)
                 break
             items.append(item)
             nclips += int(item[1].shape[0])
@@ -192,6 +209,8 @@ def main(argv=None, ucf101=False):
             done.put((val_label, host, event))
     done.put(None)
     threads[1].join()
+    if writer_error:
+        raise writer_error[0]
     if reader_error:
         raise reader_error[0]
     with open(os.path.join(args.adv_path, "loss_info_{}.json".format(args.batch_index)), "w") as opt:

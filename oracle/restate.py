@@ -254,7 +254,8 @@ def aens_coeffs(prev, coeffs, momentum):
 def run_attack(nets: Sequence[OracleNet], videos: torch.Tensor, *, steps: int, step_size: float,
                epsilon: float = 16 / 255, mode: str = "i2v", coeffs: Optional[torch.Tensor] = None,
                momentum: float = 0.0, coef_CE: bool = False, trace: bool = False,
-               forced_states: Optional[Sequence] = None, forced_coeffs: Optional[Sequence[torch.Tensor]] = None):
+               forced_states: Optional[Sequence] = None, forced_coeffs: Optional[Sequence[torch.Tensor]] = None,
+               first_step: int = 0):
     """Restates `ImageGuidedFMDirection_Adam.forward` (`image_attacks.py:294-364`, one net, one
     hook), `ImageGuidedFML2_Adam_MultiModels.forward` (`:426-496`, several nets) [mode 'i2v'],
     `AENS_I2V_MF.forward` (`TPAMI_attack.py:223-320`) [mode 'aens'] and
@@ -263,7 +264,9 @@ def run_attack(nets: Sequence[OracleNet], videos: torch.Tensor, *, steps: int, s
     Teacher forcing: `forced_states[i] = (delta, exp_avg, exp_avg_sq)`, when given and not None, replaces the
     optimiser state at the START of step i (i.e. the reference's state after step i-1; the Adam step count is i
     either way), and `forced_coeffs[i]` replaces the AENS coefficients used in step i (the self-computed ones are
-    still returned in `weights_own`).
+    still returned in `weights_own`).  `first_step` skips the iterations before it (only meaningful together with a
+    forced state for that step: a mid-trajectory step at full size without paying for the steps that led there); the
+    trace lists then hold the executed steps only.
     Returns a dict: adv (b,3,f,h,w), costs[steps] (float32), and with trace=True per-step
     delta (after the update), per-step gradients, cos per (step, layer, frame), weights.
     """
@@ -281,7 +284,7 @@ def run_attack(nets: Sequence[OracleNet], videos: torch.Tensor, *, steps: int, s
     out = {"costs": np.zeros(steps, np.float32), "deltas": [], "cos": [], "weights": [], "weights_own": [], "grad0": None,
            "grads": []}
     prev = torch.ones(L, dtype=dt) if mode == "aens" else None
-    for i in range(steps):
+    for i in range(first_step, steps):
         if forced_states is not None and forced_states[i] is not None:
             fd, fm, fv = forced_states[i]
             delta, opt.m, opt.v, opt.t = fd.clone().to(dt), fm.clone().to(dt), fv.clone().to(dt), i
@@ -326,7 +329,7 @@ def run_attack(nets: Sequence[OracleNet], videos: torch.Tensor, *, steps: int, s
             cost = cosm.sum()                                       # image_attacks.py:347
         out["costs"][i] = float(cost)
         g = compose_backward(gx, mask)
-        if i == 0 and trace:
+        if i == first_step and trace:
             out["grad0"] = g.clone()
         if trace:
             out["grads"].append(g.clone())

@@ -124,3 +124,41 @@ def check_teacher_forced(fx, atk, to_dev=lambda t: t):
             nxt = atk.coeffs.clone()                                        # = the forced coefficients of step i
             eng.aens_coeffs(atk._prev, nxt, float(atk.momentum))            # TPAMI_attack.py:265 on the engine's own prev
             np.testing.assert_allclose(nxt.cpu().numpy(), fx["weights"][i + 1], rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# full-size, WELL-CONDITIONED teacher-forced step (VERDICT r2 "what's weak" 1): the delta_0 step sits at cos = 1 - 1e-9
+# where the gradient is a difference of nearly equal fp32 activations; after t free-running steps it is not, and one
+# iteration from that state is a deterministic function that can be held to north_star's atol 1e-4 at BASELINE size
+# ---------------------------------------------------------------------------------------------------------------
+def check_mid_trajectory_step(mk, oracle_nets, vid, pick, t=3, lr=0.005, tag=""):
+    """`mk(steps)` builds the product attack.  Runs it for `t` free steps on the whole batch `vid`, takes the optimiser state
+    (delta_t, m_t, v_t) of the frames `pick`, then runs ONE `forced_step` on those frames through the HIP engine and ONE
+    step of the float64 oracle (`restate.run_attack(first_step=t)`, `image_attacks.py:325-358`) from the same state.
+    Asserts: cost rtol 2e-4; the gradient handed to Adam within 1e-4 max|g| on >= 99 % of the pixels; delta_{t+1} within
+    atol 1e-4 on EVERY pixel whose gradient is >= 5 % of max|g|."""
+    from oracle import restate
+    b = vid.shape[0]
+    run = mk(t)
+    run.clip_lanes = 1
+    run(vid, torch.zeros(b, dtype=torch.long), [f"v{i}" for i in range(b)])
+    d, m, v = (x[pick].clone() for x in (run._delta, run._m, run._v))
+    del run
+    sub = restate.unflatten_frames(restate.flatten_frames(vid)[pick].contiguous(), len(pick), 1).contiguous()   # one-frame clips
+    one = mk(1)
+    d1, m1, v1, cost = one.forced_step(sub, d, m, v, t)
+    ref = restate.run_attack(oracle_nets, sub.double(), steps=t + 1, step_size=lr, trace=True, first_step=t,
+                             forced_states=[None] * t + [(d.cpu(), m.cpu(), v.cpu())])
+    g_ref = ref["grads"][0].numpy()
+    gmax = np.abs(g_ref).max()
+    g_hip = (m1.cpu().numpy().astype(np.float64) - 0.9 * m.cpu().numpy().astype(np.float64)) / 0.1
+    rel = np.abs(g_hip - g_ref) / gmax
+    derr = np.abs(d1.cpu().numpy().astype(np.float64) - ref["deltas"][0].numpy())
+    well = np.abs(g_ref) >= 5e-2 * gmax
+    print(f"mid-trajectory step {tag}: t={t} cost hip {cost:.6f} oracle {float(ref['costs'][t]):.6f}; max|g| {gmax:.3e}; "
+          f"grad err/max|g|: max {rel.max():.2e}, frac<1e-4 {float((rel < 1e-4).mean()):.5f}; delta err: max(all) {derr.max():.2e}, "
+          f"max(|g|>=5%) {derr[well].max():.2e}, frac(all)<1e-4 {float((derr < 1e-4).mean()):.5f}, well-conditioned pixels {int(well.sum())}")
+    np.testing.assert_allclose(cost, float(ref["costs"][t]), rtol=2e-4)
+    assert (rel < 1e-4).mean() >= 0.99, float((rel < 1e-4).mean())
+    assert derr[well].max() < 1e-4, float(derr[well].max())
+    del one

@@ -235,6 +235,19 @@ def test_full_size_layers(eng, model, depths):
     assert (gx.cpu() - ref).abs().max() <= 2e-4 * ref.abs().max()
 
 
+def test_full_size_mid_trajectory_teacher_forced_step_resnet50(eng):
+    """VERDICT r2 (weak 1): the headline configuration -- ResNet-50 layer3, 224^2, one 32-frame clip -- run for 3 free steps
+    on the HIP engine; from (delta_3, m_3, v_3) of two frames ONE engine iteration against ONE float64 oracle iteration
+    (`image_attacks.py:325-358`): cost rtol 2e-4, gradient 1e-4 max|g| on >= 99 % of the pixels, delta_4 atol 1e-4 on every
+    pixel with |g| >= 5 % max.  This is the well-conditioned counterpart of the delta_0 checks (cos = 1 - 1e-9 there)."""
+    g = graphs.build("resnet50", (224, 224))
+    onet = restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hooks[3]], dtype=torch.float64)
+    u8 = torch.randint(0, 256, (1, 3, 32, 224, 224), generator=torch.Generator().manual_seed(1000), dtype=torch.uint8)
+    vid = gu.videos_of({"clip_u8": u8.numpy()})
+    mk = lambda steps: attacks.ImageGuidedFMDirection_Adam(["resnet50"], depth=3, step_size=0.005, steps=steps, weight_seed=0)   # noqa: E731
+    gu.check_mid_trajectory_step(mk, [onet], vid, [5, 29], t=3, lr=0.005, tag="resnet50 layer3 224^2")
+
+
 def _one_conv_graph(cin, cout, k, stride, pad, hw, relu, residual):
     """input(3) -> 3x3 conv to `cin` channels -> the convolution under test [-> hook]."""
     g = graphs.Graph("unit", (hw, hw))

@@ -109,6 +109,14 @@ def test_config2_ens_resnet50_vgg16_densenet121_batch8(eng):
     assert (got - want).abs().mean() < 5e-3
     del one, two
     torch.cuda.empty_cache()
+    # ---- mid-trajectory teacher-forced step: from the state after 3 free steps of the 8-clip run, one iteration
+    # of all three backbones against one float64 oracle iteration on frames {0, 255}, and each leg on its own ----
+    gu.check_mid_trajectory_step(mk, nets, vid, pick, t=3, lr=0.005, tag="config2 ENS resnet50+vgg16+densenet121")
+    torch.cuda.empty_cache()
+    for n, onet in zip(names[1:], nets[1:]):          # the VGG-16 and DenseNet-121 legs alone (ResNet-50: test_gpu_parity.py)
+        mk1 = lambda steps, n=n: attacks.ImageGuidedFMDirection_Adam([n], depth=3, step_size=0.005, steps=steps, weight_seed=0)   # noqa: E731
+        gu.check_mid_trajectory_step(mk1, [onet], vid[:1], [3, 30], t=3, lr=0.005, tag=f"{n} depth 3, 224^2")
+        torch.cuda.empty_cache()
     # ---- the stated 10-step run ----
     atk = mk(10)
     adv = atk(vid, lab, vnames).cpu()

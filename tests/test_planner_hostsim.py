@@ -304,3 +304,33 @@ def test_pool_output_plane_is_validated():
     assert pool_into(7) == 0            # ceil_mode
     assert pool_into(8) != 0 and b"pool output plane" in cap.i2v_last_error()
     assert pool_into(5) != 0
+
+
+def test_device_guard_is_per_engine():
+    """the pointer guard checks the OWNING engine's device -- a host-simulation (cpu) engine that exists, or once
+    existed, in the process must not let CPU tensors through to a HIP engine."""
+    import types
+    from i2v_amd import engine as _engine, lib as _lib
+    eng = hostsim_engine()
+    t = torch.zeros(4)
+    assert _engine._ptr(t, eng).value == t.data_ptr()
+    hip_like = types.SimpleNamespace(device=torch.device("cuda:0"))
+    with pytest.raises(_lib.I2VError, match="passed to an engine"):
+        _engine._ptr(t, hip_like)
+    assert _engine._DEVICE_TYPES.get("cpu", 0) >= 1
+    assert isinstance(eng.plan_lock, type(__import__("threading").RLock()))
+
+
+@pytest.mark.parametrize("model", ["resnet", "vgg"])
+def test_mid_trajectory_teacher_forced_step_hostsim(model):
+    """The full-size GPU check (`golden_util.check_mid_trajectory_step`) on the tiny backbones through the host simulation:
+    3 free steps, then one engine iteration vs one float64 oracle iteration from the same optimiser state."""
+    hw = 48
+    g = graphs.build_tiny(model, (hw, hw))
+    onet = restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hooks[2]], dtype=torch.float64)
+    u8 = torch.randint(0, 256, (2, 3, 4, hw, hw), generator=torch.Generator().manual_seed(77), dtype=torch.uint8)
+    vid = gu.videos_of({"clip_u8": u8.numpy()})
+    eng = hostsim_engine()
+    mk = lambda steps: attacks.ImageGuidedFMDirection_Adam([model], depth=2, step_size=0.005, steps=steps, weight_seed=0,   # noqa: E731
+                                                           engine=eng, graph_builder=graphs.build_tiny)
+    gu.check_mid_trajectory_step(mk, [onet], vid, [1, 6], t=3, lr=0.005, tag=f"hostsim tiny {model}")

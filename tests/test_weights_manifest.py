@@ -90,9 +90,16 @@ def test_gluoncv_key_converter(model_type):
     for k in list(want):
         if k.endswith("running_mean"):
             ckpt["module." + k.replace("running_mean", "num_batches_tracked")] = torch.tensor(0)
-    ckpt["module.fc.weight"] = torch.zeros(400, 2048)                               # head: dropped
+    ckpt["module.fc.weight"] = torch.zeros(400, 2048)                               # head: kept
+    ckpt["module.res_layers.9.0.conv1.weight"] = torch.zeros(1)                     # a stage the graph does not build: dropped
     got = weights.convert_gluoncv_state_dict(g, {"state_dict": ckpt})
-    assert set(got) == set(want) and all(torch.equal(got[k], want[k]) for k in want)
+    assert set(got) == set(want) | {"fc.weight"} and all(torch.equal(got[k], want[k]) for k in want)
+    got.pop("fc.weight")
+    # a parameter INSIDE a stage the graph builds that the graph does not read (an i3d_nl5 non-local block
+    # offered to the plain I3D graph) is a different network, not an ignorable extra
+    stage = next(k for k in want if k.count(".") >= 3).rsplit(".", 2)[0]
+    with pytest.raises(KeyError, match="different network"):
+        weights.convert_gluoncv_state_dict(g, dict(ckpt, **{"module." + stage + ".nl_theta.weight": torch.zeros(4, 4, 1, 1, 1)}))
     # a checkpoint whose names differ needs rules; without them the converter fails loudly
     if "i3d" in model_type:
         odd = {k.replace("res_layers.", "layer"): v for k, v in want.items()}
@@ -106,3 +113,27 @@ def test_gluoncv_key_converter(model_type):
     from i2v_amd import video
     vm = video.VideoModel(model_type, (32, 224, 224), state_dict=got)
     assert vm.state_dict_for(g) is got
+
+
+def test_classifier_head_travels_with_its_backbone(tmp_path, monkeypatch):
+    """`attack.py --model_factory native` builds VideoModel(..., num_classes=K) without a state_dict; the head
+    must come from the same `$I2V_WEIGHTS_DIR/<arch>.pth` as the backbone, and a real backbone is never paired with a
+    synthetic `fc`."""
+    from i2v_amd import video
+    vm = video.VideoModel("i3d_resnet50", (8, 32, 32), tiny=True, num_classes=5)
+    g = vm.graph_for((8, 32, 32))
+    sd = weights.synthetic_state_dict(g, 4)
+    C_ = sum(g.tensors[t].C for t in vm.classifier_hook(g))
+    monkeypatch.setenv("I2V_WEIGHTS_DIR", str(tmp_path))
+    monkeypatch.delenv("I2V_SYNTHETIC_WEIGHTS", raising=False)
+    torch.save(sd, tmp_path / f"{g.arch}.pth")                       # backbone only
+    with pytest.raises(KeyError, match="never paired"):
+        video.VideoModel("i3d_resnet50", (8, 32, 32), tiny=True, num_classes=5).head_weights(g)
+    fcw, fcb = torch.randn(5, C_), torch.randn(5)
+    torch.save(dict(sd, **{"fc.weight": fcw, "fc.bias": fcb}), tmp_path / f"{g.arch}.pth")
+    W, b = video.VideoModel("i3d_resnet50", (8, 32, 32), tiny=True, num_classes=5).head_weights(g)
+    assert torch.equal(W, fcw) and torch.equal(b, fcb)
+    # synthetic backbone (explicit seed, no checkpoint): synthetic head is allowed
+    monkeypatch.setenv("I2V_WEIGHTS_DIR", str(tmp_path / "none"))
+    W, b = video.VideoModel("i3d_resnet50", (8, 32, 32), tiny=True, num_classes=5, weight_seed=2).head_weights(g)
+    assert tuple(W.shape) == (5, C_)
