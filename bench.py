@@ -146,6 +146,8 @@ def parse_args(argv=None):
                     help="nccl = RCCL over xGMI (measurements); gloo only for functional checks of the rank plumbing")
     ap.add_argument("--share-device", action="store_true",
                     help="FUNCTIONAL CHECK ONLY: every rank uses device 0 (a 1-GPU box); the line is labelled a non-measurement")
+    ap.add_argument("--n1-value", type=float, default=None,
+                    help="the N=1 `value` of this same workload (e.g. from BENCH_rNN.json): adds efficiency_vs_n1 = value / (N * n1)")
     ap.add_argument("--selftest-hostsim", action="store_true",
                     help="FUNCTIONAL CHECK ONLY (no GPU): the rank plumbing on the CPU host simulation of the kernel backend "
                          "(tests/hostsim, tiny backbone, gloo); the line is labelled a non-measurement")
@@ -170,7 +172,7 @@ def spawn_ranks(args, argv):
     procs = []
     with tempfile.TemporaryFile(mode="w+") as out0:
         for r in range(args.gpus):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                           stdout=out0 if r == 0 else subprocess.DEVNULL))
@@ -207,9 +209,16 @@ def main(argv=None):
     return run_rank(args)
 
 
+CPU_PIN = None        # what affinity.pin_rank did for this rank (reported in the JSON line)
+
+
 def init_ranks(args):
     """(dist or None, rank, local_rank, world, device string, sum of rank ids); one all-reduce of the rank ids
-    proves that N ranks really are talking to each other."""
+    proves that N ranks really are talking to each other.  FIRST thing, before any GPU call: the rank's CPU cores
+    (`i2v_amd.affinity`: NUMA-aware share of the allowed cores; lane / reader / writer threads inherit the mask)."""
+    global CPU_PIN
+    from i2v_amd import affinity
+    CPU_PIN = affinity.pin_rank()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -244,6 +253,16 @@ def reduce_max(dist, value, dev):
     dist.all_gather(every, t)
     vals = [float(e.item()) for e in every]
     return max(vals), vals
+
+
+def add_scaling_fields(line, args):
+    """`per_gpu_min` / `per_gpu_max` (the spread between ranks: `value` is set by the slowest) and, given `--n1-value`,
+    `efficiency_vs_n1` = value / (N x the N=1 value) -- a convenience for reading a scaling run; the driver computes its own."""
+    pg = line.get("per_gpu") or []
+    if pg:
+        line["per_gpu_min"], line["per_gpu_max"] = min(pg), max(pg)
+    if args.n1_value:
+        line["efficiency_vs_n1"] = round(line["value"] / (line["n_gpus"] * args.n1_value), 4)
 
 
 def selftest_hostsim(args):
@@ -281,7 +300,9 @@ def selftest_hostsim(args):
     line = {"metric": "SELFTEST (host simulation, not a measurement)", "value": round(args.steps * b * f * world / elapsed, 3),
             "unit": "adversarial frames/s", "n_gpus": world, "steps": args.steps, "warmup": 0, "data": "synthetic",
             "ranks_proved_by_allreduce": {"sum_of_rank_ids": rank_sum, "expected": world * (world - 1) // 2},
-            "per_gpu": [round(args.steps * b * f / t, 3) for t in per_rank], "config": {"workload": f"selftest {args.workload}"}, **extra}
+            "per_gpu": [round(args.steps * b * f / t, 3) for t in per_rank], "config": {"workload": f"selftest {args.workload}"},
+            "cpu_affinity_rank0": CPU_PIN, **extra}
+    add_scaling_fields(line, args)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
@@ -431,6 +452,9 @@ def run_rank(args):
         # every rank's own frames/s over ITS wall time of the same K steps (`value` divides all frames by the slowest)
         "per_gpu": [round(args.steps * b * FRAMES * n_lanes / t, 2) for t in per_rank_s],
     }
+    add_scaling_fields(out, args)
+    if CPU_PIN is not None:
+        out["cpu_affinity_rank0"] = CPU_PIN
     if dist is not None:
         out["ranks_proved_by_allreduce"] = {"sum_of_rank_ids": rank_sum, "expected": world * (world - 1) // 2,
                                             "backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend()}

@@ -69,6 +69,8 @@ def main(argv=None, model_kwargs=None):
     args = arg_parse(argv)
     if "LOCAL_RANK" not in os.environ:
         os.environ["LOCAL_RANK"] = args.gpu.split(",")[0]
+    from i2v_amd import affinity
+    affinity.pin_rank()              # this rank's CPU cores (under a launcher), before anything touches the GPU
     print(args)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     dataset = AdvDataset(args.used_adv, args.used_ori)

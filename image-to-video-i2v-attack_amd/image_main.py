@@ -89,6 +89,14 @@ def main(argv=None, ucf101=False):
     args = arg_parse(argv, ucf101)
     if "LOCAL_RANK" not in os.environ:
         os.environ["LOCAL_RANK"] = args.gpu.split(",")[0]
+    # this shard's CPU cores, before anything touches the GPU; reader / writer / lane threads inherit them.  Under a launcher the
+    # ranks of the node; by hand (`--batch_nums 8 --batch_index k --gpu k`, run_image_guided.py) the shards of the node.
+    from i2v_amd import affinity
+    lr = int(os.environ["LOCAL_RANK"]) if os.environ["LOCAL_RANK"].isdigit() else 0
+    lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", args.batch_nums)))
+    pinned = affinity.pin_rank(lr, lw) if lr < lw else None
+    if pinned:
+        print("cpu affinity:", pinned)
     print(args)
     total = clips.num_batches(args.batch_size, args.anno, args.clip_dir, args.num_clips)
     nums_contained = int(total / args.batch_nums)                      # int(400 / batch_nums), :61

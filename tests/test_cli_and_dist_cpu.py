@@ -244,6 +244,66 @@ def test_aens_two_ranks_match_single_device(tmp_path):
     assert np.abs(adv - fx["adv"]).mean() < 5e-3
 
 
+def _aens_uneven_worker(rank, world, port, out_dir, counts):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from i2v_amd import attacks, graphs
+    from oracle.make_golden import make_clip, normalise
+    vid = normalise(make_clip(911, sum(counts), 2, 48), torch.float32)
+    lo = sum(counts[:rank])
+    atk = attacks.AENS_I2V_MF(["resnet", "vgg"], depths={"resnet": [2, 3], "vgg": [2, 3]}, step_size=0.005, steps=3, momentum=0.5,
+                              engine=hostsim_engine(), graph_builder=graphs.build_tiny, weight_seed=0)
+    adv, _, costs = atk(vid[lo:lo + counts[rank]], torch.zeros(counts[rank], dtype=torch.long), [f"c{lo + i}" for i in range(counts[rank])])
+    np.savez(os.path.join(out_dir, f"u{rank}.npz"), adv=adv.numpy(), costs=costs, weights=np.stack(atk.weights))
+    dist.destroy_process_group()
+
+
+def test_aens_four_ranks_unequal_shards_match_single_device(tmp_path):
+    """four ranks holding 2 / 1 / 1 / 1 clips.  The adaptive weights depend on sums over the GLOBAL batch
+    (`TPAMI_attack.py:265,293-297`: the inner softmax is not scale invariant), so every rank must see the weights and the cost
+    of the single-device run over all five clips, whatever its own share -- against the float64 oracle on the five clips."""
+    from oracle import restate
+    from oracle.make_golden import make_clip, normalise
+    from i2v_amd import graphs, weights
+    counts = (2, 1, 1, 1)
+    vid = normalise(make_clip(911, sum(counts), 2, 48), torch.float32)
+    nets = []
+    for m in ("resnet", "vgg"):
+        g = graphs.build_tiny(m, (48, 48))
+        nets.append(restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hook_for(2, True), g.hook_for(3, True)], dtype=torch.float64))
+    ref = restate.run_attack(nets, vid.double(), steps=3, step_size=0.005, mode="aens", momentum=0.5, trace=True,
+                             coeffs=torch.ones(4, dtype=torch.float64))
+    port = 33500 + os.getpid() % 2000
+    mp.start_processes(_aens_uneven_worker, args=(4, port, str(tmp_path), counts), nprocs=4, join=True, start_method="spawn")
+    rs = [np.load(tmp_path / f"u{r}.npz") for r in range(4)]
+    for r in rs:
+        np.testing.assert_array_equal(r["weights"], rs[0]["weights"])          # one global weight trajectory
+        np.testing.assert_array_equal(r["costs"], rs[0]["costs"])
+    np.testing.assert_allclose(rs[0]["weights"], np.stack(ref["weights"]), rtol=1e-4)
+    np.testing.assert_allclose(rs[0]["costs"], ref["costs"], rtol=2e-4)
+    adv = np.concatenate([r["adv"] for r in rs])
+    assert adv.shape[0] == 5 and np.abs(adv - ref["adv"].float().numpy()).mean() < 5e-3
+
+
+def test_affinity_plan_is_numa_and_smt_aware():
+    """Per-rank CPU placement (i2v_amd/affinity.py): ranks dealt to NUMA nodes in blocks, a node's cores cut evenly, every
+    allowed core used at most once, nothing outside the allowed set."""
+    from i2v_amd import affinity
+    nodes = [list(range(0, 64)), list(range(64, 128))]
+    got = [affinity.plan(r, 8, nodes) for r in range(8)]
+    assert [(g[0], g[-1], len(g)) for g in got] == [(16 * r, 16 * r + 15, 16) for r in range(8)]
+    assert affinity.plan(0, 1, nodes) == nodes[0] + nodes[1]                   # one rank: everything
+    assert affinity.plan(1, 2, nodes) == nodes[1]
+    three = [affinity.plan(r, 3, [list(range(8))]) for r in range(3)]
+    assert sorted(c for g in three for c in g) == list(range(8))
+    assert affinity.plan(5, 6, [[0, 1], [2, 3]]) == [2, 3]                      # more ranks than cores on a node: shared whole
+    with pytest.raises(ValueError):
+        affinity.plan(4, 4, nodes)
+    # sysfs parsing: hyper-thread siblings end up next to each other
+    assert affinity._parse_cpulist("0-3,8-11\n") == [0, 1, 2, 3, 8, 9, 10, 11]
+
+
 def _dr_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
@@ -337,8 +397,13 @@ def test_bench_gpus_n_spawns_n_ranks():
     assert out["ranks_proved_by_allreduce"] == {"sum_of_rank_ids": 1, "expected": 1}
     assert "not a measurement" in out["metric"]
     assert abs(sum(out["aens_weights_last"]) - 1) < 1e-5
-    code, lines, err = _bench(["--gpus", "1", "--selftest-hostsim", "--steps", "1"])
+    assert out["per_gpu_min"] == min(out["per_gpu"]) and out["per_gpu_max"] == max(out["per_gpu"])
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 2:          # rank 0 pinned itself to its half of the allowed cores before doing anything else
+        assert out["cpu_affinity_rank0"]["cores"] == ncpu // 2, out["cpu_affinity_rank0"]
+    code, lines, err = _bench(["--gpus", "1", "--selftest-hostsim", "--steps", "1", "--n1-value", "1000"])
     assert code == 0 and lines[0]["n_gpus"] == 1
+    assert abs(lines[0]["efficiency_vs_n1"] - lines[0]["value"] / 1000) < 1e-3 and lines[0]["cpu_affinity_rank0"] is None
 
 
 def test_bench_failed_rank_fails_the_run():
