@@ -134,7 +134,10 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU")
     ap.add_argument("--white_model", default="slowfast_resnet50", help="--workload ilaf: video backbone (graphs.build_video)")
-    ap.add_argument("--streams", type=int, default=3, help="--workload ilaf: clips in flight on separate HIP streams (one clip per call each)")
+    ap.add_argument("--streams", type=int, default=2, help="--workload ilaf: engine calls in flight on separate HIP streams")
+    ap.add_argument("--ilaf_clips", type=int, default=4,
+                    help="--workload ilaf: clips per engine call, attacked as INDEPENDENT one-clip problems (ILAF.forward_independent: "
+                         "per-clip loss segments, each clip bit-identical to its one-clip call; the reference runs one clip per call)")
     ap.add_argument("--workload", default="i2v", choices=["i2v", "ens", "aens", "config2", "ilaf"],
                     help="i2v = the headline metric (default); ens / aens = BASELINE configs[2]/[3]-style extras on the "
                          "reference's own model list (resnet101+vgg16+squeezenet1_1+alexnet); aens carries the one data-path "
@@ -335,7 +338,9 @@ def run_rank(args):
         atk = sign_attacks.ILAF(video.VideoModel(args.white_model, (FRAMES, HW, HW), weight_seed=0), args.white_model, engine=eng)
     else:
         atk = attacks.AENS_I2V_MF(names4, depths={n: [2, 3] for n in names4}, step_size=0.005, steps=ATTACK_STEPS, engine=eng, weight_seed=0)
-    b = 1 if args.workload == "ilaf" and args.clips == CLIPS_PER_GPU else args.clips
+    b = max(1, args.ilaf_clips) if args.workload == "ilaf" else args.clips
+    if args.workload == "ilaf":
+        atk.independent_clips = True
     if args.workload == "aens" and world > 1:
         out_parallelism = f"clips sharded over {world} GPUs, one all-reduce of 2L floats per attack step (RCCL)"
     videos = synthetic_clips(b, seed0=1000 + rank * b).to(dev)         # resident in HBM before timing
@@ -355,8 +360,9 @@ def run_rank(args):
         for k in range(1, max(1, args.streams)):
             o2 = synthetic_clips(b, seed0=5000 + rank * 64 + k * b).to(dev)
             n2 = (torch.randint(-10, 11, o2.shape, generator=gen).float() / 255 / std).to(dev)
-            lanes.append((sign_attacks.ILAF(video.VideoModel(args.white_model, (FRAMES, HW, HW), weight_seed=0), args.white_model, engine=eng),
-                          (o2 + n2).contiguous(), o2, torch.cuda.Stream(device=dev)))
+            a2 = sign_attacks.ILAF(video.VideoModel(args.white_model, (FRAMES, HW, HW), weight_seed=0), args.white_model, engine=eng)
+            a2.independent_clips = True
+            lanes.append((a2, (o2 + n2).contiguous(), o2, torch.cuda.Stream(device=dev)))
 
         def lane_calls(lane, reps):
             a, v, o, st = lane
@@ -503,9 +509,9 @@ def run_rank(args):
         vg = _ilaf.model.graph_for((FRAMES, HW, HW))
         vmac = vg.truncated(_ilaf.model.hook_tensors(vg)).macs_per_frame()          # per clip
         out["metric"] = f"adversarial frames/sec ({_ilaf.steps}-step ILAF, {args.white_model} white-box, 32x224^2 clips)"
-        out["config"] = {"workload": f"ILAF fine-tune (BASELINE.json configs[4]): {b} clip(s) per call, {n_lanes} calls in flight per GPU "
-                                     f"on separate HIP streams, {_ilaf.steps} sign steps of 0.005, eps=16/255, hooks of "
-                                     f"{args.white_model} (synthetic weights)",
+        out["config"] = {"workload": f"ILAF fine-tune (BASELINE.json configs[4]): {b} independent one-clip problem(s) per engine call "
+                                     f"(per-clip loss segments), {n_lanes} call(s) in flight per GPU on separate HIP streams, "
+                                     f"{_ilaf.steps} sign steps of 0.005, eps=16/255, hooks of {args.white_model} (synthetic weights)",
                          "frames_per_gpu": b * FRAMES * n_lanes, "attack_steps": _ilaf.steps, "streams": n_lanes,
                          "parallelism": f"{n_lanes} clip stream(s) per GPU x {world} GPU(s), replicas only"}
         out["algorithmic_gflop_per_frame"] = round((4 * _ilaf.steps + 4) * vmac / FRAMES / 1e9, 2)

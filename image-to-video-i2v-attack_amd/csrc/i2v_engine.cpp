@@ -56,6 +56,7 @@ struct Tensor { int buf, c_off, C; bool post_relu; };
 struct Packed {               // one implicit-GEMM operand set
     float* wp = nullptr; I2VKEntry* ktab = nullptr;
     int K = 0, Kpad = 0, Cd = 0, Cdpad = 0, tap_uniform = 0;
+    int ntaps = 0;          // tap_uniform packings: taps per 16-channel group (I2VConvParams::ntaps)
     int halo = 0;           // 9 for a 3x3 / stride-1 / pad-1 packing in (16-channel group, tap, channel) order (kernel MODE 5), else 0
     int ph = 0, pw = 0, Hg = 0, Wg = 0;
     int pt = 0, Tg = 1;       // temporal parity class / grid frames per clip (video networks)
@@ -148,7 +149,8 @@ static int pack_fwd(Net& n, Node& nd) {
     int K = c.kt * c.kh * c.kw * c.cin;
     Packed& P = nd.fwd;
     P.K = K; P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cout; P.Cdpad = (int)align_up(c.cout, 128);
-    P.tap_uniform = (c.cin % I2V_KC == 0) ? 1 : 0;
+    P.tap_uniform = (c.cin % I2V_KC == 0 && c.kt * c.kh * c.kw <= 64) ? 1 : 0;
+    P.ntaps = c.kt * c.kh * c.kw;
     if (P.tap_uniform && c.kt == 1 && c.kh == 3 && c.kw == 3 && c.stride == 1 && c.stride_t == 1 && c.pad == 1 && !nd.preact()) P.halo = 9;
     // "Quad rows" for narrow stems (few input channels AND few output channels: SlowFast's fast pathway, 3 -> 8): such a launch
     // spends its time ISSUING the 4-byte im2col DMA of the per-row path (one instruction per K row and 64 pixels; 17 TFLOP/s),
@@ -217,7 +219,8 @@ static int pack_bwd(Net& n, Node& nd) {
             for (int s = 0; s < c.kw; ++s) if (posmod(pw + c.pad - s, st) == 0) ts.push_back(s);
             int K = (int)(tq.size() * tr.size() * ts.size()) * c.cout;
             P.K = K; P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cin; P.Cdpad = (int)align_up(c.cin, 128);
-            P.tap_uniform = (c.cout % I2V_KC == 0) ? 1 : 0;
+            P.tap_uniform = (c.cout % I2V_KC == 0 && tq.size() * tr.size() * ts.size() <= 64) ? 1 : 0;
+            P.ntaps = (int)(tq.size() * tr.size() * ts.size());
             if (P.tap_uniform && st == 1 && stt == 1 && c.kt == 1 && c.kh == 3 && c.kw == 3 && c.pad == 1 && !nd.preact()) P.halo = 9;
             std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
             std::vector<I2VKEntry> kt(P.Kpad ? P.Kpad : 1, I2VKEntry{0, 0, 0, 0});
@@ -286,7 +289,8 @@ static int pack_img(Net& n, Node& nd) {
     const int TWq = quad ? (TW + 3) / 4 * 4 : TW;               // column taps per run, padded to whole quads
     P.K = TT * TH * TWq * c.cout; P.Kpad = (int)align_up(P.K, I2V_KC);
     P.Cd = Bt * B * B * c.cin; P.Cdpad = (int)align_up(P.Cd, 128);
-    P.tap_uniform = (!quad && c.cout % I2V_KC == 0) ? 1 : 0;
+    P.tap_uniform = (!quad && c.cout % I2V_KC == 0 && TT * TH * TW <= 64) ? 1 : 0;
+    P.ntaps = TT * TH * TW;
     if (quad) { P.quad = TWq / 4; P.quad_kw = TW; P.quad_dw0 = dw_lo; }
     P.Tg = sparse ? (sb.T - ct0 + stt - 1) / stt : (sb.T + Bt - 1) / Bt; P.Hg = (sb.H + B - 1) / B; P.Wg = (sb.W + B - 1) / B;
     nd.img_blk = B; nd.img_sh = m; nd.img_blkt = Bt; nd.img_ost = sparse ? stt : Bt; nd.img_ot0 = ct0;
@@ -531,7 +535,7 @@ extern "C" int i2v_net_add_avgpool(i2v_handle h, int net, const i2v_pool_desc* d
 // ---------------------------------------------------------------------------------------------
 static void conv_common(I2VConvParams& p, const Packed& P) {
     memset(&p, 0, sizeof p);
-    p.wp = P.wp; p.ktab = P.ktab; p.K = P.K; p.Kpad = P.Kpad; p.tap_uniform = P.tap_uniform; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
+    p.wp = P.wp; p.ktab = P.ktab; p.K = P.K; p.Kpad = P.Kpad; p.tap_uniform = P.tap_uniform; p.ntaps = P.ntaps; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
     p.add0_stride = 1;
     p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1; p.ot0 = 0;
     p.temporal = P.has_dt;      // conv_run adds the frame-mapping half of the condition
@@ -1341,10 +1345,12 @@ extern "C" int i2v_sign_step_delta_gx_f32(float* delta, const float* gx, const f
 }
 
 static void ilaf_params(I2VIlafParams& p, const float* a, int64_t a_stride, const float* ori, const float* adv0,
-                        int64_t D, int frames, void* scratch) {
+                        int64_t D, int frames, void* scratch, int frames_per_seg = 0) {
     memset(&p, 0, sizeof p);
     p.a = a; p.a_nstride = a_stride; p.ori = ori; p.adv0 = adv0; p.D = D; p.N = frames; p.nblk = cos_nblk(D);
-    p.sums = (double*)scratch; p.partial = (double*)scratch + 2;        // same layout as the std kernels
+    p.fps = frames_per_seg;
+    const int nseg = frames_per_seg > 0 ? frames / frames_per_seg : 1;
+    p.sums = (double*)scratch; p.partial = (double*)scratch + 2 * nseg;  // [nseg][2] sums, then the per-(frame, block) partials
 }
 
 extern "C" int i2v_ilaf_reduce_f32(const float* a, int64_t a_stride, const float* ori, const float* adv0, int64_t D,
@@ -1362,6 +1368,35 @@ extern "C" int i2v_ilaf_grad_f32(const float* a, int64_t a_stride, const float* 
         return fail("i2v_ilaf_grad_f32: bad argument");
     I2VIlafParams p; ilaf_params(p, a, a_stride, ori, adv0, D, frames, scratch);
     p.init_norm = init_norm; p.mask_relu = mask_relu; p.accumulate = accumulate; p.loss_out = loss_out;
+    p.grad = grad; p.grad_nstride = grad_stride;
+    CHECK_BE(k_ilaf_grad(p, stream));
+    return 0;
+}
+
+// K independent one-clip problems in one launch (segments of frames_per_seg frames): per-segment sums / losses; the initial
+// norms come from device memory (the squared norms an initial `reduce` left), so the loop needs no read-back at all.
+extern "C" size_t i2v_ilaf_scratch_bytes(int64_t D, int frames, int frames_per_seg) {
+    const int nseg = frames_per_seg > 0 ? frames / frames_per_seg : 1;
+    return ((size_t)2 * nseg + (size_t)2 * frames * cos_nblk(D)) * sizeof(double) + 64;
+}
+
+extern "C" int i2v_ilaf_reduce_seg_f32(const float* a, int64_t a_stride, const float* ori, const float* adv0, int64_t D,
+                                       int frames, int frames_per_seg, void* scratch, void* stream) {
+    if (!a || !ori || !adv0 || !scratch || D <= 0 || frames <= 0 || frames_per_seg <= 0 || frames % frames_per_seg)
+        return fail("i2v_ilaf_reduce_seg_f32: bad argument");
+    I2VIlafParams p; ilaf_params(p, a, a_stride, ori, adv0, D, frames, scratch, frames_per_seg);
+    CHECK_BE(k_ilaf_reduce(p, stream));
+    return 0;
+}
+
+extern "C" int i2v_ilaf_grad_seg_f32(const float* a, int64_t a_stride, const float* ori, const float* adv0, int64_t D,
+                                     int frames, int frames_per_seg, const double* init_sq, int mask_relu, int accumulate,
+                                     float* loss_out, float* grad, int64_t grad_stride, void* scratch, void* stream) {
+    if (!a || !ori || !adv0 || !scratch || !loss_out || !grad || !init_sq || D <= 0 || frames <= 0 || frames_per_seg <= 0 ||
+        frames % frames_per_seg)
+        return fail("i2v_ilaf_grad_seg_f32: bad argument");
+    I2VIlafParams p; ilaf_params(p, a, a_stride, ori, adv0, D, frames, scratch, frames_per_seg);
+    p.init_sq = init_sq; p.mask_relu = mask_relu; p.accumulate = accumulate; p.loss_out = loss_out;
     p.grad = grad; p.grad_nstride = grad_stride;
     CHECK_BE(k_ilaf_grad(p, stream));
     return 0;

@@ -52,14 +52,16 @@ int be_event_elapsed_ms(void* a, void* b, float* ms) { HIPCHK(hipEventElapsedTim
 int be_stream_sync(i2v_stream_t s) { HIPCHK(hipStreamSynchronize((hipStream_t)s)); return 0; }
 int be_device_sync() { HIPCHK(hipDeviceSynchronize()); return 0; }
 
-#ifdef X_CLOCK
-__device__ unsigned long long g_xclk[1 << 20];      // diagnostic build only: per block 8 words {K-loop shader cycles, K-loop 100 MHz ticks, entry, loop start, loop end, exit (100 MHz), HW_ID, XCC_ID}
-#define X_CLOCK_ENTRY const unsigned long long xc_e = __builtin_amdgcn_s_memrealtime();
-#define X_CLOCK_EXIT(bid_) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 0 && (bid_) < (1 << 17)) { g_xclk[8 * (bid_) + 2] = xc_e; g_xclk[8 * (bid_) + 5] = __builtin_amdgcn_s_memrealtime(); \
-      g_xclk[8 * (bid_) + 6] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4); g_xclk[8 * (bid_) + 7] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20); } }
-#else
-#define X_CLOCK_ENTRY
-#define X_CLOCK_EXIT(bid_)
+// Developer hook: tools/conv_microbench.cpp defines I2V_PROBE_T as a type that records per-block time stamps (kernel entry, K-loop
+// start / end, exit) before it includes this file.  The product compiles the empty probe below: every call is an inline no-op.
+#ifndef I2V_PROBE_T
+struct I2VNoProbe {
+    __device__ __forceinline__ void entry() {}
+    __device__ __forceinline__ void loop_begin() {}
+    __device__ __forceinline__ void loop_end(int /*block slot*/) {}
+    __device__ __forceinline__ void exit(int /*block slot*/) {}
+};
+#define I2V_PROBE_T I2VNoProbe
 #endif
 __constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};
 __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
@@ -135,18 +137,23 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 #ifndef I2V_BIG_WPE
 #define I2V_BIG_WPE 3
 #endif
-static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi) {
-#ifdef I2V_WPE_OFF
-    return hi ? 8 : 1;
-#else
-    return (BD == 64 && BP == 64) ? (PREF ? I2V_PREF_WPE : I2V_SMALL_WPE) : (BD == 128 && BP == 64) ? I2V_TALL_WPE : BD * BP == 8192 ? I2V_MID_WPE : BD * BP == 16384 ? I2V_BIG_WPE : (hi ? 8 : 1);
-#endif
+// The seam-pipelined loop (MODE 1 / 2, conv_seam) keeps three LDS buffers, so LDS bounds those tiles: 64x64 24 KB -> 6 blocks,
+// 128x64 / 64x128 36 KB -> 4, 128x128 48 KB -> 3.
+static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi, int MODE) {
+    const bool seam = MODE == 1 || MODE == 2;
+    return (BD == 64 && BP == 64) ? (seam ? 6 : (PREF ? I2V_PREF_WPE : I2V_SMALL_WPE)) : (BD == 128 && BP == 64) ? (seam ? 4 : I2V_TALL_WPE) :
+           BD * BP == 8192 ? (seam ? 4 : I2V_MID_WPE) : BD * BP == 16384 ? I2V_BIG_WPE : (hi ? 8 : 1);
 }
-#define I2V_CONV_WPE __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(BD, BP, PREF, false), conv_waves_per_simd(BD, BP, PREF, true))))
-// LDS floats one tile needs: operand staging [2][KC][BD] + [2][KC][BP], re-used by the epilogue as a [WD*FR][BP] transpose buffer
-template <int BD, int BP, int WD, bool MF16>
+#define I2V_CONV_WPE __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(BD, BP, PREF, false, PRE ? 0 : MODE), conv_waves_per_simd(BD, BP, PREF, true, PRE ? 0 : MODE))))
+// Which main loop a tile runs.  The seam-pipelined loop (three LDS buffers, see conv_tile) serves the pointwise (MODE 1) and
+// tap-uniform (MODE 2) launches -- everything but the stems; the per-row (MODE 0) and quad-row (MODE 4) paths, whose DMA
+// instructions read k-table rows from scalar memory, and the pre-activation variant keep the two-buffer loop.
+static constexpr bool conv_seam(int MODE, bool PRE) { return (MODE == 1 || MODE == 2) && !PRE; }
+static constexpr int conv_nst(int MODE, bool PRE) { return conv_seam(MODE, PRE) ? 3 : 2; }
+// LDS floats one tile needs: operand staging [NST][KC][BD] + [NST][KC][BP], re-used by the epilogue as a [WD*FR][BP] transpose buffer
+template <int BD, int BP, int WD, bool MF16, int NST = 2>
 constexpr int conv_lds_floats() {
-    constexpr int stage = 2 * I2V_KC * (BD + BP), epi = WD * (MF16 ? 16 : 32) * BP;
+    constexpr int stage = NST * I2V_KC * (BD + BP), epi = WD * (MF16 ? 16 : 32) * BP;
     return stage > epi ? stage : epi;
 }
 
@@ -161,16 +168,17 @@ constexpr int conv_halo_lds_floats() {
 // starting at pixel `px_base` (a launch may be cut into regions with different tile shapes, conv_igemm_tail below).
 template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false, int HWM = 0>
 __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd_tiles, const int bid, const int nwg, const int64_t px_base,
-                                          float* const smem) {
+                                          float* const smem, I2V_PROBE_T& probe, const int probe_slot) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-resource types and LDS-DMA builtins exist only in the device pass
     constexpr int KC = I2V_KC;
     constexpr int FR = MF16 ? 16 : 32;                       // fragment edge
     constexpr int NR = MF16 ? 4 : 16;                        // accumulator registers per fragment
     constexpr int TD = BD / WD / FR, TP = BP / WP / FR;
     static_assert(!(MF16 && (PRE || PREF)), "no pre-activation / prefetch variants of the 16x16 tile");
-    // one LDS array: operand staging [2][KC][BD] + [2][KC][BP], re-used by the epilogue as a
+    // one LDS array: operand staging [NST][KC][BD] + [NST][KC][BP], re-used by the epilogue as a
     // [WD*32][BP] transpose buffer
-    constexpr int NST = 2;      // LDS operand buffers: chunk c is consumed while chunk c+1 is in flight
+    constexpr bool SEAM = conv_seam(MODE, PRE);               // seam-pipelined main loop (below): three LDS buffers
+    constexpr int NST = conv_nst(MODE, PRE);
     // MODE 5 ("halo"): a 3x3 / stride-1 / pad-1 launch on planes exactly HWM wide stages, per 16-channel group, ONE halo row per
     // channel -- the tile's 64 pixels plus a source row and a pixel on either side -- instead of nine shifted copies of the tile
     constexpr bool HALO = MODE == 5;
@@ -241,7 +249,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     unsigned aoff[NAQ];
 #pragma unroll
     for (int q = 0; q < NAQ; ++q) {
-        const int f = (wave + 4 * q) * 256 + lane * 4;
+        const int f = (SEAM ? (wave + 4 * q) % NA : wave + 4 * q) * 256 + lane * 4;
         aoff[q] = (unsigned)(((f / BD) * p.Cdpad + f % BD + cd0) * 4);
     }
     unsigned boff[PW ? NBQ : 1];                              // PW: + row inside the chunk (lane dependent)
@@ -250,18 +258,6 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         for (int q = 0; q < NBQ; ++q) boff[q] = pvalid ? xoff + (unsigned)((((wave + 4 * q) * 256 + lane * 4) / BP) * HWs * 4) : OOB;
     }
 
-#if defined(X_NOA_DMA) || defined(X_NOA_LDS)
-#define X_ADMA false
-#else
-#define X_ADMA true
-#endif
-#ifdef X_DMAHOT
-#define X_HOT(v) ((v) & 0xFFCu)
-#define X_HOTS(v) 0
-#else
-#define X_HOT(v) (v)
-#define X_HOTS(v) (v)
-#endif
     // One DMA instruction of this wave's share of a K chunk.  Piece j (compile-time) of the NL = NAQ + NBQ pieces a wave
     // issues per chunk: j < NAQ is a 16-byte piece of the weight tile, the others are pieces of the activation tile.
     // `vb_` is the per-lane byte offset of the chunk's tap (MODE 2; computed once per chunk by I2V_CHUNK_VB).
@@ -270,10 +266,12 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         constexpr int jj = (j_);                                                                          \
         const int k0 = (k0_);                                                                             \
         if constexpr (jj < NAQ) {                                                                         \
-            const int ins = wv + 4 * jj;                                                                  \
-            if (X_ADMA && (NA % 4 == 0 || ins < NA))                                                      \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(&As[buf_][0][0] + ins * 256), 16, X_HOT(aoff[jj]), \
-                                                         X_HOTS(k0 * p.Cdpad * 4), 0, 0);                 \
+            /* seam-pipelined loop: every wave issues the SAME number of pieces (its vmcnt waits count them); a wave without a \
+               piece of its own (NA < 4: 32- and 16-row tiles) re-issues another wave's -- same bytes to the same place */ \
+            const int ins = SEAM ? (wv + 4 * jj) % NA : wv + 4 * jj;                                       \
+            if (NA % 4 == 0 || ins < NA)                                                                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(&As[buf_][0][0] + ins * 256), 16, aoff[jj],  \
+                                                         k0 * p.Cdpad * 4, 0, 0);                         \
         } else {                                                                                          \
             constexpr int q = jj - NAQ;                                                                   \
             const int ins = wv + 4 * q;                                                                   \
@@ -283,8 +281,8 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
                     unsigned v = boff[q];                                                                 \
                     if (k0 + KC > p.K)       /* K tail (uniform test): rows >= K contribute zeros */      \
                         v = (k0 + ((wave + 4 * q) * 256 + lane * 4) / BP < p.K) ? v : OOB;                \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 256), 16, X_HOT(v),  \
-                                                             X_HOTS(k0 * HWs * 4), 0, 0);                 \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 256), 16, v,         \
+                                                             k0 * HWs * 4, 0, 0);                         \
                 } else if constexpr (QUAD) {                                                              \
                     /* piece = quad (ins*64)/BP of the chunk x 64 pixels; its first row's k-table entry gives   \
                        channel plane, row / frame tap and dw0; the row run's quads alternate (quad = 1 or 2) */ \
@@ -294,8 +292,8 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
                     const unsigned v = ok ? xoff + (unsigned)((e.chan_off + dtk * nstr + e.dh * p.Ws + e.dw) * 4) : OOB; \
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 256), 16, v, 0, 0, 0); \
                 } else if constexpr (MODE == 2) {                                                         \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 64), 4, X_HOT(vb_), \
-                                                             X_HOTS(((ins * 64) / BP) * HWs * 4), 0, 0);  \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bbuf + ins * 64), 4, vb_,         \
+                                                             ((ins * 64) / BP) * HWs * 4, 0, 0);          \
                 } else {                                                                                  \
                     const I2VKEntry e = load_kentry(p.ktab, k0 + (ins * 64) / BP);                        \
                     const int hs = h0 + e.dh, ws = w0 + e.dw, dtk = VID ? (e.valid >> 1) : 0;             \
@@ -342,9 +340,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         }
     }
 
-#ifdef X_CLOCK
-    const unsigned long long xc_t0 = __builtin_amdgcn_s_memtime(), xc_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
+    probe.loop_begin();
     typedef typename std::conditional<MF16, f32x4, f32x16>::type acc_t;
     acc_t acc[TD][TP];
 #pragma unroll
@@ -484,7 +480,121 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
             }(std::make_integer_sequence<int, NT>{});
             gbuf ^= 1;
         }
-    } else {   // prologue: chunk 0 (and the k-table row of chunk 1)
+    } else if constexpr (SEAM) {
+        // ---- seam-pipelined main loop (MODE 1 / 2): three LDS buffers, chunk c in buffer c % 3 -----------------------------
+        // Why: the per-block timeline of a launch (tools/conv_microbench.cpp, probe build) shows that the co-resident blocks of
+        // a CU do not finish together -- the hardware arbitrates oldest wave first -- so every CU ends a launch with one or two
+        // blocks left, and a block on its own (one wave per SIMD) reached only HALF the matrix pipe with the two-buffer loop:
+        // its DMA of chunk c+1 is issued ~6 MFMAs before the chunk seam (an L2 round trip), and behind the seam's barrier the
+        // first fragments are requested and awaited with nothing else to issue (tools/tile_lab.cpp: 999 cycles per chunk for
+        // 8 MFMAs of 64).  Here nothing a wave needs at the seam is requested at the seam:
+        //   * the DMA of chunk c+2 is issued during chunk c (behind its MFMAs): it has a whole chunk and a half to land.  Its buffer
+        //     held chunk c-1, which every wave finished reading before it passed the barrier of iteration c-1;
+        //   * ONE barrier per chunk, behind MFMA KS-3: the wave first waits for ITS pieces of chunk c+1 (counted vmcnt: the pieces
+        //     of chunk c+2 issued so far this iteration stay in flight) -- by then they are 1.5 chunks old;
+        //   * fragments are requested TWO k-steps ahead of their MFMA through a ring of four register sets (KS % 4 == 0, so k-step 0
+        //     of every chunk is set 0), across the seam as well: behind the barrier the last two k-steps of the iteration request
+        //     k-steps 0 and 1 of chunk c+1.  The requests of the last two k-steps of chunk c are both made at k-step KS-4, so the
+        //     youngest LDS read in front of the barrier is two MFMAs old and `lgkmcnt(0)` there costs nothing;
+        //   * MODE 2: a chunk's tap comes from a per-tap table held in ONE register across the lanes (lane t: tap t of the packing,
+        //     I2VConvParams::ntaps) and read with v_readlane -- no scalar-memory load in the loop, whose out-of-order return
+        //     would turn hipcc's counted LDS waits into lgkmcnt(0).
+        // Measured (tile_lab, 64x64 tile, K = 2304, TFLOP/s two-buffer -> seam): one block per CU 77 -> 114 (16-byte pieces),
+        // 68 -> 103 (4-byte pieces); two per CU 106 -> 118 (4-byte); four per CU on par.  Same products in the same order.
+        static_assert(KS % 4 == 0, "fragment ring of four register sets");
+        constexpr int SB = KS - 3;                                          // the barrier sits behind the MFMAs of k-step SB
+        constexpr int NBEF = (SB + 1) * PPS < NL ? (SB + 1) * PPS : NL;     // pieces of chunk c+2 issued before the seam wait
+        int vtap = 0, nt = 1, ichan = 0, gstride = 0;
+        if constexpr (MODE == 2) {
+            nt = p.ntaps;
+            const I2VKEntry e = p.ktab[(lane < nt ? lane : 0) * KC];        // (ordinary load, in front of every DMA)
+            vtap = (e.dh & 0xff) | ((e.dw & 0xff) << 8) | (((e.valid >> 1) & 0xff) << 16);
+            ichan = load_kentry(p.ktab, 0).chan_off;
+            gstride = nchunks > nt ? load_kentry(p.ktab, nt * KC).chan_off - ichan : 0;
+        }
+        // (the two table scalars are "used" here so that hipcc waits for their loads in front of the loop, not with an lgkmcnt(0) in it)
+        asm volatile("" ::"s"(ichan), "s"(gstride));
+        int itap = 0;                                                       // issue cursor: tap of the next chunk to stage
+        auto issue_vb = [&]() -> unsigned {                                 // MODE 2: per-lane byte offset of the cursor's tap
+            if constexpr (MODE == 2) {
+                const int pk = __builtin_amdgcn_readlane(vtap, itap);
+                const int dh = (int)(int8_t)pk, dw = (int)(int8_t)(pk >> 8), dtk = VID ? (int)(int8_t)(pk >> 16) : 0;
+                const int hs = h0 + dh, ws = w0 + dw;
+                const bool ok = pvalid && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws &&
+                                (!VID || (unsigned)(t0 + dtk) < (unsigned)p.Ts);
+                return ok ? xoff + (unsigned)((ichan + dtk * nstr + dh * p.Ws + dw) * 4) : OOB;
+            } else return OOB;
+        };
+        auto advance = [&]() {
+            if constexpr (MODE == 2) { if (++itap == nt) { itap = 0; ichan += gstride; } }
+        };
+        float fa[4][TD], fb[4][TP];
+        auto read_frags = [&](const int buf, const int s, const int set) {
+#pragma unroll
+            for (int i = 0; i < TD; ++i) fa[set][i] = As[buf][KR * s + lk][wd * (BD / WD) + i * FR + l31];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) fb[set][j] = Bs[buf][KR * s + lk][wpx * (BP / WP) + j * FR + l31];
+        };
+        // prologue: chunks 0 and 1 on their way, chunk 0 landed, its first two k-steps requested
+        for (int c0 = 0; c0 < 2 && c0 < nchunks; ++c0) {
+            const unsigned vb = issue_vb();
+            (void)vb;
+            [&]<int... J>(std::integer_sequence<int, J...>) { (([&] { I2V_ISSUE_PIECE(J, c0 * KC, c0, vb); }()), ...); }
+            (std::make_integer_sequence<int, NL>{});
+            advance();
+        }
+        if (nchunks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (nchunks > 0) { read_frags(0, 0, 0); read_frags(0, 1, 1); }
+        int b0 = 0, b1 = 1, b2 = 2;                                         // buffers of chunks c, c+1, c+2
+        for (int c = 0; c < nchunks; ++c) {
+            const bool more1 = c + 1 < nchunks, more2 = c + 2 < nchunks;
+            const unsigned vb = more2 ? issue_vb() : OOB;
+            (void)vb;
+            // the two fragment sets carried across the seam are "used" here, so hipcc places its wait for them HERE (they were
+            // requested two MFMAs ago: free) and not behind the next requests as lgkmcnt(0)
+#pragma unroll
+            for (int i = 0; i < TD; ++i) asm volatile("" ::"v"(fa[0][i]), "v"(fa[1][i]));
+#pragma unroll
+            for (int j = 0; j < TP; ++j) asm volatile("" ::"v"(fb[0][j]), "v"(fb[1][j]));
+            [&]<int... S>(std::integer_sequence<int, S...>) {
+                (([&] {
+                    constexpr int s = S, set = S % 4;
+                    if constexpr (s < KS - 4) read_frags(b0, s + 2, (s + 2) % 4);
+                    else if constexpr (s == KS - 4) { read_frags(b0, KS - 2, (KS - 2) % 4); read_frags(b0, KS - 1, (KS - 1) % 4); }
+                    else if constexpr (s >= KS - 2) read_frags(b1, s + 2 - KS, (s + 2) % 4);      // (last chunk: a stale buffer, never used)
+                    __builtin_amdgcn_sched_barrier(0);          // keep the requests in front of this step's MFMAs
+#pragma unroll
+                    for (int i = 0; i < TD; ++i)
+#pragma unroll
+                        for (int j = 0; j < TP; ++j) {
+                            if constexpr (MF16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+                        }
+                    if (more2) {
+                        [&]<int... Q>(std::integer_sequence<int, Q...>) {
+                            (([&] {
+                                constexpr int jp = s * PPS + Q;
+                                if constexpr (jp < NL) I2V_ISSUE_PIECE(jp, (c + 2) * KC, b2, vb);      // (chunk index from the loop counter: provably uniform -- no waterfall loop around the DMA)
+                            }()), ...);
+                        }(std::make_integer_sequence<int, PPS>{});
+                    }
+                    if constexpr (s == SB) {
+                        if (more1) {
+                            if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBEF) : "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }()), ...);
+            }(std::make_integer_sequence<int, KS>{});
+            advance();
+            const int tb = b0; b0 = b1; b1 = b2; b2 = tb;
+        }
+    } else {   // two-buffer loop, prologue: chunk 0 (and the k-table row of chunk 1)
         unsigned vb0 = OOB;
         if constexpr (MODE == 2) {
             const I2VKEntry e0 = load_kentry(p.ktab, 0);
@@ -493,27 +603,15 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         }
         (void)vb0;
         if (nchunks > 0) {
-#if defined(X_NODMA) || defined(X_NOA_DMA)       // ablations: both LDS buffers hold REAL operand data (same MFMA power as the full kernel)
-#undef X_ADMA
-#define X_ADMA true
-            [&]<int... J>(std::integer_sequence<int, J...>) { (([&] { I2V_ISSUE_PIECE(J, (nchunks > 1 ? KC : 0), 1, vb0); }()), ...); }
-            (std::make_integer_sequence<int, NL>{});
-#endif
             [&]<int... J>(std::integer_sequence<int, J...>) { (([&] { I2V_ISSUE_PIECE(J, 0, 0, vb0); }()), ...); }
             (std::make_integer_sequence<int, NL>{});
-#if defined(X_NOA_DMA)
-#undef X_ADMA
-#define X_ADMA false
-#endif
         }
     }
     auto chunk_body = [&](const int c, const int buf, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;                // a chunk c+1 exists: its DMA is issued here
-#ifndef X_NOBAR
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-#endif
         unsigned vb = OOB;
         if constexpr (MORE && MODE == 2) {
             vb = I2V_CHUNK_VB(e_next);                                  // tap of chunk c+1 (row fetched last iteration)
@@ -523,17 +621,8 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         (void)vb;
         float fa[2][TD], fb[2][TP];
         auto read_frags = [&](const int s, const int set) {
-#ifdef X_NOLDS
-            for (int i = 0; i < TD; ++i) { fa[set][i] = 1.0f + s; asm volatile("" : "+v"(fa[set][i])); }
-            for (int j = 0; j < TP; ++j) { fb[set][j] = 0.5f + s; asm volatile("" : "+v"(fb[set][j])); }
-            return;
-#endif
-#ifdef X_NOA_LDS
-            for (int i = 0; i < TD; ++i) { fa[set][i] = 1.0f + s; asm volatile("" : "+v"(fa[set][i])); }
-#else
 #pragma unroll
             for (int i = 0; i < TD; ++i) fa[set][i] = As[buf][KR * s + lk][wd * (BD / WD) + i * FR + l31];
-#endif
             if constexpr (QUAD) {       // [quad][pixel][4] image: 16x16x4 reads element lk of quad s, 32x32x2 element 2(s&1)+lk of quad s>>1
                 const float* const bq = &Bs[buf][0][0];
 #pragma unroll
@@ -550,9 +639,6 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
             }
         };
         read_frags(0, 0);
-#ifdef X_PRIO
-        __builtin_amdgcn_s_setprio(X_PRIO);
-#endif
         [&]<int... S>(std::integer_sequence<int, S...>) {
             (([&] {
                 constexpr int s = S, set = S & 1;
@@ -573,11 +659,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
                         if constexpr (MF16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
                     }
-#ifdef X_NODMA
-                if constexpr (false) {
-#else
                 if constexpr (MORE) {
-#endif
                     [&]<int... Q>(std::integer_sequence<int, Q...>) {
                         (([&] {
                             constexpr int jp = s * PPS + Q;
@@ -587,24 +669,15 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
                 }
             }()), ...);
         }(std::make_integer_sequence<int, KS>{});
-#ifdef X_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
     };
-    if constexpr (!HALO) {
+    if constexpr (!HALO && !SEAM) {
         int buf = 0;
         for (int c = 0; c + 1 < nchunks; ++c) { chunk_body(c, buf, std::true_type{}); buf ^= 1; }
         if (nchunks > 0) chunk_body(nchunks - 1, buf, std::false_type{});
     }
 #undef I2V_ISSUE_PIECE
 #undef I2V_CHUNK_VB
-#ifdef X_CLOCK
-    if (t == 0 && bid + (px_base ? 65536 : 0) < (1 << 17)) {      // (tail-split launches: the quarter tiles are recorded from slot 65536 on)
-        const int xb = bid + (px_base ? 65536 : 0);
-        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-        g_xclk[8 * xb] = __builtin_amdgcn_s_memtime() - xc_t0; g_xclk[8 * xb + 1] = r1 - xc_r0; g_xclk[8 * xb + 3] = xc_r0; g_xclk[8 * xb + 4] = r1;
-    }
-#endif
+    probe.loop_end(probe_slot);
 
     // ---- epilogue: shift, addends, ReLU, gradient gate, NCHW store ----
     const int HoWo = p.Ho * p.Wo;
@@ -809,10 +882,11 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
 
 template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false>
 __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
-    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<BD, BP, WD, MF16>()];
-    X_CLOCK_ENTRY
-    conv_tile<BD, BP, WD, WP, MODE, PREF, PRE, VID, MF16>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem);
-    X_CLOCK_EXIT(blockIdx.x)
+    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<BD, BP, WD, MF16, conv_nst(MODE, PRE)>()];
+    I2V_PROBE_T probe;
+    probe.entry();
+    conv_tile<BD, BP, WD, WP, MODE, PREF, PRE, VID, MF16>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x);
+    probe.exit(blockIdx.x);
 }
 
 // MODE 5 launches (halo staging of 3x3 / stride-1 convolutions on planes HWM wide)
@@ -820,9 +894,10 @@ template <int HWM>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HWM <= 14 ? I2V_SMALL_WPE : (HWM <= 28 ? 6 : 5), HWM <= 14 ? I2V_SMALL_WPE : (HWM <= 28 ? 6 : 5))))
 conv_igemm_halo(const I2VConvParams p, const int n_cd_tiles) {
     __shared__ __attribute__((aligned(16))) float smem[conv_halo_lds_floats<HWM>()];
-    X_CLOCK_ENTRY
-    conv_tile<64, 64, 2, 2, 5, false, false, false, false, HWM>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem);
-    X_CLOCK_EXIT(blockIdx.x)
+    I2V_PROBE_T probe;
+    probe.entry();
+    conv_tile<64, 64, 2, 2, 5, false, false, false, false, HWM>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x);
+    probe.exit(blockIdx.x);
 }
 
 // "Tail split": the first `nA` blocks compute 64x64 tiles over the pixel tiles [0, px_base_b / 64); the remaining blocks cover the
@@ -830,14 +905,16 @@ conv_igemm_halo(const I2VConvParams p, const int n_cd_tiles) {
 // 32 CUs with 7 tiles and 224 with 6; cut this way it is 6 tiles everywhere plus 128 quarter tiles on 128 CUs.  Every output
 // element is still the same k-ordered fmaf chain (fragment shape does not enter): results are bit-identical.
 template <int MODE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I2V_SMALL_WPE, I2V_SMALL_WPE)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(64, 64, false, false, MODE), conv_waves_per_simd(64, 64, false, true, MODE))))
 conv_igemm_tail(const I2VConvParams p, const int n_cd_a, const int nA, const int n_cd_b, const int64_t px_base_b) {
-    constexpr int LA = conv_lds_floats<64, 64, 2, false>(), LB = conv_lds_floats<16, 64, 1, true>();
+    constexpr int LA = conv_lds_floats<64, 64, 2, false, conv_nst(MODE, false)>(), LB = conv_lds_floats<16, 64, 1, true, conv_nst(MODE, false)>();
     __shared__ __attribute__((aligned(16))) float smem[LA > LB ? LA : LB];
-    X_CLOCK_ENTRY
-    if ((int)blockIdx.x < nA) conv_tile<64, 64, 2, 2, MODE, false, false, false, false>(p, n_cd_a, blockIdx.x, nA, 0, smem);
-    else conv_tile<16, 64, 1, 4, MODE, false, false, false, true>(p, n_cd_b, (int)blockIdx.x - nA, (int)gridDim.x - nA, px_base_b, smem);
-    X_CLOCK_EXIT((int)blockIdx.x < nA ? (int)blockIdx.x : 65536 + (int)blockIdx.x - nA)
+    I2V_PROBE_T probe;
+    probe.entry();
+    const int slot = (int)blockIdx.x < nA ? (int)blockIdx.x : 65536 + (int)blockIdx.x - nA;      // (probe builds: quarter tiles from slot 65536 on)
+    if ((int)blockIdx.x < nA) conv_tile<64, 64, 2, 2, MODE, false, false, false, false>(p, n_cd_a, blockIdx.x, nA, 0, smem, probe, slot);
+    else conv_tile<16, 64, 1, 4, MODE, false, false, false, true>(p, n_cd_b, (int)blockIdx.x - nA, (int)gridDim.x - nA, px_base_b, smem, probe, slot);
+    probe.exit(slot);
 }
 
 // Low-K layers with epilogue operands are HBM-bound (their FLOP/byte is below the machine balance): they
@@ -1454,25 +1531,29 @@ __global__ void __launch_bounds__(256) ilaf_reduce_kernel(const I2VIlafParams p)
     }
 }
 
+// one block per segment (I2VIlafParams::fps): the partials of its frames in the order a one-clip call sums them
 __global__ void __launch_bounds__(256) ilaf_finish_kernel(const I2VIlafParams p) {
     __shared__ double red[2][4];
     double s = 0, q = 0;
-    const int np = p.N * p.nblk;
-    for (int i = threadIdx.x; i < np; i += 256) { s += p.partial[2 * i]; q += p.partial[2 * i + 1]; }
+    const int fps = p.fps > 0 ? p.fps : p.N, seg = blockIdx.x;
+    const int np = fps * p.nblk;
+    const double* part = p.partial + (int64_t)seg * np * 2;
+    for (int i = threadIdx.x; i < np; i += 256) { s += part[2 * i]; q += part[2 * i + 1]; }
     s = wave_sum_d(s); q = wave_sum_d(q);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        p.sums[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        p.sums[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        p.sums[2 * seg] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        p.sums[2 * seg + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
 }
 
 // loss = -(0.5 s/n0 + q/(n0 s)),  s = |d|, q = <d0, d>;   d loss/d a = -((0.5/s - q/s^3) d + d0/s) / n0
 __global__ void __launch_bounds__(256) ilaf_grad_kernel(const I2VIlafParams p) {
     const int n = blockIdx.y;
-    const double s = sqrt(p.sums[0]), q = p.sums[1], n0 = p.init_norm;
-    if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) p.loss_out[0] = (float)(-(0.5 * s / n0 + q / (n0 * s)));
+    const int fps = p.fps > 0 ? p.fps : p.N, seg = n / fps;
+    const double s = sqrt(p.sums[2 * seg]), q = p.sums[2 * seg + 1], n0 = p.init_sq ? sqrt(p.init_sq[seg]) : p.init_norm;
+    if (blockIdx.x == 0 && n == seg * fps && threadIdx.x == 0) p.loss_out[seg] = (float)(-(0.5 * s / n0 + q / (n0 * s)));
     const double cd = -(0.5 / s - q / (s * s * s)) / n0, c0 = -1.0 / (s * n0);
     const float* a = p.a + (int64_t)n * p.a_nstride;
     const float* o = p.ori + (int64_t)n * p.D;
@@ -1489,7 +1570,7 @@ __global__ void __launch_bounds__(256) ilaf_grad_kernel(const I2VIlafParams p) {
 int k_ilaf_reduce(const I2VIlafParams& p, i2v_stream_t s) {
     hipLaunchKernelGGL(ilaf_reduce_kernel, dim3(p.nblk, p.N), dim3(256), 0, (hipStream_t)s, p);
     LAUNCH_CHECK("ilaf_reduce");
-    hipLaunchKernelGGL(ilaf_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, p);
+    hipLaunchKernelGGL(ilaf_finish_kernel, dim3(p.fps > 0 ? p.N / p.fps : 1), dim3(256), 0, (hipStream_t)s, p);
     LAUNCH_CHECK("ilaf_finish");
     return 0;
 }

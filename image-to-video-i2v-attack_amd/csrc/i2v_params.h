@@ -76,6 +76,11 @@ struct I2VConvParams {
     // channel and group (tile pixels + a row and a pixel on either side) instead of nine shifted copies of the tile.  Same
     // products in the same order: results are bit-identical.
     int32_t halo;
+    // tap_uniform packings order their K rows (16-channel group, tap, channel in group): chunk c is tap c % ntaps of group c / ntaps,
+    // every group repeating the taps of the first one with its channel planes offset by a constant -- which lets the kernel derive
+    // a chunk's k-table row from a per-tap table held in registers instead of loading it (no scalar-memory access in the K loop).
+    // ntaps <= 64 (the planner packs convolutions with more taps in (tap, channel) order, tap_uniform = 0).
+    int32_t ntaps;
     // exact division of a pixel index (< 2^31) by Hg*Wg, Wg, Tg and Wo as multiply-high + shift: filled in by k_conv (the
     // hardware has no integer divide; the 64-bit software divisions of round 1 cost a block more VALU issue slots than a
     // K = 64 tile spends on its MFMAs)
@@ -122,11 +127,18 @@ struct I2VIlafParams {
     const float* ori;  const float* adv0;    // dense [N][D] copies of the clean / initial adversarial features
     int64_t D;         int32_t N;
     double* partial;   int32_t nblk;         // [N*nblk][2]
-    double* sums;                            // [2]
-    double init_norm;                        // |d0|
-    float* loss_out;                         // [1]
+    double* sums;                            // [nseg][2]
+    double init_norm;                        // |d0| (used when init_sq is null)
+    float* loss_out;                         // [nseg]
     float* grad;       int64_t grad_nstride;
     int32_t mask_relu, accumulate;
+    // Segments: the reference attacks ONE clip per ILAF call (image_fine_tune_attack.py:73-79) and its norms run over that clip
+    // only, so K clips batched into one launch list are K independent problems: frames [k*fps, (k+1)*fps) form segment k with its
+    // own sums, initial norm and loss.  fps = 0: one segment of all N frames.  init_sq (device, [nseg]): |d0|^2 per segment as
+    // left by the reduction over the initial adversarial features (the kernel takes the square root: correctly rounded, the
+    // value the host path passes in init_norm).
+    int32_t fps;
+    const double* init_sq;
 };
 
 // Classifier head of a white-box video model over its last feature map (frame-major: clips*T frames of (C, HW)):

@@ -340,18 +340,37 @@ class Net:
         """Frames hook i holds when `in_frames` input frames were run (video backbones change the clip length)."""
         return in_frames // self.graph.tensors[self.graph.input].T * self.hooks[i].T
 
-    def ilaf_reduce(self, i: int, ori: torch.Tensor, adv0: torch.Tensor, scratch: torch.Tensor, frames: int, act=None):
+    def ilaf_scratch_bytes(self, i: int, frames: int, frames_per_seg: int = 0) -> int:
+        return self.eng.capi.i2v_ilaf_scratch_bytes(self.hooks[i].D, frames, frames_per_seg)
+
+    def ilaf_reduce(self, i: int, ori: torch.Tensor, adv0: torch.Tensor, scratch: torch.Tensor, frames: int, act=None,
+                    frames_per_seg: int = 0):
         """(sum d*d, sum d*d0) of hook i against the dense clean / initial-adversarial feature copies, left as two
-        doubles at the start of `scratch`.  `act` overrides the activation (used once to measure |d0|)."""
+        doubles at the start of `scratch`.  `act` overrides the activation (used once to measure |d0|).  `frames_per_seg`:
+        independent segments of that many frames (one clip each), two doubles per segment."""
         hi = self.hooks[i]
         capi = self.eng.capi
         a, a_s = (C.c_void_p(hi.act), hi.act_stride) if act is None else (_ptr(act, self.eng), hi.D)
+        if frames_per_seg:
+            _lib.check(capi, capi.i2v_ilaf_reduce_seg_f32(a, a_s, _ptr(ori, self.eng), _ptr(adv0, self.eng), hi.D, frames, frames_per_seg,
+                                                          C.c_void_p(scratch.data_ptr()), self.eng.stream()))
+            return
         _lib.check(capi, capi.i2v_ilaf_reduce_f32(a, a_s, _ptr(ori, self.eng), _ptr(adv0, self.eng), hi.D, frames,
                                                   C.c_void_p(scratch.data_ptr()), self.eng.stream()))
 
-    def ilaf_grad(self, i: int, ori, adv0, init_norm: float, loss_out: torch.Tensor, scratch: torch.Tensor, frames: int):
+    def ilaf_grad(self, i: int, ori, adv0, init_norm, loss_out: torch.Tensor, scratch: torch.Tensor, frames: int,
+                  frames_per_seg: int = 0):
+        """`init_norm`: |d0| as a host float -- or, with `frames_per_seg`, a DEVICE tensor of float64 holding |d0|^2 per segment;
+        `loss_out` then has one element per segment."""
         hi = self.hooks[i]
         capi = self.eng.capi
+        if frames_per_seg:
+            assert init_norm.dtype == torch.float64 and init_norm.numel() == frames // frames_per_seg
+            _lib.check(capi, capi.i2v_ilaf_grad_seg_f32(C.c_void_p(hi.act), hi.act_stride, _ptr(ori, self.eng), _ptr(adv0, self.eng), hi.D, frames,
+                                                        frames_per_seg, C.c_void_p(init_norm.data_ptr()), hi.post_relu, 0,
+                                                        C.c_void_p(loss_out.data_ptr()), C.c_void_p(hi.grad), hi.grad_stride,
+                                                        C.c_void_p(scratch.data_ptr()), self.eng.stream()))
+            return
         _lib.check(capi, capi.i2v_ilaf_grad_f32(C.c_void_p(hi.act), hi.act_stride, _ptr(ori, self.eng), _ptr(adv0, self.eng), hi.D, frames,
                                                 init_norm, hi.post_relu, 0, C.c_void_p(loss_out.data_ptr()),
                                                 C.c_void_p(hi.grad), hi.grad_stride, C.c_void_p(scratch.data_ptr()),

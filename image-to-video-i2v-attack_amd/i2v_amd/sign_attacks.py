@@ -263,7 +263,20 @@ class ILAF(object):
     def __call__(self, *a, **k):
         return self.forward(*a, **k)
 
-    def _native(self, videos, ori_videos, video_names):
+    #: True: the b clips of a call are b INDEPENDENT one-clip problems (what b calls of the reference, which fine-tunes one
+    #: clip per call -- image_fine_tune_attack.py:73-79 --, compute): every norm, loss and logged cost is per clip, and every
+    #: clip's output is bit-identical to its own one-clip call.  False (the reference's semantics for a b > 1 call): the
+    #: whole-tensor norms of image_attacks.py:563-567,595-613 run over all b clips together.
+    independent_clips = False
+
+    def forward_independent(self, videos, ori_videos, labels, video_names):
+        """K one-clip ILAF problems in ONE launch list (segmented loss kernels, `i2v_ilaf_*_seg_f32`): the convolution launches
+        see K times the frames -- real occupancy instead of HIP-stream concurrency.  Native models only."""
+        if not isinstance(self.model, VideoModel):
+            raise TypeError("forward_independent needs a native VideoModel")
+        return self._native(videos, ori_videos, video_names, independent=True)
+
+    def _native(self, videos, ori_videos, video_names, independent=None):
         """The whole of `image_attacks.py:534-629` behind the C ABI.  Activations are frame-major (b*T, C, H, W); the
         loss only needs whole-tensor norms and a dot product, so no layout change is ever materialised."""
         eng = self._engine or get_engine()
@@ -272,6 +285,8 @@ class ILAF(object):
         videos = videos.detach().to(**kw).contiguous()
         ori = ori_videos.detach().to(**kw).contiguous()
         b, c, f, h, w = videos.shape
+        independent = self.independent_clips if independent is None else independent
+        nseg = b if independent else 1                                          # loss segments: one per clip, or the whole batch
         N, eps = b * f, float(self.epsilon)
         key = (f, h, w)
         if self._net is None or self._net_key != key or self._net.max_frames < N:
@@ -286,44 +301,48 @@ class ILAF(object):
         eng.frames_from_video(ori, x, u_ori)                                     # :572 `_transform_video_ILAF(..,'back')`
         net.forward(x)                                                          # :545-549 clean features
         nf = [net.hook_frames(i, N) for i in range(L)]
+        fps = [n // nseg for n in nf]                                           # frames per segment at each hook
         ori_f = [net.save_hook(i, nf[i]) for i in range(L)]
         eng.frames_from_video(videos, x, u_adv)
         net.forward(x)                                                          # :555-559 features of the given adversarial clip
         adv_f = [net.save_hook(i, nf[i]) for i in range(L)]
-        scratch = torch.empty((max(net.scratch_bytes(n) for n in nf) + 64) // 4, **kw)
-        sums = torch.empty(L, 2, dtype=torch.float64, device=dev)
+        scratch = torch.empty((max(net.ilaf_scratch_bytes(i, nf[i], fps[i]) for i in range(L)) + 64) // 4, **kw)
+        init_sq = torch.empty(L, nseg, dtype=torch.float64, device=dev)         # |adv0 - ori|^2 per (layer, segment), stays on the device
         for i in range(L):                                                      # :563-567 |adv0 - ori| per layer
-            net.ilaf_reduce(i, ori_f[i], adv_f[i], scratch, nf[i], act=adv_f[i])
-            sums[i].copy_(scratch[:4].view(torch.float64))
-        init_norms = [float(v) ** 0.5 for v in sums[:, 0].cpu()]                # the loop's only pre-loop read-back
+            net.ilaf_reduce(i, ori_f[i], adv_f[i], scratch, nf[i], act=adv_f[i], frames_per_seg=fps[i])
+            init_sq[i].copy_(scratch[:4 * nseg].view(torch.float64).view(nseg, 2)[:, 0])
         modifier = torch.sub(u_adv, u_ori)                                      # :574-575 existing perturbation
         gx = torch.empty_like(x)
-        loss = torch.zeros(L, **kw)
-        costs = torch.zeros(self.steps, **kw)
+        loss = torch.zeros(L, nseg, **kw)
+        costs = torch.zeros(self.steps, nseg, **kw)
         slot = torch.zeros(1, dtype=torch.long, device=dev)
 
         def one_step():
             eng.compose(u_ori, modifier, x, b, f, eps)                          # :585-588
             net.forward(x)                                                      # :591
             for k in range(L):                                                  # :599-610
-                net.ilaf_reduce(k, ori_f[k], adv_f[k], scratch, nf[k])
-                net.ilaf_grad(k, ori_f[k], adv_f[k], init_norms[k], loss[k:k + 1], scratch, nf[k])
+                net.ilaf_reduce(k, ori_f[k], adv_f[k], scratch, nf[k], frames_per_seg=fps[k])
+                net.ilaf_grad(k, ori_f[k], adv_f[k], init_sq[k], loss[k], scratch, nf[k], frames_per_seg=fps[k])
             net.backward(gx)                                                    # :613-614 (input gradient only)
             eng.sign_step_delta_gx(modifier, gx, u_ori, eps, self.step_size)    # :617
-            costs.index_copy_(0, slot, loss.sum().reshape(1))                   # :611, stays on the device
+            costs.index_copy_(0, slot, loss.sum(dim=0, keepdim=True))           # :611, stays on the device
             slot.add_(1)
 
         # (Recording the step into a HIP graph was measured and dropped: 272.8 vs 274.8 frames/s without it --
         # the loop is device-bound even for a single clip.)
         for _ in range(self.steps):
             one_step()
-        self.last_costs = costs.cpu().numpy()
+        costs_h = costs.cpu().numpy()                                           # the call's only read-back
+        self.last_costs = costs_h if independent else costs_h[:, 0]
         for i in range(self.steps):
-            for name in video_names:
-                self.loss_info.setdefault(name, {})[i] = {"cost": str(np.asarray(self.last_costs[i], dtype=np.float32))}
+            for k, name in enumerate(video_names):
+                cost = costs_h[i, k if independent else 0]
+                self.loss_info.setdefault(name, {})[i] = {"cost": str(np.asarray(cost, dtype=np.float32))}
         out = torch.empty(b, 3, f, h, w, **kw)
         eng.compose(u_ori, modifier, out, b, f, eps, video_layout=True)         # :625-626
         self._modifier = modifier
+        if independent:         # each clip through the reference's (sic) reshape / permute of ITS one-clip call (:627-628)
+            return out.reshape(b, 1, f, c, h, w).permute(0, 1, 3, 2, 4, 5).reshape(b, c, f, h, w)
         return out.reshape(b, f, c, h, w).permute(0, 2, 1, 3, 4)                # :627-628 (sic, see class docstring)
 
     def forward(self, videos, ori_videos, labels, video_names):

@@ -8,8 +8,10 @@ Differences: the white-box model is an `i2v_amd.video.VideoModel` (graph IR + we
 module from a YACS config, `:58-66`), so `--white_model` is one of the names `graphs.build_video` knows and the whole
 ILAF loop runs in `libi2v_hip.so`; under `torchrun` the file list is dealt round-robin over the ranks (replicas only,
 no collective); `--steps` / `--step_size` expose ILAF's constructor defaults (60, 0.005; `image_attacks.py:502`);
-`--resume` skips clips whose output exists; `--streams N` (default 3) keeps N clips in flight on separate HIP streams
-(`sign_attacks.run_concurrent`: one clip per call as in the reference, but a single clip cannot fill the GPU)."""
+`--resume` skips clips whose output exists; `--group_clips K` (default 4) hands K clips to ONE engine call as K independent
+one-clip problems (`ILAF.forward_independent`: per-clip loss segments, every `{label}-adv.npy` bit-identical to the
+one-clip call -- the reference's one clip per call cannot fill the GPU); `--streams N` (default 2) keeps N such calls in
+flight on separate HIP streams (`sign_attacks.run_concurrent`)."""
 import argparse
 import os
 
@@ -58,7 +60,9 @@ def arg_parse(argv=None):
     parser.add_argument("--synthetic_weights", action="store_true",
                         help="run on the seeded synthetic initialiser when no checkpoint lies under $I2V_WEIGHTS_DIR "
                              "(same as I2V_SYNTHETIC_WEIGHTS=1); without it a missing checkpoint is an error")
-    parser.add_argument("--streams", type=int, default=3, help="clips in flight on separate HIP streams")
+    parser.add_argument("--streams", type=int, default=2, help="engine calls in flight on separate HIP streams")
+    parser.add_argument("--group_clips", type=int, default=4,
+                        help="clips per engine call, attacked as independent one-clip problems (1 = the reference's call pattern)")
     args = parser.parse_args(argv)
     if args.synthetic_weights:
         os.environ["I2V_SYNTHETIC_WEIGHTS"] = "1"
@@ -87,13 +91,19 @@ def main(argv=None, model_kwargs=None):
 
     def make_attack():
         model = VideoModel(args.white_model, shape, **(model_kwargs or {}))
-        return getattr(image_attacks, args.attack_method)(model, args.white_model, step_size=args.step_size, steps=args.steps)
+        atk = getattr(image_attacks, args.attack_method)(model, args.white_model, step_size=args.step_size, steps=args.steps)
+        atk.independent_clips = True          # a grouped call = its clips' one-clip calls (image_fine_tune_attack.py:73-79)
+        return atk
+
+    group = max(1, args.group_clips)
 
     def items():
-        for step in todo:
-            print("Running {}, {}/{}".format(args.attack_method, step + 1, len(dataset)))
-            val_batch, ori_batch, val_label = dataset[step]
-            yield val_batch, ori_batch, val_label, ["..."]
+        for g0 in range(0, len(todo), group):
+            got = []
+            for step in todo[g0:g0 + group]:
+                print("Running {}, {}/{}".format(args.attack_method, step + 1, len(dataset)))
+                got.append(dataset[step])
+            yield (torch.cat([g[0] for g in got]), torch.cat([g[1] for g in got]), torch.cat([g[2] for g in got]), ["..."] * len(got))
     def save(_i, item, adv_batches):
         for ind, label in enumerate(item[2]):
             np.save(os.path.join(args.opt_path, "{}-adv".format(label.item())), adv_batches[ind].detach().cpu().numpy())

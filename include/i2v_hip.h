@@ -218,6 +218,18 @@ int i2v_ilaf_reduce_f32(const float* a, int64_t a_stride, const float* ori, cons
 int i2v_ilaf_grad_f32(const float* a, int64_t a_stride, const float* ori, const float* adv0, int64_t D,
                       int frames, double init_norm, int mask_relu, int accumulate, float* loss_out,
                       float* grad, int64_t grad_stride, void* scratch, void* stream);
+/* Segmented form: the reference fine-tunes ONE clip per call (image_fine_tune_attack.py:73-79) and every norm of its loss runs
+ * over that clip alone (image_attacks.py:563-567,595-613), so K clips batched into one launch list are K independent
+ * problems.  Frames [k*frames_per_seg, (k+1)*frames_per_seg) form segment k: `reduce` leaves (sum d*d, sum d*d0) of segment k at
+ * doubles [2k, 2k+1] of `scratch`; `grad` takes |d0|^2 per segment from DEVICE memory (`init_sq[k]`: what a reduce with
+ * a == adv0 left), writes loss_out[k] and the gradient.  Every segment's result is bit-identical to the one-clip call.
+ * Scratch: i2v_ilaf_scratch_bytes(D, frames, frames_per_seg). */
+size_t i2v_ilaf_scratch_bytes(int64_t D, int frames, int frames_per_seg);
+int i2v_ilaf_reduce_seg_f32(const float* a, int64_t a_stride, const float* ori, const float* adv0, int64_t D,
+                            int frames, int frames_per_seg, void* scratch, void* stream);
+int i2v_ilaf_grad_seg_f32(const float* a, int64_t a_stride, const float* ori, const float* adv0, int64_t D,
+                          int frames, int frames_per_seg, const double* init_sq, int mask_relu, int accumulate,
+                          float* loss_out, float* grad, int64_t grad_stride, void* scratch, void* stream);
 /* Classifier head of a white-box video model and the cross-entropy gradient the BIM family starts from
  * (`attack.py:63-96` builds the classifier, `base_attacks.py:282-284`: `cost = targeted * CrossEntropyLoss()(model(adv), labels)`):
  * over the hooked LAST feature map (frame-major, clips*T frames of (C, HW)): global average pool over (T,H,W) ->

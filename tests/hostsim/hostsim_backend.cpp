@@ -394,21 +394,28 @@ int k_ilaf_reduce(const I2VIlafParams& p, i2v_stream_t) {
         }
         block_sums2(t0, t1, &partial[((size_t)n * p.nblk + blk) * 2], &partial[((size_t)n * p.nblk + blk) * 2 + 1]);
     }
-    finish_sums2(partial, p.N * p.nblk, p.sums);
+    // one finishing block per segment (I2VIlafParams::fps), over that segment's partials only
+    const int fps = p.fps > 0 ? p.fps : p.N, nseg = p.N / fps;
+    for (int seg = 0; seg < nseg; ++seg) {
+        std::vector<double> part(partial.begin() + (size_t)seg * fps * p.nblk * 2, partial.begin() + (size_t)(seg + 1) * fps * p.nblk * 2);
+        finish_sums2(part, fps * p.nblk, p.sums + 2 * seg);
+    }
     return 0;
 }
 
 int k_ilaf_grad(const I2VIlafParams& p, i2v_stream_t) {
-    const double s = sqrt(p.sums[0]), q = p.sums[1], n0 = p.init_norm;
+    const int fps = p.fps > 0 ? p.fps : p.N, nseg = p.N / fps;
+    for (int seg = 0; seg < nseg; ++seg) {
+    const double s = sqrt(p.sums[2 * seg]), q = p.sums[2 * seg + 1], n0 = p.init_sq ? sqrt(p.init_sq[seg]) : p.init_norm;
     {
         volatile double t1 = 0.5 * s, t2 = t1 / n0, t3 = n0 * s, t4 = q / t3, t5 = t2 + t4;
-        p.loss_out[0] = (float)(-t5);
+        p.loss_out[seg] = (float)(-t5);
     }
     volatile double h = 0.5 / s, ss = s * s, sss = ss * s, qs = q / sss, hd = h - qs, nhd = -hd;
     volatile double cd = nhd / n0;
     volatile double sn = s * n0;
     volatile double c0 = -1.0 / sn;
-    for (int n = 0; n < p.N; ++n) {
+    for (int n = seg * fps; n < (seg + 1) * fps; ++n) {
         const float* a = p.a + (size_t)n * p.a_nstride; const float* o = p.ori + (size_t)n * p.D; const float* a0 = p.adv0 + (size_t)n * p.D;
         float* g = p.grad + (size_t)n * p.grad_nstride;
         for (int64_t i = 0; i < p.D; ++i) {
@@ -418,6 +425,7 @@ int k_ilaf_grad(const I2VIlafParams& p, i2v_stream_t) {
             if (p.mask_relu && !(a[i] > 0.f)) v = 0.f;
             g[i] = p.accumulate ? g[i] + v : v;
         }
+    }
     }
     return 0;
 }

@@ -138,6 +138,11 @@ def test_image_fine_tune_attack_file_contract(tiny_engine, tmp_path):
     out = np.load(out_dir / "3-adv.npy")
     assert out.dtype == np.float32 and out.shape == (3, 8, 32, 32)
     assert list(atk.loss_info["..."].keys()) == [0, 1] and abs(float(atk.loss_info["..."][0]["cost"]) + 1.5) < 1e-4
+    # the default groups clips into one engine call (independent one-clip problems): byte-identical to one clip per call
+    one = tmp_path / "one_per_call"
+    ift.main(argv[:5] + [str(one)] + argv[6:] + ["--group_clips", "1", "--streams", "1"], model_kwargs=dict(tiny=True))
+    for f in ("3-adv.npy", "17-adv.npy"):
+        assert np.array_equal(np.load(one / f), np.load(out_dir / f)), f
     before = os.path.getmtime(out_dir / "3-adv.npy")
     assert ift.main(argv + ["--resume"], model_kwargs=dict(tiny=True)) is None      # nothing left to do
     assert os.path.getmtime(out_dir / "3-adv.npy") == before

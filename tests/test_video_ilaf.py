@@ -120,3 +120,30 @@ def test_concurrent_clip_streams_match_sequential():
     assert sorted(seen) == list(range(5)) and all(torch.equal(seen[i], want[i]) for i in range(5))
     with pytest.raises(ZeroDivisionError):
         run_concurrent(make, items, streams=2, device="cpu", on_result=lambda i, item, res: 1 / 0)
+
+
+@pytest.mark.parametrize("name", ["ilaf_i3d_f32", "ilaf_slowfast_f64"])
+def test_independent_clips_in_one_call_match_one_clip_calls(name):
+    """K clips batched into ONE launch list with per-clip loss segments (`ILAF.forward_independent`,
+    `i2v_ilaf_*_seg_f32`) are K independent calls: every clip's output and every logged cost is BIT-identical to the one-clip
+    call (the reference fine-tunes one clip per call, image_fine_tune_attack.py:73-79, and its norms run over that clip only)."""
+    eng = hostsim_engine()
+    fx = load(name)
+    adv, ori = clips(fx)
+    gen = torch.Generator().manual_seed(11)
+    advs = torch.cat([adv + 0.02 * torch.randn(adv.shape, generator=gen) for _ in range(3)])
+    oris = torch.cat([ori + 0.01 * torch.randn(ori.shape, generator=gen) for _ in range(3)])
+
+    def make():
+        return sign_attacks.ILAF(video.VideoModel(fx["model_type"], fx["thw"], weight_seed=fx["wseed"], tiny=True),
+                                 fx["model_type"], step_size=0.005, steps=3, engine=eng)
+    one = make()
+    want = [one(advs[k:k + 1].float(), oris[k:k + 1].float(), torch.zeros(1, dtype=torch.long), [f"c{k}"]).clone() for k in range(3)]
+    many = make()
+    got = many.forward_independent(advs.float(), oris.float(), torch.zeros(3, dtype=torch.long), ["c0", "c1", "c2"])
+    for k in range(3):
+        assert torch.equal(got[k:k + 1], want[k]), k
+        assert many.loss_info[f"c{k}"] == one.loss_info[f"c{k}"]
+    # the coupled form (the reference's semantics for a b > 1 call) is a different computation
+    coupled = make()(advs.float(), oris.float(), torch.zeros(3, dtype=torch.long), ["c0", "c1", "c2"])
+    assert not torch.equal(coupled, got)

@@ -5,8 +5,35 @@
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++20 -x hip -DKSRC='"../image-to-video-i2v-attack_amd/csrc/i2v_kernels.hip"' tools/conv_microbench.cpp -o tools/cmb
 //   tools/cmb [frames] [iters]            all shapes x all valid tile configurations
 //   tools/cmb <frames> <Cin> <Cout> <H> <k> [iters]     one shape (I2V_FORCE_CFG picks the configuration)
+// -DCMB_PROBE: per-block time stamps through the kernel source's probe hook (I2V_PROBE_T): 8 words per block {K-loop shader cycles,
+// K-loop 100 MHz ticks, entry, loop start, loop end, exit (100 MHz wall clock), HW_ID, XCC_ID}; the timeline of the last launch is
+// printed with every measurement (when the blocks of a CU start and finish, blocks per CU, in-kernel clock).
 #ifndef KSRC
 #define KSRC "../image-to-video-i2v-attack_amd/csrc/i2v_kernels.hip"
+#endif
+#ifdef CMB_PROBE
+#include <hip/hip_runtime.h>
+__device__ unsigned long long g_xclk[1 << 20];
+struct CmbProbe {
+    unsigned long long e, t0, r0;
+    __device__ __forceinline__ void entry() { e = __builtin_amdgcn_s_memrealtime(); }
+    __device__ __forceinline__ void loop_begin() { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    __device__ __forceinline__ void loop_end(int slot) {
+        if (threadIdx.x == 0 && slot < (1 << 17)) {
+            const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+            g_xclk[8 * slot] = __builtin_amdgcn_s_memtime() - t0; g_xclk[8 * slot + 1] = r1 - r0; g_xclk[8 * slot + 3] = r0; g_xclk[8 * slot + 4] = r1;
+        }
+    }
+    __device__ __forceinline__ void exit(int slot) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0 && slot < (1 << 17)) {
+            g_xclk[8 * slot + 2] = e; g_xclk[8 * slot + 5] = __builtin_amdgcn_s_memrealtime();
+            g_xclk[8 * slot + 6] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);       // HW_REG_HW_ID
+            g_xclk[8 * slot + 7] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);      // HW_REG_XCC_ID
+        }
+    }
+};
+#define I2V_PROBE_T CmbProbe
 #endif
 #include KSRC
 
@@ -65,7 +92,7 @@ static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
     p.add0_stride = 1; p.relu = 1;
     p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1;
     if (with_epi) { p.add0 = da; p.add0_nstride = p.dst_nstride; }      // residual-style addend (the expand convolutions)
-    p.tap_uniform = tu;
+    p.tap_uniform = tu; p.ntaps = NT;
     p.pointwise = (k == 1 && st == 1 && (H * H) % 4 == 0 && !getenv("CMB_NOPW")); p.tap_uniform = tu;
     p.vec_epilogue = ((Ho * Ho) % 4 == 0);
     p.cfg = cfg + 1;
@@ -87,7 +114,7 @@ static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
     for (int i = 0; i < iters; ++i) k_conv(p, nullptr);
     hipEventRecord(b, nullptr); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b); ms /= iters;
-#ifdef X_CLOCK
+#ifdef CMB_PROBE
     {   // diagnostic build: timeline of the LAST launch from per-block stamps (100 MHz wall clock, shader cycles over the K loop)
         const size_t NW = (size_t)8 << 17;
         std::vector<unsigned long long> h(NW);
