@@ -122,6 +122,15 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 //   128x64  6  (70 registers, 24 KB of LDS; +0.5 % over 5)     64x128  5  (83 registers, 32 KB)
 //   128x128  3  (147-150; left alone the allocator used 147 + 64 AGPRs = 2 blocks)
 // The 256-pixel tiles are bounded by LDS (4 blocks) and are left alone.  All without spills (-Rpass-analysis).
+#ifndef I2V_SEAM
+#define I2V_SEAM 0
+#endif
+#ifndef I2V_PRIO_LEVELS      // > 0: a block lowers its waves' priority as it advances through its K loop (levels .. 0), see chunk_body
+#define I2V_PRIO_LEVELS 0
+#endif
+#ifndef I2V_TAIL_PRIO        // 1: the quarter tiles of a tail-split launch run above the full tiles' priorities
+#define I2V_TAIL_PRIO 0
+#endif
 #ifndef I2V_SMALL_WPE
 #define I2V_SMALL_WPE 7
 #endif
@@ -140,7 +149,7 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 // The seam-pipelined loop (MODE 1 / 2, conv_seam) keeps three LDS buffers, so LDS bounds those tiles: 64x64 24 KB -> 6 blocks,
 // 128x64 / 64x128 36 KB -> 4, 128x128 48 KB -> 3.
 static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi, int MODE) {
-    const bool seam = MODE == 1 || MODE == 2;
+    const bool seam = I2V_SEAM && (MODE == 1 || MODE == 2);
     return (BD == 64 && BP == 64) ? (seam ? 6 : (PREF ? I2V_PREF_WPE : I2V_SMALL_WPE)) : (BD == 128 && BP == 64) ? (seam ? 4 : I2V_TALL_WPE) :
            BD * BP == 8192 ? (seam ? 4 : I2V_MID_WPE) : BD * BP == 16384 ? I2V_BIG_WPE : (hi ? 8 : 1);
 }
@@ -148,7 +157,7 @@ static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi, int
 // Which main loop a tile runs.  The seam-pipelined loop (three LDS buffers, see conv_tile) serves the pointwise (MODE 1) and
 // tap-uniform (MODE 2) launches -- everything but the stems; the per-row (MODE 0) and quad-row (MODE 4) paths, whose DMA
 // instructions read k-table rows from scalar memory, and the pre-activation variant keep the two-buffer loop.
-static constexpr bool conv_seam(int MODE, bool PRE) { return (MODE == 1 || MODE == 2) && !PRE; }
+static constexpr bool conv_seam(int MODE, bool PRE) { return I2V_SEAM && (MODE == 1 || MODE == 2) && !PRE; }
 static constexpr int conv_nst(int MODE, bool PRE) { return conv_seam(MODE, PRE) ? 3 : 2; }
 // LDS floats one tile needs: operand staging [NST][KC][BD] + [NST][KC][BP], re-used by the epilogue as a [WD*FR][BP] transpose buffer
 template <int BD, int BP, int WD, bool MF16, int NST = 2>
@@ -168,7 +177,7 @@ constexpr int conv_halo_lds_floats() {
 // starting at pixel `px_base` (a launch may be cut into regions with different tile shapes, conv_igemm_tail below).
 template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false, int HWM = 0>
 __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd_tiles, const int bid, const int nwg, const int64_t px_base,
-                                          float* const smem, I2V_PROBE_T& probe, const int probe_slot) {
+                                          float* const smem, I2V_PROBE_T& probe, const int probe_slot, const int prio_hi = I2V_PRIO_LEVELS) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-resource types and LDS-DMA builtins exist only in the device pass
     constexpr int KC = I2V_KC;
     constexpr int FR = MF16 ? 16 : 32;                       // fragment edge
@@ -607,11 +616,24 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
             (std::make_integer_sequence<int, NL>{});
         }
     }
+    // Progress-ordered priority (I2V_PRIO_LEVELS): the hardware arbitrates oldest wave first, so the co-resident blocks of a CU
+    // finish one after the other and every CU ends its launch with one or two blocks left, which cannot fill the matrix pipe on
+    // their own.  A block starts at priority `prio_hi` and steps down each time it completes another 1 / (prio_hi + 1) of its
+    // K loop: blocks that are behind outrank blocks that are ahead, so they advance together and finish together.
+    int prio_lvl = prio_hi, prio_next = 0, prio_step = 0;
+    if (prio_hi > 0) {
+        prio_step = (nchunks + prio_hi) / (prio_hi + 1); prio_next = prio_step;
+        if (prio_hi >= 3) __builtin_amdgcn_s_setprio(3); else if (prio_hi == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+    }
     auto chunk_body = [&](const int c, const int buf, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;                // a chunk c+1 exists: its DMA is issued here
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (prio_hi > 0 && c == prio_next) {
+            prio_next += prio_step; --prio_lvl;
+            if (prio_lvl == 2) __builtin_amdgcn_s_setprio(2); else if (prio_lvl == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
         unsigned vb = OOB;
         if constexpr (MORE && MODE == 2) {
             vb = I2V_CHUNK_VB(e_next);                                  // tap of chunk c+1 (row fetched last iteration)
@@ -677,6 +699,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     }
 #undef I2V_ISSUE_PIECE
 #undef I2V_CHUNK_VB
+    if (prio_hi > 0) __builtin_amdgcn_s_setprio(0);
     probe.loop_end(probe_slot);
 
     // ---- epilogue: shift, addends, ReLU, gradient gate, NCHW store ----
@@ -912,8 +935,20 @@ conv_igemm_tail(const I2VConvParams p, const int n_cd_a, const int nA, const int
     I2V_PROBE_T probe;
     probe.entry();
     const int slot = (int)blockIdx.x < nA ? (int)blockIdx.x : 65536 + (int)blockIdx.x - nA;      // (probe builds: quarter tiles from slot 65536 on)
+#if I2V_TAIL_PRIO
+    // the quarter tiles are dispatched last, i.e. they are the youngest waves of their CU and would be served last -- and finish
+    // last, alone: they run ABOVE every priority the full tiles use instead, are done in a quarter of a tile time and leave the
+    // CU to its six full tiles
+    if ((int)blockIdx.x < nA) conv_tile<64, 64, 2, 2, MODE, false, false, false, false>(p, n_cd_a, blockIdx.x, nA, 0, smem, probe, slot, I2V_PRIO_LEVELS > 2 ? 2 : I2V_PRIO_LEVELS);
+    else {
+        __builtin_amdgcn_s_setprio(3);
+        conv_tile<16, 64, 1, 4, MODE, false, false, false, true>(p, n_cd_b, (int)blockIdx.x - nA, (int)gridDim.x - nA, px_base_b, smem, probe, slot, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+#else
     if ((int)blockIdx.x < nA) conv_tile<64, 64, 2, 2, MODE, false, false, false, false>(p, n_cd_a, blockIdx.x, nA, 0, smem, probe, slot);
     else conv_tile<16, 64, 1, 4, MODE, false, false, false, true>(p, n_cd_b, (int)blockIdx.x - nA, (int)gridDim.x - nA, px_base_b, smem, probe, slot);
+#endif
     probe.exit(slot);
 }
 

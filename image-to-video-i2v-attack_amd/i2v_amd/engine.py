@@ -411,5 +411,25 @@ class Net:
                                                     Ctot, off, hi.post_relu, 0, C.c_void_p(hi.grad), hi.grad_stride, sp, st))
             off += hi.shape[0]
 
+    def head_logits(self, i, W: torch.Tensor, bias, in_frames: int, logits: torch.Tensor, scratch: torch.Tensor):
+        """Forward-only classifier head (the evaluator, `reference.py:108-129`): global average pool of hook i -- or of a LIST of
+        hooks, concatenated in that order -- then `fc`; no loss gradient is written.  `logits`: (clips, K) on the device."""
+        capi = self.eng.capi
+        his = [self.hooks[k] for k in (i if isinstance(i, (list, tuple)) else [i])]
+        clips = in_frames // self.graph.tensors[self.graph.input].T
+        Ctot = sum(hi.shape[0] for hi in his)
+        assert W.shape[1] == Ctot and scratch.numel() >= capi.i2v_head_scratch_bytes(Ctot, clips)
+        sp, st = C.c_void_p(scratch.data_ptr()), self.eng.stream()
+        off = 0
+        for hi in his:
+            _lib.check(capi, capi.i2v_head_pool_f32(C.c_void_p(hi.act), hi.act_stride, hi.shape[0], hi.shape[1] * hi.shape[2], hi.T, clips,
+                                                    Ctot, off, sp, st))
+            off += hi.shape[0]
+        labels = torch.zeros(clips, dtype=torch.int32, device=logits.device)
+        loss_each = torch.empty(clips, dtype=torch.float32, device=logits.device)
+        bias_p = _ptr(bias, self.eng) if bias is not None else C.c_void_p(0)
+        _lib.check(capi, capi.i2v_head_logits_ce_f32(Ctot, clips, _ptr(W, self.eng), bias_p, W.shape[0], C.c_void_p(labels.data_ptr()), 1.0,
+                                                     _ptr(logits, self.eng), _ptr(loss_each, self.eng), sp, st))
+
     def scratch_bytes(self, frames: int) -> int:
         return max(self.eng.capi.i2v_cossim_scratch_bytes(hi.D, frames) for hi in self.hooks)

@@ -86,3 +86,46 @@ class VideoModel(object):
 
     def train(self, mode=True):
         return self
+
+
+class NativeClassifier(object):
+    """Forward-only classifier for the evaluator (`/root/reference/reference.py:108-129`: `model(clips)` -> logits, top-1): a
+    `VideoModel` with its head, every launch behind the C ABI (3-D backbone to the last stage, global average pool, `fc`).
+    Quacks like the torch module the evaluator expects (`.to()`, `.eval()`, call)."""
+
+    def __init__(self, model: VideoModel, engine=None):
+        if model.num_classes is None:
+            raise ValueError("a VideoModel used as a classifier needs num_classes (its head)")
+        self.model, self._engine = model, engine
+        self._net = self._key = self._head = None
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def __call__(self, clips):
+        import torch
+        from .attacks import get_engine
+        eng = self._engine or get_engine()
+        kw = dict(dtype=torch.float32, device=eng.device)
+        clips = clips.detach().to(**kw).contiguous()
+        b, c, f, h, w = clips.shape
+        N, key = b * f, (f, h, w)
+        if self._net is None or self._key != key or self._net.max_frames < N:
+            if self._net is not None:
+                self._net.close()
+            g = self.model.graph_for((f, h, w))
+            self._net = eng.build_net(g, self.model.state_dict_for(g), self.model.classifier_hook(g), N)
+            self._head = tuple(t.to(eng.device) if t is not None else None for t in self.model.head_weights(g))
+            self._key = key
+        net = self._net
+        x, u = torch.empty(N, 3, h, w, **kw), torch.empty(N, 3, h, w, **kw)
+        eng.frames_from_video(clips, x, u)
+        net.forward(x)
+        W, bias = self._head
+        logits = torch.empty(b, W.shape[0], **kw)
+        scratch = torch.empty(eng.capi.i2v_head_scratch_bytes(W.shape[1], b), dtype=torch.uint8, device=eng.device)
+        net.head_logits(list(range(len(net.hooks))), W, bias, N, logits, scratch)
+        return logits

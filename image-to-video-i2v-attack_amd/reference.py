@@ -12,7 +12,8 @@ twice (`:21-25`) -- `$I2V_OPT_PATH` is joined once.
 The six gluoncv Kinetics-400 models of the reference are not vendored, so models come from a factory:
 `--model_factory pkg.module:function`, a callable `name -> torch.nn.Module` mapping a normalised
 (b,3,f,h,w) batch to logits; `--models a,b,c` are the names handed to it (default: the reference's
-six names).  The built-in factory `proxy` is a seeded random 3-D conv classifier: useless as an
+six names).  `--model_factory native` scores with the NATIVE classifiers (`i2v_amd.video.NativeClassifier`: I3D / SlowFast graph IR +
+head behind the C ABI).  The built-in factory `proxy` is a seeded random 3-D conv classifier: useless as an
 accuracy number, but it lets two sets of adversarial clips (reference-oracle vs HIP) be scored by the
 same code, optionally against the model's own clean prediction (`--clean_dir`)."""
 import argparse
@@ -34,6 +35,15 @@ def proxy(name: str, num_classes: int = 400) -> torch.nn.Module:
     return torch.nn.Sequential(torch.nn.Conv3d(3, 16, (3, 7, 7), stride=(1, 4, 4), padding=(1, 3, 3)), torch.nn.ReLU(),
                                torch.nn.Conv3d(16, 32, 3, stride=(2, 2, 2), padding=1), torch.nn.ReLU(),
                                torch.nn.AdaptiveAvgPool3d(1), torch.nn.Flatten(), torch.nn.Linear(32, num_classes))
+
+
+def native(name: str, num_classes: int = 400, **model_kwargs):
+    """`--model_factory native`: the evaluated video model runs in libi2v_hip.so (`i2v_amd.video.NativeClassifier`: graph IR to
+    the last stage + pool + fc, forward only).  Built for the names whose graphs reach their last stage -- the I3D ResNets and
+    the whole SlowFast (`video.VideoModel(num_classes=...)`); `tpn_*` raises KeyError (neck / head not built).  Weights:
+    `$I2V_WEIGHTS_DIR/<arch>.pth` with its `fc.*`, or -- only under I2V_SYNTHETIC_WEIGHTS=1 -- the seeded synthetic initialiser."""
+    from i2v_amd.video import NativeClassifier, VideoModel
+    return NativeClassifier(VideoModel(name, num_classes=num_classes, **model_kwargs))
 
 
 def accuracy(output, target):
@@ -68,13 +78,15 @@ def main(argv=None):
     ap.add_argument("--gpu", type=str, default="0", help="gpu device.")
     ap.add_argument("--batch_size", type=int, default=16, metavar="N")
     ap.add_argument("--models", type=str, default=",".join(DEFAULT_MODELS))
-    ap.add_argument("--model_factory", type=str, default="proxy", help="'proxy' or pkg.module:function")
+    ap.add_argument("--model_factory", type=str, default="proxy", help="'proxy', 'native' (i2v_amd.video.NativeClassifier) or pkg.module:function")
     ap.add_argument("--clean_dir", type=str, default="", help="directory of {label}-ori.npy clean clips")
     args = ap.parse_args(argv)
     adv_path = os.path.join(os.environ.get("I2V_OPT_PATH", ""), args.adv_path)
     device = torch.device(f"cuda:{args.gpu.split(',')[0]}" if torch.cuda.is_available() else "cpu")
     if args.model_factory == "proxy":
         factory = proxy
+    elif args.model_factory == "native":
+        factory = native
     else:
         mod, fn = args.model_factory.split(":")
         factory = getattr(importlib.import_module(mod), fn)

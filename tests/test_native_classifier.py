@@ -171,3 +171,54 @@ def test_native_classifier_full_architecture_vs_torch(model_type):
         assert abs(float(atk.last_loss) - float(loss.detach())) < 1e-4 * max(1.0, abs(float(loss.detach())))
         rels.append(float((gx - gref).norm() / gref.norm()))
     assert sorted(rels)[1] < 5e-3 and max(rels) < 5e-2, rels
+
+
+@pytest.mark.parametrize("model_type", MODELS)
+def test_native_evaluator_classifier_hostsim(model_type):
+    """forward-only logits for the evaluator (`reference.py:108-129`) through the C ABI
+    (`video.NativeClassifier`) against the float64 torch module on the same weights: rtol 1e-4."""
+    from tests.hostsim_util import hostsim_engine
+    thw, K = (8, 32, 32), 7
+    m, ref = torch_classifier(model_type, thw, 3, K)
+    vid = torch.randn(3, 3, *thw, generator=torch.Generator().manual_seed(5))
+    clf = video.NativeClassifier(m, engine=hostsim_engine())
+    got = clf.to("cpu").eval()(vid)
+    want = ref(vid.double()).detach()
+    np.testing.assert_allclose(got.double().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
+    # the same numbers as the attack path's logits
+    atk = sign_attacks.BIM(m, steps=1, engine=hostsim_engine())
+    atk._grad(vid, torch.tensor([0, 1, 2]))
+    assert torch.equal(atk.last_logits, got)
+
+
+def test_evaluator_with_the_native_factory(tmp_path, monkeypatch):
+    """`reference.py --model_factory native` end to end on the host simulation: the native classifiers score saved clips, and the
+    prediction of an unperturbed clip equals the torch module's arg-max."""
+    import functools
+    import reference as evaluator
+    from i2v_amd import attacks
+    from tests.hostsim_util import hostsim_engine
+    monkeypatch.setattr(attacks, "get_engine", lambda *a, **k: hostsim_engine())
+    thw, K = (8, 32, 32), 7
+    m, ref = torch_classifier("i3d_resnet50", thw, 3, K)
+    gen = torch.Generator().manual_seed(9)
+    clips = torch.randn(4, 3, *thw, generator=gen)
+    pred = ref(clips.double()).argmax(1)
+    for k in range(4):
+        np.save(tmp_path / f"{int(pred[k]) if k < 3 else (int(pred[k]) + 1) % K}-adv-{k}.npy", clips[k].numpy())
+    monkeypatch.setattr(evaluator, "native", functools.partial(evaluator.native, num_classes=K, in_thw=thw, weight_seed=3, tiny=True))
+    acc = evaluator.main(["--adv_path", str(tmp_path), "--model_factory", "native", "--models", "i3d_resnet50", "--batch_size", "3"])
+    assert abs(acc["i3d_resnet50"] - 75.0) < 1e-6            # three clips carry their own arg-max as the label, one does not
+    with pytest.raises(KeyError):
+        evaluator.native("tpn_resnet50")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_type", MODELS)
+def test_native_evaluator_classifier_gpu(model_type):
+    from i2v_amd import attacks
+    thw, K = (8, 32, 32), 7
+    m, ref = torch_classifier(model_type, thw, 3, K)
+    vid = torch.randn(3, 3, *thw, generator=torch.Generator().manual_seed(5))
+    got = video.NativeClassifier(m, engine=attacks.get_engine("cuda:0"))(vid.to("cuda:0")).cpu()
+    np.testing.assert_allclose(got.double().numpy(), ref(vid.double()).detach().numpy(), rtol=1e-4, atol=1e-5)
