@@ -56,7 +56,6 @@ struct Tensor { int buf, c_off, C; bool post_relu; };
 struct Packed {               // one implicit-GEMM operand set
     float* wp = nullptr; I2VKEntry* ktab = nullptr;
     int K = 0, Kpad = 0, Cd = 0, Cdpad = 0, tap_uniform = 0;
-    int ntaps = 0;          // tap_uniform packings: taps per 16-channel group (I2VConvParams::ntaps)
     int halo = 0;           // 9 for a 3x3 / stride-1 / pad-1 packing in (16-channel group, tap, channel) order (kernel MODE 5), else 0
     int ph = 0, pw = 0, Hg = 0, Wg = 0;
     int pt = 0, Tg = 1;       // temporal parity class / grid frames per clip (video networks)
@@ -149,8 +148,7 @@ static int pack_fwd(Net& n, Node& nd) {
     int K = c.kt * c.kh * c.kw * c.cin;
     Packed& P = nd.fwd;
     P.K = K; P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cout; P.Cdpad = (int)align_up(c.cout, 128);
-    P.tap_uniform = (c.cin % I2V_KC == 0 && c.kt * c.kh * c.kw <= 64) ? 1 : 0;
-    P.ntaps = c.kt * c.kh * c.kw;
+    P.tap_uniform = (c.cin % I2V_KC == 0) ? 1 : 0;
     if (P.tap_uniform && c.kt == 1 && c.kh == 3 && c.kw == 3 && c.stride == 1 && c.stride_t == 1 && c.pad == 1 && !nd.preact()) P.halo = 9;
     // "Quad rows" for narrow stems (few input channels AND few output channels: SlowFast's fast pathway, 3 -> 8): such a launch
     // spends its time ISSUING the 4-byte im2col DMA of the per-row path (one instruction per K row and 64 pixels; 17 TFLOP/s),
@@ -219,8 +217,7 @@ static int pack_bwd(Net& n, Node& nd) {
             for (int s = 0; s < c.kw; ++s) if (posmod(pw + c.pad - s, st) == 0) ts.push_back(s);
             int K = (int)(tq.size() * tr.size() * ts.size()) * c.cout;
             P.K = K; P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cin; P.Cdpad = (int)align_up(c.cin, 128);
-            P.tap_uniform = (c.cout % I2V_KC == 0 && tq.size() * tr.size() * ts.size() <= 64) ? 1 : 0;
-            P.ntaps = (int)(tq.size() * tr.size() * ts.size());
+            P.tap_uniform = (c.cout % I2V_KC == 0) ? 1 : 0;
             if (P.tap_uniform && st == 1 && stt == 1 && c.kt == 1 && c.kh == 3 && c.kw == 3 && c.pad == 1 && !nd.preact()) P.halo = 9;
             std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
             std::vector<I2VKEntry> kt(P.Kpad ? P.Kpad : 1, I2VKEntry{0, 0, 0, 0});
@@ -289,8 +286,7 @@ static int pack_img(Net& n, Node& nd) {
     const int TWq = quad ? (TW + 3) / 4 * 4 : TW;               // column taps per run, padded to whole quads
     P.K = TT * TH * TWq * c.cout; P.Kpad = (int)align_up(P.K, I2V_KC);
     P.Cd = Bt * B * B * c.cin; P.Cdpad = (int)align_up(P.Cd, 128);
-    P.tap_uniform = (!quad && c.cout % I2V_KC == 0 && TT * TH * TW <= 64) ? 1 : 0;
-    P.ntaps = TT * TH * TW;
+    P.tap_uniform = (!quad && c.cout % I2V_KC == 0) ? 1 : 0;
     if (quad) { P.quad = TWq / 4; P.quad_kw = TW; P.quad_dw0 = dw_lo; }
     P.Tg = sparse ? (sb.T - ct0 + stt - 1) / stt : (sb.T + Bt - 1) / Bt; P.Hg = (sb.H + B - 1) / B; P.Wg = (sb.W + B - 1) / B;
     nd.img_blk = B; nd.img_sh = m; nd.img_blkt = Bt; nd.img_ost = sparse ? stt : Bt; nd.img_ot0 = ct0;
@@ -535,7 +531,7 @@ extern "C" int i2v_net_add_avgpool(i2v_handle h, int net, const i2v_pool_desc* d
 // ---------------------------------------------------------------------------------------------
 static void conv_common(I2VConvParams& p, const Packed& P) {
     memset(&p, 0, sizeof p);
-    p.wp = P.wp; p.ktab = P.ktab; p.K = P.K; p.Kpad = P.Kpad; p.tap_uniform = P.tap_uniform; p.ntaps = P.ntaps; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
+    p.wp = P.wp; p.ktab = P.ktab; p.K = P.K; p.Kpad = P.Kpad; p.tap_uniform = P.tap_uniform; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
     p.add0_stride = 1;
     p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1; p.ot0 = 0;
     p.temporal = P.has_dt;      // conv_run adds the frame-mapping half of the condition
@@ -1456,6 +1452,28 @@ extern "C" int i2v_tt_grad_mix_f32(const float* grads, float* out, const float* 
     if (!grads || !out || !kernel || !moves || D <= 0 || D > 64 || NC <= 0 || T <= 0 || HW <= 0) return fail("i2v_tt_grad_mix_f32: bad argument");
     const float w1 = (float)(1.0 - (double)weight);           // python: (1 - self.weight) in double, then a float32 tensor scalar
     CHECK_BE(k_tt_grad_mix(grads, out, kernel, (const int*)moves, D, NC, T, HW, w1, weight, stream));
+    return 0;
+}
+
+extern "C" int i2v_resample_nearest_f32(const float* src, float* dst, int64_t planes, int Hs, int Ws, int Hd, int Wd, const int32_t* map_y,
+                                        const int32_t* map_x, void* stream) {
+    if (!src || !dst || !map_y || !map_x || planes <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0) return fail("i2v_resample_nearest_f32: bad argument");
+    CHECK_BE(k_resample_nearest(src, dst, planes, Hs, Ws, Hd, Wd, map_y, map_x, stream));
+    return 0;
+}
+
+extern "C" int i2v_resample_nearest_bwd_f32(const float* g, float* gsrc, int64_t planes, int Hd, int Wd, int Hs, int Ws, const int32_t* ylo,
+                                            const int32_t* yhi, const int32_t* xlo, const int32_t* xhi, void* stream) {
+    if (!g || !gsrc || !ylo || !yhi || !xlo || !xhi || planes <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0)
+        return fail("i2v_resample_nearest_bwd_f32: bad argument");
+    CHECK_BE(k_resample_nearest_bwd(g, gsrc, planes, Hd, Wd, Hs, Ws, ylo, yhi, xlo, xhi, stream));
+    return 0;
+}
+
+extern "C" int i2v_dwconv1d_f32(const float* src, float* dst, int64_t outer, int len, int64_t inner, const float* taps, int k, void* stream) {
+    if (!src || !dst || src == dst || !taps || outer <= 0 || len <= 0 || inner <= 0 || k <= 0 || k > 64 || !(k & 1))
+        return fail("i2v_dwconv1d_f32: bad argument (odd k <= 64, out of place)");
+    CHECK_BE(k_dwconv1d(src, dst, outer, len, inner, taps, k, stream));
     return 0;
 }
 

@@ -56,6 +56,13 @@ int k_clip_resample_crop(const uint8_t* frames, float* video, const int32_t* xb,
                          int ky, int b, int t, int H, int W, int cy, int cx, int oh, int ow, i2v_stream_t s);
 int k_tt_grad_mix(const float* grads, float* out, const float* kern /*host [D]*/, const int* moves /*host [D]*/, int D, int64_t NC, int T,
                   int HW, float w1, float w, i2v_stream_t s);
+// base_attacks.py input / gradient transforms (DI-FGSM, TI-FGSM, TI-FGSM-3D): nearest resampling through index maps and its
+// transpose, depthwise 1-D convolution along one axis of a dense tensor (maps on the device, taps on the host, k <= 64)
+int k_resample_nearest(const float* src, float* dst, int64_t planes, int Hs, int Ws, int Hd, int Wd, const int32_t* map_y,
+                       const int32_t* map_x, i2v_stream_t s);
+int k_resample_nearest_bwd(const float* g, float* gsrc, int64_t planes, int Hd, int Wd, int Hs, int Ws, const int32_t* ylo,
+                           const int32_t* yhi, const int32_t* xlo, const int32_t* xhi, i2v_stream_t s);
+int k_dwconv1d(const float* src, float* dst, int64_t outer, int len, int64_t inner, const float* taps /*host [k]*/, int k, i2v_stream_t s);
 int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t s);
 int k_aens_reduce(const float* cos, const float* coeffs, int L, int frames, float* feat_sum,
                   float* weighted, i2v_stream_t s);

@@ -122,14 +122,8 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 //   128x64  6  (70 registers, 24 KB of LDS; +0.5 % over 5)     64x128  5  (83 registers, 32 KB)
 //   128x128  3  (147-150; left alone the allocator used 147 + 64 AGPRs = 2 blocks)
 // The 256-pixel tiles are bounded by LDS (4 blocks) and are left alone.  All without spills (-Rpass-analysis).
-#ifndef I2V_SEAM
-#define I2V_SEAM 0
-#endif
-#ifndef I2V_PRIO_LEVELS      // > 0: a block lowers its waves' priority as it advances through its K loop (levels .. 0), see chunk_body
-#define I2V_PRIO_LEVELS 0
-#endif
-#ifndef I2V_TAIL_PRIO        // 1: the quarter tiles of a tail-split launch run above the full tiles' priorities
-#define I2V_TAIL_PRIO 0
+#ifndef I2V_PRIO_LEVELS      // progress-ordered wave priority in the K loop (conv_tile, chunk_body): highest level; 0 = off
+#define I2V_PRIO_LEVELS 3
 #endif
 #ifndef I2V_SMALL_WPE
 #define I2V_SMALL_WPE 7
@@ -146,23 +140,14 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 #ifndef I2V_BIG_WPE
 #define I2V_BIG_WPE 3
 #endif
-// The seam-pipelined loop (MODE 1 / 2, conv_seam) keeps three LDS buffers, so LDS bounds those tiles: 64x64 24 KB -> 6 blocks,
-// 128x64 / 64x128 36 KB -> 4, 128x128 48 KB -> 3.
-static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi, int MODE) {
-    const bool seam = I2V_SEAM && (MODE == 1 || MODE == 2);
-    return (BD == 64 && BP == 64) ? (seam ? 6 : (PREF ? I2V_PREF_WPE : I2V_SMALL_WPE)) : (BD == 128 && BP == 64) ? (seam ? 4 : I2V_TALL_WPE) :
-           BD * BP == 8192 ? (seam ? 4 : I2V_MID_WPE) : BD * BP == 16384 ? I2V_BIG_WPE : (hi ? 8 : 1);
+static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi) {
+    return (BD == 64 && BP == 64) ? (PREF ? I2V_PREF_WPE : I2V_SMALL_WPE) : (BD == 128 && BP == 64) ? I2V_TALL_WPE : BD * BP == 8192 ? I2V_MID_WPE : BD * BP == 16384 ? I2V_BIG_WPE : (hi ? 8 : 1);
 }
-#define I2V_CONV_WPE __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(BD, BP, PREF, false, PRE ? 0 : MODE), conv_waves_per_simd(BD, BP, PREF, true, PRE ? 0 : MODE))))
-// Which main loop a tile runs.  The seam-pipelined loop (three LDS buffers, see conv_tile) serves the pointwise (MODE 1) and
-// tap-uniform (MODE 2) launches -- everything but the stems; the per-row (MODE 0) and quad-row (MODE 4) paths, whose DMA
-// instructions read k-table rows from scalar memory, and the pre-activation variant keep the two-buffer loop.
-static constexpr bool conv_seam(int MODE, bool PRE) { return I2V_SEAM && (MODE == 1 || MODE == 2) && !PRE; }
-static constexpr int conv_nst(int MODE, bool PRE) { return conv_seam(MODE, PRE) ? 3 : 2; }
-// LDS floats one tile needs: operand staging [NST][KC][BD] + [NST][KC][BP], re-used by the epilogue as a [WD*FR][BP] transpose buffer
-template <int BD, int BP, int WD, bool MF16, int NST = 2>
+#define I2V_CONV_WPE __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(BD, BP, PREF, false), conv_waves_per_simd(BD, BP, PREF, true))))
+// LDS floats one tile needs: operand staging [2][KC][BD] + [2][KC][BP], re-used by the epilogue as a [WD*FR][BP] transpose buffer
+template <int BD, int BP, int WD, bool MF16>
 constexpr int conv_lds_floats() {
-    constexpr int stage = NST * I2V_KC * (BD + BP), epi = WD * (MF16 ? 16 : 32) * BP;
+    constexpr int stage = 2 * I2V_KC * (BD + BP), epi = WD * (MF16 ? 16 : 32) * BP;
     return stage > epi ? stage : epi;
 }
 
@@ -177,7 +162,7 @@ constexpr int conv_halo_lds_floats() {
 // starting at pixel `px_base` (a launch may be cut into regions with different tile shapes, conv_igemm_tail below).
 template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false, int HWM = 0>
 __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd_tiles, const int bid, const int nwg, const int64_t px_base,
-                                          float* const smem, I2V_PROBE_T& probe, const int probe_slot, const int prio_hi = I2V_PRIO_LEVELS) {
+                                          float* const smem, I2V_PROBE_T& probe, const int probe_slot, const int prio_arg = I2V_PRIO_LEVELS) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-resource types and LDS-DMA builtins exist only in the device pass
     constexpr int KC = I2V_KC;
     constexpr int FR = MF16 ? 16 : 32;                       // fragment edge
@@ -186,8 +171,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     static_assert(!(MF16 && (PRE || PREF)), "no pre-activation / prefetch variants of the 16x16 tile");
     // one LDS array: operand staging [NST][KC][BD] + [NST][KC][BP], re-used by the epilogue as a
     // [WD*32][BP] transpose buffer
-    constexpr bool SEAM = conv_seam(MODE, PRE);               // seam-pipelined main loop (below): three LDS buffers
-    constexpr int NST = conv_nst(MODE, PRE);
+    constexpr int NST = 2;      // LDS operand buffers: chunk c is consumed while chunk c+1 is in flight
     // MODE 5 ("halo"): a 3x3 / stride-1 / pad-1 launch on planes exactly HWM wide stages, per 16-channel group, ONE halo row per
     // channel -- the tile's 64 pixels plus a source row and a pixel on either side -- instead of nine shifted copies of the tile
     constexpr bool HALO = MODE == 5;
@@ -258,7 +242,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     unsigned aoff[NAQ];
 #pragma unroll
     for (int q = 0; q < NAQ; ++q) {
-        const int f = (SEAM ? (wave + 4 * q) % NA : wave + 4 * q) * 256 + lane * 4;
+        const int f = (wave + 4 * q) * 256 + lane * 4;
         aoff[q] = (unsigned)(((f / BD) * p.Cdpad + f % BD + cd0) * 4);
     }
     unsigned boff[PW ? NBQ : 1];                              // PW: + row inside the chunk (lane dependent)
@@ -275,9 +259,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         constexpr int jj = (j_);                                                                          \
         const int k0 = (k0_);                                                                             \
         if constexpr (jj < NAQ) {                                                                         \
-            /* seam-pipelined loop: every wave issues the SAME number of pieces (its vmcnt waits count them); a wave without a \
-               piece of its own (NA < 4: 32- and 16-row tiles) re-issues another wave's -- same bytes to the same place */ \
-            const int ins = SEAM ? (wv + 4 * jj) % NA : wv + 4 * jj;                                       \
+            const int ins = wv + 4 * jj;                                                                  \
             if (NA % 4 == 0 || ins < NA)                                                                  \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(&As[buf_][0][0] + ins * 256), 16, aoff[jj],  \
                                                          k0 * p.Cdpad * 4, 0, 0);                         \
@@ -489,121 +471,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
             }(std::make_integer_sequence<int, NT>{});
             gbuf ^= 1;
         }
-    } else if constexpr (SEAM) {
-        // ---- seam-pipelined main loop (MODE 1 / 2): three LDS buffers, chunk c in buffer c % 3 -----------------------------
-        // Why: the per-block timeline of a launch (tools/conv_microbench.cpp, probe build) shows that the co-resident blocks of
-        // a CU do not finish together -- the hardware arbitrates oldest wave first -- so every CU ends a launch with one or two
-        // blocks left, and a block on its own (one wave per SIMD) reached only HALF the matrix pipe with the two-buffer loop:
-        // its DMA of chunk c+1 is issued ~6 MFMAs before the chunk seam (an L2 round trip), and behind the seam's barrier the
-        // first fragments are requested and awaited with nothing else to issue (tools/tile_lab.cpp: 999 cycles per chunk for
-        // 8 MFMAs of 64).  Here nothing a wave needs at the seam is requested at the seam:
-        //   * the DMA of chunk c+2 is issued during chunk c (behind its MFMAs): it has a whole chunk and a half to land.  Its buffer
-        //     held chunk c-1, which every wave finished reading before it passed the barrier of iteration c-1;
-        //   * ONE barrier per chunk, behind MFMA KS-3: the wave first waits for ITS pieces of chunk c+1 (counted vmcnt: the pieces
-        //     of chunk c+2 issued so far this iteration stay in flight) -- by then they are 1.5 chunks old;
-        //   * fragments are requested TWO k-steps ahead of their MFMA through a ring of four register sets (KS % 4 == 0, so k-step 0
-        //     of every chunk is set 0), across the seam as well: behind the barrier the last two k-steps of the iteration request
-        //     k-steps 0 and 1 of chunk c+1.  The requests of the last two k-steps of chunk c are both made at k-step KS-4, so the
-        //     youngest LDS read in front of the barrier is two MFMAs old and `lgkmcnt(0)` there costs nothing;
-        //   * MODE 2: a chunk's tap comes from a per-tap table held in ONE register across the lanes (lane t: tap t of the packing,
-        //     I2VConvParams::ntaps) and read with v_readlane -- no scalar-memory load in the loop, whose out-of-order return
-        //     would turn hipcc's counted LDS waits into lgkmcnt(0).
-        // Measured (tile_lab, 64x64 tile, K = 2304, TFLOP/s two-buffer -> seam): one block per CU 77 -> 114 (16-byte pieces),
-        // 68 -> 103 (4-byte pieces); two per CU 106 -> 118 (4-byte); four per CU on par.  Same products in the same order.
-        static_assert(KS % 4 == 0, "fragment ring of four register sets");
-        constexpr int SB = KS - 3;                                          // the barrier sits behind the MFMAs of k-step SB
-        constexpr int NBEF = (SB + 1) * PPS < NL ? (SB + 1) * PPS : NL;     // pieces of chunk c+2 issued before the seam wait
-        int vtap = 0, nt = 1, ichan = 0, gstride = 0;
-        if constexpr (MODE == 2) {
-            nt = p.ntaps;
-            const I2VKEntry e = p.ktab[(lane < nt ? lane : 0) * KC];        // (ordinary load, in front of every DMA)
-            vtap = (e.dh & 0xff) | ((e.dw & 0xff) << 8) | (((e.valid >> 1) & 0xff) << 16);
-            ichan = load_kentry(p.ktab, 0).chan_off;
-            gstride = nchunks > nt ? load_kentry(p.ktab, nt * KC).chan_off - ichan : 0;
-        }
-        // (the two table scalars are "used" here so that hipcc waits for their loads in front of the loop, not with an lgkmcnt(0) in it)
-        asm volatile("" ::"s"(ichan), "s"(gstride));
-        int itap = 0;                                                       // issue cursor: tap of the next chunk to stage
-        auto issue_vb = [&]() -> unsigned {                                 // MODE 2: per-lane byte offset of the cursor's tap
-            if constexpr (MODE == 2) {
-                const int pk = __builtin_amdgcn_readlane(vtap, itap);
-                const int dh = (int)(int8_t)pk, dw = (int)(int8_t)(pk >> 8), dtk = VID ? (int)(int8_t)(pk >> 16) : 0;
-                const int hs = h0 + dh, ws = w0 + dw;
-                const bool ok = pvalid && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws &&
-                                (!VID || (unsigned)(t0 + dtk) < (unsigned)p.Ts);
-                return ok ? xoff + (unsigned)((ichan + dtk * nstr + dh * p.Ws + dw) * 4) : OOB;
-            } else return OOB;
-        };
-        auto advance = [&]() {
-            if constexpr (MODE == 2) { if (++itap == nt) { itap = 0; ichan += gstride; } }
-        };
-        float fa[4][TD], fb[4][TP];
-        auto read_frags = [&](const int buf, const int s, const int set) {
-#pragma unroll
-            for (int i = 0; i < TD; ++i) fa[set][i] = As[buf][KR * s + lk][wd * (BD / WD) + i * FR + l31];
-#pragma unroll
-            for (int j = 0; j < TP; ++j) fb[set][j] = Bs[buf][KR * s + lk][wpx * (BP / WP) + j * FR + l31];
-        };
-        // prologue: chunks 0 and 1 on their way, chunk 0 landed, its first two k-steps requested
-        for (int c0 = 0; c0 < 2 && c0 < nchunks; ++c0) {
-            const unsigned vb = issue_vb();
-            (void)vb;
-            [&]<int... J>(std::integer_sequence<int, J...>) { (([&] { I2V_ISSUE_PIECE(J, c0 * KC, c0, vb); }()), ...); }
-            (std::make_integer_sequence<int, NL>{});
-            advance();
-        }
-        if (nchunks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (nchunks > 0) { read_frags(0, 0, 0); read_frags(0, 1, 1); }
-        int b0 = 0, b1 = 1, b2 = 2;                                         // buffers of chunks c, c+1, c+2
-        for (int c = 0; c < nchunks; ++c) {
-            const bool more1 = c + 1 < nchunks, more2 = c + 2 < nchunks;
-            const unsigned vb = more2 ? issue_vb() : OOB;
-            (void)vb;
-            // the two fragment sets carried across the seam are "used" here, so hipcc places its wait for them HERE (they were
-            // requested two MFMAs ago: free) and not behind the next requests as lgkmcnt(0)
-#pragma unroll
-            for (int i = 0; i < TD; ++i) asm volatile("" ::"v"(fa[0][i]), "v"(fa[1][i]));
-#pragma unroll
-            for (int j = 0; j < TP; ++j) asm volatile("" ::"v"(fb[0][j]), "v"(fb[1][j]));
-            [&]<int... S>(std::integer_sequence<int, S...>) {
-                (([&] {
-                    constexpr int s = S, set = S % 4;
-                    if constexpr (s < KS - 4) read_frags(b0, s + 2, (s + 2) % 4);
-                    else if constexpr (s == KS - 4) { read_frags(b0, KS - 2, (KS - 2) % 4); read_frags(b0, KS - 1, (KS - 1) % 4); }
-                    else if constexpr (s >= KS - 2) read_frags(b1, s + 2 - KS, (s + 2) % 4);      // (last chunk: a stale buffer, never used)
-                    __builtin_amdgcn_sched_barrier(0);          // keep the requests in front of this step's MFMAs
-#pragma unroll
-                    for (int i = 0; i < TD; ++i)
-#pragma unroll
-                        for (int j = 0; j < TP; ++j) {
-                            if constexpr (MF16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
-                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
-                        }
-                    if (more2) {
-                        [&]<int... Q>(std::integer_sequence<int, Q...>) {
-                            (([&] {
-                                constexpr int jp = s * PPS + Q;
-                                if constexpr (jp < NL) I2V_ISSUE_PIECE(jp, (c + 2) * KC, b2, vb);      // (chunk index from the loop counter: provably uniform -- no waterfall loop around the DMA)
-                            }()), ...);
-                        }(std::make_integer_sequence<int, PPS>{});
-                    }
-                    if constexpr (s == SB) {
-                        if (more1) {
-                            if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBEF) : "memory");
-                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            __builtin_amdgcn_s_barrier();
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }()), ...);
-            }(std::make_integer_sequence<int, KS>{});
-            advance();
-            const int tb = b0; b0 = b1; b1 = b2; b2 = tb;
-        }
-    } else {   // two-buffer loop, prologue: chunk 0 (and the k-table row of chunk 1)
+    } else {   // prologue: chunk 0 (and the k-table row of chunk 1)
         unsigned vb0 = OOB;
         if constexpr (MODE == 2) {
             const I2VKEntry e0 = load_kentry(p.ktab, 0);
@@ -616,10 +484,17 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
             (std::make_integer_sequence<int, NL>{});
         }
     }
-    // Progress-ordered priority (I2V_PRIO_LEVELS): the hardware arbitrates oldest wave first, so the co-resident blocks of a CU
-    // finish one after the other and every CU ends its launch with one or two blocks left, which cannot fill the matrix pipe on
-    // their own.  A block starts at priority `prio_hi` and steps down each time it completes another 1 / (prio_hi + 1) of its
-    // K loop: blocks that are behind outrank blocks that are ahead, so they advance together and finish together.
+    // Progress-ordered priority (round 3).  The per-block timeline of a launch (tools/conv_microbench.cpp -DCMB_PROBE) shows that
+    // the co-resident blocks of a CU do NOT finish together: the hardware serves the oldest wave first, so on the layer3 3x3
+    // shape the first of a CU's six blocks leaves its K loop after 137 us and the last after 227 -- every CU ends a launch with
+    // one or two blocks left, which cannot fill the matrix pipe on their own (a lone 64x64 block is issue-bound at ~55 % of it).
+    // A block therefore starts at priority `prio_hi` and steps down each time it completes another 1 / (prio_hi + 1) of its K
+    // loop: blocks that are behind outrank blocks that are ahead, they advance and finish together (first block out at 181 us,
+    // last at 223).  Only for loops of >= 16 chunks that are not the HBM-bound prefetching variant (those measured -3..-11 %:
+    // their time is the epilogue's memory traffic, and four steps over 4-8 chunks only reorder it).  Arbitration only: the
+    // arithmetic is untouched.  Measured per shape (same binary otherwise): +1..2 %; with the tail split, whose quarter tiles
+    // run ABOVE these levels (conv_igemm_tail), layer3 3x3 117.5 -> 124.1 TFLOP/s, layer3 reduce 120.4 -> 125.1.
+    const int prio_hi = (nchunks >= 16 && !PREF) ? prio_arg : 0;
     int prio_lvl = prio_hi, prio_next = 0, prio_step = 0;
     if (prio_hi > 0) {
         prio_step = (nchunks + prio_hi) / (prio_hi + 1); prio_next = prio_step;
@@ -692,7 +567,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
             }()), ...);
         }(std::make_integer_sequence<int, KS>{});
     };
-    if constexpr (!HALO && !SEAM) {
+    if constexpr (!HALO) {
         int buf = 0;
         for (int c = 0; c + 1 < nchunks; ++c) { chunk_body(c, buf, std::true_type{}); buf ^= 1; }
         if (nchunks > 0) chunk_body(nchunks - 1, buf, std::false_type{});
@@ -905,7 +780,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
 
 template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false>
 __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
-    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<BD, BP, WD, MF16, conv_nst(MODE, PRE)>()];
+    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<BD, BP, WD, MF16>()];
     I2V_PROBE_T probe;
     probe.entry();
     conv_tile<BD, BP, WD, WP, MODE, PREF, PRE, VID, MF16>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x);
@@ -928,27 +803,22 @@ conv_igemm_halo(const I2VConvParams p, const int n_cd_tiles) {
 // 32 CUs with 7 tiles and 224 with 6; cut this way it is 6 tiles everywhere plus 128 quarter tiles on 128 CUs.  Every output
 // element is still the same k-ordered fmaf chain (fragment shape does not enter): results are bit-identical.
 template <int MODE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(64, 64, false, false, MODE), conv_waves_per_simd(64, 64, false, true, MODE))))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I2V_SMALL_WPE, I2V_SMALL_WPE)))
 conv_igemm_tail(const I2VConvParams p, const int n_cd_a, const int nA, const int n_cd_b, const int64_t px_base_b) {
-    constexpr int LA = conv_lds_floats<64, 64, 2, false, conv_nst(MODE, false)>(), LB = conv_lds_floats<16, 64, 1, true, conv_nst(MODE, false)>();
+    constexpr int LA = conv_lds_floats<64, 64, 2, false>(), LB = conv_lds_floats<16, 64, 1, true>();
     __shared__ __attribute__((aligned(16))) float smem[LA > LB ? LA : LB];
     I2V_PROBE_T probe;
     probe.entry();
     const int slot = (int)blockIdx.x < nA ? (int)blockIdx.x : 65536 + (int)blockIdx.x - nA;      // (probe builds: quarter tiles from slot 65536 on)
-#if I2V_TAIL_PRIO
-    // the quarter tiles are dispatched last, i.e. they are the youngest waves of their CU and would be served last -- and finish
-    // last, alone: they run ABOVE every priority the full tiles use instead, are done in a quarter of a tile time and leave the
-    // CU to its six full tiles
+    // The quarter tiles are dispatched last, i.e. they are the youngest waves of their CU: served last, they used to finish last
+    // and alone (timeline: K loops of 238-248 us next to full tiles done at 229).  They run ABOVE every level the full tiles
+    // use instead, are done in a quarter of a tile time and leave the CU to its six full tiles.
     if ((int)blockIdx.x < nA) conv_tile<64, 64, 2, 2, MODE, false, false, false, false>(p, n_cd_a, blockIdx.x, nA, 0, smem, probe, slot, I2V_PRIO_LEVELS > 2 ? 2 : I2V_PRIO_LEVELS);
     else {
-        __builtin_amdgcn_s_setprio(3);
+        if (I2V_PRIO_LEVELS > 0) __builtin_amdgcn_s_setprio(3);
         conv_tile<16, 64, 1, 4, MODE, false, false, false, true>(p, n_cd_b, (int)blockIdx.x - nA, (int)gridDim.x - nA, px_base_b, smem, probe, slot, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (I2V_PRIO_LEVELS > 0) __builtin_amdgcn_s_setprio(0);
     }
-#else
-    if ((int)blockIdx.x < nA) conv_tile<64, 64, 2, 2, MODE, false, false, false, false>(p, n_cd_a, blockIdx.x, nA, 0, smem, probe, slot);
-    else conv_tile<16, 64, 1, 4, MODE, false, false, false, true>(p, n_cd_b, (int)blockIdx.x - nA, (int)gridDim.x - nA, px_base_b, smem, probe, slot);
-#endif
     probe.exit(slot);
 }
 
@@ -1976,6 +1846,64 @@ int k_tt_grad_mix(const float* grads, float* out, const float* kern, const int* 
     const int64_t M = NC * T * HW;
     hipLaunchKernelGGL(tt_grad_mix_kernel, dim3(stream_grid(M, 1024)), dim3(256), 0, (hipStream_t)s, grads, out, m, D, M, T, HW, w1, w);
     LAUNCH_CHECK("tt_grad_mix"); return 0;
+}
+// =============================================================================================
+// base_attacks.py transforms: DI-FGSM's input diversity (:357-376) = nearest resize -> zero pad -> nearest resize, which composes
+// into ONE index map per axis (map < 0: padding); its gradient gathers over the (contiguous: the maps are monotone) ranges of output
+// positions that read a source position.  TI-FGSM / TI-FGSM-3D (:412-441, :613-651) smooth the gradient with a Gaussian that is
+// an outer product of one 1-D kernel, i.e. one depthwise 1-D pass per axis.  HBM-bound streaming kernels.
+// =============================================================================================
+__global__ void __launch_bounds__(256) resample_nearest_kernel(const float* __restrict__ src, float* __restrict__ dst, const int64_t total, const int Hs,
+                                                               const int Ws, const int Hd, const int Wd, const int* __restrict__ my, const int* __restrict__ mx) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % Wd); const int64_t r = i / Wd; const int y = (int)(r % Hd); const int64_t pl = r / Hd;
+        const int sy = my[y], sx = mx[x];
+        dst[i] = (sy >= 0 && sx >= 0) ? src[(pl * Hs + sy) * Ws + sx] : 0.f;
+    }
+}
+__global__ void __launch_bounds__(256) resample_nearest_bwd_kernel(const float* __restrict__ g, float* __restrict__ gs, const int64_t total, const int Hd,
+                                                                   const int Wd, const int Hs, const int Ws, const int* __restrict__ ylo, const int* __restrict__ yhi,
+                                                                   const int* __restrict__ xlo, const int* __restrict__ xhi) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int sx = (int)(i % Ws); const int64_t r = i / Ws; const int sy = (int)(r % Hs); const int64_t pl = r / Hs;
+        float acc = 0.f;
+        for (int y = ylo[sy]; y < yhi[sy]; ++y)
+            for (int x = xlo[sx]; x < xhi[sx]; ++x) acc = __fadd_rn(acc, g[(pl * Hd + y) * Wd + x]);
+        gs[i] = acc;
+    }
+}
+struct DwTaps { float t[64]; };
+__global__ void __launch_bounds__(256) dwconv1d_kernel(const float* __restrict__ src, float* __restrict__ dst, const int64_t total, const int len,
+                                                       const int64_t inner, const DwTaps taps, const int k) {
+    const int half = k / 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t q = i / inner; const int pos = (int)(q % len);
+        const float* base = src + (i - (int64_t)pos * inner);
+        float acc = 0.f;
+        for (int t = 0; t < k; ++t) {           // zero padding: taps outside the axis contribute nothing
+            const int pp = pos + t - half;
+            if (pp >= 0 && pp < len) acc = __fadd_rn(acc, __fmul_rn(taps.t[t], base[(int64_t)pp * inner]));
+        }
+        dst[i] = acc;
+    }
+}
+int k_resample_nearest(const float* src, float* dst, int64_t planes, int Hs, int Ws, int Hd, int Wd, const int32_t* map_y, const int32_t* map_x,
+                       i2v_stream_t s) {
+    const int64_t total = planes * Hd * Wd;
+    hipLaunchKernelGGL(resample_nearest_kernel, dim3(stream_grid(total, 1024)), dim3(256), 0, (hipStream_t)s, src, dst, total, Hs, Ws, Hd, Wd, map_y, map_x);
+    LAUNCH_CHECK("resample_nearest"); return 0;
+}
+int k_resample_nearest_bwd(const float* g, float* gsrc, int64_t planes, int Hd, int Wd, int Hs, int Ws, const int32_t* ylo, const int32_t* yhi,
+                           const int32_t* xlo, const int32_t* xhi, i2v_stream_t s) {
+    const int64_t total = planes * Hs * Ws;
+    hipLaunchKernelGGL(resample_nearest_bwd_kernel, dim3(stream_grid(total, 1024)), dim3(256), 0, (hipStream_t)s, g, gsrc, total, Hd, Wd, Hs, Ws, ylo, yhi, xlo, xhi);
+    LAUNCH_CHECK("resample_nearest_bwd"); return 0;
+}
+int k_dwconv1d(const float* src, float* dst, int64_t outer, int len, int64_t inner, const float* taps, int k, i2v_stream_t s) {
+    DwTaps t; for (int i = 0; i < 64; ++i) t.t[i] = i < k ? taps[i] : 0.f;
+    const int64_t total = outer * len * inner;
+    hipLaunchKernelGGL(dwconv1d_kernel, dim3(stream_grid(total, 1024)), dim3(256), 0, (hipStream_t)s, src, dst, total, len, inner, t, k);
+    LAUNCH_CHECK("dwconv1d"); return 0;
 }
 int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t s) {
     hipLaunchKernelGGL(aens_coeffs_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, prev, coeffs, momentum, L);

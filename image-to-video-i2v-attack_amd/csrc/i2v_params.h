@@ -76,11 +76,6 @@ struct I2VConvParams {
     // channel and group (tile pixels + a row and a pixel on either side) instead of nine shifted copies of the tile.  Same
     // products in the same order: results are bit-identical.
     int32_t halo;
-    // tap_uniform packings order their K rows (16-channel group, tap, channel in group): chunk c is tap c % ntaps of group c / ntaps,
-    // every group repeating the taps of the first one with its channel planes offset by a constant -- which lets the kernel derive
-    // a chunk's k-table row from a per-tap table held in registers instead of loading it (no scalar-memory access in the K loop).
-    // ntaps <= 64 (the planner packs convolutions with more taps in (tap, channel) order, tap_uniform = 0).
-    int32_t ntaps;
     // exact division of a pixel index (< 2^31) by Hg*Wg, Wg, Tg and Wo as multiply-high + shift: filled in by k_conv (the
     // hardware has no integer divide; the 64-bit software divisions of round 1 cost a block more VALU issue slots than a
     // K = 64 tile spends on its MFMAs)

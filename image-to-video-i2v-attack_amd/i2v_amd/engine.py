@@ -185,6 +185,38 @@ class Engine:
                                                             D, N * C_, T, H * W, float(weight), self.stream()))
         return out
 
+    # ---- base_attacks.py transforms (DI / TI) ----
+    def resample_nearest(self, src: torch.Tensor, map_y: torch.Tensor, map_x: torch.Tensor) -> torch.Tensor:
+        """dst[..., y, x] = src[..., map_y[y], map_x[x]] (0 where a map is negative); maps: int32 tensors on the device."""
+        Hs, Ws = src.shape[-2:]
+        out = torch.empty(*src.shape[:-2], map_y.numel(), map_x.numel(), dtype=torch.float32, device=src.device)
+        planes = src.numel() // (Hs * Ws)
+        _lib.check(self.capi, self.capi.i2v_resample_nearest_f32(_ptr(src, self), _ptr(out, self), planes, Hs, Ws, map_y.numel(), map_x.numel(),
+                                                                 C.c_void_p(map_y.data_ptr()), C.c_void_p(map_x.data_ptr()), self.stream()))
+        return out
+
+    def resample_nearest_bwd(self, g: torch.Tensor, src_hw, ranges) -> torch.Tensor:
+        """Transpose of `resample_nearest`: `ranges` = (ylo, yhi, xlo, xhi) int32 device tensors over the SOURCE rows / columns."""
+        Hd, Wd = g.shape[-2:]
+        Hs, Ws = src_hw
+        out = torch.empty(*g.shape[:-2], Hs, Ws, dtype=torch.float32, device=g.device)
+        planes = g.numel() // (Hd * Wd)
+        _lib.check(self.capi, self.capi.i2v_resample_nearest_bwd_f32(_ptr(g, self), _ptr(out, self), planes, Hd, Wd, Hs, Ws,
+                                                                     *(C.c_void_p(r.data_ptr()) for r in ranges), self.stream()))
+        return out
+
+    def dwconv1d(self, src: torch.Tensor, taps, axis: int) -> torch.Tensor:
+        """Depthwise 1-D convolution (zero padding, odd len(taps) <= 64) along `axis` of a dense tensor, out of place."""
+        import numpy as np
+        axis = axis % src.dim()
+        k = np.ascontiguousarray(np.asarray(taps, dtype=np.float32))
+        outer = int(np.prod(src.shape[:axis], dtype=np.int64)) if axis > 0 else 1
+        inner = int(np.prod(src.shape[axis + 1:], dtype=np.int64)) if axis + 1 < src.dim() else 1
+        out = torch.empty_like(src)
+        _lib.check(self.capi, self.capi.i2v_dwconv1d_f32(_ptr(src, self), _ptr(out, self), outer, src.shape[axis], inner,
+                                                         C.c_void_p(k.ctypes.data), len(k), self.stream()))
+        return out
+
     def aens_coeffs(self, prev, coeffs, momentum):
         _lib.check(self.capi, self.capi.i2v_aens_coeffs_f32(_ptr(prev, self), _ptr(coeffs, self), momentum, coeffs.numel(), self.stream()))
 

@@ -137,6 +137,17 @@ class BIM(_SignAttack):
     def _pre(self, grad, state):
         return grad
 
+    def _gradient(self, adv, labels):
+        """The gradient the step starts from; subclasses put their input transforms here (DI, SI)."""
+        return self._grad(adv, labels)
+
+    def _l1_momentum(self, grad, state):
+        """`grad /= |grad|_1; grad += momentum * decay; momentum = grad` (base_attacks.py:394-398 and its copies)."""
+        grad = grad / torch.norm(grad, p=1)
+        grad = grad + state.get("momentum", torch.zeros_like(grad)) * self.decay
+        state["momentum"] = grad
+        return grad
+
     def forward(self, videos, labels):
         videos = videos.to(self.device).float().contiguous()
         labels = labels.to(self.device)
@@ -145,7 +156,7 @@ class BIM(_SignAttack):
         b, c, f, h, w = videos.shape
         state = {}
         for _ in range(self.steps):
-            grad = self._pre(self._grad(adv, labels), state).contiguous()
+            grad = self._pre(self._gradient(adv, labels), state).contiguous()
             adv = adv.detach()
             self.engine.sign_step(adv, u, grad, f * h * w, self.step_size, self.epsilon)   # :289-293
         return adv
@@ -164,6 +175,140 @@ class MIFGSM(BIM):
         grad = grad + state.get("momentum", torch.zeros_like(grad)) * self.decay
         state["momentum"] = grad
         return grad
+
+
+def _nearest_index(n_out: int, n_in: int):
+    """Source index of every output index of `F.interpolate(mode='nearest')` (ATen `nearest_idx`: identity when the sizes agree,
+    else `min(int(floorf(dst * scale)), n_in - 1)` with `scale = float32(n_in) / n_out`)."""
+    if n_out == n_in:
+        return np.arange(n_out, dtype=np.int64)
+    scale = np.float32(n_in) / np.float32(n_out)
+    return np.minimum(np.floor(np.arange(n_out, dtype=np.float32) * scale).astype(np.int64), n_in - 1)
+
+
+def diversity_maps(n_in: int, rnd: int, pad_lo: int, canvas: int = 250, n_out: int = 224):
+    """One axis of DI-FGSM's input diversity (`base_attacks.py:364-376`) as ONE index map: nearest resize n_in -> rnd, zero pad to
+    `canvas` with `pad_lo` in front, nearest resize canvas -> n_out.  Returns (map[n_out] with -1 for padding, lo[n_in], hi[n_in]):
+    output positions [lo[s], hi[s]) read source position s (contiguous: both resizes are monotone)."""
+    first = _nearest_index(rnd, n_in)                  # rescaled[i] = src[first[i]]
+    second = _nearest_index(n_out, canvas)             # out[y] = padded[second[y]]
+    inside = (second >= pad_lo) & (second < pad_lo + rnd)
+    m = np.where(inside, first[np.clip(second - pad_lo, 0, rnd - 1)], -1).astype(np.int32)
+    lo, hi = np.zeros(n_in, np.int32), np.zeros(n_in, np.int32)
+    for src in range(n_in):
+        hit = np.nonzero(m == src)[0]
+        if hit.size:
+            lo[src], hi[src] = hit[0], hit[-1] + 1
+            assert hit.size == hi[src] - lo[src]
+    return m, lo, hi
+
+
+class DIFGSM(BIM):
+    """Diverse Inputs (`base_attacks.py:342-409`): with probability 1/2 per step the model sees the clip resized (nearest) to a
+    random rnd in [224, 250), zero-padded to 250 at a random offset and resized back to 224 -- one composed index map per axis,
+    applied (`i2v_resample_nearest_f32`) and transposed for the gradient (`i2v_resample_nearest_bwd_f32`) on the device.  The
+    draws consume Python's and torch's global generators exactly as the reference does (`random.random()`, three
+    `torch.randint(..., size=(1, 1))`), so a seeded run sees the same transforms."""
+
+    def __init__(self, model, epsilon=16 / 255, steps=10, decay=1.0, momentum=False, engine=None):
+        super().__init__(model, epsilon, steps, engine)
+        self.attack = "DIFGSM"
+        self.decay, self.momentum = decay, momentum
+
+    def _draw(self):
+        import random
+        if random.random() < 0.5:                                        # :360
+            return None
+        rnd = torch.randint(224, 250, size=(1, 1)).item()                # :363
+        rem = 250 - rnd
+        top = torch.randint(0, rem, size=(1, 1)).item()                  # :369
+        left = torch.randint(0, rem, size=(1, 1)).item()                 # :371
+        return rnd, top, left
+
+    def _gradient(self, adv, labels):
+        draw = self._draw()
+        if draw is None:
+            return self._grad(adv, labels)
+        rnd, top, left = draw
+        b, c, f, h, w = adv.shape
+        eng, dev = self.engine, self.engine.device
+        my, ylo, yhi = diversity_maps(h, rnd, top)
+        mx, xlo, xhi = diversity_maps(w, rnd, left)
+        t = lambda a: torch.from_numpy(a).to(dev)                          # noqa: E731
+        x = eng.resample_nearest(adv.detach().to(dev).float().contiguous(), t(my), t(mx))      # (b,3,f,224,224), :364-376
+        g = self._grad(x.to(adv.device), labels).to(dev).float().contiguous()
+        return eng.resample_nearest_bwd(g, (h, w), (t(ylo), t(yhi), t(xlo), t(xhi))).to(adv.device)
+
+    def _pre(self, grad, state):
+        return self._l1_momentum(grad, state) if self.momentum else grad
+
+
+def gaussian_taps(kernlen=15, nsig=3):
+    """`_initial_kernel` (`base_attacks.py:425-430`, `:626-634`): the 2-D / 3-D kernels are outer products of `norm.pdf(linspace(-nsig,
+    nsig, kernlen))` divided by their sum, i.e. the outer product of this 1-D kernel normalised to sum 1."""
+    x = np.linspace(-nsig, nsig, kernlen)
+    k = np.exp(-0.5 * x * x) / np.sqrt(2 * np.pi)                        # scipy.stats.norm.pdf
+    return (k / k.sum()).astype(np.float32)
+
+
+class TIFGSM(BIM):
+    """Translation-Invariant attack (`base_attacks.py:411-469`): every frame of the gradient is smoothed with a 15 x 15 Gaussian
+    (depthwise `conv2d`, zero padding 7) -- two 1-D passes of `i2v_dwconv1d_f32` -- and divided by `mean(|.|, [1, 2, 3])` (sic: over
+    channels, frames and ROWS, one value per sample and column, :440)."""
+
+    def __init__(self, model, epsilon=16 / 255, steps=10, decay=1.0, momentum=False, engine=None):
+        super().__init__(model, epsilon, steps, engine)
+        self.attack = "MIFGSM"                                              # (sic) :414
+        self.decay, self.momentum = decay, momentum
+        self.taps = gaussian_taps(15, 3)
+
+    def _smooth(self, grad):
+        eng = self.engine
+        g = grad.to(eng.device).float().contiguous()
+        g = eng.dwconv1d(eng.dwconv1d(g, self.taps, 4), self.taps, 3)      # along W, then H
+        return g / torch.mean(torch.abs(g), [1, 2, 3], True)               # :440
+
+    def _pre(self, grad, state):
+        grad = self._smooth(grad).to(grad.device)
+        if self.momentum:
+            grad = grad + state.get("momentum", torch.zeros_like(grad)) * self.decay
+            state["momentum"] = grad
+        return grad
+
+
+class TIFGSM3D(TIFGSM):
+    """`base_attacks.py:612-675`: a 15 x 15 x 15 Gaussian over (T, H, W) (`conv3d`, groups 3, padding 7) -- three 1-D passes --, then the
+    frame-level `norm_grads` (:650)."""
+
+    def __init__(self, model, epsilon=16 / 255, steps=10, decay=1.0, momentum=False, engine=None):
+        super().__init__(model, epsilon, steps, decay, momentum, engine)
+        self.attack = "TIFGSM3D"
+
+    def _smooth(self, grad):
+        eng = self.engine
+        g = grad.to(eng.device).float().contiguous()
+        g = eng.dwconv1d(eng.dwconv1d(eng.dwconv1d(g, self.taps, 4), self.taps, 3), self.taps, 2)
+        return norm_grads(g, True)
+
+
+class SIM(BIM):
+    """Scale-Invariant method (`base_attacks.py:554-610`): the mean of the gradients at the clip scaled by 1, 1/2, ... 1/2^(m-1), each
+    taken w.r.t. the SCALED clip (:566-571: no chain-rule factor)."""
+
+    def __init__(self, model, epsilon=16 / 255, steps=10, decay=1.0, sclae_step=5, momentum=False, engine=None):
+        super().__init__(model, epsilon, steps, engine)
+        self.attack = "SIM"
+        self.decay, self.momentum, self.sclae_step = decay, momentum, sclae_step
+
+    def _gradient(self, adv, labels):
+        mean_grad = None
+        for i in range(self.sclae_step):
+            g = self._grad((1 / 2 ** i * adv).detach(), labels)             # :575-576
+            mean_grad = g if mean_grad is None else mean_grad + g
+        return mean_grad / self.sclae_step
+
+    def _pre(self, grad, state):
+        return self._l1_momentum(grad, state) if self.momentum else grad
 
 
 def run_concurrent(make_attack, items, streams=2, device=None, on_result=None):

@@ -256,6 +256,19 @@ int i2v_head_grad_f32(const float* a, int64_t a_stride, int C, int HW, int T, in
  * (1 - weight) * sum_d kernel[d] * grads[d]  +  weight * sum_d kernel[d] * roll(grads[d], -moves[d] along T). */
 int i2v_tt_grad_mix_f32(const float* grads, float* out, const float* kernel, const int32_t* moves, int D, int64_t NC, int T, int HW,
                         float weight, void* stream);
+/* DI-FGSM's input diversity (`base_attacks.py:357-376`): nearest resize to rnd x rnd, zero pad to 250 x 250 at a random offset, nearest
+ * resize to 224 x 224 -- composed by the caller into ONE index map per axis (`map[d]` = source index, < 0 for padding):
+ * dst[pl][y][x] = src[pl][map_y[y]][map_x[x]] or 0.  `_bwd` is its transpose (the gradient w.r.t. the un-diversified clip, what
+ * autograd returns at :391-392): gsrc[pl][sy][sx] = sum of g over the output rows [ylo[sy], yhi[sy]) x columns [xlo[sx], xhi[sx])
+ * that read (sy, sx) -- contiguous ranges because the maps are monotone; summed row-major in fp32.  Maps on the device. */
+int i2v_resample_nearest_f32(const float* src, float* dst, int64_t planes, int Hs, int Ws, int Hd, int Wd, const int32_t* map_y,
+                             const int32_t* map_x, void* stream);
+int i2v_resample_nearest_bwd_f32(const float* g, float* gsrc, int64_t planes, int Hd, int Wd, int Hs, int Ws, const int32_t* ylo,
+                                 const int32_t* yhi, const int32_t* xlo, const int32_t* xhi, void* stream);
+/* One depthwise 1-D convolution pass (zero padding k/2, odd k <= 64, taps on the host) along the middle axis of a dense
+ * [outer][len][inner] tensor, out of place: dst[o][i][j] = sum_t taps[t] * src[o][i + t - k/2][j].  TI-FGSM's 15 x 15 and
+ * TI-FGSM-3D's 15 x 15 x 15 Gaussians (`base_attacks.py:412-441`, `:613-651`) are outer products of one 1-D kernel: two / three passes. */
+int i2v_dwconv1d_f32(const float* src, float* dst, int64_t outer, int len, int64_t inner, const float* taps, int k, void* stream);
 /* Adaptive ENS-I2V re-weighting `coeffs = softmax(softmax(prev) + momentum*coeffs)`
  * (TPAMI_attack.py:265), L <= 64, in place on device. */
 int i2v_aens_coeffs_f32(const float* prev, float* coeffs, float momentum, int L, void* stream);

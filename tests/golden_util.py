@@ -131,12 +131,17 @@ def check_teacher_forced(fx, atk, to_dev=lambda t: t):
 # where the gradient is a difference of nearly equal fp32 activations; after t free-running steps it is not, and one
 # iteration from that state is a deterministic function that can be held to north_star's atol 1e-4 at BASELINE size
 # ---------------------------------------------------------------------------------------------------------------
-def check_mid_trajectory_step(mk, oracle_nets, vid, pick, t=3, lr=0.005, tag=""):
+def check_mid_trajectory_step(mk, oracle_nets, vid, pick, t=3, lr=0.005, tag="", fp32_nets=None):
     """`mk(steps)` builds the product attack.  Runs it for `t` free steps on the whole batch `vid`, takes the optimiser state
     (delta_t, m_t, v_t) of the frames `pick`, then runs ONE `forced_step` on those frames through the HIP engine and ONE
     step of the float64 oracle (`restate.run_attack(first_step=t)`, `image_attacks.py:325-358`) from the same state.
-    Asserts: cost rtol 2e-4; the gradient handed to Adam within 1e-4 max|g| on >= 99 % of the pixels; delta_{t+1} within
-    atol 1e-4 on EVERY pixel whose gradient is >= 5 % of max|g|."""
+    Asserts, without `fp32_nets` (the headline backbone): cost rtol 2e-4; the gradient handed to Adam within 1e-4 max|g| on
+    >= 99 % of the pixels; delta_{t+1} within atol 1e-4 on EVERY pixel whose gradient is >= 5 % of max|g|.
+    With `fp32_nets` (the same oracle nets in float32 = the reference's own ATen arithmetic on this host): deeper / wider
+    backbones (VGG-16's K = 4608 reductions, DenseNet's 58 layers) carry more float32 rounding than 1e-4 max|g| -- in the
+    reference itself; there the engine is held to the reference's OWN distance from float64: its gradient-error quantiles (50 %,
+    90 %, 99 %) and its worst delta error on well-conditioned pixels may be at most 3x the float32 oracle's (+ 1e-6 / 2e-5 floors),
+    the gradient direction must agree (cos > 0.9999), and delta_{t+1} stays within atol 1e-4 on >= 99.9 % of ALL pixels."""
     from oracle import restate
     b = vid.shape[0]
     run = mk(t)
@@ -147,18 +152,33 @@ def check_mid_trajectory_step(mk, oracle_nets, vid, pick, t=3, lr=0.005, tag="")
     sub = restate.unflatten_frames(restate.flatten_frames(vid)[pick].contiguous(), len(pick), 1).contiguous()   # one-frame clips
     one = mk(1)
     d1, m1, v1, cost = one.forced_step(sub, d, m, v, t)
-    ref = restate.run_attack(oracle_nets, sub.double(), steps=t + 1, step_size=lr, trace=True, first_step=t,
-                             forced_states=[None] * t + [(d.cpu(), m.cpu(), v.cpu())])
+    forced = [None] * t + [(d.cpu(), m.cpu(), v.cpu())]
+    ref = restate.run_attack(oracle_nets, sub.double(), steps=t + 1, step_size=lr, trace=True, first_step=t, forced_states=forced)
     g_ref = ref["grads"][0].numpy()
     gmax = np.abs(g_ref).max()
     g_hip = (m1.cpu().numpy().astype(np.float64) - 0.9 * m.cpu().numpy().astype(np.float64)) / 0.1
     rel = np.abs(g_hip - g_ref) / gmax
-    derr = np.abs(d1.cpu().numpy().astype(np.float64) - ref["deltas"][0].numpy())
+    d_ref = ref["deltas"][0].numpy()
+    derr = np.abs(d1.cpu().numpy().astype(np.float64) - d_ref)
     well = np.abs(g_ref) >= 5e-2 * gmax
+    cosang = float((g_hip * g_ref).sum() / np.sqrt((g_hip ** 2).sum() * (g_ref ** 2).sum()))
+    q = lambda a: [float(np.quantile(a, x)) for x in (0.5, 0.9, 0.99)]     # noqa: E731
     print(f"mid-trajectory step {tag}: t={t} cost hip {cost:.6f} oracle {float(ref['costs'][t]):.6f}; max|g| {gmax:.3e}; "
-          f"grad err/max|g|: max {rel.max():.2e}, frac<1e-4 {float((rel < 1e-4).mean()):.5f}; delta err: max(all) {derr.max():.2e}, "
-          f"max(|g|>=5%) {derr[well].max():.2e}, frac(all)<1e-4 {float((derr < 1e-4).mean()):.5f}, well-conditioned pixels {int(well.sum())}")
+          f"grad err/max|g|: max {rel.max():.2e}, q50/90/99 {q(rel)}, frac<1e-4 {float((rel < 1e-4).mean()):.5f}, cos {cosang:.7f}; "
+          f"delta err: max(all) {derr.max():.2e}, max(|g|>=5%) {derr[well].max():.2e}, frac(all)<1e-4 {float((derr < 1e-4).mean()):.5f}, "
+          f"well-conditioned pixels {int(well.sum())}")
     np.testing.assert_allclose(cost, float(ref["costs"][t]), rtol=2e-4)
-    assert (rel < 1e-4).mean() >= 0.99, float((rel < 1e-4).mean())
-    assert derr[well].max() < 1e-4, float(derr[well].max())
+    if fp32_nets is None:
+        assert (rel < 1e-4).mean() >= 0.99, float((rel < 1e-4).mean())
+        assert derr[well].max() < 1e-4, float(derr[well].max())
+    else:
+        r32 = restate.run_attack(fp32_nets, sub.float(), steps=t + 1, step_size=lr, trace=True, first_step=t, forced_states=forced)
+        rel32 = np.abs(r32["grads"][0].double().numpy() - g_ref) / gmax
+        derr32 = np.abs(r32["deltas"][0].double().numpy() - d_ref)
+        print(f"    float32 oracle vs float64 oracle: grad err/max|g| max {rel32.max():.2e}, q50/90/99 {q(rel32)}; "
+              f"delta err max(all) {derr32.max():.2e}, max(|g|>=5%) {derr32[well].max():.2e}")
+        for mine, theirs in zip(q(rel), q(rel32)):
+            assert mine <= 3 * theirs + 1e-6, (q(rel), q(rel32))
+        assert derr[well].max() <= 3 * derr32[well].max() + 2e-5, (float(derr[well].max()), float(derr32[well].max()))
+        assert cosang > 0.9999 and (derr < 1e-4).mean() >= 0.999, (cosang, float((derr < 1e-4).mean()))
     del one

@@ -628,6 +628,42 @@ int k_tt_grad_mix(const float* grads, float* out, const float* kern, const int* 
     return 0;
 }
 
+int k_resample_nearest(const float* src, float* dst, int64_t planes, int Hs, int Ws, int Hd, int Wd, const int32_t* my, const int32_t* mx, i2v_stream_t) {
+    for (int64_t pl = 0; pl < planes; ++pl)
+        for (int y = 0; y < Hd; ++y)
+            for (int x = 0; x < Wd; ++x)
+                dst[(pl * Hd + y) * Wd + x] = (my[y] >= 0 && mx[x] >= 0) ? src[(pl * Hs + my[y]) * Ws + mx[x]] : 0.f;
+    return 0;
+}
+
+int k_resample_nearest_bwd(const float* g, float* gs, int64_t planes, int Hd, int Wd, int Hs, int Ws, const int32_t* ylo, const int32_t* yhi,
+                           const int32_t* xlo, const int32_t* xhi, i2v_stream_t) {
+    for (int64_t pl = 0; pl < planes; ++pl)
+        for (int sy = 0; sy < Hs; ++sy)
+            for (int sx = 0; sx < Ws; ++sx) {
+                volatile float acc = 0.f;
+                for (int y = ylo[sy]; y < yhi[sy]; ++y)
+                    for (int x = xlo[sx]; x < xhi[sx]; ++x) acc = acc + g[(pl * Hd + y) * Wd + x];
+                gs[(pl * Hs + sy) * Ws + sx] = acc;
+            }
+    return 0;
+}
+
+int k_dwconv1d(const float* src, float* dst, int64_t outer, int len, int64_t inner, const float* taps, int k, i2v_stream_t) {
+    const int half = k / 2;
+    for (int64_t o = 0; o < outer; ++o)
+        for (int pos = 0; pos < len; ++pos)
+            for (int64_t j = 0; j < inner; ++j) {
+                volatile float acc = 0.f;
+                for (int t = 0; t < k; ++t) {
+                    const int pp = pos + t - half;
+                    if (pp >= 0 && pp < len) { volatile float m = taps[t] * src[(o * len + pp) * inner + j]; acc = acc + m; }
+                }
+                dst[(o * len + pos) * inner + j] = acc;
+            }
+    return 0;
+}
+
 int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t) {
     std::vector<float> a(L), b(L);
     float mx = -INFINITY, sum = 0.f;

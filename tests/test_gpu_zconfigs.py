@@ -111,11 +111,15 @@ def test_config2_ens_resnet50_vgg16_densenet121_batch8(eng):
     torch.cuda.empty_cache()
     # ---- mid-trajectory teacher-forced step: from the state after 3 free steps of the 8-clip run, one iteration
     # of all three backbones against one float64 oracle iteration on frames {0, 255}, and each leg on its own ----
-    gu.check_mid_trajectory_step(mk, nets, vid, pick, t=3, lr=0.005, tag="config2 ENS resnet50+vgg16+densenet121")
+    nets32 = []
+    for n in names:                                   # the same oracle in float32: the reference's own arithmetic (ATen on this host)
+        g = graphs.build(n, (hw, hw))
+        nets32.append(restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hooks[3]], dtype=torch.float32))
+    gu.check_mid_trajectory_step(mk, nets, vid, pick, t=3, lr=0.005, tag="config2 ENS resnet50+vgg16+densenet121", fp32_nets=nets32)
     torch.cuda.empty_cache()
-    for n, onet in zip(names[1:], nets[1:]):          # the VGG-16 and DenseNet-121 legs alone (ResNet-50: test_gpu_parity.py)
+    for n, onet, o32 in zip(names[1:], nets[1:], nets32[1:]):     # the VGG-16 and DenseNet-121 legs alone (ResNet-50: test_gpu_parity.py)
         mk1 = lambda steps, n=n: attacks.ImageGuidedFMDirection_Adam([n], depth=3, step_size=0.005, steps=steps, weight_seed=0)   # noqa: E731
-        gu.check_mid_trajectory_step(mk1, [onet], vid[:1], [3, 30], t=3, lr=0.005, tag=f"{n} depth 3, 224^2")
+        gu.check_mid_trajectory_step(mk1, [onet], vid[:1], [3, 30], t=3, lr=0.005, tag=f"{n} depth 3, 224^2", fp32_nets=[o32])
         torch.cuda.empty_cache()
     # ---- the stated 10-step run ----
     atk = mk(10)

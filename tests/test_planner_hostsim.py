@@ -333,4 +333,6 @@ def test_mid_trajectory_teacher_forced_step_hostsim(model):
     eng = hostsim_engine()
     mk = lambda steps: attacks.ImageGuidedFMDirection_Adam([model], depth=2, step_size=0.005, steps=steps, weight_seed=0,   # noqa: E731
                                                            engine=eng, graph_builder=graphs.build_tiny)
-    gu.check_mid_trajectory_step(mk, [onet], vid, [1, 6], t=3, lr=0.005, tag=f"hostsim tiny {model}")
+    o32 = restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hooks[2]], dtype=torch.float32)
+    gu.check_mid_trajectory_step(mk, [onet], vid, [1, 6], t=3, lr=0.005, tag=f"hostsim tiny {model}",
+                                 fp32_nets=[o32] if model == "vgg" else None)     # both assertion modes

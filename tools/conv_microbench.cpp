@@ -92,7 +92,7 @@ static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
     p.add0_stride = 1; p.relu = 1;
     p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1;
     if (with_epi) { p.add0 = da; p.add0_nstride = p.dst_nstride; }      // residual-style addend (the expand convolutions)
-    p.tap_uniform = tu; p.ntaps = NT;
+    p.tap_uniform = tu;
     p.pointwise = (k == 1 && st == 1 && (H * H) % 4 == 0 && !getenv("CMB_NOPW")); p.tap_uniform = tu;
     p.vec_epilogue = ((Ho * Ho) % 4 == 0);
     p.cfg = cfg + 1;
