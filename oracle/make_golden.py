@@ -134,6 +134,52 @@ def run_sign_step(clip_seed=77):
     return dict(clip_u8=u8.numpy(), steps=4, eps=16 / 255, **out)
 
 
+SIGN_FAMILY = (("DIFGSM", {}), ("DIFGSM", {"momentum": True}), ("TIFGSM", {}), ("TIFGSM", {"momentum": True}), ("TIFGSM3D", {}),
+               ("SIM", {}), ("SIM", {"momentum": True}))
+
+
+def run_sign_family(clip_seed=78, steps=3):
+    """The remaining image-model attacks of `base_attacks.py:342-675` (DI-, TI-, TI-3D-, SI-FGSM; each with and without momentum
+    where the class has the switch) on the toy 5-D video model of `run_sign_step`, through the imported reference classes:
+    records every raw gradient `torch.autograd.grad` returned (for DI: w.r.t. the un-diversified clip, i.e. THROUGH the
+    resize / pad / resize) and the final clip.  Python's and torch's global generators are seeded (11) in front of every
+    attack call: DI-FGSM draws its transforms from them (`random.random()`, `torch.randint`)."""
+    import random
+    ba = ref_shim.import_reference("base_attacks")
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(torch.nn.Conv3d(3, 4, 3, padding=1), torch.nn.ReLU(),
+                                torch.nn.AdaptiveAvgPool3d(1), torch.nn.Flatten(),
+                                torch.nn.Linear(4, 5))
+    u8 = make_clip(clip_seed, 1, 32, 12)
+    # DI-FGSM views its 224 x 224 result with the INPUT's shape (:375): it only accepts 224 x 224 clips -- one frame keeps the fixture small
+    u8_di = make_clip(clip_seed + 1, 1, 1, 224)
+    labels = torch.tensor([2])
+    grads = []
+    orig = torch.autograd.grad
+
+    def grad_tap(*a, **k):
+        r = orig(*a, **k)
+        grads.append(r[0].detach().clone())
+        return r
+    out = {}
+    for cls, kw in SIGN_FAMILY:
+        key = cls + ("_m" if kw.get("momentum") else "")
+        vid = normalise(u8_di if cls == "DIFGSM" else u8, torch.float32)
+        grads.clear()
+        random.seed(11); torch.manual_seed(11)
+        torch.autograd.grad = grad_tap
+        try:
+            with ref_shim.quiet():
+                atk = getattr(ba, cls)(model, epsilon=16 / 255, steps=steps, **kw)
+                adv = atk(vid.clone(), labels)
+        finally:
+            torch.autograd.grad = orig
+        if cls != "DIFGSM":
+            out[key + "_grads"] = torch.stack(grads).numpy()
+        out[key + "_adv"] = adv.detach().numpy()
+    return dict(clip_u8=u8.numpy(), clip_di_u8=u8_di.numpy(), steps=steps, eps=16 / 255, **out)
+
+
 def make_ilaf_inputs(seed, b, thw, lo, hi, amp):
     """Clean clip with pixels in [lo, hi] + an existing adversarial version of it within +-amp/255 (both
     uint8-quantised).  The f64 cases keep away from 0/255 and from eps so that no clamp mask is decided by the last
@@ -222,7 +268,14 @@ def main():
     print("aens_coefce_f64", fix["cost_str"][-1])
     np.savez_compressed(os.path.join(OUT, "sign_step.npz"), **run_sign_step())
     print("sign_step ok")
+    make_sign_family()
     make_ilaf()
+
+
+def make_sign_family():
+    path = os.path.join(OUT, "sign_family.npz")
+    np.savez_compressed(path, **run_sign_family())
+    print("sign_family", os.path.getsize(path) // 1024, "KiB")
 
 
 def make_tf():
@@ -246,6 +299,8 @@ if __name__ == "__main__":
         make_ilaf()
     elif sys.argv[1:] == ["tf"]:
         make_tf()
+    elif sys.argv[1:] == ["sign_family"]:
+        make_sign_family()
     else:
         main()
         make_tf()

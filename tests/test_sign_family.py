@@ -1,0 +1,117 @@
+"""CPU (host simulation backend): the DI- / TI- / TI-3D- / SI-FGSM drop-in classes (`base_attacks.py:342-675`) against what the
+imported reference classes returned on the same toy video model with the same seeds (fixture `sign_family.npz`,
+oracle/make_golden.py:run_sign_family), their device kernels against torch, and -- when the reference checkout is present --
+live against the reference classes."""
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from i2v_amd import sign_attacks as sa
+from oracle import ref_shim
+from oracle.make_golden import SIGN_FAMILY
+from tests import golden_util as gu
+from tests.hostsim_util import hostsim_engine
+from tests.test_sign_attacks_cpu import toy_video_model
+
+
+def _run(cls, kw, fx, engine):
+    import base_attacks
+    vid = gu.videos_of({"clip_u8": fx["clip_di_u8"] if cls == "DIFGSM" else fx["clip_u8"]})
+    model = toy_video_model()                 # (seeds torch itself: build it BEFORE the generators are set for the attack)
+    random.seed(11); torch.manual_seed(11)
+    atk = getattr(base_attacks, cls)(model, epsilon=16 / 255, steps=int(fx["steps"]), engine=engine, **kw)
+    return atk, atk(vid.clone(), torch.tensor([2]))
+
+
+@pytest.mark.parametrize("cls,kw", SIGN_FAMILY, ids=[c + ("_m" if k.get("momentum") else "") for c, k in SIGN_FAMILY])
+def test_sign_family_matches_reference_fixture(cls, kw):
+    fx = gu.load("sign_family")
+    key = cls + ("_m" if kw.get("momentum") else "")
+    atk, adv = _run(cls, kw, fx, hostsim_engine())
+    ref = torch.from_numpy(fx[key + "_adv"])
+    assert adv.shape == ref.shape
+    # the update kernel is the reference's arithmetic; the model's gradient is torch on both sides; TI's smoothing runs as
+    # separable 1-D passes (tolerance-equal to the reference's direct convolution): a sign can differ where the smoothed
+    # gradient is zero to rounding, one step of eps/steps on that pixel
+    differ = float((adv != ref).float().mean())
+    assert differ < (5e-3 if cls.startswith("TI") else 1e-3), differ
+    if not cls.startswith("TI"):
+        assert (adv - ref).abs().max() < 1e-6
+    std = torch.tensor(sa.STD).view(1, 3, 1, 1, 1)
+    assert ((adv - gu.videos_of({"clip_u8": fx["clip_di_u8"] if cls == "DIFGSM" else fx["clip_u8"]})) * std).abs().max() <= 16 / 255 + 1e-6
+
+
+def test_di_draws_follow_the_reference_generators():
+    """Three steps with seed 11 must include at least one transformed and the draws must be the reference's: same generators,
+    same order (`random.random()`, then rnd, top, left from `torch.randint(..., size=(1, 1))`)."""
+    atk = sa.DIFGSM(toy_video_model(), steps=3, engine=hostsim_engine())
+    random.seed(11); torch.manual_seed(11)
+    draws = [atk._draw() for _ in range(6)]
+    random.seed(11); torch.manual_seed(11)
+    want = []
+    for _ in range(6):
+        if random.random() < 0.5:
+            want.append(None)
+            continue
+        rnd = torch.randint(224, 250, size=(1, 1)).item()
+        rem = 250 - rnd
+        want.append((rnd, torch.randint(0, rem, size=(1, 1)).item(), torch.randint(0, rem, size=(1, 1)).item()))
+    assert draws == want and any(d is not None for d in draws[:3])
+
+
+@pytest.mark.parametrize("n_in,rnd,pad", [(224, 224, 0), (224, 237, 5), (224, 249, 0), (12, 230, 11)])
+def test_diversity_maps_equal_torch_resize_pad_resize(n_in, rnd, pad):
+    """The composed index maps against the three torch operations of `_input_diversity` (:364-376), forward and gradient,
+    through the engine's kernels."""
+    eng = hostsim_engine()
+    x = torch.randn(2, 3, n_in, n_in, generator=torch.Generator().manual_seed(1), requires_grad=True)
+    r = F.interpolate(x, size=[rnd, rnd], mode="nearest")
+    rem = 250 - rnd
+    p = F.pad(r, [pad, rem - pad, pad, rem - pad])
+    want = F.interpolate(p, size=[224, 224], mode="nearest")
+    m, lo, hi = sa.diversity_maps(n_in, rnd, pad)
+    t = torch.from_numpy
+    got = eng.resample_nearest(x.detach().contiguous(), t(m), t(m))
+    assert torch.equal(got, want.detach())
+    g = torch.randn(want.shape, generator=torch.Generator().manual_seed(2))
+    want.backward(g)
+    gx = eng.resample_nearest_bwd(g.contiguous(), (n_in, n_in), (t(lo), t(hi), t(lo), t(hi)))
+    assert (gx - x.grad).abs().max() <= 1e-6 * x.grad.abs().max()
+
+
+def test_smoothing_passes_equal_the_reference_convolutions():
+    """Two / three 1-D passes against the reference's direct depthwise conv2d / conv3d with its float32 15^2 / 15^3 kernels."""
+    from scipy import stats as st
+    eng = hostsim_engine()
+    g = torch.randn(1, 3, 32, 20, 24, generator=torch.Generator().manual_seed(3))
+    x = np.linspace(-3, 3, 15); k1 = st.norm.pdf(x)
+    k2 = np.outer(k1, k1); k2 = (k2 / k2.sum()).astype(np.float32)
+    w2 = torch.from_numpy(np.stack([k2] * 3)[:, None])
+    want2 = torch.stack([F.conv2d(g[:, :, i], w2, groups=3, padding=7) for i in range(32)], dim=2)
+    taps = sa.gaussian_taps()
+    got2 = eng.dwconv1d(eng.dwconv1d(g.contiguous(), taps, 4), taps, 3)
+    assert (got2 - want2).abs().max() <= 2e-6 * want2.abs().max()
+    k3 = np.zeros((15, 15, 15))
+    raw = np.outer(k1, k1)
+    for i in range(15):
+        k3[i] = k1[i] * raw
+    k3 = (k3 / k3.sum()).astype(np.float32)
+    want3 = F.conv3d(g, torch.from_numpy(np.stack([k3] * 3)[:, None]), groups=3, padding=7)
+    got3 = eng.dwconv1d(eng.dwconv1d(eng.dwconv1d(g.contiguous(), taps, 4), taps, 3), taps, 2)
+    assert (got3 - want3).abs().max() <= 3e-6 * want3.abs().max()
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference checkout not present")
+@pytest.mark.parametrize("cls", ["TIFGSM", "SIM"])
+def test_sign_family_live_against_reference(cls):
+    ba = ref_shim.import_reference("base_attacks")
+    fx = gu.load("sign_family")
+    vid = gu.videos_of({"clip_u8": fx["clip_u8"]})
+    with ref_shim.quiet():
+        ref = getattr(ba, cls)(toy_video_model(), epsilon=16 / 255, steps=2, momentum=True)(vid.clone(), torch.tensor([2])).detach()
+    import base_attacks
+    got = getattr(base_attacks, cls)(toy_video_model(), epsilon=16 / 255, steps=2, momentum=True, engine=hostsim_engine())(vid.clone(), torch.tensor([2]))
+    assert float((got != ref).float().mean()) < 5e-3
