@@ -64,7 +64,11 @@ struct Packed {               // one implicit-GEMM operand set
 };
 
 struct Node {
-    int type;                 // 0 conv, 1 maxpool, 2 avgpool
+    int type;                 // 0 conv, 1 maxpool, 2 avgpool, 3 attention core (non-local block)
+    i2v_attn_desc ad{};       // type 3
+    size_t p_off = 0;         // type 3: the attention matrix P [clips][M][N] (kept for the input-gradient pass), arena offset
+    int src0() const { return type == 0 ? cd.src : type == 3 ? ad.theta : pd.src; }
+    int dst0() const { return type == 0 ? cd.dst : type == 3 ? ad.dst : pd.dst; }
     i2v_conv3d_desc cd; i2v_pool3d_desc pd;        // image nodes are stored as kt = 1 video nodes
     std::vector<float> w;     // [cout][cin][kt][kh][kw] with scale folded
     std::vector<float> shift;
@@ -77,10 +81,11 @@ struct Node {
     size_t idx_off = 0;                           // maxpool: arg-max bytes, arena offset in floats
 };
 
-enum Kind { L_CONV, L_IMGGRAD, L_POOLF, L_POOLB, L_ADDMASK, L_CONVB_UNUSED, L_AVGF, L_AVGB, L_MEMSET, L_POOL3F, L_POOL3B };   // L_IMGGRAD: conv_igemm with class-packed Cd
+enum Kind { L_CONV, L_IMGGRAD, L_POOLF, L_POOLB, L_ADDMASK, L_CONVB_UNUSED, L_AVGF, L_AVGB, L_MEMSET, L_POOL3F, L_POOL3B, L_AGEMM, L_SOFTMAX };   // L_IMGGRAD: conv_igemm with class-packed Cd
 struct Launch {
     Kind kind;
     I2VConvParams conv; I2VPoolParams pool; I2VAddMaskParams am;
+    I2VAttnGemm ag; I2VSoftmaxRows sm; int sm_rows_per_clip = 0;    // L_AGEMM / L_SOFTMAX (clips are filled in at run time)
     int T = 1;                     // frames per clip of the launch's iteration space (conv launches: conv.Tg)
     bool src_is_input = false;     // conv: src pointer patched with the caller's x
     bool img_accumulate = false;   // L_IMGGRAD of a second convolution reading the input (two-pathway stems): gx += ...
@@ -526,6 +531,24 @@ extern "C" int i2v_net_add_avgpool(i2v_handle h, int net, const i2v_pool_desc* d
     return 0;
 }
 
+extern "C" int i2v_net_add_attention(i2v_handle h, int net, const i2v_attn_desc* d) {
+    Net* n = get_net(h, net); if (!n) return 1;
+    if (n->planned) return fail("net already planned");
+    const int nt = (int)n->tens.size();
+    if (!d) return fail("bad attention desc");
+    for (int t : {d->theta, d->phi, d->g, d->dst}) if (t < 0 || t >= nt) return fail("bad attention tensor");
+    const Tensor& th = n->tens[d->theta]; const Tensor& ph = n->tens[d->phi]; const Tensor& gg = n->tens[d->g]; const Tensor& ds = n->tens[d->dst];
+    if (th.C != ph.C || th.C != gg.C || th.C != ds.C) return fail("attention: theta / phi / g / dst channel counts differ");
+    const Buffer& tb = n->bufs[th.buf]; const Buffer& pb = n->bufs[ph.buf]; const Buffer& gb = n->bufs[gg.buf]; const Buffer& db = n->bufs[ds.buf];
+    if (tb.T != db.T || tb.H != db.H || tb.W != db.W) return fail("attention: dst must have theta's positions");
+    if (pb.T != gb.T || pb.H != gb.H || pb.W != gb.W) return fail("attention: phi and g must have the same positions");
+    if (th.post_relu || ph.post_relu || gg.post_relu) return fail("attention: theta / phi / g are linear embeddings (no ReLU)");
+    if (!(d->scale > 0.f)) return fail("attention: scale must be positive");
+    Node nd; nd.type = 3; nd.ad = *d; memset(&nd.cd, 0, sizeof nd.cd); memset(&nd.pd, 0, sizeof nd.pd);
+    n->nodes.push_back(std::move(nd));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // planning
 // ---------------------------------------------------------------------------------------------
@@ -709,6 +732,11 @@ struct Planner {
                 if (accum[n.tens[nd.cd.src].buf] && !nd.preact()) { err = "a dense (accumulating) buffer may only be read by pre-activation convs"; return false; }
                 if (!nd.preact()) left[nd.cd.src]++;
                 if (nd.cd.residual >= 0) left[nd.cd.residual]++;
+            } else if (nd.type == 3) {
+                for (int t : {nd.ad.theta, nd.ad.phi, nd.ad.g}) {
+                    if (accum[n.tens[t].buf]) { err = "attention over a dense (accumulating) buffer is not supported"; return false; }
+                    left[t]++;
+                }
             } else {
                 if (accum[n.tens[nd.pd.src].buf]) { err = "pooling directly from a dense (accumulating) buffer is not supported"; return false; }
                 left[nd.pd.src]++;
@@ -745,6 +773,22 @@ struct Planner {
                 if (nd.preact()) { p.pre_scale = nd.pre_scale_d; p.pre_shift = nd.pre_shift_d; }
                 if (c.relu) { int st = 0; if (uint32_t* g = gate_rows(c.dst, &st)) { p.gate_out = g; p.gate_out_stride = st; p.gate_out_pix0 = 0; } }
                 if (nd.fwd.quad) l.alg_flops_per_frame = 2.0 * d.H * d.W * c.cout * (double)c.cin * c.kt * c.kh * c.kw;
+            } else if (nd.type == 3) {
+                // S = scale * theta^T phi  ->  P = softmax rows  ->  y = g P^T   (P stays in the arena for the backward pass)
+                View th = view(nd.ad.theta, false), ph = view(nd.ad.phi, false), gv = view(nd.ad.g, false), y = view(nd.ad.dst, false);
+                const int M = th.T * th.H * th.W, Nn = ph.T * ph.H * ph.W;
+                float* P = base() + nd.p_off;
+                Launch a; a.kind = L_AGEMM; memset(&a.ag, 0, sizeof a.ag); a.T = th.T;
+                a.ag.form = 1; a.ag.Cc = th.C; a.ag.M = M; a.ag.N = Nn; a.ag.scale = nd.ad.scale;
+                a.ag.A = I2VActMat{th.p, th.nstride, th.T, th.H * th.W}; a.ag.B = I2VActMat{ph.p, ph.nstride, ph.T, ph.H * ph.W}; a.ag.D = P;
+                emit(n.fwd, a);
+                Launch sm; sm.kind = L_SOFTMAX; memset(&sm.sm, 0, sizeof sm.sm); sm.T = th.T;
+                sm.sm.X = P; sm.sm.N = Nn; sm.sm.mode = 0; sm.sm_rows_per_clip = M;
+                emit(n.fwd, sm);
+                l.kind = L_AGEMM; memset(&l.ag, 0, sizeof l.ag); l.T = th.T;
+                l.ag.form = 2; l.ag.Cc = th.C; l.ag.M = M; l.ag.N = Nn; l.ag.scale = 1.f;
+                l.ag.A = I2VActMat{gv.p, gv.nstride, gv.T, gv.H * gv.W}; l.ag.Din = P;
+                l.ag.Cact = y.p; l.ag.C_nstride = y.nstride; l.ag.C_T = y.T; l.ag.C_HW = y.H * y.W;
             } else {
                 const i2v_pool3d_desc& q = nd.pd;
                 const bool vid = q.kt != 1 || q.stride_t != 1 || q.pad_t != 0;
@@ -767,7 +811,7 @@ struct Planner {
             int t = n.hooks[hk];
             bool consumed = false;
             for (const Node& nd : n.nodes) {
-                int srcs[2] = {nd.type == 0 ? nd.cd.src : nd.pd.src, nd.type == 0 ? nd.cd.residual : -1};
+                int srcs[3] = {nd.src0(), nd.type == 0 ? nd.cd.residual : nd.type == 3 ? nd.ad.phi : -1, nd.type == 3 ? nd.ad.g : -1};
                 for (int s : srcs) if (s >= 0 && overlaps(n.tens[s], n.tens[t])) consumed = true;
             }
             if (consumed || accum[n.tens[t].buf]) { View g = view(t, true); hook_tmp[hk] = temp(nf(g.T) * g.C * g.H * g.W); }
@@ -797,7 +841,7 @@ struct Planner {
             }
         for (int i = (int)n.nodes.size() - 1; i >= 0; --i) {
             const Node& nd = n.nodes[i];
-            int dst = nd.type == 0 ? nd.cd.dst : nd.pd.dst;
+            int dst = nd.dst0();
             // a hook gradient kept in a side buffer joins the gradient of every node output the hooked view COVERS:
             // the hooked tensor itself, or -- a hooked concatenation (SqueezeNet Fire output = expand1x1 ++ expand3x3,
             // TPAMI_attack.py:195-197) -- each branch's channel slice of it
@@ -843,18 +887,52 @@ struct Planner {
                     p.pointwise = ((dz.H * dz.W) % 4 == 0) ? 1 : 0;
                     emit(n.bwd, l);
                 } else if (!contribute_conv(c.src, nd, dz)) return false;
+            } else if (nd.type == 3) {
+                // dY = dz.  dP = dY^T g;  dg = dY P;  dS = P o (dP - rowsum(dP o P));  dtheta = phi dS^T;  dphi = theta dS
+                for (int t : {nd.ad.theta, nd.ad.phi, nd.ad.g})
+                    if (left[t] != 1 || !pending[t].empty() || is_hook(t)) { err = "attention operands must have the attention node as their only consumer"; return false; }
+                View th = view(nd.ad.theta, false), ph = view(nd.ad.phi, false), gv = view(nd.ad.g, false);
+                View dth = view(nd.ad.theta, true), dph = view(nd.ad.phi, true), dgv = view(nd.ad.g, true);
+                const int M = th.T * th.H * th.W, Nn = ph.T * ph.H * ph.W;
+                float* P = base() + nd.p_off;
+                float* dP = temp(nf(th.T) / th.T * (size_t)M * Nn);
+                auto act = [](const View& v) { return I2VActMat{v.p, v.nstride, v.T, v.H * v.W}; };
+                auto gemm = [&](int form, I2VActMat A, const I2VActMat* B, float* D, const float* Din, const View* out) {
+                    Launch l; l.kind = L_AGEMM; memset(&l.ag, 0, sizeof l.ag); l.T = th.T;
+                    l.ag.form = form; l.ag.Cc = th.C; l.ag.M = M; l.ag.N = Nn; l.ag.scale = form == 1 ? nd.ad.scale : 1.f; l.ag.A = A;
+                    if (B) l.ag.B = *B;
+                    l.ag.D = D; l.ag.Din = Din;
+                    if (out) { l.ag.Cact = out->p; l.ag.C_nstride = out->nstride; l.ag.C_T = out->T; l.ag.C_HW = out->H * out->W; }
+                    emit(n.bwd, l);
+                };
+                const I2VActMat gA = act(gv);
+                // (the softmax backward works on d(scale * theta^T phi): the scale reaches dtheta / dphi through dS below)
+                { Launch l; l.kind = L_AGEMM; memset(&l.ag, 0, sizeof l.ag); l.T = th.T; l.ag.form = 1; l.ag.Cc = th.C; l.ag.M = M; l.ag.N = Nn;
+                  l.ag.scale = 1.f; l.ag.A = act(dz); l.ag.B = gA; l.ag.D = dP; emit(n.bwd, l); }
+                gemm(3, act(dz), nullptr, nullptr, P, &dgv);
+                { Launch l; l.kind = L_SOFTMAX; memset(&l.sm, 0, sizeof l.sm); l.T = th.T; l.sm.X = dP; l.sm.P = P; l.sm.N = Nn; l.sm.mode = 1;
+                  l.sm_rows_per_clip = M; emit(n.bwd, l); }
+                if (nd.ad.scale != 1.f) { err = "attention: only scale 1 is planned (gluoncv's gaussian non-local block has none)"; return false; }
+                gemm(2, act(ph), nullptr, nullptr, dP, &dth);
+                gemm(3, act(th), nullptr, nullptr, dP, &dph);
+                left[nd.ad.theta] = left[nd.ad.phi] = left[nd.ad.g] = 0;
             } else {
                 const i2v_pool3d_desc& q = nd.pd;
                 const bool vid = q.kt != 1 || q.stride_t != 1 || q.pad_t != 0;
                 left[q.src]--;
-                if (left[q.src] > 0 || !pending[q.src].empty()) { err = "maxpool input with several consumers is not supported"; return false; }
+                const bool shared = left[q.src] > 0 || !pending[q.src].empty();      // other consumers contribute to this gradient too
                 Launch l; l.kind = nd.type == 2 ? L_AVGB : vid ? L_POOL3B : L_POOLB; memset(&l.pool, 0, sizeof l.pool);
                 View x = view(q.src, false), gx = view(q.src, true);
+                if (shared) {       // (non-local block: x feeds theta, the 1x2x2 max-pool in front of phi / g, and the residual)
+                    if (left[q.src] == 0) { err = "a max-pool must not be the last contributor to a shared gradient (order the graph's nodes so that a convolution is)"; return false; }
+                    gx.nstride = (int64_t)gx.C * gx.H * gx.W; gx.p = temp(nf(gx.T) * gx.nstride);
+                    pending[q.src].push_back(Addend{gx.p, gx.nstride, 1, gx.H, gx.W});
+                }
                 l.pool.x = x.p; l.pool.x_nstride = x.nstride; l.pool.C = x.C; l.pool.Hs = x.H; l.pool.Ws = x.W;
                 l.pool.y = dz.p; l.pool.y_nstride = dz.nstride; l.pool.Ho = dz.H; l.pool.Wo = dz.W;
                 l.pool.gx = gx.p; l.pool.gx_nstride = gx.nstride;
                 l.pool.k = q.k; l.pool.stride = q.stride; l.pool.pad = q.pad;
-                l.pool.mask_relu = n.tens[q.src].post_relu ? 1 : 0;
+                l.pool.mask_relu = (n.tens[q.src].post_relu && !shared) ? 1 : 0;        // (shared: the finaliser applies the gate)
                 if (l.pool.mask_relu && nd.type == 1) { View ya = view(q.dst, false); l.pool.yact = ya.p; l.pool.yact_nstride = ya.nstride; }
                 l.pool.kt = q.kt; l.pool.stride_t = q.stride_t; l.pool.pad_t = q.pad_t; l.pool.Ts = x.T; l.pool.To = dz.T;
                 l.pool.idx = (uint8_t*)(base() + nd.idx_off);
@@ -926,6 +1004,11 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
         if (nd.type == 1) {
             const Buffer& db = n.bufs[n.tens[nd.pd.dst].buf];
             nd.idx_off = off; off = align_up(off + (N / Tin * db.T * n.tens[nd.pd.dst].C * db.H * db.W + 3) / 4, 64);
+        }
+    for (Node& nd : n.nodes)
+        if (nd.type == 3) {
+            const Buffer& tb = n.bufs[n.tens[nd.ad.theta].buf]; const Buffer& pb = n.bufs[n.tens[nd.ad.phi].buf];
+            nd.p_off = off; off = align_up(off + N / Tin * ((size_t)tb.T * tb.H * tb.W) * ((size_t)pb.T * pb.H * pb.W), 64);
         }
     Planner dry{n, true, off, N};
     if (!dry.run()) return fail("plan: %s", dry.err.c_str());
@@ -1063,9 +1146,11 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
         if (l.kind == L_CONV && l.alg_flops_per_frame > 0) flops = l.alg_flops_per_frame * frames;     // quad-row packings pad K
         else if (l.kind == L_CONV) flops = 2.0 * frames * l.conv.Hg * l.conv.Wg * (double)l.conv.Cd * l.conv.K;
         else if (l.kind == L_IMGGRAD) flops = l.alg_flops_per_frame * frames;
+        else if (l.kind == L_AGEMM) flops = 2.0 * clips * (double)l.ag.Cc * l.ag.M * l.ag.N;
         // timing kinds: 0 conv fwd, 1 image gradient, 2 pool fwd, 3 pool bwd, 4 addmask, 5 conv input-gradient
         const int tkind = (l.kind == L_CONV && backward_pass) ? 5 : (l.kind == L_AVGF || l.kind == L_POOL3F) ? 2
-                          : (l.kind == L_AVGB || l.kind == L_POOL3B) ? 3 : l.kind == L_MEMSET ? 4 : (int)l.kind;
+                          : (l.kind == L_AVGB || l.kind == L_POOL3B) ? 3 : (l.kind == L_MEMSET || l.kind == L_SOFTMAX) ? 4
+                          : l.kind == L_AGEMM ? (backward_pass ? 5 : 0) : (int)l.kind;
         TimedLaunch* tl = timing_begin(h, tkind, flops, s, prev_timed);
         prev_timed = tl;
         if (tl && (l.kind == L_CONV || l.kind == L_IMGGRAD)) {
@@ -1115,6 +1200,8 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
             case L_CONVB_UNUSED: break;
             case L_POOLB: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool_bwd(p, s)); } break;
             case L_ADDMASK: { I2VAddMaskParams p = l.am; p.N = frames; CHECK_BE(k_addmask(p, s)); } break;
+            case L_AGEMM: { I2VAttnGemm p = l.ag; p.clips = clips; CHECK_BE(k_attn_gemm(p, s)); } break;
+            case L_SOFTMAX: { I2VSoftmaxRows p = l.sm; p.rows = (int64_t)clips * l.sm_rows_per_clip; CHECK_BE(k_softmax_rows(p, s)); } break;
         }
     }
     return 0;

@@ -56,6 +56,8 @@ int k_clip_resample_crop(const uint8_t* frames, float* video, const int32_t* xb,
                          int ky, int b, int t, int H, int W, int cy, int cx, int oh, int ow, i2v_stream_t s);
 int k_tt_grad_mix(const float* grads, float* out, const float* kern /*host [D]*/, const int* moves /*host [D]*/, int D, int64_t NC, int T,
                   int HW, float w1, float w, i2v_stream_t s);
+int k_attn_gemm(const I2VAttnGemm& p, i2v_stream_t s);          // the three product forms of the non-local block
+int k_softmax_rows(const I2VSoftmaxRows& p, i2v_stream_t s);
 // base_attacks.py input / gradient transforms (DI-FGSM, TI-FGSM, TI-FGSM-3D): nearest resampling through index maps and its
 // transpose, depthwise 1-D convolution along one axis of a dense tensor (maps on the device, taps on the host, k <= 64)
 int k_resample_nearest(const float* src, float* dst, int64_t planes, int Hs, int Ws, int Hd, int Wd, const int32_t* map_y,

@@ -1848,6 +1848,147 @@ int k_tt_grad_mix(const float* grads, float* out, const float* kern, const int* 
     LAUNCH_CHECK("tt_grad_mix"); return 0;
 }
 // =============================================================================================
+// Non-local block core (gluoncv `i3d_nl5_*`; I2VAttnGemm / I2VSoftmaxRows): three product forms between frame-major activation
+// views and a dense per-clip matrix, and the row softmax / its backward.  64 x 64 output tiles, 4 waves of 32 x 32 on
+// v_mfma_f32_32x32x2_f32, K in chunks of 16 through double-buffered LDS in the canonical [k][m] image (operands whose K axis is
+// the contiguous one are transposed while they are written), register-staged prefetch.  Every output element is ONE k-ordered fmaf
+// chain computed by one block: no split K, no atomics.  The blocks cost ~15 % of the FLOPs of the stage they sit in, so the
+// kernel is kept simple (plain loads, no DMA staging).
+// =============================================================================================
+__device__ __forceinline__ const float* act_addr(const I2VActMat& a, int clip, int c, int pos) {
+    const int t = pos / a.HW, r = pos - t * a.HW;
+    return a.p + ((int64_t)clip * a.T + t) * a.nstride + (int64_t)c * a.HW + r;
+}
+// 4 consecutive elements along the contiguous axis of an operand, zero beyond `lim` (elements left on that axis)
+__device__ __forceinline__ float4 load4_guard(const float* p, int lim, bool vec_ok) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lim >= 4 && vec_ok) return *reinterpret_cast<const float4*>(p);
+    if (lim > 0) v.x = p[0];
+    if (lim > 1) v.y = p[1];
+    if (lim > 2) v.z = p[2];
+    if (lim > 3) v.w = p[3];
+    return v;
+}
+template <int FORM>
+__global__ void __launch_bounds__(256) attn_gemm_kernel(const I2VAttnGemm p) {
+    constexpr int KC = 16;
+    __shared__ __attribute__((aligned(16))) float Ls[2][KC][64], Rs[2][KC][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wd = wave >> 1, wp = wave & 1, l31 = lane & 31, lk = lane >> 5;
+    // output tile: rows m0.. (form 1: i; forms 2, 3: channel), columns n0.. (form 1: j; form 2: i; form 3: j), reduction K
+    const int ROWS = FORM == 1 ? p.M : p.Cc, COLS = FORM == 2 ? p.M : p.N, K = FORM == 1 ? p.Cc : (FORM == 2 ? p.N : p.M);
+    const int tiles_n = (COLS + 63) / 64;
+    const int clip = blockIdx.y, m0 = (blockIdx.x / tiles_n) * 64, n0 = (blockIdx.x % tiles_n) * 64;
+    const float* Dn = p.Din ? p.Din + (int64_t)clip * p.M * p.N : nullptr;
+    const bool a_vec = (p.A.HW % 4 == 0) && (p.A.nstride % 4 == 0) && (((uintptr_t)p.A.p & 15) == 0);
+    const bool b_vec = FORM == 1 && (p.B.HW % 4 == 0) && (p.B.nstride % 4 == 0) && (((uintptr_t)p.B.p & 15) == 0);
+    const bool d_vec = FORM != 1 && (p.N % 4 == 0) && (((uintptr_t)p.Din & 15) == 0);
+    // thread's share of a chunk: K-major operands: row k = t / 16, 4 columns from (t % 16) * 4; M-major: row m = t / 4, 4 k from (t % 4) * 4
+    const int kk = t >> 4, c4 = (t & 15) * 4, mm = t >> 2, k4 = (t & 3) * 4;
+    float4 ra, rb;
+    auto fetch = [&](const int k0) {
+        if constexpr (FORM == 1) {                 // Lhs[k=c][m=i] = A(c, i), Rhs[k=c][n=j] = B(c, j): both K-major
+            const int c = k0 + kk;
+            ra = (c < K && m0 + c4 < ROWS) ? load4_guard(act_addr(p.A, clip, c, m0 + c4), ROWS - (m0 + c4), a_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb = (c < K && n0 + c4 < COLS) ? load4_guard(act_addr(p.B, clip, c, n0 + c4), COLS - (n0 + c4), b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if constexpr (FORM == 2) {          // Lhs[k=j][m=c] = A(c, j) (M-major), Rhs[k=j][n=i] = D[i][j] (M-major)
+            const int c = m0 + mm, j = k0 + k4, i = n0 + mm;
+            ra = (c < ROWS && j < K) ? load4_guard(act_addr(p.A, clip, c, j), K - j, a_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb = (i < COLS && j < K) ? load4_guard(Dn + (int64_t)i * p.N + j, K - j, d_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {                                   // Lhs[k=i][m=c] = A(c, i) (M-major), Rhs[k=i][n=j] = D[i][j] (K-major)
+            const int c = m0 + mm, i = k0 + k4, ik = k0 + kk;
+            ra = (c < ROWS && i < K) ? load4_guard(act_addr(p.A, clip, c, i), K - i, a_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb = (ik < K && n0 + c4 < COLS) ? load4_guard(Dn + (int64_t)ik * p.N + n0 + c4, COLS - (n0 + c4), d_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](const int buf) {
+        if constexpr (FORM == 1) *reinterpret_cast<float4*>(&Ls[buf][kk][c4]) = ra;
+        else { Ls[buf][k4][mm] = ra.x; Ls[buf][k4 + 1][mm] = ra.y; Ls[buf][k4 + 2][mm] = ra.z; Ls[buf][k4 + 3][mm] = ra.w; }
+        if constexpr (FORM == 2) { Rs[buf][k4][mm] = rb.x; Rs[buf][k4 + 1][mm] = rb.y; Rs[buf][k4 + 2][mm] = rb.z; Rs[buf][k4 + 3][mm] = rb.w; }
+        else *reinterpret_cast<float4*>(&Rs[buf][kk][c4]) = rb;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nchunks = (K + KC - 1) / KC;
+    fetch(0); stash(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) fetch((c + 1) * KC);
+#pragma unroll
+        for (int s2 = 0; s2 < KC / 2; ++s2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ls[buf][2 * s2 + lk][wd * 32 + l31], Rs[buf][2 * s2 + lk][wp * 32 + l31], acc, 0, 0, 0);
+        if (c + 1 < nchunks) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // D layout: lane -> column wp*32 + l31, register r -> row wd*32 + (r & 3) + 8 (r >> 2) + 4 lk
+    const int col = n0 + wp * 32 + l31;
+    if (col >= COLS) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wd * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= ROWS) continue;
+        if constexpr (FORM == 1) p.D[((int64_t)clip * p.M + row) * p.N + col] = p.scale == 1.f ? acc[r] : __fmul_rn(p.scale, acc[r]);
+        else {
+            const int tt = col / p.C_HW, rr = col - tt * p.C_HW;
+            float* o = p.Cact + ((int64_t)clip * p.C_T + tt) * p.C_nstride + (int64_t)row * p.C_HW + rr;
+            *o = p.accumulate ? __fadd_rn(*o, acc[r]) : acc[r];
+        }
+    }
+}
+int k_attn_gemm(const I2VAttnGemm& p, i2v_stream_t s) {
+    const int rows = p.form == 1 ? p.M : p.Cc, cols = p.form == 2 ? p.M : p.N;
+    if (rows <= 0 || cols <= 0 || p.clips <= 0) return 0;
+    const dim3 grid((unsigned)(((rows + 63) / 64) * ((cols + 63) / 64)), (unsigned)p.clips);
+    if (p.form == 1) hipLaunchKernelGGL((attn_gemm_kernel<1>), grid, dim3(256), 0, (hipStream_t)s, p);
+    else if (p.form == 2) hipLaunchKernelGGL((attn_gemm_kernel<2>), grid, dim3(256), 0, (hipStream_t)s, p);
+    else hipLaunchKernelGGL((attn_gemm_kernel<3>), grid, dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("attn_gemm"); return 0;
+}
+// one block per row; thread t owns columns t, t + 256, ...; reductions: wave shuffles, then the four wave values in order
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const I2VSoftmaxRows p) {
+    __shared__ float red[4];
+    __shared__ float bc;
+    float* x = p.X + (int64_t)blockIdx.x * p.N;
+    const int t = threadIdx.x;
+    if (p.mode == 0) {
+        float m = -INFINITY;
+        for (int j = t; j < p.N; j += 256) m = fmaxf(m, x[j]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o));
+        if ((t & 63) == 0) red[t >> 6] = m;
+        __syncthreads();
+        if (t == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        m = bc;
+        float sum = 0.f;
+        for (int j = t; j < p.N; j += 256) { const float e = expf(__fsub_rn(x[j], m)); x[j] = e; sum = __fadd_rn(sum, e); }
+        sum = wave_sum(sum);
+        __syncthreads();
+        if ((t & 63) == 0) red[t >> 6] = sum;
+        __syncthreads();
+        if (t == 0) bc = __fadd_rn(__fadd_rn(red[0], red[1]), __fadd_rn(red[2], red[3]));
+        __syncthreads();
+        const float tot = bc;
+        for (int j = t; j < p.N; j += 256) x[j] = __fdiv_rn(x[j], tot);
+    } else {
+        const float* P = p.P + (int64_t)blockIdx.x * p.N;
+        float dot = 0.f;
+        for (int j = t; j < p.N; j += 256) dot = __fadd_rn(dot, __fmul_rn(x[j], P[j]));
+        dot = wave_sum(dot);
+        if ((t & 63) == 0) red[t >> 6] = dot;
+        __syncthreads();
+        if (t == 0) bc = __fadd_rn(__fadd_rn(red[0], red[1]), __fadd_rn(red[2], red[3]));
+        __syncthreads();
+        dot = bc;
+        for (int j = t; j < p.N; j += 256) x[j] = __fmul_rn(P[j], __fsub_rn(x[j], dot));
+    }
+}
+int k_softmax_rows(const I2VSoftmaxRows& p, i2v_stream_t s) {
+    if (p.rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)p.rows), dim3(256), 0, (hipStream_t)s, p);
+    LAUNCH_CHECK("softmax_rows"); return 0;
+}
+// =============================================================================================
 // base_attacks.py transforms: DI-FGSM's input diversity (:357-376) = nearest resize -> zero pad -> nearest resize, which composes
 // into ONE index map per axis (map < 0: padding); its gradient gathers over the (contiguous: the maps are monotone) ranges of output
 // positions that read a source position.  TI-FGSM / TI-FGSM-3D (:412-441, :613-651) smooth the gradient with a Gaussian that is

@@ -136,6 +136,27 @@ struct I2VIlafParams {
     const double* init_sq;
 };
 
+// Non-local (self-attention) block core of gluoncv's `i3d_nl5_*` models -- the reference's I3D configurations
+// (`/root/reference/utils.py:9-10`; two of the five blocks lie inside the stage ILAF hooks, `image_attacks.py:513-514`):
+//   S[i][j] = scale * sum_c theta[c][i] * phi[c][j],  P = softmax_j(S),  y[c][i] = sum_j g[c][j] * P[i][j]
+// per clip; i runs over the T*H*W positions of theta, j over the Tk*Hk*Wk positions of phi / g (max-pooled 1x2x2).
+// A channel-major operand is a frame-major activation view: element (clip b, channel c, position i) lives at
+//   p + (b * T + i / HW) * nstride + c * HW + i % HW.
+struct I2VActMat { const float* p; int64_t nstride; int32_t T, HW; };
+// The three product forms the block needs, forward and backward (fp32 MFMA, every output element one k-ordered fmaf chain, no atomics):
+//   form 1  D[i][j] = scale * sum_c A[c][i] * B[c][j]     (D dense [clips][M][N];  S = theta^T phi,  dP = dY^T g)
+//   form 2  C[c][i] = sum_j A[c][j] * D[i][j]             (C an activation view;   y = g P^T,        dtheta = phi dS^T)
+//   form 3  C[c][j] = sum_i A[c][i] * D[i][j]             (                        dg = dY P,        dphi = theta dS)
+struct I2VAttnGemm {
+    int32_t form, clips, Cc, M, N;        // channels, rows (i) and columns (j) of the dense matrix
+    I2VActMat A, B;                        // B only in form 1
+    float* Cact; int64_t C_nstride; int32_t C_T, C_HW;   // forms 2 / 3: the output activation view
+    float* D; const float* Din;            // dense matrix: output (form 1) / input (forms 2, 3), [clips][M][N]
+    float scale; int32_t accumulate;       // forms 2 / 3: Cact += ...
+};
+// row-wise softmax (mode 0: P = softmax(S) in place) and its backward (mode 1: dS = P o (dP - rowsum(dP o P)), in place over dP)
+struct I2VSoftmaxRows { float* X; const float* P; int64_t rows; int32_t N; int32_t mode; };
+
 // Classifier head of a white-box video model over its last feature map (frame-major: clips*T frames of (C, HW)):
 // global average pool over (T, H, W) -> Linear(C -> K) -> softmax cross-entropy against `labels`, mean over the clips
 // (attack.py:63-96 builds the gluoncv classifier, base_attacks.py:282-284 takes `CrossEntropyLoss()(model(adv), labels)`),

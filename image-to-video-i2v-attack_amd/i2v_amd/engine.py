@@ -243,6 +243,7 @@ class Net:
         used_t = {g.input}
         for nd in g.nodes:
             used_t.update([nd.src, nd.dst])
+            used_t.update(getattr(nd, "extra_srcs", ()))
             if getattr(nd, "residual", None) is not None:
                 used_t.add(nd.residual)
         used_t.update(hook_tensors)
@@ -282,6 +283,9 @@ class Net:
                                                                   _hptr(ps), _hptr(pt)))
                 else:
                     _lib.check(capi, capi.i2v_net_add_conv(h, self.id, C.byref(d), _hptr(w), _hptr(scale), _hptr(shift)))
+            elif nd.op == "attention":
+                d = _lib.AttnDesc(self.ten_id[nd.src], self.ten_id[nd.phi], self.ten_id[nd.g], self.ten_id[nd.dst], float(nd.scale))
+                _lib.check(capi, capi.i2v_net_add_attention(h, self.id, C.byref(d)))
             elif g.video:
                 d = _lib.Pool3dDesc(self.ten_id[nd.src], self.ten_id[nd.dst], nd.kt, nd.k, nd.stride_t, nd.stride, nd.pad_t, nd.pad)
                 _lib.check(capi, capi.i2v_net_add_maxpool3d(h, self.id, C.byref(d)))

@@ -74,6 +74,21 @@ class PoolNode:
 
 
 @dataclass
+class AttnNode:
+    """Core of a non-local block: dst[c][i] = sum_j g[c][j] softmax_j(scale * <theta[:, i], phi[:, j]>) per clip (`i2v_net_add_attention`)."""
+    src: int                    # theta
+    phi: int
+    g: int
+    dst: int
+    scale: float = 1.0
+    op: str = "attention"
+
+    @property
+    def extra_srcs(self):
+        return (self.phi, self.g)
+
+
+@dataclass
 class Graph:
     arch: str
     in_hw: Tuple[int, int]
@@ -130,7 +145,7 @@ class Graph:
         return self.maxpool(src, k, stride, 0, False, name, dst_buf, dst_c_off, op="avgpool")
 
     def conv3d(self, src, cout, k, stride, pad, weight, bn=None, relu=True, residual=None, name="",
-               dst_buf=None, dst_c_off=0, dil_t=1) -> int:
+               dst_buf=None, dst_c_off=0, dil_t=1, bias=None) -> int:
         """k / stride / pad are (temporal, spatial) pairs, as in `nn.Conv3d((kt,k,k), (st,s,s), (pt,p,p))`."""
         (kt, ks), (st, ss), (pt, ps) = k, stride, pad
         s = self.tensors[src]
@@ -138,9 +153,30 @@ class Graph:
         Ho = (s.H + 2 * ps - ks) // ss + 1
         Wo = (s.W + 2 * ps - ks) // ss + 1
         dst = self.new_tensor(cout, Ho, Wo, relu, name, dst_buf, dst_c_off, T=To)
-        self.nodes.append(ConvNode(src, dst, s.C, cout, ks, ks, ss, ps, weight, None, bn, relu, residual, None,
+        self.nodes.append(ConvNode(src, dst, s.C, cout, ks, ks, ss, ps, weight, bias, bn, relu, residual, None,
                                    "conv", kt, st, pt, dil_t))
         return dst
+
+    def attention(self, theta, phi, gg, name="", scale=1.0) -> int:
+        t = self.tensors[theta]
+        assert t.C == self.tensors[phi].C == self.tensors[gg].C
+        dst = self.new_tensor(t.C, t.H, t.W, False, name, T=t.T)
+        self.nodes.append(AttnNode(theta, phi, gg, dst, scale))
+        return dst
+
+    def nonlocal_block(self, x, prefix) -> int:
+        """gluoncv / mmaction `NonLocalModule` (embedded gaussian, sub-sampled, with BatchNorm): theta = conv1x1x1(x); phi, g =
+        conv1x1x1(maxpool 1x2x2 (x)); y = g softmax(theta^T phi)^T; z = BN(W y) + x.  Node order matters to the planner: a
+        convolution (theta) must be the LAST contributor to x's gradient, i.e. the first consumer listed."""
+        c = self.tensors[x].C
+        e = c // 2
+        theta = self.conv3d(x, e, (1, 1), (1, 1), (0, 0), f"{prefix}.theta.weight", relu=False, name=f"{prefix}.theta", bias=f"{prefix}.theta.bias")
+        xp = self.maxpool3d(x, (1, 2), (1, 2), (0, 0), name=f"{prefix}.max_pool")
+        phi = self.conv3d(xp, e, (1, 1), (1, 1), (0, 0), f"{prefix}.phi.1.weight", relu=False, name=f"{prefix}.phi", bias=f"{prefix}.phi.1.bias")
+        gg = self.conv3d(xp, e, (1, 1), (1, 1), (0, 0), f"{prefix}.g.1.weight", relu=False, name=f"{prefix}.g", bias=f"{prefix}.g.1.bias")
+        y = self.attention(theta, phi, gg, name=f"{prefix}.y")
+        return self.conv3d(y, c, (1, 1), (1, 1), (0, 0), f"{prefix}.W.0.weight", bn=f"{prefix}.W.1", relu=False, residual=x,
+                           name=f"{prefix}.out", bias=f"{prefix}.W.0.bias")
 
     def maxpool3d(self, src, k, stride, pad=(0, 0), name="") -> int:
         (kt, ks), (st, ss), (pt, ps) = k, stride, pad
@@ -164,6 +200,7 @@ class Graph:
             if hit:
                 keep[i] = True
                 needed.add(nd.src)
+                needed.update(getattr(nd, "extra_srcs", ()))
                 if getattr(nd, "residual", None) is not None:
                     needed.add(nd.residual)
         g = Graph(self.arch, self.in_hw, self.tensors, self.buffers,
@@ -185,6 +222,9 @@ class Graph:
             if nd.op == "conv":
                 d = self.tensors[nd.dst]
                 tot += d.T * d.H * d.W * nd.cout * nd.cin * nd.kt * nd.kh * nd.kw
+            elif nd.op == "attention":          # theta^T phi and g P^T
+                t, k = self.tensors[nd.src], self.tensors[nd.phi]
+                tot += 2 * t.C * (t.T * t.H * t.W) * (k.T * k.H * k.W)
         return tot
 
     def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
@@ -385,11 +425,17 @@ def densenet(growth=32, block_config=(6, 12, 24, 16), init_features=64, bn_size=
 # against `torch.nn.functional.conv3d / max_pool3d` (oracle/video_models.py).  Not built: the non-local blocks of
 # the `i3d_nl5_*` configs and TPN.
 # ---------------------------------------------------------------------------
+NL5_FREQ = ((0, 0, 0), (0, 1, 0, 1), (0, 1, 0, 1, 0, 1), (0, 0, 0))     # gluoncv i3d_nl5: non-local blocks behind blocks 1, 3 of res3 and 1, 3, 5 of res4
+
+
 def i3d_resnet(layers=(3, 4, 6, 3), width=64, in_thw=(32, 224, 224), arch="i3d_resnet50",
-               inflate=((1, 1, 1), (1, 0, 1, 0), (1, 0, 1, 0, 1, 0), (0, 1, 0))) -> Graph:
+               inflate=((1, 1, 1), (1, 0, 1, 0), (1, 0, 1, 0, 1, 0), (0, 1, 0)), nonlocal_freq=None) -> Graph:
     """Inflated Bottleneck ResNet: stem 5x7x7 / (2,2,2), max-pool 1x3x3 / (2,2,2), pool2 2x1x1 after the first
     stage, `inflate[stage][block] == 1` turns that block's first 1x1x1 convolution into 3x1x1.  `hooks[d]` is the
-    output of stage d; the reference hooks `res_layers._modules['1']`, i.e. d = 2 (`image_attacks.py:514`)."""
+    output of stage d; the reference hooks `res_layers._modules['1']`, i.e. d = 2 (`image_attacks.py:514`).
+    `nonlocal_freq[stage][block] == 1` appends a non-local block to that Bottleneck (`Graph.nonlocal_block`): the reference's I3D
+    configurations are gluoncv's `i3d_nl5_resnet50/101_v1` (`utils.py:9-10`), NL5_FREQ; for the 101-layer net the pattern of
+    res4 repeats over its 23 blocks' first six only (gluoncv lists five blocks in all)."""
     T, H, W = in_thw
     g = Graph(arch, (H, W), video=True)
     x = g.new_tensor(3, H, W, False, "input", T=T)
@@ -413,6 +459,8 @@ def i3d_resnet(layers=(3, 4, 6, 3), width=64, in_thw=(32, 224, 224), arch="i3d_r
                 idt = x
             x = g.conv3d(a, planes * 4, (1, 1), (1, 1), (0, 0), f"{p}.conv3.weight", bn=f"{p}.bn3", residual=idt,
                          name=f"{p}.out")
+            if nonlocal_freq is not None and li < len(nonlocal_freq) and b < len(nonlocal_freq[li]) and nonlocal_freq[li][b]:
+                x = g.nonlocal_block(x, f"{p}.nonlocal_block")
             inplanes = planes * 4
         g.hooks[li + 1] = x
         if li == 0:
@@ -591,10 +639,15 @@ def build_video(model_type: str, in_thw=(32, 224, 224), full: bool = False) -> G
     classifier head needs); the I3D graphs always are, SlowFast then gets res3..res5 and its lateral connections."""
     if full and model_type in ("slowfast_resnet50", "slowfast_resnet101"):
         return slowfast_resnet((3, 4, 23, 3) if "101" in model_type else (3, 4, 6, 3), 64, in_thw, model_type + "_full", **SLOWFAST_8X8)
-    if model_type == "i3d_resnet50":
-        return i3d_resnet((3, 4, 6, 3), 64, in_thw, "i3d_resnet50")
-    if model_type == "i3d_resnet101":
-        return i3d_resnet((3, 4, 23, 3), 64, in_thw, "i3d_resnet101")
+    # the reference's 'i3d_resnet50' / 'i3d_resnet101' ARE gluoncv's i3d_nl5_resnet50/101_v1 (utils.py:9-10): five non-local blocks
+    if model_type in ("i3d_resnet50", "i3d_nl5_resnet50"):
+        return i3d_resnet((3, 4, 6, 3), 64, in_thw, "i3d_nl5_resnet50", nonlocal_freq=NL5_FREQ)
+    if model_type in ("i3d_resnet101", "i3d_nl5_resnet101"):
+        return i3d_resnet((3, 4, 23, 3), 64, in_thw, "i3d_nl5_resnet101", nonlocal_freq=NL5_FREQ)
+    if model_type == "i3d_plain_resnet50":          # the inflated ResNet without non-local blocks (not a reference configuration)
+        return i3d_resnet((3, 4, 6, 3), 64, in_thw, "i3d_plain_resnet50")
+    if model_type == "i3d_plain_resnet101":
+        return i3d_resnet((3, 4, 23, 3), 64, in_thw, "i3d_plain_resnet101")
     if model_type == "slowfast_resnet50":
         return slowfast_res2(64, in_thw, "slowfast_resnet50", **SLOWFAST_8X8)
     if model_type == "slowfast_resnet101":          # res2 is identical for the 50- and 101-layer variants
@@ -603,7 +656,10 @@ def build_video(model_type: str, in_thw=(32, 224, 224), full: bool = False) -> G
         return tpn_resnet((3, 4, 6, 3), 64, in_thw, "tpn_resnet50")
     if model_type == "tpn_resnet101":          # layer1 / layer2 are the same for the 50- and 101-layer backbones
         return tpn_resnet((3, 4, 23, 3), 64, in_thw, "tpn_resnet101")
-    raise KeyError(f"video backbone {model_type!r} is not built (the non-local i3d_nl5 blocks are out of scope)")
+    raise KeyError(f"video backbone {model_type!r} is not built")
+
+
+TINY_NL_FREQ = ((0, 0), (1, 1), (1,), (0,))      # tiny I3D: a non-local block behind both blocks of the hooked stage and one in the next
 
 
 def build_video_tiny(model_type: str, in_thw=(8, 32, 32), full: bool = False) -> Graph:
@@ -612,7 +668,9 @@ def build_video_tiny(model_type: str, in_thw=(8, 32, 32), full: bool = False) ->
     if "tpn" in model_type:
         return tpn_resnet((2, 2, 1, 1), 8, in_thw, "tpn_tiny")
     if "i3d" in model_type:
-        return i3d_resnet((2, 2, 1, 1), 8, in_thw, "i3d_tiny", inflate=((1, 1), (1, 0), (1,), (0,)))
+        plain = "plain" in model_type
+        return i3d_resnet((2, 2, 1, 1), 8, in_thw, "i3d_plain_tiny" if plain else "i3d_tiny", inflate=((1, 1), (1, 0), (1,), (0,)),
+                          nonlocal_freq=None if plain else TINY_NL_FREQ)
     return slowfast_res2(16, in_thw, "slowfast_tiny", slow_stride=4, fast_stride=1, beta_inv=4, blocks=2)
 
 

@@ -27,6 +27,10 @@ class Conv3dDesc(C.Structure):
                  "relu", "residual")]
 
 
+class AttnDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("theta", "phi", "g", "dst")] + [("scale", C.c_float)]
+
+
 class Pool3dDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("src", "dst", "kt", "k", "stride_t", "stride", "pad_t", "pad")]
 
@@ -54,6 +58,7 @@ _PROTOS = {
     "i2v_net_add_buffer3d": ([_P, _I, _I, _I, _I, _I, C.POINTER(_I)], _I),
     "i2v_net_add_conv3d": ([_P, _I, C.POINTER(Conv3dDesc), _P, _P, _P], _I),
     "i2v_net_add_maxpool3d": ([_P, _I, C.POINTER(Pool3dDesc)], _I),
+    "i2v_net_add_attention": ([_P, _I, C.POINTER(AttnDesc)], _I),
     "i2v_net_tensor_frames": ([_P, _I, _I, C.POINTER(_I)], _I),
     "i2v_net_plan": ([_P, _I, C.POINTER(_I), _I, _I], _I),
     "i2v_net_workspace_bytes": ([_P, _I], C.c_size_t),

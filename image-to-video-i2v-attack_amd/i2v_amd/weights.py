@@ -34,13 +34,20 @@ def synthetic_state_dict(graph: Graph, seed: int = 0) -> Dict[str, torch.Tensor]
             continue
         fan_out = nd.cout * nd.kt * nd.kh * nd.kw
         std = (2.0 / fan_out) ** 0.5
+        # Non-local blocks: gluoncv zero-initialises the BatchNorm behind W (the block starts as the identity) and a trained
+        # block stays a correction to its input, with attention logits of moderate size.  Kaiming-sized theta / phi and a unit
+        # BatchNorm make the un-normalised softmax one-hot and the whole network chaotic instead (two float32 evaluations of a
+        # 4-step ILAF run then differ by percents): smaller embeddings, and a small BatchNorm gain below.
+        nl = ".nonlocal_block." in nd.weight
+        if nl and (".theta." in nd.weight or ".phi." in nd.weight):
+            std *= 0.1
         shape = (nd.cout, nd.cin, nd.kt, nd.kh, nd.kw) if graph.video else (nd.cout, nd.cin, nd.kh, nd.kw)
         sd[nd.weight] = torch.randn(*shape, generator=_gen(seed, nd.weight)) * std
         if nd.bias:
             sd[nd.bias] = torch.randn(nd.cout, generator=_gen(seed, nd.bias)) * 0.05
         if nd.bn:
             g = _gen(seed, nd.bn)
-            sd[nd.bn + ".weight"] = torch.rand(nd.cout, generator=g) + 0.5
+            sd[nd.bn + ".weight"] = (torch.rand(nd.cout, generator=g) + 0.5) * (0.1 if nl else 1.0)
             sd[nd.bn + ".bias"] = torch.randn(nd.cout, generator=g) * 0.1
             sd[nd.bn + ".running_mean"] = torch.randn(nd.cout, generator=g) * 0.1
             sd[nd.bn + ".running_var"] = torch.rand(nd.cout, generator=g) + 0.5
@@ -188,6 +195,8 @@ def fold_affine(nd, sd):
         v = sd[nd.bn + ".running_var"].double()
         s = g / torch.sqrt(v + BN_EPS)
         t = b - m * s
+        if nd.bias:                 # conv WITH bias followed by BatchNorm (the non-local block's W): BN(conv + bias)
+            t = t + sd[nd.bias].double() * s
         return s.float(), t.float()
     s = torch.ones(nd.cout)
     t = sd[nd.bias].float() if nd.bias else torch.zeros(nd.cout)

@@ -97,6 +97,18 @@ int i2v_net_add_buffer3d(i2v_handle h, int net, int C, int T, int H, int W, int*
 int i2v_net_add_conv3d(i2v_handle h, int net, const i2v_conv3d_desc* d, const float* weight,
                        const float* scale, const float* shift);
 int i2v_net_add_maxpool3d(i2v_handle h, int net, const i2v_pool3d_desc* d);
+/* Core of a non-local (self-attention) block -- gluoncv's `i3d_nl5_resnet50/101_v1`, which ARE the reference's I3D models
+ * (`/root/reference/utils.py:9-10`; `image_attacks.py:513-514` hooks `res_layers[1]`, which holds two of the five blocks):
+ *   dst[c][i] = sum_j g[c][j] * softmax_j(scale * sum_c' theta[c'][i] * phi[c'][j])     per clip,
+ * i over the T*H*W positions of `theta` (= those of `dst`), j over the positions of `phi` and `g` (the block max-pools their input
+ * 1x2x2).  theta / phi / g / dst are tensors of the graph with equal channel counts, produced / consumed by ordinary nodes: the
+ * 1x1x1 embeddings, the max-pool and `W` + BatchNorm + residual are convolution / pooling nodes.  The attention matrix is kept in
+ * the arena for the input-gradient pass, which produces the gradients of theta, phi and g (each must have no other consumer). */
+typedef struct {
+    int32_t theta, phi, g, dst;
+    float scale;
+} i2v_attn_desc;
+int i2v_net_add_attention(i2v_handle h, int net, const i2v_attn_desc* d);
 /* Frames per clip of a tensor (1 for image networks). */
 int i2v_net_tensor_frames(i2v_handle h, int net, int tensor, int* T);
 /* Freeze the graph: pack weights for forward and input-gradient, plan both passes for up to

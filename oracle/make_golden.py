@@ -224,7 +224,7 @@ def run_ilaf(model_type, prec, steps, b, thw, seed, lo, hi, amp, wseed=0):
 
 ILAF_CASES = {
     "ilaf_i3d_f64": ("i3d_resnet50", "f64", 4, 1, (8, 32, 32), 2001, 16, 239, 10),
-    "ilaf_i3d_f32": ("i3d_resnet50", "f32", 4, 1, (8, 32, 32), 2002, 0, 255, 15),
+    "ilaf_i3d_f32": ("i3d_resnet50", "f32", 3, 1, (8, 32, 32), 2002, 0, 255, 15),      # (3 steps: with the non-local blocks two float32 evaluations of the 4th differ by 1 %)
     "ilaf_slowfast_f64": ("slowfast_resnet50", "f64", 3, 2, (8, 32, 32), 2003, 16, 239, 10),
     "ilaf_tpn_f64": ("tpn_resnet50", "f64", 3, 1, (4, 32, 32), 2004, 16, 239, 10),
 }

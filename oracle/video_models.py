@@ -15,9 +15,34 @@ import torch
 import torch.nn as nn
 
 
-class Bottleneck3d(nn.Module):
-    def __init__(self, inplanes, planes, stride=1, head_t=1, downsample=None):
+class NonLocal3d(nn.Module):
+    """gluoncv / mmaction `NonLocalModule` as the reference's `i3d_nl5_*` models use it (restated from the public code, gluoncv
+    is not installed): embedded gaussian, `sub_sample=True` (a 1x2x2 max-pool in front of phi and g), `use_bn=True`.
+    State-dict keys: theta.{weight,bias}, phi.1.*, g.1.*, W.0.{weight,bias}, W.1.{BatchNorm}."""
+
+    def __init__(self, in_channels):
         super().__init__()
+        e = in_channels // 2
+        self.theta = nn.Conv3d(in_channels, e, 1)
+        self.max_pool = nn.MaxPool3d((1, 2, 2))
+        self.phi = nn.Sequential(self.max_pool, nn.Conv3d(in_channels, e, 1))
+        self.g = nn.Sequential(self.max_pool, nn.Conv3d(in_channels, e, 1))
+        self.W = nn.Sequential(nn.Conv3d(e, in_channels, 1), nn.BatchNorm3d(in_channels))
+        self.softmax = nn.Softmax(dim=2)
+
+    def forward(self, x):
+        theta, phi, g = self.theta(x), self.phi(x), self.g(x)
+        shape = theta.shape
+        theta, phi, g = theta.reshape(shape[0], shape[1], -1), phi.reshape(shape[0], shape[1], -1), g.reshape(shape[0], shape[1], -1)
+        p = self.softmax(torch.matmul(theta.transpose(1, 2), phi))          # (b, THW, T'H'W')
+        y = torch.matmul(g, p.transpose(1, 2)).reshape(shape)
+        return self.W(y) + x
+
+
+class Bottleneck3d(nn.Module):
+    def __init__(self, inplanes, planes, stride=1, head_t=1, downsample=None, nonlocal_block=False):
+        super().__init__()
+        self.nonlocal_block = NonLocal3d(planes * 4) if nonlocal_block else None
         self.conv1 = nn.Conv3d(inplanes, planes, (head_t, 1, 1), padding=(head_t // 2, 0, 0), bias=False)
         self.bn1 = nn.BatchNorm3d(planes)
         self.conv2 = nn.Conv3d(planes, planes, (1, 3, 3), stride=(1, stride, stride), padding=(0, 1, 1), bias=False)
@@ -32,23 +57,24 @@ class Bottleneck3d(nn.Module):
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
-        return self.relu(out + idt)
+        out = self.relu(out + idt)
+        return out if self.nonlocal_block is None else self.nonlocal_block(out)
 
 
-def _stage(inplanes, planes, blocks, stride, head_t_of):
+def _stage(inplanes, planes, blocks, stride, head_t_of, nl_of=lambda b: False):
     layers = []
     for b in range(blocks):
         s = stride if b == 0 else 1
         ds = None
         if s != 1 or inplanes != planes * 4:
             ds = nn.Sequential(nn.Conv3d(inplanes, planes * 4, 1, stride=(1, s, s), bias=False), nn.BatchNorm3d(planes * 4))
-        layers.append(Bottleneck3d(inplanes, planes, s, head_t_of(b), ds))
+        layers.append(Bottleneck3d(inplanes, planes, s, head_t_of(b), ds, nl_of(b)))
         inplanes = planes * 4
     return nn.Sequential(*layers), inplanes
 
 
 class I3DResNet(nn.Module):
-    def __init__(self, layers=(3, 4, 6, 3), width=64, inflate=((1, 1, 1), (1, 0, 1, 0), (1, 0, 1, 0, 1, 0), (0, 1, 0))):
+    def __init__(self, layers=(3, 4, 6, 3), width=64, inflate=((1, 1, 1), (1, 0, 1, 0), (1, 0, 1, 0, 1, 0), (0, 1, 0)), nonlocal_freq=None):
         super().__init__()
         self.conv1 = nn.Conv3d(3, width, (5, 7, 7), stride=(2, 2, 2), padding=(2, 3, 3), bias=False)
         self.bn1 = nn.BatchNorm3d(width)
@@ -58,8 +84,10 @@ class I3DResNet(nn.Module):
         stages, inplanes = [], width
         for li, nb in enumerate(layers):
             infl = inflate[li]
+            nl = nonlocal_freq[li] if nonlocal_freq is not None and li < len(nonlocal_freq) else ()
             st, inplanes = _stage(inplanes, width * 2 ** li, nb, 1 if li == 0 else 2,
-                                  lambda b, infl=infl: 3 if infl[b % len(infl)] else 1)
+                                  lambda b, infl=infl: 3 if infl[b % len(infl)] else 1,
+                                  lambda b, nl=nl: bool(b < len(nl) and nl[b]))
             stages.append(st)
         self.res_layers = nn.Sequential(*stages)
 
@@ -182,10 +210,12 @@ def make(model_type: str, tiny: bool, full: bool = False) -> nn.Module:
         if tiny:
             return TPNBackbone((2, 2, 1, 1), 8)
         return TPNBackbone((3, 4, 23, 3) if "101" in model_type else (3, 4, 6, 3))
-    if "i3d" in model_type:
+    if "i3d" in model_type:          # the reference's I3D models are the non-local i3d_nl5 ones (utils.py:9-10); 'i3d_plain_*' are not
+        from i2v_amd.graphs import NL5_FREQ, TINY_NL_FREQ
+        plain = "plain" in model_type
         if tiny:
-            return I3DResNet((2, 2, 1, 1), 8, inflate=((1, 1), (1, 0), (1,), (0,)))
-        return I3DResNet((3, 4, 23, 3) if "101" in model_type else (3, 4, 6, 3))
+            return I3DResNet((2, 2, 1, 1), 8, inflate=((1, 1), (1, 0), (1,), (0,)), nonlocal_freq=None if plain else TINY_NL_FREQ)
+        return I3DResNet((3, 4, 23, 3) if "101" in model_type else (3, 4, 6, 3), nonlocal_freq=None if plain else NL5_FREQ)
     if tiny:
         return SlowFastRes2(16, slow_stride=4, fast_stride=1, beta_inv=4, blocks=2)
     return SlowFastRes2(slow_stride=8, fast_stride=2, fusion_kernel=7)          # the 8x8 configuration the reference names (utils.py:11-12)

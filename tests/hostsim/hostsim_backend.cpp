@@ -628,6 +628,81 @@ int k_tt_grad_mix(const float* grads, float* out, const float* kern, const int* 
     return 0;
 }
 
+static inline const float* act_addr(const I2VActMat& a, int clip, int c, int pos) {
+    const int t = pos / a.HW, r = pos - t * a.HW;
+    return a.p + ((int64_t)clip * a.T + t) * a.nstride + (int64_t)c * a.HW + r;
+}
+
+// the three product forms of the non-local block: one fmaf chain per output element, in k order (what an MFMA chain computes)
+int k_attn_gemm(const I2VAttnGemm& p, i2v_stream_t) {
+    for (int b = 0; b < p.clips; ++b) {
+        const float* Dn = p.Din ? p.Din + (int64_t)b * p.M * p.N : nullptr;
+        if (p.form == 1) {
+            for (int i = 0; i < p.M; ++i) for (int j = 0; j < p.N; ++j) {
+                float acc = 0.f;
+                for (int c = 0; c < p.Cc; ++c) acc = fmaf(*act_addr(p.A, b, c, i), *act_addr(p.B, b, c, j), acc);
+                volatile float v = p.scale == 1.f ? acc : p.scale * acc;
+                p.D[((int64_t)b * p.M + i) * p.N + j] = v;
+            }
+        } else {
+            const int cols = p.form == 2 ? p.M : p.N, K = p.form == 2 ? p.N : p.M;
+            for (int c = 0; c < p.Cc; ++c) for (int x = 0; x < cols; ++x) {
+                float acc = 0.f;
+                for (int k = 0; k < K; ++k)
+                    acc = p.form == 2 ? fmaf(*act_addr(p.A, b, c, k), Dn[(int64_t)x * p.N + k], acc)      // C[c][i] = sum_j A[c][j] D[i][j]
+                                      : fmaf(*act_addr(p.A, b, c, k), Dn[(int64_t)k * p.N + x], acc);      // C[c][j] = sum_i A[c][i] D[i][j]
+                const int tt = x / p.C_HW, rr = x - tt * p.C_HW;
+                float* o = p.Cact + ((int64_t)b * p.C_T + tt) * p.C_nstride + (int64_t)c * p.C_HW + rr;
+                volatile float v = p.accumulate ? *o + acc : acc;
+                *o = v;
+            }
+        }
+    }
+    return 0;
+}
+
+// row softmax / its backward with the device's summation order: thread t owns columns t, t + 256, ...; a wave's 64 partial sums
+// are folded by shuffles (offsets 32, 16, ... 1), then the four wave values are added pairwise
+static float block_sum256(const std::vector<float>& part) {
+    float w[4];
+    for (int wv = 0; wv < 4; ++wv) {
+        float v[64];
+        for (int l = 0; l < 64; ++l) v[l] = part[wv * 64 + l];
+        for (int o = 32; o > 0; o >>= 1) for (int l = 0; l < 64; ++l) { volatile float t = v[l] + (l + o < 64 ? v[l + o] : v[l]); v[l] = t; }
+        w[wv] = v[0];
+    }
+    volatile float a = w[0] + w[1], b = w[2] + w[3], r = a + b;
+    return r;
+}
+
+int k_softmax_rows(const I2VSoftmaxRows& p, i2v_stream_t) {
+    for (int64_t r = 0; r < p.rows; ++r) {
+        float* x = p.X + r * p.N;
+        std::vector<float> part(256, 0.f);
+        if (p.mode == 0) {
+            float m = -INFINITY;
+            for (int j = 0; j < p.N; ++j) m = std::max(m, x[j]);
+            for (int t = 0; t < 256; ++t) {
+                volatile float s = 0.f;
+                for (int j = t; j < p.N; j += 256) { volatile float d = x[j] - m; const float e = expf(d); x[j] = e; s = s + e; }
+                part[t] = s;
+            }
+            const float tot = block_sum256(part);
+            for (int j = 0; j < p.N; ++j) { volatile float q = x[j] / tot; x[j] = q; }
+        } else {
+            const float* P = p.P + r * p.N;
+            for (int t = 0; t < 256; ++t) {
+                volatile float s = 0.f;
+                for (int j = t; j < p.N; j += 256) { volatile float q = x[j] * P[j]; s = s + q; }
+                part[t] = s;
+            }
+            const float dot = block_sum256(part);
+            for (int j = 0; j < p.N; ++j) { volatile float d = x[j] - dot; volatile float q = P[j] * d; x[j] = q; }
+        }
+    }
+    return 0;
+}
+
 int k_resample_nearest(const float* src, float* dst, int64_t planes, int Hs, int Ws, int Hd, int Wd, const int32_t* my, const int32_t* mx, i2v_stream_t) {
     for (int64_t pl = 0; pl < planes; ++pl)
         for (int y = 0; y < Hd; ++y)

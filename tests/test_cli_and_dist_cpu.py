@@ -147,7 +147,7 @@ def test_image_fine_tune_attack_file_contract(tiny_engine, tmp_path):
     assert ift.main(argv + ["--resume"], model_kwargs=dict(tiny=True)) is None      # nothing left to do
     assert os.path.getmtime(out_dir / "3-adv.npy") == before
     with pytest.raises(KeyError):
-        ift.main(argv[:-2] + ["--white_model", "i3d_nl5_resnet50"])
+        ift.main(argv[:-2] + ["--white_model", "i3d_nl10_resnet50"])          # (not a reference configuration, utils.py:9-14)
 
 
 def test_attack_cli_feeds_fine_tune(tiny_engine, tmp_path, monkeypatch):

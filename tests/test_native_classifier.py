@@ -73,7 +73,14 @@ def check_attacks(eng, dev, model_type="i3d_resnet50"):
 
         def forward(self, x):
             return self.net(x).float()
-    for cls, kw in ((sign_attacks.FGSM, {}), (sign_attacks.BIM, dict(steps=3)), (sign_attacks.MIFGSM, dict(steps=3))):
+    # The I3D graphs carry non-local blocks (the reference's i3d_nl5): with SYNTHETIC weights their un-normalised softmax attention
+    # saturates, and after two eps/3 steps the loss surface is chaotic -- measured on this clip: two float64 evaluations whose
+    # inputs differ in 0.008 % of the pixels have gradients of max 49 vs 194, while the native gradient at the SAME point agrees
+    # with float64 autograd in 99.999 % of the signs (float32 torch: the same).  So the free-running comparison runs two steps
+    # there, and the third step is checked teacher-forced (both paths from the torch path's clip).
+    nl = "i3d" in model_type and "plain" not in model_type
+    ns = 2 if nl else 3
+    for cls, kw in ((sign_attacks.FGSM, {}), (sign_attacks.BIM, dict(steps=ns)), (sign_attacks.MIFGSM, dict(steps=ns))):
         a = cls(m, engine=eng, **kw)(vid.to(dev), labels).cpu()
         r = cls(F32(ref).to(dev), engine=eng, **kw)(vid.clone().to(dev), labels).cpu()     # the module lives where the engine does
         assert a.shape == vid.shape
@@ -81,6 +88,12 @@ def check_attacks(eng, dev, model_type="i3d_resnet50"):
         assert agree > 0.97, (cls.__name__, agree)
         un = a * torch.tensor(sign_attacks.STD).view(1, 3, 1, 1, 1) + torch.tensor(sign_attacks.MEAN).view(1, 3, 1, 1, 1)
         assert un.min() >= -1e-5 and un.max() <= 1 + 1e-5
+    if nl:      # teacher-forced third step: the gradient at the torch path's two-step clip, native vs float64 autograd
+        r2 = sign_attacks.BIM(F32(ref).to(dev), engine=eng, steps=2)(vid.clone().to(dev), labels).cpu()
+        g = sign_attacks.BIM(m, steps=1, engine=eng)._grad(r2.clone().to(dev), labels).cpu().double()
+        x = r2.double().requires_grad_(True)
+        gref = torch.autograd.grad(torch.nn.CrossEntropyLoss()(ref.eval()(x), labels), x)[0]
+        assert float((torch.sign(g) == torch.sign(gref)).float().mean()) > 0.999
 
 
 MODELS = ["i3d_resnet50", "slowfast_resnet50"]
@@ -208,7 +221,7 @@ def test_evaluator_with_the_native_factory(tmp_path, monkeypatch):
         np.save(tmp_path / f"{int(pred[k]) if k < 3 else (int(pred[k]) + 1) % K}-adv-{k}.npy", clips[k].numpy())
     monkeypatch.setattr(evaluator, "native", functools.partial(evaluator.native, num_classes=K, in_thw=thw, weight_seed=3, tiny=True))
     acc = evaluator.main(["--adv_path", str(tmp_path), "--model_factory", "native", "--models", "i3d_resnet50", "--batch_size", "3"])
-    assert abs(acc["i3d_resnet50"] - 75.0) < 1e-6            # three clips carry their own arg-max as the label, one does not
+    assert abs(acc["i3d_resnet50"] - 75.0) < 1e-4            # three clips carry their own arg-max as the label, one does not
     with pytest.raises(KeyError):
         evaluator.native("tpn_resnet50")
 

@@ -65,8 +65,11 @@ def check_native(eng, dev, model_type):
     vid = torch.randn(1, 3, *thw, generator=torch.Generator().manual_seed(13)) * 0.5
     labels = torch.tensor([3])
     params = {"kernlen": 5, "momentum": True, "weight": 0.5, "move_type": "adj", "kernel_mode": "linear"}
-    a = va.TemporalTranslation(m, dict(params), steps=2, engine=eng)(vid.to(dev), labels).cpu()
-    r = va.TemporalTranslation(F32(ref).to(dev), dict(params), steps=2, engine=eng)(vid.clone().to(dev), labels).cpu()
+    # (the I3D graphs carry the reference's non-local blocks: with synthetic weights their saturated attention makes the SECOND eps/2
+    # step chaotic -- tests/test_native_classifier.py:check_attacks has the measurement -- so that model takes one step here)
+    ns = 1 if ("i3d" in model_type and "plain" not in model_type) else 2
+    a = va.TemporalTranslation(m, dict(params), steps=ns, engine=eng)(vid.to(dev), labels).cpu()
+    r = va.TemporalTranslation(F32(ref).to(dev), dict(params), steps=ns, engine=eng)(vid.clone().to(dev), labels).cpu()
     # the mix of D shifted gradients cancels more often than a single gradient: a few % of the pixels have a mixed gradient whose SIGN fp32
     # and float64 backbones decide differently (BIM alone: > 97 %, tests/test_native_classifier.py)
     assert a.shape == vid.shape and float(((a - r).abs() < 1e-5).float().mean()) > 0.94
@@ -74,7 +77,7 @@ def check_native(eng, dev, model_type):
     assert un.min() >= -1e-5 and un.max() <= 1 + 1e-5 and not torch.equal(a, vid)
 
 
-@pytest.mark.parametrize("model_type", ["i3d_resnet50", "slowfast_resnet50"])
+@pytest.mark.parametrize("model_type", ["i3d_resnet50", "i3d_plain_resnet50", "slowfast_resnet50"])
 def test_temporal_translation_native_classifier_hostsim(model_type):
     from tests.hostsim_util import hostsim_engine
     check_native(hostsim_engine(), "cpu", model_type)

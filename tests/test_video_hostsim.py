@@ -42,7 +42,8 @@ def test_video_backbone_forward_backward(model_type, thw):
         assert net.hook_frames(i, b * T) == f.shape[0]
         got = net.save_hook(i, f.shape[0]).double()
         assert got.shape == f.shape
-        assert torch.allclose(got, f, rtol=1e-4, atol=1e-5), (i, (got - f).abs().max())
+        # (absolute part relative to the tensor's scale: behind a non-local block with synthetic weights the features reach +-50)
+        assert torch.allclose(got, f, rtol=1e-4, atol=1e-5 * max(1.0, float(f.abs().max()))), (i, (got - f).abs().max())
     hg = [torch.randn_like(f) for f in feats]
     cost = sum((f * h).sum() for f, h in zip(feats, hg))       # autograd applies the hooks' own ReLU gates
     ref = vm.to_frames(torch.autograd.grad(cost, x)[0])
@@ -50,13 +51,14 @@ def test_video_backbone_forward_backward(model_type, thw):
     gx = torch.empty(b * T, 3, thw[1], thw[2])
     net.backward(gx)
     err = (gx.double() - ref).abs().max() / ref.abs().max()
-    assert err < 1e-4, err
+    assert err < (3e-4 if "i3d" in model_type else 1e-4), err        # (i3d: softmax attention of the non-local blocks in float32)
     gx2 = gx.clone()
     net.backward(gx2, accumulate=True)
     assert torch.allclose(gx2, 2 * gx, rtol=1e-5, atol=1e-6 * float(gx.abs().max()))   # two stems: (gx+g1)+g2 vs 2(g1+g2)
     # a smaller batch than planned (whole clips only)
     net.forward(vm.to_frames(x.detach()[:1]).float())
-    assert torch.allclose(net.save_hook(0, ffeat[0].shape[0] // b).double(), ffeat[0][: ffeat[0].shape[0] // b], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(net.save_hook(0, ffeat[0].shape[0] // b).double(), ffeat[0][: ffeat[0].shape[0] // b], rtol=1e-4,
+                          atol=1e-5 * max(1.0, float(ffeat[0].abs().max())))
     from i2v_amd.lib import I2VError
     with pytest.raises(I2VError):
         net.forward(torch.zeros(T + 1, 3, thw[1], thw[2]))           # not a whole number of clips
@@ -169,7 +171,9 @@ def test_ilaf_kernels_against_autograd():
     ad = a.double().requires_grad_(True)
     d, d0 = ad - ori.double(), (adv0 - ori).double()
     ref_loss = -(0.5 * d.norm() / d0.norm() + (d0 / d0.norm() * d / d.norm()).sum())
-    gref = torch.autograd.grad(ref_loss, ad)[0] * (a > 0)            # the hook is a ReLU output
+    gref = torch.autograd.grad(ref_loss, ad)[0]
+    if hi.post_relu:                                                  # a hooked ReLU output gates its own gradient (the I3D hook, a
+        gref = gref * (a > 0)                                         # non-local block's output, is not one)
     assert abs(float(loss) - float(ref_loss.detach())) < 1e-5 * abs(float(ref_loss.detach()))
     import ctypes
     got = torch.empty_like(a)

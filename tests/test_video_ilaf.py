@@ -86,7 +86,8 @@ def test_native_first_step_follows_reference_gradient_sign(name):
 
 def test_video_model_errors():
     with pytest.raises(KeyError):
-        video.VideoModel("i3d_nl5_resnet50")
+        video.VideoModel("i3d_nl10_resnet50")          # (the reference names i3d_nl5 only, utils.py:9-10)
+    assert video.VideoModel("i3d_nl5_resnet50").graph_for((32, 224, 224)).arch == video.VideoModel("i3d_resnet50").graph_for((32, 224, 224)).arch
     m = video.VideoModel("i3d_resnet50", (8, 32, 32), tiny=True)
     assert m.cuda() is m and m.eval() is m
 
