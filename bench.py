@@ -59,7 +59,7 @@ def build_id():
     return h.hexdigest()[:16]
 
 
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2_traffic_by_instantiation.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r3_traffic_by_instantiation.json")
 PMC_MFMA_BUSY = None      # MFMA-busy fraction of the conv launches from the same PMC summary (same build-id rule as the traffic)
 
 
@@ -72,7 +72,7 @@ def measured_traffic():
         with open(TRAFFIC_JSON) as fh:
             t = json.load(fh)
         if t.get("build_id") != build_id():
-            return None, f"profiles/r2_traffic_by_instantiation.json is from build {t.get('build_id')}, running {build_id()}"
+            return None, f"profiles/r3_traffic_by_instantiation.json is from build {t.get('build_id')}, running {build_id()}"
         global PMC_MFMA_BUSY
         PMC_MFMA_BUSY = t["conv_igemm"].get("mfma_busy_frac")
         return round(t["conv_igemm"]["hbm_bytes_per_launch"]), None
@@ -438,6 +438,22 @@ def run_rank(args):
                            "unit": "adversarial frames/s", "ms_per_step": round(1e3 * el2 / args.steps, 3),
                            "note": "same K steps, no per-launch events, batch cut into concurrent clip lanes (bit-identical output)"}
 
+    # the reference CLI's default `--batch_size 1` (image_main.py:22; BASELINE.json configs[0] shape): one clip per call, product
+    # default lanes (a single clip is cut along its frames), after the headline regions -- an extra field, never `value`
+    single_clip = None
+    if args.workload == "i2v" and b > 1:
+        atk.clip_lanes = None
+        v1 = videos[:1].contiguous()
+        atk(v1, labels[:1], names[:1])           # plans the 32-frame nets
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = max(3, args.steps)
+        for _ in range(reps):
+            atk(v1, labels[:1], names[:1])
+        torch.cuda.synchronize()
+        el1 = time.perf_counter() - t1
+        single_clip = {"value": round(reps * FRAMES / el1, 2), "unit": "adversarial frames/s", "ms_per_clip": round(1e3 * el1 / reps, 3),
+                       "clip_lanes": atk._lane_count(1, FRAMES), "note": "one 32-frame clip per call (the reference CLI's default batch), this rank only"}
     n_lanes = len(lanes) if args.workload == "ilaf" else 1
     frames_total = args.steps * b * FRAMES * world * n_lanes
     value = frames_total / elapsed
@@ -480,7 +496,7 @@ def run_rank(args):
                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                            "traffic": traffic,
-                           "traffic_unit": "B per launch (rocprofv3 PMC passes of this build: 2*FETCH_SIZE + WRITE_SIZE, profiles/r2_traffic_by_instantiation.json)",
+                           "traffic_unit": "B per launch (rocprofv3 PMC passes of this build: 2*FETCH_SIZE + WRITE_SIZE, profiles/r3_traffic_by_instantiation.json)",
                            "launches": int(c["launches"]), "avg_launch_us": round(1e3 * c["ms"] / c["launches"], 2),
                            "avg_gflop_per_launch": round(c["flops"] / c["launches"] / 1e9, 3),
                            "algorithmic_bytes_per_launch": round(c["bytes"] / c["launches"]),
@@ -529,6 +545,8 @@ def run_rank(args):
                               "autotuning of every convolution launch); paid once per (backbone, resolution, max batch), never inside a timed region"}
     if product_default is not None:
         out["product_default"] = product_default
+    if single_clip is not None:
+        out["single_clip"] = single_clip
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.workload == "i2v":
             out["cpu_baseline"] = cpu_baseline()

@@ -125,6 +125,12 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 #ifndef I2V_PRIO_LEVELS      // progress-ordered wave priority in the K loop (conv_tile, chunk_body): highest level; 0 = off
 #define I2V_PRIO_LEVELS 3
 #endif
+#ifndef I2V_DEEP             // deeper-prefetch K loop for the short-K HBM-bound pointwise launches (conv_tile, DEEP)
+#define I2V_DEEP 1
+#endif
+#ifndef I2V_DEEP_STAGES      // LDS buffers of that loop: 3 = two chunks ahead at the two-buffer loop's residency (24 KB, 6 blocks)
+#define I2V_DEEP_STAGES 3
+#endif
 #ifndef I2V_SMALL_WPE
 #define I2V_SMALL_WPE 7
 #endif
@@ -140,14 +146,16 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 #ifndef I2V_BIG_WPE
 #define I2V_BIG_WPE 3
 #endif
-static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi) {
-    return (BD == 64 && BP == 64) ? (PREF ? I2V_PREF_WPE : I2V_SMALL_WPE) : (BD == 128 && BP == 64) ? I2V_TALL_WPE : BD * BP == 8192 ? I2V_MID_WPE : BD * BP == 16384 ? I2V_BIG_WPE : (hi ? 8 : 1);
+static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi, int MODE = 0) {
+    return (BD == 64 && BP == 64) ? (PREF ? (I2V_DEEP && MODE == 1 && I2V_DEEP_STAGES > 3 ? 4 /* 32 KB of LDS: the 5th block does not fit beside the runtime's own */ : I2V_PREF_WPE) : I2V_SMALL_WPE) : (BD == 128 && BP == 64) ? I2V_TALL_WPE : BD * BP == 8192 ? I2V_MID_WPE : BD * BP == 16384 ? I2V_BIG_WPE : (hi ? 8 : 1);
 }
-#define I2V_CONV_WPE __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(BD, BP, PREF, false), conv_waves_per_simd(BD, BP, PREF, true))))
-// LDS floats one tile needs: operand staging [2][KC][BD] + [2][KC][BP], re-used by the epilogue as a [WD*FR][BP] transpose buffer
-template <int BD, int BP, int WD, bool MF16>
+#define I2V_CONV_WPE __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(BD, BP, PREF, false, MODE), conv_waves_per_simd(BD, BP, PREF, true, MODE))))
+// The pointwise variant with prefetched epilogue operands (short K, HBM-bound) stages four chunks instead of two (conv_tile, DEEP)
+static constexpr bool conv_deep(int MODE, bool PREF) { return I2V_DEEP && PREF && MODE == 1; }
+// LDS floats one tile needs: operand staging [NST][KC][BD] + [NST][KC][BP], re-used by the epilogue as a [WD*FR][BP] transpose buffer
+template <int BD, int BP, int WD, bool MF16, int NST = 2>
 constexpr int conv_lds_floats() {
-    constexpr int stage = 2 * I2V_KC * (BD + BP), epi = WD * (MF16 ? 16 : 32) * BP;
+    constexpr int stage = NST * I2V_KC * (BD + BP), epi = WD * (MF16 ? 16 : 32) * BP;
     return stage > epi ? stage : epi;
 }
 
@@ -171,7 +179,10 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     static_assert(!(MF16 && (PRE || PREF)), "no pre-activation / prefetch variants of the 16x16 tile");
     // one LDS array: operand staging [NST][KC][BD] + [NST][KC][BP], re-used by the epilogue as a
     // [WD*32][BP] transpose buffer
-    constexpr int NST = 2;      // LDS operand buffers: chunk c is consumed while chunk c+1 is in flight
+    // LDS operand buffers: chunk c is consumed while chunk c+1 is in flight -- or, for the short-K HBM-bound pointwise launches
+    // (DEEP, see the main loop), while chunks c+1 .. c+3 are
+    constexpr bool DEEP = conv_deep(MODE, PREF);
+    constexpr int NST = DEEP ? I2V_DEEP_STAGES : 2, AHEAD = NST - 1;
     // MODE 5 ("halo"): a 3x3 / stride-1 / pad-1 launch on planes exactly HWM wide stages, per 16-channel group, ONE halo row per
     // channel -- the tile's 64 pixels plus a source row and a pixel on either side -- instead of nine shifted copies of the tile
     constexpr bool HALO = MODE == 5;
@@ -479,8 +490,8 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
             e_next = load_kentry(p.ktab, nchunks > 1 ? KC : 0);
         }
         (void)vb0;
-        if (nchunks > 0) {
-            [&]<int... J>(std::integer_sequence<int, J...>) { (([&] { I2V_ISSUE_PIECE(J, 0, 0, vb0); }()), ...); }
+        for (int c0 = 0; c0 < AHEAD && c0 < nchunks; ++c0) {
+            [&]<int... J>(std::integer_sequence<int, J...>) { (([&] { I2V_ISSUE_PIECE(J, c0 * KC, c0, vb0); }()), ...); }
             (std::make_integer_sequence<int, NL>{});
         }
     }
@@ -494,15 +505,29 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     // their time is the epilogue's memory traffic, and four steps over 4-8 chunks only reorder it).  Arbitration only: the
     // arithmetic is untouched.  Measured per shape (same binary otherwise): +1..2 %; with the tail split, whose quarter tiles
     // run ABOVE these levels (conv_igemm_tail), layer3 3x3 117.5 -> 124.1 TFLOP/s, layer3 reduce 120.4 -> 125.1.
-    const int prio_hi = (nchunks >= 16 && !PREF) ? prio_arg : 0;
+    // ... and only for launches that fill the chip several times over (>= 3 blocks per CU): an under-filled launch has nothing to
+    // keep together, and when two clip lanes share the GPU a nearly finished block (level 0) would starve behind the other lane's
+    // fresh ones (single clip, two frame lanes: 495-504 frames/s with the levels everywhere, 507-517 without)
+    const int prio_hi = (nchunks >= 16 && !PREF && nwg >= 3 * 256) ? prio_arg : 0;
     int prio_lvl = prio_hi, prio_next = 0, prio_step = 0;
     if (prio_hi > 0) {
         prio_step = (nchunks + prio_hi) / (prio_hi + 1); prio_next = prio_step;
         if (prio_hi >= 3) __builtin_amdgcn_s_setprio(3); else if (prio_hi == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
     }
+    // DEEP (round 3; the pointwise variant with prefetched epilogue operands, i.e. K <= 256 and HBM-bound): four LDS buffers, the
+    // DMA of chunk c+3 issued during chunk c.  These launches spend their time waiting for memory, not in the matrix pipe: a
+    // 64 -> 256 expand convolution has FOUR chunks of 8 MFMAs (0.2 us) each, and with one chunk in flight every one of them
+    // exposed a full round trip of the saturated memory system (per-block timeline: K loop 4.6 us of a 13 us block).  With three
+    // chunks in flight the loop pays about one round trip in all.  The wait at the top of a chunk counts the DMA instructions of
+    // the YOUNGER chunks that may stay in flight (every wave issues the same NL per chunk; the epilogue prefetch loads are older).
     auto chunk_body = [&](const int c, const int buf, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;                // a chunk c+1 exists: its DMA is issued here
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        constexpr bool MORE = decltype(more_tag)::value;                // a chunk c+AHEAD exists: its DMA is issued here
+        if constexpr (DEEP) {
+            const int younger = nchunks - 1 - c < AHEAD - 1 ? nchunks - 1 - c : AHEAD - 1;      // chunks behind c already issued
+            if (NST > 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (prio_hi > 0 && c == prio_next) {
@@ -560,7 +585,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
                     [&]<int... Q>(std::integer_sequence<int, Q...>) {
                         (([&] {
                             constexpr int jp = s * PPS + Q;
-                            if constexpr (jp < NL) I2V_ISSUE_PIECE(jp, (c + 1) * KC, buf ^ 1, vb);
+                            if constexpr (jp < NL) I2V_ISSUE_PIECE(jp, (c + AHEAD) * KC, DEEP ? (buf + AHEAD) % NST : (buf ^ 1), vb);
                         }()), ...);
                     }(std::make_integer_sequence<int, PPS>{});
                 }
@@ -568,9 +593,9 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         }(std::make_integer_sequence<int, KS>{});
     };
     if constexpr (!HALO) {
-        int buf = 0;
-        for (int c = 0; c + 1 < nchunks; ++c) { chunk_body(c, buf, std::true_type{}); buf ^= 1; }
-        if (nchunks > 0) chunk_body(nchunks - 1, buf, std::false_type{});
+        int c = 0, buf = 0;
+        for (; c + AHEAD < nchunks; ++c) { chunk_body(c, buf, std::true_type{}); buf = buf + 1 == NST ? 0 : buf + 1; }
+        for (; c < nchunks; ++c) { chunk_body(c, buf, std::false_type{}); buf = buf + 1 == NST ? 0 : buf + 1; }
     }
 #undef I2V_ISSUE_PIECE
 #undef I2V_CHUNK_VB
@@ -780,7 +805,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
 
 template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false>
 __global__ void __launch_bounds__(256) I2V_CONV_WPE conv_igemm(const I2VConvParams p, const int n_cd_tiles) {
-    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<BD, BP, WD, MF16>()];
+    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<BD, BP, WD, MF16, conv_deep(MODE, PREF) ? I2V_DEEP_STAGES : 2>()];
     I2V_PROBE_T probe;
     probe.entry();
     conv_tile<BD, BP, WD, WP, MODE, PREF, PRE, VID, MF16>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x);

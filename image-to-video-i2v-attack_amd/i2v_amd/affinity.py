@@ -71,6 +71,11 @@ def plan(local_rank: int, local_world: int, nodes: Sequence[Sequence[int]]) -> L
     return cores[lo:hi]
 
 
+#: the cores this process was allowed when the module was first imported: repeated calls plan from THESE, never from an already
+#: narrowed mask (a second call would otherwise halve the first call's share)
+_INITIAL = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+
+
 def pin_rank(local_rank: Optional[int] = None, local_world: Optional[int] = None) -> Optional[Dict]:
     """Restrict this process to its share of the cores; returns {"cores": n, "first": c0, "last": c1, "nodes": k} or None when
     nothing was done (single rank, `I2V_PIN_CPUS=0`, a platform without sched_setaffinity)."""
@@ -82,7 +87,7 @@ def pin_rank(local_rank: Optional[int] = None, local_world: Optional[int] = None
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
-    allowed = sorted(os.sched_getaffinity(0))
+    allowed = _INITIAL or sorted(os.sched_getaffinity(0))
     nodes = numa_nodes(allowed)
     mine = plan(local_rank, local_world, nodes)
     if not mine:

@@ -118,12 +118,14 @@ def load():
     """Open the gfx950 library or fail loudly -- there is no CPU path in the product."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise I2VError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+        # $I2V_LIB: another BUILD of the same gfx950 library (developer A/B of compile-time kernel switches); it must still answer hip:gfx950
+        path = os.environ.get("I2V_LIB") or LIB_PATH
+        if not os.path.exists(path):
+            raise I2VError(f"{path} not found: build it with `python __graft_entry__.py` "
                            "(hipcc --offload-arch=gfx950); the attack engine has no CPU fallback")
-        lib = bind(C.CDLL(LIB_PATH))
+        lib = bind(C.CDLL(path))
         if lib.i2v_backend() != HIP_BACKEND:
-            raise I2VError(f"{LIB_PATH} reports backend {lib.i2v_backend()!r}, expected {HIP_BACKEND!r}")
+            raise I2VError(f"{path} reports backend {lib.i2v_backend()!r}, expected {HIP_BACKEND!r}")
         _lib = lib
     return _lib
 

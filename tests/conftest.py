@@ -14,6 +14,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # uses when asked to (i2v_amd/weights.py)
 os.environ.setdefault("I2V_SYNTHETIC_WEIGHTS", "1")
 os.environ.setdefault("I2V_QUIET_WEIGHTS", "1")
+# the CLIs pin their process to its rank's CPU cores (i2v_amd/affinity.py); tests call their main() IN this process, sometimes with
+# WORLD_SIZE set -- the test process itself must keep all its cores (the subprocess tests that check the pinning ask for it)
+os.environ["I2V_PIN_CPUS"] = "0"
 
 
 def pytest_configure(config):

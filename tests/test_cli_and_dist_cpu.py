@@ -381,7 +381,7 @@ def _bench(args, env=None):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ, I2V_QUIET_WEIGHTS="1", **(env or {}))
+    e = dict(os.environ, I2V_QUIET_WEIGHTS="1", I2V_PIN_CPUS="1", **(env or {}))
     for k in ("RANK", "WORLD_SIZE", "MASTER_PORT", "LOCAL_RANK"):
         e.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, env=e, timeout=600)
