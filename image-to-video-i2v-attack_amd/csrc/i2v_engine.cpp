@@ -903,6 +903,14 @@ struct Planner {
                     if (B) l.ag.B = *B;
                     l.ag.D = D; l.ag.Din = Din;
                     if (out) { l.ag.Cact = out->p; l.ag.C_nstride = out->nstride; l.ag.C_T = out->T; l.ag.C_HW = out->H * out->W; }
+                    // few output tiles per clip under a long reduction (dg, dphi: Cc x N outputs summed over the M positions): cut K.
+                    // The cut depends on the clip's own shape only, so a clip's result does not depend on the batch it is in.
+                    const int cols = form == 2 ? M : Nn, K = form == 2 ? Nn : M;
+                    const int tiles = ((th.C + 63) / 64) * ((cols + 63) / 64);
+                    if (form != 1 && tiles <= 128 && K >= 512) {
+                        l.ag.ksplit = std::min(8, K / 256);
+                        l.ag.part = temp(nf(th.T) / th.T * (size_t)l.ag.ksplit * th.C * cols);
+                    }
                     emit(n.bwd, l);
                 };
                 const I2VActMat gA = act(gv);
@@ -1167,6 +1175,11 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
             if (q.gate) b += out / 8.0;
             if (q.gate_out) b += out / 8.0;
             tl->bytes = b;
+        }
+        if (tl && l.kind == L_AGEMM) {                  // (dump fields: channels, reduction length, output columns, 10 + product form)
+            const I2VAttnGemm& q = l.ag;
+            tl->Cd = q.Cc; tl->K = q.form == 1 ? q.Cc : (q.form == 2 ? q.N : q.M); tl->HWg = q.form == 2 ? q.M : q.N; tl->frames = frames; tl->pw = 10 + q.form;
+            tl->bytes = 4.0 * clips * ((double)q.M * q.N + (double)q.Cc * q.M + (double)q.Cc * q.N);
         }
         struct Stop { TimedLaunch* t; i2v_stream_t s; ~Stop() { if (t) be_event_record(t->stop, s); } } stop{tl, s};
         switch (l.kind) {

@@ -1875,7 +1875,7 @@ int k_tt_grad_mix(const float* grads, float* out, const float* kern, const int* 
 // =============================================================================================
 // Non-local block core (gluoncv `i3d_nl5_*`; I2VAttnGemm / I2VSoftmaxRows): three product forms between frame-major activation
 // views and a dense per-clip matrix, and the row softmax / its backward.  64 x 64 output tiles, 4 waves of 32 x 32 on
-// v_mfma_f32_32x32x2_f32, K in chunks of 16 through double-buffered LDS in the canonical [k][m] image (operands whose K axis is
+// v_mfma_f32_32x32x2_f32, K in chunks of 32 through double-buffered LDS in the canonical [k][m] image (operands whose K axis is
 // the contiguous one are transposed while they are written), register-staged prefetch.  Every output element is ONE k-ordered fmaf
 // chain computed by one block: no split K, no atomics.  The blocks cost ~15 % of the FLOPs of the stage they sit in, so the
 // kernel is kept simple (plain loads, no DMA staging).
@@ -1894,52 +1894,78 @@ __device__ __forceinline__ float4 load4_guard(const float* p, int lim, bool vec_
     if (lim > 3) v.w = p[3];
     return v;
 }
+// the same along the POSITION axis of a frame-major activation view: positions are contiguous inside a frame only, so without
+// the vector path (HW % 4 == 0 keeps an aligned group of four inside one frame) every element takes its own address
+__device__ __forceinline__ float4 load4_act(const I2VActMat& a, int clip, int c, int pos, int lim, bool vec_ok) {
+    if (lim >= 4 && vec_ok) return *reinterpret_cast<const float4*>(act_addr(a, clip, c, pos));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lim > 0) v.x = *act_addr(a, clip, c, pos);
+    if (lim > 1) v.y = *act_addr(a, clip, c, pos + 1);
+    if (lim > 2) v.z = *act_addr(a, clip, c, pos + 2);
+    if (lim > 3) v.w = *act_addr(a, clip, c, pos + 3);
+    return v;
+}
 template <int FORM>
 __global__ void __launch_bounds__(256) attn_gemm_kernel(const I2VAttnGemm p) {
-    constexpr int KC = 16;
-    __shared__ __attribute__((aligned(16))) float Ls[2][KC][64], Rs[2][KC][64];
+    // LDS images [k][m]; an operand whose K axis is the contiguous one in memory is transposed while it is written: row stride 66
+    // (66 % 32 = 2: the four k-quads x eight rows of a 32-lane write group land on 32 different banks; with 64 they were 4-way
+    // conflicts that kept the LDS busier than the matrix pipe), 64 (16-byte rows for ds_write_b128) for the K-major ones
+    constexpr int KC = 32, LS = FORM == 1 ? 64 : 66, RS = FORM == 2 ? 66 : 64;
+    __shared__ __attribute__((aligned(16))) float Ls[2][KC][LS], Rs[2][KC][RS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wd = wave >> 1, wp = wave & 1, l31 = lane & 31, lk = lane >> 5;
     // output tile: rows m0.. (form 1: i; forms 2, 3: channel), columns n0.. (form 1: j; form 2: i; form 3: j), reduction K
-    const int ROWS = FORM == 1 ? p.M : p.Cc, COLS = FORM == 2 ? p.M : p.N, K = FORM == 1 ? p.Cc : (FORM == 2 ? p.N : p.M);
+    const int ROWS = FORM == 1 ? p.M : p.Cc, COLS = FORM == 2 ? p.M : p.N, KFULL = FORM == 1 ? p.Cc : (FORM == 2 ? p.N : p.M);
+    // this block's K segment [KBEG, K)
+    const int split = (FORM != 1 && p.ksplit > 1) ? p.ksplit : 1, kseg = attn_kseg(KFULL, split);
+    const int KBEG = min((int)blockIdx.z * kseg, KFULL), K = min(KBEG + kseg, KFULL);
     const int tiles_n = (COLS + 63) / 64;
     const int clip = blockIdx.y, m0 = (blockIdx.x / tiles_n) * 64, n0 = (blockIdx.x % tiles_n) * 64;
     const float* Dn = p.Din ? p.Din + (int64_t)clip * p.M * p.N : nullptr;
     const bool a_vec = (p.A.HW % 4 == 0) && (p.A.nstride % 4 == 0) && (((uintptr_t)p.A.p & 15) == 0);
     const bool b_vec = FORM == 1 && (p.B.HW % 4 == 0) && (p.B.nstride % 4 == 0) && (((uintptr_t)p.B.p & 15) == 0);
     const bool d_vec = FORM != 1 && (p.N % 4 == 0) && (((uintptr_t)p.Din & 15) == 0);
-    // thread's share of a chunk: K-major operands: row k = t / 16, 4 columns from (t % 16) * 4; M-major: row m = t / 4, 4 k from (t % 4) * 4
+    // thread's share of a chunk, two pieces h = 0, 1.  K-major operands: row k = t / 16 + 16 h, 4 columns from (t % 16) * 4;
+    // M-major: row m = t / 4, 4 k from (t % 4) * 4 + 16 h
     const int kk = t >> 4, c4 = (t & 15) * 4, mm = t >> 2, k4 = (t & 3) * 4;
-    float4 ra, rb;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ra[2], rb[2];
     auto fetch = [&](const int k0) {
-        if constexpr (FORM == 1) {                 // Lhs[k=c][m=i] = A(c, i), Rhs[k=c][n=j] = B(c, j): both K-major
-            const int c = k0 + kk;
-            ra = (c < K && m0 + c4 < ROWS) ? load4_guard(act_addr(p.A, clip, c, m0 + c4), ROWS - (m0 + c4), a_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb = (c < K && n0 + c4 < COLS) ? load4_guard(act_addr(p.B, clip, c, n0 + c4), COLS - (n0 + c4), b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
-        } else if constexpr (FORM == 2) {          // Lhs[k=j][m=c] = A(c, j) (M-major), Rhs[k=j][n=i] = D[i][j] (M-major)
-            const int c = m0 + mm, j = k0 + k4, i = n0 + mm;
-            ra = (c < ROWS && j < K) ? load4_guard(act_addr(p.A, clip, c, j), K - j, a_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb = (i < COLS && j < K) ? load4_guard(Dn + (int64_t)i * p.N + j, K - j, d_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {                                   // Lhs[k=i][m=c] = A(c, i) (M-major), Rhs[k=i][n=j] = D[i][j] (K-major)
-            const int c = m0 + mm, i = k0 + k4, ik = k0 + kk;
-            ra = (c < ROWS && i < K) ? load4_guard(act_addr(p.A, clip, c, i), K - i, a_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb = (ik < K && n0 + c4 < COLS) ? load4_guard(Dn + (int64_t)ik * p.N + n0 + c4, COLS - (n0 + c4), d_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if constexpr (FORM == 1) {                 // Lhs[k=c][m=i] = A(c, i), Rhs[k=c][n=j] = B(c, j): both K-major
+                const int c = k0 + kk + 16 * h;
+                ra[h] = (c < K && m0 + c4 < ROWS) ? load4_act(p.A, clip, c, m0 + c4, ROWS - (m0 + c4), a_vec) : zero4;
+                rb[h] = (c < K && n0 + c4 < COLS) ? load4_act(p.B, clip, c, n0 + c4, COLS - (n0 + c4), b_vec) : zero4;
+            } else if constexpr (FORM == 2) {          // Lhs[k=j][m=c] = A(c, j) (M-major), Rhs[k=j][n=i] = D[i][j] (M-major)
+                const int c = m0 + mm, j = k0 + k4 + 16 * h, i = n0 + mm;
+                ra[h] = (c < ROWS && j < K) ? load4_act(p.A, clip, c, j, K - j, a_vec) : zero4;
+                rb[h] = (i < COLS && j < K) ? load4_guard(Dn + (int64_t)i * p.N + j, K - j, d_vec) : zero4;
+            } else {                                   // Lhs[k=i][m=c] = A(c, i) (M-major), Rhs[k=i][n=j] = D[i][j] (K-major)
+                const int c = m0 + mm, i = k0 + k4 + 16 * h, ik = k0 + kk + 16 * h;
+                ra[h] = (c < ROWS && i < K) ? load4_act(p.A, clip, c, i, K - i, a_vec) : zero4;
+                rb[h] = (ik < K && n0 + c4 < COLS) ? load4_guard(Dn + (int64_t)ik * p.N + n0 + c4, COLS - (n0 + c4), d_vec) : zero4;
+            }
         }
     };
     auto stash = [&](const int buf) {
-        if constexpr (FORM == 1) *reinterpret_cast<float4*>(&Ls[buf][kk][c4]) = ra;
-        else { Ls[buf][k4][mm] = ra.x; Ls[buf][k4 + 1][mm] = ra.y; Ls[buf][k4 + 2][mm] = ra.z; Ls[buf][k4 + 3][mm] = ra.w; }
-        if constexpr (FORM == 2) { Rs[buf][k4][mm] = rb.x; Rs[buf][k4 + 1][mm] = rb.y; Rs[buf][k4 + 2][mm] = rb.z; Rs[buf][k4 + 3][mm] = rb.w; }
-        else *reinterpret_cast<float4*>(&Rs[buf][kk][c4]) = rb;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kr = kk + 16 * h, kq = k4 + 16 * h;
+            if constexpr (FORM == 1) *reinterpret_cast<float4*>(&Ls[buf][kr][c4]) = ra[h];
+            else { Ls[buf][kq][mm] = ra[h].x; Ls[buf][kq + 1][mm] = ra[h].y; Ls[buf][kq + 2][mm] = ra[h].z; Ls[buf][kq + 3][mm] = ra[h].w; }
+            if constexpr (FORM == 2) { Rs[buf][kq][mm] = rb[h].x; Rs[buf][kq + 1][mm] = rb[h].y; Rs[buf][kq + 2][mm] = rb[h].z; Rs[buf][kq + 3][mm] = rb[h].w; }
+            else *reinterpret_cast<float4*>(&Rs[buf][kr][c4]) = rb[h];
+        }
     };
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int nchunks = (K + KC - 1) / KC;
-    fetch(0); stash(0);
+    const int nchunks = (K - KBEG + KC - 1) / KC;
+    fetch(KBEG); stash(0);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunks) fetch((c + 1) * KC);
+        if (c + 1 < nchunks) fetch(KBEG + (c + 1) * KC);
 #pragma unroll
         for (int s2 = 0; s2 < KC / 2; ++s2)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ls[buf][2 * s2 + lk][wd * 32 + l31], Rs[buf][2 * s2 + lk][wp * 32 + l31], acc, 0, 0, 0);
@@ -1954,6 +1980,7 @@ __global__ void __launch_bounds__(256) attn_gemm_kernel(const I2VAttnGemm p) {
         const int row = m0 + wd * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (row >= ROWS) continue;
         if constexpr (FORM == 1) p.D[((int64_t)clip * p.M + row) * p.N + col] = p.scale == 1.f ? acc[r] : __fmul_rn(p.scale, acc[r]);
+        else if (split > 1) p.part[(((int64_t)clip * split + blockIdx.z) * ROWS + row) * COLS + col] = acc[r];
         else {
             const int tt = col / p.C_HW, rr = col - tt * p.C_HW;
             float* o = p.Cact + ((int64_t)clip * p.C_T + tt) * p.C_nstride + (int64_t)row * p.C_HW + rr;
@@ -1961,14 +1988,35 @@ __global__ void __launch_bounds__(256) attn_gemm_kernel(const I2VAttnGemm p) {
         }
     }
 }
+// the segment sums of a K-split launch, added in segment order
+__global__ void __launch_bounds__(256) attn_split_reduce_kernel(const I2VAttnGemm p, const int COLS) {
+    const int64_t per = (int64_t)p.Cc * COLS, total = per * p.clips;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int clip = (int)(e / per); const int64_t w = e - (int64_t)clip * per;
+        const int row = (int)(w / COLS), col = (int)(w - (int64_t)row * COLS);
+        const float* q = p.part + (int64_t)clip * p.ksplit * per + w;
+        float sum = q[0];
+        for (int z = 1; z < p.ksplit; ++z) sum = __fadd_rn(sum, q[(int64_t)z * per]);
+        const int tt = col / p.C_HW, rr = col - tt * p.C_HW;
+        float* o = p.Cact + ((int64_t)clip * p.C_T + tt) * p.C_nstride + (int64_t)row * p.C_HW + rr;
+        *o = p.accumulate ? __fadd_rn(*o, sum) : sum;
+    }
+}
 int k_attn_gemm(const I2VAttnGemm& p, i2v_stream_t s) {
     const int rows = p.form == 1 ? p.M : p.Cc, cols = p.form == 2 ? p.M : p.N;
     if (rows <= 0 || cols <= 0 || p.clips <= 0) return 0;
-    const dim3 grid((unsigned)(((rows + 63) / 64) * ((cols + 63) / 64)), (unsigned)p.clips);
+    const int split = (p.form != 1 && p.ksplit > 1) ? p.ksplit : 1;
+    if (split > 1 && !p.part) return pool_fail("attn_gemm: a K-split launch needs its scratch");
+    const dim3 grid((unsigned)(((rows + 63) / 64) * ((cols + 63) / 64)), (unsigned)p.clips, (unsigned)split);
     if (p.form == 1) hipLaunchKernelGGL((attn_gemm_kernel<1>), grid, dim3(256), 0, (hipStream_t)s, p);
     else if (p.form == 2) hipLaunchKernelGGL((attn_gemm_kernel<2>), grid, dim3(256), 0, (hipStream_t)s, p);
     else hipLaunchKernelGGL((attn_gemm_kernel<3>), grid, dim3(256), 0, (hipStream_t)s, p);
-    LAUNCH_CHECK("attn_gemm"); return 0;
+    LAUNCH_CHECK("attn_gemm");
+    if (split > 1) {
+        hipLaunchKernelGGL(attn_split_reduce_kernel, dim3(stream_grid((int64_t)p.clips * p.Cc * cols, 1024)), dim3(256), 0, (hipStream_t)s, p, cols);
+        LAUNCH_CHECK("attn_split_reduce");
+    }
+    return 0;
 }
 // one block per row; thread t owns columns t, t + 256, ...; reductions: wave shuffles, then the four wave values in order
 __global__ void __launch_bounds__(256) softmax_rows_kernel(const I2VSoftmaxRows p) {

@@ -153,7 +153,15 @@ struct I2VAttnGemm {
     float* Cact; int64_t C_nstride; int32_t C_T, C_HW;   // forms 2 / 3: the output activation view
     float* D; const float* Din;            // dense matrix: output (form 1) / input (forms 2, 3), [clips][M][N]
     float scale; int32_t accumulate;       // forms 2 / 3: Cact += ...
+    // forms 2 / 3 with few output tiles and a long reduction: the K axis in `ksplit` segments of attn_kseg(K, ksplit) rows, one block
+    // each; segment sums go to part[clips][ksplit][Cc][cols] and are added in segment order (fixed by the shape: deterministic)
+    int32_t ksplit; float* part;
 };
+// rows of one K segment: a whole number of the kernel's 32-row chunks
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline int attn_kseg(int K, int ksplit) { return ksplit <= 1 ? K : ((K + ksplit - 1) / ksplit + 31) / 32 * 32; }
 // row-wise softmax (mode 0: P = softmax(S) in place) and its backward (mode 1: dS = P o (dP - rowsum(dP o P)), in place over dP)
 struct I2VSoftmaxRows { float* X; const float* P; int64_t rows; int32_t N; int32_t mode; };
 

@@ -311,6 +311,107 @@ class SIM(BIM):
         return self._l1_momentum(grad, state) if self.momentum else grad
 
 
+class SGM(BIM):
+    """Skip Gradient Method (`base_attacks.py:481-551`): the gradient passing BACK through a ReLU is multiplied by gamma ** 0.5 at every
+    ReLU module whose qualified name contains 'relu' but not '0.relu' (:511-513: the stem's and those of every residual block but
+    the first of its stage -- and, by the same string test, not the 10th / 20th either).  The attacked classifier is the caller's
+    torch module, as in the reference; the gain is attached once, at construction, as there (:493) -- to the module's OUTPUT gradient
+    (a tensor hook set from a forward hook), which for a ReLU is the same number as the reference's gain on its input gradient
+    (the gate is 0 or 1) and also works on in-place ReLUs.  Update rule: `i2v_sign_step_f32`.  A native `VideoModel` classifier is
+    refused: the planner's 1-bit ReLU gates carry no gain."""
+
+    def __init__(self, model, epsilon=16 / 255, steps=10, decay=1.0, gamma=0.5, momentum=False, engine=None):
+        if isinstance(model, VideoModel):
+            raise NotImplementedError("SGM needs a torch module: the native planner's ReLU gates carry no backward gain")
+        super().__init__(model, epsilon, steps, engine)
+        self.attack = "SGM"
+        self.decay, self.momentum, self.gamma = decay, momentum, gamma
+        gain = float(np.power(self.gamma, 0.5))
+
+        def scale_output_gradient(module, inputs, output):
+            if torch.is_tensor(output) and output.requires_grad:
+                output.register_hook(lambda g: gain * g)
+        self.hooked = []
+        for name, module in model.named_modules():
+            if "relu" in name and "0.relu" not in name and isinstance(module, nn.ReLU):
+                module.register_forward_hook(scale_output_gradient)
+                self.hooked.append(name)
+
+    def _pre(self, grad, state):
+        return self._l1_momentum(grad, state) if self.momentum else grad
+
+
+class TAP(_SignAttack):
+    """Transferable Adversarial Perturbations (`base_attacks.py:685-799`): cost = CE + 1e3 * sum|box-filtered perturbation| + 0.05 *
+    sum over the hooked stages of || sgn(a) sqrt|a| - sgn(a0) sqrt|a0| ||_2 (a: the stage's activation on the adversarial clip, a0:
+    on the clean one), sign step as BIM.  `params` = {'kernlen', 'temporal_kernlen', 'eta', 'conv3d'} become attributes (:699-700);
+    `model_type` has to be among them (the reference reads `self.model_type` in `_find_target_layer` without ever setting it: an
+    AttributeError there, and here).  `eta` is accepted and unused, as there (the weight 1e3 is a literal, :780).  The model is the
+    caller's torch module (forward hooks on its own stages), the update is `i2v_sign_step_f32`.  As in the reference the cost is a
+    (batch,)-vector, so autograd accepts one clip per call only.  `loss_info[step]` holds the three terms (the reference keys
+    the dict with a loop variable its inner loop has rebound to a tensor, :793)."""
+
+    def __init__(self, model, params, epsilon=16 / 255, steps=10, engine=None):
+        if isinstance(model, VideoModel):
+            raise NotImplementedError("TAP needs a torch module (forward hooks on its stages)")
+        super().__init__("TAP", model, engine)
+        self.epsilon, self.steps = epsilon, steps
+        self.step_size = self.epsilon / self.steps
+        for name, value in params.items():
+            setattr(self, name, value)
+        k, kt = int(self.kernlen), int(self.temporal_kernlen)
+        self.box2d = torch.full((3, 1, k, k), 1.0 / (k * k), dtype=torch.float32)            # :713-717, one filter per colour channel
+        self.box3d = torch.full((3, 1, kt, k, k), 1.0 / (kt * k * k), dtype=torch.float32)   # :719-722
+        self._features = []
+        for stage in self._find_target_layer():
+            stage.register_forward_hook(lambda mod, inp, out: self._features.append(out))
+
+    def _find_target_layer(self):
+        m = self.model
+        if "i3d" in self.model_type:
+            return [m.res_layers._modules["0"], m.res_layers._modules["1"]]
+        if "slowfast" in self.model_type:
+            return [m._modules[n] for n in ("slow_res2", "slow_res3", "fast_res2", "fast_res3")]
+        if "tpn" in self.model_type:
+            return [m.layer1, m.layer2]
+
+    def _smoothness(self, perts):
+        k, kt = int(self.kernlen), int(self.temporal_kernlen)
+        if self.conv3d:
+            out = nn.functional.conv3d(perts, self.box3d.to(perts.device), groups=3, stride=1, padding=[(kt - 1) // 2, (k - 1) // 2, (k - 1) // 2])
+        else:                                                               # frame by frame (:724-731); the 2-D filter stays float32
+            out = torch.stack([nn.functional.conv2d(perts[:, :, f], self.box2d.to(perts.device), groups=3, stride=1,
+                                                    padding=[(k - 1) // 2, (k - 1) // 2]) for f in range(perts.shape[2])], 2)
+        return torch.sum(torch.abs(out))
+
+    def forward(self, videos, labels):
+        videos = videos.to(self.device).float().contiguous()
+        labels = labels.to(self.device)
+        b, c, f, h, w = videos.shape
+        self.loss_info = {}
+        self._features = []
+        self.model(videos)
+        clean = self._features
+        root = lambda a: torch.sign(a) * torch.sqrt(torch.abs(a))          # noqa: E731
+        std = torch.as_tensor(self.std, dtype=videos.dtype, device=videos.device)[:, None, None, None]
+        u = self._unnorm(videos)
+        adv = videos.clone().detach()
+        for step in range(self.steps):
+            self._features = []
+            adv.requires_grad = True
+            cost1 = self._targeted * nn.CrossEntropyLoss()(self.model(adv), labels)
+            cost2 = torch.sum(torch.stack([torch.norm(root(a).reshape(b, -1) - root(a0).reshape(b, -1), p=2, dim=1)
+                                           for a, a0 in zip(self._features, clean)]), 0)
+            reg = self._smoothness((adv - videos) / std)                    # (sic) divided by std, `_transform_perts` :138-143
+            cost = cost1 + 1e3 * reg + 0.05 * cost2
+            grad = torch.autograd.grad(cost, adv, retain_graph=False, create_graph=False)[0]
+            self.loss_info[step] = {"ce loss": cost1.detach().cpu().numpy(), "reg_cost": reg.detach().cpu().numpy(),
+                                    "distance": cost2.detach().cpu().numpy()}
+            adv = adv.detach()
+            self.engine.sign_step(adv, u, grad.contiguous(), f * h * w, self.step_size, self.epsilon)
+        return adv
+
+
 def run_concurrent(make_attack, items, streams=2, device=None, on_result=None):
     """Run `attack(*item)` for every item of the iterable `items` on `streams` concurrent clip streams.  Returns
     (results in item order, attack objects); with `on_result(index, item, result)` given, results are handed to it

@@ -180,6 +180,55 @@ def run_sign_family(clip_seed=78, steps=3):
     return dict(clip_u8=u8.numpy(), clip_di_u8=u8_di.numpy(), steps=steps, eps=16 / 255, **out)
 
 
+RESIDUAL_FAMILY = (("SGM", {}), ("SGM", {"momentum": True}), ("SGM", {"gamma": 0.2}),
+                   ("TAP", {"conv3d": True}), ("TAP", {"conv3d": False}))
+
+
+def residual_key(cls, kw):
+    return cls + "".join("_%s%s" % (k[0], str(v)[0]) for k, v in sorted(kw.items()))
+
+
+def run_residual_family(clip_seed=91, steps=3, thw=(8, 32, 32)):
+    """`base_attacks.SGM` (:481-551) and `base_attacks.TAP` (:685-799) through the imported reference classes on the tiny plain-I3D
+    classifier of oracle/video_models.py (`tiny_stage_classifier`: gluoncv's module names, which both classes select their hooks
+    by).  SGM registers its hooks on the model it is given, for good -- every case gets a fresh model.  TAP reads
+    `self.model_type` without setting it: the fixture passes it inside `params`, the only way the class can be constructed."""
+    from oracle import video_models
+    ba = ref_shim.import_reference("base_attacks")
+    u8 = make_clip(clip_seed, 1, thw[0], thw[1])
+    labels = torch.tensor([3])
+    grads = []
+    orig = torch.autograd.grad
+
+    def grad_tap(*a, **k):
+        r = orig(*a, **k)
+        grads.append(r[0].detach().clone())
+        return r
+    out = {}
+    for cls, kw in RESIDUAL_FAMILY:
+        key = residual_key(cls, kw)
+        model = video_models.tiny_stage_classifier(thw=thw)
+        vid = normalise(u8, torch.float32)
+        grads.clear()
+        torch.autograd.grad = grad_tap
+        try:
+            with ref_shim.quiet():
+                if cls == "TAP":
+                    atk = ba.TAP(model, dict(kernlen=3, temporal_kernlen=3, eta=1e3, model_type="i3d_resnet50", **kw), epsilon=16 / 255, steps=steps)
+                else:
+                    atk = ba.SGM(model, epsilon=16 / 255, steps=steps, **kw)
+                adv = atk(vid.clone(), labels)
+        finally:
+            torch.autograd.grad = orig
+        out[key + "_grads"] = torch.stack(grads).numpy()
+        out[key + "_adv"] = adv.detach().numpy()
+        if cls == "TAP":
+            info = list(atk.loss_info.values())           # (keyed by tensors there, :793; insertion order = step order)
+            for term in ("ce loss", "reg_cost", "distance"):
+                out[key + "_" + term.split()[0]] = np.array([np.asarray(i[term], dtype=np.float64).reshape(-1)[0] for i in info])
+    return dict(clip_u8=u8.numpy(), steps=steps, eps=16 / 255, thw=np.array(thw), **out)
+
+
 def make_ilaf_inputs(seed, b, thw, lo, hi, amp):
     """Clean clip with pixels in [lo, hi] + an existing adversarial version of it within +-amp/255 (both
     uint8-quantised).  The f64 cases keep away from 0/255 and from eps so that no clamp mask is decided by the last
@@ -269,7 +318,14 @@ def main():
     np.savez_compressed(os.path.join(OUT, "sign_step.npz"), **run_sign_step())
     print("sign_step ok")
     make_sign_family()
+    make_residual_family()
     make_ilaf()
+
+
+def make_residual_family():
+    path = os.path.join(OUT, "residual_family.npz")
+    np.savez_compressed(path, **run_residual_family())
+    print("residual_family", os.path.getsize(path) // 1024, "KiB")
 
 
 def make_sign_family():
@@ -301,6 +357,8 @@ if __name__ == "__main__":
         make_tf()
     elif sys.argv[1:] == ["sign_family"]:
         make_sign_family()
+    elif sys.argv[1:] == ["residual_family"]:
+        make_residual_family()
     else:
         main()
         make_tf()

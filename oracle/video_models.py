@@ -244,3 +244,37 @@ def to_frames(t: torch.Tensor) -> torch.Tensor:
     """(b, C, T, H, W) -> the engine's frame-major (b*T, C, H, W)."""
     b, c, tt, h, w = t.shape
     return t.permute(0, 2, 1, 3, 4).reshape(b * tt, c, h, w).contiguous()
+
+
+class StageClassifier(nn.Module):
+    """A backbone of this file + global average pool + Linear, shaped like the gluoncv classifiers the reference's white-box attacks
+    take (`attack.py:63-96`): the backbone's stages stay reachable under their gluoncv names ON THE CLASSIFIER itself
+    (`model.res_layers`, `model.slow_res2`, `model.layer1` ...), which is where `base_attacks.TAP._find_target_layer` (:737-743) looks
+    them up, and every ReLU keeps a qualified name ending in `.relu`, which is what `base_attacks.SGM` (:511-513) selects by."""
+
+    def __init__(self, backbone: nn.Module, feat_channels: int, num_classes: int, seed: int = 0):
+        super().__init__()
+        for name, child in backbone.named_children():
+            setattr(self, name, child)
+        self._backbone_forward = backbone.forward
+        self.fc = nn.Linear(feat_channels, num_classes)
+        gen = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            self.fc.weight.copy_(torch.randn(self.fc.weight.shape, generator=gen) * 0.05)
+            self.fc.bias.copy_(torch.randn(self.fc.bias.shape, generator=gen) * 0.05)
+
+    def forward(self, x):
+        f = self._backbone_forward(x)
+        feats = f if isinstance(f, tuple) else (f,)
+        return self.fc(torch.cat([t.mean(dim=(2, 3, 4)) for t in feats], dim=1))
+
+
+def tiny_stage_classifier(model_type="i3d_plain_resnet50", thw=(8, 32, 32), num_classes=5, wseed=4):
+    """The float32 classifier the SGM / TAP fixtures of oracle/make_golden.py and their tests attack (tiny widths, every stage)."""
+    from i2v_amd import graphs, weights
+    g = graphs.build_video_tiny(model_type, thw, full=True)
+    back = load_weights(make(model_type, True, full=True), weights.synthetic_state_dict(g, wseed)).float()
+    with torch.no_grad():
+        c = back(torch.zeros(1, 3, *thw))
+    c = sum(t.shape[1] for t in (c if isinstance(c, tuple) else (c,)))
+    return StageClassifier(back, c, num_classes, wseed).eval()

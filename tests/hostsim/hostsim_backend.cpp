@@ -646,11 +646,17 @@ int k_attn_gemm(const I2VAttnGemm& p, i2v_stream_t) {
             }
         } else {
             const int cols = p.form == 2 ? p.M : p.N, K = p.form == 2 ? p.N : p.M;
+            const int split = p.ksplit > 1 ? p.ksplit : 1, kseg = attn_kseg(K, split);
             for (int c = 0; c < p.Cc; ++c) for (int x = 0; x < cols; ++x) {
                 float acc = 0.f;
-                for (int k = 0; k < K; ++k)
-                    acc = p.form == 2 ? fmaf(*act_addr(p.A, b, c, k), Dn[(int64_t)x * p.N + k], acc)      // C[c][i] = sum_j A[c][j] D[i][j]
-                                      : fmaf(*act_addr(p.A, b, c, k), Dn[(int64_t)k * p.N + x], acc);      // C[c][j] = sum_i A[c][i] D[i][j]
+                for (int z = 0; z < split; ++z) {                // K-split launches: one chain per segment, segments added in order
+                    float seg = 0.f;
+                    for (int k = std::min(z * kseg, K); k < std::min((z + 1) * kseg, K); ++k)
+                        seg = p.form == 2 ? fmaf(*act_addr(p.A, b, c, k), Dn[(int64_t)x * p.N + k], seg)      // C[c][i] = sum_j A[c][j] D[i][j]
+                                          : fmaf(*act_addr(p.A, b, c, k), Dn[(int64_t)k * p.N + x], seg);      // C[c][j] = sum_i A[c][i] D[i][j]
+                    volatile float v2 = z == 0 ? seg : acc + seg;
+                    acc = v2;
+                }
                 const int tt = x / p.C_HW, rr = x - tt * p.C_HW;
                 float* o = p.Cact + ((int64_t)b * p.C_T + tt) * p.C_nstride + (int64_t)c * p.C_HW + rr;
                 volatile float v = p.accumulate ? *o + acc : acc;

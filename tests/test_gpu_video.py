@@ -84,7 +84,8 @@ def run_backbone(eng, model_type, thw, b, tiny, seed=1):
 
 
 @pytest.mark.parametrize("model_type,thw", [("i3d_resnet50", (8, 32, 32)), ("slowfast_resnet50", (8, 32, 32)), ("tpn_resnet50", (4, 32, 32)),
-                                            ("i3d_resnet50", (16, 24, 40)), ("slowfast_resnet50", (16, 40, 24))])
+                                            ("i3d_resnet50", (16, 24, 40)), ("slowfast_resnet50", (16, 40, 24)),
+                                            ("i3d_resnet50", (16, 96, 96))])       # (the attention gradients' K-split path)
 def test_video_backbone_tiny(eng, model_type, thw):
     gx, ref = run_backbone(eng, model_type, thw, 2, True)
     assert (gx - ref).abs().max() <= (3e-4 if "i3d" in model_type else 1e-4) * ref.abs().max()      # (i3d: float32 softmax attention)
@@ -161,7 +162,9 @@ def test_ilaf_kernels(eng):
     ad = a.cpu().double().requires_grad_(True)
     d, d0 = ad - ori.cpu().double(), (adv0 - ori).cpu().double()
     ref_loss = -(0.5 * d.norm() / d0.norm() + (d0 / d0.norm() * d / d.norm()).sum())
-    gref = torch.autograd.grad(ref_loss, ad)[0] * (a.cpu() > 0)
+    gref = torch.autograd.grad(ref_loss, ad)[0]
+    if hi.post_relu:                                # (the I3D hook -- a non-local block's output -- is not a ReLU output)
+        gref = gref * (a.cpu() > 0)
     assert abs(float(loss) - float(ref_loss.detach())) < 1e-5 * abs(float(ref_loss.detach()))
     got = torch.empty_like(a)
     torch.cuda.synchronize()

@@ -115,3 +115,86 @@ def test_sign_family_live_against_reference(cls):
     import base_attacks
     got = getattr(base_attacks, cls)(toy_video_model(), epsilon=16 / 255, steps=2, momentum=True, engine=hostsim_engine())(vid.clone(), torch.tensor([2]))
     assert float((got != ref).float().mean()) < 5e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SGM / TAP (`base_attacks.py:481-551`, `:685-799`): torch-module classes whose hooks select the model's stages / ReLUs by
+# gluoncv's module names -- fixture `residual_family.npz` from the imported reference classes on oracle/video_models.py's
+# tiny plain-I3D classifier (oracle/make_golden.py:run_residual_family)
+# ---------------------------------------------------------------------------------------------------------------
+def _residual_case(cls, kw, engine):
+    import base_attacks
+    from oracle import video_models
+    fx = gu.load("residual_family")
+    model = video_models.tiny_stage_classifier(thw=tuple(int(v) for v in fx["thw"]))
+    vid = gu.videos_of(fx)
+    if cls == "TAP":
+        atk = base_attacks.TAP(model, dict(kernlen=3, temporal_kernlen=3, eta=1e3, model_type="i3d_resnet50", **kw), epsilon=16 / 255,
+                               steps=int(fx["steps"]), engine=engine)
+    else:
+        atk = base_attacks.SGM(model, epsilon=16 / 255, steps=int(fx["steps"]), engine=engine, **kw)
+    return fx, atk, vid, atk(vid.clone(), torch.tensor([3]))
+
+
+def _residual_family():
+    from oracle.make_golden import RESIDUAL_FAMILY, residual_key
+    return [pytest.param(c, k, id=residual_key(c, k)) for c, k in RESIDUAL_FAMILY]
+
+
+@pytest.mark.parametrize("cls,kw", _residual_family())
+def test_sgm_tap_match_reference_fixture(cls, kw):
+    from oracle.make_golden import residual_key
+    fx, atk, vid, adv = _residual_case(cls, kw, hostsim_engine())
+    key = residual_key(cls, kw)
+    ref = torch.from_numpy(fx[key + "_adv"])
+    # torch computes the model gradient on both sides (same ops, same host): the clips agree exactly unless a threading difference
+    # moves a last bit under a sign
+    assert adv.shape == ref.shape and float((adv != ref).float().mean()) < 1e-3, float((adv != ref).float().mean())
+    assert (adv - ref).abs().max() < 2 * (16 / 255 / int(fx["steps"])) / min(sa.STD) + 1e-6
+    if cls == "TAP":
+        for term, name in (("ce loss", "ce"), ("reg_cost", "reg_cost"), ("distance", "distance")):
+            got = np.array([np.asarray(atk.loss_info[s][term], dtype=np.float64).reshape(-1)[0] for s in range(int(fx["steps"]))])
+            np.testing.assert_allclose(got, fx[key + "_" + name], rtol=1e-5, atol=1e-7)
+    else:
+        assert atk.hooked == ["relu", "res_layers.0.1.relu", "res_layers.1.1.relu"]           # :511-513 on this model
+
+
+def test_sgm_gain_is_the_reference_hook():
+    """One gradient, hook by hook: the repo's output-gradient gain against the reference's own `register_backward_hook` on the ReLU
+    modules (live; skipped without the reference checkout), and against gamma = 1 (no effect)."""
+    import base_attacks
+    from oracle import video_models
+    x = torch.randn(1, 3, 8, 32, 32, generator=torch.Generator().manual_seed(2)) * 0.5
+    lab = torch.tensor([1])
+
+    def grad_of(model):
+        xx = x.clone().requires_grad_(True)
+        return torch.autograd.grad(torch.nn.CrossEntropyLoss()(model(xx), lab), xx)[0]
+    plain = grad_of(video_models.tiny_stage_classifier())
+    m1 = video_models.tiny_stage_classifier()
+    base_attacks.SGM(m1, gamma=1.0, engine=hostsim_engine())
+    assert torch.equal(grad_of(m1), plain)
+    m2 = video_models.tiny_stage_classifier()
+    base_attacks.SGM(m2, gamma=0.5, engine=hostsim_engine())
+    mine = grad_of(m2)
+    assert not torch.allclose(mine, plain, rtol=1e-3, atol=0)
+    if not ref_shim.available():
+        pytest.skip("reference checkout not present")
+    m3 = video_models.tiny_stage_classifier()
+    with ref_shim.quiet():
+        ref_shim.import_reference("base_attacks").SGM(m3, gamma=0.5)
+    theirs = grad_of(m3)
+    assert torch.allclose(mine, theirs, rtol=1e-5, atol=1e-7 * float(theirs.abs().max()))
+
+
+def test_sgm_tap_refuse_the_native_classifier():
+    from i2v_amd import video
+    import base_attacks
+    m = video.VideoModel("i3d_resnet50", (8, 32, 32), weight_seed=0, tiny=True, num_classes=5)
+    with pytest.raises(NotImplementedError):
+        base_attacks.SGM(m, engine=hostsim_engine())
+    with pytest.raises(NotImplementedError):
+        base_attacks.TAP(m, dict(kernlen=3, temporal_kernlen=3, eta=1e3, conv3d=True, model_type="i3d"), engine=hostsim_engine())
+    from oracle import video_models
+    with pytest.raises(AttributeError):                     # `model_type` is never set by the class itself (:737-743)
+        base_attacks.TAP(video_models.tiny_stage_classifier(), dict(kernlen=3, temporal_kernlen=3, eta=1e3, conv3d=True), engine=hostsim_engine())

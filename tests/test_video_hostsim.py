@@ -23,7 +23,8 @@ def capture(model, mods, x):
 
 
 @pytest.mark.parametrize("model_type,thw", [("i3d_resnet50", (8, 32, 32)), ("slowfast_resnet50", (8, 32, 32)), ("tpn_resnet50", (4, 32, 32)),
-                                            ("i3d_resnet50", (16, 24, 40))])
+                                            ("i3d_resnet50", (16, 24, 40)),
+                                            ("i3d_resnet50", (16, 96, 96))])      # (576 positions: the attention gradients' K-split path)
 def test_video_backbone_forward_backward(model_type, thw):
     eng = hostsim_engine()
     g = graphs.build_video_tiny(model_type, thw)
