@@ -51,7 +51,7 @@ namespace {
 
 struct Buffer { int C, H, W; int T = 1; size_t act_off = 0, grad_off = 0; bool is_input = false;    // T: frames per clip (video networks)
                 size_t gate_off = 0; int gate_words = 0; bool gated = false; };   // 1-bit ReLU gates: C rows of gate_words 32-bit words
-struct Tensor { int buf, c_off, C; bool post_relu; };
+struct Tensor { int buf, c_off, C; bool post_relu; float bwd_gain = 1.f; };   // bwd_gain: i2v_net_set_relu_gain
 
 struct Packed {               // one implicit-GEMM operand set
     float* wp = nullptr; I2VKEntry* ktab = nullptr;
@@ -441,6 +441,16 @@ extern "C" int i2v_net_set_input(i2v_handle h, int net, int tensor) {
     if (tensor < 0 || tensor >= (int)n->tens.size()) return fail("bad tensor id");
     n->input = tensor;
     n->bufs[n->tens[tensor].buf].is_input = true;
+    return 0;
+}
+
+extern "C" int i2v_net_set_relu_gain(i2v_handle h, int net, int tensor, float gain) {
+    Net* n = get_net(h, net); if (!n) return 1;
+    if (n->planned) return fail("net already planned");
+    if (tensor < 0 || tensor >= (int)n->tens.size()) return fail("bad tensor id");
+    if (!n->tens[tensor].post_relu) return fail("i2v_net_set_relu_gain: tensor %d is not the output of a ReLU", tensor);
+    if (!(gain > 0.f) || !isfinite(gain)) return fail("i2v_net_set_relu_gain: the gain must be positive and finite");
+    n->tens[tensor].bwd_gain = gain;
     return 0;
 }
 
@@ -858,6 +868,16 @@ struct Planner {
             }
             View dz = view(dst, true);
             if (need_gate[dst]) emit_addmask(dz, {Addend{dz.p, dz.nstride, 1, dz.H, dz.W}}, dst);
+            // a backward gain on this node's ReLU (i2v_net_set_relu_gain): G(dst) is complete and gated here -- every consumer and
+            // hook has contributed, the finaliser applied the gate -- so the gain is one in-place pass in front of the node's own
+            // input-gradient work (the gate is 0 or 1: gain * gate * g, whichever is applied first)
+            if (n.tens[dst].bwd_gain != 1.f) {
+                if (accum[n.tens[dst].buf] || has_alias[dst]) { err = "a ReLU gain on an accumulating or aliased gradient view is not planned"; return false; }
+                Launch l; memset(&l.am, 0, sizeof l.am); l.kind = L_ADDMASK; l.T = dz.T;
+                l.am.out = dz.p; l.am.out_nstride = dz.nstride; l.am.a[0] = dz.p; l.am.a_nstride[0] = dz.nstride;
+                l.am.C = dz.C; l.am.HW = dz.H * dz.W; l.am.gain = n.tens[dst].bwd_gain;
+                emit(n.bwd, l);
+            }
             if (nd.type == 0) {
                 const i2v_conv3d_desc& c = nd.cd;
                 if (c.residual >= 0 && !contribute_alias(c.residual, dz)) return false;

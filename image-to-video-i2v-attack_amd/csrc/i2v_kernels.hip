@@ -1268,6 +1268,7 @@ __global__ void addmask_kernel(const I2VAddMaskParams p) {
             const int64_t c = i / p.HW, bit = n * p.HW + (i - c * p.HW);
             if (!((p.gate[c * p.gate_stride + (bit >> 5)] >> (bit & 31)) & 1u)) v = 0.f;
         } else if (p.mask && !(p.mask[n * p.mask_nstride + i] > 0.f)) v = 0.f;
+        if (p.gain != 0.f) v = __fmul_rn(p.gain, v);
         p.out[n * p.out_nstride + i] = v;
     }
 }

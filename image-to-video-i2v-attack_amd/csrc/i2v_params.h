@@ -102,6 +102,7 @@ struct I2VAddMaskParams {
     const float* mask; int64_t mask_nstride;
     const uint32_t* gate; int32_t gate_stride;     // 1-bit gates instead of `mask` (rows per channel, bit n*HW + i)
     int32_t N, C, HW;
+    float gain;                                    // != 0: the result times this (backward gain of a ReLU, i2v_net_set_relu_gain)
 };
 
 struct I2VCosParams {

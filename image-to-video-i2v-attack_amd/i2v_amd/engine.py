@@ -74,12 +74,12 @@ class Engine:
         except Exception:
             pass
 
-    def build_net(self, graph: Graph, state_dict, hook_tensors: Sequence[int], max_frames: int) -> "Net":
+    def build_net(self, graph: Graph, state_dict, hook_tensors: Sequence[int], max_frames: int, relu_gain=None) -> "Net":
         """Thread-safe (concurrent clip streams plan their own nets); execution of DIFFERENT nets on different
         streams needs no lock -- a planned net owns its arena, the library keeps no other mutable state."""
         with self.plan_lock:
             t0 = time.perf_counter()
-            net = Net(self, graph, state_dict, list(hook_tensors), max_frames)
+            net = Net(self, graph, state_dict, list(hook_tensors), max_frames, relu_gain)
             self.plan_ms += 1e3 * (time.perf_counter() - t0)      # pack + upload + plan + autotune (i2v_net_plan syncs)
             self.plans += 1
             return net
@@ -232,7 +232,8 @@ class HookInfo:
 class Net:
     """A planned backbone truncated at its deepest hook."""
 
-    def __init__(self, eng: Engine, graph: Graph, sd, hook_tensors: List[int], max_frames: int):
+    def __init__(self, eng: Engine, graph: Graph, sd, hook_tensors: List[int], max_frames: int, relu_gain=None):
+        """`relu_gain`: {ReLU-output tensor of `graph`: backward gain} (`i2v_net_set_relu_gain`; the Skip Gradient Method)."""
         self.eng, capi, h = eng, eng.capi, eng.h
         self.graph = g = graph.truncated(hook_tensors)
         self.max_frames = max_frames
@@ -293,6 +294,9 @@ class Net:
                 d = _lib.PoolDesc(self.ten_id[nd.src], self.ten_id[nd.dst], nd.k, nd.stride, nd.pad)
                 add = capi.i2v_net_add_avgpool if nd.op == "avgpool" else capi.i2v_net_add_maxpool
                 _lib.check(capi, add(h, self.id, C.byref(d)))
+        for t, gain in (relu_gain or {}).items():
+            if t in self.ten_id:                  # (a ReLU behind the deepest hook is not part of the truncated graph)
+                _lib.check(capi, capi.i2v_net_set_relu_gain(h, self.id, self.ten_id[t], float(gain)))
         hooks = (C.c_int * len(hook_tensors))(*[self.ten_id[t] for t in hook_tensors])
         _lib.check(capi, capi.i2v_net_plan(h, self.id, hooks, len(hook_tensors), max_frames))
         self.hook_tensors = hook_tensors

@@ -674,6 +674,24 @@ def build_video_tiny(model_type: str, in_thw=(8, 32, 32), full: bool = False) ->
     return slowfast_res2(16, in_thw, "slowfast_tiny", slow_stride=4, fast_stride=1, beta_inv=4, blocks=2)
 
 
+def relu_module_names(g: Graph) -> dict:
+    """{output tensor of a ReLU convolution: qualified name of the gluoncv `nn.ReLU` module that applies it} for the video
+    backbones -- what `base_attacks.SGM` (:511-513) selects its hooks by.  A residual block owns ONE ReLU module, `<block>.relu`,
+    applied after each of its three convolutions; the stems' are top-level modules named `*relu` (`relu`; SlowFast: `fast_relu` /
+    `slow_relu`); the ReLUs inside SlowFast's lateral `nn.Sequential`s are numbered children (`lateral_p1.2`), no `relu` in their
+    names, and are left out."""
+    out = {}
+    for nd in g.nodes:
+        if getattr(nd, "op", "") != "conv" or not nd.relu:
+            continue
+        parts = nd.weight.split(".")
+        if len(parts) == 2 and parts[0].endswith("conv1"):                       # conv1 / fast_conv1 / slow_conv1
+            out[nd.dst] = parts[0][:-len("conv1")] + "relu"
+        elif len(parts) >= 3 and parts[-1] == "weight" and parts[-2] in ("conv1", "conv2", "conv3"):
+            out[nd.dst] = ".".join(parts[:-2] + ["relu"])
+    return out
+
+
 def video_hooks(g: Graph, model_type: str) -> List[int]:
     """Hooked tensors (`image_attacks.py:513-519`).  ILAF's loss is a plain sum over the hooked layers, each paired
     with its own clean feature, so the order is immaterial."""

@@ -51,6 +51,7 @@ _PROTOS = {
     "i2v_net_add_buffer": ([_P, _I, _I, _I, _I, C.POINTER(_I)], _I),
     "i2v_net_add_tensor": ([_P, _I, _I, _I, _I, _I, C.POINTER(_I)], _I),
     "i2v_net_set_input": ([_P, _I, _I], _I),
+    "i2v_net_set_relu_gain": ([_P, _I, _I, _F], _I),
     "i2v_net_add_conv": ([_P, _I, C.POINTER(ConvDesc), _P, _P, _P], _I),
     "i2v_net_add_maxpool": ([_P, _I, C.POINTER(PoolDesc)], _I),
     "i2v_net_add_conv_preact": ([_P, _I, C.POINTER(ConvDesc), _P, _P, _P, _P, _P], _I),

@@ -74,7 +74,7 @@ class _SignAttack(object):
             if self._net is not None:
                 self._net.close()
             g = m.graph_for((f, h, w))
-            self._net = eng.build_net(g, m.state_dict_for(g), m.classifier_hook(g), N)
+            self._net = eng.build_net(g, m.state_dict_for(g), m.classifier_hook(g), N, relu_gain=self._relu_gain(g))
             self._head = tuple(t.to(eng.device) if t is not None else None for t in m.head_weights(g))
             self._net_key = key
         net = self._net
@@ -91,6 +91,10 @@ class _SignAttack(object):
         net.backward(gx)
         self.last_logits, self.last_loss = logits, loss_each.mean()
         return gx.view(b, f, 3, h, w).permute(0, 2, 1, 3, 4).contiguous()
+
+    def _relu_gain(self, graph):
+        """{ReLU-output tensor: backward gain} for the native classifier's planned net (SGM); None: plain gradients."""
+        return None
 
     def _grad(self, adv, labels):
         if isinstance(self.model, VideoModel):
@@ -317,25 +321,38 @@ class SGM(BIM):
     the first of its stage -- and, by the same string test, not the 10th / 20th either).  The attacked classifier is the caller's
     torch module, as in the reference; the gain is attached once, at construction, as there (:493) -- to the module's OUTPUT gradient
     (a tensor hook set from a forward hook), which for a ReLU is the same number as the reference's gain on its input gradient
-    (the gate is 0 or 1) and also works on in-place ReLUs.  Update rule: `i2v_sign_step_f32`.  A native `VideoModel` classifier is
-    refused: the planner's 1-bit ReLU gates carry no gain."""
+    (the gate is 0 or 1) and also works on in-place ReLUs.  Update rule: `i2v_sign_step_f32`.  With a native `VideoModel` classifier
+    the same name test runs over the graph's ReLU convolutions (`graphs.relu_module_names`) and the gain becomes part of the planned
+    backward pass (`i2v_net_set_relu_gain`: one in-place pass over the ReLU's finished gradient)."""
 
     def __init__(self, model, epsilon=16 / 255, steps=10, decay=1.0, gamma=0.5, momentum=False, engine=None):
-        if isinstance(model, VideoModel):
-            raise NotImplementedError("SGM needs a torch module: the native planner's ReLU gates carry no backward gain")
         super().__init__(model, epsilon, steps, engine)
         self.attack = "SGM"
         self.decay, self.momentum, self.gamma = decay, momentum, gamma
         gain = float(np.power(self.gamma, 0.5))
+        self._gain = gain
+        self.hooked = []
+        if isinstance(model, VideoModel):
+            return
 
         def scale_output_gradient(module, inputs, output):
             if torch.is_tensor(output) and output.requires_grad:
                 output.register_hook(lambda g: gain * g)
         self.hooked = []
         for name, module in model.named_modules():
-            if "relu" in name and "0.relu" not in name and isinstance(module, nn.ReLU):
+            if self.selects(name) and isinstance(module, nn.ReLU):
                 module.register_forward_hook(scale_output_gradient)
                 self.hooked.append(name)
+
+    @staticmethod
+    def selects(name):
+        return "relu" in name and "0.relu" not in name                     # :512
+
+    def _relu_gain(self, graph):
+        from .graphs import relu_module_names
+        names = relu_module_names(graph)
+        self.hooked = sorted({n for n in names.values() if self.selects(n)})
+        return {t: self._gain for t, n in names.items() if self.selects(n)}
 
     def _pre(self, grad, state):
         return self._l1_momentum(grad, state) if self.momentum else grad

@@ -60,6 +60,10 @@ int i2v_net_destroy(i2v_handle h, int net);
 int i2v_net_add_buffer(i2v_handle h, int net, int C, int H, int W, int* buf);
 int i2v_net_add_tensor(i2v_handle h, int net, int buf, int c_off, int C, int post_relu, int* tensor);
 int i2v_net_set_input(i2v_handle h, int net, int tensor);
+/* Backward gain of the ReLU that produced `tensor` (a post_relu tensor; before i2v_net_plan): the gradient that passes back through
+ * that ReLU is multiplied by `gain` -- the Skip Gradient Method's hook on the model's ReLU modules
+ * (base_attacks.py:495-513: `gamma ** 0.5 * grad_in[0]` on every module named *relu* but not *0.relu*).  The forward pass is unchanged. */
+int i2v_net_set_relu_gain(i2v_handle h, int net, int tensor, float gain);
 /* weight: host [cout][cin][kh][kw]; scale/shift: host [cout] -- the node computes
  * relu(conv(x,W)*scale + shift + residual): eval-mode BatchNorm folded (image_attacks.py:253-256)
  * or the conv bias. */

@@ -237,6 +237,7 @@ int k_addmask(const I2VAddMaskParams& p, i2v_stream_t) {
                 const size_t c = i / p.HW, bit = (size_t)n * p.HW + (i - c * p.HW);
                 if (!((p.gate[c * p.gate_stride + (bit >> 5)] >> (bit & 31)) & 1u)) v = 0.f;
             } else if (p.mask && !(p.mask[(size_t)n * p.mask_nstride + i] > 0.f)) v = 0.f;
+            if (p.gain != 0.f) { volatile float w = p.gain * v; v = w; }
             p.out[(size_t)n * p.out_nstride + i] = v;
         }
     return 0;

@@ -187,12 +187,10 @@ def test_sgm_gain_is_the_reference_hook():
     assert torch.allclose(mine, theirs, rtol=1e-5, atol=1e-7 * float(theirs.abs().max()))
 
 
-def test_sgm_tap_refuse_the_native_classifier():
+def test_tap_refuses_the_native_classifier_and_needs_model_type():
     from i2v_amd import video
     import base_attacks
     m = video.VideoModel("i3d_resnet50", (8, 32, 32), weight_seed=0, tiny=True, num_classes=5)
-    with pytest.raises(NotImplementedError):
-        base_attacks.SGM(m, engine=hostsim_engine())
     with pytest.raises(NotImplementedError):
         base_attacks.TAP(m, dict(kernlen=3, temporal_kernlen=3, eta=1e3, conv3d=True, model_type="i3d"), engine=hostsim_engine())
     from oracle import video_models
