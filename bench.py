@@ -441,7 +441,7 @@ def run_rank(args):
     # the reference CLI's default `--batch_size 1` (image_main.py:22; BASELINE.json configs[0] shape): one clip per call, product
     # default lanes (a single clip is cut along its frames), after the headline regions -- an extra field, never `value`
     single_clip = None
-    if args.workload == "i2v" and b > 1:
+    if args.workload == "i2v" and b > 1 and timing:       # (--no-kernel-timing = the rocprofv3 passes: only the headline launches)
         atk.clip_lanes = None
         v1 = videos[:1].contiguous()
         atk(v1, labels[:1], names[:1])           # plans the 32-frame nets

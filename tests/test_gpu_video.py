@@ -204,10 +204,12 @@ def test_native_ilaf_against_reference_fixture(eng, name):
     assert torch.equal(atk2(adv.clone(), ori.clone(), torch.zeros(fx["b"], dtype=torch.long), ["v"]).cpu(), out)
 
 
-def test_native_ilaf_full_size_against_oracle(eng):
-    """BASELINE.json configs[4] shape (1 clip of 32 x 224 x 224 per call), 2 steps, SlowFast res2 hooks: the native
-    loop against the oracle's restatement run on the torch module (CPU, float32)."""
-    mt, thw = "slowfast_resnet50", (32, 224, 224)
+@pytest.mark.parametrize("mt", ["slowfast_resnet50", "i3d_resnet50"])
+def test_native_ilaf_full_size_against_oracle(eng, mt):
+    """BASELINE.json configs[4] shape (1 clip of 32 x 224 x 224 per call), 2 steps, SlowFast res2 hooks / the non-local I3D's
+    res3 hook (two non-local blocks inside the hooked stage): the native loop against the oracle's restatement run on the
+    torch module (CPU, float32)."""
+    thw = (32, 224, 224)
     gen = torch.Generator().manual_seed(11)
     ori_u8 = torch.randint(0, 256, (1, 3, *thw), generator=gen, dtype=torch.uint8)
     adv_u8 = (ori_u8.long() + torch.randint(-10, 11, ori_u8.shape, generator=gen)).clamp(0, 255).to(torch.uint8)
@@ -219,7 +221,7 @@ def test_native_ilaf_full_size_against_oracle(eng):
     tm = vm.load_weights(vm.make(mt, False), weights.synthetic_state_dict(g, 0))
     ref, costs, _, _ = restate.run_ilaf(tm, vm.hook_modules(tm, mt), adv, ori, steps=2)
     np.testing.assert_allclose(atk.last_costs, costs, rtol=2e-3)
-    assert abs(atk.last_costs[0] + 1.5 * 2) < 1e-4          # two hooked layers, each -(0.5 + 1) at the start
+    assert abs(atk.last_costs[0] + 1.5 * len(graphs.video_hooks(g, mt))) < 1e-4     # every hooked layer: -(0.5 + 1) at the start
     assert float((out - ref).abs().mean()) < 2e-3
     assert float((out != ref).float().mean()) < 0.05        # sign steps: pixels differ only where |g| ~ 0
 
