@@ -92,7 +92,15 @@ struct Launch {
     float* ms_ptr = nullptr; size_t ms_floats_per_frame = 0;   // L_MEMSET
     bool ms_gx = false;            // L_MEMSET of the caller's gradient output (skipped when accumulating)
     double alg_flops_per_frame = 0; // L_IMGGRAD: algorithmic (not class-padded) flops
+    // conv launches: the autotuner's tile configuration (conv.cfg encoding) per batch bucket b = clips in (max >> (b + 1), max >> b];
+    // 0: not tuned (conv.cfg as planned).  Every configuration computes the same bits, so the choice never shows in a result.
+    int cfg_b[4] = {0, 0, 0, 0};
 };
+static int cfg_bucket(int clips, int max_clips) {
+    int b = 0;
+    while (b < 3 && (max_clips >> (b + 1)) >= clips && (max_clips >> (b + 1)) >= 1) ++b;
+    return b;
+}
 
 struct Addend { const float* p; int64_t nstride; int stride, H, W; };
 
@@ -1117,26 +1125,36 @@ static int autotune(Net& n) {
     void* e0 = be_event_create(); void* e1 = be_event_create();
     const float* xin = n.stage_input ? n.arena + n.in_stage_off : scratch;      // quad-row stems need slack around their source
     int rc = 0;
+    // One tuning per batch bucket (the planned size, half, a quarter, an eighth of its clips): a configuration that wins at 128
+    // frames (fewer, larger tiles) loses up to 10 % at 32, where the launch no longer fills the chip -- a caller that plans once for
+    // its largest group (image_main.py --group_clips, bench.py's single_clip phase) runs every group size on its own choice.
+    const int max_clips = n.maxN / n.Tin();
     for (std::vector<Launch>* L : {&n.fwd, &n.bwd})
         for (Launch& l : *L) {
             if (l.kind != L_CONV && l.kind != L_IMGGRAD) continue;
-            const int lf = n.maxN / n.Tin() * l.conv.Tg;        // grid frames of this launch at the planned size
-            if (lf * l.conv.Hg * l.conv.Wg == 0) continue;
-            int cand[8]; I2VConvParams probe = l.conv; probe.N = lf;
-            const int nc = k_conv_candidates(probe, cand);
-            if (nc <= 1) { if (nc == 1) l.conv.cfg = cand[0] + 1; continue; }
-            float best = 1e30f; int best_c = -1;
-            for (int ci = 0; ci < nc && !rc; ++ci) {
-                l.conv.cfg = cand[ci] + 1;
-                rc |= conv_run(l, lf, xin, scratch + img, 0, nullptr);                      // warm-up
-                be_event_record(e0, nullptr);
-                for (int r = 0; r < 2 && !rc; ++r) rc |= conv_run(l, lf, xin, scratch + img, 0, nullptr);
-                be_event_record(e1, nullptr);
-                if (rc || be_stream_sync(nullptr)) { rc = 1; break; }
-                float ms = 0.f; be_event_elapsed_ms(e0, e1, &ms);
-                if (ms < best) { best = ms; best_c = cand[ci]; }
+            const int planned_cfg = l.conv.cfg;
+            for (int b = 3; b >= 0 && !rc; --b) {               // (bucket 0 last: conv.cfg ends as the planned size's choice)
+                const int clips_b = max_clips >> b;
+                if (clips_b < 1 || (b > 0 && clips_b == (max_clips >> (b - 1)))) continue;
+                const int lf = clips_b * l.conv.Tg;             // grid frames of this launch at the bucket's size
+                if (lf * l.conv.Hg * l.conv.Wg == 0) continue;
+                int cand[8]; I2VConvParams probe = l.conv; probe.N = lf;
+                const int nc = k_conv_candidates(probe, cand);
+                if (nc <= 1) { if (nc == 1) l.cfg_b[b] = cand[0] + 1; continue; }
+                float best = 1e30f; int best_c = -1;
+                for (int ci = 0; ci < nc && !rc; ++ci) {
+                    l.conv.cfg = cand[ci] + 1;
+                    rc |= conv_run(l, lf, xin, scratch + img, 0, nullptr);                      // warm-up
+                    be_event_record(e0, nullptr);
+                    for (int r = 0; r < 2 && !rc; ++r) rc |= conv_run(l, lf, xin, scratch + img, 0, nullptr);
+                    be_event_record(e1, nullptr);
+                    if (rc || be_stream_sync(nullptr)) { rc = 1; break; }
+                    float ms = 0.f; be_event_elapsed_ms(e0, e1, &ms);
+                    if (ms < best) { best = ms; best_c = cand[ci]; }
+                }
+                l.cfg_b[b] = best_c >= 0 ? best_c + 1 : 0;
             }
-            l.conv.cfg = best_c >= 0 ? best_c + 1 : 0;
+            l.conv.cfg = l.cfg_b[0] ? l.cfg_b[0] : planned_cfg;
             if (rc) break;
         }
     be_event_destroy(e0); be_event_destroy(e1); be_free(scratch);
@@ -1206,6 +1224,8 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
             case L_CONV:
             case L_IMGGRAD: {
                 if (frames * l.conv.Hg * l.conv.Wg == 0) break;
+                const int cb = l.cfg_b[cfg_bucket(clips, n.maxN / n.Tin())];
+                if (cb) l.conv.cfg = cb;
                 if (conv_run(l, frames, x, gx, accumulate, s)) return 1;
             } break;
             case L_POOLF: { I2VPoolParams p = l.pool; p.N = frames; CHECK_BE(k_pool_fwd(p, s)); } break;

@@ -242,11 +242,15 @@ class _ImageGuided(Attack):
     clip_lanes = None          # None: $I2V_CLIP_LANES (default 2) on a GPU engine, 1 on the host simulation
 
     def _lane_count(self, b, f=1):
-        """Lanes for a batch of b clips of f frames: whole clips per lane, or -- for a single clip, the reference
-        CLI's default `--batch_size 1` -- halves of its frames (519 -> 548 frames/s)."""
+        """Lanes for a batch of b clips of f frames: whole clips per lane.  A single clip (the reference CLI's default
+        `--batch_size 1`) is cut along its frames only when lanes are asked for explicitly (`clip_lanes`): frame lanes paid with the
+        round-2 kernels (519 -> 548 frames/s) and no longer do with round 3's -- fresh processes, 1 / 2 / 3 frame lanes: 577 / 569 / 550
+        (tools/lanes_single.py)."""
         if self._mode != "i2v":
             return 1
         n = self.clip_lanes
+        if n is None and b == 1:
+            return 1
         if n is None:
             # Two lanes, whatever the batch.  Measured on the headline shape in fresh processes (tools/lanes_fresh.py, frames/s with
             # 1 / 2 / 4 lanes): 695 / 734 / 630 -- the HIP runtime multiplexes a process's streams onto 4 hardware queues by

@@ -430,7 +430,10 @@ def test_clip_lanes_full_size_bit_identical(eng):
     assert torch.equal(got, ref)
     assert np.array_equal(two.last_costs, one.last_costs)      # canonical per-clip summation: the split does not show in the log either
     assert torch.equal(two(vid, torch.zeros(4, dtype=torch.long), names).cpu(), ref)
-    # one clip (the reference CLI's default batch): the two lanes take its frames 0..15 and 16..31
+    # one clip (the reference CLI's default batch): one lane by default; on request two lanes take its frames 0..15 and 16..31
+    assert two._lane_count(1, 32) == 1
+    assert torch.equal(two(vid[:1], torch.zeros(1, dtype=torch.long), names[:1]).cpu(), ref[:1])
+    two.clip_lanes = 2
     assert two._lane_count(1, 32) == 2
     assert torch.equal(two(vid[:1], torch.zeros(1, dtype=torch.long), names[:1]).cpu(), ref[:1])
 
