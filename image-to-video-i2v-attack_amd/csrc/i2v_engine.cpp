@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <deque>
 #include <mutex>
 #include <string>
@@ -61,6 +62,7 @@ struct Packed {               // one implicit-GEMM operand set
     int pt = 0, Tg = 1;       // temporal parity class / grid frames per clip (video networks)
     int has_dt = 0;           // some k-table row carries a temporal tap offset
     int quad = 0, quad_kw = 0, quad_dw0 = 0;     // "quad rows" packing (I2VConvParams::quad): quads per row run, taps per run, first tap
+    int tpair = 0;            // forward packing with TWO output frames per grid frame (rows = (frame class, channel)): see pack_fwd
 };
 
 struct Node {
@@ -171,19 +173,43 @@ static int pack_fwd(Net& n, Node& nd) {
     static const bool no_quad = [] { const char* e = getenv("I2V_QUAD"); return e && e[0] == '0'; }();
     if (!no_quad && c.cin < I2V_KC && c.cout <= 32 && c.kw >= 2 && c.kw <= 8 && !nd.preact()) {
         const int kwq = (c.kw + 3) / 4;
-        P.K = c.cin * c.kt * c.kh * kwq * 4; P.Kpad = (int)align_up(P.K, I2V_KC); P.tap_uniform = 0;
+        // Frame PAIRS (round 3): with <= 8 output channels (SlowFast's fast stem) half of even a 16-row fragment is empty.  Two
+        // consecutive output frames share most of their source frames when the kernel spans time (5 taps at stride = dilation 2:
+        // six distinct source frames for the pair instead of ten), so one grid frame computes BOTH -- rows (frame class, channel), K
+        // rows over the UNION of the pair's frame taps, zero weights where a class has no tap there -- with 0.6x the matrix work
+        // and im2col traffic of two half-empty launches.  A zero weight adds an exact +0 to the k-ordered chain and the real taps
+        // keep their order: same bits as the unpaired packing.  The epilogue is the class-packed one of the image gradient
+        // (I2VConvParams::blkt = 2: row -> channel, frame 2 tau + class).
+        static const bool no_tpair = [] { const char* e = getenv("I2V_TPAIR"); return e && e[0] == '0'; }();
+        const Buffer& dbuf = n.bufs[n.tens[c.dst].buf];
+        std::vector<int> taps;                       // frame offsets relative to the grid frame's base source frame
+        const int classes = (!no_tpair && c.kt > 1 && 2 * c.cout <= 16 && dbuf.T >= 2) ? 2 : 1;
+        for (int ct = 0; ct < classes; ++ct)
+            for (int q = 0; q < c.kt; ++q) {
+                const int u = ct * c.stride_t + q * c.dil_t - c.pad_t;
+                if (std::find(taps.begin(), taps.end(), u) == taps.end()) taps.push_back(u);
+            }
+        std::sort(taps.begin(), taps.end());
+        const int NU = (int)taps.size();
+        if (classes == 2) { P.tpair = 2; P.Cd = 2 * c.cout; P.Cdpad = (int)align_up(P.Cd, 128); }
+        P.K = c.cin * NU * c.kh * kwq * 4; P.Kpad = (int)align_up(P.K, I2V_KC); P.tap_uniform = 0;
         P.quad = kwq; P.quad_kw = c.kw; P.quad_dw0 = -c.pad;
         std::vector<float> wq((size_t)P.Kpad * P.Cdpad, 0.f);
         std::vector<I2VKEntry> kq(P.Kpad, I2VKEntry{0, 0, 0, 0});
         for (int ci = 0; ci < c.cin; ++ci)
-            for (int q = 0; q < c.kt; ++q)
+            for (int ui = 0; ui < NU; ++ui)
                 for (int r = 0; r < c.kh; ++r)
                     for (int s4 = 0; s4 < kwq * 4; ++s4) {
-                        const int k = (((ci * c.kt + q) * c.kh + r) * kwq) * 4 + s4;
-                        kq[k] = I2VKEntry{ci * sb.H * sb.W, r - c.pad, s4 - c.pad, (s4 < c.kw ? 1 : 0) + 2 * (q * c.dil_t - c.pad_t)};
-                        if (s4 < c.kw)
+                        const int k = (((ci * NU + ui) * c.kh + r) * kwq) * 4 + s4;
+                        kq[k] = I2VKEntry{ci * sb.H * sb.W, r - c.pad, s4 - c.pad, (s4 < c.kw ? 1 : 0) + 2 * taps[ui]};
+                        if (s4 >= c.kw) continue;
+                        for (int ct = 0; ct < classes; ++ct) {
+                            const int num = taps[ui] - ct * c.stride_t + c.pad_t;       // = q * dil_t for this class's tap q
+                            if (num < 0 || num % c.dil_t || num / c.dil_t >= c.kt) continue;
+                            const int q = num / c.dil_t;
                             for (int co = 0; co < c.cout; ++co)
-                                wq[(size_t)k * P.Cdpad + co] = nd.w[((((size_t)co * c.cin + ci) * c.kt + q) * c.kh + r) * c.kw + s4];
+                                wq[(size_t)k * P.Cdpad + ct * c.cout + co] = nd.w[((((size_t)co * c.cin + ci) * c.kt + q) * c.kh + r) * c.kw + s4];
+                        }
                     }
         for (const I2VKEntry& e : kq) if (e.valid >> 1) P.has_dt = 1;
         if (upload(n, wq, &P.wp)) return 1;
@@ -784,13 +810,16 @@ struct Planner {
                 p.Hs = sb.H; p.Ws = sb.W; p.Cs = c.cin; p.Hg = d.H; p.Wg = d.W; p.sh = p.sw = c.stride;
                 p.dst = d.p; p.dst_nstride = d.nstride; p.Ho = d.H; p.Wo = d.W; p.osh = p.osw = 1;
                 p.Tg = p.To = d.T; p.Ts = sb.T; p.st = c.stride_t; l.T = d.T;
+                if (nd.fwd.tpair) {              // two output frames per grid frame (pack_fwd): class-packed epilogue, blk = 1
+                    p.Tg = (d.T + 1) / 2; l.T = p.Tg; p.st = 2 * c.stride_t; p.ost = 2; p.ot0 = 0; p.blkt = 2; p.blk = 1;
+                }
                 p.shift = nd.shift_d; p.relu = c.relu;
                 if (c.residual >= 0) { View r = view(c.residual, false); p.add0 = r.p; p.add0_nstride = r.nstride; p.add0_stride = 1; }
                 p.pointwise = (c.kt == 1 && c.stride_t == 1 && c.pad_t == 0 && c.kh == 1 && c.kw == 1 && c.stride == 1 &&
                                c.pad == 0 && (sb.H * sb.W) % 4 == 0 && c.src != n.input) ? 1 : 0;
                 if (nd.preact()) { p.pre_scale = nd.pre_scale_d; p.pre_shift = nd.pre_shift_d; }
                 if (c.relu) { int st = 0; if (uint32_t* g = gate_rows(c.dst, &st)) { p.gate_out = g; p.gate_out_stride = st; p.gate_out_pix0 = 0; } }
-                if (nd.fwd.quad) l.alg_flops_per_frame = 2.0 * d.H * d.W * c.cout * (double)c.cin * c.kt * c.kh * c.kw;
+                if (nd.fwd.quad) l.alg_flops_per_frame = 2.0 * d.H * d.W * c.cout * (double)c.cin * c.kt * c.kh * c.kw * d.T / p.Tg;   // per GRID frame
             } else if (nd.type == 3) {
                 // S = scale * theta^T phi  ->  P = softmax rows  ->  y = g P^T   (P stays in the arena for the backward pass)
                 View th = view(nd.ad.theta, false), ph = view(nd.ad.phi, false), gv = view(nd.ad.g, false), y = view(nd.ad.dst, false);
@@ -1028,7 +1057,7 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
     const char* gates_env = getenv("I2V_GATES");           // developer knob: I2V_GATES=0 keeps the fp32-activation gates
     const bool use_gates = !(gates_env && gates_env[0] == '0');
     for (const Node& nd : n.nodes)
-        if (use_gates && nd.type == 0 && nd.cd.relu) n.bufs[n.tens[nd.cd.dst].buf].gated = true;
+        if (use_gates && nd.type == 0 && nd.cd.relu && !nd.fwd.tpair) n.bufs[n.tens[nd.cd.dst].buf].gated = true;   // (the class-packed epilogue writes no gate words)
     for (Buffer& b : n.bufs) {
         if (!b.gated) continue;
         const size_t pix = N / Tin * b.T * b.H * b.W;

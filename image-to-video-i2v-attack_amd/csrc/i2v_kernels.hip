@@ -699,8 +699,9 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         }
         return;
     }
-    if (p.blk > 1) {
-        // class-packed Cd (image gradient): cd = (ph*blk + pw)*Creal + c -> channel c at (gi*osh+ph, gj*osw+pw)
+    if (p.blk > 1 || (VID && p.blkt > 1)) {
+        // class-packed Cd (image gradient; frame-paired forward stems with blk = 1): cd = ((ct*blk + ph)*blk + pw)*Creal + c -> channel c at
+        // (gi*osh+ph, gj*osw+pw) of frame tau*ost + ot0 + ct
         const int bb = p.blk * p.blk, Creal = p.Cd / ((VID ? p.blkt : 1) * bb);
 #pragma unroll
         for (int j = 0; j < TP; ++j) {

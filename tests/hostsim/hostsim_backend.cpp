@@ -67,7 +67,7 @@ int k_conv(const I2VConvParams& p, i2v_stream_t) {
                         if (p.pre_scale) { xv = fmaf(xv, p.pre_scale[k], p.pre_shift[k]); xv = xv > 0.f ? xv : 0.f; }
                         acc = fmaf(p.wp[(size_t)k * p.Cdpad + cd], xv, acc);      // one fused multiply-add per K row, in packed-K order: what an fp32 MFMA chain computes
                     }
-                    if (p.blk > 1) {            // class-packed Cd (image gradient)
+                    if (p.blk > 1 || p.blkt > 1) {            // class-packed Cd (image gradient; frame-paired forward stems: blk = 1)
                         int Creal = p.Cd / (p.blkt * p.blk * p.blk), cls3 = cd / Creal, c = cd % Creal;
                         int ct = cls3 / (p.blk * p.blk), cls = cls3 % (p.blk * p.blk);
                         int bh = i * p.osh + cls / p.blk + p.oh0, bw = j * p.osw + cls % p.blk + p.ow0;
