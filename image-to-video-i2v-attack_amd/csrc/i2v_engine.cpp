@@ -80,6 +80,7 @@ struct Node {
     Packed fwd; std::vector<Packed> bwd;
     Packed img; int img_blk = 0, img_sh = 1, img_blkt = 1;   // input-gradient of the first conv (class-packed)
     int img_ost = 1, img_ot0 = 0;                            // its temporal output stride / offset
+    int img_st = 1, img_oct = 1; bool img_skips = false;     // dz frames per grid frame, frames between its temporal classes, frames left to a memset
     size_t idx_off = 0;                           // maxpool: arg-max bytes, arena offset in floats
 };
 
@@ -305,11 +306,20 @@ static int pack_img(Net& n, Node& nd) {
         if (any) { with_taps++; only = ct; }
     }
     const bool sparse = stt > 1 && with_taps == 1;
-    const int Bt = sparse ? 1 : stt, ct0 = sparse ? only : 0;
+    int Bt = sparse ? 1 : stt; const int ct0 = sparse ? only : 0;
+    static const bool no_tpair = [] { const char* e = getenv("I2V_TPAIR"); return e && e[0] == '0'; }();
+    // (Tried and dropped for the DENSE temporal stride of I3D's stem: two stride periods per grid frame -- 48 of 64 rows over 4 dz frames
+    //  instead of 2 x (24 of 32 over 3) -- runs the 64-row tiles and was 23 % SLOWER, 1343 -> 1657 us per launch.)
     int dt_lo = 1 << 30, dt_hi = -(1 << 30), dh_lo = 1 << 30, dh_hi = -(1 << 30), dw_lo = 1 << 30, dw_hi = -(1 << 30);
     for (int ct = ct0; ct < ct0 + Bt; ++ct)
         for (int q = 0; q < c.kt; ++q)
             if (posmod(ct + c.pad_t - q * c.dil_t, stt) == 0) { int d = floordiv(ct + c.pad_t - q * c.dil_t, stt); dt_lo = d < dt_lo ? d : dt_lo; dt_hi = d > dt_hi ? d : dt_hi; }
+    // Pairs of SAMPLED frames (round 3; the gradient-side twin of pack_fwd's frame pairs): a frame-skipping stem whose kernel spans
+    // time (SlowFast's fast stem: every 2nd frame, 5 taps) gives each sampled frame 5 dz frames, two neighbouring sampled frames 6
+    // between them -- both as temporal classes of ONE grid frame: 24 of 32 rows over 6 frame taps instead of two launches' worth
+    // of 12 of 16 rows over 5.  The classes lie stt frames apart (I2VConvParams::oct).  Zero weights where a class has no tap: same bits.
+    const bool pairs = sparse && !no_tpair && dt_hi > dt_lo && 2 * B * B * c.cin <= 32 && (sb.T - ct0 + stt - 1) / stt >= 2;
+    if (pairs) { Bt = 2; dt_hi += 1; }
     for (int ph = 0; ph < B; ++ph)
         for (int r = 0; r < c.kh; ++r)
             if (posmod(ph + c.pad - r, st) == 0) { int d = floordiv(ph + c.pad - r, st); dh_lo = d < dh_lo ? d : dh_lo; dh_hi = d > dh_hi ? d : dh_hi; }
@@ -328,7 +338,8 @@ static int pack_img(Net& n, Node& nd) {
     P.tap_uniform = (!quad && c.cout % I2V_KC == 0) ? 1 : 0;
     if (quad) { P.quad = TWq / 4; P.quad_kw = TW; P.quad_dw0 = dw_lo; }
     P.Tg = sparse ? (sb.T - ct0 + stt - 1) / stt : (sb.T + Bt - 1) / Bt; P.Hg = (sb.H + B - 1) / B; P.Wg = (sb.W + B - 1) / B;
-    nd.img_blk = B; nd.img_sh = m; nd.img_blkt = Bt; nd.img_ost = sparse ? stt : Bt; nd.img_ot0 = ct0;
+    nd.img_blk = B; nd.img_sh = m; nd.img_blkt = Bt; nd.img_ost = sparse ? stt : Bt; nd.img_ot0 = ct0; nd.img_skips = sparse;
+    if (pairs) { P.Tg = (P.Tg + 1) / 2; nd.img_ost = 2 * stt; nd.img_st = 2; nd.img_oct = stt; }
     std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
     std::vector<I2VKEntry> kt(P.Kpad, I2VKEntry{0, 0, 0, 0});
     // K order = (16-channel chunk, tap, channel in chunk) when the channel count allows: every 16-row K chunk
@@ -348,9 +359,9 @@ static int pack_img(Net& n, Node& nd) {
                 kt[krow(tt, th, tw, co)] = I2VKEntry{co * db.H * db.W, th + dh_lo, tw + dw_lo, (tw < TW ? 1 : 0) + 2 * (tt + dt_lo)};
     for (int cc = 0; cc < Bt; ++cc)
     for (int q = 0; q < c.kt; ++q) {
-        const int ct = ct0 + cc;
+        const int ct = pairs ? ct0 : ct0 + cc;          // (pairs: both classes are the ONE residue with taps, a sampled frame apart)
         if (posmod(ct + c.pad_t - q * c.dil_t, stt)) continue;
-        const int tt = floordiv(ct + c.pad_t - q * c.dil_t, stt) - dt_lo;
+        const int tt = floordiv(ct + c.pad_t - q * c.dil_t, stt) - dt_lo + (pairs ? cc : 0);
         for (int ph = 0; ph < B; ++ph)
             for (int pw = 0; pw < B; ++pw)
                 for (int r = 0; r < c.kh; ++r) {
@@ -600,7 +611,7 @@ static void conv_common(I2VConvParams& p, const Packed& P) {
     memset(&p, 0, sizeof p);
     p.wp = P.wp; p.ktab = P.ktab; p.K = P.K; p.Kpad = P.Kpad; p.tap_uniform = P.tap_uniform; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
     p.add0_stride = 1;
-    p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1; p.ot0 = 0;
+    p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1; p.ot0 = 0; p.oct = 1;
     p.temporal = P.has_dt;      // conv_run adds the frame-mapping half of the condition
     p.quad = P.quad; p.quad_kw = P.quad_kw; p.quad_dw0 = P.quad_dw0;
     p.halo = P.halo;
@@ -865,7 +876,7 @@ struct Planner {
         }
         // ---------------- backward ----------------
         for (const Node& nd : n.nodes)
-            if (nd.type == 0 && nd.cd.src == n.input && nd.img_ost != nd.img_blkt) {     // a stem gradient that skips frames
+            if (nd.type == 0 && nd.cd.src == n.input && nd.img_skips) {     // a stem gradient that skips frames
                 const Buffer& ib = n.bufs[n.tens[n.input].buf];
                 Launch l; l.kind = L_MEMSET; l.ms_gx = true; l.ms_floats_per_frame = (size_t)ib.C * ib.H * ib.W; l.T = ib.T;
                 emit(n.bwd, l);
@@ -927,7 +938,7 @@ struct Planner {
                     p.Hg = nd.img.Hg; p.Wg = nd.img.Wg; p.sh = p.sw = nd.img_sh;
                     p.dst = nullptr; p.dst_nstride = (int64_t)ib.C * ib.H * ib.W; p.Ho = ib.H; p.Wo = ib.W;
                     p.osh = p.osw = nd.img_blk; p.blk = nd.img_blk;
-                    p.blkt = nd.img_blkt; p.Tg = nd.img.Tg; p.Ts = dz.T; p.st = 1; p.To = ib.T; p.ost = nd.img_ost; p.ot0 = nd.img_ot0; l.T = nd.img.Tg;
+                    p.blkt = nd.img_blkt; p.Tg = nd.img.Tg; p.Ts = dz.T; p.st = nd.img_st; p.To = ib.T; p.ost = nd.img_ost; p.ot0 = nd.img_ot0; p.oct = nd.img_oct; l.T = nd.img.Tg;
                     l.alg_flops_per_frame = 2.0 * dz.T * dz.H * dz.W * c.cout * c.cin * c.kt * c.kh * c.kw / nd.img.Tg;   // per grid frame
                     emit(n.bwd, l);
                 } else if (nd.preact()) {

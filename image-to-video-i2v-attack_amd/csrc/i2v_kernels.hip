@@ -721,8 +721,8 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
                     const int cls3 = cd / Creal, c = cd - cls3 * Creal;
                     const int ct = VID ? cls3 / bb : 0, cls = cls3 - ct * bb;
                     const int oh = gi * p.osh + cls / p.blk + p.oh0, ow = gj * p.osw + cls % p.blk + p.ow0;
-                    if (oh >= p.Ho || ow >= p.Wo || (VID && otb + ct >= p.To)) continue;
-                    const int64_t n = VID ? clip * p.To + otb + ct : ng;
+                    if (oh >= p.Ho || ow >= p.Wo || (VID && otb + ct * p.oct >= p.To)) continue;
+                    const int64_t n = VID ? clip * p.To + otb + ct * p.oct : ng;
                     const int64_t o = (int64_t)c * HoWo + oh * p.Wo + ow;
                     float v = acc[i][j][r];
                     if (p.shift) v += p.shift[c];

@@ -59,6 +59,7 @@ struct I2VConvParams {
     int32_t blk;
     int32_t blkt;           // temporal classes in front of the blk*blk spatial ones (video stem); 1 otherwise
     int32_t Tg, Ts, To, st, ost, ot0;   // frames per clip of grid / source / destination, temporal strides (see above)
+    int32_t oct;            // frames between two temporal classes of a class-packed launch (1; the stride of a frame-skipping stem's paired gradient)
     int32_t temporal;       // 1: some k-table row has dt != 0 or the frame mapping is not the identity -> the kernel's video
                             //    variant runs; 0 (all image launches, spatial / pointwise launches of video networks): the
                             //    temporal fields are ignored altogether

@@ -41,7 +41,7 @@ int k_conv_candidates(const I2VConvParams&, int* out) { out[0] = 0; return 1; }
 int k_conv(const I2VConvParams& p, i2v_stream_t) {
     if (!p.temporal) {      // image variant of the kernel: the temporal fields are ignored (a launch that needs them
         I2VConvParams q = p; // but is not flagged must therefore FAIL the planner tests, as it would on the GPU)
-        q.temporal = 1; q.Tg = q.Ts = q.To = q.st = q.ost = 1; q.ot0 = 0; q.blkt = 1;
+        q.temporal = 1; q.Tg = q.Ts = q.To = q.st = q.ost = 1; q.ot0 = 0; q.blkt = 1; q.oct = 1;
         std::vector<I2VKEntry> kt(p.ktab, p.ktab + (p.Kpad ? p.Kpad : 0));
         for (auto& e : kt) e.valid &= 1;
         q.ktab = kt.data();
@@ -71,7 +71,7 @@ int k_conv(const I2VConvParams& p, i2v_stream_t) {
                         int Creal = p.Cd / (p.blkt * p.blk * p.blk), cls3 = cd / Creal, c = cd % Creal;
                         int ct = cls3 / (p.blk * p.blk), cls = cls3 % (p.blk * p.blk);
                         int bh = i * p.osh + cls / p.blk + p.oh0, bw = j * p.osw + cls % p.blk + p.ow0;
-                        int ot = tg * p.ost + p.ot0 + ct;
+                        int ot = tg * p.ost + p.ot0 + ct * p.oct;
                         if (bh >= p.Ho || bw >= p.Wo || ot >= p.To) continue;
                         size_t n = (size_t)clip * p.To + ot;
                         size_t o = (size_t)c * p.Ho * p.Wo + (size_t)bh * p.Wo + bw;

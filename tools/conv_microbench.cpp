@@ -90,7 +90,7 @@ static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
     p.N = N; p.Hg = p.Wg = Ho; p.sh = p.sw = st;
     p.dst = dd; p.dst_nstride = (int64_t)Cout * Ho * Ho; p.Ho = p.Wo = Ho; p.osh = p.osw = 1;
     p.add0_stride = 1; p.relu = 1;
-    p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1;
+    p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1; p.oct = 1;
     if (with_epi) { p.add0 = da; p.add0_nstride = p.dst_nstride; }      // residual-style addend (the expand convolutions)
     p.tap_uniform = tu;
     p.pointwise = (k == 1 && st == 1 && (H * H) % 4 == 0 && !getenv("CMB_NOPW")); p.tap_uniform = tu;
