@@ -134,8 +134,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU")
     ap.add_argument("--white_model", default="slowfast_resnet50", help="--workload ilaf: video backbone (graphs.build_video)")
-    ap.add_argument("--streams", type=int, default=2, help="--workload ilaf: engine calls in flight on separate HIP streams")
-    ap.add_argument("--ilaf_clips", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=3, help="--workload ilaf: engine calls in flight on separate HIP streams")
+    ap.add_argument("--ilaf_clips", type=int, default=8,
                     help="--workload ilaf: clips per engine call, attacked as INDEPENDENT one-clip problems (ILAF.forward_independent: "
                          "per-clip loss segments, each clip bit-identical to its one-clip call; the reference runs one clip per call)")
     ap.add_argument("--workload", default="i2v", choices=["i2v", "ens", "aens", "config2", "ilaf"],
