@@ -1578,6 +1578,19 @@ extern "C" int i2v_ilaf_grad_seg_f32(const float* a, int64_t a_stride, const flo
     return 0;
 }
 
+extern "C" int i2v_tap_distance_f32(const float* a, int64_t a_stride, const float* clean, int64_t D, int frames, int frames_per_seg,
+                                    double coef, int mask_relu, int accumulate, float* dist_out, float* grad, int64_t grad_stride,
+                                    void* scratch, void* stream) {
+    if (!a || !clean || !scratch || !dist_out || !grad || D <= 0 || frames <= 0 || frames_per_seg <= 0 || frames % frames_per_seg)
+        return fail("i2v_tap_distance_f32: bad argument");
+    I2VIlafParams p; ilaf_params(p, a, a_stride, clean, clean, D, frames, scratch, frames_per_seg);
+    p.mode = 1; p.coef = coef; p.mask_relu = mask_relu; p.accumulate = accumulate; p.loss_out = dist_out;
+    p.grad = grad; p.grad_nstride = grad_stride;
+    CHECK_BE(k_ilaf_reduce(p, stream));
+    CHECK_BE(k_ilaf_grad(p, stream));
+    return 0;
+}
+
 extern "C" size_t i2v_head_scratch_bytes(int C, int clips) { return (size_t)2 * C * clips * sizeof(float) + 64; }
 
 static void head_feature(I2VHeadParams& p, const float* a, int64_t a_stride, int C, int HW, int T, int clips, int Ctot, int c_off, void* scratch) {

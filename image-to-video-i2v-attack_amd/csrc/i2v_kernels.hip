@@ -1439,6 +1439,7 @@ int k_std_grad(const I2VStdParams& p, i2v_stream_t s) {
 // =============================================================================================
 // ILAF loss (image_attacks.py:579-611) over one hooked tensor: whole-tensor norms, so reduce -> finish -> grad
 // =============================================================================================
+__device__ __forceinline__ float tap_root(float x) { return x > 0.f ? sqrtf(x) : (x < 0.f ? -sqrtf(-x) : 0.f); }
 __global__ void __launch_bounds__(256) ilaf_reduce_kernel(const I2VIlafParams p) {
     const int blk = blockIdx.x, n = blockIdx.y;
     const int64_t chunk = (p.D + p.nblk - 1) / p.nblk;
@@ -1447,6 +1448,12 @@ __global__ void __launch_bounds__(256) ilaf_reduce_kernel(const I2VIlafParams p)
     const float* o = p.ori + (int64_t)n * p.D;
     const float* a0 = p.adv0 + (int64_t)n * p.D;
     double dd = 0, dq = 0;
+    if (p.mode == 1) {                                       // TAP: r(a) - r(ori) with r(x) = sign(x) sqrt|x| in fp32, as torch
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+            const double d = (double)__fsub_rn(tap_root(a[i]), tap_root(o[i]));
+            dd += d * d;
+        }
+    } else
     for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
         const float ov = o[i];
         const double d = (double)__fsub_rn(a[i], ov), d0 = (double)__fsub_rn(a0[i], ov);    // fp32 differences, as torch
@@ -1484,6 +1491,22 @@ __global__ void __launch_bounds__(256) ilaf_finish_kernel(const I2VIlafParams p)
 __global__ void __launch_bounds__(256) ilaf_grad_kernel(const I2VIlafParams p) {
     const int n = blockIdx.y;
     const int fps = p.fps > 0 ? p.fps : p.N, seg = n / fps;
+    if (p.mode == 1) {                                       // TAP feature distance (I2VIlafParams::mode)
+        const double dist = sqrt(p.sums[2 * seg]);
+        if (blockIdx.x == 0 && n == seg * fps && threadIdx.x == 0) p.loss_out[seg] = (float)dist;
+        const double c = dist > 0.0 ? p.coef / dist : 0.0;
+        const float* a = p.a + (int64_t)n * p.a_nstride;
+        const float* o = p.ori + (int64_t)n * p.D;
+        float* g = p.grad + (int64_t)n * p.grad_nstride;
+        for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < p.D; i += (int64_t)gridDim.x * 256) {
+            const float av = a[i];
+            float v = 0.f;
+            if (av != 0.f && !(p.mask_relu && !(av > 0.f)))
+                v = (float)(c * (double)__fsub_rn(tap_root(av), tap_root(o[i])) * 0.5 / (double)sqrtf(fabsf(av)));
+            g[i] = p.accumulate ? g[i] + v : v;
+        }
+        return;
+    }
     const double s = sqrt(p.sums[2 * seg]), q = p.sums[2 * seg + 1], n0 = p.init_sq ? sqrt(p.init_sq[seg]) : p.init_norm;
     if (blockIdx.x == 0 && n == seg * fps && threadIdx.x == 0) p.loss_out[seg] = (float)(-(0.5 * s / n0 + q / (n0 * s)));
     const double cd = -(0.5 / s - q / (s * s * s)) / n0, c0 = -1.0 / (s * n0);

@@ -136,6 +136,12 @@ struct I2VIlafParams {
     // value the host path passes in init_norm).
     int32_t fps;
     const double* init_sq;
+    // mode 1: the feature-distance term of base_attacks.TAP (:770-776) instead of the ILAF loss: per segment
+    //   dist = || r(a) - r(ori) ||_2,  r(x) = sign(x) sqrt|x|   (sums[2 seg] = dist^2, loss_out[seg] = dist),
+    //   grad = coef * (r(a) - r(ori)) / dist * 1 / (2 sqrt|a|),  0 where a == 0 (the ReLU behind a hooked stage selects 0 there in
+    //   the reference, which is what keeps its NaN from sqrt'(0) out of the gradient) and 0 while dist == 0 (torch's norm backward).
+    // adv0 / init_* are unused.
+    int32_t mode; double coef;
 };
 
 // Non-local (self-attention) block core of gluoncv's `i3d_nl5_*` models -- the reference's I3D configurations

@@ -416,6 +416,15 @@ class Net:
                                                 C.c_void_p(hi.grad), hi.grad_stride, C.c_void_p(scratch.data_ptr()),
                                                 self.eng.stream()))
 
+    def tap_distance(self, i: int, clean: torch.Tensor, coef: float, dist_out: torch.Tensor, scratch: torch.Tensor, frames: int,
+                     frames_per_seg: int):
+        """TAP's feature-distance term over hook i (`i2v_tap_distance_f32`): per clip || r(a) - r(clean) ||_2 into `dist_out`, and
+        coef * its gradient into the hook's gradient view."""
+        hi = self.hooks[i]
+        _lib.check(self.eng.capi, self.eng.capi.i2v_tap_distance_f32(
+            C.c_void_p(hi.act), hi.act_stride, _ptr(clean, self.eng), hi.D, frames, frames_per_seg, float(coef), hi.post_relu, 0,
+            C.c_void_p(dist_out.data_ptr()), C.c_void_p(hi.grad), hi.grad_stride, C.c_void_p(scratch.data_ptr()), self.eng.stream()))
+
     def head_ce(self, i, W: torch.Tensor, bias, labels: torch.Tensor, in_frames: int, scale: float, logits: torch.Tensor,
                 loss_each: torch.Tensor, scratch: torch.Tensor):
         """Classifier head over hook i -- or over a LIST of hooks whose pooled features are concatenated in that order

@@ -89,6 +89,7 @@ _PROTOS = {
     "i2v_ilaf_scratch_bytes": ([_L, _I, _I], C.c_size_t),
     "i2v_ilaf_reduce_seg_f32": ([_P, _L, _P, _P, _L, _I, _I, _P, _P], _I),
     "i2v_ilaf_grad_seg_f32": ([_P, _L, _P, _P, _L, _I, _I, _P, _I, _I, _P, _P, _L, _P, _P], _I),
+    "i2v_tap_distance_f32": ([_P, _L, _P, _L, _I, _I, C.c_double, _I, _I, _P, _P, _L, _P, _P], _I),
     "i2v_head_scratch_bytes": ([_I, _I], C.c_size_t),
     "i2v_head_ce_f32": ([_P, _L, _I, _I, _I, _I, _P, _P, _I, _P, _F, _I, _I, _P, _P, _P, _L, _P, _P], _I),
     "i2v_clip_resample_crop_u8_f32": ([_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P], _I),

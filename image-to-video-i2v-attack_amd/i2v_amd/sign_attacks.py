@@ -364,18 +364,20 @@ class TAP(_SignAttack):
     on the clean one), sign step as BIM.  `params` = {'kernlen', 'temporal_kernlen', 'eta', 'conv3d'} become attributes (:699-700);
     `model_type` has to be among them (the reference reads `self.model_type` in `_find_target_layer` without ever setting it: an
     AttributeError there, and here).  `eta` is accepted and unused, as there (the weight 1e3 is a literal, :780).  The model is the
-    caller's torch module (forward hooks on its own stages), the update is `i2v_sign_step_f32`.  As in the reference the cost is a
+    caller's torch module (forward hooks on its own stages) or a native `VideoModel` classifier (`_forward_native`: the stages are hooks of
+    the planned net, the feature distance is `i2v_tap_distance_f32`); the update is `i2v_sign_step_f32`.  As in the reference the cost is a
     (batch,)-vector, so autograd accepts one clip per call only.  `loss_info[step]` holds the three terms (the reference keys
     the dict with a loop variable its inner loop has rebound to a tensor, :793)."""
 
     def __init__(self, model, params, epsilon=16 / 255, steps=10, engine=None):
-        if isinstance(model, VideoModel):
-            raise NotImplementedError("TAP needs a torch module (forward hooks on its stages)")
         super().__init__("TAP", model, engine)
         self.epsilon, self.steps = epsilon, steps
         self.step_size = self.epsilon / self.steps
         for name, value in params.items():
             setattr(self, name, value)
+        if isinstance(model, VideoModel):            # native classifier: stages hooked in the planned net (`_forward_native`)
+            self._find_target_stages()
+            return
         k, kt = int(self.kernlen), int(self.temporal_kernlen)
         self.box2d = torch.full((3, 1, k, k), 1.0 / (k * k), dtype=torch.float32)            # :713-717, one filter per colour channel
         self.box3d = torch.full((3, 1, kt, k, k), 1.0 / (kt * k * k), dtype=torch.float32)   # :719-722
@@ -392,6 +394,84 @@ class TAP(_SignAttack):
         if "tpn" in self.model_type:
             return [m.layer1, m.layer2]
 
+    def _find_target_stages(self):
+        """`_find_target_layer` on the graph IR: the stage prefixes whose last block's output is hooked."""
+        if "i3d" in self.model_type:
+            return ["res_layers.0", "res_layers.1"]
+        if "slowfast" in self.model_type:
+            return ["slow_res2", "slow_res3", "fast_res2", "fast_res3"]
+        raise KeyError(f"TAP on the native classifier: no full graph for {self.model_type!r} (TPN's neck / head are not built)")
+
+    @staticmethod
+    def _stage_output(graph, prefix):
+        import re
+        best = None
+        for t, ts in enumerate(graph.tensors):
+            m = re.fullmatch(re.escape(prefix) + r"\.(\d+)\.out", ts.name or "")
+            if m and (best is None or int(m.group(1)) > best[0]):
+                best = (int(m.group(1)), t)
+        if best is None:
+            raise KeyError(f"no stage {prefix!r} in graph {graph.name!r}")
+        return best[1]
+
+    def _forward_native(self, videos, labels):
+        """The whole TAP step behind the C ABI: planned net hooked at the stages AND at the classifier's features; per step forward,
+        cross-entropy head (`i2v_head_ce_f32`), feature distance per stage (`i2v_tap_distance_f32`), one input-gradient pass over all
+        hooks; the smoothness term's gradient -- 1e3 / std * box(sign(box(perts))), the box filter being symmetric under zero
+        padding -- from the depthwise kernels; sign step.  One clip per call, like the reference (its cost is a (batch,)-vector)."""
+        eng, m = self.engine, self.model
+        dev = eng.device
+        videos = videos.to(dev).float().contiguous()
+        labels = labels.to(dev)
+        b, c, f, h, w = videos.shape
+        if b != 1:
+            raise RuntimeError("grad can be implicitly created only for scalar outputs")       # what autograd says in the reference
+        g = m.graph_for((f, h, w))
+        stages = [self._stage_output(g, p) for p in self._find_target_stages()]
+        cls = m.classifier_hook(g)
+        net = eng.build_net(g, m.state_dict_for(g), stages + cls, b * f)
+        W, bias = (t.to(dev) if t is not None else None for t in m.head_weights(g))
+        kw = dict(dtype=torch.float32, device=dev)
+        N = b * f
+        x, u = torch.empty(N, 3, h, w, **kw), torch.empty(N, 3, h, w, **kw)
+        eng.frames_from_video(videos, x, u)
+        net.forward(x)
+        ns = [net.hook_frames(i, N) for i in range(len(stages))]
+        clean = [net.save_hook(i, ns[i]).contiguous() for i in range(len(stages))]
+        std = torch.as_tensor(self.std, **kw)[:, None, None, None]
+        unnorm = self._unnorm(videos)
+        adv = videos.clone()
+        k, kt = int(self.kernlen), int(self.temporal_kernlen)
+        taps_s, taps_t = np.full(k, 1.0 / k, np.float32), np.full(kt, 1.0 / kt, np.float32)
+
+        def box(t):
+            t = eng.dwconv1d(eng.dwconv1d(t.contiguous(), taps_s, 4), taps_s, 3)
+            return eng.dwconv1d(t, taps_t, 2) if self.conv3d else t
+        logits, loss_each = torch.empty(b, W.shape[0], **kw), torch.empty(b, **kw)
+        hscratch = torch.empty(eng.capi.i2v_head_scratch_bytes(W.shape[1], b), dtype=torch.uint8, device=dev)
+        dist = [torch.empty(b, **kw) for _ in stages]
+        dscratch = [torch.empty(net.ilaf_scratch_bytes(i, ns[i], ns[i] // b), dtype=torch.uint8, device=dev) for i in range(len(stages))]
+        feats = list(range(len(stages), len(stages) + len(cls)))
+        self.loss_info = {}
+        gx = torch.empty_like(x)
+        for step in range(self.steps):
+            eng.frames_from_video(adv, x, u)
+            net.forward(x)
+            net.head_ce(feats[0] if len(feats) == 1 else feats, W, bias, labels.to(torch.int32).contiguous(), N, float(self._targeted),
+                        logits, loss_each, hscratch)
+            for i in range(len(stages)):
+                net.tap_distance(i, clean[i], 0.05, dist[i], dscratch[i], ns[i], ns[i] // b)
+            net.backward(gx)
+            grad = gx.view(b, f, 3, h, w).permute(0, 2, 1, 3, 4)
+            perts = ((adv - videos) / std).contiguous()                 # (sic) `_transform_perts` divides
+            smooth = box(perts)
+            grad = grad + 1e3 * box(torch.sign(smooth)) / std
+            self.loss_info[step] = {"ce loss": loss_each.mean().cpu().numpy(), "reg_cost": smooth.abs().sum().cpu().numpy(),
+                                    "distance": sum(d for d in dist).cpu().numpy()}
+            eng.sign_step(adv, unnorm, grad.contiguous(), f * h * w, self.step_size, self.epsilon)
+        net.close()
+        return adv
+
     def _smoothness(self, perts):
         k, kt = int(self.kernlen), int(self.temporal_kernlen)
         if self.conv3d:
@@ -402,6 +482,8 @@ class TAP(_SignAttack):
         return torch.sum(torch.abs(out))
 
     def forward(self, videos, labels):
+        if isinstance(self.model, VideoModel):
+            return self._forward_native(videos, labels)
         videos = videos.to(self.device).float().contiguous()
         labels = labels.to(self.device)
         b, c, f, h, w = videos.shape

@@ -246,6 +246,14 @@ int i2v_ilaf_reduce_seg_f32(const float* a, int64_t a_stride, const float* ori, 
 int i2v_ilaf_grad_seg_f32(const float* a, int64_t a_stride, const float* ori, const float* adv0, int64_t D,
                           int frames, int frames_per_seg, const double* init_sq, int mask_relu, int accumulate,
                           float* loss_out, float* grad, int64_t grad_stride, void* scratch, void* stream);
+/* Feature-distance term of base_attacks.TAP (`/root/reference/base_attacks.py:770-776`) over one hooked stage: per segment (clip) of
+ * frames_per_seg frames  dist = || r(a) - r(clean) ||_2 with r(x) = sign(x) sqrt|x|, written to dist_out[seg], and
+ * grad (+)= coef * d dist / d a  (0 where a == 0: the stage's own ReLU selects 0 there in the reference; 0 while dist == 0, as
+ * torch's norm backward).  `clean`: dense [frames][D] copy of the stage's activation on the clean clip; scratch as
+ * i2v_ilaf_scratch_bytes(D, frames, frames / frames_per_seg). */
+int i2v_tap_distance_f32(const float* a, int64_t a_stride, const float* clean, int64_t D, int frames, int frames_per_seg,
+                         double coef, int mask_relu, int accumulate, float* dist_out, float* grad, int64_t grad_stride,
+                         void* scratch, void* stream);
 /* Classifier head of a white-box video model and the cross-entropy gradient the BIM family starts from
  * (`attack.py:63-96` builds the classifier, `base_attacks.py:282-284`: `cost = targeted * CrossEntropyLoss()(model(adv), labels)`):
  * over the hooked LAST feature map (frame-major, clips*T frames of (C, HW)): global average pool over (T,H,W) ->

@@ -377,6 +377,7 @@ int k_std_grad(const I2VStdParams& p, i2v_stream_t) {
     return 0;
 }
 
+static float tap_root(float x) { return x > 0.f ? sqrtf(x) : (x < 0.f ? -sqrtf(-x) : 0.f); }
 int k_ilaf_reduce(const I2VIlafParams& p, i2v_stream_t) {
     std::vector<double> partial((size_t)p.N * p.nblk * 2);
     for (int n = 0; n < p.N; ++n) for (int blk = 0; blk < p.nblk; ++blk) {
@@ -386,7 +387,7 @@ int k_ilaf_reduce(const I2VIlafParams& p, i2v_stream_t) {
         for (int t = 0; t < 256; ++t) {
             volatile double dd = 0, dq = 0;
             for (int64_t i = lo + t; i < hi; i += 256) {
-                volatile float df = a[i] - o[i], d0f = a0[i] - o[i];
+                volatile float df = p.mode == 1 ? tap_root(a[i]) - tap_root(o[i]) : a[i] - o[i], d0f = p.mode == 1 ? 0.f : a0[i] - o[i];
                 const double d = df, d0 = d0f;
                 volatile double m1 = d * d, m2 = d * d0;
                 dd = dd + m1; dq = dq + m2;
@@ -407,6 +408,25 @@ int k_ilaf_reduce(const I2VIlafParams& p, i2v_stream_t) {
 int k_ilaf_grad(const I2VIlafParams& p, i2v_stream_t) {
     const int fps = p.fps > 0 ? p.fps : p.N, nseg = p.N / fps;
     for (int seg = 0; seg < nseg; ++seg) {
+    if (p.mode == 1) {                        // TAP feature distance (I2VIlafParams::mode)
+        const double dist = sqrt(p.sums[2 * seg]);
+        p.loss_out[seg] = (float)dist;
+        volatile double c = dist > 0.0 ? p.coef / dist : 0.0;
+        for (int n = seg * fps; n < (seg + 1) * fps; ++n) {
+            const float* a = p.a + (size_t)n * p.a_nstride; const float* o = p.ori + (size_t)n * p.D;
+            float* g = p.grad + (size_t)n * p.grad_nstride;
+            for (int64_t i = 0; i < p.D; ++i) {
+                float v = 0.f;
+                if (a[i] != 0.f && !(p.mask_relu && !(a[i] > 0.f))) {
+                    volatile float df = tap_root(a[i]) - tap_root(o[i]);
+                    volatile double t1 = c * (double)df, t2 = t1 * 0.5, t3 = t2 / (double)sqrtf(fabsf(a[i]));
+                    v = (float)t3;
+                }
+                g[i] = p.accumulate ? g[i] + v : v;
+            }
+        }
+        continue;
+    }
     const double s = sqrt(p.sums[2 * seg]), q = p.sums[2 * seg + 1], n0 = p.init_sq ? sqrt(p.init_sq[seg]) : p.init_norm;
     {
         volatile double t1 = 0.5 * s, t2 = t1 / n0, t3 = n0 * s, t4 = q / t3, t5 = t2 + t4;

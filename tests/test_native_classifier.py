@@ -277,3 +277,55 @@ def test_native_evaluator_classifier_gpu(model_type):
     vid = torch.randn(3, 3, *thw, generator=torch.Generator().manual_seed(5))
     got = video.NativeClassifier(m, engine=attacks.get_engine("cuda:0"))(vid.to("cuda:0")).cpu()
     np.testing.assert_allclose(got.double().numpy(), ref(vid.double()).detach().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def tap_twins(model_type, thw, seed, K):
+    """The native classifier and its float32 torch twin with the stages under gluoncv's names on the classifier itself (what TAP hooks)."""
+    g = graphs.build_video_tiny(model_type, thw, full=True)
+    m = video.VideoModel(model_type, thw, weight_seed=seed, tiny=True, num_classes=K)
+    W, b = m.head_weights(g)
+    back = vm.load_weights(vm.make(model_type, True, full=True), weights.synthetic_state_dict(g, seed)).float()
+    twin = vm.StageClassifier(back, W.shape[1], K)
+    with torch.no_grad():
+        twin.fc.weight.copy_(W); twin.fc.bias.copy_(b)
+    return m, twin.eval()
+
+
+def check_tap(eng, dev, model_type, conv3d):
+    """`base_attacks.TAP` with everything behind the C ABI (stages hooked in the planned net, `i2v_tap_distance_f32`, cross-entropy head,
+    box-filter smoothness gradient from the depthwise kernels) against the torch-module TAP of this repo -- itself pinned against the
+    imported reference class (tests/test_sign_family.py) -- on the twin of the same network: the three logged cost terms of every
+    step and the perturbed clip."""
+    thw, K = (8, 32, 32), 5
+    m, twin = tap_twins(model_type, thw, 4, K)
+    twin = twin.to(dev)
+    vid = (torch.randn(1, 3, *thw, generator=torch.Generator().manual_seed(21)) * 0.5).to(dev)
+    labels = torch.tensor([3])
+    params = dict(kernlen=3, temporal_kernlen=3, eta=1e3, conv3d=conv3d, model_type=model_type)
+    a_nat = sign_attacks.TAP(m, params, steps=3, engine=eng)
+    a_ref = sign_attacks.TAP(twin, params, steps=3, engine=eng)
+    out_n, out_r = a_nat(vid.clone(), labels).cpu(), a_ref(vid.clone(), labels).cpu()
+    for step in range(3):
+        for term, tol in (("ce loss", 2e-4), ("reg_cost", 2e-3), ("distance", 2e-4)):
+            got, want = float(np.asarray(a_nat.loss_info[step][term]).reshape(-1)[0]), float(np.asarray(a_ref.loss_info[step][term]).reshape(-1)[0])
+            # (from the third step on the two clips differ where a gradient was zero to rounding -- each such pixel a sign step apart)
+            assert abs(got - want) <= (tol if step < 2 else 1e-2) * max(1.0, abs(want)), (step, term, got, want)
+    first = [float(np.asarray(a_nat.loss_info[s]["distance"]).reshape(-1)[0]) for s in (0, 1)]
+    assert first[0] == 0.0 and first[1] > 0
+    assert float(((out_n - out_r).abs() < 1e-5).float().mean()) > 0.97
+    with pytest.raises(RuntimeError):
+        a_nat(torch.cat([vid, vid]), torch.tensor([3, 3]))                  # one clip per call, as in the reference
+
+
+@pytest.mark.parametrize("conv3d", [True, False])
+@pytest.mark.parametrize("model_type", ["i3d_plain_resnet50", "slowfast_resnet50"])
+def test_native_tap_hostsim(model_type, conv3d):
+    from tests.hostsim_util import hostsim_engine
+    check_tap(hostsim_engine(), "cpu", model_type, conv3d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_type", ["i3d_plain_resnet50", "slowfast_resnet50"])
+def test_native_tap_gpu(model_type):
+    from i2v_amd import attacks
+    check_tap(attacks.get_engine("cuda:0"), "cuda:0", model_type, True)

@@ -187,12 +187,14 @@ def test_sgm_gain_is_the_reference_hook():
     assert torch.allclose(mine, theirs, rtol=1e-5, atol=1e-7 * float(theirs.abs().max()))
 
 
-def test_tap_refuses_the_native_classifier_and_needs_model_type():
+def test_tap_needs_model_type_and_a_full_graph():
     from i2v_amd import video
     import base_attacks
-    m = video.VideoModel("i3d_resnet50", (8, 32, 32), weight_seed=0, tiny=True, num_classes=5)
-    with pytest.raises(NotImplementedError):
-        base_attacks.TAP(m, dict(kernlen=3, temporal_kernlen=3, eta=1e3, conv3d=True, model_type="i3d"), engine=hostsim_engine())
     from oracle import video_models
+    m = video.VideoModel("i3d_resnet50", (8, 32, 32), weight_seed=0, tiny=True, num_classes=5)
     with pytest.raises(AttributeError):                     # `model_type` is never set by the class itself (:737-743)
+        base_attacks.TAP(m, dict(kernlen=3, temporal_kernlen=3, eta=1e3, conv3d=True), engine=hostsim_engine())
+    with pytest.raises(KeyError):                           # native classifier: no TPN neck / head
+        base_attacks.TAP(m, dict(kernlen=3, temporal_kernlen=3, eta=1e3, conv3d=True, model_type="tpn_resnet50"), engine=hostsim_engine())
+    with pytest.raises(AttributeError):
         base_attacks.TAP(video_models.tiny_stage_classifier(), dict(kernlen=3, temporal_kernlen=3, eta=1e3, conv3d=True), engine=hostsim_engine())
