@@ -426,11 +426,17 @@ class TAP(_SignAttack):
         b, c, f, h, w = videos.shape
         if b != 1:
             raise RuntimeError("grad can be implicitly created only for scalar outputs")       # what autograd says in the reference
-        g = m.graph_for((f, h, w))
-        stages = [self._stage_output(g, p) for p in self._find_target_stages()]
-        cls = m.classifier_hook(g)
-        net = eng.build_net(g, m.state_dict_for(g), stages + cls, b * f)
-        W, bias = (t.to(dev) if t is not None else None for t in m.head_weights(g))
+        if self._net is None or self._net_key != (f, h, w):          # planned once per clip shape (packing, upload, autotuning)
+            if self._net is not None:
+                self._net.close()
+            g = m.graph_for((f, h, w))
+            self._tap_stages = [self._stage_output(g, p) for p in self._find_target_stages()]
+            self._tap_cls = m.classifier_hook(g)
+            self._net = eng.build_net(g, m.state_dict_for(g), self._tap_stages + self._tap_cls, b * f)
+            self._head = tuple(t.to(dev) if t is not None else None for t in m.head_weights(g))
+            self._net_key = (f, h, w)
+        net, stages, cls = self._net, self._tap_stages, self._tap_cls
+        W, bias = self._head
         kw = dict(dtype=torch.float32, device=dev)
         N = b * f
         x, u = torch.empty(N, 3, h, w, **kw), torch.empty(N, 3, h, w, **kw)
@@ -469,7 +475,6 @@ class TAP(_SignAttack):
             self.loss_info[step] = {"ce loss": loss_each.mean().cpu().numpy(), "reg_cost": smooth.abs().sum().cpu().numpy(),
                                     "distance": sum(d for d in dist).cpu().numpy()}
             eng.sign_step(adv, unnorm, grad.contiguous(), f * h * w, self.step_size, self.epsilon)
-        net.close()
         return adv
 
     def _smoothness(self, perts):
