@@ -325,6 +325,35 @@ def test_tile_configurations_are_bit_identical(eng, monkeypatch):
         assert torch.equal(f, outs[0][0]) and torch.equal(gx, outs[0][1])
 
 
+def test_batch_buckets_of_the_autotuner_are_bit_identical(eng):
+    """Round 3: a planned net keeps one tuned tile configuration per batch bucket (its planned size, 1/2, 1/4, 1/8 of it) and a call
+    picks the bucket that covers its frames -- whatever it picks, a frame's result is the one a net planned for exactly that batch
+    gives (every configuration computes the same k-ordered chain), image and video graph."""
+    for video_graph in (False, True):
+        if video_graph:
+            g = graphs.build_video_tiny("slowfast_resnet50", (8, 32, 32)); hooks = graphs.video_hooks(g, "slowfast_resnet50"); per, shape = 8, (32, 32)
+        else:
+            g = graphs.build_tiny("resnet", (64, 64)); hooks = [g.hooks[3]]; per, shape = 1, (64, 64)
+        sd = weights.synthetic_state_dict(g, 0)
+        big = eng.build_net(g, sd, hooks, 8 * per)
+        x = dev(torch.randn(8 * per, 3, *shape, generator=torch.Generator().manual_seed(3)))
+        for clips in (1, 2, 3, 5, 8):
+            n = clips * per
+            own = eng.build_net(g, sd, hooks, n)
+            outs = []
+            for net in (big, own):
+                net.forward(x[:n].contiguous())
+                feats = [net.save_hook(i, net.hook_frames(i, n)).cpu() for i in range(len(hooks))]
+                hg = [torch.randn(f.shape, generator=torch.Generator().manual_seed(7 + i)) for i, f in enumerate(feats)]
+                write_hook_grads(net, feats, hg)
+                gx = torch.empty(n, 3, *shape, device="cuda:0")
+                net.backward(gx)
+                outs.append((feats, gx.cpu()))
+            assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0])) and torch.equal(outs[0][1], outs[1][1]), (video_graph, clips)
+            own.close()
+        big.close()
+
+
 def test_halo_staging_is_bit_identical(eng, monkeypatch):
     """MODE 5 (`conv_igemm_halo`): 3x3 / stride-1 layers stage one halo row per channel and 16-channel group instead of nine shifted
     tile copies.  Forced onto every eligible launch (configuration 3 | 16; plane widths 14 / 28 / 56 are instantiated) of a VGG-style
