@@ -88,7 +88,7 @@ def cpu_baseline():
     Thread count: the best of {16, 32, 64} on a short probe (ATen/oneDNN slows down badly when
     over-subscribed: 256 threads on the GPU box's 2x64-core host is >20x slower than 16)."""
     from i2v_amd import graphs, weights
-    from oracle import restate
+    from oracle import restate, size_parity
     g = graphs.build(MODEL, (HW, HW))
     net = restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hooks[DEPTH]])
     vid = synthetic_clips(1)
@@ -103,28 +103,44 @@ def cpu_baseline():
         if best is None or dt < best:
             best, cores = dt, thr
     torch.set_num_threads(cores)
-    u = restate.unnormalise(x)
-    t0 = time.time()
-    init = [t.clone() for t in net.forward(x)]
-    t_clean = time.time() - t0
-    def one_iteration(delta, opt):
-        xn, mask = restate.compose(u, delta, 16 / 255)
-        feats = net.forward(xn)
-        _, gr = restate.cosine_fwd_bwd(feats[0], init[0])
-        opt.step(delta, restate.compose_backward(net.backward([gr]), mask))
-
-    delta = torch.full_like(x, 0.01 / 255)
-    one_iteration(delta, restate.AdamState(delta, 0.005))          # warm-up iteration (untimed)
-    delta = torch.full_like(x, 0.01 / 255)
-    opt = restate.AdamState(delta, 0.005)
-    t0 = time.time()
-    for _ in range(ATTACK_STEPS):
-        one_iteration(delta, opt)
-    t_iters = time.time() - t0
+    ora = size_parity.oracle_attack(net, vid, steps=ATTACK_STEPS, lr=0.005, warmup=True)
+    t_clean, t_iters = ora["t_clean"], ora["t_iters"]
     fps = FRAMES / (t_clean + t_iters)
-    return {"value": round(fps, 3), "unit": "adversarial frames/s", "cores": cores, "kind": "port",
+    base = {"value": round(fps, 3), "unit": "adversarial frames/s", "cores": cores, "kind": "port",
             "sample": f"1 clip x {FRAMES} frames x 224^2, ResNet-50 layer3: 1 warm-up iteration, then the whole attack timed -- "
                       f"clean pass {t_clean:.2f}s + {ATTACK_STEPS} iterations {t_iters:.2f}s on {cores} of {ncpu} host threads"}
+    return base, ora
+
+
+def parity_check(ora, costs, delta, adv, f64=False):
+    """The free-running rung of the parity ladder from the oracle run `cpu_baseline` pays for anyway:
+    the device's 10-step attack on the SAME clip (seed 1000) against the oracle's -- cost of every step and mean|delta_10| (the
+    well-conditioned quantities: bounded), and the perturbed pixels (chaotic under Adam's +-lr steps in ANY pair of fp32
+    implementations: reported; bounded only with `--parity-f64`, which pays for the float64 oracle as the yardstick --
+    `oracle/size_parity.py`, tests/test_gpu_size_parity.py).  The per-step atol-1e-4 contract is the teacher-forced rung's."""
+    from oracle import size_parity
+    st = size_parity.compare(costs, delta.cpu(), adv.cpu(), ora)
+    st64 = y32 = None
+    if f64:
+        from i2v_amd import graphs, weights
+        from oracle import restate
+        g = graphs.build(MODEL, (HW, HW))
+        net64 = restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hooks[DEPTH]], dtype=torch.float64)
+        ora64, y32 = size_parity.yardstick(net64, synthetic_clips(1), ora, steps=ATTACK_STEPS)
+        st64 = size_parity.compare(costs, delta.cpu(), adv.cpu(), ora64)
+    ok, bad = size_parity.within_bounds(st, st64, y32)
+    rnd = lambda d: {k: float(f"{v:.4g}") for k, v in d.items()}          # noqa: E731
+    out = rnd(st)
+    out.update({"against": "fp32 CPU oracle, free-running", "clip": "seed 1000, 1 x 32 x 224^2 (BASELINE.json configs[0])",
+                "steps": ATTACK_STEPS, "costs_device": [float(f"{c:.7g}") for c in costs],
+                "costs_oracle": [float(f"{c:.7g}") for c in ora["costs"]],
+                "bounds": {"max_rel_cost_err": size_parity.COST_RTOL, "mean_abs_delta_ratio": f"1 +- {size_parity.DELTA_MEAN_RTOL}",
+                           "pixel statistics": "held to the fp32 oracle's own distance from the float64 oracle "
+                                               f"(x{size_parity.ADV_DIFF_MARGIN}, -{size_parity.PIXEL_FRAC_SLACK}) when --parity-f64 is given"},
+                "within_bounds": bool(ok), "failures": bad})
+    if st64 is not None:
+        out["device_vs_f64_oracle"], out["fp32_oracle_vs_f64_oracle"] = rnd(st64), rnd(y32)
+    return out
 
 
 def parse_args(argv=None):
@@ -132,17 +148,21 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU")
+    ap.add_argument("--clips", type=int, default=None, help=f"clips per GPU and engine call (default {CLIPS_PER_GPU}; --workload ilaf: 8)")
     ap.add_argument("--white_model", default="slowfast_resnet50", help="--workload ilaf: video backbone (graphs.build_video)")
     ap.add_argument("--streams", type=int, default=3, help="--workload ilaf: engine calls in flight on separate HIP streams")
-    ap.add_argument("--ilaf_clips", type=int, default=8,
-                    help="--workload ilaf: clips per engine call, attacked as INDEPENDENT one-clip problems (ILAF.forward_independent: "
+    ap.add_argument("--ilaf_clips", type=int, default=None,
+                    help="--workload ilaf: the same as --clips (kept for older command lines; giving both is an error): clips per "
+                         "engine call (default 8), attacked as INDEPENDENT one-clip problems (ILAF.forward_independent: "
                          "per-clip loss segments, each clip bit-identical to its one-clip call; the reference runs one clip per call)")
     ap.add_argument("--workload", default="i2v", choices=["i2v", "ens", "aens", "config2", "ilaf"],
                     help="i2v = the headline metric (default); ens / aens = BASELINE configs[2]/[3]-style extras on the "
                          "reference's own model list (resnet101+vgg16+squeezenet1_1+alexnet); aens carries the one data-path "
                          "collective (2L floats all-reduced per step, TPAMI_attack.py:265,293-297) inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-f64", action="store_true",
+                    help="parity_check: also run the float64 oracle on the same clip (about a minute of host time) and hold the "
+                         "device's perturbed pixels to the fp32 oracle's own distance from it")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket backbone launches with HIP events in the timed region")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -154,7 +174,14 @@ def parse_args(argv=None):
     ap.add_argument("--selftest-hostsim", action="store_true",
                     help="FUNCTIONAL CHECK ONLY (no GPU): the rank plumbing on the CPU host simulation of the kernel backend "
                          "(tests/hostsim, tiny backbone, gloo); the line is labelled a non-measurement")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.clips is not None and args.ilaf_clips is not None and args.clips != args.ilaf_clips:
+        ap.error("--clips and --ilaf_clips both given with different values")
+    if args.workload == "ilaf":
+        args.clips = max(1, args.clips if args.clips is not None else (args.ilaf_clips if args.ilaf_clips is not None else 8))
+    elif args.clips is None:
+        args.clips = CLIPS_PER_GPU
+    return args
 
 
 def under_launcher():
@@ -338,7 +365,7 @@ def run_rank(args):
         atk = sign_attacks.ILAF(video.VideoModel(args.white_model, (FRAMES, HW, HW), weight_seed=0), args.white_model, engine=eng)
     else:
         atk = attacks.AENS_I2V_MF(names4, depths={n: [2, 3] for n in names4}, step_size=0.005, steps=ATTACK_STEPS, engine=eng, weight_seed=0)
-    b = max(1, args.ilaf_clips) if args.workload == "ilaf" else args.clips
+    b = args.clips
     if args.workload == "ilaf":
         atk.independent_clips = True
     if args.workload == "aens" and world > 1:
@@ -549,7 +576,13 @@ def run_rank(args):
         out["single_clip"] = single_clip
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.workload == "i2v":
-            out["cpu_baseline"] = cpu_baseline()
+            # device run of the clip the oracle is about to attack (seed 1000 = this rank's first clip), outside every timed region
+            atk.clip_lanes = None
+            adv1 = atk(videos[:1].contiguous(), labels[:1], names[:1])
+            torch.cuda.synchronize()
+            dev_costs, dev_delta = atk.last_costs.copy(), atk._delta.clone()
+            out["cpu_baseline"], ora = cpu_baseline()
+            out["parity_check"] = parity_check(ora, dev_costs, dev_delta, adv1, f64=args.parity_f64)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -422,8 +422,9 @@ def densenet(growth=32, block_config=(6, 12, 24, 16), init_features=64, bn_size=
 # not vendored and not installed; the graphs below restate the PUBLIC architectures (I3D: Carreira & Zisserman /
 # Wang et al. "3x1x1" inflation; SlowFast: Feichtenhofer et al.) up to the hooked stage.  Parity with gluoncv's
 # exact module layout and checkpoints is therefore UNPINNED; what is pinned is the arithmetic of every node
-# against `torch.nn.functional.conv3d / max_pool3d` (oracle/video_models.py).  Not built: the non-local blocks of
-# the `i3d_nl5_*` configs and TPN.
+# against `torch.nn.functional.conv3d / max_pool3d` (oracle/video_models.py).  The non-local blocks of the `i3d_nl5_*`
+# configs ARE built (`NL5_FREQ` below, the attention core behind `i2v_net_add_attention`): `'i3d_resnet50'` is that
+# network, `'i3d_plain_resnet50'` the one without them.  Not built: TPN's pyramid neck and heads (its ResNet backbone is).
 # ---------------------------------------------------------------------------
 NL5_FREQ = ((0, 0, 0), (0, 1, 0, 1), (0, 1, 0, 1, 0, 1), (0, 0, 0))     # gluoncv i3d_nl5: non-local blocks behind blocks 1, 3 of res3 and 1, 3, 5 of res4
 

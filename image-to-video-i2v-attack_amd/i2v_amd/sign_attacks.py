@@ -404,14 +404,19 @@ class TAP(_SignAttack):
 
     @staticmethod
     def _stage_output(graph, prefix):
+        """The tensor a forward hook on the stage MODULE sees (`base_attacks.py:700-711`): the output of the stage's last block --
+        which, where gluoncv's `i3d_nl5` appends a non-local block to a Bottleneck, is that block's `nonlocal_block.out`, not the
+        Bottleneck's own `.out`."""
         import re
         best = None
         for t, ts in enumerate(graph.tensors):
-            m = re.fullmatch(re.escape(prefix) + r"\.(\d+)\.out", ts.name or "")
-            if m and (best is None or int(m.group(1)) > best[0]):
-                best = (int(m.group(1)), t)
+            m = re.fullmatch(re.escape(prefix) + r"\.(\d+)(\.nonlocal_block)?\.out", ts.name or "")
+            if m:
+                key = (int(m.group(1)), m.group(2) is not None)
+                if best is None or key > best[0]:
+                    best = (key, t)
         if best is None:
-            raise KeyError(f"no stage {prefix!r} in graph {graph.name!r}")
+            raise KeyError(f"no stage {prefix!r} in graph {graph.arch!r}")
         return best[1]
 
     def _forward_native(self, videos, labels):
@@ -661,6 +666,14 @@ class ILAF(object):
         for i in range(L):                                                      # :563-567 |adv0 - ori| per layer
             net.ilaf_reduce(i, ori_f[i], adv_f[i], scratch, nf[i], act=adv_f[i], frames_per_seg=fps[i])
             init_sq[i].copy_(scratch[:4 * nseg].view(torch.float64).view(nseg, 2)[:, 0])
+        # A given adversarial clip whose hooked features equal its original's has no direction to follow: |adv0 - ori| = 0 makes
+        # every later loss and gradient of that segment 0/0 (the reference would return a NaN clip, :566-567).  One small
+        # read-back per call (60 steps) instead of a silently saved NaN file.
+        dead = (init_sq <= 0).any(dim=0).nonzero().flatten().tolist()
+        if dead:
+            who = [video_names[k] if independent and k < len(video_names) else k for k in dead]
+            raise ValueError(f"ILAF: the given adversarial clip equals its original at a hooked layer (|adv0 - ori| = 0), "
+                             f"nothing to fine-tune: {who}")
         modifier = torch.sub(u_adv, u_ori)                                      # :574-575 existing perturbation
         gx = torch.empty_like(x)
         loss = torch.zeros(L, nseg, **kw)

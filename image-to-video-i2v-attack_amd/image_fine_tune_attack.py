@@ -102,7 +102,13 @@ def main(argv=None, model_kwargs=None):
             got = []
             for step in todo[g0:g0 + group]:
                 print("Running {}, {}/{}".format(args.attack_method, step + 1, len(dataset)))
-                got.append(dataset[step])
+                vid, ori_vid, label = dataset[step]
+                if torch.equal(vid, ori_vid):        # no perturbation to fine-tune (ILAF's direction would be 0/0): skip, loudly
+                    print("Skipping {}: its adversarial clip equals its original".format(dataset.files[step]))
+                    continue
+                got.append((vid, ori_vid, label))
+            if not got:
+                continue
             yield (torch.cat([g[0] for g in got]), torch.cat([g[1] for g in got]), torch.cat([g[2] for g in got]), ["..."] * len(got))
     def save(_i, item, adv_batches):
         for ind, label in enumerate(item[2]):

@@ -48,6 +48,9 @@ def arg_parse(argv=None, ucf101=False):
     parser.add_argument("--frames", type=int, default=32)
     parser.add_argument("--hw", type=int, default=224)
     parser.add_argument("--resume", action="store_true")
+    parser.add_argument("--pin_cpus", action="store_true",
+                        help="hand-started shards only (no launcher): confine this process to slot batch_index-1 of batch_nums "
+                             "of the host's cores -- for a node running ALL batch_nums shards at once (run_image_guided.py)")
     parser.add_argument("--workers", type=int, default=2, help="loader threads (0: load in the reader thread itself)")
     parser.add_argument("--group_clips", type=int, default=4,
                         help="attack up to this many clips of READY loader batches in one engine call (I2V / ENS-I2V only; same clips, "
@@ -89,12 +92,17 @@ def main(argv=None, ucf101=False):
     args = arg_parse(argv, ucf101)
     if "LOCAL_RANK" not in os.environ:
         os.environ["LOCAL_RANK"] = args.gpu.split(",")[0]
-    # this shard's CPU cores, before anything touches the GPU; reader / writer / lane threads inherit them.  Under a launcher the
-    # ranks of the node; by hand (`--batch_nums 8 --batch_index k --gpu k`, run_image_guided.py) the shards of the node.
+    # This shard's CPU cores, before anything touches the GPU; reader / writer / lane threads inherit them.  Only where the
+    # placement is KNOWN: under a launcher (LOCAL_RANK / LOCAL_WORLD_SIZE are the ranks of this node), or by hand with
+    # `--pin_cpus` (`--batch_nums 8 --batch_index k --gpu k-1`, run_image_guided.py: the node's shards, slot = batch_index - 1).
+    # A lone hand-started shard (`--batch_nums 8 --batch_index 3 --gpu 0`) is NOT confined to an eighth of the host.
     from i2v_amd import affinity
-    lr = int(os.environ["LOCAL_RANK"]) if os.environ["LOCAL_RANK"].isdigit() else 0
-    lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", args.batch_nums)))
-    pinned = affinity.pin_rank(lr, lw) if lr < lw else None
+    pinned = None
+    if "LOCAL_WORLD_SIZE" in os.environ and os.environ["LOCAL_RANK"].isdigit():
+        lr, lw = int(os.environ["LOCAL_RANK"]), int(os.environ["LOCAL_WORLD_SIZE"])
+        pinned = affinity.pin_rank(lr, lw) if lr < lw else None
+    elif args.pin_cpus:
+        pinned = affinity.pin_rank(args.batch_index - 1, args.batch_nums) if 1 <= args.batch_index <= args.batch_nums else None
     if pinned:
         print("cpu affinity:", pinned)
     print(args)

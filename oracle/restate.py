@@ -339,6 +339,7 @@ def run_attack(nets: Sequence[OracleNet], videos: torch.Tensor, *, steps: int, s
             out["cos"].append(cosm.clone())
     xn, _ = compose(u, delta, epsilon)                              # :360-361
     out["adv"] = unflatten_frames(xn, b, f)
+    out["delta"] = delta                                            # the unconstrained Adam variable after the last step
     out["coeffs"] = coeffs
     return out
 

@@ -1,0 +1,116 @@
+"""TEST INFRASTRUCTURE -- the free-running rung of the parity ladder at BASELINE size.
+
+`oracle_attack` runs the CPU restatement's whole I2V attack (`restate.run_attack` arithmetic, spelled out here so that
+the clean pass and the iterations can be timed separately: `/root/reference/image_attacks.py:294-364`) on one synthetic
+clip of BASELINE.json configs[0] -- ResNet-50 layer3, 32 x 224^2, 10 steps -- and keeps what the ladder compares: the cost
+of every step, the final Adam variable and the perturbed clip.  `compare` turns a device run of the same clip into the
+four statistics of the rung.  Used by `tests/test_gpu_size_parity.py` and by `bench.py`'s `cpu_baseline` leg (which
+times the same run), never by the product package.
+
+Why statistics and not atol 1e-4: the free-running fp32 loop is chaotic (the reference against ITSELF with
+another summation order differs by > 1e-4 on 40 % of the pixels after 10 Adam steps, the cost trajectory agrees to ~1e-5);
+the per-step atol contract is held by the teacher-forced rungs (tests/golden/tf_*.npz, test_gpu_parity.py).
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import restate
+
+MEAN = torch.tensor(restate.MEAN).view(1, 3, 1, 1, 1)
+STD = torch.tensor(restate.STD).view(1, 3, 1, 1, 1)
+
+# The rung's bounds.  Costs and mean|delta| are well-conditioned (cost rel-err <= 1e-4...2e-4 per step,
+# mean|delta| within 1 %).  The perturbed PIXELS are not: Adam's first steps move every pixel by +-lr whatever the size of its
+# gradient, so each sign flip of a gradient component that is zero to rounding puts that pixel 2*lr away, in ANY pair of
+# correct fp32 implementations.  The yardstick for the pixel statistics is therefore the reference arithmetic's own distance
+# from exact arithmetic -- the fp32 oracle against the SAME oracle in float64 (`yardstick`) -- and the device run is held to
+# that distance times the margins below.
+COST_RTOL = 2e-4            # every step's cost, against the fp32 oracle and against the float64 oracle
+DELTA_MEAN_RTOL = 0.01      # mean|delta_S| of the two runs
+ADV_DIFF_MARGIN = 1.25      # mean|adv - adv_f64| of the device <= margin x mean|adv_f32oracle - adv_f64|
+PIXEL_FRAC_SLACK = 0.02     # share of pixel-channels within 2*lr of the f64 run: device >= fp32 oracle's share - slack
+
+
+def synthetic_clip(seed, frames=32, hw=224):
+    """uint8 noise (exact 0 / 255 pixels occur), ImageNet-normalised, (1,3,f,h,w)."""
+    gen = torch.Generator().manual_seed(seed)
+    u8 = torch.randint(0, 256, (1, 3, frames, hw, hw), generator=gen, dtype=torch.uint8)
+    return (u8.float() / 255 - MEAN) / STD
+
+
+def oracle_attack(net, vid, steps=10, lr=0.005, eps=16 / 255, warmup=False):
+    """One whole I2V attack of the oracle on `vid` (1,3,f,h,w).  Returns costs (steps,) float32, delta (N,3,h,w), adv
+    (1,3,f,h,w) and the wall time of the clean pass / the iterations.  `warmup`: one untimed iteration first."""
+    b, _, f, _, _ = vid.shape
+    x = restate.flatten_frames(vid).contiguous()
+    u = restate.unnormalise(x)                                          # image_attacks.py:308
+    t0 = time.time()
+    init = [t.clone() for t in net.forward(x)]                          # :318-323 (raw x)
+    t_clean = time.time() - t0
+
+    def iteration(delta, opt):
+        xn, mask = restate.compose(u, delta, eps)                       # :331-332
+        feats = net.forward(xn)                                         # :334
+        cs, gr = restate.cosine_fwd_bwd(feats[0], init[0])              # :341-347
+        opt.step(delta, restate.compose_backward(net.backward([gr]), mask))   # :351-353
+        return float(cs.sum())
+
+    if warmup:
+        d0 = torch.full_like(x, 0.01 / 255)
+        iteration(d0, restate.AdamState(d0, lr))
+    delta = torch.full_like(x, 0.01 / 255)                              # :304
+    opt = restate.AdamState(delta, lr)
+    costs = np.zeros(steps, np.float32)
+    t0 = time.time()
+    for i in range(steps):
+        costs[i] = iteration(delta, opt)
+    t_iters = time.time() - t0
+    xn, _ = restate.compose(u, delta, eps)                              # :360-361
+    return {"costs": costs, "delta": delta, "adv": restate.unflatten_frames(xn, b, f).contiguous(), "t_clean": t_clean,
+            "t_iters": t_iters, "lr": lr}
+
+
+def compare(costs, delta, adv, ora):
+    """The rung's statistics for a device run (`costs`, final `delta` (N,3,h,w), `adv` (b,3,f,h,w), CPU tensors) against the
+    oracle's `ora` of the same clip(s)."""
+    costs = np.asarray(costs, np.float64)
+    oc = np.asarray(ora["costs"], np.float64)
+    rel = np.abs(costs - oc) / np.abs(oc)
+    d_dev, d_ora = float(delta.float().abs().mean()), float(ora["delta"].float().abs().mean())
+    diff = (adv.float() - ora["adv"].float()).abs()
+    un = diff * STD                                                     # back to [0,1] pixel units
+    return {"max_rel_cost_err": float(rel.max()), "rel_cost_err_last_step": float(rel[-1]),
+            "mean_abs_delta_ratio": d_dev / d_ora, "mean_abs_adv_diff": float(diff.mean()),
+            "frac_pixels_within_2lr": float((un <= 2 * ora["lr"]).float().mean()),
+            "max_abs_adv_diff_pixel_units": float(un.max())}
+
+
+def yardstick(net64, vid, ora32, steps=10, lr=0.005, eps=16 / 255):
+    """The fp32 oracle's own distance from exact arithmetic on this clip: the same attack by the float64 oracle (same fp32
+    input values, same weights cast up) and `compare(fp32 oracle, f64 oracle)`.  Returns (ora64, stats32)."""
+    ora64 = oracle_attack(net64, vid.double(), steps=steps, lr=lr, eps=eps)
+    ora64["delta"], ora64["adv"] = ora64["delta"].float(), ora64["adv"].float()
+    return ora64, compare(ora32["costs"], ora32["delta"], ora32["adv"], ora64)
+
+
+def within_bounds(dev_vs_32, dev_vs_64=None, ora32_vs_64=None):
+    """The rung: costs and mean|delta| against the fp32 oracle (and, when the float64 run is at hand, against it too); the pixel
+    statistics against the float64 run, held to the fp32 oracle's own distance from it.  Returns (ok, list of failures)."""
+    bad = []
+    for tag, st in (("fp32 oracle", dev_vs_32), ("f64 oracle", dev_vs_64)):
+        if st is None:
+            continue
+        if not st["max_rel_cost_err"] <= COST_RTOL:
+            bad.append(f"cost trajectory vs {tag}: {st['max_rel_cost_err']:.3g} > {COST_RTOL}")
+        if not abs(st["mean_abs_delta_ratio"] - 1) <= DELTA_MEAN_RTOL:
+            bad.append(f"mean|delta| ratio vs {tag}: {st['mean_abs_delta_ratio']:.5f}")
+    if dev_vs_64 is not None and ora32_vs_64 is not None:
+        if not dev_vs_64["mean_abs_adv_diff"] <= ADV_DIFF_MARGIN * ora32_vs_64["mean_abs_adv_diff"]:
+            bad.append(f"mean|adv - adv_f64|: device {dev_vs_64['mean_abs_adv_diff']:.4g} > {ADV_DIFF_MARGIN} x fp32 oracle's "
+                       f"{ora32_vs_64['mean_abs_adv_diff']:.4g}")
+        if not dev_vs_64["frac_pixels_within_2lr"] >= ora32_vs_64["frac_pixels_within_2lr"] - PIXEL_FRAC_SLACK:
+            bad.append(f"pixels within 2*lr of the f64 run: device {dev_vs_64['frac_pixels_within_2lr']:.4f}, fp32 oracle "
+                       f"{ora32_vs_64['frac_pixels_within_2lr']:.4f}")
+    return not bad, bad

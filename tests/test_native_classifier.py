@@ -318,14 +318,14 @@ def check_tap(eng, dev, model_type, conv3d):
 
 
 @pytest.mark.parametrize("conv3d", [True, False])
-@pytest.mark.parametrize("model_type", ["i3d_plain_resnet50", "slowfast_resnet50"])
+@pytest.mark.parametrize("model_type", ["i3d_plain_resnet50", "i3d_resnet50", "slowfast_resnet50"])
 def test_native_tap_hostsim(model_type, conv3d):
     from tests.hostsim_util import hostsim_engine
     check_tap(hostsim_engine(), "cpu", model_type, conv3d)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model_type", ["i3d_plain_resnet50", "slowfast_resnet50"])
+@pytest.mark.parametrize("model_type", ["i3d_plain_resnet50", "i3d_resnet50", "slowfast_resnet50"])
 def test_native_tap_gpu(model_type):
     from i2v_amd import attacks
     check_tap(attacks.get_engine("cuda:0"), "cuda:0", model_type, True)

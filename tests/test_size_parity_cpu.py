@@ -1,0 +1,35 @@
+"""CPU: the free-running rung's machinery (`oracle/size_parity.py`: oracle attack, float64 yardstick, statistics, bounds) on a tiny
+backbone, with the planner's host simulation standing in for the device -- the `-m gpu` twin at BASELINE size is
+tests/test_gpu_size_parity.py.  Rung: `/root/reference/image_attacks.py:325-364`, SURVEY.md 7.3-1 (iv)."""
+import numpy as np
+import torch
+
+from i2v_amd import attacks, graphs, weights
+from oracle import restate, size_parity
+from tests.hostsim_util import hostsim_engine
+
+
+def test_rung_statistics_on_the_host_simulation():
+    eng = hostsim_engine()
+    vid = size_parity.synthetic_clip(1000, frames=4, hw=64)
+    g = graphs.build_tiny("resnet", (64, 64))
+    sd = weights.synthetic_state_dict(g, 0)
+    net32 = restate.OracleNet(g, sd, [g.hooks[3]])
+    net64 = restate.OracleNet(g, sd, [g.hooks[3]], dtype=torch.float64)
+    ora32 = size_parity.oracle_attack(net32, vid, steps=6, lr=0.005)
+    ref = restate.run_attack([net32], vid, steps=6, step_size=0.005)          # the same arithmetic as the pinned restatement
+    assert np.array_equal(ora32["costs"], ref["costs"]) and torch.equal(ora32["adv"], ref["adv"]) and torch.equal(ora32["delta"], ref["delta"])
+    ora64, y32 = size_parity.yardstick(net64, vid, ora32, steps=6, lr=0.005)
+    atk = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=3, step_size=0.005, steps=6, engine=eng,
+                                              graph_builder=graphs.build_tiny, weight_seed=0)
+    adv = atk(vid, torch.zeros(1, dtype=torch.long), ["c"])
+    st32 = size_parity.compare(atk.last_costs, atk._delta, adv, ora32)
+    st64 = size_parity.compare(atk.last_costs, atk._delta, adv, ora64)
+    ok, bad = size_parity.within_bounds(st32, st64, y32)
+    assert ok, (bad, st32, st64, y32)
+    # a run that is NOT the same attack fails the well-conditioned bounds
+    atk2 = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=3, step_size=0.004, steps=6, engine=eng,
+                                               graph_builder=graphs.build_tiny, weight_seed=0)
+    adv2 = atk2(vid, torch.zeros(1, dtype=torch.long), ["c"])
+    ok2, bad2 = size_parity.within_bounds(size_parity.compare(atk2.last_costs, atk2._delta, adv2, ora32))
+    assert not ok2 and bad2

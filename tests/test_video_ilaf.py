@@ -148,3 +148,8 @@ def test_independent_clips_in_one_call_match_one_clip_calls(name):
     # the coupled form (the reference's semantics for a b > 1 call) is a different computation
     coupled = make()(advs.float(), oris.float(), torch.zeros(3, dtype=torch.long), ["c0", "c1", "c2"])
     assert not torch.equal(coupled, got)
+    # a clip whose given adversarial equals its original has |adv0 - ori| = 0 at every hook: refused by name, not a NaN clip
+    advs2 = advs.clone().float()
+    advs2[1] = oris[1].float()
+    with pytest.raises(ValueError, match="c1"):
+        many.forward_independent(advs2, oris.float(), torch.zeros(3, dtype=torch.long), ["c0", "c1", "c2"])

@@ -7,7 +7,6 @@ G1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_AN
 G2="SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_MFMA SQ_ACTIVE_INST_SCA"
 i=0
 for bin in "$@"; do
-for args in ${SHAPES:-"32 256 256 14 3 4" "32 1024 256 14 1 4" "128 256 256 14 3 4"}; do :; done
 while read -r args; do
   i=$((i+1)); tag=$(basename $bin)_$(echo $args | tr ' ' '_')
   I2V_FORCE_CFG=${CFG:-3} rocprofv3 --kernel-trace --pmc $G1 -d $OUT/a_$tag -o p --output-format csv -- $R/$bin $args > $OUT/a_$tag.log 2>&1
