@@ -53,28 +53,9 @@ def batches(batch_size, csv_path=None, clip_dir=None, frames=32, hw=224, n=400, 
         clips = [torch.from_numpy(np.load(p)) if p else synthetic_clip(s + i, frames, hw)
                  for i, (_, _, p) in enumerate(chunk)]
         return torch.stack(clips), torch.tensor([c[1] for c in chunk]), [c[0] for c in chunk]
-    starts = list(range(0, len(items), batch_size))
-    if workers <= 0:
-        for s in starts:
-            yield load(s)
-        return
     # `workers` loader threads, a window of 2 x workers batches in flight, results in order (np.load and the synthetic
     # generator release the GIL): what the reference's DataLoader workers are for
-    import collections
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(workers) as ex:
-        window = collections.deque()
-        it = iter(starts)
-        for s in it:
-            window.append(ex.submit(load, s))
-            if len(window) >= 2 * workers:
-                break
-        while window:
-            out = window.popleft().result()
-            nxt = next(it, None)
-            if nxt is not None:
-                window.append(ex.submit(load, nxt))
-            yield out
+    yield from _prefetched(load, list(range(0, len(items), batch_size)), workers)
 
 
 def num_batches(batch_size, csv_path=None, clip_dir=None, n=400):
@@ -178,3 +159,123 @@ def pil_resample_table(n_in, n_out):
             coeffs[xx, x] = int(-0.5 + k * (1 << PIL_PRECISION_BITS)) if k < 0 else int(0.5 + k * (1 << PIL_PRECISION_BITS))
         bounds[xx] = (xmin, xmax)
     return bounds, coeffs, ksize
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# UCF-101 jpg-frame folders (`/root/reference/dataset_ucf101.py`): the clip list, the temporal selection and the
+# decoding -- everything in front of the loader's spatial transform, which runs on the device (`Engine.clip_resample_crop`).
+# Decoding is Pillow's (installed here, and what the reference calls, :14-18), so the reader is pinned by construction.
+# (The Kinetics-400 half of N4 -- decord reading mp4s, `datasets.py:188-244` -- is NOT buildable in this image: no decord,
+# PyAV, OpenCV or ffmpeg.  `--clip_dir` of `{label}-raw.npy` decoded frames is that half's entry point.)
+# ---------------------------------------------------------------------------------------------------------------
+def loop_padding(frame_indices, size=32):
+    """`transforms_ucf101.LoopPadding(size)` (:23-40), quirks included: the selection starts at the SECOND entry
+    (`frame_indices[1:size+1]`), and a clip shorter than `size + 1` frames is padded by cycling through that selection (the
+    reference appends to the list it is iterating over, which walks the growing list from its start)."""
+    out = list(frame_indices[1:size + 1])
+    k = 0
+    while len(out) < size and k < len(out):
+        out.append(out[k])
+        k += 1
+    return out
+
+
+def _load_index_list(path):
+    """The reference's `used_idxs.pkl` (a pickled list of ints, `dataset_ucf101.py:59-63`) -- read with an unpickler that
+    admits NO globals (a list of ints needs none; anything else in the file is refused) --, or a .json / whitespace-separated
+    text file holding the same list."""
+    if path.endswith(".pkl"):
+        import pickle
+
+        class _NoGlobals(pickle.Unpickler):
+            def find_class(self, module, name):
+                raise pickle.UnpicklingError(f"{path}: only a plain list of integers is accepted (found {module}.{name})")
+        with open(path, "rb") as fh:
+            idx = _NoGlobals(fh).load()
+    elif path.endswith(".json"):
+        import json
+        with open(path) as fh:
+            idx = json.load(fh)
+    else:
+        with open(path) as fh:
+            idx = fh.read().split()
+    return [int(i) for i in idx]
+
+
+def ucf101_clip_list(setting, image_root, used_idxs=None):
+    """`attack_ucf101._make_dataset` (:81-99) + the index selection (:59-64): [(frame directory, duration, label)] from the
+    lines `video_path duration label` of `test01_setting.txt`, reduced to the rows `used_idxs` names (a path to the index list,
+    a list of ints, or None = every row)."""
+    if not os.path.exists(setting):
+        raise RuntimeError("Setting file %s doesn't exist. Check opt.train-list and opt.val-list. " % setting)      # :83
+    rows = []
+    with open(setting) as fh:
+        for line in fh.readlines():
+            info = line.split()
+            if len(info) < 3:
+                raise RuntimeError("Video input format is not correct, missing one or more element. %s" % line)     # :91
+            rows.append((os.path.join(image_root, info[0]), int(info[1]), int(info[2])))
+    if used_idxs is None:
+        return rows
+    idx = _load_index_list(used_idxs) if isinstance(used_idxs, str) else [int(i) for i in used_idxs]
+    return [rows[i] for i in idx]
+
+
+def load_frame_folder(directory, frame_indices):
+    """`video_loader` + `pil_loader` (:14-18, 36-45): `image_{:05d}.jpg` of every index, decoded by Pillow and converted to
+    RGB; the list ENDS at the first missing file (as the reference's loader returns what it has).  uint8 (t,H,W,3)."""
+    from PIL import Image
+    frames = []
+    for i in frame_indices:
+        path = os.path.join(directory, "image_{:05d}.jpg".format(i))
+        if not os.path.exists(path):
+            break
+        with open(path, "rb") as fh:
+            with Image.open(fh) as img:
+                frames.append(np.asarray(img.convert("RGB")))
+    if not frames:
+        raise FileNotFoundError(f"no frames under {directory} (expected image_{{:05d}}.jpg)")
+    return np.stack(frames)
+
+
+def ucf101_batches(batch_size, setting, image_root, used_idxs=None, frames=32, workers=0):
+    """The UCF-101 loader (`attack_genearte_dataeset`, :103-110) up to its spatial transform: yields (uint8 (b,t,H,W,3) decoded
+    frames, labels (b,), names) in list order; the caller runs Scale / CornerCrop / ToTensor / Normalize on the device.  `workers`
+    decoder threads (Pillow releases the GIL while decoding) with 2 x workers batches in flight -- the reference's DataLoader
+    `num_workers=9`.  Clips of one batch must share their frame size (UCF-101: 240 x 320) and length (`frames`, LoopPadding)."""
+    rows = ucf101_clip_list(setting, image_root, used_idxs)
+
+    def load(s):
+        chunk = rows[s:s + batch_size]
+        clips_ = [load_frame_folder(d, loop_padding(list(range(1, dur + 1)), frames)) for d, dur, _ in chunk]     # :66-72
+        return (torch.from_numpy(np.stack(clips_)), torch.tensor([t for _, _, t in chunk]),
+                [os.path.basename(d) for d, _, _ in chunk])
+    starts = list(range(0, len(rows), batch_size))
+    yield from _prefetched(load, starts, workers)
+
+
+def ucf101_num_batches(batch_size, setting, image_root, used_idxs=None):
+    return (len(ucf101_clip_list(setting, image_root, used_idxs)) + batch_size - 1) // batch_size
+
+
+def _prefetched(load, starts, workers):
+    """`load(start)` for every start, in order, on `workers` threads with a window of 2 x workers results in flight."""
+    if workers <= 0:
+        for s in starts:
+            yield load(s)
+        return
+    import collections
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(workers) as ex:
+        window = collections.deque()
+        it = iter(starts)
+        for s in it:
+            window.append(ex.submit(load, s))
+            if len(window) >= 2 * workers:
+                break
+        while window:
+            out = window.popleft().result()
+            nxt = next(it, None)
+            if nxt is not None:
+                window.append(ex.submit(load, nxt))
+            yield out

@@ -48,6 +48,12 @@ def arg_parse(argv=None, ucf101=False):
     parser.add_argument("--frames", type=int, default=32)
     parser.add_argument("--hw", type=int, default=224)
     parser.add_argument("--resume", action="store_true")
+    if ucf101:           # the UCF-101 loader's inputs (dataset_ucf101.py:52-64, utils.UCF_IMAGE_ROOT): jpg frame folders + clip list
+        parser.add_argument("--frame_dir", type=str, default=os.environ.get("I2V_UCF_IMAGE_ROOT", ""),
+                            help="UCF_IMAGE_ROOT: <frame_dir>/<video_path>/image_00001.jpg ...; decoded by Pillow on the --workers threads")
+        parser.add_argument("--setting", type=str, default="./test01_setting.txt", help="lines `video_path duration label`")
+        parser.add_argument("--used_idxs", type=str, default="./used_idxs.pkl",
+                            help="rows of --setting to attack (the reference's pickled list of ints, or .json / text); '' = all rows")
     parser.add_argument("--pin_cpus", action="store_true",
                         help="hand-started shards only (no launcher): confine this process to slot batch_index-1 of batch_nums "
                              "of the host's cores -- for a node running ALL batch_nums shards at once (run_image_guided.py)")
@@ -106,7 +112,18 @@ def main(argv=None, ucf101=False):
     if pinned:
         print("cpu affinity:", pinned)
     print(args)
-    total = clips.num_batches(args.batch_size, args.anno, args.clip_dir, args.num_clips)
+    frame_dir = getattr(args, "frame_dir", "")
+    if frame_dir:        # UCF-101 jpg frame folders: clip list + LoopPadding(32) + Pillow decoding on the host, transform on the device
+        used = args.used_idxs or None
+        total = clips.ucf101_num_batches(args.batch_size, args.setting, frame_dir, used)
+
+        def source():
+            return clips.ucf101_batches(args.batch_size, args.setting, frame_dir, used, args.frames, workers=args.workers)
+    else:
+        total = clips.num_batches(args.batch_size, args.anno, args.clip_dir, args.num_clips)
+
+        def source():
+            return clips.batches(args.batch_size, args.anno, args.clip_dir, args.frames, args.hw, args.num_clips, workers=args.workers)
     nums_contained = int(total / args.batch_nums)                      # int(400 / batch_nums), :61
     left = (args.batch_index - 1) * nums_contained
     right = args.batch_index * nums_contained
@@ -133,8 +150,7 @@ def main(argv=None, ucf101=False):
         try:
             if cuda:
                 torch.cuda.set_device(device)      # per-thread state: pin_memory() would otherwise create a context on device 0
-            for step, item in enumerate(clips.batches(args.batch_size, args.anno, args.clip_dir, args.frames, args.hw, args.num_clips,
-                                                       workers=args.workers)):
+            for step, item in enumerate(source()):
                 if not (left <= step < right):
                     continue
                 if args.resume and all(os.path.exists(os.path.join(args.adv_path, f"{l.item()}-adv.npy")) for l in item[1]):
