@@ -1178,7 +1178,7 @@ static int autotune(Net& n) {
                 if (clips_b < 1 || (b > 0 && clips_b == (max_clips >> (b - 1)))) continue;
                 const int lf = clips_b * l.conv.Tg;             // grid frames of this launch at the bucket's size
                 if (lf * l.conv.Hg * l.conv.Wg == 0) continue;
-                int cand[8]; I2VConvParams probe = l.conv; probe.N = lf;
+                int cand[16]; I2VConvParams probe = l.conv; probe.N = lf;
                 const int nc = k_conv_candidates(probe, cand);
                 if (nc <= 1) { if (nc == 1) l.cfg_b[b] = cand[0] + 1; continue; }
                 float best = 1e30f; int best_c = -1;
@@ -1667,6 +1667,21 @@ extern "C" int i2v_dwconv1d_f32(const float* src, float* dst, int64_t outer, int
     if (!src || !dst || src == dst || !taps || outer <= 0 || len <= 0 || inner <= 0 || k <= 0 || k > 64 || !(k & 1))
         return fail("i2v_dwconv1d_f32: bad argument (odd k <= 64, out of place)");
     CHECK_BE(k_dwconv1d(src, dst, outer, len, inner, taps, k, stream));
+    return 0;
+}
+
+extern "C" int64_t i2v_grad_post_scratch_bytes(int b, int c, int f, int h, int w, int mode) {
+    if (b <= 0 || c <= 0 || f <= 0 || h <= 0 || w <= 0 || mode < 0 || mode > 4) return 0;
+    int64_t ge = 0; const int G = k_grad_post_groups(b, c, f, h, w, mode, &ge);
+    return (int64_t)(G > 0 ? G : 1) * k_grad_post_splits(ge) * 8 + 64;
+}
+
+extern "C" int i2v_grad_post_f32(const float* g, float* momentum, float* out, int b, int c, int f, int h, int w, int frame_major, int mode,
+                                 float decay, void* scratch, void* stream) {
+    if (!g || !out || g == out || b <= 0 || c <= 0 || f <= 0 || h <= 0 || w <= 0 || mode < 0 || mode > 4 || (mode > 0 && !scratch) ||
+        (int64_t)b * c * f * h * w >= (1ll << 31))
+        return fail("i2v_grad_post_f32: bad argument (out of place, mode 0..4, < 2^31 elements)");
+    CHECK_BE(k_grad_post(g, momentum, out, b, c, f, h, w, frame_major, mode, decay, (double*)scratch, stream));
     return 0;
 }
 

@@ -64,6 +64,11 @@ int k_resample_nearest(const float* src, float* dst, int64_t planes, int Hs, int
                        const int32_t* map_x, i2v_stream_t s);
 int k_resample_nearest_bwd(const float* g, float* gsrc, int64_t planes, int Hd, int Wd, int Hs, int Ws, const int32_t* ylo,
                            const int32_t* yhi, const int32_t* xlo, const int32_t* xhi, i2v_stream_t s);
+// gradient post-processing (i2v_grad_post_f32): groups / splits of the mean-abs reduction, then the fused apply pass
+int k_grad_post_groups(int b, int c, int f, int h, int w, int mode, int64_t* group_elems);     // number of groups, elements per group
+int k_grad_post_splits(int64_t group_elems);
+int k_grad_post(const float* g, float* momentum, float* out, int b, int c, int f, int h, int w, int frame_major, int mode, float decay,
+                double* partial, i2v_stream_t s);
 int k_dwconv1d(const float* src, float* dst, int64_t outer, int len, int64_t inner, const float* taps /*host [k]*/, int k, i2v_stream_t s);
 int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t s);
 int k_aens_reduce(const float* cos, const float* coeffs, int L, int frames, float* feat_sum,

@@ -146,6 +146,7 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 #ifndef I2V_BIG_WPE
 #define I2V_BIG_WPE 3
 #endif
+
 static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi, int MODE = 0) {
     return (BD == 64 && BP == 64) ? (PREF ? (I2V_DEEP && MODE == 1 && I2V_DEEP_STAGES > 3 ? 4 /* 32 KB of LDS: the 5th block does not fit beside the runtime's own */ : I2V_PREF_WPE) : I2V_SMALL_WPE) : (BD == 128 && BP == 64) ? I2V_TALL_WPE : BD * BP == 8192 ? I2V_MID_WPE : BD * BP == 16384 ? I2V_BIG_WPE : (hi ? 8 : 1);
 }
@@ -153,9 +154,9 @@ static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi, int
 // The pointwise variant with prefetched epilogue operands (short K, HBM-bound) stages four chunks instead of two (conv_tile, DEEP)
 static constexpr bool conv_deep(int MODE, bool PREF) { return I2V_DEEP && PREF && MODE == 1; }
 // LDS floats one tile needs: operand staging [NST][KC][BD] + [NST][KC][BP], re-used by the epilogue as a [WD*FR][BP] transpose buffer
-template <int BD, int BP, int WD, bool MF16, int NST = 2>
+template <int BD, int BP, int WD, bool MF16, int NST = 2, int CPB = 1>
 constexpr int conv_lds_floats() {
-    constexpr int stage = NST * I2V_KC * (BD + BP), epi = WD * (MF16 ? 16 : 32) * BP;
+    constexpr int stage = NST * CPB * I2V_KC * (BD + BP), epi = WD * (MF16 ? 16 : 32) * BP;
     return stage > epi ? stage : epi;
 }
 
@@ -168,7 +169,12 @@ constexpr int conv_halo_lds_floats() {
 
 // One tile of the implicit GEMM.  `bid` of `nwg` blocks share `n_cd_tiles` channel tiles per pixel tile, the first pixel tile
 // starting at pixel `px_base` (a launch may be cut into regions with different tile shapes, conv_igemm_tail below).
-template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false, int HWM = 0>
+// CPB ("chunks per barrier", round 4): an LDS buffer holds CPB consecutive K chunks and the loop synchronises once per CPB chunks --
+// the same packing, k-table and k order (results are bit-identical), half the vmcnt(0) / barrier / first-fragment round trips per
+// MFMA.  Those are what a block that is alone on its CU (an under-filled launch: a single 32-frame clip leaves the 14x14 layers
+// with 1.5 tiles per CU) cannot hide behind a neighbour.  Costs LDS (64x64: 32 KB, 5 resident blocks), so it is one more
+// configuration of the autotuner (bit 6), for launches whose chunk count is a multiple of CPB.
+template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false, int HWM = 0, int CPB = 1>
 __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd_tiles, const int bid, const int nwg, const int64_t px_base,
                                           float* const smem, I2V_PROBE_T& probe, const int probe_slot, const int prio_arg = I2V_PRIO_LEVELS) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-resource types and LDS-DMA builtins exist only in the device pass
@@ -188,8 +194,10 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     constexpr bool HALO = MODE == 5;
     constexpr int HS = HALO ? BP + 2 * HWM + 2 : 1, HQ = (HS + 63) / 64;
     static_assert(!HALO || (HWM > 0 && BD == 64 && BP == 64 && !PREF && !PRE && !VID && !MF16), "halo staging: the plain 64x64 image tile only");
-    float (*As)[KC][BD] = reinterpret_cast<float (*)[KC][BD]>(smem);
-    float (*Bs)[KC][BP] = reinterpret_cast<float (*)[KC][BP]>(smem + NST * KC * BD);
+    static_assert(CPB == 1 || (!HALO && !DEEP && !PREF && !PRE && MODE != 4 && MODE != 0), "several chunks per barrier: the plain pointwise / tap-uniform loops only");
+    constexpr int KB = CPB * KC;                              // K rows per LDS buffer
+    float (*As)[KB][BD] = reinterpret_cast<float (*)[KB][BD]>(smem);
+    float (*Bs)[KB][BP] = reinterpret_cast<float (*)[KB][BP]>(smem + NST * KB * BD);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wd = wave / WP, wpx = wave % WP;
@@ -265,19 +273,21 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     // One DMA instruction of this wave's share of a K chunk.  Piece j (compile-time) of the NL = NAQ + NBQ pieces a wave
     // issues per chunk: j < NAQ is a 16-byte piece of the weight tile, the others are pieces of the activation tile.
     // `vb_` is the per-lane byte offset of the chunk's tap (MODE 2; computed once per chunk by I2V_CHUNK_VB).
-#define I2V_ISSUE_PIECE(j_, k0_, buf_, vb_)                                                               \
+#define I2V_ISSUE_PIECE(j_, k0_, buf_, vb_) I2V_ISSUE_PIECE_SUB(j_, k0_, buf_, vb_, 0)
+    // ... `sub_`: which of the buffer's CPB chunks the piece belongs to (its rows start at sub_ * KC)
+#define I2V_ISSUE_PIECE_SUB(j_, k0_, buf_, vb_, sub_)                                                     \
     {                                                                                                     \
         constexpr int jj = (j_);                                                                          \
         const int k0 = (k0_);                                                                             \
         if constexpr (jj < NAQ) {                                                                         \
             const int ins = wv + 4 * jj;                                                                  \
             if (NA % 4 == 0 || ins < NA)                                                                  \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(&As[buf_][0][0] + ins * 256), 16, aoff[jj],  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(&As[buf_][(sub_) * KC][0] + ins * 256), 16, aoff[jj],  \
                                                          k0 * p.Cdpad * 4, 0, 0);                         \
         } else {                                                                                          \
             constexpr int q = jj - NAQ;                                                                   \
             const int ins = wv + 4 * q;                                                                   \
-            float* const bbuf = &Bs[buf_][0][0];                                                          \
+            float* const bbuf = &Bs[buf_][(sub_) * KC][0];                                                \
             if (NB % 4 == 0 || ins < NB) {                                                                \
                 if constexpr (PW) {                                                                       \
                     unsigned v = boff[q];                                                                 \
@@ -372,7 +382,10 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     constexpr int KR = MF16 ? 4 : 2;                                    // K rows per MFMA (32x32x2 / 16x16x4)
     constexpr int KS = KC / KR;                                         // k-steps per chunk
     constexpr int PPS = (NL + KS - 1) / KS;                             // DMA pieces issued behind each k-step
-    I2VKEntry e_next = I2VKEntry{0, 0, 0, 0};
+    I2VKEntry e_next[CPB];                                              // MODE 2: k-table rows of the chunks of the next-but-one buffer fill
+#pragma unroll
+    for (int h = 0; h < CPB; ++h) e_next[h] = I2VKEntry{0, 0, 0, 0};
+    const int nsuper = nchunks / CPB;                                   // loop iterations (k_conv offers CPB > 1 only when it divides)
     // MODE 4: which of this lane's B-fragment elements are real taps.  Element e of run-quad qi is dw = quad_dw0 + 4 qi + e; it
     // counts if it lies inside the kernel (4 qi + e < quad_kw) and inside the row.  16x16x4: a lane's element is lk, k-step s
     // is quad s of the chunk; 32x32x2: k-step s is half (s & 1) of quad s >> 1, element 2 (s & 1) + lk.  A chunk holds 4
@@ -482,17 +495,21 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
             }(std::make_integer_sequence<int, NT>{});
             gbuf ^= 1;
         }
-    } else {   // prologue: chunk 0 (and the k-table row of chunk 1)
-        unsigned vb0 = OOB;
+    } else {   // prologue: the first buffer fill(s) (and the k-table rows of the next one)
+        unsigned vb0[CPB];
+#pragma unroll
+        for (int h = 0; h < CPB; ++h) vb0[h] = OOB;
         if constexpr (MODE == 2) {
-            const I2VKEntry e0 = load_kentry(p.ktab, 0);
-            vb0 = I2V_CHUNK_VB(e0);
-            e_next = load_kentry(p.ktab, nchunks > 1 ? KC : 0);
+#pragma unroll
+            for (int h = 0; h < CPB; ++h) { const I2VKEntry e0 = load_kentry(p.ktab, h * KC); vb0[h] = I2V_CHUNK_VB(e0); }
+#pragma unroll
+            for (int h = 0; h < CPB; ++h) e_next[h] = load_kentry(p.ktab, (nsuper > 1 ? CPB + h : h) * KC);
         }
         (void)vb0;
-        for (int c0 = 0; c0 < AHEAD && c0 < nchunks; ++c0) {
-            [&]<int... J>(std::integer_sequence<int, J...>) { (([&] { I2V_ISSUE_PIECE(J, c0 * KC, c0, vb0); }()), ...); }
-            (std::make_integer_sequence<int, NL>{});
+        for (int c0 = 0; c0 < AHEAD && c0 < nsuper; ++c0) {
+            [&]<int... J>(std::integer_sequence<int, J...>) {
+                (([&] { constexpr int sub = J / NL; I2V_ISSUE_PIECE_SUB(J % NL, (c0 * CPB + sub) * KC, c0, vb0[sub], sub); }()), ...);
+            }(std::make_integer_sequence<int, CPB * NL>{});
         }
     }
     // Progress-ordered priority (round 3).  The per-block timeline of a launch (tools/conv_microbench.cpp -DCMB_PROBE) shows that
@@ -511,7 +528,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     const int prio_hi = (nchunks >= 16 && !PREF && nwg >= 3 * 256) ? prio_arg : 0;
     int prio_lvl = prio_hi, prio_next = 0, prio_step = 0;
     if (prio_hi > 0) {
-        prio_step = (nchunks + prio_hi) / (prio_hi + 1); prio_next = prio_step;
+        prio_step = (nsuper + prio_hi) / (prio_hi + 1); prio_next = prio_step;
         if (prio_hi >= 3) __builtin_amdgcn_s_setprio(3); else if (prio_hi == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
     }
     // DEEP (round 3; the pointwise variant with prefetched epilogue operands, i.e. K <= 256 and HBM-bound): four LDS buffers, the
@@ -523,7 +540,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     auto chunk_body = [&](const int c, const int buf, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;                // a chunk c+AHEAD exists: its DMA is issued here
         if constexpr (DEEP) {
-            const int younger = nchunks - 1 - c < AHEAD - 1 ? nchunks - 1 - c : AHEAD - 1;      // chunks behind c already issued
+            const int younger = nsuper - 1 - c < AHEAD - 1 ? nsuper - 1 - c : AHEAD - 1;      // chunks behind c already issued
             if (NST > 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
             else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -534,11 +551,17 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
             prio_next += prio_step; --prio_lvl;
             if (prio_lvl == 2) __builtin_amdgcn_s_setprio(2); else if (prio_lvl == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
-        unsigned vb = OOB;
+        unsigned vb[CPB];
+#pragma unroll
+        for (int h = 0; h < CPB; ++h) vb[h] = OOB;
         if constexpr (MORE && MODE == 2) {
-            vb = I2V_CHUNK_VB(e_next);                                  // tap of chunk c+1 (row fetched last iteration)
-            const int c2 = c + 2 < nchunks ? c + 2 : nchunks - 1;
-            e_next = load_kentry(p.ktab, c2 * KC);                      // prefetch the row of chunk c+2
+#pragma unroll
+            for (int h = 0; h < CPB; ++h) vb[h] = I2V_CHUNK_VB(e_next[h]);      // taps of the next fill's chunks (rows fetched last iteration)
+#pragma unroll
+            for (int h = 0; h < CPB; ++h) {
+                const int c2 = (c + 2) * CPB + h < nchunks ? (c + 2) * CPB + h : nchunks - 1;
+                e_next[h] = load_kentry(p.ktab, c2 * KC);                       // prefetch the rows of the fill after that
+            }
         }
         (void)vb;
         float fa[2][TD], fb[2][TP];
@@ -564,11 +587,11 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         [&]<int... S>(std::integer_sequence<int, S...>) {
             (([&] {
                 constexpr int s = S, set = S & 1;
-                if constexpr (s + 1 < KS) read_frags(s + 1, set ^ 1);
+                if constexpr (s + 1 < CPB * KS) read_frags(s + 1, set ^ 1);
                 __builtin_amdgcn_sched_barrier(0);          // keep the NEXT step's LDS reads in front of this step's MFMAs
                 if constexpr (PRE) {
                     typedef const __attribute__((address_space(4))) float* cfp;       // scalar (SMEM) loads
-                    const int kr = c * KC + 2 * s;
+                    const int kr = c * KB + 2 * s;
                     const float sc = lk ? ((cfp)p.pre_scale)[kr + 1] : ((cfp)p.pre_scale)[kr];
                     const float sh = lk ? ((cfp)p.pre_shift)[kr + 1] : ((cfp)p.pre_shift)[kr];
 #pragma unroll
@@ -585,19 +608,23 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
                     [&]<int... Q>(std::integer_sequence<int, Q...>) {
                         (([&] {
                             constexpr int jp = s * PPS + Q;
-                            if constexpr (jp < NL) I2V_ISSUE_PIECE(jp, (c + AHEAD) * KC, DEEP ? (buf + AHEAD) % NST : (buf ^ 1), vb);
+                            if constexpr (jp < CPB * NL) {
+                                constexpr int sub = jp / NL;
+                                I2V_ISSUE_PIECE_SUB(jp % NL, ((c + AHEAD) * CPB + sub) * KC, DEEP ? (buf + AHEAD) % NST : (buf ^ 1), vb[sub], sub);
+                            }
                         }()), ...);
                     }(std::make_integer_sequence<int, PPS>{});
                 }
             }()), ...);
-        }(std::make_integer_sequence<int, KS>{});
+        }(std::make_integer_sequence<int, CPB * KS>{});
     };
     if constexpr (!HALO) {
         int c = 0, buf = 0;
-        for (; c + AHEAD < nchunks; ++c) { chunk_body(c, buf, std::true_type{}); buf = buf + 1 == NST ? 0 : buf + 1; }
-        for (; c < nchunks; ++c) { chunk_body(c, buf, std::false_type{}); buf = buf + 1 == NST ? 0 : buf + 1; }
+        for (; c + AHEAD < nsuper; ++c) { chunk_body(c, buf, std::true_type{}); buf = buf + 1 == NST ? 0 : buf + 1; }
+        for (; c < nsuper; ++c) { chunk_body(c, buf, std::false_type{}); buf = buf + 1 == NST ? 0 : buf + 1; }
     }
 #undef I2V_ISSUE_PIECE
+#undef I2V_ISSUE_PIECE_SUB
 #undef I2V_CHUNK_VB
     if (prio_hi > 0) __builtin_amdgcn_s_setprio(0);
     probe.loop_end(probe_slot);
@@ -824,6 +851,20 @@ conv_igemm_halo(const I2VConvParams p, const int n_cd_tiles) {
     probe.exit(blockIdx.x);
 }
 
+// Several chunks per barrier (conv_tile, CPB): the plain 64x64 image tile with 32-row LDS buffers -- 32 KB, 5 resident blocks.
+#ifndef I2V_DC_WPE
+#define I2V_DC_WPE 5
+#endif
+template <int MODE, int CPB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(I2V_DC_WPE, I2V_DC_WPE)))
+conv_igemm_dc(const I2VConvParams p, const int n_cd_tiles) {
+    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<64, 64, 2, false, 2, CPB>()];
+    I2V_PROBE_T probe;
+    probe.entry();
+    conv_tile<64, 64, 2, 2, MODE, false, false, false, false, 0, CPB>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x);
+    probe.exit(blockIdx.x);
+}
+
 // "Tail split": the first `nA` blocks compute 64x64 tiles over the pixel tiles [0, px_base_b / 64); the remaining blocks cover the
 // rest of the pixels with 16x64 tiles on 16x16x4 fragments (a quarter of the work each).  A launch of 6.125 tiles per CU leaves
 // 32 CUs with 7 tiles and 224 with 6; cut this way it is 6 tiles everywhere plus 128 quarter tiles on 128 CUs.  Every output
@@ -875,6 +916,11 @@ static bool conv_halo_ok(const I2VConvParams& p) {
            p.Ws == p.Wg && (p.Ws == 14 || p.Ws == 28 || p.Ws == 56) && p.Kpad == p.K && (p.Kpad / I2V_KC) % 9 == 0;
 }
 
+// CPB = 2 applies (autotuner bit 6): a plain pointwise / tap-uniform image launch with an even chunk count and a full 64-row tile
+static bool conv_dc_ok(const I2VConvParams& p) {
+    return (p.pointwise || p.tap_uniform) && !p.temporal && !p.pre_scale && !p.quad && p.Cd > 32 && (p.Kpad / I2V_KC) % 2 == 0 && p.Kpad >= 4 * I2V_KC;
+}
+
 template <int BD, int BP, int WD, int WP, bool MF16 = false>
 static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     const int64_t P = (int64_t)p.N * p.Hg * p.Wg;
@@ -896,6 +942,12 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
             else if (p.Ws == 28) hipLaunchKernelGGL((conv_igemm_halo<28>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
             else hipLaunchKernelGGL((conv_igemm_halo<56>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
             LAUNCH_CHECK("conv_igemm_halo");
+            return 0;
+        }
+        if (p.cfg > 0 && ((p.cfg - 1) & 64) && conv_dc_ok(p)) {
+            if (p.pointwise) hipLaunchKernelGGL((conv_igemm_dc<1, 2>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+            else hipLaunchKernelGGL((conv_igemm_dc<2, 2>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+            LAUNCH_CHECK("conv_igemm_dc");
             return 0;
         }
         if (p.cfg > 0 && ((p.cfg - 1) & 32)) {
@@ -990,6 +1042,8 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
     else if (conv_tail_px_tiles(p) > 0 && p.Cd > 32) out[n++] = 3 | 32;      // 64x64 with the remainder tiles cut into quarter tiles
     static const bool no_halo = [] { const char* e = getenv("I2V_HALO"); return e && e[0] == '0'; }();
     if (conv_halo_ok(p) && p.Cd > 32 && !no_halo) out[n++] = 3 | 16;         // 64x64 with halo staging (MODE 5)
+    static const bool no_dc = [] { const char* e = getenv("I2V_DC"); return e && e[0] == '0'; }();
+    if (conv_dc_ok(p) && !no_dc) out[n++] = 3 | 64;                          // 64x64 with two chunks per barrier (32-row LDS buffers)
     if (p.Cd <= 16) out[n++] = 5;                        // 16x256 tile on 16x16x4 MFMA fragments
     return n;
 }
@@ -1115,6 +1169,71 @@ __global__ void __launch_bounds__(256) pool_bwd_kernel(const I2VPoolParams p, co
     }
 }
 
+// Round 4: the 3 / 2 / 1 window of the ResNet stems (112^2 -> 56^2, 540 MB per launch at 128 frames -- three quarters of them the
+// gradient it WRITES) as a patch kernel.  The generic gather above spends ~150 instructions per float4 (two runtime divisions, a
+// window loop with byte compares per element: 2.2 TB/s of algorithmic bytes, 0.28 of the HBM peak).  Here a thread owns a 2 x 4
+// input patch (rows 2a, 2a+1; columns 4b .. 4b+3): the windows that can point into it are the 2 x 3 outputs (a .. a+1, 2b .. 2b+2),
+// read from LDS once; which of them covers which element, and with which window-relative index, is a compile-time table (an even
+// row / column is the centre of one window, an odd one the edge of two), so an element is <= 4 compare-select-adds -- in the
+// generic kernel's order (output row, then output column), hence bit-identical to it and to the scalar restatement.
+__global__ void __launch_bounds__(256) pool_bwd_321_kernel(const I2VPoolParams p, const int band_pairs, const unsigned w4_m, const unsigned w4_s) {
+    __shared__ float gs[POOL_LDS_FLOATS / 2];
+    __shared__ uint8_t is[POOL_LDS_FLOATS / 2];
+    const int plane = blockIdx.x, n = plane / p.C, c = plane - n * p.C;
+    const int a0 = blockIdx.y * band_pairs, a1 = min(a0 + band_pairs, p.Hs >> 1);      // pair rows [a0, a1) = input rows [2 a0, 2 a1)
+    const int ho_lo = a0, ho_hi = min(a1, p.Ho - 1);                                     // output rows [a0, min(a1, Ho - 1)]
+    const float* gy = p.y + (int64_t)n * p.y_nstride + (int64_t)c * p.Ho * p.Wo;
+    const float* yv = p.yact ? p.yact + (int64_t)n * p.yact_nstride + (int64_t)c * p.Ho * p.Wo : nullptr;
+    const uint8_t* ix = p.idx + (int64_t)plane * p.Ho * p.Wo;
+    const int cnt = (ho_hi - ho_lo + 1) * p.Wo;
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        float g = gy[ho_lo * p.Wo + e];
+        if (yv && !(yv[ho_lo * p.Wo + e] > 0.f)) g = 0.f;       // gate folded into the staged upstream gradient
+        gs[e] = g; is[e] = ix[ho_lo * p.Wo + e];
+    }
+    __syncthreads();
+    float* gx = p.gx + (int64_t)n * p.gx_nstride + (int64_t)c * p.Hs * p.Ws;
+    const int W4 = p.Ws >> 2, items = (a1 - a0) * W4;
+    for (int e = threadIdx.x; e < items; e += 256) {
+        const int al = (int)fastdiv((unsigned)e, w4_m, w4_s), b = e - al * W4, a = a0 + al;
+        // the 2 x 3 windows (output rows a, a+1; columns 2b, 2b+1, 2b+2); rows / columns past the pooled plane contribute nothing
+        float g[2][3]; int ix6[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const bool in = (a + r) <= ho_hi && (2 * b + q) < p.Wo;
+                const int li = (al + r) * p.Wo + 2 * b + q;
+                g[r][q] = in ? gs[li] : 0.f;
+                ix6[r][q] = in ? (int)is[li] : 255;
+            }
+        // element (row parity rp, column u): windows in (output row, output column) order with their window-relative index kr * 3 + ks.
+        // row 2a: window row a with kr = 1; row 2a+1: window rows a (kr = 2) and a+1 (kr = 0).
+        // column 4b: window column 2b, ks = 1; 4b+1: 2b (ks = 2), 2b+1 (ks = 0); 4b+2: 2b+1, ks = 1; 4b+3: 2b+1 (ks = 2), 2b+2 (ks = 0).
+        float o[2][4];
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float acc = 0.f;
+#pragma unroll
+                for (int wr = 0; wr < (rp ? 2 : 1); ++wr) {
+                    const int kr = rp ? (wr ? 0 : 2) : 1;
+#pragma unroll
+                    for (int wc = 0; wc < ((u & 1) ? 2 : 1); ++wc) {
+                        const int q = (u >> 1) + ((u & 1) ? wc : 0) + ((u == 2) ? 0 : 0);       // window column 2b + q
+                        const int ks = (u & 1) ? (wc ? 0 : 2) : 1;
+                        if (ix6[wr][q] == kr * 3 + ks) acc += g[wr][q];
+                    }
+                }
+                o[rp][u] = acc;
+            }
+        float* row = gx + (int64_t)(2 * a) * p.Ws + 4 * b;
+        *reinterpret_cast<float4*>(row) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+        *reinterpret_cast<float4*>(row + p.Ws) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+    }
+}
+
 __global__ void avgpool_fwd_kernel(const I2VPoolParams p) {
     const int64_t total = (int64_t)p.N * p.C * p.Ho * p.Wo;
     const float inv = 1.f / (float)(p.k * p.k);
@@ -1171,7 +1290,16 @@ int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s) {
     if (band < 1) return pool_fail("max-pool row too wide for the LDS band");
     if (band > p.Hs) band = p.Hs;
     dim3 grid((unsigned)(p.N * p.C), (unsigned)((p.Hs + band - 1) / band));
-    if (p.k == 3 && p.stride == 2 && p.pad == 1) hipLaunchKernelGGL((pool_bwd_kernel<3, 2, 1>), grid, dim3(256), 0, (hipStream_t)s, p, band);
+    if (p.k == 3 && p.stride == 2 && p.pad == 1 && (p.yact || !p.mask_relu) && (p.Ws & 3) == 0 && (p.Hs & 1) == 0 && p.Ho * 2 == p.Hs && p.Wo * 2 == p.Ws &&
+        (((uintptr_t)p.gx | (uintptr_t)(p.gx_nstride * 4)) & 15) == 0) {
+        // patch kernel: bands of pair rows whose output rows (one more than the pairs) fit the LDS buffers
+        int pairs = (POOL_LDS_FLOATS / 2) / p.Wo - 1;
+        if (pairs < 1) return pool_fail("max-pool row too wide for the LDS band");
+        if (pairs > p.Hs / 2) pairs = p.Hs / 2;
+        uint32_t m, sh; fastdiv_magic((unsigned)(p.Ws >> 2), &m, &sh);
+        dim3 g2((unsigned)(p.N * p.C), (unsigned)((p.Hs / 2 + pairs - 1) / pairs));
+        hipLaunchKernelGGL(pool_bwd_321_kernel, g2, dim3(256), 0, (hipStream_t)s, p, pairs, m, sh);
+    } else if (p.k == 3 && p.stride == 2 && p.pad == 1) hipLaunchKernelGGL((pool_bwd_kernel<3, 2, 1>), grid, dim3(256), 0, (hipStream_t)s, p, band);
     else if (p.k == 2 && p.stride == 2 && p.pad == 0) hipLaunchKernelGGL((pool_bwd_kernel<2, 2, 0>), grid, dim3(256), 0, (hipStream_t)s, p, band);
     else if (p.k == 3 && p.stride == 2 && p.pad == 0) hipLaunchKernelGGL((pool_bwd_kernel<3, 2, 0>), grid, dim3(256), 0, (hipStream_t)s, p, band);
     else hipLaunchKernelGGL((pool_bwd_kernel<0, 0, 0>), grid, dim3(256), 0, (hipStream_t)s, p, band);
@@ -2144,6 +2272,78 @@ int k_dwconv1d(const float* src, float* dst, int64_t outer, int len, int64_t inn
     hipLaunchKernelGGL(dwconv1d_kernel, dim3(stream_grid(total, 1024)), dim3(256), 0, (hipStream_t)s, src, dst, total, len, inner, t, k);
     LAUNCH_CHECK("dwconv1d"); return 0;
 }
+// ---- gradient post-processing of the sign-step family (i2v_grad_post_f32): mean-abs / L1 normalisation, momentum, layout -------------
+// Element e of group q sits at base(q) + (e / inner) * outer_stride + (e % inner) in the clip layout; `fm` maps a clip-layout offset to
+// the frame-major gradient the backbone wrote.
+struct GradPost {
+    const float* g; float* mom; float* out; double* partial;
+    int B, C, F, H, W, fm, mode, splits; float decay;
+    int64_t ge;
+};
+__device__ __forceinline__ int64_t gp_src(const GradPost& p, int64_t o) {           // clip-layout offset -> offset in `g`
+    if (!p.fm) return o;
+    const int HW = p.H * p.W; const int i = (int)(o % HW); int64_t r = o / HW;
+    const int f = (int)(r % p.F); r /= p.F; const int c = (int)(r % p.C); const int64_t b = r / p.C;
+    return ((b * p.F + f) * p.C + c) * (int64_t)HW + i;
+}
+__device__ __forceinline__ int64_t gp_elem(const GradPost& p, int q, int64_t e) {   // element e of group q -> clip-layout offset
+    const int64_t HW = (int64_t)p.H * p.W, CFHW = (int64_t)p.C * p.F * HW;
+    switch (p.mode) {
+        case 1: { const int b = q / p.F, f = q - b * p.F; return b * CFHW + (e / HW) * (p.F * HW) + f * HW + e % HW; }
+        case 2: return (int64_t)q * CFHW + e;
+        case 3: { const int b = q / p.W, wcol = q - b * p.W; return b * CFHW + e * p.W + wcol; }
+        default: return e;
+    }
+}
+__global__ void __launch_bounds__(256) grad_post_reduce_kernel(const GradPost p) {
+    __shared__ double red[256];
+    const int q = blockIdx.x, sp = blockIdx.y;
+    const int64_t per = (p.ge + p.splits - 1) / p.splits, e0 = sp * per, e1 = min(e0 + per, p.ge);
+    double acc = 0.0;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) acc += (double)fabsf(p.g[gp_src(p, gp_elem(p, q, e))]);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) p.partial[(int64_t)q * p.splits + sp] = red[0];
+}
+__global__ void __launch_bounds__(256) grad_post_apply_kernel(const GradPost p, const int64_t total) {
+    const int64_t HW = (int64_t)p.H * p.W, CFHW = (int64_t)p.C * p.F * HW;
+    for (int64_t o = blockIdx.x * 256ll + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        float v = p.g[gp_src(p, o)];
+        if (p.mode) {
+            const int b = (int)(o / CFHW);
+            const int q = p.mode == 1 ? b * p.F + (int)((o / HW) % p.F) : p.mode == 2 ? b : p.mode == 3 ? b * p.W + (int)(o % p.W) : 0;
+            double sum = 0.0;
+            for (int sidx = 0; sidx < p.splits; ++sidx) sum += p.partial[(int64_t)q * p.splits + sidx];
+            const float den = p.mode == 4 ? (float)sum : (float)sum / (float)p.ge;          // ||g||_1, or mean|g| (fp32 quotient as torch.mean)
+            v = v / den;
+        }
+        if (p.mom) { v = v + p.mom[o] * p.decay; p.mom[o] = v; }
+        p.out[o] = v;
+    }
+}
+int k_grad_post_groups(int b, int c, int f, int h, int w, int mode, int64_t* ge) {
+    const int64_t HW = (int64_t)h * w;
+    switch (mode) {
+        case 1: *ge = c * HW; return b * f;
+        case 2: *ge = (int64_t)c * f * HW; return b;
+        case 3: *ge = (int64_t)c * f * h; return b * w;
+        case 4: *ge = (int64_t)b * c * f * HW; return 1;
+        default: *ge = 0; return 0;
+    }
+}
+int k_grad_post_splits(int64_t ge) { const int64_t s = (ge + 65535) / 65536; return (int)(s < 1 ? 1 : (s > 256 ? 256 : s)); }
+int k_grad_post(const float* g, float* momentum, float* out, int b, int c, int f, int h, int w, int frame_major, int mode, float decay,
+                double* partial, i2v_stream_t s) {
+    GradPost p{g, momentum, out, partial, b, c, f, h, w, frame_major, mode, 1, decay, 0};
+    const int G = k_grad_post_groups(b, c, f, h, w, mode, &p.ge);
+    p.splits = k_grad_post_splits(p.ge);
+    if (mode) { hipLaunchKernelGGL(grad_post_reduce_kernel, dim3((unsigned)G, (unsigned)p.splits), dim3(256), 0, (hipStream_t)s, p); LAUNCH_CHECK("grad_post_reduce"); }
+    const int64_t total = (int64_t)b * c * f * h * w;
+    hipLaunchKernelGGL(grad_post_apply_kernel, dim3(stream_grid(total, 1024)), dim3(256), 0, (hipStream_t)s, p, total);
+    LAUNCH_CHECK("grad_post_apply"); return 0;
+}
+
 int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t s) {
     hipLaunchKernelGGL(aens_coeffs_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, prev, coeffs, momentum, L);
     LAUNCH_CHECK("aens_coeffs"); return 0;

@@ -217,6 +217,22 @@ class Engine:
                                                          C.c_void_p(k.ctypes.data), len(k), self.stream()))
         return out
 
+    GRAD_POST_MODES = {None: 0, "frame": 1, "clip": 2, "column": 3, "l1": 4}
+
+    def grad_post(self, g: torch.Tensor, shape, mode=None, momentum=None, decay=1.0, frame_major=False) -> torch.Tensor:
+        """The step between the input gradient and the sign step, fused (`i2v_grad_post_f32`): mean-abs (`'frame'` / `'clip'` /
+        `'column'`) or L1 (`'l1'`) normalisation, `+ decay * momentum` with the momentum updated in place, and -- `frame_major` -- the
+        change from the backbone's (b*f,c,h,w) gradient to the clip layout.  Returns the (b,c,f,h,w) gradient."""
+        b, c, f, h, w = (int(v) for v in shape)
+        m = self.GRAD_POST_MODES[mode]
+        g = g.contiguous()
+        out = torch.empty(b, c, f, h, w, dtype=torch.float32, device=g.device)
+        nbytes = int(self.capi.i2v_grad_post_scratch_bytes(b, c, f, h, w, m))
+        scratch = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=g.device)
+        _lib.check(self.capi, self.capi.i2v_grad_post_f32(_ptr(g, self), _ptr(momentum, self) if momentum is not None else None, _ptr(out, self),
+                                                          b, c, f, h, w, 1 if frame_major else 0, m, float(decay), C.c_void_p(scratch.data_ptr()), self.stream()))
+        return out
+
     def aens_coeffs(self, prev, coeffs, momentum):
         _lib.check(self.capi, self.capi.i2v_aens_coeffs_f32(_ptr(prev, self), _ptr(coeffs, self), momentum, coeffs.numel(), self.stream()))
 

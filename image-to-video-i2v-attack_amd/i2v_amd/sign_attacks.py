@@ -23,6 +23,20 @@ MEAN = [0.485, 0.456, 0.406]
 STD = [0.229, 0.224, 0.225]
 
 
+_ANNOUNCED = set()
+
+
+def _announce(obj):
+    """Every sign-family / ILAF object says, once per (class, path), which of its two calling conventions it runs on: `native` (a
+    `VideoModel`: every launch behind the C ABI) or `torch-module` (the reference's convention: the caller's torch module, its
+    gradient from PyTorch autograd, only the update rule native) -- so that a torch-module run is never mistaken for the product."""
+    key = (type(obj).__name__, obj.path)
+    if key not in _ANNOUNCED:
+        _ANNOUNCED.add(key)
+        print(f"[i2v_amd] {key[0]}: path = {obj.path}" + ("" if obj.path == "native" else
+              " (model and its gradient run in PyTorch; pass an i2v_amd.video.VideoModel for the native path)"), flush=True)
+
+
 def norm_grads(grads, frame_level=True):
     """`/root/reference/utils.py:58-67` (asserts 32 frames like the reference)."""
     assert len(grads.shape) == 5 and grads.shape[2] == 32
@@ -38,6 +52,8 @@ class _SignAttack(object):
         self.model = model
         self.model_name = str(model).split("(")[0]
         self.training = model.training
+        self.path = "native" if isinstance(model, VideoModel) else "torch-module"
+        _announce(self)
         if isinstance(model, VideoModel):     # native classifier: graph IR + head, everything behind the C ABI (`_grad_native`)
             if model.num_classes is None:
                 raise ValueError("a VideoModel used as a classifier needs num_classes (its head)")
@@ -65,7 +81,8 @@ class _SignAttack(object):
     def _grad_native(self, adv, labels):
         """`autograd.grad(targeted * CrossEntropyLoss()(model(adv), labels), adv)` (base_attacks.py:282-286) without
         autograd: frames -> 3-D backbone to its last stage -> pool / fc / softmax-CE head and its gradient -> input
-        gradient, all in libi2v_hip.so.  Returns the gradient in the clip layout (b,3,f,h,w)."""
+        gradient, all in libi2v_hip.so.  Returns the backbone's input gradient as it is written, FRAME-major (b*f,3,h,w): the change
+        to the clip layout rides along in the fused post-processing pass (`_post_native`, `i2v_grad_post_f32`)."""
         eng, m = self.engine, self.model
         b, c, f, h, w = adv.shape
         N = b * f
@@ -89,16 +106,37 @@ class _SignAttack(object):
         net.head_ce(feats, W, bias, labels.to(eng.device).to(torch.int32).contiguous(), N, float(self._targeted), logits, loss_each, scratch)
         gx = torch.empty_like(x)
         net.backward(gx)
-        self.last_logits, self.last_loss = logits, loss_each.mean()
-        return gx.view(b, f, 3, h, w).permute(0, 2, 1, 3, 4).contiguous()
+        self.last_logits, self._loss_each = logits, loss_each
+        return gx
+
+    @property
+    def last_loss(self):
+        """Mean cross-entropy of the last native gradient call (read on demand: no framework kernel inside the step)."""
+        return self._loss_each.mean()
+
+    def _post_native(self, g, state, shape, mode=None, momentum=False):
+        """Native path: frame-major gradient -> [normalisation `mode`] -> [+ decay * momentum, momentum updated] -> clip layout, one fused
+        pass of the library (no framework kernel between the backward pass and the sign step)."""
+        mom = None
+        if momentum:
+            if "momentum" not in state:
+                state["momentum"] = torch.zeros(tuple(shape), dtype=torch.float32, device=self.engine.device)
+            mom = state["momentum"]
+        return self.engine.grad_post(g, shape, mode, momentum=mom, decay=getattr(self, "decay", 1.0), frame_major=True)
 
     def _relu_gain(self, graph):
         """{ReLU-output tensor: backward gain} for the native classifier's planned net (SGM); None: plain gradients."""
         return None
 
+    def _grad_step(self, adv, labels):
+        """The gradient as the step loops consume it: frame-major (b*f,3,h,w) on the native path (`_pre_native` / `_post_native` turn it
+        into the clip layout in their fused pass), the clip layout from autograd on the torch-module path."""
+        return self._grad_native(adv, labels) if self.path == "native" else self._grad(adv, labels)
+
     def _grad(self, adv, labels):
+        """d(targeted * CE) / d adv in the clip layout (b,3,f,h,w), whichever path."""
         if isinstance(self.model, VideoModel):
-            return self._grad_native(adv, labels)
+            return self.engine.grad_post(self._grad_native(adv, labels), adv.shape, None, frame_major=True)
         adv.requires_grad = True
         cost = self._targeted * nn.CrossEntropyLoss()(self.model(adv), labels)
         return torch.autograd.grad(cost, adv, retain_graph=False, create_graph=False)[0]
@@ -122,7 +160,9 @@ class FGSM(_SignAttack):
     def forward(self, videos, labels):
         videos = videos.to(self.device).float().contiguous()
         labels = labels.to(self.device)
-        grad = self._grad(videos.clone().detach(), labels).contiguous()
+        grad = self._grad_step(videos.clone().detach(), labels).contiguous()
+        if self.path == "native":
+            grad = self._post_native(grad, {}, videos.shape)
         adv = videos.clone().detach()
         u = self._unnorm(videos)
         b, c, f, h, w = videos.shape
@@ -141,9 +181,13 @@ class BIM(_SignAttack):
     def _pre(self, grad, state):
         return grad
 
+    def _pre_native(self, g, state, shape):
+        """`_pre` on the native path: `g` is the frame-major input gradient; returns the clip-layout gradient the sign step takes."""
+        return self._post_native(g, state, shape)
+
     def _gradient(self, adv, labels):
         """The gradient the step starts from; subclasses put their input transforms here (DI, SI)."""
-        return self._grad(adv, labels)
+        return self._grad_step(adv, labels)
 
     def _l1_momentum(self, grad, state):
         """`grad /= |grad|_1; grad += momentum * decay; momentum = grad` (base_attacks.py:394-398 and its copies)."""
@@ -160,7 +204,8 @@ class BIM(_SignAttack):
         b, c, f, h, w = videos.shape
         state = {}
         for _ in range(self.steps):
-            grad = self._pre(self._gradient(adv, labels), state).contiguous()
+            g = self._gradient(adv, labels)
+            grad = self._pre_native(g, state, videos.shape) if self.path == "native" else self._pre(g, state).contiguous()
             adv = adv.detach()
             self.engine.sign_step(adv, u, grad, f * h * w, self.step_size, self.epsilon)   # :289-293
         return adv
@@ -179,6 +224,10 @@ class MIFGSM(BIM):
         grad = grad + state.get("momentum", torch.zeros_like(grad)) * self.decay
         state["momentum"] = grad
         return grad
+
+    def _pre_native(self, g, state, shape):
+        assert len(shape) == 5 and shape[2] == 32                        # norm_grads' own assertion (utils.py:59)
+        return self._post_native(g, state, shape, "frame", momentum=True)
 
 
 def _nearest_index(n_out: int, n_in: int):
@@ -232,7 +281,7 @@ class DIFGSM(BIM):
     def _gradient(self, adv, labels):
         draw = self._draw()
         if draw is None:
-            return self._grad(adv, labels)
+            return self._grad_step(adv, labels)
         rnd, top, left = draw
         b, c, f, h, w = adv.shape
         eng, dev = self.engine, self.engine.device
@@ -240,11 +289,14 @@ class DIFGSM(BIM):
         mx, xlo, xhi = diversity_maps(w, rnd, left)
         t = lambda a: torch.from_numpy(a).to(dev)                          # noqa: E731
         x = eng.resample_nearest(adv.detach().to(dev).float().contiguous(), t(my), t(mx))      # (b,3,f,224,224), :364-376
-        g = self._grad(x.to(adv.device), labels).to(dev).float().contiguous()
-        return eng.resample_nearest_bwd(g, (h, w), (t(ylo), t(yhi), t(xlo), t(xhi))).to(adv.device)
+        g = self._grad_step(x.to(adv.device), labels).to(dev).float().contiguous()
+        return eng.resample_nearest_bwd(g, (h, w), (t(ylo), t(yhi), t(xlo), t(xhi))).to(adv.device)     # (plane-wise: either layout)
 
     def _pre(self, grad, state):
         return self._l1_momentum(grad, state) if self.momentum else grad
+
+    def _pre_native(self, g, state, shape):
+        return self._post_native(g, state, shape, "l1" if self.momentum else None, momentum=bool(self.momentum))
 
 
 def gaussian_taps(kernlen=15, nsig=3):
@@ -279,6 +331,15 @@ class TIFGSM(BIM):
             state["momentum"] = grad
         return grad
 
+    def _smooth_native(self, g, shape):
+        """The same separable passes on the frame-major gradient (b*f,c,h,w): along W, then H."""
+        eng = self.engine
+        return eng.dwconv1d(eng.dwconv1d(g.contiguous(), self.taps, 3), self.taps, 2), "column"          # :440 (sic)
+
+    def _pre_native(self, g, state, shape):
+        g, mode = self._smooth_native(g, shape)
+        return self._post_native(g, state, shape, mode, momentum=bool(self.momentum))
+
 
 class TIFGSM3D(TIFGSM):
     """`base_attacks.py:612-675`: a 15 x 15 x 15 Gaussian over (T, H, W) (`conv3d`, groups 3, padding 7) -- three 1-D passes --, then the
@@ -294,6 +355,15 @@ class TIFGSM3D(TIFGSM):
         g = eng.dwconv1d(eng.dwconv1d(eng.dwconv1d(g, self.taps, 4), self.taps, 3), self.taps, 2)
         return norm_grads(g, True)
 
+    def _smooth_native(self, g, shape):
+        """Frame-major gradient viewed (b,f,c,h,w): along W, H, then T -- the torch-module path's pass order."""
+        eng = self.engine
+        b, c, f, h, w = shape
+        assert f == 32                                                      # norm_grads' own assertion (utils.py:59)
+        g5 = g.contiguous().view(b, f, c, h, w)
+        g5 = eng.dwconv1d(eng.dwconv1d(eng.dwconv1d(g5, self.taps, 4), self.taps, 3), self.taps, 1)
+        return g5.view(b * f, c, h, w), "frame"
+
 
 class SIM(BIM):
     """Scale-Invariant method (`base_attacks.py:554-610`): the mean of the gradients at the clip scaled by 1, 1/2, ... 1/2^(m-1), each
@@ -307,12 +377,15 @@ class SIM(BIM):
     def _gradient(self, adv, labels):
         mean_grad = None
         for i in range(self.sclae_step):
-            g = self._grad((1 / 2 ** i * adv).detach(), labels)             # :575-576
+            g = self._grad_step((1 / 2 ** i * adv).detach(), labels)        # :575-576
             mean_grad = g if mean_grad is None else mean_grad + g
-        return mean_grad / self.sclae_step
+        return mean_grad / self.sclae_step             # (the scaled inputs and this mean are framework elementwise ops on either path)
 
     def _pre(self, grad, state):
         return self._l1_momentum(grad, state) if self.momentum else grad
+
+    def _pre_native(self, g, state, shape):
+        return self._post_native(g, state, shape, "l1" if self.momentum else None, momentum=bool(self.momentum))
 
 
 class SGM(BIM):
@@ -356,6 +429,9 @@ class SGM(BIM):
 
     def _pre(self, grad, state):
         return self._l1_momentum(grad, state) if self.momentum else grad
+
+    def _pre_native(self, g, state, shape):
+        return self._post_native(g, state, shape, "l1" if self.momentum else None, momentum=bool(self.momentum))
 
 
 class TAP(_SignAttack):

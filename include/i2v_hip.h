@@ -293,6 +293,20 @@ int i2v_resample_nearest_bwd_f32(const float* g, float* gsrc, int64_t planes, in
  * [outer][len][inner] tensor, out of place: dst[o][i][j] = sum_t taps[t] * src[o][i + t - k/2][j].  TI-FGSM's 15 x 15 and
  * TI-FGSM-3D's 15 x 15 x 15 Gaussians (`base_attacks.py:412-441`, `:613-651`) are outer products of one 1-D kernel: two / three passes. */
 int i2v_dwconv1d_f32(const float* src, float* dst, int64_t outer, int len, int64_t inner, const float* taps, int k, void* stream);
+/* Gradient post-processing of the momentum / normalisation family between the input gradient and the sign step, fused (two launches, no
+ * atomics; replaces a chain of framework elementwise / reduction kernels):
+ *   utils.norm_grads (`utils.py:58-67`, MI-FGSM `base_attacks.py:326`, TI-FGSM-3D `:650`)  mode 1: g / mean|g| over (c,h,w), per (clip, frame)
+ *                                                                     (frame_level=False)    mode 2: ... over (c,f,h,w), per clip
+ *   TI-FGSM (`:440`, sic: mean over channels, frames and ROWS)                              mode 3: ... over (c,f,h), per (clip, column)
+ *   the L1 form of DI / SI / SGM (`:394`, `:545`, `:599`: grad / torch.norm(grad, p=1))     mode 4: g / sum|g| over everything
+ *   mode 0: no normalisation
+ * then, when `momentum` is given (`:327-329`, `:395-397`): out = g_normalised + decay * momentum; momentum = out.
+ * `g` is the gradient either in the clip layout (b,c,f,h,w) or -- `frame_major` != 0 -- as the backbone's input gradient (b*f,c,h,w);
+ * `out` / `momentum` are always (b,c,f,h,w), so the layout change rides along.  True division by the fp32 mean / norm (sums in
+ * double, fixed order).  `scratch`: i2v_grad_post_scratch_bytes(...) bytes. */
+int64_t i2v_grad_post_scratch_bytes(int b, int c, int f, int h, int w, int mode);
+int i2v_grad_post_f32(const float* g, float* momentum, float* out, int b, int c, int f, int h, int w, int frame_major, int mode, float decay,
+                      void* scratch, void* stream);
 /* Adaptive ENS-I2V re-weighting `coeffs = softmax(softmax(prev) + momentum*coeffs)`
  * (TPAMI_attack.py:265), L <= 64, in place on device. */
 int i2v_aens_coeffs_f32(const float* prev, float* coeffs, float momentum, int L, void* stream);

@@ -766,6 +766,41 @@ int k_dwconv1d(const float* src, float* dst, int64_t outer, int len, int64_t inn
     return 0;
 }
 
+// i2v_grad_post_f32 on the host: the same group enumeration, double sums, fp32 quotients
+int k_grad_post_groups(int b, int c, int f, int h, int w, int mode, int64_t* ge) {
+    const int64_t HW = (int64_t)h * w;
+    switch (mode) {
+        case 1: *ge = c * HW; return b * f;
+        case 2: *ge = (int64_t)c * f * HW; return b;
+        case 3: *ge = (int64_t)c * f * h; return b * w;
+        case 4: *ge = (int64_t)b * c * f * HW; return 1;
+        default: *ge = 0; return 0;
+    }
+}
+int k_grad_post_splits(int64_t) { return 1; }
+int k_grad_post(const float* g, float* momentum, float* out, int B, int C, int F, int H, int W, int fm, int mode, float decay, double*, i2v_stream_t) {
+    const int64_t HW = (int64_t)H * W, CFHW = (int64_t)C * F * HW, total = (int64_t)B * CFHW;
+    auto src = [&](int64_t o) -> int64_t {
+        if (!fm) return o;
+        const int64_t i = o % HW; int64_t r = o / HW; const int64_t f = r % F; r /= F; const int64_t c = r % C, b = r / C;
+        return ((b * F + f) * C + c) * HW + i;
+    };
+    auto group = [&](int64_t o) -> int64_t {
+        const int64_t b = o / CFHW;
+        return mode == 1 ? b * F + (o / HW) % F : mode == 2 ? b : mode == 3 ? b * W + o % W : 0;
+    };
+    int64_t ge = 0; const int G = k_grad_post_groups(B, C, F, H, W, mode, &ge);
+    std::vector<double> sum(G > 0 ? G : 1, 0.0);
+    if (mode) for (int64_t o = 0; o < total; ++o) sum[group(o)] += (double)fabsf(g[src(o)]);
+    for (int64_t o = 0; o < total; ++o) {
+        volatile float v = g[src(o)];
+        if (mode) { const float den = mode == 4 ? (float)sum[group(o)] : (float)sum[group(o)] / (float)ge; v = v / den; }
+        if (momentum) { volatile float m = momentum[o] * decay; v = v + m; momentum[o] = v; }
+        out[o] = v;
+    }
+    return 0;
+}
+
 int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t) {
     std::vector<float> a(L), b(L);
     float mx = -INFINITY, sum = 0.f;

@@ -389,6 +389,40 @@ def test_halo_staging_is_bit_identical(eng, monkeypatch):
     assert float(outs[0][1].abs().max()) > 0
 
 
+def test_two_chunks_per_barrier_is_bit_identical(eng, monkeypatch):
+    """`conv_igemm_dc` (round 4): 32-row LDS buffers, one barrier per TWO K chunks -- same packing, same k order.  Forced onto every
+    eligible launch (configuration 3 | 64: pointwise and tap-uniform layers with an even chunk count and > 32 output rows) of a
+    bottleneck-style stack -- forward and input-gradient launches, residual / gate epilogues, a stride-2 parity-class gradient,
+    pixel tails and tiles that straddle frames -- against the plain 64x64 configuration: features and input gradient bit for bit."""
+    monkeypatch.setenv("I2V_AUTOTUNE", "0")
+    g = graphs.Graph("dc_test", (28, 28))
+    x = g.new_tensor(3, 28, 28, False, "input")
+    g.input = x
+    a = g.conv(x, 64, 3, 1, 1, "a.weight", bn="a_bn", relu=True)              # K = 27: not eligible (per-row gather)
+    c = g.conv(a, 96, 1, 1, 0, "c.weight", bn="c_bn", relu=True)              # pointwise K = 64 (4 chunks), 96 rows
+    d = g.conv(c, 64, 3, 1, 1, "d.weight", bn="d_bn", relu=True)              # 3x3, K = 864 (54 chunks)
+    e = g.conv(d, 64, 1, 1, 0, "e.weight", bn="e_bn", relu=True, residual=a)  # expand with a residual (epilogue prefetch variant otherwise)
+    f = g.conv(e, 128, 3, 2, 1, "f.weight", bn="f_bn", relu=True)             # stride 2: parity-class input gradients
+    h = g.conv(f, 80, 1, 1, 0, "h.weight", bn="h_bn", relu=True)              # K = 128, 80 rows (a partial second channel tile)
+    g.hooks[1] = h
+    sd = weights.synthetic_state_dict(g, 0)
+    frames = 5
+    xin = dev(torch.randn(frames, 3, 28, 28, generator=torch.Generator().manual_seed(0)))
+    outs = []
+    for cfg in (3, 3 | 64):
+        monkeypatch.setenv("I2V_FORCE_CFG", str(cfg))
+        net = eng.build_net(g, sd, [h], frames)
+        net.forward(xin)
+        ft = net.save_hook(0, frames).cpu()
+        write_hook_grads(net, [ft], [torch.randn(ft.shape, generator=torch.Generator().manual_seed(1))])
+        gx = torch.empty(frames, 3, 28, 28, device="cuda:0")
+        net.backward(gx)
+        outs.append((ft, gx.cpu()))
+        net.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].abs().max()) > 0
+
+
 def test_tail_split_is_bit_identical(eng, monkeypatch):
     """`conv_igemm_tail`: the remainder tiles of a launch as 16x64 quarter tiles in the same grid.  Forced onto every eligible launch
     (configuration 3 | 32) of a net whose layers leave remainders of 64 / 16 pixel tiles over the 256 CUs (576 and 144+... tiles), against
