@@ -50,8 +50,10 @@ def arg_parse(argv=None):
     for f in IGNORED_FLAGS:
         parser.add_argument(f, action="store_true", default=False, help="parsed by the reference, read by nothing")
     # additions (not in the reference)
-    parser.add_argument("--model_factory", type=str, default="reference:proxy",
-                        help="pkg.module:function (name -> torch classifier), or 'native' for the I3D / SlowFast graphs with a native classifier head")
+    parser.add_argument("--model_factory", type=str, default="native",
+                        help="'native' (default): the I3D / SlowFast graphs with a native classifier head, every launch behind the C ABI; or "
+                             "pkg.module:function (name -> torch classifier; e.g. reference:proxy): the caller's torch module, its gradient from "
+                             "PyTorch autograd, only the update rule native -- the attack object prints which path it runs on")
     parser.add_argument("--num_classes", type=int, default=400)
     parser.add_argument("--anno", type=str, default=os.environ.get("I2V_ANNO", ""))
     parser.add_argument("--clip_dir", type=str, default="")

@@ -1685,6 +1685,26 @@ extern "C" int i2v_grad_post_f32(const float* g, float* momentum, float* out, in
     return 0;
 }
 
+extern "C" int64_t i2v_tap_scratch_bytes(int64_t) { return 1024 * 8 + 64; }
+
+extern "C" int i2v_tap_perts_f32(const float* adv, const float* videos, float* out, int b, int c, int f, int h, int w, void* stream) {
+    if (!adv || !videos || !out || b <= 0 || c != 3 || f <= 0 || h <= 0 || w <= 0) return fail("i2v_tap_perts_f32: bad argument (c == 3)");
+    CHECK_BE(k_tap_perts(adv, videos, out, b, c, f, h, w, stream));
+    return 0;
+}
+
+extern "C" int i2v_tap_sign_abs_f32(const float* smooth, float* sign_out, float* reg, int64_t n, void* scratch, void* stream) {
+    if (!smooth || !sign_out || !reg || !scratch || n <= 0) return fail("i2v_tap_sign_abs_f32: bad argument");
+    CHECK_BE(k_tap_sign_abs(smooth, sign_out, reg, n, (double*)scratch, stream));
+    return 0;
+}
+
+extern "C" int i2v_tap_grad_f32(const float* gx, const float* boxsign, float* out, int b, int c, int f, int h, int w, float weight, void* stream) {
+    if (!gx || !boxsign || !out || gx == out || b <= 0 || c != 3 || f <= 0 || h <= 0 || w <= 0) return fail("i2v_tap_grad_f32: bad argument (c == 3, out of place)");
+    CHECK_BE(k_tap_grad(gx, boxsign, out, b, c, f, h, w, weight, stream));
+    return 0;
+}
+
 extern "C" int i2v_aens_coeffs_f32(const float* prev, float* coeffs, float momentum, int L, void* stream) {
     if (!prev || !coeffs || L <= 0 || L > 64) return fail("i2v_aens_coeffs_f32: bad argument");
     CHECK_BE(k_aens_coeffs(prev, coeffs, momentum, L, stream));

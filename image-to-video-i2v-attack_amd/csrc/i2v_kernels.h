@@ -69,6 +69,9 @@ int k_grad_post_groups(int b, int c, int f, int h, int w, int mode, int64_t* gro
 int k_grad_post_splits(int64_t group_elems);
 int k_grad_post(const float* g, float* momentum, float* out, int b, int c, int f, int h, int w, int frame_major, int mode, float decay,
                 double* partial, i2v_stream_t s);
+int k_tap_perts(const float* adv, const float* videos, float* out, int b, int c, int f, int h, int w, i2v_stream_t s);
+int k_tap_sign_abs(const float* smooth, float* sign_out, float* reg, int64_t n, double* partial, i2v_stream_t s);     // partial: [1024] doubles
+int k_tap_grad(const float* gx, const float* boxsign, float* out, int b, int c, int f, int h, int w, float weight, i2v_stream_t s);
 int k_dwconv1d(const float* src, float* dst, int64_t outer, int len, int64_t inner, const float* taps /*host [k]*/, int k, i2v_stream_t s);
 int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t s);
 int k_aens_reduce(const float* cos, const float* coeffs, int L, int frames, float* feat_sum,

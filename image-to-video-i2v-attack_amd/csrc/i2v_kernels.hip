@@ -2344,6 +2344,50 @@ int k_grad_post(const float* g, float* momentum, float* out, int b, int c, int f
     LAUNCH_CHECK("grad_post_apply"); return 0;
 }
 
+// ---- TAP's elementwise steps (i2v_tap_*_f32) ----
+__global__ void __launch_bounds__(256) tap_perts_kernel(const float* __restrict__ adv, const float* __restrict__ vid, float* __restrict__ out, const int64_t n, const int64_t fhw) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (adv[i] - vid[i]) / c_std[(i / fhw) % 3];
+}
+__global__ void __launch_bounds__(256) tap_sign_abs_kernel(const float* __restrict__ sm, float* __restrict__ sg, double* __restrict__ partial, const int64_t n) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = sm[i];
+        sg[i] = v > 0.f ? 1.f : (v < 0.f ? -1.f : v);                   // torch.sign: +-0 and NaN pass through
+        acc += (double)fabsf(v);
+    }
+    red[threadIdx.x] = acc; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void tap_sum_finish_kernel(const double* __restrict__ partial, const int nblk, float* __restrict__ reg) {
+    double s = 0.0; for (int i = 0; i < nblk; ++i) s += partial[i];
+    *reg = (float)s;
+}
+__global__ void __launch_bounds__(256) tap_grad_kernel(const float* __restrict__ gx, const float* __restrict__ bs, float* __restrict__ out, const int64_t n,
+                                                       const int C, const int F, const int HW, const float weight) {
+    for (int64_t o = blockIdx.x * 256ll + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256) {
+        const int i = (int)(o % HW); int64_t r = o / HW; const int f = (int)(r % F); r /= F; const int c = (int)(r % C); const int64_t b = r / C;
+        out[o] = gx[((b * F + f) * C + c) * (int64_t)HW + i] + weight * bs[o] / c_std[c];
+    }
+}
+int k_tap_perts(const float* adv, const float* videos, float* out, int b, int c, int f, int h, int w, i2v_stream_t s) {
+    const int64_t n = (int64_t)b * c * f * h * w;
+    hipLaunchKernelGGL(tap_perts_kernel, dim3(stream_grid(n, 1024)), dim3(256), 0, (hipStream_t)s, adv, videos, out, n, (int64_t)f * h * w);
+    LAUNCH_CHECK("tap_perts"); return 0;
+}
+int k_tap_sign_abs(const float* smooth, float* sign_out, float* reg, int64_t n, double* partial, i2v_stream_t s) {
+    unsigned nblk = stream_grid(n, 4096); if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(tap_sign_abs_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, smooth, sign_out, partial, n);
+    hipLaunchKernelGGL(tap_sum_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, partial, (int)nblk, reg);
+    LAUNCH_CHECK("tap_sign_abs"); return 0;
+}
+int k_tap_grad(const float* gx, const float* boxsign, float* out, int b, int c, int f, int h, int w, float weight, i2v_stream_t s) {
+    const int64_t n = (int64_t)b * c * f * h * w;
+    hipLaunchKernelGGL(tap_grad_kernel, dim3(stream_grid(n, 1024)), dim3(256), 0, (hipStream_t)s, gx, boxsign, out, n, c, f, h * w, weight);
+    LAUNCH_CHECK("tap_grad"); return 0;
+}
+
 int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t s) {
     hipLaunchKernelGGL(aens_coeffs_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, prev, coeffs, momentum, L);
     LAUNCH_CHECK("aens_coeffs"); return 0;

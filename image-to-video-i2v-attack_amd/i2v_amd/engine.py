@@ -233,6 +233,28 @@ class Engine:
                                                           b, c, f, h, w, 1 if frame_major else 0, m, float(decay), C.c_void_p(scratch.data_ptr()), self.stream()))
         return out
 
+    def tap_perts(self, adv: torch.Tensor, videos: torch.Tensor) -> torch.Tensor:
+        """TAP: `(adv - videos) / std` (`base_attacks.py:138-143`, sic), clip layout."""
+        b, c, f, h, w = adv.shape
+        out = torch.empty_like(adv)
+        _lib.check(self.capi, self.capi.i2v_tap_perts_f32(_ptr(adv, self), _ptr(videos, self), _ptr(out, self), b, c, f, h, w, self.stream()))
+        return out
+
+    def tap_sign_abs(self, smooth: torch.Tensor, reg_out: torch.Tensor) -> torch.Tensor:
+        """TAP: sign(smooth) and, into the one-element `reg_out`, sum|smooth| (`base_attacks.py:731`)."""
+        sg = torch.empty_like(smooth)
+        scratch = torch.empty(int(self.capi.i2v_tap_scratch_bytes(smooth.numel())), dtype=torch.uint8, device=smooth.device)
+        _lib.check(self.capi, self.capi.i2v_tap_sign_abs_f32(_ptr(smooth, self), _ptr(sg, self), _ptr(reg_out, self), smooth.numel(),
+                                                            C.c_void_p(scratch.data_ptr()), self.stream()))
+        return sg
+
+    def tap_grad(self, gx: torch.Tensor, boxsign: torch.Tensor, weight: float) -> torch.Tensor:
+        """TAP: clip-layout gradient = frame-major backbone gradient + weight * boxsign / std."""
+        b, c, f, h, w = boxsign.shape
+        out = torch.empty_like(boxsign)
+        _lib.check(self.capi, self.capi.i2v_tap_grad_f32(_ptr(gx, self), _ptr(boxsign, self), _ptr(out, self), b, c, f, h, w, float(weight), self.stream()))
+        return out
+
     def aens_coeffs(self, prev, coeffs, momentum):
         _lib.check(self.capi, self.capi.i2v_aens_coeffs_f32(_ptr(prev, self), _ptr(coeffs, self), momentum, coeffs.numel(), self.stream()))
 

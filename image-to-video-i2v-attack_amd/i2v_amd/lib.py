@@ -97,6 +97,10 @@ _PROTOS = {
     "i2v_resample_nearest_f32": ([_P, _P, _L, _I, _I, _I, _I, _P, _P, _P], _I),
     "i2v_resample_nearest_bwd_f32": ([_P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P], _I),
     "i2v_dwconv1d_f32": ([_P, _P, _L, _I, _L, _P, _I, _P], _I),
+    "i2v_tap_scratch_bytes": ([_L], _L),
+    "i2v_tap_perts_f32": ([_P, _P, _P, _I, _I, _I, _I, _I, _P], _I),
+    "i2v_tap_sign_abs_f32": ([_P, _P, _P, _L, _P, _P], _I),
+    "i2v_tap_grad_f32": ([_P, _P, _P, _I, _I, _I, _I, _I, _F, _P], _I),
     "i2v_grad_post_scratch_bytes": ([_I, _I, _I, _I, _I, _I], _L),
     "i2v_grad_post_f32": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P], _I),
     "i2v_head_pool_f32": ([_P, _L, _I, _I, _I, _I, _I, _I, _P, _P], _I),

@@ -541,6 +541,7 @@ class TAP(_SignAttack):
         feats = list(range(len(stages), len(stages) + len(cls)))
         self.loss_info = {}
         gx = torch.empty_like(x)
+        logged = torch.zeros(self.steps, 2 + len(stages), **kw)          # per step: CE, regulariser, distance per stage
         for step in range(self.steps):
             eng.frames_from_video(adv, x, u)
             net.forward(x)
@@ -549,13 +550,17 @@ class TAP(_SignAttack):
             for i in range(len(stages)):
                 net.tap_distance(i, clean[i], 0.05, dist[i], dscratch[i], ns[i], ns[i] // b)
             net.backward(gx)
-            grad = gx.view(b, f, 3, h, w).permute(0, 2, 1, 3, 4)
-            perts = ((adv - videos) / std).contiguous()                 # (sic) `_transform_perts` divides
-            smooth = box(perts)
-            grad = grad + 1e3 * box(torch.sign(smooth)) / std
-            self.loss_info[step] = {"ce loss": loss_each.mean().cpu().numpy(), "reg_cost": smooth.abs().sum().cpu().numpy(),
-                                    "distance": sum(d for d in dist).cpu().numpy()}
-            eng.sign_step(adv, unnorm, grad.contiguous(), f * h * w, self.step_size, self.epsilon)
+            smooth = box(eng.tap_perts(adv, videos))                    # (sic) `_transform_perts` divides by std
+            sg = eng.tap_sign_abs(smooth, logged[step, 1:2])            # sign(smooth), and the regulariser's value for the log
+            grad = eng.tap_grad(gx, box(sg), 1e3)                       # clip-layout gradient + 1e3 * box(sign(box(perts))) / std
+            logged[step, 0:1].copy_(loss_each)                          # (device-to-device, one clip per call)
+            for i in range(len(stages)):
+                logged[step, 2 + i:3 + i].copy_(dist[i])
+            eng.sign_step(adv, unnorm, grad, f * h * w, self.step_size, self.epsilon)
+        host = logged.cpu().numpy()                                      # one read-back per call
+        for step in range(self.steps):
+            self.loss_info[step] = {"ce loss": host[step, 0], "reg_cost": host[step, 1],
+                                    "distance": np.float32(sum(np.float32(v) for v in host[step, 2:]))}
         return adv
 
     def _smoothness(self, perts):
@@ -672,6 +677,8 @@ class ILAF(object):
         self._engine = engine
         self.activations = {"value": []}
         self._net = self._net_key = None
+        self.path = "native" if isinstance(model, VideoModel) else "torch-module"
+        _announce(self)
         if isinstance(model, VideoModel):
             return                                      # native path: hooks are tensors of the graph IR
         layers = hook_layers if hook_layers is not None else self._find_target_layer()

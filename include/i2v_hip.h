@@ -307,6 +307,15 @@ int i2v_dwconv1d_f32(const float* src, float* dst, int64_t outer, int len, int64
 int64_t i2v_grad_post_scratch_bytes(int b, int c, int f, int h, int w, int mode);
 int i2v_grad_post_f32(const float* g, float* momentum, float* out, int b, int c, int f, int h, int w, int frame_major, int mode, float decay,
                       void* scratch, void* stream);
+/* TAP's elementwise steps around the box filter (`base_attacks.py:724-731, 777-790`), clip layout (b,c,f,h,w), c == 3:
+ *   _perts:     out = (adv - videos) / std[c]                      (`_transform_perts`, sic: divided)
+ *   _sign_abs:  sign_out = sign(smooth);  *reg = sum |smooth|      (the regulariser's value, double sums in a fixed order; `scratch`
+ *               holds i2v_tap_scratch_bytes(n) bytes)
+ *   _grad:      out = gx + weight * boxsign / std[c], gx being the backbone's FRAME-major input gradient (b*f,c,h,w) */
+int64_t i2v_tap_scratch_bytes(int64_t n);
+int i2v_tap_perts_f32(const float* adv, const float* videos, float* out, int b, int c, int f, int h, int w, void* stream);
+int i2v_tap_sign_abs_f32(const float* smooth, float* sign_out, float* reg, int64_t n, void* scratch, void* stream);
+int i2v_tap_grad_f32(const float* gx, const float* boxsign, float* out, int b, int c, int f, int h, int w, float weight, void* stream);
 /* Adaptive ENS-I2V re-weighting `coeffs = softmax(softmax(prev) + momentum*coeffs)`
  * (TPAMI_attack.py:265), L <= 64, in place on device. */
 int i2v_aens_coeffs_f32(const float* prev, float* coeffs, float momentum, int L, void* stream);

@@ -801,6 +801,28 @@ int k_grad_post(const float* g, float* momentum, float* out, int B, int C, int F
     return 0;
 }
 
+static const float kStdH[3] = {0.229f, 0.224f, 0.225f};
+int k_tap_perts(const float* adv, const float* videos, float* out, int b, int c, int f, int h, int w, i2v_stream_t) {
+    const int64_t fhw = (int64_t)f * h * w, n = (int64_t)b * c * fhw;
+    for (int64_t i = 0; i < n; ++i) { volatile float d = adv[i] - videos[i]; out[i] = d / kStdH[(i / fhw) % 3]; }
+    return 0;
+}
+int k_tap_sign_abs(const float* smooth, float* sign_out, float* reg, int64_t n, double*, i2v_stream_t) {
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) { const float v = smooth[i]; sign_out[i] = v > 0.f ? 1.f : (v < 0.f ? -1.f : v); s += (double)fabsf(v); }
+    *reg = (float)s;
+    return 0;
+}
+int k_tap_grad(const float* gx, const float* bs, float* out, int B, int C, int F, int H, int W, float weight, i2v_stream_t) {
+    const int64_t HW = (int64_t)H * W, n = (int64_t)B * C * F * HW;
+    for (int64_t o = 0; o < n; ++o) {
+        const int64_t i = o % HW; int64_t r = o / HW; const int64_t f = r % F; r /= F; const int64_t c = r % C, b = r / C;
+        volatile float t = weight * bs[o]; volatile float q = t / kStdH[c];
+        out[o] = gx[((b * F + f) * C + c) * HW + i] + q;
+    }
+    return 0;
+}
+
 int k_aens_coeffs(const float* prev, float* coeffs, float momentum, int L, i2v_stream_t) {
     std::vector<float> a(L), b(L);
     float mx = -INFINITY, sum = 0.f;

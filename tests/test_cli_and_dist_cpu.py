@@ -158,7 +158,8 @@ def test_attack_cli_feeds_fine_tune(tiny_engine, tmp_path, monkeypatch):
     import attack as attack_cli
     importlib.reload(attack_cli)
     out = attack_cli.main(["--attack_method", "BIM", "--step", "2", "--model", "i3d_resnet50", "--num_clips", "2", "--batch_size", "1",
-                           "--frames", "32", "--hw", "16", "--file_prefix", "t", "--kernlen", "15", "--noise"])
+                           "--frames", "32", "--hw", "16", "--file_prefix", "t", "--kernlen", "15", "--noise",
+                           "--model_factory", "reference:proxy"])     # (file contract only: a small torch classifier; the default is 'native')
     assert out == str(tmp_path / "i3d_resnet50-BIM-2-t")
     assert sorted(os.listdir(out)) == ["0-adv.npy", "0-ori.npy", "1-adv.npy", "1-ori.npy"]
     adv, ori = np.load(os.path.join(out, "1-adv.npy")), np.load(os.path.join(out, "1-ori.npy"))
