@@ -327,6 +327,13 @@ def selftest_hostsim(args):
     extra = {}
     if args.workload == "aens":
         extra["aens_weights_last"] = [round(float(x), 6) for x in atk.weights[-1]]     # identical on every rank: global batch
+        extra["aens_weights"] = [[float(x) for x in wrow] for wrow in atk.weights]      # every step of the last call
+        if dist is not None:          # ... proved: every rank's whole weight trajectory gathered and compared bit for bit
+            import numpy as np
+            mine = torch.from_numpy(np.stack(atk.weights).astype(np.float32))
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            extra["aens_weights_identical_on_all_ranks"] = bool(all(torch.equal(e, every[0]) for e in every))
     line = {"metric": "SELFTEST (host simulation, not a measurement)", "value": round(args.steps * b * f * world / elapsed, 3),
             "unit": "adversarial frames/s", "n_gpus": world, "steps": args.steps, "warmup": 0, "data": "synthetic",
             "ranks_proved_by_allreduce": {"sum_of_rank_ids": rank_sum, "expected": world * (world - 1) // 2},

@@ -160,8 +160,10 @@ class _ImageGuided(Attack):
             if self.coeffs is None or self.coeffs.device != dev:
                 self.coeffs = torch.ones(L, **kw)                       # TPAMI_attack.py:165
             prev = torch.ones(L, **kw)                                  # :257
-            feat_sum = torch.empty(L, **kw)
-            weighted = torch.empty(steps, L, **kw)
+            # per step ONE contiguous pair [sum_frames cos_l | coeff_l * sum_frames cos_l]: what `aens_reduce_kernel` writes is what
+            # the all-reduce works on in place and what the next step's `aens_coeffs_kernel` reads -- no pack / unpack kernels between
+            exch = torch.empty(steps, 2, L, **kw)
+            weighted = exch[:, 1]
             wts = torch.empty(steps, L, **kw)
         begin = time.time()
         for i in range(steps):
@@ -186,9 +188,9 @@ class _ImageGuided(Attack):
                     l += 1
                 net.backward(gx, accumulate=n > 0)                      # :352 (input gradient only)
             if aens:
-                eng.aens_reduce(vals[i], self.coeffs, feat_sum, weighted[i])
-                self._exchange(feat_sum, weighted[i])
-                prev = (weighted[i] if self.coef_CE else feat_sum).clone()   # TPAMI_attack.py:293-297
+                eng.aens_reduce(vals[i], self.coeffs, exch[i, 0], exch[i, 1])
+                self._exchange(exch[i])                                  # sharded runs: 2L floats summed over the ranks, in place
+                prev = exch[i, 1] if self.coef_CE else exch[i, 0]        # TPAMI_attack.py:293-297 (this step's row is not written again)
             eng.adam_step(delta, m, v, gx, u, eps, float(self.step_size), t0 + i + 1)   # :351-353
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
@@ -213,7 +215,7 @@ class _ImageGuided(Attack):
         self._delta, self._m, self._v = delta, m, v
         self._gx = gx                        # d cost / d composed frames of the LAST iteration (before the compose backward)
         if aens:
-            self._prev = prev                # previous_cs_loss after the last iteration (TPAMI_attack.py:293-297)
+            self._prev = prev.clone()        # previous_cs_loss after the last iteration (TPAMI_attack.py:293-297)
         return out
 
     def forced_step(self, videos, delta, m, v, t, coeffs=None):
@@ -227,7 +229,7 @@ class _ImageGuided(Attack):
             self.loss_info = saved
         return self._delta, self._m, self._v, float(self.last_costs[0])
 
-    def _exchange(self, feat_sum, weighted_row):
+    def _exchange(self, pair):
         pass
 
     def _std_exchange(self):
@@ -467,16 +469,20 @@ class AENS_I2V_MF(_ImageGuided):
         self._pg = process_group
         self._dist = distributed
 
-    def _exchange(self, feat_sum, weighted_row):
+    def _exchange(self, pair):
+        """The path's one collective: `pair` = this step's (2, L) floats, summed over the ranks IN PLACE.
+        Ordering, with RCCL (`backend="nccl"`): the engine launches on torch's current stream S (`Engine.stream()`); `all_reduce`
+        records an event on S behind `aens_reduce_kernel`, makes the process group's own stream wait for it, enqueues the RCCL
+        kernel there, and -- a synchronous op -- makes S wait for the collective's completion EVENT (a stream wait, `work.wait()` of
+        ProcessGroupNCCL; the host does not block unless TORCH_NCCL_BLOCKING_WAIT asks for it).  So the chain is
+        aens_reduce_kernel -> [event] -> RCCL all-reduce (2L floats) -> [event] -> next step's aens_coeffs_kernel,
+        entirely on the device; the host runs ahead queueing the next step's compose / forward launches, which only the
+        coefficient kernel's consumers (the cosine gradient) wait behind.  With gloo (CPU tensors, the tests) it is a blocking call."""
         import torch.distributed as dist
         on = self._dist if self._dist is not None else (dist.is_available() and dist.is_initialized()
                                                           and dist.get_world_size(self._pg) > 1)
         if on:
-            packed = torch.cat([feat_sum, weighted_row])
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self._pg)
-            L = feat_sum.numel()
-            feat_sum.copy_(packed[:L])
-            weighted_row.copy_(packed[L:])
+            dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=self._pg)
 
     def forward(self, videos, labels, video_names):
         adv = self._run(videos, video_names)

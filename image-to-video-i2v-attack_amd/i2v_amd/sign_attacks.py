@@ -553,10 +553,10 @@ class TAP(_SignAttack):
             smooth = box(eng.tap_perts(adv, videos))                    # (sic) `_transform_perts` divides by std
             sg = eng.tap_sign_abs(smooth, logged[step, 1:2])            # sign(smooth), and the regulariser's value for the log
             grad = eng.tap_grad(gx, box(sg), 1e3)                       # clip-layout gradient + 1e3 * box(sign(box(perts))) / std
-            logged[step, 0:1].copy_(loss_each)                          # (device-to-device, one clip per call)
+            eng.sign_step(adv, unnorm, grad, f * h * w, self.step_size, self.epsilon)
+            logged[step, 0:1].copy_(loss_each)                          # the step's logged terms stay on the device (one clip per call)
             for i in range(len(stages)):
                 logged[step, 2 + i:3 + i].copy_(dist[i])
-            eng.sign_step(adv, unnorm, grad, f * h * w, self.step_size, self.epsilon)
         host = logged.cpu().numpy()                                      # one read-back per call
         for step in range(self.steps):
             self.loss_info[step] = {"ce loss": host[step, 0], "reg_cost": host[step, 1],

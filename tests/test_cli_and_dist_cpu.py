@@ -412,6 +412,29 @@ def test_bench_gpus_n_spawns_n_ranks():
     assert abs(lines[0]["efficiency_vs_n1"] - lines[0]["value"] / 1000) < 1e-3 and lines[0]["cpu_affinity_rank0"] is None
 
 
+def test_bench_eight_ranks_aens_weights_follow_the_global_batch():
+    """`bench.py --gpus 8 --workload aens` as it will run on the 8-GPU node, here on the host simulation over gloo --
+    eight ranks x 2 clips, the 2L-float all-reduce of `AENS_I2V_MF._exchange` inside every step (`TPAMI_attack.py:265,293-297`): the
+    weight trajectory is bit-identical on all eight ranks and equals the ONE-device run over the global batch of 16 clips (float64
+    oracle), because the inner softmax sees the sums over all b*f frames."""
+    from oracle import restate
+    from i2v_amd import graphs, weights
+    import bench
+    code, lines, err = _bench(["--gpus", "8", "--selftest-hostsim", "--steps", "1", "--workload", "aens"], env={"OMP_NUM_THREADS": "1"})
+    assert code == 0, err[-2000:]
+    out = lines[0]
+    assert out["n_gpus"] == 8 and len(out["per_gpu"]) == 8
+    assert out["ranks_proved_by_allreduce"] == {"sum_of_rank_ids": 28, "expected": 28}
+    assert out["aens_weights_identical_on_all_ranks"] is True
+    vids = torch.cat([bench.synthetic_clips(1, seed0=1000 + k)[:, :, :2, :32, :32] for k in range(16)]).contiguous()     # selftest_hostsim's clips
+    nets = []
+    for m in ("resnet", "vgg"):
+        g = graphs.build_tiny(m, (32, 32))
+        nets.append(restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hook_for(2, True), g.hook_for(3, True)], dtype=torch.float64))
+    ref = restate.run_attack(nets, vids.double(), steps=2, step_size=0.005, mode="aens", coeffs=torch.ones(4, dtype=torch.float64))
+    np.testing.assert_allclose(np.array(out["aens_weights"]), np.stack(ref["weights"]), rtol=1e-4)
+
+
 def test_bench_failed_rank_fails_the_run():
     code, lines, err = _bench(["--gpus", "2", "--selftest-hostsim", "--steps", "1"], env={"I2V_BENCH_SELFTEST_FAIL_RANK": "1"})
     assert code != 0 and "rank(s) failed" in err and not lines
