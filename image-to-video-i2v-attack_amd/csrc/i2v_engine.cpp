@@ -98,6 +98,11 @@ struct Launch {
     // conv launches: the autotuner's tile configuration (conv.cfg encoding) per batch bucket b = clips in (max >> (b + 1), max >> b];
     // 0: not tuned (conv.cfg as planned).  Every configuration computes the same bits, so the choice never shows in a result.
     int cfg_b[4] = {0, 0, 0, 0};
+    // Fused pair (k_conv_fused): this 3x3 launch and the NEXT launch of its list, the pointwise convolution over its output, may run as
+    // one kernel that never stores the intermediate.  fuse_ok: k_conv_fusable's bits, 0 when anything else reads the intermediate
+    // (mark_fusable); fuse_b[bucket]: what the autotuner measured -- 0 two launches, 1 fused (plain staging), 2 fused (halo staging).
+    int fuse_ok = 0;
+    int fuse_b[4] = {0, 0, 0, 0};
 };
 static int cfg_bucket(int clips, int max_clips) {
     int b = 0;
@@ -1023,6 +1028,7 @@ struct Planner {
 }  // namespace
 
 static int autotune(Net& n);
+static void mark_fusable(Net& n);
 
 extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int n_hooks, int max_frames) {
     Net* np = get_net(h, net); if (!np) return 1;
@@ -1095,11 +1101,24 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
     Planner real{n, false, off, N};
     if (!real.run()) return fail("plan: %s", real.err.c_str());
     n.hook_tmp = real.hook_tmp;
+    mark_fusable(n);
     if (autotune(n)) return 1;
     // planning works on the null stream (uploads, arena clears, tuning probes); the caller may execute the net on any
     // stream, including non-blocking ones that do not order against it
     CHECK_BE(be_stream_sync(nullptr));
     n.planned = true;
+    return 0;
+}
+
+extern "C" int i2v_net_fusion_info(i2v_handle h, int net, int32_t out[4]) {
+    Net* n = get_net(h, net); if (!n) return 1;
+    if (!n->planned || !out) return fail("i2v_net_fusion_info: net not planned");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    int k = 0;
+    for (const std::vector<Launch>* L : {&n->fwd, &n->bwd}) {
+        for (const Launch& l : *L) { out[k] += l.fuse_ok ? 1 : 0; out[2 + k] += (l.fuse_ok && l.fuse_b[0]) ? 1 : 0; }
+        ++k;
+    }
     return 0;
 }
 
@@ -1111,9 +1130,9 @@ extern "C" size_t i2v_net_workspace_bytes(i2v_handle h, int net) {
 // ---------------------------------------------------------------------------------------------
 // execution
 // ---------------------------------------------------------------------------------------------
-// One convolution launch over `frames` grid frames (= clips * Tg), possibly sliced over whole clips: 32-bit
-// buffer offsets keep a launch's source span < 2 GiB
-static int conv_run(const Launch& l, int frames, const float* x, float* gx, int accumulate, i2v_stream_t s) {
+// A launch's parameters as the kernel sees them: the caller's input / gradient pointers patched in, the dense-epilogue and temporal
+// flags derived (shared by the plain launch and the fused pair)
+static I2VConvParams conv_prep(const Launch& l, const float* x, float* gx, int accumulate) {
     I2VConvParams p = l.conv;
     if (l.src_is_input) p.src = x;
     if (l.kind == L_IMGGRAD) { p.dst = gx; if (accumulate || l.img_accumulate) { p.add1 = gx; p.add1_nstride = p.dst_nstride; } }
@@ -1126,6 +1145,33 @@ static int conv_run(const Launch& l, int frames, const float* x, float* gx, int 
                       (((uintptr_t)p.dst | (uintptr_t)p.add0 | (uintptr_t)p.add1 | (uintptr_t)p.mask) & 15) == 0)
                          ? 1 : 0;
     if (!(p.Tg == p.Ts && p.Ts == p.To && p.st == 1 && p.ost == 1 && p.ot0 == 0 && p.blkt == 1)) p.temporal = 1;
+    return p;
+}
+
+// The fused pair: `a` (3x3) and `b` (the pointwise convolution over a's output) as ONE launch; only for pairs mark_fusable admitted.
+// A pair whose source would have to be sliced (>= 2 GiB spans) is not fused (the caller falls back to two launches).
+static bool fused_fits(const Launch& a, const Launch& b, int frames) {
+    for (const Launch* l : {&a, &b}) {
+        const I2VConvParams& p = l->conv;
+        const int64_t span = ((int64_t)frames * p.Ts / p.Tg - 1) * p.src_nstride * 4 + (int64_t)p.Cs * p.Hs * p.Ws * 4;
+        if (span >= (1ll << 31)) return false;
+    }
+    return true;
+}
+static int fused_run(const Launch& a, const Launch& b, int frames, const float* x, int halo, i2v_stream_t s) {
+    I2VConvParams pa = conv_prep(a, x, nullptr, 0), pb = conv_prep(b, x, nullptr, 0);
+    for (I2VConvParams* p : {&pa, &pb}) {
+        p->N = frames;
+        p->src_span_bytes = (int32_t)(((int64_t)frames * p->Ts / p->Tg - 1) * p->src_nstride * 4 + (int64_t)p->Cs * p->Hs * p->Ws * 4);
+    }
+    CHECK_BE(k_conv_fused(pa, pb, halo, s));
+    return 0;
+}
+
+// One convolution launch over `frames` grid frames (= clips * Tg), possibly sliced over whole clips: 32-bit
+// buffer offsets keep a launch's source span < 2 GiB
+static int conv_run(const Launch& l, int frames, const float* x, float* gx, int accumulate, i2v_stream_t s) {
+    I2VConvParams p = conv_prep(l, x, gx, accumulate);
     const int clips = frames / p.Tg;
     const int64_t plane_bytes = (int64_t)p.Cs * p.Hs * p.Ws * 4, stride_bytes = p.src_nstride * 4;
     const int64_t clip_bytes = (int64_t)(p.Ts - 1) * stride_bytes + plane_bytes;        // span of one clip's source frames
@@ -1149,6 +1195,79 @@ static int conv_run(const Launch& l, int frames, const float* x, float* gx, int 
         CHECK_BE(k_conv(q, s));
     }
     return 0;
+}
+
+// Fused pairs (k_conv_fused): launch i a 3x3 convolution, launch i + 1 the pointwise convolution that reads its output -- a
+// bottleneck's conv2 -> conv3 in the forward list, the input gradients of conv2 -> conv1 in the backward list.  The fused kernel
+// never stores the intermediate, so the pair qualifies only if NOTHING else touches that memory: no other launch of either list
+// (as source, addend, mask, destination -- which also rules out I2V_GATES=0, whose backward pass reads fp32 activations, and the
+// in-place ReLU gain of i2v_net_set_relu_gain), no hook, and not the network input.  Conservative: any overlap of address ranges counts.
+static void mark_fusable(Net& n) {
+    const int64_t frames = n.maxN;
+    auto overlaps = [&](const void* q, const float* lo, const float* hi) { return q && (const float*)q >= lo && (const float*)q < hi; };
+    std::vector<std::pair<const float*, const float*>> hooked;
+    for (size_t h = 0; h < n.hooks.size(); ++h) {
+        View a = view_of(n, n.hooks[h], false), g = view_of(n, n.hooks[h], true);
+        hooked.push_back({a.p, a.p + frames * a.nstride});
+        hooked.push_back({g.p, g.p + frames * g.nstride});
+    }
+    // A first bottleneck runs its shortcut convolution between conv2 and conv3 (conv3 adds it): where that launch and the 3x3 are
+    // independent of each other, they swap places so that the pair becomes adjacent.
+    for (std::vector<Launch>* L : {&n.fwd, &n.bwd})
+        for (size_t i = 0; i + 2 < L->size(); ++i) {
+            Launch& a = (*L)[i]; Launch& c = (*L)[i + 1]; Launch& b = (*L)[i + 2];
+            if (a.kind != L_CONV || c.kind != L_CONV || b.kind != L_CONV || a.src_is_input || c.src_is_input || !k_conv_fusable(a.conv, b.conv)) continue;
+            if (k_conv_fusable(a.conv, c.conv)) continue;
+            auto rng = [&](const float* q, int64_t ns) { return std::pair<const float*, const float*>(q, q ? q + frames * ns : q); };
+            auto hit = [&](std::pair<const float*, const float*> w, const void* r) { return r && w.first && (const float*)r >= w.first && (const float*)r < w.second; };
+            const auto wa = rng(a.conv.dst, a.conv.dst_nstride), wc = rng(c.conv.dst, c.conv.dst_nstride);
+            const I2VConvParams& pa = a.conv; const I2VConvParams& pc = c.conv;
+            const bool dep = hit(wa, pc.src) || hit(wa, pc.add0) || hit(wa, pc.add1) || hit(wa, pc.mask) || hit(wc, pa.src) || hit(wc, pa.add0) ||
+                             hit(wc, pa.add1) || hit(wc, pa.mask) || hit(wa, pc.dst) || hit(wc, pa.dst) ||
+                             (pa.gate_out && (pa.gate_out == pc.gate || pa.gate_out == pc.gate_out)) || (pc.gate_out && pc.gate_out == pa.gate);
+            if (!dep) std::swap(a, c);
+        }
+    for (std::vector<Launch>* L : {&n.fwd, &n.bwd})
+        for (size_t i = 0; i + 1 < L->size(); ++i) {
+            Launch& a = (*L)[i]; Launch& b = (*L)[i + 1];
+            a.fuse_ok = 0;
+            if (a.kind != L_CONV || b.kind != L_CONV || a.src_is_input || b.src_is_input || a.T != b.T) continue;
+            const int ok = k_conv_fusable(a.conv, b.conv);
+            if (!ok) continue;
+            const float* lo = a.conv.dst; const float* hi = lo + frames * a.conv.dst_nstride;
+            bool other = false;
+            for (auto& hk : hooked) other |= (hk.first < hi && lo < hk.second);
+            for (std::vector<Launch>* M : {&n.fwd, &n.bwd})
+                for (size_t j = 0; j < M->size() && !other; ++j) {
+                    const Launch& c = (*M)[j];
+                    const bool is_a = (M == L && j == i), is_b = (M == L && j == i + 1);
+                    if (c.kind == L_CONV || c.kind == L_IMGGRAD) {
+                        const I2VConvParams& q = c.conv;
+                        other |= (!is_b && overlaps(q.src, lo, hi)) || overlaps(q.add0, lo, hi) || overlaps(q.add1, lo, hi) || overlaps(q.mask, lo, hi) ||
+                                 (!is_a && overlaps(q.dst, lo, hi));
+                    } else if (c.kind == L_ADDMASK) {
+                        other |= overlaps(c.am.out, lo, hi) || overlaps(c.am.a[0], lo, hi) || overlaps(c.am.a[1], lo, hi) || overlaps(c.am.a[2], lo, hi) ||
+                                 overlaps(c.am.mask, lo, hi);
+                    } else if (c.kind == L_MEMSET) {
+                        other |= overlaps(c.ms_ptr, lo, hi);
+                    } else if (c.kind == L_AGEMM || c.kind == L_SOFTMAX) {
+                        other = true;              // (attention launches address whole matrices: not analysed, such nets are not fused)
+                    } else {
+                        const I2VPoolParams& q = c.pool;
+                        other |= overlaps(q.x, lo, hi) || overlaps(q.y, lo, hi) || overlaps(q.gx, lo, hi) || overlaps(q.yact, lo, hi);
+                    }
+                }
+            if (!other) a.fuse_ok = ok;
+            if (getenv("I2V_FUSE_DEBUG"))
+                fprintf(stderr, "[i2v fuse] %s pair %zu: 3x3 Cd=%d K=%d %dx%d -> 1x1 Cd=%d K=%d: eligible=%d other_reader=%d\n", L == &n.fwd ? "fwd" : "bwd", i,
+                        a.conv.Cd, a.conv.K, a.conv.Hg, a.conv.Wg, b.conv.Cd, b.conv.K, ok, (int)other);
+        }
+    // without the autotuner (I2V_AUTOTUNE=0: tests, tools) a pair is fused only on request: I2V_FORCE_FUSE = 1 (plain) / 2 (halo where it applies)
+    const char* force = getenv("I2V_FORCE_FUSE");
+    const int f = force ? atoi(force) : 0;
+    for (std::vector<Launch>* L : {&n.fwd, &n.bwd})
+        for (Launch& a : *L)
+            for (int b = 0; b < 4; ++b) a.fuse_b[b] = (a.fuse_ok && f) ? ((f == 2 && (a.fuse_ok & 2)) ? 2 : 1) : 0;
 }
 
 // Plan-time autotuning ("measure, don't guess"): every convolution launch of both passes is timed with each
@@ -1197,6 +1316,41 @@ static int autotune(Net& n) {
             l.conv.cfg = l.cfg_b[0] ? l.cfg_b[0] : planned_cfg;
             if (rc) break;
         }
+    // Fused pairs, per batch bucket: the two launches on their tuned tiles against the pair as one kernel (plain / halo staging).
+    // (Only where timing means something: the host simulation of the tests has one configuration of everything.)
+    const bool on_device = strncmp(be_name(), "hip", 3) == 0;
+    for (std::vector<Launch>* L : {&n.fwd, &n.bwd})
+        for (size_t i = 0; on_device && i + 1 < L->size() && !rc; ++i) {
+            Launch& a = (*L)[i]; Launch& b = (*L)[i + 1];
+            if (!a.fuse_ok) continue;
+            for (int bk = 3; bk >= 0 && !rc; --bk) {
+                a.fuse_b[bk] = 0;
+                const int clips_b = max_clips >> bk;
+                if (clips_b < 1 || (bk > 0 && clips_b == (max_clips >> (bk - 1)))) continue;
+                const int lf = clips_b * a.conv.Tg;
+                if (!fused_fits(a, b, lf)) continue;
+                const int ca = a.conv.cfg, cb = b.conv.cfg;
+                if (a.cfg_b[bk]) a.conv.cfg = a.cfg_b[bk];
+                if (b.cfg_b[bk]) b.conv.cfg = b.cfg_b[bk];
+                float best = 1e30f; int best_v = 0;
+                for (int v = 0; v <= ((a.fuse_ok & 2) ? 2 : 1) && !rc; ++v) {
+                    auto once = [&]() { return v == 0 ? (conv_run(a, lf, xin, scratch + img, 0, nullptr) || conv_run(b, lf, xin, scratch + img, 0, nullptr))
+                                                      : fused_run(a, b, lf, xin, v == 2, nullptr); };
+                    rc |= once();
+                    be_event_record(e0, nullptr);
+                    for (int r = 0; r < 2 && !rc; ++r) rc |= once();
+                    be_event_record(e1, nullptr);
+                    if (rc || be_stream_sync(nullptr)) { rc = 1; break; }
+                    float ms = 0.f; be_event_elapsed_ms(e0, e1, &ms);
+                    if (ms < best) { best = ms; best_v = v; }
+                    if (getenv("I2V_FUSE_DEBUG"))
+                        fprintf(stderr, "[i2v fuse] %s pair %zu (Cd %d -> %d, %dx%d) at %d frames: variant %d = %.1f us\n", L == &n.fwd ? "fwd" : "bwd", i,
+                                a.conv.Cd, b.conv.Cd, a.conv.Hg, a.conv.Wg, lf, v, ms * 500.f);
+                }
+                a.fuse_b[bk] = best_v;
+                a.conv.cfg = ca; b.conv.cfg = cb;
+            }
+        }
     be_event_destroy(e0); be_event_destroy(e1); be_free(scratch);
     if (rc) return g_err.empty() ? fail("autotune failed") : 1;
     // the probes scribbled over activations and gradients; start from a clean arena like a fresh plan
@@ -1226,11 +1380,15 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
                     i2v_stream_t s, bool backward_pass) {
     const int clips = in_frames / n.Tin();
     TimedLaunch* prev_timed = nullptr;                   // the first launch of the list records its own start event
-    for (Launch& l : L) {
+    for (size_t li = 0; li < L.size(); ++li) {
+        Launch& l = L[li];
         const int frames = clips * l.T;                  // frames this launch iterates over
+        // this 3x3 launch and the pointwise launch behind it as ONE kernel (mark_fusable / autotune): the next entry is skipped
+        const int fuse = (l.kind == L_CONV && l.fuse_ok && li + 1 < L.size() && frames * l.conv.Hg * l.conv.Wg > 0 && fused_fits(l, L[li + 1], frames))
+                             ? l.fuse_b[cfg_bucket(clips, n.maxN / n.Tin())] : 0;
         double flops = 0.0;
         if (l.kind == L_CONV && l.alg_flops_per_frame > 0) flops = l.alg_flops_per_frame * frames;     // quad-row packings pad K
-        else if (l.kind == L_CONV) flops = 2.0 * frames * l.conv.Hg * l.conv.Wg * (double)l.conv.Cd * l.conv.K;
+        else if (l.kind == L_CONV) flops = 2.0 * frames * l.conv.Hg * l.conv.Wg * ((double)l.conv.Cd * l.conv.K + (fuse ? (double)L[li + 1].conv.Cd * L[li + 1].conv.K : 0.0));
         else if (l.kind == L_IMGGRAD) flops = l.alg_flops_per_frame * frames;
         else if (l.kind == L_AGEMM) flops = 2.0 * clips * (double)l.ag.Cc * l.ag.M * l.ag.N;
         // timing kinds: 0 conv fwd, 1 image gradient, 2 pool fwd, 3 pool bwd, 4 addmask, 5 conv input-gradient
@@ -1252,6 +1410,16 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
             if (q.mask) b += 4.0 * out;
             if (q.gate) b += out / 8.0;
             if (q.gate_out) b += out / 8.0;
+            if (fuse) {       // + the pointwise half: its weights, output and epilogue operands; the intermediate is neither written nor read
+                const I2VConvParams& r = L[li + 1].conv;
+                const double out2 = (double)frames * r.Hg * r.Wg * r.Cd;
+                b += 4.0 * ((double)r.K * r.Cd + out2) - 4.0 * out;
+                if (r.add0) b += 4.0 * out2;
+                if (r.add1) b += 4.0 * out2;
+                if (r.mask) b += 4.0 * out2;
+                if (r.gate) b += out2 / 8.0;
+                if (r.gate_out) b += out2 / 8.0;
+            }
             tl->bytes = b;
         }
         if (tl && l.kind == L_AGEMM) {                  // (dump fields: channels, reduction length, output columns, 10 + product form)
@@ -1264,6 +1432,7 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
             case L_CONV:
             case L_IMGGRAD: {
                 if (frames * l.conv.Hg * l.conv.Wg == 0) break;
+                if (fuse) { if (fused_run(l, L[li + 1], frames, x, fuse == 2, s)) return 1; ++li; break; }
                 const int cb = l.cfg_b[cfg_bucket(clips, n.maxN / n.Tin())];
                 if (cb) l.conv.cfg = cb;
                 if (conv_run(l, frames, x, gx, accumulate, s)) return 1;

@@ -24,6 +24,10 @@ int  be_stream_sync(i2v_stream_t s);
 int  be_device_sync();                                                       // last backend error or null
 
 int k_conv(const I2VConvParams& p, i2v_stream_t s);
+// fused pair (3x3 convolution `a` -> pointwise convolution `b` over its channels, one launch, a's output never stored):
+// eligibility of the parameter pair (0 no, 1 plain staging, 3 also halo staging) and the launch (both vec_epilogue, same N)
+int k_conv_fusable(const I2VConvParams& a, const I2VConvParams& b);
+int k_conv_fused(const I2VConvParams& a, const I2VConvParams& b, int halo, i2v_stream_t s);
 int k_conv_candidates(const I2VConvParams& p, int* out);   // tile configurations valid for p (ids 0..5, +8 = no epilogue prefetch), returns count
 int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s);

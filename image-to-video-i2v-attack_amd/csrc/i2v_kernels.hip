@@ -167,6 +167,119 @@ constexpr int conv_halo_lds_floats() {
     return stage > epi ? stage : epi;
 }
 
+// The dense ("vector") epilogue of a tile, shared by conv_tile and by the second phase of the fused pair kernel (conv_fused_kernel):
+// accumulators -> LDS transpose -> per lane 4 consecutive pixels of one channel -> gate_scale / shift / addends / ReLU / gates ->
+// 16-byte store (+ this tensor's own 1-bit gates).  FUSE: the result is deposited in the LDS tile `mid` ([BD][BP], zeros where the
+// tile sticks out of the launch) instead of `p.dst` -- the intermediate of a fused pair never goes to memory.
+#define I2V_FROW(r) (MF16 ? 4 * lk + (r) : ((r) & 3) + 8 * ((r) >> 2) + 4 * lk)
+template <int BD, int BP, int WD, int WP, bool PREF, bool MF16, bool FUSE, typename ACC, typename PT>
+__device__ __forceinline__ void conv_vec_epilogue(const PT& p, ACC (&acc)[BD / WD / (MF16 ? 16 : 32)][BP / WP / (MF16 ? 16 : 32)], const int cd0,
+                                                  const int64_t px0, float* const smem, const float4* const pre0, const unsigned* const pregw,
+                                                  float* const mid) {
+    constexpr int FR = MF16 ? 16 : 32, NR = MF16 ? 4 : 16, TD = BD / WD / FR, TP = BP / WP / FR;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wd = wave / WP, wpx = wave % WP;
+    const int l31 = MF16 ? (lane & 15) : (lane & 31), lk = MF16 ? (lane >> 4) : (lane >> 5);
+    const int HWg = p.Hg * p.Wg, HoWo = p.Ho * p.Wo;
+    const int64_t P = (int64_t)p.N * HWg;
+    (void)pre0; (void)pregw; (void)mid;
+    // Dense output (grid == output plane, plane % 4 == 0): transpose the accumulators through LDS so
+    // that each lane owns 4 consecutive pixels of one channel; addends, gate and result then move as
+    // 16-byte accesses, 512 contiguous bytes per channel row.
+    constexpr int C4 = BP / 4, RSTEP = 1024 / BP, NQ = WD * FR / RSTEP;
+    const int c4 = t % C4, rbase = t / C4;
+    const int64_t pp = px0 + (int64_t)c4 * 4;
+    const bool pok = pp < P;
+    const int64_t n = pok ? fastdiv((unsigned)pp, p.dv_hw_m, p.dv_hw_s) : 0;
+    const int64_t poff = pp - n * HWg;
+    float (*Cs)[BP] = reinterpret_cast<float (*)[BP]>(smem);
+#pragma unroll
+    for (int i = 0; i < TD; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                Cs[wd * FR + I2V_FROW(r)][wpx * (BP / WP) + j * FR + l31] = acc[i][j][r];
+        __syncthreads();
+        {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int row = rbase + q * RSTEP;
+                const int cd = cd0 + (row / FR) * (BD / WD) + i * FR + (row % FR);
+                const bool valid = pok && cd < p.Cd;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid) {
+                v = *reinterpret_cast<const float4*>(&Cs[row][c4 * 4]);
+                const int64_t o = (int64_t)cd * HoWo + poff;
+                if (p.gate_scale) {      // pre-activation gate on THIS contribution, before the (accumulating) adds
+                    const float4 m = *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
+                    const float gs = p.gate_scale[cd], gt = p.gate_shift[cd];
+                    if (!(fmaf(m.x, gs, gt) > 0.f)) v.x = 0.f;
+                    if (!(fmaf(m.y, gs, gt) > 0.f)) v.y = 0.f;
+                    if (!(fmaf(m.z, gs, gt) > 0.f)) v.z = 0.f;
+                    if (!(fmaf(m.w, gs, gt) > 0.f)) v.w = 0.f;
+                }
+                if (p.shift) { const float sh = p.shift[cd]; v.x += sh; v.y += sh; v.z += sh; v.w += sh; }
+                if (PREF) {
+                    v.x += pre0[q].x; v.y += pre0[q].y; v.z += pre0[q].z; v.w += pre0[q].w;
+                } else {
+                    if (p.add0 && p.add0_stride == 1) {
+                        const float4 a = *reinterpret_cast<const float4*>(p.add0 + n * p.add0_nstride + o);
+                        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                    } else if (p.add0) {
+                        // compact stride-2 addend (input-gradient of a 1x1/2 shortcut): defined at even
+                        // (h, w) only; the 4 pixels start at a multiple of 4, so elements 0 and 2 receive
+                        const int oh = (int)fastdiv((unsigned)poff, p.dv_wo_m, p.dv_wo_s), ow = (int)(poff - (int64_t)oh * p.Wo);
+                        if (!(oh & 1) && (oh >> 1) < p.add0_H) {
+                            const float2 a = *reinterpret_cast<const float2*>(
+                                p.add0 + n * p.add0_nstride + (int64_t)cd * p.add0_H * p.add0_W + (oh >> 1) * p.add0_W + (ow >> 1));
+                            v.x += a.x; v.z += a.y;
+                        }
+                    }
+                }
+                if (p.add1) {
+                    const float4 a = *reinterpret_cast<const float4*>(p.add1 + n * p.add1_nstride + o);
+                    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (p.gate) {            // 1-bit gates of the tensor whose gradient this is: 4 bits of one word
+                    const unsigned w = PREF ? pregw[q] : p.gate[(int64_t)cd * p.gate_stride + ((p.gate_pix0 + pp) >> 5)];
+                    const unsigned g = w >> ((unsigned)(p.gate_pix0 + pp) & 31u);
+                    if (!(g & 1u)) v.x = 0.f;
+                    if (!(g & 2u)) v.y = 0.f;
+                    if (!(g & 4u)) v.z = 0.f;
+                    if (!(g & 8u)) v.w = 0.f;
+                } else if (p.mask && !p.gate_scale) {
+                    const float4 m = *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
+                    if (!(m.x > 0.f)) v.x = 0.f;
+                    if (!(m.y > 0.f)) v.y = 0.f;
+                    if (!(m.z > 0.f)) v.z = 0.f;
+                    if (!(m.w > 0.f)) v.w = 0.f;
+                }
+                if constexpr (!FUSE) *reinterpret_cast<float4*>(p.dst + n * p.dst_nstride + o) = v;
+                }
+                if constexpr (FUSE)       // first phase of a fused pair: the finished tile stays in LDS, [channel][pixel], zeros outside
+                    *reinterpret_cast<float4*>(mid + (cd - cd0) * BP + c4 * 4) = v;
+                if (p.gate_out) {
+                    // this tensor's own gates: 8 consecutive lanes hold 32 consecutive pixels of one channel row
+                    // (BP/4 lanes per row, a multiple of 8); every lane takes part in the exchange, invalid ones with 0
+                    unsigned nib = valid ? ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) : 0u;
+                    nib <<= 4 * (lane & 7);
+                    // OR over the 8 lanes with DPP moves (VALU only; __shfl_xor would go through the LDS crossbar):
+                    // quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7-i of each 8)
+                    nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0xB1, 0xF, 0xF, true);
+                    nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x4E, 0xF, 0xF, true);
+                    nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x141, 0xF, 0xF, true);
+                    if (valid && (lane & 7) == 0)
+                        p.gate_out[(int64_t)cd * p.gate_out_stride + ((p.gate_out_pix0 + pp) >> 5)] = nib;
+                }
+            }
+        }
+    }
+}
+#undef I2V_FROW
+
 // One tile of the implicit GEMM.  `bid` of `nwg` blocks share `n_cd_tiles` channel tiles per pixel tile, the first pixel tile
 // starting at pixel `px_base` (a launch may be cut into regions with different tile shapes, conv_igemm_tail below).
 // CPB ("chunks per barrier", round 4): an LDS buffer holds CPB consecutive K chunks and the loop synchronises once per CPB chunks --
@@ -174,9 +287,10 @@ constexpr int conv_halo_lds_floats() {
 // MFMA.  Those are what a block that is alone on its CU (an under-filled launch: a single 32-frame clip leaves the 14x14 layers
 // with 1.5 tiles per CU) cannot hide behind a neighbour.  Costs LDS (64x64: 32 KB, 5 resident blocks), so it is one more
 // configuration of the autotuner (bit 6), for launches whose chunk count is a multiple of CPB.
-template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false, int HWM = 0, int CPB = 1>
+template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false, int HWM = 0, int CPB = 1, int FUSE = 0>
 __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd_tiles, const int bid, const int nwg, const int64_t px_base,
-                                          float* const smem, I2V_PROBE_T& probe, const int probe_slot, const int prio_arg = I2V_PRIO_LEVELS) {
+                                          float* const smem, I2V_PROBE_T& probe, const int probe_slot, const int prio_arg = I2V_PRIO_LEVELS,
+                                          float* const mid = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)      // buffer-resource types and LDS-DMA builtins exist only in the device pass
     constexpr int KC = I2V_KC;
     constexpr int FR = MF16 ? 16 : 32;                       // fragment edge
@@ -632,98 +746,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     // ---- epilogue: shift, addends, ReLU, gradient gate, NCHW store ----
     const int HoWo = p.Ho * p.Wo;
     if (p.vec_epilogue) {
-        // Dense output (grid == output plane, plane % 4 == 0): transpose the accumulators through LDS so
-        // that each lane owns 4 consecutive pixels of one channel; addends, gate and result then move as
-        // 16-byte accesses, 512 contiguous bytes per channel row.
-        constexpr int C4 = BP / 4, RSTEP = 1024 / BP, NQ = WD * FR / RSTEP;
-        const int c4 = t % C4, rbase = t / C4;
-        const int64_t pp = px0 + (int64_t)c4 * 4;
-        const bool pok = pp < P;
-        const int64_t n = pok ? fastdiv((unsigned)pp, p.dv_hw_m, p.dv_hw_s) : 0;
-        const int64_t poff = pp - n * HWg;
-        float (*Cs)[BP] = reinterpret_cast<float (*)[BP]>(smem);
-#pragma unroll
-        for (int i = 0; i < TD; ++i) {
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < TP; ++j)
-#pragma unroll
-                for (int r = 0; r < NR; ++r)
-                    Cs[wd * FR + I2V_FROW(r)][wpx * (BP / WP) + j * FR + l31] = acc[i][j][r];
-            __syncthreads();
-            {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const int row = rbase + q * RSTEP;
-                    const int cd = cd0 + (row / FR) * (BD / WD) + i * FR + (row % FR);
-                    const bool valid = pok && cd < p.Cd;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (valid) {
-                    v = *reinterpret_cast<const float4*>(&Cs[row][c4 * 4]);
-                    const int64_t o = (int64_t)cd * HoWo + poff;
-                    if (p.gate_scale) {      // pre-activation gate on THIS contribution, before the (accumulating) adds
-                        const float4 m = *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
-                        const float gs = p.gate_scale[cd], gt = p.gate_shift[cd];
-                        if (!(fmaf(m.x, gs, gt) > 0.f)) v.x = 0.f;
-                        if (!(fmaf(m.y, gs, gt) > 0.f)) v.y = 0.f;
-                        if (!(fmaf(m.z, gs, gt) > 0.f)) v.z = 0.f;
-                        if (!(fmaf(m.w, gs, gt) > 0.f)) v.w = 0.f;
-                    }
-                    if (p.shift) { const float sh = p.shift[cd]; v.x += sh; v.y += sh; v.z += sh; v.w += sh; }
-                    if (PREF) {
-                        v.x += pre0[q].x; v.y += pre0[q].y; v.z += pre0[q].z; v.w += pre0[q].w;
-                    } else {
-                        if (p.add0 && p.add0_stride == 1) {
-                            const float4 a = *reinterpret_cast<const float4*>(p.add0 + n * p.add0_nstride + o);
-                            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-                        } else if (p.add0) {
-                            // compact stride-2 addend (input-gradient of a 1x1/2 shortcut): defined at even
-                            // (h, w) only; the 4 pixels start at a multiple of 4, so elements 0 and 2 receive
-                            const int oh = (int)fastdiv((unsigned)poff, p.dv_wo_m, p.dv_wo_s), ow = (int)(poff - (int64_t)oh * p.Wo);
-                            if (!(oh & 1) && (oh >> 1) < p.add0_H) {
-                                const float2 a = *reinterpret_cast<const float2*>(
-                                    p.add0 + n * p.add0_nstride + (int64_t)cd * p.add0_H * p.add0_W + (oh >> 1) * p.add0_W + (ow >> 1));
-                                v.x += a.x; v.z += a.y;
-                            }
-                        }
-                    }
-                    if (p.add1) {
-                        const float4 a = *reinterpret_cast<const float4*>(p.add1 + n * p.add1_nstride + o);
-                        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-                    }
-                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (p.gate) {            // 1-bit gates of the tensor whose gradient this is: 4 bits of one word
-                        const unsigned w = PREF ? pregw[q] : p.gate[(int64_t)cd * p.gate_stride + ((p.gate_pix0 + pp) >> 5)];
-                        const unsigned g = w >> ((unsigned)(p.gate_pix0 + pp) & 31u);
-                        if (!(g & 1u)) v.x = 0.f;
-                        if (!(g & 2u)) v.y = 0.f;
-                        if (!(g & 4u)) v.z = 0.f;
-                        if (!(g & 8u)) v.w = 0.f;
-                    } else if (p.mask && !p.gate_scale) {
-                        const float4 m = *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
-                        if (!(m.x > 0.f)) v.x = 0.f;
-                        if (!(m.y > 0.f)) v.y = 0.f;
-                        if (!(m.z > 0.f)) v.z = 0.f;
-                        if (!(m.w > 0.f)) v.w = 0.f;
-                    }
-                    *reinterpret_cast<float4*>(p.dst + n * p.dst_nstride + o) = v;
-                    }
-                    if (p.gate_out) {
-                        // this tensor's own gates: 8 consecutive lanes hold 32 consecutive pixels of one channel row
-                        // (BP/4 lanes per row, a multiple of 8); every lane takes part in the exchange, invalid ones with 0
-                        unsigned nib = valid ? ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) : 0u;
-                        nib <<= 4 * (lane & 7);
-                        // OR over the 8 lanes with DPP moves (VALU only; __shfl_xor would go through the LDS crossbar):
-                        // quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7-i of each 8)
-                        nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0xB1, 0xF, 0xF, true);
-                        nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x4E, 0xF, 0xF, true);
-                        nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x141, 0xF, 0xF, true);
-                        if (valid && (lane & 7) == 0)
-                            p.gate_out[(int64_t)cd * p.gate_out_stride + ((p.gate_out_pix0 + pp) >> 5)] = nib;
-                    }
-                }
-            }
-        }
+        conv_vec_epilogue<BD, BP, WD, WP, PREF, MF16, FUSE != 0>(p, acc, cd0, px0, smem, pre0, pregw, mid);
         return;
     }
     if (p.blk > 1 || (VID && p.blkt > 1)) {
@@ -848,6 +871,148 @@ conv_igemm_halo(const I2VConvParams p, const int n_cd_tiles) {
     I2V_PROBE_T probe;
     probe.entry();
     conv_tile<64, 64, 2, 2, 5, false, false, false, false, HWM>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x);
+    probe.exit(blockIdx.x);
+}
+
+// =============================================================================================
+// Fused pair (round 4): 3x3 convolution -> pointwise convolution over its channels, one launch
+// =============================================================================================
+// A bottleneck's conv2 (3x3, Cmid -> Cmid) and conv3 (1x1, Cmid -> 4 Cmid, + residual, ReLU) -- and, in the backward pass, the input
+// gradient of conv2 (a 3x3 convolution with the flipped filter) followed by the input gradient of conv1 (1x1, Cmid -> 4 Cmid, + the
+// residual path's gradient, gate) -- are a matrix-bound launch followed by an HBM-bound one whose only product is the other's operand.
+// Unfused, the Cmid-channel intermediate is written and read back, and the two launches cannot overlap: the expand convolution streams
+// at ~4.3 TB/s of algorithmic bytes (elementwise kernels reach 4.7-4.9 on this part) with the matrix pipe half idle, then the 3x3 runs
+// with HBM idle.  Here a block computes its 64-pixel tile of ALL Cmid intermediate channels (phase 1: conv_tile's own main loop,
+// MODE 2 or halo staging; its epilogue -- shift / ReLU / gates -- deposits the tile in LDS as [channel][pixel], which IS the B-operand
+// image of a pointwise K loop), then runs the pointwise convolution over its Cout / 64 channel tiles with only the weights staged by
+// DMA (phase 2), each through the ordinary dense epilogue.  The intermediate never goes to memory (only its 1-bit gates do), and the
+// blocks of a CU are in different phases, so one block's streaming overlaps another's matrix work.  Every output element is the same
+// k-ordered chain over the same fp32 values as in the two separate launches: bit-identical (tests/test_gpu_video.py).
+// Phase 2 of the fused pair.  The epilogue operands of a channel tile (first addend -- the residual --, and the 1-bit gate words) are
+// fetched into registers ONE TILE AHEAD (`prefetch`), tile 0's before phase 1 even starts (conv_fused_kernel): a channel tile's K loop
+// is 4-8 chunks, far too short to cover a memory round trip issued at its start.
+template <int BD1>
+struct PwPre { float4 a0[2][4]; unsigned gw[2][4]; };
+// (PT: the parameter block is read through a pointer into the kernel-argument segment -- constant address space, scalar loads -- that
+// conv_fused_kernel launders per use: the fields are then loaded where they are needed and die there.  Named as a by-value argument
+// next to phase 1's block, its ~40 live scalars pushed the kernel over the 102-SGPR file and the spills into VGPRs cost two blocks
+// per CU.)
+template <int BD1, typename PT>
+__device__ __forceinline__ void conv_pw_prefetch(const PT& p, const int64_t px0, const int ct, float4 (&a0)[4], unsigned (&gw)[4]) {
+    const int t = threadIdx.x;
+    const int HWg = p.Hg * p.Wg;
+    const int64_t P = (int64_t)p.N * HWg;
+    const int e_c4 = t % 16, e_rbase = t / 16;
+    const int64_t e_pp = px0 + (int64_t)e_c4 * 4;
+    const bool e_ok = e_pp < P;
+    const int64_t e_n = e_ok ? fastdiv((unsigned)e_pp, p.dv_hw_m, p.dv_hw_s) : 0;
+    const int64_t e_poff = e_pp - e_n * HWg;
+    const int e_HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = e_rbase + q * 16;
+        const int cd = ct * 64 + (row >> 5) * 32 + (row & 31);
+        const bool ok = e_ok && cd < p.Cd;
+        const int64_t o = (int64_t)cd * e_HoWo + e_poff;
+        // Every wave issues the SAME number of loads (a lane outside the launch reads element 0 and discards it): the K loop's first
+        // wait counts them (conv_pw_from_lds), and a wave whose lanes are all outside must not come up short.
+        if (p.add0) { const float4 v = *reinterpret_cast<const float4*>(p.add0 + (ok ? e_n * p.add0_nstride + o : 0)); a0[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
+        else a0[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.gate) { const unsigned v = p.gate[ok ? (int64_t)cd * p.gate_stride + ((p.gate_pix0 + e_pp) >> 5) : 0]; gw[q] = ok ? v : 0xffffffffu; }
+        else gw[q] = 0xffffffffu;
+    }
+}
+typedef const __attribute__((address_space(4))) I2VConvParams I2VConvParamsK;
+__device__ __forceinline__ I2VConvParamsK* conv_second_kernarg() {           // the SECOND I2VConvParams of conv_fused_kernel's argument list
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long v = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(I2VConvParams);
+    asm volatile("" : "+s"(v));                                               // no load is hoisted or shared across this point
+    return (I2VConvParamsK*)v;
+#else
+    return nullptr;
+#endif
+}
+template <int BD1>
+__device__ __forceinline__ void conv_pw_from_lds(const int64_t px0, const float* const mid, float* const smem,
+                                                 float4 (&pa)[2][4], unsigned (&pg)[2][4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KC = I2V_KC, NCH = BD1 / KC, KS = KC / 2;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    float (*As)[KC][64] = reinterpret_cast<float (*)[KC][64]>(smem);          // [2][16][64], under the epilogue's transpose buffer
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wd = wave >> 1, wpx = wave & 1;
+    const int l31 = lane & 31, lk = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int f = wave * 256 + lane * 4;                                       // this wave's quarter of a [16][64] chunk image
+    const int n_ct = (conv_second_kernarg()->Cd + 63) / 64;
+    const float* const mb = mid + lk * 64 + wpx * 32 + l31;                   // this lane's B element of k-step 0, chunk 0
+    auto tile = [&](const int ct, auto set_tag) {
+        constexpr int set = decltype(set_tag)::value;
+        const I2VConvParamsK& p = *conv_second_kernarg();
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.Kpad * p.Cdpad * 4, 0x00020000);
+        const unsigned aoff0 = (unsigned)(((f / 64) * p.Cdpad + f % 64) * 4);
+        const int cd0 = ct * 64;
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+        __syncthreads();                                                      // the previous tile's epilogue has left the transpose buffer
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(&As[0][0][0] + wv * 256), 16, aoff0 + (unsigned)(cd0 * 4), 0, 0, 0);
+        const bool more = ct + 1 < n_ct;
+        if (more) conv_pw_prefetch<BD1>(p, px0, ct + 1, pa[set ^ 1], pg[set ^ 1]);              // the NEXT tile's addend / gates
+        const int younger = more ? (p.add0 ? 4 : 0) + (p.gate ? 4 : 0) : 0;                       // loads issued behind the chunk-0 DMA
+        [&]<int... CC>(std::integer_sequence<int, CC...>) {
+            (([&] {
+                constexpr int c = CC, buf = CC & 1;
+                // the weight chunk is the wave's oldest-but-(prefetch) load: the prefetched operands may stay in flight
+                if (c == 0 && younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (c == 0 && younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                float fa[2], fb[2];
+                fa[0] = As[buf][lk][wd * 32 + l31]; fb[0] = mb[c * KC * 64];
+                [&]<int... S>(std::integer_sequence<int, S...>) {
+                    (([&] {
+                        constexpr int st = S, set2 = S & 1;
+                        if constexpr (st + 1 < KS) { fa[set2 ^ 1] = As[buf][2 * (st + 1) + lk][wd * 32 + l31]; fb[set2 ^ 1] = mb[(c * KC + 2 * (st + 1)) * 64]; }
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set2], fb[set2], acc[0][0], 0, 0, 0);
+                        if constexpr (st == 0 && c + 1 < NCH)                  // the next chunk's weights, behind the first MFMA
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(&As[buf ^ 1][0][0] + wv * 256), 16, aoff0 + (unsigned)(cd0 * 4),
+                                                                     (c + 1) * KC * p.Cdpad * 4, 0, 0);
+                    }()), ...);
+                }(std::make_integer_sequence<int, KS>{});
+            }()), ...);
+        }(std::make_integer_sequence<int, NCH>{});
+        conv_vec_epilogue<64, 64, 2, 2, true, false, false>(p, acc, cd0, px0, smem, pa[set], pg[set], nullptr);
+    };
+    for (int ct = 0; ct < n_ct; ct += 2) {
+        tile(ct, std::integral_constant<int, 0>{});
+        if (ct + 1 < n_ct) tile(ct + 1, std::integral_constant<int, 1>{});
+    }
+#endif
+}
+
+// LDS of the fused kernel: [phase-1 staging | phase-2 weight staging + transpose buffer] + the intermediate tile [BD1][64]
+template <int BD1, int HWM>
+constexpr int conv_fused_stage_floats() {
+    constexpr int st1 = HWM ? conv_halo_lds_floats<HWM>() : conv_lds_floats<BD1, 64, 2, false>();
+    return st1 > 64 * 64 ? st1 : 64 * 64;
+}
+template <int BD1, int HWM> constexpr int conv_fused_wpe() { return BD1 == 128 ? 2 : HWM == 56 ? 3 : 4; }      // bounded by LDS (two parameter blocks cost ~100 VGPRs: 5 would spill)
+template <int BD1, int HWM>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_fused_wpe<BD1, HWM>(), conv_fused_wpe<BD1, HWM>())))
+conv_fused_kernel(const I2VConvParams p1, const I2VConvParams /* p2: read through conv_second_kernarg() */) {
+    __shared__ __attribute__((aligned(16))) float smem[conv_fused_stage_floats<BD1, HWM>() + BD1 * 64];
+    float* const mid = smem + conv_fused_stage_floats<BD1, HWM>();
+    I2V_PROBE_T probe;
+    probe.entry();
+    // the pixel tile conv_tile takes (its XCD-aware remap with one channel tile per pixel tile)
+    const int nwg = gridDim.x, bid = blockIdx.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    float4 pa[2][4]; unsigned pg[2][4];
+    conv_pw_prefetch<BD1>(*conv_second_kernarg(), (int64_t)lid * 64, 0, pa[0], pg[0]);      // phase 2's first addend / gate tile rides under all of phase 1
+    conv_tile<BD1, 64, 2, 2, HWM ? 5 : 2, false, false, false, false, HWM, 1, 1>(p1, 1, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x, I2V_PRIO_LEVELS, mid);
+    __syncthreads();                                                          // the whole intermediate tile is in LDS
+    conv_pw_from_lds<BD1>((int64_t)lid * 64, mid, smem, pa, pg);
     probe.exit(blockIdx.x);
 }
 
@@ -1048,14 +1213,52 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
     return n;
 }
 
-int k_conv(const I2VConvParams& p_in, i2v_stream_t s) {
-    hipStream_t st = (hipStream_t)s;
-    I2VConvParams p = p_in;
-    if ((int64_t)p.N * p.Hg * p.Wg + 1024 >= (1ll << 31)) { snprintf(g_be_err, sizeof g_be_err, "conv launch of more than 2^31 grid pixels"); g_be_has_err = true; return 1; }
+static void conv_magics(I2VConvParams& p) {
     fastdiv_magic((unsigned)(p.Hg * p.Wg), &p.dv_hw_m, &p.dv_hw_s);
     fastdiv_magic((unsigned)p.Wg, &p.dv_w_m, &p.dv_w_s);
     fastdiv_magic((unsigned)(p.Tg > 0 ? p.Tg : 1), &p.dv_t_m, &p.dv_t_s);
     fastdiv_magic((unsigned)(p.Wo > 0 ? p.Wo : 1), &p.dv_wo_m, &p.dv_wo_s);
+}
+
+// Fused pair (conv_fused_kernel): `a` a 3x3 / stride-1 / same-size tap-uniform image convolution with 64 or 128 output channels and a
+// dense epilogue, `b` the pointwise convolution that reads exactly a's output.  Returns 0 (no), 1 (plain staging only) or 3 (halo
+// staging available too).  Whether a's output has OTHER readers is the planner's business (i2v_engine.cpp: mark_fusable).
+int k_conv_fusable(const I2VConvParams& a, const I2VConvParams& b) {
+    static const bool off = [] { const char* e = getenv("I2V_FUSE"); return e && e[0] == '0'; }();
+    if (off) return 0;
+    if (a.pointwise || !a.tap_uniform || a.temporal || a.quad || a.pre_scale || a.gate_scale || a.blk > 1 || a.blkt > 1) return 0;
+    if (a.sh != 1 || a.sw != 1 || a.Hs != a.Hg || a.Ws != a.Wg || a.Hg != a.Ho || a.Wg != a.Wo || a.osh != 1 || a.osw != 1 || a.oh0 || a.ow0) return 0;
+    if ((a.Cd != 64 && a.Cd != 128) || a.Kpad != a.K || a.add0_stride > 1) return 0;
+    if (!b.pointwise || b.temporal || b.quad || b.pre_scale || b.gate_scale || b.blk > 1 || b.blkt > 1 || b.add0_stride > 1) return 0;
+    if (b.K != a.Cd || b.Kpad != b.K || b.Cs != a.Cd || b.src != a.dst || b.src_nstride != a.dst_nstride) return 0;
+    if (b.Hs != a.Ho || b.Ws != a.Wo || b.Hg != a.Hg || b.Wg != a.Wg || b.Ho != a.Ho || b.Wo != a.Wo || b.sh != 1 || b.sw != 1 || b.osh != 1 || b.osw != 1 ||
+        b.oh0 || b.ow0 || b.Cd < 64 || b.Tg != a.Tg) return 0;
+    return (a.Cd == 64 && conv_halo_ok(a)) ? 3 : 1;
+}
+
+int k_conv_fused(const I2VConvParams& a_in, const I2VConvParams& b_in, int halo, i2v_stream_t s) {
+    I2VConvParams a = a_in, b = b_in;
+    const int64_t P = (int64_t)a.N * a.Hg * a.Wg;
+    if (P + 1024 >= (1ll << 31) || b.N != a.N) { snprintf(g_be_err, sizeof g_be_err, "fused conv launch: bad grid"); g_be_has_err = true; return 1; }
+    const int ok = k_conv_fusable(a, b);
+    if (!ok || !a.vec_epilogue || !b.vec_epilogue || (halo && !(ok & 2))) { snprintf(g_be_err, sizeof g_be_err, "fused conv launch: pair not eligible"); g_be_has_err = true; return 1; }
+    conv_magics(a); conv_magics(b);
+    const dim3 grid((unsigned)((P + 63) / 64));
+    hipStream_t st = (hipStream_t)s;
+    if (a.Cd == 128) hipLaunchKernelGGL((conv_fused_kernel<128, 0>), grid, dim3(256), 0, st, a, b);
+    else if (!halo) hipLaunchKernelGGL((conv_fused_kernel<64, 0>), grid, dim3(256), 0, st, a, b);
+    else if (a.Ws == 14) hipLaunchKernelGGL((conv_fused_kernel<64, 14>), grid, dim3(256), 0, st, a, b);
+    else if (a.Ws == 28) hipLaunchKernelGGL((conv_fused_kernel<64, 28>), grid, dim3(256), 0, st, a, b);
+    else hipLaunchKernelGGL((conv_fused_kernel<64, 56>), grid, dim3(256), 0, st, a, b);
+    LAUNCH_CHECK("conv_fused");
+    return 0;
+}
+
+int k_conv(const I2VConvParams& p_in, i2v_stream_t s) {
+    hipStream_t st = (hipStream_t)s;
+    I2VConvParams p = p_in;
+    if ((int64_t)p.N * p.Hg * p.Wg + 1024 >= (1ll << 31)) { snprintf(g_be_err, sizeof g_be_err, "conv launch of more than 2^31 grid pixels"); g_be_has_err = true; return 1; }
+    conv_magics(p);
     if (p.cfg <= 0) p.cfg = conv_pick(p) + 1;          // the model's pick -- or $I2V_FORCE_CFG, which may carry the variant bits too
     switch ((p.cfg - 1) & 7) {
         case 0: return launch_conv_cfg<128, 128, 2, 2>(p, st);

@@ -370,6 +370,13 @@ class Net:
     def workspace_bytes(self) -> int:
         return self.eng.capi.i2v_net_workspace_bytes(self.eng.h, self.id)
 
+    def fusion_info(self):
+        """(eligible forward pairs, eligible backward pairs, fused forward pairs, fused backward pairs) of the planned launch lists
+        (`i2v_net_fusion_info`): 3x3 convolution + the pointwise convolution over its output as one launch."""
+        out = (C.c_int32 * 4)()
+        _lib.check(self.eng.capi, self.eng.capi.i2v_net_fusion_info(self.eng.h, self.id, out))
+        return tuple(int(v) for v in out)
+
     def forward(self, x: torch.Tensor):
         _lib.check(self.eng.capi, self.eng.capi.i2v_net_forward(self.eng.h, self.id, _ptr(x, self.eng), x.shape[0], self.eng.stream()))
 

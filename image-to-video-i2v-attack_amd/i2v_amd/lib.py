@@ -63,6 +63,7 @@ _PROTOS = {
     "i2v_net_tensor_frames": ([_P, _I, _I, C.POINTER(_I)], _I),
     "i2v_net_plan": ([_P, _I, C.POINTER(_I), _I, _I], _I),
     "i2v_net_workspace_bytes": ([_P, _I], C.c_size_t),
+    "i2v_net_fusion_info": ([_P, _I, _P], _I),
     "i2v_net_forward": ([_P, _I, _P, _I, _P], _I),
     "i2v_net_hook_info": ([_P, _I, _I, C.POINTER(_P), C.POINTER(_L), C.POINTER(_P), C.POINTER(_L),
                            C.POINTER(_L), C.POINTER(C.c_int32)], _I),

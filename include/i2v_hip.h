@@ -120,6 +120,11 @@ int i2v_net_tensor_frames(i2v_handle h, int net, int tensor, int* T);
  * the order the reference's forward hooks fire (image_attacks.py:281-283). */
 int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int n_hooks, int max_frames);
 size_t i2v_net_workspace_bytes(i2v_handle h, int net);
+/* Fused pairs of a planned net (a 3x3 convolution and the pointwise convolution over its output as ONE launch, the intermediate
+ * kept in LDS -- a bottleneck's conv2 -> conv3, `torchvision.models.resnet.Bottleneck.forward`, and the mirrored pair of input
+ * gradients): out[0..1] = pairs that qualify in the forward / backward launch list, out[2..3] = pairs the plan-time autotuner
+ * (or I2V_FORCE_FUSE) fused at the planned batch size.  Diagnostics; results never depend on it. */
+int i2v_net_fusion_info(i2v_handle h, int net, int32_t out[4]);
 
 /* ---- backbone execution ----------------------------------------------------------------
  * `_ = self.model(x)` up to the deepest hook (image_attacks.py:318,334).  x: (frames,3,H,W). */

@@ -423,6 +423,52 @@ def test_two_chunks_per_barrier_is_bit_identical(eng, monkeypatch):
     assert float(outs[0][1].abs().max()) > 0
 
 
+def test_fused_3x3_pointwise_pairs_are_bit_identical(eng, monkeypatch):
+    """`conv_fused_kernel` (round 4): a 3x3 convolution and the pointwise convolution over its output as ONE launch, the intermediate kept
+    in LDS -- a bottleneck's conv2 -> conv3 and, in the backward list, the input gradients of conv2 -> conv1.  Forced onto every pair
+    the planner admits (I2V_FORCE_FUSE = 1: plain staging, 2: halo staging where the plane is 14 / 28 / 56 wide), on a three-stage
+    bottleneck stack: 64- and 128-channel intermediates, a shortcut convolution between conv2 and conv3 (the planner swaps it out of
+    the way), residual / ReLU / gate epilogues, a 96-channel output (partial channel tile), tiles that straddle frames and a pixel
+    tail -- against the two-launch plan: features and input gradient bit for bit."""
+    monkeypatch.setenv("I2V_AUTOTUNE", "0")
+    g = graphs.Graph("fuse_test", (56, 56))
+    x = g.new_tensor(3, 56, 56, False, "input")
+    g.input = x
+    a = g.conv(x, 64, 3, 1, 1, "a.weight", bn="a_bn", relu=True)
+    c1 = g.conv(a, 64, 1, 1, 0, "c1.weight", bn="c1_bn", relu=True)
+    c2 = g.conv(c1, 64, 3, 1, 1, "c2.weight", bn="c2_bn", relu=True)                    # 56 wide, 64-channel intermediate
+    d = g.conv(a, 256, 1, 1, 0, "d.weight", bn="d_bn", relu=False)                      # shortcut, planned between c2 and c3
+    c3 = g.conv(c2, 256, 1, 1, 0, "c3.weight", bn="c3_bn", relu=True, residual=d)
+    p1 = g.maxpool(c3, 2, 2)
+    r = g.conv(p1, 128, 1, 1, 0, "r.weight", bn="r_bn", relu=True)
+    e2 = g.conv(r, 128, 3, 1, 1, "e2.weight", bn="e2_bn", relu=True)                    # 28 wide, 128-channel intermediate
+    e3 = g.conv(e2, 256, 1, 1, 0, "e3.weight", bn="e3_bn", relu=True, residual=p1)
+    p2 = g.maxpool(e3, 2, 2)
+    f1 = g.conv(p2, 64, 1, 1, 0, "f1.weight", bn="f1_bn", relu=True)
+    f2 = g.conv(f1, 64, 3, 1, 1, "f2.weight", bn="f2_bn", relu=True)                    # 14 wide
+    f3 = g.conv(f2, 96, 1, 1, 0, "f3.weight", bn="f3_bn", relu=True)                    # 96 output channels: a partial second channel tile
+    g.hooks[1] = f3
+    sd = weights.synthetic_state_dict(g, 0)
+    frames = 5
+    xin = dev(torch.randn(frames, 3, 56, 56, generator=torch.Generator().manual_seed(0)))
+    outs, infos = [], []
+    for force in ("0", "1", "2"):
+        monkeypatch.setenv("I2V_FORCE_FUSE", force)
+        net = eng.build_net(g, sd, [f3], frames)
+        infos.append(net.fusion_info())
+        net.forward(xin)
+        ft = net.save_hook(0, frames).cpu()
+        write_hook_grads(net, [ft], [torch.randn(ft.shape, generator=torch.Generator().manual_seed(1))])
+        gx = torch.empty(frames, 3, 56, 56, device="cuda:0")
+        net.backward(gx)
+        outs.append((ft, gx.cpu()))
+        net.close()
+    assert infos[0][:2] == (3, 3) and infos[0][2:] == (0, 0) and infos[1][2:] == (3, 3) and infos[2][2:] == (3, 3), infos
+    for ft, gx in outs[1:]:
+        assert torch.equal(ft, outs[0][0]) and torch.equal(gx, outs[0][1])
+    assert float(outs[0][1].abs().max()) > 0
+
+
 def test_tail_split_is_bit_identical(eng, monkeypatch):
     """`conv_igemm_tail`: the remainder tiles of a launch as 16x64 quarter tiles in the same grid.  Forced onto every eligible launch
     (configuration 3 | 32) of a net whose layers leave remainders of 64 / 16 pixel tiles over the 256 CUs (576 and 144+... tiles), against
