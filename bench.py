@@ -59,7 +59,7 @@ def build_id():
     return h.hexdigest()[:16]
 
 
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r3_traffic_by_instantiation.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r4_traffic_by_instantiation.json")
 PMC_MFMA_BUSY = None      # MFMA-busy fraction of the conv launches from the same PMC summary (same build-id rule as the traffic)
 
 
@@ -72,7 +72,7 @@ def measured_traffic():
         with open(TRAFFIC_JSON) as fh:
             t = json.load(fh)
         if t.get("build_id") != build_id():
-            return None, f"profiles/r3_traffic_by_instantiation.json is from build {t.get('build_id')}, running {build_id()}"
+            return None, f"profiles/r4_traffic_by_instantiation.json is from build {t.get('build_id')}, running {build_id()}"
         global PMC_MFMA_BUSY
         PMC_MFMA_BUSY = t["conv_igemm"].get("mfma_busy_frac")
         return round(t["conv_igemm"]["hbm_bytes_per_launch"]), None
@@ -530,7 +530,7 @@ def run_rank(args):
                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                            "traffic": traffic,
-                           "traffic_unit": "B per launch (rocprofv3 PMC passes of this build: 2*FETCH_SIZE + WRITE_SIZE, profiles/r3_traffic_by_instantiation.json)",
+                           "traffic_unit": "B per launch (rocprofv3 PMC passes of this build: 2*FETCH_SIZE + WRITE_SIZE, profiles/r4_traffic_by_instantiation.json)",
                            "launches": int(c["launches"]), "avg_launch_us": round(1e3 * c["ms"] / c["launches"], 2),
                            "avg_gflop_per_launch": round(c["flops"] / c["launches"] / 1e9, 3),
                            "algorithmic_bytes_per_launch": round(c["bytes"] / c["launches"]),
