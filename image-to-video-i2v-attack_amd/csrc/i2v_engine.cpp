@@ -130,12 +130,13 @@ struct Net {
 // `chain`: the launch follows the previous timed launch back to back on the same stream (same launch list), so its
 // start IS that launch's stop event -- one event record per launch instead of two (the records cost ~2 us of stream
 // time each, 4 % of the headline bench when every launch carried a pair).
-struct TimedLaunch { void* start; void* stop; int kind; double flops; int Cd, K, HWg, frames, pw; void* chain_from; double bytes; };
+struct TimedLaunch { void* start; void* stop; int kind; double flops; int Cd, K, HWg, frames, pw; void* chain_from; double bytes; int count = 1; };
 struct i2v_ctx {
     int device; std::vector<Net*> nets; std::mutex nets_mu;     // the table: created / destroyed under the lock, ids of destroyed nets are handed out again
     // nets may be executed from several threads on several streams (clip lanes): entries are handed out under a lock,
     // live in a deque (stable addresses) and chain to an explicit event, never to "the previous entry"
-    bool timing = false; std::deque<TimedLaunch> timed; size_t timed_used = 0; std::mutex timing_mu;
+    int timing = 0;          // 0 off, 1 one event pair per launch, 2 one per SEGMENT (run of consecutive launches of one kind)
+    std::deque<TimedLaunch> timed; size_t timed_used = 0; std::mutex timing_mu;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1364,13 +1365,13 @@ static TimedLaunch* timing_begin(i2v_ctx* h, int kind, double flops, i2v_stream_
     {
         std::lock_guard<std::mutex> lock(h->timing_mu);
         if (h->timed_used == h->timed.size()) {
-            TimedLaunch fresh{be_event_create(), be_event_create(), 0, 0.0, 0, 0, 0, 0, 0, nullptr, 0.0};
+            TimedLaunch fresh{be_event_create(), be_event_create(), 0, 0.0, 0, 0, 0, 0, 0, nullptr, 0.0, 1};
             if (!fresh.start || !fresh.stop) return nullptr;
             h->timed.push_back(fresh);
         }
         t = &h->timed[h->timed_used++];
     }
-    t->kind = kind; t->flops = flops; t->Cd = t->K = t->HWg = t->frames = t->pw = 0; t->bytes = 0.0;
+    t->kind = kind; t->flops = flops; t->Cd = t->K = t->HWg = t->frames = t->pw = 0; t->bytes = 0.0; t->count = 1;
     t->chain_from = prev ? prev->stop : nullptr;
     if (!t->chain_from) be_event_record(t->start, s);
     return t;
@@ -1380,6 +1381,7 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
                     i2v_stream_t s, bool backward_pass) {
     const int clips = in_frames / n.Tin();
     TimedLaunch* prev_timed = nullptr;                   // the first launch of the list records its own start event
+    TimedLaunch* seg = nullptr;                          // segment mode: the open segment
     for (size_t li = 0; li < L.size(); ++li) {
         Launch& l = L[li];
         const int frames = clips * l.T;                  // frames this launch iterates over
@@ -1395,9 +1397,23 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
         const int tkind = (l.kind == L_CONV && backward_pass) ? 5 : (l.kind == L_AVGF || l.kind == L_POOL3F) ? 2
                           : (l.kind == L_AVGB || l.kind == L_POOL3B) ? 3 : (l.kind == L_MEMSET || l.kind == L_SOFTMAX) ? 4
                           : l.kind == L_AGEMM ? (backward_pass ? 5 : 0) : (int)l.kind;
-        TimedLaunch* tl = timing_begin(h, tkind, flops, s, prev_timed);
+        // Segment mode (i2v_timing_enable(h, 2)): consecutive launches of one kind share ONE event pair -- a forward list is three or
+        // four segments instead of fifty event records -- and the segment accumulates their flops / bytes / count; the per-launch
+        // fields of a dump line and the low-intensity split need mode 1.
+        TimedLaunch* tl = nullptr;
+        if (h->timing == 2) {
+            if (!seg || seg->kind != tkind) {
+                if (seg) be_event_record(seg->stop, s);
+                seg = timing_begin(h, tkind, 0.0, s, seg);
+                if (seg) seg->count = 0;
+            }
+            if (seg) { seg->flops += flops; seg->count += 1; }
+        } else tl = timing_begin(h, tkind, flops, s, prev_timed);
         prev_timed = tl;
-        if (tl && (l.kind == L_CONV || l.kind == L_IMGGRAD)) {
+        TimedLaunch seg_bytes_sink{};              // (segment mode: the byte count below is added to the open segment)
+        TimedLaunch* const bt = tl ? tl : (seg ? &seg_bytes_sink : nullptr);
+        if (bt && (l.kind == L_CONV || l.kind == L_IMGGRAD)) {
+            TimedLaunch* const tl = bt;
             tl->Cd = l.conv.Cd; tl->K = l.conv.K; tl->HWg = l.conv.Hg * l.conv.Wg; tl->frames = frames; tl->pw = l.conv.pointwise;
             // ALGORITHMIC bytes of the launch: every operand once -- the source view, the packed weights, the output, each
             // epilogue addend, and the ReLU gate (fp32 activation, or 1 bit per element) -- whatever the tiling re-reads
@@ -1422,6 +1438,7 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
             }
             tl->bytes = b;
         }
+        if (seg && !tl) seg->bytes += seg_bytes_sink.bytes;
         if (tl && l.kind == L_AGEMM) {                  // (dump fields: channels, reduction length, output columns, 10 + product form)
             const I2VAttnGemm& q = l.ag;
             tl->Cd = q.Cc; tl->K = q.form == 1 ? q.Cc : (q.form == 2 ? q.N : q.M); tl->HWg = q.form == 2 ? q.M : q.N; tl->frames = frames; tl->pw = 10 + q.form;
@@ -1466,6 +1483,7 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
             case L_SOFTMAX: { I2VSoftmaxRows p = l.sm; p.rows = (int64_t)clips * l.sm_rows_per_clip; CHECK_BE(k_softmax_rows(p, s)); } break;
         }
     }
+    if (seg) be_event_record(seg->stop, s);
     return 0;
 }
 
@@ -1495,7 +1513,7 @@ extern "C" int i2v_net_backward(i2v_handle h, int net, float* gx, int accumulate
 
 extern "C" int i2v_timing_enable(i2v_handle h, int enable) {
     if (!h) return fail("null handle");
-    h->timing = enable != 0; h->timed_used = 0;
+    h->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0); h->timed_used = 0;
     return 0;
 }
 
@@ -1517,8 +1535,8 @@ extern "C" int i2v_timing_collect_ex(i2v_handle h, double* out, int n_kinds, int
         if (dump) fprintf(dump, "%d %d %d %d %d %d %.4f %.3f %.3f\n", t.kind, t.Cd, t.K, t.HWg, t.frames, t.pw, ms, t.flops * 1e-9, t.bytes * 1e-6);
         if (t.kind < 0 || t.kind >= n_kinds) continue;
         double* o = out + (size_t)t.kind * n_fields;
-        o[0] += ms; o[1] += t.flops; o[2] += 1; o[3] += t.bytes;
-        if (t.bytes > 0 && t.flops < 19.7 * t.bytes) { o[4] += ms; o[5] += t.bytes; o[6] += 1; o[7] += t.flops; }
+        o[0] += ms; o[1] += t.flops; o[2] += t.count; o[3] += t.bytes;
+        if (h->timing != 2 && t.bytes > 0 && t.flops < 19.7 * t.bytes) { o[4] += ms; o[5] += t.bytes; o[6] += 1; o[7] += t.flops; }
     }
     if (dump) fclose(dump);
     h->timed_used = 0;

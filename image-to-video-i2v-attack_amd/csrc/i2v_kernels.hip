@@ -1070,7 +1070,11 @@ static int conv_tail_px_tiles(const I2VConvParams& p) {
     const int64_t tiles = n_px * n_cd;
     if (tiles < 2 * 256) return 0;
     const int r = (int)(tiles % 256);
-    if (r == 0 || r > 104) return 0;                  // a remainder beyond ~0.4 tiles per CU is better left as whole tiles
+    // a remainder beyond ~0.4 tiles per CU is better left as whole tiles.  (Round 4: ONE round plus a remainder -- a single 32-frame clip
+    // leaves the 14x14 layers with 392 tiles, 1.53 per CU -- was tried with the whole remainder as quarter tiles: layer3 3x3 81.9 ->
+    // 80.3 TFLOP/s, the K = 1024 reduce 78.1 -> 85.8 where two chunks per barrier reach 90.1: sixteen quarter tiles per pixel tile
+    // re-stage the activations four times as often.  Not offered.)
+    if (r == 0 || r > 104) return 0;
     return r / n_cd;
 }
 

@@ -88,7 +88,11 @@ class Engine:
     KINDS = ("conv_igemm_fwd", "conv_igemm_imggrad", "pool_fwd", "pool_bwd", "addmask", "conv_igemm_dgrad")
 
     def timing_enable(self, on=True):
-        _lib.check(self.capi, self.capi.i2v_timing_enable(self.h, 1 if on else 0))
+        """True / 1: one HIP event pair per backbone launch (per-launch times, the low-intensity split, dump lines);
+        'segments' / 2: one pair per run of consecutive launches of one kind (a forward list is 3-4 segments: ~2 % less
+        overhead on the headline attack, same per-kind totals); False: off."""
+        mode = 2 if on in (2, "segments") else (1 if on else 0)
+        _lib.check(self.capi, self.capi.i2v_timing_enable(self.h, mode))
 
     def timing_collect(self):
         """Per kernel kind: device ms, algorithmic flops, launches, algorithmic bytes, and the same over the launches

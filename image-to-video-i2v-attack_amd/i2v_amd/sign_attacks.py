@@ -185,6 +185,9 @@ class BIM(_SignAttack):
         """`_pre` on the native path: `g` is the frame-major input gradient; returns the clip-layout gradient the sign step takes."""
         return self._post_native(g, state, shape)
 
+    def _uses_momentum(self):
+        return bool(getattr(self, "momentum", False))
+
     def _gradient(self, adv, labels):
         """The gradient the step starts from; subclasses put their input transforms here (DI, SI)."""
         return self._grad_step(adv, labels)
@@ -203,6 +206,8 @@ class BIM(_SignAttack):
         adv = videos.clone().detach()
         b, c, f, h, w = videos.shape
         state = {}
+        if self.path == "native" and self._uses_momentum():     # allocated (a fill kernel) before the loop, not inside a step
+            state["momentum"] = torch.zeros(tuple(videos.shape), dtype=torch.float32, device=self.engine.device)
         for _ in range(self.steps):
             g = self._gradient(adv, labels)
             grad = self._pre_native(g, state, videos.shape) if self.path == "native" else self._pre(g, state).contiguous()
@@ -228,6 +233,9 @@ class MIFGSM(BIM):
     def _pre_native(self, g, state, shape):
         assert len(shape) == 5 and shape[2] == 32                        # norm_grads' own assertion (utils.py:59)
         return self._post_native(g, state, shape, "frame", momentum=True)
+
+    def _uses_momentum(self):
+        return True
 
 
 def _nearest_index(n_out: int, n_in: int):

@@ -147,7 +147,9 @@ int i2v_net_read_tensor(i2v_handle h, int net, int tensor, int which, float* out
  * 1 first-layer image gradient, 2 pool fwd, 3 pool bwd, 4 addmask, 5 conv_igemm input-gradient; n_kinds >= 6),
  * the summed device time,
  * the summed ALGORITHMIC flops (2*pixels*Cout*Cin*kh*kw per convolution launch) and the launch
- * count since the last collect. */
+ * count since the last collect.  `enable` = 2: one event pair per SEGMENT -- a run of consecutive launches of one kind in a launch
+ * list -- instead of per launch (the same per-kind totals at a fraction of the event records; the low-intensity split of
+ * `i2v_timing_collect_ex` and the per-launch dump need mode 1). */
 int i2v_timing_enable(i2v_handle h, int enable);
 int i2v_timing_collect(i2v_handle h, double* ms_by_kind, double* flops_by_kind,
                        int64_t* launches_by_kind, int n_kinds);
