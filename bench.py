@@ -593,6 +593,10 @@ def run_rank(args):
         out["config"]["workload"] = f"{args.workload} ensemble ({models}), batch={b} clips per GPU"
         for k in ("end_to_end_tflops_per_gpu", "algorithmic_gflop_per_frame"):
             out.pop(k, None)
+    if args.workload == "i2v" and getattr(atk, "_nets", None):       # what the autotuner did with the fusable 3x3 -> pointwise pairs (headline plan)
+        fi = atk._nets[0].fusion_info()
+        out["fused_pairs"] = {"eligible_fwd": fi[0], "eligible_bwd": fi[1], "fused_fwd": fi[2], "fused_bwd": fi[3],
+                              "note": "pairs run as one conv_fused_kernel launch at the planned batch size (autotuned per pair; DESIGN.md section 10)"}
     out["plan_ms"] = {"total": round(eng.plan_ms, 1), "plans": eng.plans,
                       "note": "host wall time of building the planned backbones (weight packing, upload, launch lists, plan-time "
                               "autotuning of every convolution launch); paid once per (backbone, resolution, max batch), never inside a timed region"}

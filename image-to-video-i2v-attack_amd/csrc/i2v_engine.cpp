@@ -1343,7 +1343,9 @@ static int autotune(Net& n) {
                     be_event_record(e1, nullptr);
                     if (rc || be_stream_sync(nullptr)) { rc = 1; break; }
                     float ms = 0.f; be_event_elapsed_ms(e0, e1, &ms);
-                    if (ms < best) { best = ms; best_v = v; }
+                    // one launch instead of two also saves whatever a tracing tool adds per dispatch (under `rocprofv3 --pmc` that made the
+                    // fused kernel "win" pairs it loses by 10-40 % in a plain run): it has to be 3 % faster to be taken
+                    if ((v == 0 ? ms : ms * 1.03f) < best) { best = v == 0 ? ms : ms * 1.03f; best_v = v; }
                     if (getenv("I2V_FUSE_DEBUG"))
                         fprintf(stderr, "[i2v fuse] %s pair %zu (Cd %d -> %d, %dx%d) at %d frames: variant %d = %.1f us\n", L == &n.fwd ? "fwd" : "bwd", i,
                                 a.conv.Cd, b.conv.Cd, a.conv.Hg, a.conv.Wg, lf, v, ms * 500.f);
@@ -1532,7 +1534,7 @@ extern "C" int i2v_timing_collect_ex(i2v_handle h, double* out, int n_kinds, int
         const TimedLaunch& t = h->timed[i];
         float ms = 0.f;
         CHECK_BE(be_event_elapsed_ms(t.chain_from ? t.chain_from : t.start, t.stop, &ms));
-        if (dump) fprintf(dump, "%d %d %d %d %d %d %.4f %.3f %.3f\n", t.kind, t.Cd, t.K, t.HWg, t.frames, t.pw, ms, t.flops * 1e-9, t.bytes * 1e-6);
+        if (dump && h->timing != 2) fprintf(dump, "%d %d %d %d %d %d %.4f %.3f %.3f\n", t.kind, t.Cd, t.K, t.HWg, t.frames, t.pw, ms, t.flops * 1e-9, t.bytes * 1e-6);
         if (t.kind < 0 || t.kind >= n_kinds) continue;
         double* o = out + (size_t)t.kind * n_fields;
         o[0] += ms; o[1] += t.flops; o[2] += t.count; o[3] += t.bytes;

@@ -10,6 +10,9 @@ mkdir -p $OUT
 python3 -c "import bench; print(bench.build_id())" > $OUT/build_id.txt
 cd /tmp && export TMPDIR=/tmp
 export I2V_CLIP_LANES=1     # one clip lane: a kernel's duration is then its own (bench.py's timed region does the same)
+export I2V_FUSE=0           # the plan-time autotuner runs INSIDE the profiled process, where every dispatch carries the tool's overhead: one
+                            # fused launch then "beats" two that win in a plain run.  The plain bench fuses nothing at 128 frames
+                            # (`fused_pairs` in its JSON line), so the profiled plan is made the same.
 CMD="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- $CMD > $OUT/fetch.log 2>&1
