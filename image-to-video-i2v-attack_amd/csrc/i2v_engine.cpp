@@ -1337,7 +1337,8 @@ static int autotune(Net& n) {
                 for (int v = 0; v <= ((a.fuse_ok & 2) ? 2 : 1) && !rc; ++v) {
                     auto once = [&]() { return v == 0 ? (conv_run(a, lf, xin, scratch + img, 0, nullptr) || conv_run(b, lf, xin, scratch + img, 0, nullptr))
                                                       : fused_run(a, b, lf, xin, v == 2, nullptr); };
-                    rc |= once();
+                    if (v > 0 && once()) { g_err.clear(); continue; }       // a fused variant that will not launch is simply not a candidate
+                    if (v == 0) rc |= once();
                     be_event_record(e0, nullptr);
                     for (int r = 0; r < 2 && !rc; ++r) rc |= once();
                     be_event_record(e1, nullptr);

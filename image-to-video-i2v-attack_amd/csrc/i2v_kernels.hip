@@ -1231,6 +1231,9 @@ int k_conv_fusable(const I2VConvParams& a, const I2VConvParams& b) {
     static const bool off = [] { const char* e = getenv("I2V_FUSE"); return e && e[0] == '0'; }();
     if (off) return 0;
     if (a.pointwise || !a.tap_uniform || a.temporal || a.quad || a.pre_scale || a.gate_scale || a.blk > 1 || a.blkt > 1) return 0;
+    // identity frame maps on both (the executor derives `temporal` from exactly this at run time: plan-time and run-time answers agree)
+    for (const I2VConvParams* q : {&a, &b})
+        if (!(q->Tg == q->Ts && q->Ts == q->To && q->st == 1 && q->ost == 1 && q->ot0 == 0 && q->blkt <= 1)) return 0;
     if (a.sh != 1 || a.sw != 1 || a.Hs != a.Hg || a.Ws != a.Wg || a.Hg != a.Ho || a.Wg != a.Wo || a.osh != 1 || a.osw != 1 || a.oh0 || a.ow0) return 0;
     if ((a.Cd != 64 && a.Cd != 128) || a.Kpad != a.K || a.add0_stride > 1) return 0;
     if (!b.pointwise || b.temporal || b.quad || b.pre_scale || b.gate_scale || b.blk > 1 || b.blkt > 1 || b.add0_stride > 1) return 0;

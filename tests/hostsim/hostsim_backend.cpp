@@ -46,6 +46,8 @@ int k_conv_fusable(const I2VConvParams& a, const I2VConvParams& b) {
     if (a.pointwise || !a.tap_uniform || a.temporal || a.quad || a.pre_scale || a.gate_scale || a.blk > 1 || a.blkt > 1) return 0;
     if (a.sh != 1 || a.sw != 1 || a.Hs != a.Hg || a.Ws != a.Wg || a.Hg != a.Ho || a.Wg != a.Wo) return 0;
     if ((a.Cd != 64 && a.Cd != 128) || a.Kpad != a.K || a.add0_stride > 1) return 0;
+    for (const I2VConvParams* q : {&a, &b})
+        if (!(q->Tg == q->Ts && q->Ts == q->To && q->st == 1 && q->ost == 1 && q->ot0 == 0 && q->blkt <= 1)) return 0;
     if (!b.pointwise || b.temporal || b.quad || b.pre_scale || b.gate_scale || b.blk > 1 || b.add0_stride > 1) return 0;
     if (b.K != a.Cd || b.Kpad != b.K || b.src != a.dst || b.src_nstride != a.dst_nstride || b.Hg != a.Hg || b.Wg != a.Wg || b.Cd < 64) return 0;
     return 1;
