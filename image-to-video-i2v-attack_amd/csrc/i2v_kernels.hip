@@ -183,6 +183,11 @@ __device__ __forceinline__ void conv_vec_epilogue(const PT& p, ACC (&acc)[BD / W
     const int HWg = p.Hg * p.Wg, HoWo = p.Ho * p.Wo;
     const int64_t P = (int64_t)p.N * HWg;
     (void)pre0; (void)pregw; (void)mid;
+#ifdef I2V_NT_ALL
+    const bool nt_store = true;
+#else
+    const bool nt_store = p.cfg > 0 && ((p.cfg - 1) & 128);
+#endif
     // Dense output (grid == output plane, plane % 4 == 0): transpose the accumulators through LDS so
     // that each lane owns 4 consecutive pixels of one channel; addends, gate and result then move as
     // 16-byte accesses, 512 contiguous bytes per channel row.
@@ -257,7 +262,16 @@ __device__ __forceinline__ void conv_vec_epilogue(const PT& p, ACC (&acc)[BD / W
                     if (!(m.z > 0.f)) v.z = 0.f;
                     if (!(m.w > 0.f)) v.w = 0.f;
                 }
-                if constexpr (!FUSE) *reinterpret_cast<float4*>(p.dst + n * p.dst_nstride + o) = v;
+                if constexpr (!FUSE) {
+                    // Streaming (non-temporal) store, autotuner bit 7 (round 4): the tile's 16-byte stores go past the L2 instead of
+                    // allocating lines in it.  Isolated (tools/pw_sweep.sh, configurations | 128): +13 % on 128 -> 512 @28^2, +13...20 % on
+                    // 64 -> 64 @56^2, +3 % on 64 -> 256 @56^2, -4 % on 256 -> 1024 @14^2: shape- and epilogue-dependent, so it is timed per launch
+                    // (second stage of the plan-time autotuner); in the attack it is worth 0.3-0.45 % (64 -> 256 forward -5 %).  Streaming LOADS of
+                    // the addend were measured too (+1.5...7 % alone, worse than the stores alone when combined) and not kept.
+                    if (nt_store) { typedef float nt4 __attribute__((ext_vector_type(4))); const nt4 w4 = {v.x, v.y, v.z, v.w};
+                                    __builtin_nontemporal_store(w4, reinterpret_cast<nt4*>(p.dst + n * p.dst_nstride + o)); }
+                    else *reinterpret_cast<float4*>(p.dst + n * p.dst_nstride + o) = v;
+                }
                 }
                 if constexpr (FUSE)       // first phase of a fused pair: the finished tile stays in LDS, [channel][pixel], zeros outside
                     *reinterpret_cast<float4*>(mid + (cd - cd0) * BP + c4 * 4) = v;
@@ -1250,6 +1264,7 @@ int k_conv_fused(const I2VConvParams& a_in, const I2VConvParams& b_in, int halo,
     const int ok = k_conv_fusable(a, b);
     if (!ok || !a.vec_epilogue || !b.vec_epilogue || (halo && !(ok & 2))) { snprintf(g_be_err, sizeof g_be_err, "fused conv launch: pair not eligible"); g_be_has_err = true; return 1; }
     conv_magics(a); conv_magics(b);
+    a.cfg = b.cfg = 0;                    // (the variant bits of the separate launches -- streaming stores among them -- do not apply)
     const dim3 grid((unsigned)((P + 63) / 64));
     hipStream_t st = (hipStream_t)s;
     if (a.Cd == 128) hipLaunchKernelGGL((conv_fused_kernel<128, 0>), grid, dim3(256), 0, st, a, b);

@@ -230,6 +230,8 @@ class Engine:
         b, c, f, h, w = (int(v) for v in shape)
         m = self.GRAD_POST_MODES[mode]
         g = g.contiguous()
+        assert g.numel() == b * c * f * h * w, (tuple(g.shape), (b, c, f, h, w))
+        assert momentum is None or (momentum.is_contiguous() and tuple(momentum.shape) == (b, c, f, h, w))
         out = torch.empty(b, c, f, h, w, dtype=torch.float32, device=g.device)
         nbytes = int(self.capi.i2v_grad_post_scratch_bytes(b, c, f, h, w, m))
         scratch = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=g.device)

@@ -533,7 +533,6 @@ class TAP(_SignAttack):
         net.forward(x)
         ns = [net.hook_frames(i, N) for i in range(len(stages))]
         clean = [net.save_hook(i, ns[i]).contiguous() for i in range(len(stages))]
-        std = torch.as_tensor(self.std, **kw)[:, None, None, None]
         unnorm = self._unnorm(videos)
         adv = videos.clone()
         k, kt = int(self.kernlen), int(self.temporal_kernlen)

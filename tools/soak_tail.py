@@ -1,6 +1,6 @@
 """Developer soak test (GPU box) for the 64x64 tile's variants: random three-layer image nets run with the plain 64x64 configuration and
 with a variant forced onto every eligible launch (no autotuning): features and input gradient must agree BIT FOR BIT.
-    python tools/soak_tail.py <seconds> [seed] [tail|halo|dc|fuse|fusehalo]
+    python tools/soak_tail.py <seconds> [seed] [tail|halo|dc|nt|fuse|fusehalo]
   tail: the tail split (conv_igemm_tail, I2V_FORCE_CFG = 3 | 32) on nets large enough to leave a remainder over the 256 CUs;
   halo: halo staging (conv_igemm_halo, 3 | 16) on planes 14 / 28 / 56 wide, any height, few or many frames;
   dc:   two K chunks per barrier (conv_igemm_dc, 3 | 64; round 4), channel counts that are multiples of 32;
@@ -16,7 +16,7 @@ from tests.test_gpu_video import write_hook_grads
 
 budget, seed = float(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 0
 mode = sys.argv[3] if len(sys.argv) > 3 else "tail"
-variant = 3 | {"halo": 16, "tail": 32, "dc": 64}.get(mode, 0)
+variant = 3 | {"halo": 16, "tail": 32, "dc": 64, "nt": 128}.get(mode, 0)           # nt: streaming epilogue stores (round 4)
 fuse = {"fuse": "1", "fusehalo": "2"}.get(mode)
 rnd = random.Random(seed)
 eng = attacks.get_engine("cuda:0")
@@ -25,7 +25,7 @@ while time.time() < t_end:
     H = rnd.choice([14, 20, 28, 33, 56]); W = rnd.choice([14, 28, 56] if mode in ("halo", "fusehalo") else [14, 24, 28, 40, 56])
     c1 = rnd.choice([16, 32, 48, 64]); c2 = rnd.choice([16, 32, 64, 80, 128, 256])
     k = rnd.choice([1, 3])
-    frames = rnd.choice([1, 2, 3, 5, 8, 24] if mode in ("halo", "dc", "fuse", "fusehalo") else [24, 40, 64, 96, 128])
+    frames = rnd.choice([1, 2, 3, 5, 8, 24] if mode in ("halo", "dc", "nt", "fuse", "fusehalo") else [24, 40, 64, 96, 128])
     if mode == "dc":
         c1 = rnd.choice([32, 64, 96]); c2 = rnd.choice([64, 96, 128, 256])
     if fuse:            # a (3 -> c1) -> b (3x3, c1 -> 64 | 128: the fused pair's first half) -> c (1x1 -> c3 >= 64, optional residual)
