@@ -336,3 +336,27 @@ def test_mid_trajectory_teacher_forced_step_hostsim(model):
     o32 = restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hooks[2]], dtype=torch.float32)
     gu.check_mid_trajectory_step(mk, [onet], vid, [1, 6], t=3, lr=0.005, tag=f"hostsim tiny {model}",
                                  fp32_nets=[o32] if model == "vgg" else None)     # both assertion modes
+
+
+def test_segment_timing_reports_the_same_totals_as_per_launch_timing():
+    """`i2v_timing_enable(h, 2)` (round 4): one event pair per SEGMENT -- a run of consecutive launches of one kind in a launch list --
+    instead of one per launch (what `bench.py`'s timed region uses: the per-launch records cost 1.7 % of the figure they measured).  The
+    per-kind launch counts, algorithmic flops and algorithmic bytes must be exactly those of the per-launch mode; only the low-intensity
+    split needs per-launch records.  Fused pairs (forced) count as one launch carrying both halves' flops in either mode."""
+    from i2v_amd import attacks
+    eng = hostsim_engine()
+    vid = torch.randn(1, 3, 2, 32, 32, generator=torch.Generator().manual_seed(5))
+    totals = {}
+    for mode in (True, "segments"):
+        atk = attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=3, step_size=0.005, steps=2, engine=eng, graph_builder=graphs.build_tiny,
+                                                  weight_seed=0)
+        atk(vid, torch.zeros(1, dtype=torch.long), ["w"])            # plan outside the timed call
+        eng.timing_enable(mode)
+        atk(vid, torch.zeros(1, dtype=torch.long), ["a"])
+        kt = eng.timing_collect()
+        eng.timing_enable(False)
+        totals[mode] = {k: (int(v["launches"]), v["flops"], v["bytes"]) for k, v in kt.items()}
+        if mode == "segments":
+            assert all(v["lowi_launches"] == 0 for v in kt.values())
+    assert totals[True] == totals["segments"], totals
+    assert totals[True]["conv_igemm_fwd"][0] > 0 and totals[True]["conv_igemm_dgrad"][0] > 0
