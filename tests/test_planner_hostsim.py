@@ -360,3 +360,35 @@ def test_segment_timing_reports_the_same_totals_as_per_launch_timing():
             assert all(v["lowi_launches"] == 0 for v in kt.values())
     assert totals[True] == totals["segments"], totals
     assert totals[True]["conv_igemm_fwd"][0] > 0 and totals[True]["conv_igemm_dgrad"][0] > 0
+
+
+def test_fusable_pairs_of_resnet50_are_found_and_change_nothing(monkeypatch):
+    """Round 4, planner side of the fused 3x3 -> pointwise pair (`mark_fusable`): on ResNet-50 -> layer3 the forward list holds six pairs
+    (conv2 -> conv3 of layer1's three and layer2's three stride-1 bottlenecks; the first bottleneck's shortcut convolution, planned
+    between conv2 and conv3, is swapped out of the way) and the backward list six (the input gradients of conv2 -> conv1).  A pair is
+    admitted only if nothing else touches the intermediate: a hook on a conv2 output removes that pair.  Forcing the fusion executes
+    the pairs through `k_conv_fused` (on the host: the two convolutions one after the other) -- features and gradient unchanged."""
+    eng = hostsim_engine()
+    g = graphs.build("resnet50", (32, 32))
+    sd = weights.synthetic_state_dict(g, 0)
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(0))
+    outs = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("I2V_FORCE_FUSE", force)
+        net = eng.build_net(g, sd, [g.hooks[3]], 2)
+        info = net.fusion_info()
+        assert info[:2] == (6, 6) and info[2:] == ((6, 6) if force == "1" else (0, 0)), info
+        net.forward(x)
+        f = net.save_hook(0, 2).clone()
+        write_hook_grads(net, [f], [torch.randn(f.shape, generator=torch.Generator().manual_seed(1))], 2)
+        gx = torch.empty(2, 3, 32, 32)
+        net.backward(gx)
+        outs.append((f, gx.clone()))
+        net.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # a hook on layer1.0.conv2's output: that tensor now has another reader
+    monkeypatch.setenv("I2V_FORCE_FUSE", "1")
+    t_conv2 = next(i for i, t in enumerate(g.tensors) if (t.name or "").endswith("layer1.0.conv2"))
+    net = eng.build_net(g, sd, [g.hooks[3], t_conv2], 2)
+    assert net.fusion_info()[0] == 5
+    net.close()
