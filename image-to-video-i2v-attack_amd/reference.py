@@ -72,7 +72,10 @@ def evaluate(model, adv_path, files_batch, device, clean_dir=None):
     return predictions, labels, hit / max(seen, 1)
 
 
-def main(argv=None):
+def main(argv=None, ucf101=False):
+    """`ucf101`: the UCF-101 twin (`/root/reference/reference_ucf101.py`, drop-in module of that name): 101 classes (`:125`) and
+    fine-tuned checkpoints from its own directory (`MODEL_TO_CKPTS`, `:24-31`) -- `$I2V_UCF_CKPT_PATH` takes the place of
+    `$I2V_WEIGHTS_DIR` for the native factory.  Everything else is the same code."""
     ap = argparse.ArgumentParser(description="")
     ap.add_argument("--adv_path", type=str, default="", help="the path of adversarial examples.")
     ap.add_argument("--gpu", type=str, default="0", help="gpu device.")
@@ -80,7 +83,10 @@ def main(argv=None):
     ap.add_argument("--models", type=str, default=",".join(DEFAULT_MODELS))
     ap.add_argument("--model_factory", type=str, default="proxy", help="'proxy', 'native' (i2v_amd.video.NativeClassifier) or pkg.module:function")
     ap.add_argument("--clean_dir", type=str, default="", help="directory of {label}-ori.npy clean clips")
+    ap.add_argument("--num_classes", type=int, default=101 if ucf101 else 400)
     args = ap.parse_args(argv)
+    if ucf101 and os.environ.get("I2V_UCF_CKPT_PATH"):
+        os.environ["I2V_WEIGHTS_DIR"] = os.environ["I2V_UCF_CKPT_PATH"]
     adv_path = os.path.join(os.environ.get("I2V_OPT_PATH", ""), args.adv_path)
     device = torch.device(f"cuda:{args.gpu.split(',')[0]}" if torch.cuda.is_available() else "cpu")
     if args.model_factory == "proxy":
@@ -95,7 +101,7 @@ def main(argv=None):
     files_batch = [files[i * args.batch_size:(i + 1) * args.batch_size] for i in range(nb)]
     model_val_acc, columns = {}, {}
     for name in [m for m in args.models.split(",") if m]:
-        model = factory(name).to(device).eval()
+        model = (factory(name, num_classes=args.num_classes) if factory in (proxy, native) else factory(name)).to(device).eval()
         preds, labels, top1 = evaluate(model, adv_path, files_batch, device, args.clean_dir or None)
         predd = np.zeros_like(preds)
         for i, ind in enumerate(np.argsort(labels)):          # reference.py:116-119

@@ -214,9 +214,43 @@ def test_sample_list_fixture():
 def test_run_image_guided_plan():
     import run_image_guided
     jobs = run_image_guided.plan("0", 1)
-    assert len(jobs) == 25 + 16 + 8 + 1
+    assert len(jobs) == 25 + 16 + 9 + 9           # Figure 4, Table 2, Table 3, Table 4
     assert any("ImageGuidedFML2_Adam_MultiModels" in j[0] for j in jobs)
-    assert jobs[0][1] == "Image-ImageGuidedFMDirection_Adam-20-resnet_step_size_0.001_paper_study"
+    assert jobs[0][1][-1] == "Image-ImageGuidedFMDirection_Adam-20-resnet_step_size_0.001_paper_study"
+    ucf = [j for j in jobs if j[0][1].endswith("image_main_ucf101.py")]
+    assert len(ucf) == 9 and all(j[1][1].endswith("reference_ucf101.py") for j in ucf)
+    for a, e in jobs:                             # every script the sweep starts exists next to it
+        assert os.path.isfile(a[1]) and os.path.isfile(e[1])
+
+
+def test_run_image_guided_matches_the_reference_commands(monkeypatch, capsys):
+    """The reference's own `run_image_guided.py` executed with `os.system` recording instead of running: its formatted
+    command lines (templates `:5-29`, loops `:44-100`), in order, against `plan()` flag for flag -- and against what
+    `--dry_run` prints."""
+    import runpy
+    import sys
+    from oracle import ref_shim
+    path = os.path.join(ref_shim.REFERENCE_DIR, "run_image_guided.py")
+    if not os.path.isfile(path):
+        pytest.skip("reference not present")
+    import run_image_guided
+    for gpu, bs in (("0", 1), ("3", 4)):
+        issued = []
+        monkeypatch.setattr(os, "system", lambda c: issued.append(c.split()) or 0)
+        monkeypatch.setattr(sys, "argv", ["run_image_guided.py", "--gpu", gpu, "--batch_size", str(bs)])
+        runpy.run_path(path, run_name="__main__")
+        monkeypatch.undo()
+        ours = [c for pair in run_image_guided.plan(gpu, bs) for c in pair]
+        assert len(issued) == len(ours) == 2 * 59
+        for ref, mine in zip(issued, ours):
+            assert ref[0] == "python" and mine[0] == sys.executable
+            assert ref[1] == os.path.basename(mine[1])
+            assert ref[2:] == mine[2:], (ref, mine)
+        monkeypatch.delenv("I2V_EVAL_CMD", raising=False)
+        monkeypatch.delenv("I2V_EVAL_ARGS", raising=False)
+        run_image_guided.main(["--gpu", gpu, "--batch_size", str(bs), "--dry_run"])
+        printed = [l.split() for l in capsys.readouterr().out.splitlines() if l.strip()]
+        assert [p[2:] for p in printed] == [r[2:] for r in issued]
 
 
 def _aens_worker(rank, world, port, out_dir):
