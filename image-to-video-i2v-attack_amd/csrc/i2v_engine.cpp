@@ -1204,14 +1204,47 @@ static int conv_run(const Launch& l, int frames, const float* x, float* gx, int 
 // (as source, addend, mask, destination -- which also rules out I2V_GATES=0, whose backward pass reads fp32 activations, and the
 // in-place ReLU gain of i2v_net_set_relu_gain), no hook, and not the network input.  Conservative: any overlap of address ranges counts.
 static void mark_fusable(Net& n) {
-    const int64_t frames = n.maxN;
-    auto overlaps = [&](const void* q, const float* lo, const float* hi) { return q && (const float*)q >= lo && (const float*)q < hi; };
-    std::vector<std::pair<const float*, const float*>> hooked;
+    const int64_t frames = n.maxN, clips = n.maxN / n.Tin();
+    typedef std::pair<const float*, const float*> Range;
+    // extent of an operand: `fr` frames of stride `ns`, the last one `plane` floats long (a view of a wider buffer ends with its own
+    // channels, not with the frame stride); null operands have no extent
+    auto rng = [](const void* q, int64_t fr, int64_t ns, int64_t plane) {
+        const float* f = (const float*)q;
+        return f ? Range(f, f + (fr > 0 ? (fr - 1) * ns : 0) + std::max<int64_t>(plane, 1)) : Range(nullptr, nullptr);
+    };
+    auto meet = [](const Range& a, const Range& b) { return a.first && b.first && a.first < b.second && b.first < a.second; };
+    // every memory range a launch reads or writes, with the launch's OWN frame count; `skip_src` / `skip_dst` leave out the operand
+    // that legitimately is the intermediate (b's source, a's destination)
+    auto touches = [&](const Launch& c, const Range& w, bool skip_src, bool skip_dst) {
+        if (c.kind == L_CONV || c.kind == L_IMGGRAD) {
+            const I2VConvParams& q = c.conv;
+            const int64_t fs = clips * std::max(1, q.Ts), fo = clips * std::max(1, q.To), dplane = (int64_t)(q.blk > 1 ? q.Cd / (q.blk * q.blk) : q.Cd) * q.Ho * q.Wo;
+            return (!skip_src && meet(w, rng(q.src, fs, q.src_nstride, (int64_t)q.Cs * q.Hs * q.Ws))) ||
+                   meet(w, rng(q.add0, fo, q.add0_nstride, dplane)) || meet(w, rng(q.add1, fo, q.add1_nstride, dplane)) ||
+                   meet(w, rng(q.mask, fo, q.mask_nstride, dplane)) || (!skip_dst && meet(w, rng(q.dst, fo, q.dst_nstride, dplane)));
+        }
+        if (c.kind == L_ADDMASK) {
+            const int64_t fr = clips * std::max(1, c.T), pl = (int64_t)c.am.C * c.am.HW;
+            return meet(w, rng(c.am.out, fr, c.am.out_nstride, pl)) || meet(w, rng(c.am.a[0], fr, c.am.a_nstride[0], pl)) ||
+                   meet(w, rng(c.am.a[1], fr, c.am.a_nstride[1], pl)) || meet(w, rng(c.am.a[2], fr, c.am.a_nstride[2], pl)) ||
+                   meet(w, rng(c.am.mask, fr, c.am.mask_nstride, pl));
+        }
+        if (c.kind == L_MEMSET) return meet(w, rng(c.ms_ptr, 1, 0, (int64_t)c.ms_floats_per_frame * clips * std::max(1, c.T)));
+        if (c.kind == L_AGEMM || c.kind == L_SOFTMAX) return true;     // attention launches address whole matrices: not analysed, such nets are not fused
+        const I2VPoolParams& q = c.pool;
+        const int64_t fr = clips * std::max(std::max(1, c.T), std::max(q.Ts, q.To)), pin = (int64_t)q.C * q.Hs * q.Ws, pout = (int64_t)q.C * q.Ho * q.Wo;
+        return meet(w, rng(q.x, fr, q.x_nstride, pin)) || meet(w, rng(q.gx, fr, q.gx_nstride, pin)) || meet(w, rng(q.y, fr, q.y_nstride, pout)) ||
+               meet(w, rng(q.yact, fr, q.yact_nstride, pout));
+    };
+    std::vector<Range> hooked;
     for (size_t h = 0; h < n.hooks.size(); ++h) {
         View a = view_of(n, n.hooks[h], false), g = view_of(n, n.hooks[h], true);
-        hooked.push_back({a.p, a.p + frames * a.nstride});
-        hooked.push_back({g.p, g.p + frames * g.nstride});
+        hooked.push_back(rng(a.p, frames, a.nstride, (int64_t)a.C * a.H * a.W));
+        hooked.push_back(rng(g.p, frames, g.nstride, (int64_t)g.C * g.H * g.W));
     }
+    auto dst_of = [&](const Launch& l) {
+        return rng(l.conv.dst, clips * std::max(1, l.conv.To), l.conv.dst_nstride, (int64_t)l.conv.Cd * l.conv.Ho * l.conv.Wo);
+    };
     // A first bottleneck runs its shortcut convolution between conv2 and conv3 (conv3 adds it): where that launch and the 3x3 are
     // independent of each other, they swap places so that the pair becomes adjacent.
     for (std::vector<Launch>* L : {&n.fwd, &n.bwd})
@@ -1219,12 +1252,8 @@ static void mark_fusable(Net& n) {
             Launch& a = (*L)[i]; Launch& c = (*L)[i + 1]; Launch& b = (*L)[i + 2];
             if (a.kind != L_CONV || c.kind != L_CONV || b.kind != L_CONV || a.src_is_input || c.src_is_input || !k_conv_fusable(a.conv, b.conv)) continue;
             if (k_conv_fusable(a.conv, c.conv)) continue;
-            auto rng = [&](const float* q, int64_t ns) { return std::pair<const float*, const float*>(q, q ? q + frames * ns : q); };
-            auto hit = [&](std::pair<const float*, const float*> w, const void* r) { return r && w.first && (const float*)r >= w.first && (const float*)r < w.second; };
-            const auto wa = rng(a.conv.dst, a.conv.dst_nstride), wc = rng(c.conv.dst, c.conv.dst_nstride);
             const I2VConvParams& pa = a.conv; const I2VConvParams& pc = c.conv;
-            const bool dep = hit(wa, pc.src) || hit(wa, pc.add0) || hit(wa, pc.add1) || hit(wa, pc.mask) || hit(wc, pa.src) || hit(wc, pa.add0) ||
-                             hit(wc, pa.add1) || hit(wc, pa.mask) || hit(wa, pc.dst) || hit(wc, pa.dst) ||
+            const bool dep = touches(c, dst_of(a), false, false) || touches(a, dst_of(c), false, false) ||
                              (pa.gate_out && (pa.gate_out == pc.gate || pa.gate_out == pc.gate_out)) || (pc.gate_out && pc.gate_out == pa.gate);
             if (!dep) std::swap(a, c);
         }
@@ -1235,29 +1264,12 @@ static void mark_fusable(Net& n) {
             if (a.kind != L_CONV || b.kind != L_CONV || a.src_is_input || b.src_is_input || a.T != b.T) continue;
             const int ok = k_conv_fusable(a.conv, b.conv);
             if (!ok) continue;
-            const float* lo = a.conv.dst; const float* hi = lo + frames * a.conv.dst_nstride;
+            const Range w = dst_of(a);
             bool other = false;
-            for (auto& hk : hooked) other |= (hk.first < hi && lo < hk.second);
+            for (auto& hk : hooked) other |= meet(hk, w);
             for (std::vector<Launch>* M : {&n.fwd, &n.bwd})
-                for (size_t j = 0; j < M->size() && !other; ++j) {
-                    const Launch& c = (*M)[j];
-                    const bool is_a = (M == L && j == i), is_b = (M == L && j == i + 1);
-                    if (c.kind == L_CONV || c.kind == L_IMGGRAD) {
-                        const I2VConvParams& q = c.conv;
-                        other |= (!is_b && overlaps(q.src, lo, hi)) || overlaps(q.add0, lo, hi) || overlaps(q.add1, lo, hi) || overlaps(q.mask, lo, hi) ||
-                                 (!is_a && overlaps(q.dst, lo, hi));
-                    } else if (c.kind == L_ADDMASK) {
-                        other |= overlaps(c.am.out, lo, hi) || overlaps(c.am.a[0], lo, hi) || overlaps(c.am.a[1], lo, hi) || overlaps(c.am.a[2], lo, hi) ||
-                                 overlaps(c.am.mask, lo, hi);
-                    } else if (c.kind == L_MEMSET) {
-                        other |= overlaps(c.ms_ptr, lo, hi);
-                    } else if (c.kind == L_AGEMM || c.kind == L_SOFTMAX) {
-                        other = true;              // (attention launches address whole matrices: not analysed, such nets are not fused)
-                    } else {
-                        const I2VPoolParams& q = c.pool;
-                        other |= overlaps(q.x, lo, hi) || overlaps(q.y, lo, hi) || overlaps(q.gx, lo, hi) || overlaps(q.yact, lo, hi);
-                    }
-                }
+                for (size_t j = 0; j < M->size() && !other; ++j)
+                    other |= touches((*M)[j], w, M == L && j == i + 1, M == L && j == i);
             if (!other) a.fuse_ok = ok;
             if (getenv("I2V_FUSE_DEBUG"))
                 fprintf(stderr, "[i2v fuse] %s pair %zu: 3x3 Cd=%d K=%d %dx%d -> 1x1 Cd=%d K=%d: eligible=%d other_reader=%d\n", L == &n.fwd ? "fwd" : "bwd", i,
@@ -1336,7 +1348,11 @@ static int autotune(Net& n) {
         }
     // Fused pairs, per batch bucket: the two launches on their tuned tiles against the pair as one kernel (plain / halo staging).
     // (Only where timing means something: the host simulation of the tests has one configuration of everything.)
-    const bool on_device = strncmp(be_name(), "hip", 3) == 0;
+    // Opt-in (I2V_FUSE=1) since round 5: the fused kernel loses 7-35 % on every pair at the headline size and wins 1-2 % on three pairs at
+    // 32 frames (profiles/r4_fuse_pairs.txt) -- not worth up to 9 probe launches per pair and bucket in every plan, nor a plan that
+    // depends on the process environment (a profiling tool's per-dispatch overhead flatters the single launch).
+    static const bool fuse_on = [] { const char* e = getenv("I2V_FUSE"); return e && e[0] == '1'; }();
+    const bool on_device = fuse_on && strncmp(be_name(), "hip", 3) == 0;
     for (std::vector<Launch>* L : {&n.fwd, &n.bwd})
         for (size_t i = 0; on_device && i + 1 < L->size() && !rc; ++i) {
             Launch& a = (*L)[i]; Launch& b = (*L)[i + 1];
@@ -1354,7 +1370,10 @@ static int autotune(Net& n) {
                 for (int v = 0; v <= ((a.fuse_ok & 2) ? 2 : 1) && !rc; ++v) {
                     auto once = [&]() { return v == 0 ? (conv_run(a, lf, xin, scratch + img, 0, nullptr) || conv_run(b, lf, xin, scratch + img, 0, nullptr))
                                                       : fused_run(a, b, lf, xin, v == 2, nullptr); };
-                    if (v > 0 && once()) { g_err.clear(); continue; }       // a fused variant that will not launch is simply not a candidate
+                    if (v > 0 && once()) {       // a fused variant that will not launch is simply not a candidate
+                        if (getenv("I2V_FUSE_DEBUG")) fprintf(stderr, "[i2v fuse] pair %zu variant %d does not launch: %s\n", i, v, g_err.c_str());
+                        g_err.clear(); continue;
+                    }
                     if (v == 0) rc |= once();
                     be_event_record(e0, nullptr);
                     for (int r = 0; r < 2 && !rc; ++r) rc |= once();
@@ -1599,6 +1618,16 @@ extern "C" int i2v_net_read_tensor(i2v_handle h, int net, int tensor, int which,
     if (tensor < 0 || tensor >= (int)n->tens.size() || tensor == n->input) return fail("bad tensor id");
     View v = view_of(*n, tensor, which != 0);
     if (frames <= 0 || frames > n->maxN / n->Tin() * v.T) return fail("bad frame count");
+    // The intermediate of a fused pair (k_conv_fused) is never stored: reading it back would hand out stale arena contents.
+    for (const std::vector<Launch>* L : {&n->fwd, &n->bwd})
+        for (const Launch& l : *L) {
+            if (l.kind != L_CONV || !l.fuse_ok || !(l.fuse_b[0] | l.fuse_b[1] | l.fuse_b[2] | l.fuse_b[3])) continue;
+            const float* lo = l.conv.dst; const float* hi = lo + (int64_t)(n->maxN / n->Tin() * std::max(1, l.conv.To) - 1) * l.conv.dst_nstride + (int64_t)l.conv.Cd * l.conv.Ho * l.conv.Wo;
+            const float* vlo = v.p; const float* vhi = v.p + (int64_t)(frames - 1) * v.nstride + (int64_t)v.C * v.H * v.W;
+            if (vlo < hi && lo < vhi)
+                return fail("i2v_net_read_tensor: this tensor is the intermediate of a fused 3x3 -> pointwise pair and is never stored "
+                            "(plan without I2V_FUSE / I2V_FORCE_FUSE to read it)");
+        }
     size_t row = (size_t)v.C * v.H * v.W * sizeof(float);
     CHECK_BE(be_d2d_2d(out, row, v.p, (size_t)v.nstride * sizeof(float), row, frames, stream));
     return 0;

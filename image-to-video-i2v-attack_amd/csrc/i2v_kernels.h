@@ -2,6 +2,7 @@
 // The product backend is i2v_kernels.hip (gfx950).  tests/hostsim/ holds a scalar host backend of
 // the same interface that exists ONLY so the planner can be unit-tested without a GPU.
 #pragma once
+#include <initializer_list>
 #include "i2v_params.h"
 
 typedef void* i2v_stream_t;
@@ -27,6 +28,21 @@ int k_conv(const I2VConvParams& p, i2v_stream_t s);
 // fused pair (3x3 convolution `a` -> pointwise convolution `b` over its channels, one launch, a's output never stored):
 // eligibility of the parameter pair (0 no, 1 plain staging, 3 also halo staging) and the launch (both vec_epilogue, same N)
 int k_conv_fusable(const I2VConvParams& a, const I2VConvParams& b);
+// The STRUCTURAL half of that answer, shared by every backend (the device adds only the halo-staging bit): `a` a 3x3 / stride-1 /
+// same-size tap-uniform image convolution with 64 or 128 output channels and a dense epilogue, `b` the pointwise convolution that
+// reads exactly a's output, both with identity frame maps (the executor derives `temporal` from exactly this at run time).
+inline bool i2v_conv_pair_fusable(const I2VConvParams& a, const I2VConvParams& b) {
+    if (a.pointwise || !a.tap_uniform || a.temporal || a.quad || a.pre_scale || a.gate_scale || a.blk > 1 || a.blkt > 1) return false;
+    for (const I2VConvParams* q : {&a, &b})
+        if (!(q->Tg == q->Ts && q->Ts == q->To && q->st == 1 && q->ost == 1 && q->ot0 == 0 && q->blkt <= 1)) return false;
+    if (a.sh != 1 || a.sw != 1 || a.Hs != a.Hg || a.Ws != a.Wg || a.Hg != a.Ho || a.Wg != a.Wo || a.osh != 1 || a.osw != 1 || a.oh0 || a.ow0) return false;
+    if ((a.Cd != 64 && a.Cd != 128) || a.Kpad != a.K || a.add0_stride > 1) return false;
+    if (!b.pointwise || b.temporal || b.quad || b.pre_scale || b.gate_scale || b.blk > 1 || b.blkt > 1 || b.add0_stride > 1) return false;
+    if (b.K != a.Cd || b.Kpad != b.K || b.Cs != a.Cd || b.src != a.dst || b.src_nstride != a.dst_nstride) return false;
+    if (b.Hs != a.Ho || b.Ws != a.Wo || b.Hg != a.Hg || b.Wg != a.Wg || b.Ho != a.Ho || b.Wo != a.Wo || b.sh != 1 || b.sw != 1 || b.osh != 1 || b.osw != 1 ||
+        b.oh0 || b.ow0 || b.Cd < 64 || b.Tg != a.Tg) return false;
+    return true;
+}
 int k_conv_fused(const I2VConvParams& a, const I2VConvParams& b, int halo, i2v_stream_t s);
 int k_conv_candidates(const I2VConvParams& p, int* out);   // tile configurations valid for p (ids 0..5, +8 = no epilogue prefetch), returns count
 int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t s);

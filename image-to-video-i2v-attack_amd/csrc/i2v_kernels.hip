@@ -121,7 +121,7 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 //   64x64 with epilogue prefetch  6  (78 registers; 7 would spill)
 //   128x64  6  (70 registers, 24 KB of LDS; +0.5 % over 5)     64x128  5  (83 registers, 32 KB)
 //   128x128  3  (147-150; left alone the allocator used 147 + 64 AGPRs = 2 blocks)
-// The 256-pixel tiles are bounded by LDS (4 blocks) and are left alone.  All without spills (-Rpass-analysis).
+// The 256-pixel tiles are bounded by LDS: 32x256 is compiled for the 4 blocks it gets, 16x256 is left alone.  All without spills (-Rpass-analysis).
 #ifndef I2V_PRIO_LEVELS      // progress-ordered wave priority in the K loop (conv_tile, chunk_body): highest level; 0 = off
 #define I2V_PRIO_LEVELS 3
 #endif
@@ -148,7 +148,7 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 #endif
 
 static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi, int MODE = 0) {
-    return (BD == 64 && BP == 64) ? (PREF ? (I2V_DEEP && MODE == 1 && I2V_DEEP_STAGES > 3 ? 4 /* 32 KB of LDS: the 5th block does not fit beside the runtime's own */ : I2V_PREF_WPE) : I2V_SMALL_WPE) : (BD == 128 && BP == 64) ? I2V_TALL_WPE : BD * BP == 8192 ? I2V_MID_WPE : BD * BP == 16384 ? I2V_BIG_WPE : (hi ? 8 : 1);
+    return (BD == 64 && BP == 64) ? (PREF ? (I2V_DEEP && MODE == 1 && I2V_DEEP_STAGES > 3 ? 4 /* 32 KB of LDS: the 5th block does not fit beside the runtime's own */ : I2V_PREF_WPE) : I2V_SMALL_WPE) : (BD == 128 && BP == 64) ? I2V_TALL_WPE : (BD == 32 && BP == 256) ? 4 /* LDS-bound: what the allocator delivers anyway */ : BD * BP == 8192 ? I2V_MID_WPE : BD * BP == 16384 ? I2V_BIG_WPE : (hi ? 8 : 1);
 }
 #define I2V_CONV_WPE __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(BD, BP, PREF, false, MODE), conv_waves_per_simd(BD, BP, PREF, true, MODE))))
 // The pointwise variant with prefetched epilogue operands (short K, HBM-bound) stages four chunks instead of two (conv_tile, DEEP)
@@ -1238,22 +1238,11 @@ static void conv_magics(I2VConvParams& p) {
     fastdiv_magic((unsigned)(p.Wo > 0 ? p.Wo : 1), &p.dv_wo_m, &p.dv_wo_s);
 }
 
-// Fused pair (conv_fused_kernel): `a` a 3x3 / stride-1 / same-size tap-uniform image convolution with 64 or 128 output channels and a
-// dense epilogue, `b` the pointwise convolution that reads exactly a's output.  Returns 0 (no), 1 (plain staging only) or 3 (halo
-// staging available too).  Whether a's output has OTHER readers is the planner's business (i2v_engine.cpp: mark_fusable).
+// Fused pair (conv_fused_kernel): the structural rule is i2v_conv_pair_fusable (i2v_kernels.h, shared with the host simulation).
+// Returns 0 (no), 1 (plain staging only) or 3 (halo staging available too).  Whether a's output has OTHER readers is the planner's
+// business (i2v_engine.cpp: mark_fusable).
 int k_conv_fusable(const I2VConvParams& a, const I2VConvParams& b) {
-    static const bool off = [] { const char* e = getenv("I2V_FUSE"); return e && e[0] == '0'; }();
-    if (off) return 0;
-    if (a.pointwise || !a.tap_uniform || a.temporal || a.quad || a.pre_scale || a.gate_scale || a.blk > 1 || a.blkt > 1) return 0;
-    // identity frame maps on both (the executor derives `temporal` from exactly this at run time: plan-time and run-time answers agree)
-    for (const I2VConvParams* q : {&a, &b})
-        if (!(q->Tg == q->Ts && q->Ts == q->To && q->st == 1 && q->ost == 1 && q->ot0 == 0 && q->blkt <= 1)) return 0;
-    if (a.sh != 1 || a.sw != 1 || a.Hs != a.Hg || a.Ws != a.Wg || a.Hg != a.Ho || a.Wg != a.Wo || a.osh != 1 || a.osw != 1 || a.oh0 || a.ow0) return 0;
-    if ((a.Cd != 64 && a.Cd != 128) || a.Kpad != a.K || a.add0_stride > 1) return 0;
-    if (!b.pointwise || b.temporal || b.quad || b.pre_scale || b.gate_scale || b.blk > 1 || b.blkt > 1 || b.add0_stride > 1) return 0;
-    if (b.K != a.Cd || b.Kpad != b.K || b.Cs != a.Cd || b.src != a.dst || b.src_nstride != a.dst_nstride) return 0;
-    if (b.Hs != a.Ho || b.Ws != a.Wo || b.Hg != a.Hg || b.Wg != a.Wg || b.Ho != a.Ho || b.Wo != a.Wo || b.sh != 1 || b.sw != 1 || b.osh != 1 || b.osw != 1 ||
-        b.oh0 || b.ow0 || b.Cd < 64 || b.Tg != a.Tg) return 0;
+    if (!i2v_conv_pair_fusable(a, b)) return 0;
     return (a.Cd == 64 && conv_halo_ok(a)) ? 3 : 1;
 }
 

@@ -721,9 +721,12 @@ class ILAF(object):
             raise TypeError("forward_independent needs a native VideoModel")
         return self._native(videos, ori_videos, video_names, independent=True)
 
-    def _native(self, videos, ori_videos, video_names, independent=None):
+    def _native(self, videos, ori_videos, video_names, independent=None, modifier0=None, keep_gradient=False):
         """The whole of `image_attacks.py:534-629` behind the C ABI.  Activations are frame-major (b*T, C, H, W); the
-        loss only needs whole-tensor norms and a dot product, so no layout change is ever materialised."""
+        loss only needs whole-tensor norms and a dot product, so no layout change is ever materialised.
+        `modifier0` (b*f, 3, h, w; frame-major like `self._modifier`) starts the loop from that perturbation instead of
+        `videos - ori_videos` and `keep_gradient` leaves the last step's input gradient in `self._last_gx` -- the teacher-forced step
+        of the parity tests (`tests/test_gpu_video.py`), nothing the reference's call protocol has."""
         eng = self._engine or get_engine()
         dev = eng.device
         kw = dict(dtype=torch.float32, device=dev)
@@ -765,6 +768,8 @@ class ILAF(object):
             raise ValueError(f"ILAF: the given adversarial clip equals its original at a hooked layer (|adv0 - ori| = 0), "
                              f"nothing to fine-tune: {who}")
         modifier = torch.sub(u_adv, u_ori)                                      # :574-575 existing perturbation
+        if modifier0 is not None:
+            modifier = modifier0.detach().to(**kw).reshape(N, 3, h, w).clone()
         gx = torch.empty_like(x)
         loss = torch.zeros(L, nseg, **kw)
         costs = torch.zeros(self.steps, nseg, **kw)
@@ -777,6 +782,8 @@ class ILAF(object):
                 net.ilaf_reduce(k, ori_f[k], adv_f[k], scratch, nf[k], frames_per_seg=fps[k])
                 net.ilaf_grad(k, ori_f[k], adv_f[k], init_sq[k], loss[k], scratch, nf[k], frames_per_seg=fps[k])
             net.backward(gx)                                                    # :613-614 (input gradient only)
+            if keep_gradient:
+                self._last_gx, self._last_modifier_in = gx.clone(), modifier.clone()
             eng.sign_step_delta_gx(modifier, gx, u_ori, eps, self.step_size)    # :617
             costs.index_copy_(0, slot, loss.sum(dim=0, keepdim=True))           # :611, stays on the device
             slot.add_(1)

@@ -83,7 +83,8 @@ def main(argv=None, ucf101=False):
     ap.add_argument("--models", type=str, default=",".join(DEFAULT_MODELS))
     ap.add_argument("--model_factory", type=str, default="proxy", help="'proxy', 'native' (i2v_amd.video.NativeClassifier) or pkg.module:function")
     ap.add_argument("--clean_dir", type=str, default="", help="directory of {label}-ori.npy clean clips")
-    ap.add_argument("--num_classes", type=int, default=101 if ucf101 else 400)
+    ap.add_argument("--num_classes", type=int, default=101 if ucf101 else None,
+                    help="classes of the built-in factories' heads (default: 400, the UCF-101 twin 101)")
     args = ap.parse_args(argv)
     if ucf101 and os.environ.get("I2V_UCF_CKPT_PATH"):
         os.environ["I2V_WEIGHTS_DIR"] = os.environ["I2V_UCF_CKPT_PATH"]
@@ -101,7 +102,8 @@ def main(argv=None, ucf101=False):
     files_batch = [files[i * args.batch_size:(i + 1) * args.batch_size] for i in range(nb)]
     model_val_acc, columns = {}, {}
     for name in [m for m in args.models.split(",") if m]:
-        model = (factory(name, num_classes=args.num_classes) if factory in (proxy, native) else factory(name)).to(device).eval()
+        own = factory in (proxy, native) and args.num_classes is not None
+        model = (factory(name, num_classes=args.num_classes) if own else factory(name)).to(device).eval()
         preds, labels, top1 = evaluate(model, adv_path, files_batch, device, args.clean_dir or None)
         predd = np.zeros_like(preds)
         for i, ind in enumerate(np.argsort(labels)):          # reference.py:116-119

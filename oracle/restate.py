@@ -344,11 +344,13 @@ def run_attack(nets: Sequence[OracleNet], videos: torch.Tensor, *, steps: int, s
     return out
 
 
-def run_ilaf(model, hook_modules, videos, ori_videos, *, steps, step_size=0.005, eps=16 / 255):
+def run_ilaf(model, hook_modules, videos, ori_videos, *, steps, step_size=0.005, eps=16 / 255, modifier0=None):
     """Restatement of `ILAF.forward` (`/root/reference/image_attacks.py:534-629`) for a torch video model whose
     hooked modules are `hook_modules`: whole-tensor norms, `-(0.5*|d|/|d0| + <d0/|d0|, d/|d|>)` summed over the
     hooked layers, gradient w.r.t. the perturbation through the clamped compose, `modifier -= step*sign(grad)`.
-    Returns (output in the reference's scrambled layout, costs[steps], first-step gradient, final modifier)."""
+    Returns (output in the reference's scrambled layout, costs[steps], first-step gradient, final modifier).
+    `modifier0` (b,c,f,h,w), test infrastructure only: start the loop from this perturbation instead of `videos - ori_videos`
+    (a teacher-forced step from another implementation's state; the initial direction still comes from `videos`)."""
     feats = []
     handles = [m.register_forward_hook(lambda mod, i, o: feats.append(o)) for m in hook_modules]
     dtype = videos.dtype
@@ -364,6 +366,8 @@ def run_ilaf(model, hook_modules, videos, ori_videos, *, steps, step_size=0.005,
         dir0 = [d / n for d, n in zip(d0, n0)]
         ori_u = ori_videos.clone().mul_(std).add_(mean)
         modifier = videos.clone().mul_(std).add_(mean) - ori_u                 # `torch.Tensor(t)` aliases t: dtype kept (:574-575)
+        if modifier0 is not None:
+            modifier = modifier0.to(dtype).clone()
         costs, grad0 = [], None
         for _ in range(steps):
             modifier.requires_grad_(True)

@@ -78,7 +78,9 @@ def compare(costs, delta, adv, ora):
     costs = np.asarray(costs, np.float64)
     oc = np.asarray(ora["costs"], np.float64)
     rel = np.abs(costs - oc) / np.abs(oc)
-    d_dev, d_ora = float(delta.float().abs().mean()), float(ora["delta"].float().abs().mean())
+    # (an oracle run that was saved by a worker process carries mean|delta| as a number instead of the tensor: oracle/fooling_worker.py)
+    d_dev = float(delta.float().abs().mean())
+    d_ora = float(ora["mean_abs_delta"]) if "mean_abs_delta" in ora else float(ora["delta"].float().abs().mean())
     diff = (adv.float() - ora["adv"].float()).abs()
     un = diff * STD                                                     # back to [0,1] pixel units
     return {"max_rel_cost_err": float(rel.max()), "rel_cost_err_last_step": float(rel[-1]),
@@ -93,6 +95,76 @@ def yardstick(net64, vid, ora32, steps=10, lr=0.005, eps=16 / 255):
     ora64 = oracle_attack(net64, vid.double(), steps=steps, lr=lr, eps=eps)
     ora64["delta"], ora64["adv"] = ora64["delta"].float(), ora64["adv"].float()
     return ora64, compare(ora32["costs"], ora32["delta"], ora32["adv"], ora64)
+
+
+YARDSTICK_NPZ = "size_parity_f64_seed1000.npz"      # tests/golden/, written by oracle/make_size_yardstick.py
+
+
+def load_yardstick(golden_dir, seed=1000, steps=10, lr=0.005):
+    """The committed float64 run of configs[0] on clip `seed` (`oracle/make_size_yardstick.py`): its costs, mean|delta_S| and every
+    STRIDE-th element of its perturbed clip -- or None when the request is not the configuration the file was made for."""
+    import os
+    path = os.path.join(golden_dir, YARDSTICK_NPZ)
+    if not os.path.isfile(path):
+        return None
+    z = np.load(path)
+    if int(z["seed"]) != seed or int(z["steps"]) != steps or float(z["lr"]) != lr:
+        return None
+    return {k: z[k] for k in z.files}
+
+
+def compare_sampled(costs, delta, adv, yard, lr=0.005):
+    """`compare` against the committed float64 run: the pixel statistics over its sample of the clip (every `stride`-th element of the
+    flattened (1,3,f,h,w) tensor: 117 k of 4.8 M values)."""
+    costs = np.asarray(costs, np.float64)
+    rel = np.abs(costs - yard["costs"]) / np.abs(yard["costs"])
+    flat = adv.float().reshape(-1)
+    assert flat.numel() == int(yard["numel"]), (flat.numel(), int(yard["numel"]))
+    stride = int(yard["stride"])
+    idx = torch.arange(0, flat.numel(), stride)
+    diff = (flat[idx] - torch.from_numpy(yard["adv_sample"])).abs()
+    chan = idx // (flat.numel() // 3)                                   # (1, 3, f, h, w): channel of every sampled element
+    un = diff * torch.tensor(restate.STD)[chan]
+    return {"max_rel_cost_err": float(rel.max()), "rel_cost_err_last_step": float(rel[-1]),
+            "mean_abs_delta_ratio": float(delta.float().abs().mean()) / float(yard["mean_abs_delta"]),
+            "mean_abs_adv_diff": float(diff.mean()), "frac_pixels_within_2lr": float((un <= 2 * lr).float().mean()),
+            "max_abs_adv_diff_pixel_units": float(un.max())}
+
+
+def start_oracle_workers(rows, out_dir, workers=8, threads=32, steps=10, lr=0.005, extra=()):
+    """Start `workers` CPU child processes of `oracle.fooling_worker` over `rows` (dealt round-robin, so the early rows of every worker
+    finish first); returns the Popen objects.  Children of the caller -- never an exec of the caller itself, which may hold the GPU."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = max(1, min(workers, len(rows)))
+    threads = max(1, min(threads, ncpu // workers))
+    procs = []
+    for w in range(workers):
+        mine = rows[w::workers]
+        cmd = [sys.executable, "-m", "oracle.fooling_worker", "--rows", ",".join(str(r) for r in mine), "--threads", str(threads), "--slot", str(w),
+               "--out", out_dir, "--steps", str(steps), "--lr", str(lr)] + list(extra)
+        procs.append(subprocess.Popen(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))))
+    return procs
+
+
+def wait_oracle_row(out_dir, row, procs, timeout=1800.0, lr=0.005):
+    """Block until row `row` of a `start_oracle_workers` run is complete; returns its `ora` dict (costs, mean_abs_delta, adv (1,3,f,h,w), lr).
+    Raises if a worker died without producing it."""
+    import os
+    done = os.path.join(out_dir, f"{row}-oracle.npz")
+    t0 = time.time()
+    while not os.path.exists(done):
+        if all(p.poll() is not None for p in procs) and not os.path.exists(done):
+            raise RuntimeError(f"oracle workers exited ({[p.returncode for p in procs]}) without row {row}")
+        if time.time() - t0 > timeout:
+            raise TimeoutError(f"oracle row {row} not ready after {timeout} s")
+        time.sleep(0.2)
+    z = np.load(done)
+    adv = torch.from_numpy(np.load(os.path.join(out_dir, f"{row}-oracle-adv.npy")))[None]
+    return {"costs": z["costs"], "mean_abs_delta": float(z["mean_abs_delta"]), "adv": adv, "lr": lr, "seconds": float(z["seconds"])}
 
 
 def within_bounds(dev_vs_32, dev_vs_64=None, ora32_vs_64=None):

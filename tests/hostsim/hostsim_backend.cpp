@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <limits>
 #include <vector>
 
 #include "../../image-to-video-i2v-attack_amd/csrc/i2v_kernels.h"
@@ -39,20 +40,17 @@ int cos_nblk(int64_t D) { return (int)std::min<int64_t>(64, std::max<int64_t>(1,
 int k_conv_candidates(const I2VConvParams&, int* out) { out[0] = 0; return 1; }
 
 // the fused pair on the host: the two convolutions one after the other (the intermediate IS written here; the device kernel keeps
-// it in LDS -- same values either way); eligibility is structural only and never chosen without the device autotuner
+// it in LDS -- same values either way); eligibility is the shared structural rule of i2v_kernels.h (no halo staging here) and never chosen without the device autotuner
 int k_conv(const I2VConvParams& p, i2v_stream_t);
-int k_conv_fusable(const I2VConvParams& a, const I2VConvParams& b) {
-    const char* e = getenv("I2V_FUSE"); if (e && e[0] == '0') return 0;
-    if (a.pointwise || !a.tap_uniform || a.temporal || a.quad || a.pre_scale || a.gate_scale || a.blk > 1 || a.blkt > 1) return 0;
-    if (a.sh != 1 || a.sw != 1 || a.Hs != a.Hg || a.Ws != a.Wg || a.Hg != a.Ho || a.Wg != a.Wo) return 0;
-    if ((a.Cd != 64 && a.Cd != 128) || a.Kpad != a.K || a.add0_stride > 1) return 0;
-    for (const I2VConvParams* q : {&a, &b})
-        if (!(q->Tg == q->Ts && q->Ts == q->To && q->st == 1 && q->ost == 1 && q->ot0 == 0 && q->blkt <= 1)) return 0;
-    if (!b.pointwise || b.temporal || b.quad || b.pre_scale || b.gate_scale || b.blk > 1 || b.add0_stride > 1) return 0;
-    if (b.K != a.Cd || b.Kpad != b.K || b.src != a.dst || b.src_nstride != a.dst_nstride || b.Hg != a.Hg || b.Wg != a.Wg || b.Cd < 64) return 0;
-    return 1;
+int k_conv_fusable(const I2VConvParams& a, const I2VConvParams& b) { return i2v_conv_pair_fusable(a, b) ? 1 : 0; }
+int k_conv_fused(const I2VConvParams& a, const I2VConvParams& b, int, i2v_stream_t s) {
+    if (k_conv(a, s) || k_conv(b, s)) return 1;
+    // the device kernel never stores the intermediate: poison it here, so that any reader the planner overlooked shows up as NaN
+    // in the CPU tests instead of passing on values the GPU would not have
+    for (int64_t f = 0; f < (int64_t)a.N / a.Tg * a.To; ++f)
+        std::fill(a.dst + f * a.dst_nstride, a.dst + f * a.dst_nstride + (int64_t)a.Cd * a.Ho * a.Wo, std::numeric_limits<float>::quiet_NaN());
+    return 0;
 }
-int k_conv_fused(const I2VConvParams& a, const I2VConvParams& b, int, i2v_stream_t s) { if (k_conv(a, s)) return 1; return k_conv(b, s); }
 int k_conv(const I2VConvParams& p, i2v_stream_t) {
     if (!p.temporal) {      // image variant of the kernel: the temporal fields are ignored (a launch that needs them
         I2VConvParams q = p; // but is not flagged must therefore FAIL the planner tests, as it would on the GPU)

@@ -203,7 +203,13 @@ def test_net_forward_backward_match_oracle(eng, model, depths, hw):
 
 
 @pytest.mark.parametrize("model,depths", [("resnet50", [3]), ("vgg", [3]), ("alexnet", [2, 4]), ("squeezenet", [2, 4]),
-                                          ("densenet121", [2, 4])])
+                                          ("densenet121", [2, 4]),
+                                          # round 5: the reference's OWN model grid -- `'resnet'` is ResNet-101, the CLI default
+                                          # (image_attacks.py:94-95), and run_image_guided.py:55-60 sweeps 4 models x depths 1-4.
+                                          # ResNet layer4 at 224^2 has 7x7 = 49-pixel planes (not a multiple of 4: the scalar epilogue
+                                          # at Cd = 2048); VGG depth 1 is a 64-channel 224^2 plane.
+                                          ("resnet", [1]), ("resnet", [2]), ("resnet", [3]), ("resnet", [4]), ("vgg", [1]), ("vgg", [4]),
+                                          ("vgg", [2]), ("alexnet", [1, 3]), ("squeezenet", [1, 3])])
 def test_full_size_layers(eng, model, depths):
     """Real shapes (224^2) on 2 frames: every conv configuration of SURVEY.md 8(a4) (ResNet-50 to
     layer3), VGG-16 to features[20], AlexNet 11x11/4 + 5x5 + 3x3, SqueezeNet ceil-mode pools and Fire
@@ -246,6 +252,19 @@ def test_full_size_mid_trajectory_teacher_forced_step_resnet50(eng):
     vid = gu.videos_of({"clip_u8": u8.numpy()})
     mk = lambda steps: attacks.ImageGuidedFMDirection_Adam(["resnet50"], depth=3, step_size=0.005, steps=steps, weight_seed=0)   # noqa: E731
     gu.check_mid_trajectory_step(mk, [onet], vid, [5, 29], t=3, lr=0.005, tag="resnet50 layer3 224^2")
+
+
+def test_full_size_mid_trajectory_teacher_forced_step_resnet101_depth2(eng):
+    """The paper's Table-3 setting (run_image_guided.py:63-70: `--direction_image_model resnet --depth 2`, i.e. ResNet-101 layer2 --
+    image_attacks.py:94-95,260-271) at 224^2: 3 free steps on the HIP engine over one 32-frame clip, then ONE engine iteration from
+    (delta_3, m_3, v_3) of two frames against ONE float64 oracle iteration -- the same bounds as the ResNet-50 layer3 step above."""
+    g = graphs.build("resnet", (224, 224))
+    assert g.arch == "resnet101"
+    onet = restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hooks[2]], dtype=torch.float64)
+    u8 = torch.randint(0, 256, (1, 3, 32, 224, 224), generator=torch.Generator().manual_seed(1001), dtype=torch.uint8)
+    vid = gu.videos_of({"clip_u8": u8.numpy()})
+    mk = lambda steps: attacks.ImageGuidedFMDirection_Adam(["resnet"], depth=2, step_size=0.005, steps=steps, weight_seed=0)   # noqa: E731
+    gu.check_mid_trajectory_step(mk, [onet], vid, [3, 30], t=3, lr=0.005, tag="resnet101 layer2 224^2")
 
 
 def _one_conv_graph(cin, cout, k, stride, pad, hw, relu, residual):

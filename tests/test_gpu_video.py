@@ -204,26 +204,57 @@ def test_native_ilaf_against_reference_fixture(eng, name):
     assert torch.equal(atk2(adv.clone(), ori.clone(), torch.zeros(fx["b"], dtype=torch.long), ["v"]).cpu(), out)
 
 
+ILAF_FULL_STEPS = {"slowfast_resnet50": 12, "i3d_resnet50": 4}
+
+
 @pytest.mark.parametrize("mt", ["slowfast_resnet50", "i3d_resnet50"])
 def test_native_ilaf_full_size_against_oracle(eng, mt):
-    """BASELINE.json configs[4] shape (1 clip of 32 x 224 x 224 per call), 2 steps, SlowFast res2 hooks / the non-local I3D's
-    res3 hook (two non-local blocks inside the hooked stage): the native loop against the oracle's restatement run on the
-    torch module (CPU, float32)."""
+    """BASELINE.json configs[4] shape (1 clip of 32 x 224 x 224 per call), SlowFast res2 hooks / the non-local I3D's res3 hook (two
+    non-local blocks inside the hooked stage): the native loop against the oracle's restatement run on the torch module (CPU,
+    float32), free-running -- EVERY step's cost within rtol 2e-4 (round 5: SlowFast, configs[4]'s guide, for 12 steps of the
+    reference's 60, `image_attacks.py:502,579-629`; the I3D for 4: its CPU oracle costs ~4x the time per step).
+    Then a MID-TRAJECTORY TEACHER-FORCED sign step: from the native modifier after those steps, one native step and one float64
+    oracle step from the same state -- cost rtol 2e-4, and the update direction `sign(d cost / d modifier)` agreeing on >= 99.9 % of
+    the elements whose gradient is >= 5 % of max|g| (a sign step moves EVERY element by 0.005 whatever |g|: elements with a
+    gradient that is zero to rounding flip freely in any two correct implementations)."""
     thw = (32, 224, 224)
+    steps = ILAF_FULL_STEPS[mt]
     gen = torch.Generator().manual_seed(11)
     ori_u8 = torch.randint(0, 256, (1, 3, *thw), generator=gen, dtype=torch.uint8)
     adv_u8 = (ori_u8.long() + torch.randint(-10, 11, ori_u8.shape, generator=gen)).clamp(0, 255).to(torch.uint8)
     ori, adv = gu.videos_of({"clip_u8": ori_u8.numpy()}), gu.videos_of({"clip_u8": adv_u8.numpy()})
     model = video.VideoModel(mt, thw)
-    atk = sign_attacks.ILAF(model, mt, step_size=0.005, steps=2)
+    atk = sign_attacks.ILAF(model, mt, step_size=0.005, steps=steps)
     out = atk(adv.clone(), ori.clone(), torch.zeros(1, dtype=torch.long), ["v"]).cpu()
     g = graphs.build_video(mt, thw)
     tm = vm.load_weights(vm.make(mt, False), weights.synthetic_state_dict(g, 0))
-    ref, costs, _, _ = restate.run_ilaf(tm, vm.hook_modules(tm, mt), adv, ori, steps=2)
-    np.testing.assert_allclose(atk.last_costs, costs, rtol=2e-3)
+    ref, costs, _, _ = restate.run_ilaf(tm, vm.hook_modules(tm, mt), adv, ori, steps=steps)
+    rel = np.abs(np.asarray(atk.last_costs, np.float64) - costs) / np.abs(costs)
+    print(f"ILAF {mt} full size, {steps} free steps: cost rel. err per step {np.array2string(rel, precision=2)}; "
+          f"mean|out - ref| {float((out - ref).abs().mean()):.2e}, elements differing {float((out != ref).float().mean()):.4f}")
+    np.testing.assert_allclose(atk.last_costs, costs, rtol=2e-4)
     assert abs(atk.last_costs[0] + 1.5 * len(graphs.video_hooks(g, mt))) < 1e-4     # every hooked layer: -(0.5 + 1) at the start
-    assert float((out - ref).abs().mean()) < 2e-3
-    assert float((out != ref).float().mean()) < 0.05        # sign steps: pixels differ only where |g| ~ 0
+    assert float((out - ref).abs().mean()) < 2e-3 * steps / 2
+    # ---- teacher-forced step from the native state (float64 oracle)
+    m_t = atk._modifier.clone()                                                  # (f, 3, h, w), frame-major
+    one = sign_attacks.ILAF(model, mt, step_size=0.005, steps=1)
+    one._native(adv.clone(), ori.clone(), ["tf"], modifier0=m_t, keep_gradient=True)
+    gx, m_in, m_out = one._last_gx.cpu(), one._last_modifier_in.cpu(), one._modifier.cpu()
+    assert torch.equal(m_in, m_t.cpu())
+    m_bc = m_t.cpu().reshape(1, thw[0], 3, thw[1], thw[2]).permute(0, 2, 1, 3, 4).contiguous()       # -> (b, c, f, h, w)
+    _, c64, g64, m64 = restate.run_ilaf(tm.double(), vm.hook_modules(tm, mt), adv.double(), ori.double(), steps=1, modifier0=m_bc.double())
+    tm.float()
+    np.testing.assert_allclose(one.last_costs[0], c64[0], rtol=2e-4)
+    g_ref = g64[0].permute(1, 0, 2, 3).numpy()                                    # (f, c, h, w)
+    step = (m_in - m_out).numpy()                                                 # = 0.005 * sign(d cost / d modifier) * mask
+    well = np.abs(g_ref) >= 5e-2 * np.abs(g_ref).max()
+    agree = np.sign(step)[well] == np.sign(g_ref)[well]
+    m_ref = m64[0].permute(1, 0, 2, 3).float().numpy()
+    print(f"    teacher-forced step {steps}: cost native {one.last_costs[0]:.6f} f64 oracle {c64[0]:.6f}; well-conditioned elements "
+          f"{int(well.sum())}, sign agreement {float(agree.mean()):.6f}; modifier_{steps + 1} equal on {float((m_out.numpy() == m_ref).mean()):.5f} of all elements")
+    assert well.sum() > 1000 and agree.mean() >= 0.999, float(agree.mean())
+    assert np.abs(m_out.numpy() - m_ref)[well].max() <= 1e-6 or float((np.abs(m_out.numpy() - m_ref)[well] <= 1e-6).mean()) >= 0.999
+    del gx
 
 
 @pytest.mark.parametrize("model_type", ["slowfast_resnet50", "i3d_resnet50"])
@@ -462,6 +493,11 @@ def test_fused_3x3_pointwise_pairs_are_bit_identical(eng, monkeypatch):
         gx = torch.empty(frames, 3, 56, 56, device="cuda:0")
         net.backward(gx)
         outs.append((ft, gx.cpu()))
+        if force != "0":        # the unstored intermediates cannot be read back: refused by name, not answered with stale arena contents
+            for tid, grad in ((c2, False), (e2, False), (f2, False), (c1, True), (r, True), (f1, True)):
+                with pytest.raises(RuntimeError, match="never stored"):
+                    net.read_tensor(tid, frames, grad=grad)
+            assert bool(torch.isfinite(net.read_tensor(c3, frames)).all())
         net.close()
     assert infos[0][:2] == (3, 3) and infos[0][2:] == (0, 0) and infos[1][2:] == (3, 3) and infos[2][2:] == (3, 3), infos
     for ft, gx in outs[1:]:

@@ -386,9 +386,20 @@ def test_fusable_pairs_of_resnet50_are_found_and_change_nothing(monkeypatch):
         outs.append((f, gx.clone()))
         net.close()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert bool(torch.isfinite(outs[1][0]).all()) and bool(torch.isfinite(outs[1][1]).all())   # the host backend POISONS the unstored intermediate
     # a hook on layer1.0.conv2's output: that tensor now has another reader
     monkeypatch.setenv("I2V_FORCE_FUSE", "1")
     t_conv2 = next(i for i, t in enumerate(g.tensors) if (t.name or "").endswith("layer1.0.conv2"))
+    # read-back of a fused pair's intermediate (activation or gradient view) is refused by name; every other tensor still reads
+    net = eng.build_net(g, sd, [g.hooks[3]], 2)
+    net.forward(x)
+    t_conv1 = next(i for i, t in enumerate(g.tensors) if (t.name or "").endswith("layer1.0.conv1"))
+    for tid, grad in ((t_conv2, False), (t_conv1, True)):       # forward pair conv2 -> conv3; backward pair dgrad(conv2) -> dgrad(conv1)
+        with pytest.raises(RuntimeError, match="never stored"):
+            net.read_tensor(tid, 2, grad=grad)
+    t_conv3 = next(i for i, t in enumerate(g.tensors) if (t.name or "").endswith("layer1.0.out"))
+    assert bool(torch.isfinite(net.read_tensor(t_conv3, 2)).all())
+    net.close()
     net = eng.build_net(g, sd, [g.hooks[3], t_conv2], 2)
     assert net.fusion_info()[0] == 5
     net.close()

@@ -33,3 +33,26 @@ def test_rung_statistics_on_the_host_simulation():
     adv2 = atk2(vid, torch.zeros(1, dtype=torch.long), ["c"])
     ok2, bad2 = size_parity.within_bounds(size_parity.compare(atk2.last_costs, atk2._delta, adv2, ora32))
     assert not ok2 and bad2
+
+
+def test_committed_float64_yardstick_fixture():
+    """`tests/golden/size_parity_f64_seed1000.npz` (oracle/make_size_yardstick.py): what `bench.py`'s default `parity_check` holds the
+    perturbed pixels to.  The file is for clip seed 1000 / 10 steps / lr 0.005 only; its first cost is the 32 frames' cos = 1 at
+    delta_0; `compare_sampled` of the run against itself is the identity; another configuration gets no yardstick."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import size_parity
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    y = size_parity.load_yardstick(gold)
+    assert y is not None and y["costs"].shape == (10,) and abs(float(y["costs"][0]) - 32.0) < 1e-6
+    assert np.all(np.diff(y["costs"]) < 0)
+    assert int(y["numel"]) == 3 * 32 * 224 * 224 and y["adv_sample"].shape[0] == -(-int(y["numel"]) // int(y["stride"]))
+    assert size_parity.load_yardstick(gold, seed=1001) is None and size_parity.load_yardstick(gold, steps=3) is None
+    adv = torch.zeros(1, 3, 32, 224, 224)
+    adv.reshape(-1)[::int(y["stride"])] = torch.from_numpy(y["adv_sample"])
+    st = size_parity.compare_sampled(y["costs"], torch.full((8,), float(y["mean_abs_delta"])), adv, y)
+    assert st["max_rel_cost_err"] == 0 and st["mean_abs_adv_diff"] == 0 and st["frac_pixels_within_2lr"] == 1.0
+    assert abs(st["mean_abs_delta_ratio"] - 1) < 1e-6
+    # the sample's values are normalised pixels of a clamped clip: inside the ImageNet-normalised [0, 1] box
+    assert float(y["adv_sample"].min()) >= (0 - 0.485) / 0.229 - 1e-5 and float(y["adv_sample"].max()) <= (1 - 0.406) / 0.225 + 1e-5

@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Fooling-rate parity on the WHOLE sample list (n = 400): BASELINE.json's "fooling-rate within +-0.5 % of reference on the same
+kinetics400_attack_samples.csv clips" measured at a sample size that can resolve it (one clip = 0.25 points).
+
+For every row r of `tests/golden/kinetics400_attack_samples.csv` (clip = synthetic seed 1000 + r, label = gt_label -- there are no
+videos or checkpoints offline):
+  * the fp32 CPU oracle's whole 10-step I2V attack (ResNet-50 layer3; `oracle/fooling_worker.py`, CPU child processes started
+    BEFORE this process touches the GPU, 8 x 32 threads by default: ~11 min for 400 clips on the GPU box's host);
+  * the HIP attack, 8 clips per engine call (the product class `ImageGuidedFMDirection_Adam`);
+  * per clip: worst relative cost error over the 10 steps, mean|delta| ratio, mean|adv - adv'|;
+  * both sets of `{label}-adv.npy` scored chunk by chunk by the evaluator CLI's own `main` (`reference.py --model_factory ...`,
+    `/root/reference/reference.py:28-36,96-129`) on the native I3D-NL and SlowFast classifiers, against gt_label and against the
+    models' own clean predictions (`--clean_dir`); the prediction csv of every chunk is kept and compared row by row.
+
+Writes `profiles/r5_fooling_parity.json`.  Test infrastructure around the product: the oracle is the checker, never the thing measured.
+
+    python tools/fooling_parity.py [--rows 400] [--workers 8] [--threads 32] [--chunk 80] [--out profiles/r5_fooling_parity.json]
+"""
+import argparse
+import csv
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "image-to-video-i2v-attack_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+_MODELS = {}
+
+
+def cached_native(name):
+    """`--model_factory tools.fooling_parity:cached_native`: the evaluator's `native` factory, one planned classifier per name for all
+    chunks (planning a video backbone costs seconds; the evaluator builds its models anew on every call)."""
+    import reference as ev
+    if name not in _MODELS:
+        _MODELS[name] = ev.native(name)
+    return _MODELS[name]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=400)
+    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--threads", type=int, default=32)
+    ap.add_argument("--chunk", type=int, default=80, help="clips scored per evaluator call (disk: 3 x 19 MB per clip)")
+    ap.add_argument("--models", default="i3d_resnet50,slowfast_resnet50")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r5_fooling_parity.json"))
+    ap.add_argument("--workdir", default=None)
+    args = ap.parse_args(argv)
+    t_start = time.time()
+    from oracle import size_parity                                  # (imports torch; no GPU call yet)
+    work = args.workdir or tempfile.mkdtemp(prefix="fooling_parity_")
+    os.makedirs(work, exist_ok=True)
+    ora_dir = os.path.join(work, "oracle_rows")
+    STEPS, LR = 10, 0.005
+    procs = size_parity.start_oracle_workers(list(range(args.rows)), ora_dir, workers=args.workers, threads=args.threads, steps=STEPS, lr=LR)
+    try:
+        return run(args, work, ora_dir, procs, STEPS, LR, t_start)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            p.wait()
+        if not args.workdir:
+            shutil.rmtree(work, ignore_errors=True)
+
+
+def run(args, work, ora_dir, procs, STEPS, LR, t_start):
+    import numpy as np
+    import torch
+    from oracle import size_parity
+    import reference as ev
+    from i2v_amd import attacks
+    os.environ["I2V_SYNTHETIC_WEIGHTS"] = "1"
+    os.environ["I2V_OPT_PATH"] = work
+    with open(os.path.join(ROOT, "tests", "golden", "kinetics400_attack_samples.csv")) as fh:
+        rows = list(csv.DictReader(fh))[:args.rows]
+    labels = [int(r["gt_label"]) for r in rows]
+    eng = attacks.get_engine("cuda:0")
+    assert eng.capi.i2v_backend() == b"hip:gfx950"
+    atk = attacks.ImageGuidedFMDirection_Adam(["resnet50"], depth=3, step_size=LR, steps=STEPS, weight_seed=0)
+    models = [m for m in args.models.split(",") if m]
+    per_clip, preds = [], {k: {m: {} for m in models} for k in ("oracle_gt", "hip_gt", "oracle_clean", "hip_clean")}
+    top1 = {k: {m: 0.0 for m in models} for k in preds}
+    hip_seconds = oracle_seconds = 0.0
+    n_done = 0
+    for c0 in range(0, args.rows, args.chunk):
+        cl = list(range(c0, min(c0 + args.chunk, args.rows)))
+        dirs = {d: os.path.join(work, f"{d}_{c0}") for d in ("oracle", "hip", "clean")}
+        for d in dirs.values():
+            os.makedirs(d, exist_ok=True)
+        for b0 in range(0, len(cl), 8):
+            rs = cl[b0:b0 + 8]
+            vids = torch.cat([size_parity.synthetic_clip(1000 + r) for r in rs])
+            t0 = time.time()
+            adv = atk(vids, torch.tensor([labels[r] for r in rs]), [rows[r]["path"] for r in rs]).cpu()
+            hip_seconds += time.time() - t0
+            delta = atk._delta.cpu().reshape(len(rs), 32, 3, 224, 224)
+            cc = atk.last_clip_costs
+            for k, r in enumerate(rs):
+                ora = size_parity.wait_oracle_row(ora_dir, r, procs, timeout=3600, lr=LR)
+                oracle_seconds += ora["seconds"]
+                st = size_parity.compare(cc[:, k], delta[k], adv[k:k + 1], ora)
+                per_clip.append({"row": r, "label": labels[r], **{key: float(f"{v:.5g}") for key, v in st.items()}})
+                np.save(os.path.join(dirs["clean"], f"{labels[r]}-ori.npy"), vids[k].numpy())
+                os.replace(os.path.join(ora_dir, f"{r}-oracle-adv.npy"), os.path.join(dirs["oracle"], f"{labels[r]}-adv.npy"))
+                np.save(os.path.join(dirs["hip"], f"{labels[r]}-adv.npy"), adv[k].numpy())
+        common = ["--models", ",".join(models), "--model_factory", "tools.fooling_parity:cached_native", "--batch_size", "8"]
+        for tag, d, clean in (("oracle_gt", "oracle", False), ("hip_gt", "hip", False), ("oracle_clean", "oracle", True), ("hip_clean", "hip", True)):
+            acc = ev.main(["--adv_path", os.path.basename(dirs[d])] + common + (["--clean_dir", dirs["clean"]] if clean else []))
+            with open(os.path.join(dirs[d], "results_all_models_prediction.csv")) as fh:
+                for line in csv.DictReader(fh):
+                    for m in models:
+                        preds[tag][m][int(line["gt_label"])] = int(line[f"{m}-pre"])
+            for m in models:
+                top1[tag][m] += acc[m] * len(cl)
+        n_done += len(cl)
+        for d in dirs.values():
+            shutil.rmtree(d, ignore_errors=True)
+        print(f"[fooling_parity] {n_done}/{args.rows} clips scored, {time.time() - t_start:.0f} s", flush=True)
+    n = args.rows
+    res = {"n": n, "attack": "I2V ResNet-50 layer3, 10 steps, eps 16/255, lr 0.005, 32 x 224^2 (BASELINE.json configs[0]/[1])",
+           "clips": "synthetic, seed 1000 + row; name / label of row r of kinetics400_attack_samples.csv",
+           "classifiers": "native I3D-NL (i3d_resnet50) and SlowFast (slowfast_resnet50), seeded synthetic weights (no checkpoints offline)",
+           "top1": {}, "fooling_rate": {}, "differing_predictions": {}, "abs_delta_top1": {}}
+    for m in models:
+        res["top1"][m] = {k: round(top1[k][m] / n, 4) for k in preds}
+        res["fooling_rate"][m] = {k: round(100 - top1[k][m] / n, 4) for k in preds}
+        res["differing_predictions"][m] = {"vs_gt_label_runs": sum(preds["oracle_gt"][m][l] != preds["hip_gt"][m][l] for l in labels),
+                                           "labels": [l for l in labels if preds["oracle_gt"][m][l] != preds["hip_gt"][m][l]]}
+        res["abs_delta_top1"][m] = {"vs_gt_label": round(abs(top1["oracle_gt"][m] - top1["hip_gt"][m]) / n, 4),
+                                    "vs_clean_prediction": round(abs(top1["oracle_clean"][m] - top1["hip_clean"][m]) / n, 4)}
+    worst = max(per_clip, key=lambda s: s["max_rel_cost_err"])
+    res["per_clip_statistics"] = {
+        "worst_max_rel_cost_err": worst["max_rel_cost_err"], "worst_row": worst["row"],
+        "clips_over_cost_rtol_2e-4": [s["row"] for s in per_clip if s["max_rel_cost_err"] > size_parity.COST_RTOL],
+        "max_abs_mean_delta_ratio_minus_1": max(abs(s["mean_abs_delta_ratio"] - 1) for s in per_clip),
+        "mean_abs_adv_diff": {"mean": float(np.mean([s["mean_abs_adv_diff"] for s in per_clip])), "max": max(s["mean_abs_adv_diff"] for s in per_clip)},
+        "frac_pixels_within_2lr": {"mean": float(np.mean([s["frac_pixels_within_2lr"] for s in per_clip])), "min": min(s["frac_pixels_within_2lr"] for s in per_clip)}}
+    res["within_half_point"] = all(v <= 0.5 for m in models for v in res["abs_delta_top1"][m].values())
+    res["timing"] = {"wall_s": round(time.time() - t_start, 1), "hip_attack_s": round(hip_seconds, 1),
+                     "hip_frames_per_s": round(n * 32 / hip_seconds, 1), "oracle_cpu_s_sum": round(oracle_seconds, 1),
+                     "oracle_frames_per_s_per_worker": round(n * 32 / oracle_seconds, 3), "workers": args.workers, "threads_per_worker": args.threads}
+    res["per_clip"] = per_clip
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps({k: v for k, v in res.items() if k != "per_clip"}, indent=1))
+    return 0 if res["within_half_point"] else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Developer tool: where the wall time of an attack goes BETWEEN kernels.  Reads a rocprofv3 --kernel-trace csv, keeps the dispatches from
-the first attack kernel (compose_kernel) on, and reports -- per queue and overall -- the span, the sum of kernel durations, and the gaps
+the first Adam step (`adam_kernel`) on -- planning, autotuning and the first step's compose / forward / backward are left out, so the window
+is "steady state from the end of step 1" (`profiles/r4_gap_probe.txt` was produced with this cut) -- and reports -- per queue and overall -- the span, the sum of kernel durations, and the gaps
 between the end of one dispatch and the start of the next (median / mean / total), plus the durations by kernel name.
-    python3 tools/gap_probe.py <dir-with-*_kernel_trace.csv> [skip_first_n_compose]"""
+    python3 tools/gap_probe.py <dir-with-*_kernel_trace.csv>"""
 import csv
 import glob
 import sys
