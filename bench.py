@@ -157,7 +157,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--clips", type=int, default=None, help=f"clips per GPU and engine call (default {CLIPS_PER_GPU}; --workload ilaf: 8)")
+    ap.add_argument("--clips", type=int, default=None,
+                    help=f"clips per GPU and engine call (default {CLIPS_PER_GPU}; --workload ilaf: 8; --workload aens: 8 = BASELINE.json configs[3], batch 64 over 8 GPUs)")
     ap.add_argument("--white_model", default="slowfast_resnet50", help="--workload ilaf: video backbone (graphs.build_video)")
     ap.add_argument("--streams", type=int, default=3, help="--workload ilaf: engine calls in flight on separate HIP streams")
     ap.add_argument("--ilaf_clips", type=int, default=None,
@@ -189,7 +190,7 @@ def parse_args(argv=None):
     if args.workload == "ilaf":
         args.clips = max(1, args.clips if args.clips is not None else (args.ilaf_clips if args.ilaf_clips is not None else 8))
     elif args.clips is None:
-        args.clips = CLIPS_PER_GPU
+        args.clips = 8 if args.workload == "aens" else CLIPS_PER_GPU
     return args
 
 
@@ -292,6 +293,41 @@ def reduce_max(dist, value, dev):
     dist.all_gather(every, t)
     vals = [float(e.item()) for e in every]
     return max(vals), vals
+
+
+def aens_fields(atk, dist, world, dev):
+    """What a multi-GPU AENS line carries beside the contract (the path's ONE collective): the layer weights of the
+    last step -- functions of the GLOBAL batch, so identical on every rank (gathered and compared bit for bit) and equal to a
+    one-device run over the same clips --, the size of the process group as the collective library sees it, and the measured device
+    time of one (2, L) in-place all-reduce on the launch stream (HIP events around 20 back-to-back exchanges, after the timed region)."""
+    import numpy as np
+    w = np.stack(atk.weights).astype(np.float32)                      # (steps, L) of the last call
+    f = {"layer_weights_last_step": [float(x) for x in w[-1]], "layers": int(w.shape[1]),
+         "exchange": "one in-place all-reduce of 2L floats per attack step (TPAMI_attack.py:265,293-297)"}
+    if dist is None:
+        f["rccl_ranks"] = 1
+        f["note"] = "single process, no process group: the exchange is a no-op"
+        return f
+    f["rccl_ranks"] = dist.get_world_size()
+    f["backend"] = "rccl" if dist.get_backend() == "nccl" else dist.get_backend()
+    on = dev if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.from_numpy(w).to(on)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    f["weights_identical_on_all_ranks"] = bool(all(torch.equal(e, every[0]) for e in every))
+    pair = torch.zeros(2, w.shape[1], device=dev)
+    atk._exchange(pair)                                               # warm the path
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        atk._exchange(pair)
+    e1.record()
+    torch.cuda.synchronize()
+    f["allreduce_device_us"] = round(1e3 * e0.elapsed_time(e1) / reps, 2)
+    f["allreduce_bytes"] = int(pair.numel() * 4)
+    return f
 
 
 def add_scaling_fields(line, args):
@@ -602,6 +638,8 @@ def run_rank(args):
         out["config"]["workload"] = f"{args.workload} ensemble ({models}), batch={b} clips per GPU"
         for k in ("end_to_end_tflops_per_gpu", "algorithmic_gflop_per_frame"):
             out.pop(k, None)
+    if args.workload == "aens":
+        out["aens"] = aens_fields(atk, dist, world, dev)
     if args.workload == "i2v" and getattr(atk, "_nets", None):       # what the autotuner did with the fusable 3x3 -> pointwise pairs (headline plan)
         fi = atk._nets[0].fusion_info()
         out["fused_pairs"] = {"eligible_fwd": fi[0], "eligible_bwd": fi[1], "fused_fwd": fi[2], "fused_bwd": fi[3],

@@ -410,6 +410,7 @@ static View view_of(Net& n, int t, bool grad) {
 extern "C" const char* i2v_last_error(void) { return g_err.c_str(); }
 extern "C" int i2v_abi_version(void) { return 1; }
 extern "C" const char* i2v_backend(void) { return be_name(); }
+extern "C" long long i2v_backend_stat(const char* name) { return name ? be_stat(name) : -1; }
 
 extern "C" int i2v_create(int device, i2v_handle* out) {
     if (!out) return fail("i2v_create: null out");

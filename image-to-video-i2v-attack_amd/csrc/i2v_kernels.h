@@ -8,6 +8,7 @@
 typedef void* i2v_stream_t;
 
 const char* be_name();
+long long be_stat(const char* name);          // launch counters ("conv_launches", "pws_launches"), -1 for an unknown name
 int  be_set_device(int device);
 void* be_malloc(size_t bytes);
 void be_free(void* p);

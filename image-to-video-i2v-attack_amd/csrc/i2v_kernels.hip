@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 #include <utility>
@@ -34,6 +35,12 @@ static int hip_fail(hipError_t e, const char* what) {
 #define LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return hip_fail(e_, name); } while (0)
 
 const char* be_name() { return "hip:gfx950"; }
+static long long g_stat_conv = 0, g_stat_pws = 0;      // (relaxed counters: diagnostics only)
+long long be_stat(const char* name) {
+    if (!strcmp(name, "conv_launches")) return __atomic_load_n(&g_stat_conv, __ATOMIC_RELAXED);
+    if (!strcmp(name, "pws_launches")) return __atomic_load_n(&g_stat_pws, __ATOMIC_RELAXED);
+    return -1;
+}
 const char* be_error() { return g_be_has_err ? g_be_err : nullptr; }
 int be_set_device(int device) { HIPCHK(hipSetDevice(device)); return 0; }
 void* be_malloc(size_t bytes) { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; return p; }
@@ -171,6 +178,112 @@ constexpr int conv_halo_lds_floats() {
 // accumulators -> LDS transpose -> per lane 4 consecutive pixels of one channel -> gate_scale / shift / addends / ReLU / gates ->
 // 16-byte store (+ this tensor's own 1-bit gates).  FUSE: the result is deposited in the LDS tile `mid` ([BD][BP], zeros where the
 // tile sticks out of the launch) instead of `p.dst` -- the intermediate of a fused pair never goes to memory.
+// ... its second half, the ROW pass: thread `t` of 256 (lane = t & 63) takes 4 consecutive pixels of NQ channel rows of the transposed
+// tile `Cs` ([rows][BP], pass `i` of the tile's TD passes) through gate_scale / shift / addends / ReLU / gates to the 16-byte store.  A
+// function of its own since round 5: the persistent pointwise kernel (conv_pw_stream) runs it on dedicated epilogue waves while the
+// matrix waves are already in the next tile -- one implementation, the same expressions in the same order.
+template <int BD, int BP, int WD, bool PREF, bool MF16, bool FUSE, typename PT>
+__device__ __forceinline__ void conv_vec_rows(const PT& p, const int i, const int cd0, const int64_t px0, const float (*const Cs)[BP], const int t,
+                                              const float4* const pre0, const unsigned* const pregw, float* const mid) {
+    constexpr int FR = MF16 ? 16 : 32;
+    const int lane = t & 63;
+    const int HWg = p.Hg * p.Wg, HoWo = p.Ho * p.Wo;
+    const int64_t P = (int64_t)p.N * HWg;
+    (void)pre0; (void)pregw; (void)mid;
+#ifdef I2V_NT_ALL
+    const bool nt_store = true;
+#else
+    const bool nt_store = p.cfg > 0 && ((p.cfg - 1) & 128);
+#endif
+    constexpr int C4 = BP / 4, RSTEP = 1024 / BP, NQ = WD * FR / RSTEP;
+    const int c4 = t % C4, rbase = t / C4;
+    const int64_t pp = px0 + (int64_t)c4 * 4;
+    const bool pok = pp < P;
+    const int64_t n = pok ? fastdiv((unsigned)pp, p.dv_hw_m, p.dv_hw_s) : 0;
+    const int64_t poff = pp - n * HWg;
+    #pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int row = rbase + q * RSTEP;
+        const int cd = cd0 + (row / FR) * (BD / WD) + i * FR + (row % FR);
+        const bool valid = pok && cd < p.Cd;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+        v = *reinterpret_cast<const float4*>(&Cs[row][c4 * 4]);
+        const int64_t o = (int64_t)cd * HoWo + poff;
+        if (p.gate_scale) {      // pre-activation gate on THIS contribution, before the (accumulating) adds
+            const float4 m = *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
+            const float gs = p.gate_scale[cd], gt = p.gate_shift[cd];
+            if (!(fmaf(m.x, gs, gt) > 0.f)) v.x = 0.f;
+            if (!(fmaf(m.y, gs, gt) > 0.f)) v.y = 0.f;
+            if (!(fmaf(m.z, gs, gt) > 0.f)) v.z = 0.f;
+            if (!(fmaf(m.w, gs, gt) > 0.f)) v.w = 0.f;
+        }
+        if (p.shift) { const float sh = p.shift[cd]; v.x += sh; v.y += sh; v.z += sh; v.w += sh; }
+        if (PREF) {
+            v.x += pre0[q].x; v.y += pre0[q].y; v.z += pre0[q].z; v.w += pre0[q].w;
+        } else {
+            if (p.add0 && p.add0_stride == 1) {
+                const float4 a = *reinterpret_cast<const float4*>(p.add0 + n * p.add0_nstride + o);
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            } else if (p.add0) {
+                // compact stride-2 addend (input-gradient of a 1x1/2 shortcut): defined at even
+                // (h, w) only; the 4 pixels start at a multiple of 4, so elements 0 and 2 receive
+                const int oh = (int)fastdiv((unsigned)poff, p.dv_wo_m, p.dv_wo_s), ow = (int)(poff - (int64_t)oh * p.Wo);
+                if (!(oh & 1) && (oh >> 1) < p.add0_H) {
+                    const float2 a = *reinterpret_cast<const float2*>(
+                        p.add0 + n * p.add0_nstride + (int64_t)cd * p.add0_H * p.add0_W + (oh >> 1) * p.add0_W + (ow >> 1));
+                    v.x += a.x; v.z += a.y;
+                }
+            }
+        }
+        if (p.add1) {
+            const float4 a = *reinterpret_cast<const float4*>(p.add1 + n * p.add1_nstride + o);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (p.gate) {            // 1-bit gates of the tensor whose gradient this is: 4 bits of one word
+            const unsigned w = PREF ? pregw[q] : p.gate[(int64_t)cd * p.gate_stride + ((p.gate_pix0 + pp) >> 5)];
+            const unsigned g = w >> ((unsigned)(p.gate_pix0 + pp) & 31u);
+            if (!(g & 1u)) v.x = 0.f;
+            if (!(g & 2u)) v.y = 0.f;
+            if (!(g & 4u)) v.z = 0.f;
+            if (!(g & 8u)) v.w = 0.f;
+        } else if (p.mask && !p.gate_scale) {
+            const float4 m = *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
+            if (!(m.x > 0.f)) v.x = 0.f;
+            if (!(m.y > 0.f)) v.y = 0.f;
+            if (!(m.z > 0.f)) v.z = 0.f;
+            if (!(m.w > 0.f)) v.w = 0.f;
+        }
+        if constexpr (!FUSE) {
+            // Streaming (non-temporal) store, autotuner bit 7 (round 4): the tile's 16-byte stores go past the L2 instead of
+            // allocating lines in it.  Isolated (tools/pw_sweep.sh, configurations | 128): +13 % on 128 -> 512 @28^2, +13...20 % on
+            // 64 -> 64 @56^2, +3 % on 64 -> 256 @56^2, -4 % on 256 -> 1024 @14^2: shape- and epilogue-dependent, so it is timed per launch
+            // (second stage of the plan-time autotuner); in the attack it is worth 0.3-0.45 % (64 -> 256 forward -5 %).  Streaming LOADS of
+            // the addend were measured too (+1.5...7 % alone, worse than the stores alone when combined) and not kept.
+            if (nt_store) { typedef float nt4 __attribute__((ext_vector_type(4))); const nt4 w4 = {v.x, v.y, v.z, v.w};
+                            __builtin_nontemporal_store(w4, reinterpret_cast<nt4*>(p.dst + n * p.dst_nstride + o)); }
+            else *reinterpret_cast<float4*>(p.dst + n * p.dst_nstride + o) = v;
+        }
+        }
+        if constexpr (FUSE)       // first phase of a fused pair: the finished tile stays in LDS, [channel][pixel], zeros outside
+            *reinterpret_cast<float4*>(mid + (cd - cd0) * BP + c4 * 4) = v;
+        if (p.gate_out) {
+            // this tensor's own gates: 8 consecutive lanes hold 32 consecutive pixels of one channel row
+            // (BP/4 lanes per row, a multiple of 8); every lane takes part in the exchange, invalid ones with 0
+            unsigned nib = valid ? ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) : 0u;
+            nib <<= 4 * (lane & 7);
+            // OR over the 8 lanes with DPP moves (VALU only; __shfl_xor would go through the LDS crossbar):
+            // quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7-i of each 8)
+            nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0xB1, 0xF, 0xF, true);
+            nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x4E, 0xF, 0xF, true);
+            nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x141, 0xF, 0xF, true);
+            if (valid && (lane & 7) == 0)
+                p.gate_out[(int64_t)cd * p.gate_out_stride + ((p.gate_out_pix0 + pp) >> 5)] = nib;
+        }
+    }
+}
+
 #define I2V_FROW(r) (MF16 ? 4 * lk + (r) : ((r) & 3) + 8 * ((r) >> 2) + 4 * lk)
 template <int BD, int BP, int WD, int WP, bool PREF, bool MF16, bool FUSE, typename ACC, typename PT>
 __device__ __forceinline__ void conv_vec_epilogue(const PT& p, ACC (&acc)[BD / WD / (MF16 ? 16 : 32)][BP / WP / (MF16 ? 16 : 32)], const int cd0,
@@ -180,23 +293,9 @@ __device__ __forceinline__ void conv_vec_epilogue(const PT& p, ACC (&acc)[BD / W
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wd = wave / WP, wpx = wave % WP;
     const int l31 = MF16 ? (lane & 15) : (lane & 31), lk = MF16 ? (lane >> 4) : (lane >> 5);
-    const int HWg = p.Hg * p.Wg, HoWo = p.Ho * p.Wo;
-    const int64_t P = (int64_t)p.N * HWg;
-    (void)pre0; (void)pregw; (void)mid;
-#ifdef I2V_NT_ALL
-    const bool nt_store = true;
-#else
-    const bool nt_store = p.cfg > 0 && ((p.cfg - 1) & 128);
-#endif
     // Dense output (grid == output plane, plane % 4 == 0): transpose the accumulators through LDS so
     // that each lane owns 4 consecutive pixels of one channel; addends, gate and result then move as
     // 16-byte accesses, 512 contiguous bytes per channel row.
-    constexpr int C4 = BP / 4, RSTEP = 1024 / BP, NQ = WD * FR / RSTEP;
-    const int c4 = t % C4, rbase = t / C4;
-    const int64_t pp = px0 + (int64_t)c4 * 4;
-    const bool pok = pp < P;
-    const int64_t n = pok ? fastdiv((unsigned)pp, p.dv_hw_m, p.dv_hw_s) : 0;
-    const int64_t poff = pp - n * HWg;
     float (*Cs)[BP] = reinterpret_cast<float (*)[BP]>(smem);
 #pragma unroll
     for (int i = 0; i < TD; ++i) {
@@ -207,89 +306,7 @@ __device__ __forceinline__ void conv_vec_epilogue(const PT& p, ACC (&acc)[BD / W
             for (int r = 0; r < NR; ++r)
                 Cs[wd * FR + I2V_FROW(r)][wpx * (BP / WP) + j * FR + l31] = acc[i][j][r];
         __syncthreads();
-        {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int row = rbase + q * RSTEP;
-                const int cd = cd0 + (row / FR) * (BD / WD) + i * FR + (row % FR);
-                const bool valid = pok && cd < p.Cd;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid) {
-                v = *reinterpret_cast<const float4*>(&Cs[row][c4 * 4]);
-                const int64_t o = (int64_t)cd * HoWo + poff;
-                if (p.gate_scale) {      // pre-activation gate on THIS contribution, before the (accumulating) adds
-                    const float4 m = *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
-                    const float gs = p.gate_scale[cd], gt = p.gate_shift[cd];
-                    if (!(fmaf(m.x, gs, gt) > 0.f)) v.x = 0.f;
-                    if (!(fmaf(m.y, gs, gt) > 0.f)) v.y = 0.f;
-                    if (!(fmaf(m.z, gs, gt) > 0.f)) v.z = 0.f;
-                    if (!(fmaf(m.w, gs, gt) > 0.f)) v.w = 0.f;
-                }
-                if (p.shift) { const float sh = p.shift[cd]; v.x += sh; v.y += sh; v.z += sh; v.w += sh; }
-                if (PREF) {
-                    v.x += pre0[q].x; v.y += pre0[q].y; v.z += pre0[q].z; v.w += pre0[q].w;
-                } else {
-                    if (p.add0 && p.add0_stride == 1) {
-                        const float4 a = *reinterpret_cast<const float4*>(p.add0 + n * p.add0_nstride + o);
-                        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-                    } else if (p.add0) {
-                        // compact stride-2 addend (input-gradient of a 1x1/2 shortcut): defined at even
-                        // (h, w) only; the 4 pixels start at a multiple of 4, so elements 0 and 2 receive
-                        const int oh = (int)fastdiv((unsigned)poff, p.dv_wo_m, p.dv_wo_s), ow = (int)(poff - (int64_t)oh * p.Wo);
-                        if (!(oh & 1) && (oh >> 1) < p.add0_H) {
-                            const float2 a = *reinterpret_cast<const float2*>(
-                                p.add0 + n * p.add0_nstride + (int64_t)cd * p.add0_H * p.add0_W + (oh >> 1) * p.add0_W + (ow >> 1));
-                            v.x += a.x; v.z += a.y;
-                        }
-                    }
-                }
-                if (p.add1) {
-                    const float4 a = *reinterpret_cast<const float4*>(p.add1 + n * p.add1_nstride + o);
-                    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-                }
-                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (p.gate) {            // 1-bit gates of the tensor whose gradient this is: 4 bits of one word
-                    const unsigned w = PREF ? pregw[q] : p.gate[(int64_t)cd * p.gate_stride + ((p.gate_pix0 + pp) >> 5)];
-                    const unsigned g = w >> ((unsigned)(p.gate_pix0 + pp) & 31u);
-                    if (!(g & 1u)) v.x = 0.f;
-                    if (!(g & 2u)) v.y = 0.f;
-                    if (!(g & 4u)) v.z = 0.f;
-                    if (!(g & 8u)) v.w = 0.f;
-                } else if (p.mask && !p.gate_scale) {
-                    const float4 m = *reinterpret_cast<const float4*>(p.mask + n * p.mask_nstride + o);
-                    if (!(m.x > 0.f)) v.x = 0.f;
-                    if (!(m.y > 0.f)) v.y = 0.f;
-                    if (!(m.z > 0.f)) v.z = 0.f;
-                    if (!(m.w > 0.f)) v.w = 0.f;
-                }
-                if constexpr (!FUSE) {
-                    // Streaming (non-temporal) store, autotuner bit 7 (round 4): the tile's 16-byte stores go past the L2 instead of
-                    // allocating lines in it.  Isolated (tools/pw_sweep.sh, configurations | 128): +13 % on 128 -> 512 @28^2, +13...20 % on
-                    // 64 -> 64 @56^2, +3 % on 64 -> 256 @56^2, -4 % on 256 -> 1024 @14^2: shape- and epilogue-dependent, so it is timed per launch
-                    // (second stage of the plan-time autotuner); in the attack it is worth 0.3-0.45 % (64 -> 256 forward -5 %).  Streaming LOADS of
-                    // the addend were measured too (+1.5...7 % alone, worse than the stores alone when combined) and not kept.
-                    if (nt_store) { typedef float nt4 __attribute__((ext_vector_type(4))); const nt4 w4 = {v.x, v.y, v.z, v.w};
-                                    __builtin_nontemporal_store(w4, reinterpret_cast<nt4*>(p.dst + n * p.dst_nstride + o)); }
-                    else *reinterpret_cast<float4*>(p.dst + n * p.dst_nstride + o) = v;
-                }
-                }
-                if constexpr (FUSE)       // first phase of a fused pair: the finished tile stays in LDS, [channel][pixel], zeros outside
-                    *reinterpret_cast<float4*>(mid + (cd - cd0) * BP + c4 * 4) = v;
-                if (p.gate_out) {
-                    // this tensor's own gates: 8 consecutive lanes hold 32 consecutive pixels of one channel row
-                    // (BP/4 lanes per row, a multiple of 8); every lane takes part in the exchange, invalid ones with 0
-                    unsigned nib = valid ? ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) : 0u;
-                    nib <<= 4 * (lane & 7);
-                    // OR over the 8 lanes with DPP moves (VALU only; __shfl_xor would go through the LDS crossbar):
-                    // quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7-i of each 8)
-                    nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0xB1, 0xF, 0xF, true);
-                    nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x4E, 0xF, 0xF, true);
-                    nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x141, 0xF, 0xF, true);
-                    if (valid && (lane & 7) == 0)
-                        p.gate_out[(int64_t)cd * p.gate_out_stride + ((p.gate_out_pix0 + pp) >> 5)] = nib;
-                }
-            }
-        }
+        conv_vec_rows<BD, BP, WD, PREF, MF16, FUSE>(p, i, cd0, px0, Cs, t, pre0, pregw, mid);
     }
 }
 #undef I2V_FROW
@@ -1068,6 +1085,193 @@ conv_igemm_tail(const I2VConvParams p, const int n_cd_a, const int nA, const int
     probe.exit(slot);
 }
 
+// =============================================================================================
+// Persistent, role-split pointwise kernel (round 5): conv_pw_stream
+// =============================================================================================
+// The short-K pointwise launches (64 -> 256 @56^2, 128 -> 512 @28^2 and their input gradients) run a 4-8 chunk K loop and then a
+// byte-heavy epilogue, serially inside every block of conv_igemm; seven co-resident blocks overlap the two only statistically
+// (PMC: matrix pipe 0.58 busy, HBM at 0.43 of its peak -- on neither roof).  Here ONE 512-thread workgroup per CU owns a 64-channel
+// tile for the whole launch and walks its share of the pixel tiles:
+//   * the [K][64] weight panel is staged into LDS ONCE and stays;
+//   * waves 0-3 ("matrix waves", one per SIMD) only issue MFMAs from LDS -- K / 2 of them back to back per tile, no wait inside a
+//     tile -- and, behind the first ones, the LDS-DMA of the NEXT tile's activations into the other buffer of a ring; at the end of a
+//     tile they deposit the accumulators transposed into one of two [64][64] hand-off buffers;
+//   * waves 4-7 ("epilogue waves", the SIMDs' second wave) meanwhile drain the PREVIOUS tile's hand-off buffer through
+//     conv_vec_rows -- addend / gate words prefetched into registers one to two tiles ahead, shift, ReLU, gates, 16-byte stores;
+//   * ONE s_barrier per tile hands the buffers over: B ring slot full / free, hand-off buffer full / free.
+// So a CU's matrix pipe, its HBM reads (activations, addend) and its stores run concurrently by construction, not by luck of block
+// phases.  Every output element is the same k-ordered fmaf chain over the same values as in conv_igemm (a 32x32x2 fp32 MFMA is a
+// sequential chain along K whatever feeds it), and the row pass IS conv_igemm's: bit-identical.
+// Blocks b, b + 8, ... share an XCD: the n_cd channel-tile blocks of one pixel-tile stream are neighbours there, so a pixel tile is
+// fetched from HBM once and served to the other n_cd - 1 blocks by that XCD's L2.
+// K = 256 (256 -> 1024 @14^2): the activations of a tile arrive as two 128-row SLABS through the same two-slot ring -- one barrier per
+// slab --, the 64 KB weight panel stays whole: 160 KB of LDS, all a workgroup may have.
+template <int K> constexpr int pws_slab() { return K < 128 ? K : 128; }                   // K rows per ring slot
+template <int K> constexpr int pws_nbuf() { return K <= 64 ? 3 : 2; }                      // activation ring slots ([slab][64] floats each)
+template <int K> constexpr int pws_lds_floats() { return K * 64 + pws_nbuf<K>() * pws_slab<K>() * 64 + 2 * 64 * 64; }
+#ifndef I2V_PWS_NSET
+#define I2V_PWS_NSET 2                // epilogue-operand register sets (tiles of addend / gate words in flight per epilogue wave)
+#endif
+template <int K>
+__global__ void __launch_bounds__(512) conv_pw_stream(const I2VConvParams p, const int n_cd, const int n_streams, const int n_px_tiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KSL = pws_slab<K>(), S = K / KSL, NBUF = pws_nbuf<K>(), NSET = I2V_PWS_NSET, KS = KSL / 2, NPW = KSL / 16;     // NPW: DMA pieces per matrix wave per slab
+    static_assert(K % KSL == 0 && (S == 1 || NBUF == 2), "slabs: whole, and through a two-slot ring");
+    __shared__ __attribute__((aligned(16))) float smem[pws_lds_floats<K>()];
+    float* const Wl = smem;                                   // [K][64]   weight panel of this block's channel tile
+    float* const Bl = smem + K * 64;                          // [NBUF][KSL][64] activation ring
+    float (*const Cl)[64][64] = reinterpret_cast<float (*)[64][64]>(smem + K * 64 + NBUF * KSL * 64);      // [2][64][64] hand-off buffers
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int cd0 = (j % n_cd) * 64;
+    const int stream = xcd * ((int)(gridDim.x >> 3) / n_cd) + j / n_cd;
+    const int n_mine = stream < n_px_tiles ? (n_px_tiles - stream + n_streams - 1) / n_streams : 0;
+    const int HWg = p.Hg * p.Wg;
+    const int64_t P = (int64_t)p.N * HWg;
+    auto px_of = [&](const int i) { return ((int64_t)stream + (int64_t)i * n_streams) * 64; };
+    if (wv < 4) {
+        // ------------------------------------------------------------------ matrix waves
+        constexpr unsigned OOB = 0x80000000u;
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.Kpad * p.Cdpad * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_span_bytes, 0x00020000);
+        const int HWs = p.Hs * p.Ws;
+        const int wd = wv >> 1, wpx = wv & 1, l31 = lane & 31, lk = lane >> 5;
+        // piece `ins` of a [rows][64] image = its rows 4 ins .. 4 ins + 3; lane l moves 16 bytes: row 4 ins + l / 16, columns 4 (l % 16) ..
+        const unsigned aoff = (unsigned)(((lane >> 4) * p.Cdpad + cd0 + (lane & 15) * 4) * 4);
+        auto b_off = [&](const int i) -> unsigned {           // byte offset of this lane's 4 pixels of tile i in row 0 of piece 0 of slab 0
+            const int64_t pp = px_of(i) + (lane & 15) * 4;
+            if (i >= n_mine || pp >= P) return OOB;
+            const int64_t n = fastdiv((unsigned)pp, p.dv_hw_m, p.dv_hw_s);
+            return (unsigned)((n * p.src_nstride + (pp - n * HWg) + (int64_t)(lane >> 4) * HWs) * 4);
+        };
+        auto issue_b = [&]<int Q>(std::integral_constant<int, Q>, const unsigned bo, const int slot_, const int h) {      // piece wv + 4 Q of slab h of a tile
+            const int ins = wv + 4 * Q;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(Bl + slot_ * (KSL * 64) + ins * 256), 16, bo, (h * KSL + ins * 4) * HWs * 4, 0, 0);
+        };
+        auto issue_slab = [&](const int i, const int h, const int slot_) {                // all of this wave's pieces of one slab at once
+            const unsigned bo = b_off(i);
+            [&]<int... Q>(std::integer_sequence<int, Q...>) { ((issue_b(std::integral_constant<int, Q>{}, bo, slot_, h)), ...); }(std::make_integer_sequence<int, NPW>{});
+        };
+        // prologue: the weight panel, then the first NBUF - 1 slabs of the sequence (tile 0 slab 0, ...)
+#pragma unroll
+        for (int q = 0; q < K / 16; ++q) {
+            const int ins = wv + 4 * q;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Wl + ins * 256), 16, aoff, ins * 4 * p.Cdpad * 4, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < NBUF - 1; ++g) issue_slab(g / S, g % S, g);
+        if constexpr (NBUF > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                                     // #0: panel + the first slab in LDS
+        int slot = 0;
+        for (int i = 0; i < n_mine; ++i) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            [&]<int... H>(std::integer_sequence<int, H...>) {
+                (([&] {
+                    constexpr int h = H, hn = (H + NBUF - 1) % S, di = (H + NBUF - 1) / S;      // the slab issued now: slab hn of tile i + di
+                    const float* const wbase = Wl + (h * KSL + lk) * 64 + wd * 32 + l31;
+                    const float* const bbase = Bl + slot * (KSL * 64) + lk * 64 + wpx * 32 + l31;
+                    const int nslot = slot + (NBUF - 1) >= NBUF ? slot + (NBUF - 1) - NBUF : slot + (NBUF - 1);
+                    const unsigned bo = b_off(i + di);                                    // OOB beyond this block's tiles: zero fill, same counts
+                    float fa[3], fb[3];
+                    fa[0] = wbase[0]; fb[0] = bbase[0];
+                    fa[1] = wbase[128]; fb[1] = bbase[128];
+                    [&]<int... SS>(std::integer_sequence<int, SS...>) {
+                        (([&] {
+                            constexpr int s_ = SS, cur = SS % 3, nx2 = (SS + 2) % 3;
+                            if constexpr (s_ + 2 < KS) { fa[nx2] = wbase[(s_ + 2) * 128]; fb[nx2] = bbase[(s_ + 2) * 128]; }
+                            __builtin_amdgcn_sched_barrier(0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur], fb[cur], acc, 0, 0, 0);
+                            if constexpr (s_ < NPW) issue_b(std::integral_constant<int, s_>{}, bo, nslot, hn);      // the ring's next slab, one piece per MFMA
+                        }()), ...);
+                    }(std::make_integer_sequence<int, KS>{});
+                    if constexpr (h == S - 1) {      // hand the tile over: accumulators transposed into the hand-off buffer (conv_vec_epilogue's deposit)
+                        float (*const Cs)[64] = Cl[i & 1];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Cs[wd * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk][wpx * 32 + l31] = acc[r];
+                    }
+                    if constexpr (NBUF > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * NPW) : "memory");      // the next slab has landed
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                                         // #(i S + h + 1)
+                    slot = slot + 1 == NBUF ? 0 : slot + 1;
+                }()), ...);
+            }(std::make_integer_sequence<int, S>{});
+        }
+    } else {
+        // ------------------------------------------------------------------ epilogue waves
+        const int te = t - 256;
+        float4 pa[NSET][4]; unsigned pg[NSET][4];
+        auto prefetch = [&](const int i, float4 (&a0)[4], unsigned (&gw)[4]) {           // tile i's first addend and gate words (conv_tile's PREF)
+            const int e_c4 = te & 15, e_rbase = te >> 4;
+            const int64_t e_pp = px_of(i) + (int64_t)e_c4 * 4;
+            const bool e_ok = i < n_mine && e_pp < P;
+            const int64_t e_n = e_ok ? fastdiv((unsigned)e_pp, p.dv_hw_m, p.dv_hw_s) : 0;
+            const int64_t e_poff = e_pp - e_n * HWg;
+            const int e_HoWo = p.Ho * p.Wo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cd = cd0 + e_rbase + q * 16;
+                const bool ok = e_ok && cd < p.Cd;
+                const int64_t o = (int64_t)cd * e_HoWo + e_poff;
+                a0[q] = (ok && p.add0) ? *reinterpret_cast<const float4*>(p.add0 + e_n * p.add0_nstride + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                gw[q] = (ok && p.gate) ? p.gate[(int64_t)cd * p.gate_stride + ((p.gate_pix0 + e_pp) >> 5)] : 0xffffffffu;
+            }
+        };
+        [&]<int... T>(std::integer_sequence<int, T...>) { ((prefetch(T, pa[T], pg[T])), ...); }(std::make_integer_sequence<int, NSET>{});
+        __builtin_amdgcn_s_barrier();                                                     // #0
+        // phase i: the rows of tile i - 1 (deposited before barrier #(i S)), then the prefetch of tile i - 1 + NSET into the set just freed
+        for (int i0 = 0; i0 <= n_mine; i0 += NSET) {
+            [&]<int... U>(std::integer_sequence<int, U...>) {
+                (([&] {
+                    constexpr int u = U, set = (U + NSET - 1) % NSET;                     // tile i - 1 uses set (i - 1) % NSET; i0 % NSET == 0
+                    const int i = i0 + u;
+                    if (i <= n_mine) {
+                        if (i >= 1) {
+                            conv_vec_rows<64, 64, 2, true, false, false>(p, 0, cd0, px_of(i - 1), Cl[(i - 1) & 1], te, pa[set], pg[set], nullptr);
+                            prefetch(i - 1 + NSET, pa[set], pg[set]);
+                        }
+                        if (i < n_mine) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's reads of the hand-off buffer are done
+#pragma unroll
+                            for (int h = 0; h < S; ++h) __builtin_amdgcn_s_barrier();     // #(i S + 1) .. #(i S + S)
+                        }
+                    }
+                }()), ...);
+            }(std::make_integer_sequence<int, NSET>{});
+        }
+    }
+#endif
+}
+
+// conv_pw_stream applies (autotuner bit 8): a plain dense pointwise image launch with K = 64, 128 or 256, whole 64-channel tiles whose
+// count divides the 32 blocks of an XCD, and enough pixel tiles to give every stream a few
+static int conv_pws_grid(const I2VConvParams& p) {           // blocks (one per CU), 0 = not applicable
+    if (!p.pointwise || !p.vec_epilogue || p.temporal || p.quad || p.pre_scale || p.gate_scale || p.blk > 1 || p.blkt > 1) return 0;
+    if (p.K != p.Kpad || (p.K != 64 && p.K != 128 && p.K != 256) || p.Cd % 64 != 0 || p.add0_stride > 1 || p.Hs != p.Hg || p.Ws != p.Wg) return 0;
+    const int n_cd = p.Cd / 64;
+    if (n_cd > 32 || 32 % n_cd != 0) return 0;
+    const int64_t n_px = ((int64_t)p.N * p.Hg * p.Wg + 63) / 64;
+    // fewer than four tiles per stream: the prologue (the weight panel, the ring's first slabs) would not amortise.  (I2V_PWS_MIN_TILES:
+    // developer / test knob -- 0 admits launches that leave streams with one tile or none.)
+    static const int min_tiles = [] { const char* e = getenv("I2V_PWS_MIN_TILES"); return e ? atoi(e) : 4; }();
+    if (n_px < (int64_t)min_tiles * (256 / n_cd)) return 0;
+    return 256;
+}
+static int launch_conv_pws(const I2VConvParams& p, hipStream_t s) {
+    const int grid = conv_pws_grid(p), n_cd = p.Cd / 64, n_streams = grid / n_cd;
+    const int n_px = (int)(((int64_t)p.N * p.Hg * p.Wg + 63) / 64);
+    if (p.K == 64) hipLaunchKernelGGL((conv_pw_stream<64>), dim3(grid), dim3(512), 0, s, p, n_cd, n_streams, n_px);
+    else if (p.K == 128) hipLaunchKernelGGL((conv_pw_stream<128>), dim3(grid), dim3(512), 0, s, p, n_cd, n_streams, n_px);
+    else hipLaunchKernelGGL((conv_pw_stream<256>), dim3(grid), dim3(512), 0, s, p, n_cd, n_streams, n_px);
+    LAUNCH_CHECK("conv_pw_stream");
+    return 0;
+}
+
 // Low-K layers with epilogue operands are HBM-bound (their FLOP/byte is below the machine balance): they
 // run on 64x64 tiles with the epilogue operands prefetched under the K loop.
 static bool conv_wants_prefetch(const I2VConvParams& p) {
@@ -1104,6 +1308,7 @@ static bool conv_dc_ok(const I2VConvParams& p) {
     return (p.pointwise || p.tap_uniform) && !p.temporal && !p.pre_scale && !p.quad && p.Cd > 32 && (p.Kpad / I2V_KC) % 2 == 0 && p.Kpad >= 4 * I2V_KC;
 }
 
+#ifndef I2V_NO_CONV_DISPATCH      // (tools/pw_stream_probe.cpp compiles the kernels it launches itself, not the whole dispatch)
 template <int BD, int BP, int WD, int WP, bool MF16 = false>
 static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     const int64_t P = (int64_t)p.N * p.Hg * p.Wg;
@@ -1175,6 +1380,8 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     return 0;
 }
 
+#endif
+
 // Tile choice per launch.  A 32x32x2 fp32 MFMA occupies its SIMD for 64 cycles, so a block's matrix
 // time is fixed by its tile; what varies is how evenly the grid covers the 256 CUs (the 14x14 layers
 // have only a few hundred 128x128 tiles) against the extra operand traffic of small tiles.
@@ -1228,6 +1435,8 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
     static const bool no_dc = [] { const char* e = getenv("I2V_DC"); return e && e[0] == '0'; }();
     if (conv_dc_ok(p) && !no_dc) out[n++] = 3 | 64;                          // 64x64 with two chunks per barrier (32-row LDS buffers)
     if (p.Cd <= 16) out[n++] = 5;                        // 16x256 tile on 16x16x4 MFMA fragments
+    static const bool no_pws = [] { const char* e = getenv("I2V_PWS"); return e && e[0] == '0'; }();
+    if (conv_pws_grid(p) && !no_pws) out[n++] = 3 | 256;                      // conv_pw_stream: one persistent role-split workgroup per CU
     return n;
 }
 
@@ -1246,6 +1455,7 @@ int k_conv_fusable(const I2VConvParams& a, const I2VConvParams& b) {
     return (a.Cd == 64 && conv_halo_ok(a)) ? 3 : 1;
 }
 
+#ifndef I2V_NO_CONV_DISPATCH
 int k_conv_fused(const I2VConvParams& a_in, const I2VConvParams& b_in, int halo, i2v_stream_t s) {
     I2VConvParams a = a_in, b = b_in;
     const int64_t P = (int64_t)a.N * a.Hg * a.Wg;
@@ -1271,6 +1481,11 @@ int k_conv(const I2VConvParams& p_in, i2v_stream_t s) {
     if ((int64_t)p.N * p.Hg * p.Wg + 1024 >= (1ll << 31)) { snprintf(g_be_err, sizeof g_be_err, "conv launch of more than 2^31 grid pixels"); g_be_has_err = true; return 1; }
     conv_magics(p);
     if (p.cfg <= 0) p.cfg = conv_pick(p) + 1;          // the model's pick -- or $I2V_FORCE_CFG, which may carry the variant bits too
+    __atomic_fetch_add(&g_stat_conv, 1, __ATOMIC_RELAXED);
+    if (((p.cfg - 1) & 256) && conv_pws_grid(p)) {     // persistent role-split pointwise kernel (autotuner bit 8)
+        __atomic_fetch_add(&g_stat_pws, 1, __ATOMIC_RELAXED);
+        return launch_conv_pws(p, st);
+    }
     switch ((p.cfg - 1) & 7) {
         case 0: return launch_conv_cfg<128, 128, 2, 2>(p, st);
         case 1: return launch_conv_cfg<64, 128, 2, 2>(p, st);
@@ -1280,6 +1495,8 @@ int k_conv(const I2VConvParams& p_in, i2v_stream_t s) {
         default: return launch_conv_cfg<32, 256, 1, 4>(p, st);
     }
 }
+
+#endif
 
 // =============================================================================================
 // max pooling (window-relative arg-max byte saved by forward: first maximum in scan order, as ATen)

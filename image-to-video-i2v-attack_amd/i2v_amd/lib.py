@@ -46,6 +46,7 @@ _PROTOS = {
     "i2v_last_error": ([], C.c_char_p),
     "i2v_abi_version": ([], _I),
     "i2v_backend": ([], C.c_char_p),
+    "i2v_backend_stat": ([C.c_char_p], C.c_longlong),
     "i2v_net_create": ([_P, C.POINTER(_I)], _I),
     "i2v_net_destroy": ([_P, _I], _I),
     "i2v_net_add_buffer": ([_P, _I, _I, _I, _I, C.POINTER(_I)], _I),

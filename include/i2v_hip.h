@@ -37,6 +37,10 @@ int i2v_abi_version(void);
  * the same ABI that answers "hostsim"; the Python package refuses to load anything else than
  * the HIP build.) */
 const char* i2v_backend(void);
+/* Launch counters of the kernel backend since the library was loaded: "conv_launches" (every conv_igemm-family launch),
+ * "pws_launches" (of those, the persistent role-split pointwise kernel conv_pw_stream), anything else -1.  Diagnostics for the
+ * tests (a forced configuration must really have run); results never depend on it.  No counterpart in the reference. */
+long long i2v_backend_stat(const char* name);
 
 /* ---- backbone description --------------------------------------------------------------
  * Replaces `get_model`/`get_models` + `.cuda()` (image_attacks.py:84-115) and the hook lookup

@@ -9,6 +9,12 @@ A worker is a child PROCESS of its caller (started with subprocess, never an exe
 confines itself to `threads` of the host's CPUs (slot k takes the k-th group of that many allowed CPUs).  Per row it writes
 `DIR/{row}-oracle-adv.npy` (float32 (3,32,224,224), the file the evaluator scores) and then `DIR/{row}-oracle.npz` (costs,
 mean|delta_10|, seconds) -- the npz appears last and atomically (rename), so its presence means the row is complete.
+`--f64_rows` adds the float64 oracle's run of those rows (`{row}-oracle64*`: the yardstick of `oracle/size_parity.py`).
+
+Measured on the GPU box's host (2 x 64 cores, 256 threads): EIGHT workers of 28 threads -- their slots running into the SMT siblings
+of the first ones, beside an unpinned 32-thread oracle in the caller -- took 43 s per clip in aggregate, three times LONGER than one
+32-thread process alone (13.4 s per clip): ATen's convolutions are bound by the memory system long before the host runs out of
+threads.  Hence the default of FOUR workers of 32 threads on the first 128 CPUs (physical cores), and a caller that waits idle.
 """
 import argparse
 import os
@@ -33,6 +39,7 @@ def pin(slot, threads):
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", required=True, help="comma-separated row indices of the sample list")
+    ap.add_argument("--f64_rows", default="", help="rows to attack with the FLOAT64 oracle as well (the yardstick run; done first)")
     ap.add_argument("--threads", type=int, default=32)
     ap.add_argument("--slot", type=int, default=None)
     ap.add_argument("--out", required=True)
@@ -55,16 +62,22 @@ def main(argv=None):
     g = graphs.build_tiny("resnet", (args.hw, args.hw)) if args.tiny else graphs.build("resnet50", (args.hw, args.hw))
     net = restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hooks[3]])
     os.makedirs(args.out, exist_ok=True)
-    for row in [int(r) for r in args.rows.split(",") if r != ""]:
-        done = os.path.join(args.out, f"{row}-oracle.npz")
+    jobs = [(int(r), "oracle64") for r in args.f64_rows.split(",") if r != ""] + [(int(r), "oracle") for r in args.rows.split(",") if r != ""]
+    net64 = None
+    for row, tag in jobs:
+        done = os.path.join(args.out, f"{row}-{tag}.npz")
         if os.path.exists(done):
             continue
         t0 = time.time()
         vid = size_parity.synthetic_clip(1000 + row, args.frames, args.hw)
-        ora = size_parity.oracle_attack(net, vid, steps=args.steps, lr=args.lr)
-        np.save(os.path.join(args.out, f"{row}-oracle-adv.npy"), ora["adv"][0].numpy())
-        tmp = os.path.join(args.out, f".{row}-oracle.tmp.npz")
-        np.savez(tmp, costs=ora["costs"], mean_abs_delta=float(ora["delta"].abs().mean()), seconds=time.time() - t0)
+        if tag == "oracle64":
+            net64 = net64 or restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hooks[3]], dtype=torch.float64)
+            ora = size_parity.oracle_attack(net64, vid.double(), steps=args.steps, lr=args.lr)
+        else:
+            ora = size_parity.oracle_attack(net, vid, steps=args.steps, lr=args.lr)
+        np.save(os.path.join(args.out, f"{row}-{tag}-adv.npy"), ora["adv"][0].float().numpy())
+        tmp = os.path.join(args.out, f".{row}-{tag}.tmp.npz")
+        np.savez(tmp, costs=np.asarray(ora["costs"], np.float64), mean_abs_delta=float(ora["delta"].abs().mean()), seconds=time.time() - t0)
         os.replace(tmp, done)
 
 

@@ -79,7 +79,7 @@ def compare(costs, delta, adv, ora):
     oc = np.asarray(ora["costs"], np.float64)
     rel = np.abs(costs - oc) / np.abs(oc)
     # (an oracle run that was saved by a worker process carries mean|delta| as a number instead of the tensor: oracle/fooling_worker.py)
-    d_dev = float(delta.float().abs().mean())
+    d_dev = float(delta) if isinstance(delta, float) else float(delta.float().abs().mean())
     d_ora = float(ora["mean_abs_delta"]) if "mean_abs_delta" in ora else float(ora["delta"].float().abs().mean())
     diff = (adv.float() - ora["adv"].float()).abs()
     un = diff * STD                                                     # back to [0,1] pixel units
@@ -131,9 +131,10 @@ def compare_sampled(costs, delta, adv, yard, lr=0.005):
             "max_abs_adv_diff_pixel_units": float(un.max())}
 
 
-def start_oracle_workers(rows, out_dir, workers=8, threads=32, steps=10, lr=0.005, extra=()):
+def start_oracle_workers(rows, out_dir, workers=4, threads=32, steps=10, lr=0.005, extra=(), f64_rows=()):
     """Start `workers` CPU child processes of `oracle.fooling_worker` over `rows` (dealt round-robin, so the early rows of every worker
-    finish first); returns the Popen objects.  Children of the caller -- never an exec of the caller itself, which may hold the GPU."""
+    finish first); returns the Popen objects.  Children of the caller -- never an exec of the caller itself, which may hold the GPU.
+    `f64_rows`: rows whose float64 run the LAST worker does first.  (Four workers of 32 threads: see the worker's docstring.)"""
     import os
     import subprocess
     import sys
@@ -146,15 +147,17 @@ def start_oracle_workers(rows, out_dir, workers=8, threads=32, steps=10, lr=0.00
         mine = rows[w::workers]
         cmd = [sys.executable, "-m", "oracle.fooling_worker", "--rows", ",".join(str(r) for r in mine), "--threads", str(threads), "--slot", str(w),
                "--out", out_dir, "--steps", str(steps), "--lr", str(lr)] + list(extra)
+        if f64_rows and w == workers - 1:
+            cmd += ["--f64_rows", ",".join(str(r) for r in f64_rows)]
         procs.append(subprocess.Popen(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))))
     return procs
 
 
-def wait_oracle_row(out_dir, row, procs, timeout=1800.0, lr=0.005):
+def wait_oracle_row(out_dir, row, procs, timeout=1800.0, lr=0.005, tag="oracle"):
     """Block until row `row` of a `start_oracle_workers` run is complete; returns its `ora` dict (costs, mean_abs_delta, adv (1,3,f,h,w), lr).
-    Raises if a worker died without producing it."""
+    Raises if a worker died without producing it.  `tag="oracle64"`: the float64 run of an `f64_rows` row."""
     import os
-    done = os.path.join(out_dir, f"{row}-oracle.npz")
+    done = os.path.join(out_dir, f"{row}-{tag}.npz")
     t0 = time.time()
     while not os.path.exists(done):
         if all(p.poll() is not None for p in procs) and not os.path.exists(done):
@@ -163,7 +166,7 @@ def wait_oracle_row(out_dir, row, procs, timeout=1800.0, lr=0.005):
             raise TimeoutError(f"oracle row {row} not ready after {timeout} s")
         time.sleep(0.2)
     z = np.load(done)
-    adv = torch.from_numpy(np.load(os.path.join(out_dir, f"{row}-oracle-adv.npy")))[None]
+    adv = torch.from_numpy(np.load(os.path.join(out_dir, f"{row}-{tag}-adv.npy")))[None]
     return {"costs": z["costs"], "mean_abs_delta": float(z["mean_abs_delta"]), "adv": adv, "lr": lr, "seconds": float(z["seconds"])}
 
 

@@ -29,6 +29,7 @@ int be_d2d_2d(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t row
 }
 int be_memset0(void* p, size_t b, i2v_stream_t) { memset(p, 0, b); return 0; }
 const char* be_error() { return nullptr; }
+long long be_stat(const char*) { return -1; }
 void* be_event_create() { return malloc(8); }
 void be_event_destroy(void* e) { free(e); }
 int be_event_record(void*, i2v_stream_t) { return 0; }

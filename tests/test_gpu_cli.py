@@ -114,3 +114,29 @@ def test_bench_starts_its_own_ranks_on_the_gpu():
     assert d["n_gpus"] == 2 and len(d["per_gpu"]) == 2 and d["value"] > 0
     assert d["ranks_proved_by_allreduce"]["sum_of_rank_ids"] == 1 == d["ranks_proved_by_allreduce"]["expected"]
     assert abs(sum(d["per_gpu"]) - d["value"]) <= 0.05 * d["value"]
+
+
+def test_bench_aens_two_ranks_exchange_on_device_tensors():
+    """`bench.py --workload aens --gpus 2`: the path's ONE collective with 2 ranks on the GPU -- the in-place all-reduce of the (2, L)
+    DEVICE tensor `aens_reduce_kernel` wrote, read by the next step's `aens_coeffs_kernel` (TPAMI_attack.py:265,293-297).  Both ranks
+    share device 0 over gloo (RCCL cannot put two ranks on one device: the most a 1-GPU box allows); rank r attacks clip seed
+    1000 + r, so the global batch is clips 1000, 1001 -- the layer weights must be identical on both ranks and equal to ONE process
+    attacking those two clips (they are functions of the global batch's sums, exchanged in fp32: the sum of two per-rank partial sums
+    against one device's sum over both clips differs in the last bits, hence rtol 1e-5)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(I2V_SYNTHETIC_WEIGHTS="1", I2V_QUIET_WEIGHTS="1")
+    common = ["--workload", "aens", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-kernel-timing"]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--dist-backend", "gloo", "--clips", "1"] + common,
+                         capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-3000:]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--clips", "2"] + common,
+                         capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][0])
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    a2, a1 = d2["aens"], d1["aens"]
+    assert d2["n_gpus"] == 2 and a2["rccl_ranks"] == 2 and a2["backend"] == "gloo" and a1["rccl_ranks"] == 1
+    assert a2["weights_identical_on_all_ranks"] is True
+    assert a2["layers"] == a1["layers"] == 8 and a2["allreduce_device_us"] > 0 and a2["allreduce_bytes"] == 2 * 8 * 4
+    np.testing.assert_allclose(a2["layer_weights_last_step"], a1["layer_weights_last_step"], rtol=1e-5)
+    assert abs(sum(a1["layer_weights_last_step"]) - 1.0) < 1e-5 or min(a1["layer_weights_last_step"]) > 0

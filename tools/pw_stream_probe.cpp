@@ -1,0 +1,116 @@
+// Developer tool (round 5): conv_pw_stream -- the persistent, role-split pointwise kernel -- alone on synthetic operands.
+//   * correctness: every output word (values AND the tensor's own 1-bit gates) bit for bit against a scalar restatement of the
+//     launch (`ref_kernel`: the k-ordered fmaf chain, then the epilogue of conv_vec_rows in its order);
+//   * speed: TFLOP/s and algorithmic TB/s per shape, after a clock warm-up, as tools/conv_microbench.cpp measures conv_igemm.
+// Built WITHOUT the product's dispatch (-DI2V_NO_CONV_DISPATCH: only the kernels launched here are instantiated -- seconds, not minutes):
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++20 -x hip -DI2V_NO_CONV_DISPATCH tools/pw_stream_probe.cpp -o tools/pws_probe
+//   tools/pws_probe [frames] [mode]      modes: 0 = forward (shift, residual addend, ReLU, own gates), 1 = input gradient (addend, gate words), 2 = forward without an addend
+#ifndef I2V_NO_CONV_DISPATCH
+#define I2V_NO_CONV_DISPATCH
+#endif
+#include "../image-to-video-i2v-attack_amd/csrc/i2v_kernels.hip"
+
+#include <string.h>
+
+#include <vector>
+
+__global__ void ref_kernel(const I2VConvParams p, float* out, unsigned* gates) {
+    const int HW = p.Hg * p.Wg;
+    const int64_t P = (int64_t)p.N * HW;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P * p.Cd) return;
+    const int cd = (int)(idx / P);
+    const int64_t pp = idx % P, n = pp / HW, rem = pp % HW;
+    float acc = 0.f;
+    for (int k = 0; k < p.K; ++k) acc = fmaf(p.wp[(int64_t)k * p.Cdpad + cd], p.src[n * p.src_nstride + (int64_t)k * HW + rem], acc);
+    const int64_t o = (int64_t)cd * HW + rem;
+    float v = acc;
+    if (p.shift) v += p.shift[cd];
+    if (p.add0) v += p.add0[n * p.add0_nstride + o];
+    if (p.relu) v = fmaxf(v, 0.f);
+    if (p.gate && !((p.gate[(int64_t)cd * p.gate_stride + ((p.gate_pix0 + pp) >> 5)] >> ((p.gate_pix0 + pp) & 31)) & 1u)) v = 0.f;
+    out[n * p.dst_nstride + o] = v;
+    if (gates && v > 0.f) atomicOr(&gates[(int64_t)cd * p.gate_out_stride + ((p.gate_out_pix0 + pp) >> 5)], 1u << ((p.gate_out_pix0 + pp) & 31));
+}
+
+struct Shape { int Cin, Cout, H; const char* what; };
+
+static int run(int N, const Shape& sh, int mode, int nt) {
+    const int K = sh.Cin, Cd = sh.Cout, HW = sh.H * sh.H, Cdpad = (Cd + 127) / 128 * 128;
+    const int64_t P = (int64_t)N * HW;
+    std::vector<float> wp((size_t)K * Cdpad, 0.f), src((size_t)N * K * HW), add((size_t)N * Cd * HW), shift(Cd);
+    for (int k = 0; k < K; ++k) for (int c = 0; c < Cd; ++c) wp[(size_t)k * Cdpad + c] = (rand() % 2001 - 1000) * 1e-4f;
+    for (auto& v : src) { v = (rand() % 2001 - 1000) * 1e-3f; if (mode != 1 && v < 0.f) v = 0.f; }
+    for (auto& v : add) v = (rand() % 2001 - 1000) * 2e-3f;
+    for (auto& v : shift) v = (rand() % 2001 - 1000) * 1e-3f;
+    const int gstride = (int)((P + 31) / 32) + 4;
+    std::vector<unsigned> gate((size_t)Cd * gstride);
+    for (auto& g : gate) g = (unsigned)rand() * 2654435761u ^ (unsigned)rand();
+    float *dw, *ds, *dd, *dr, *da, *dsh; unsigned *dg, *dgo, *dgr;
+    const size_t outn = (size_t)N * Cd * HW;
+    hipMalloc(&dw, wp.size() * 4); hipMalloc(&ds, src.size() * 4); hipMalloc(&dd, outn * 4); hipMalloc(&dr, outn * 4); hipMalloc(&da, outn * 4);
+    hipMalloc(&dsh, Cd * 4); hipMalloc(&dg, gate.size() * 4); hipMalloc(&dgo, gate.size() * 4); hipMalloc(&dgr, gate.size() * 4);
+    hipMemcpy(dw, wp.data(), wp.size() * 4, hipMemcpyHostToDevice); hipMemcpy(ds, src.data(), src.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(da, add.data(), outn * 4, hipMemcpyHostToDevice); hipMemcpy(dsh, shift.data(), Cd * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dg, gate.data(), gate.size() * 4, hipMemcpyHostToDevice);
+    hipMemset(dd, 0xff, outn * 4); hipMemset(dgo, 0, gate.size() * 4); hipMemset(dgr, 0, gate.size() * 4);
+    I2VConvParams p; memset((void*)&p, 0, sizeof p);
+    p.src = ds; p.src_nstride = (int64_t)K * HW; p.Hs = p.Ws = sh.H; p.Cs = K; p.src_span_bytes = (int32_t)((int64_t)N * K * HW * 4);
+    p.wp = dw; p.K = p.Kpad = K; p.Cd = Cd; p.Cdpad = Cdpad;
+    p.N = N; p.Hg = p.Wg = sh.H; p.sh = p.sw = 1;
+    p.dst = dd; p.dst_nstride = (int64_t)Cd * HW; p.Ho = p.Wo = sh.H; p.osh = p.osw = 1;
+    p.add0_stride = 1; p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1; p.oct = 1;
+    p.pointwise = 1; p.tap_uniform = 1; p.vec_epilogue = 1;
+    if (mode != 2) { p.add0 = da; p.add0_nstride = p.dst_nstride; }      // mode 2: forward without a residual (the reduce convolutions)
+    if (mode != 1) { p.shift = dsh; p.relu = 1; p.gate_out = dgo; p.gate_out_stride = gstride; p.gate_out_pix0 = 32; }
+    else { p.gate = dg; p.gate_stride = gstride; p.gate_pix0 = 64; }
+    p.cfg = (3 | 256 | (nt ? 128 : 0)) + 1;
+    conv_magics(p);
+    const int grid = conv_pws_grid(p);
+    if (!grid) { printf("%-16s not eligible\n", sh.what); return 0; }
+    // reference
+    I2VConvParams pr = p; pr.dst = dr;
+    hipLaunchKernelGGL(ref_kernel, dim3((unsigned)((P * Cd + 255) / 256)), dim3(256), 0, nullptr, pr, dr, mode != 1 ? dgr : nullptr);
+    if (launch_conv_pws(p, nullptr)) { printf("launch failed: %s\n", be_error()); return 1; }
+    if (hipDeviceSynchronize() != hipSuccess) { printf("kernel fault: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
+    std::vector<float> got(outn), want(outn);
+    hipMemcpy(got.data(), dd, outn * 4, hipMemcpyDeviceToHost); hipMemcpy(want.data(), dr, outn * 4, hipMemcpyDeviceToHost);
+    size_t bad = 0, first = 0;
+    for (size_t i = 0; i < outn; ++i) if (memcmp(&got[i], &want[i], 4)) { if (!bad) first = i; ++bad; }
+    size_t gbad = 0;
+    if (mode != 1) {
+        std::vector<unsigned> g1(gate.size()), g2(gate.size());
+        hipMemcpy(g1.data(), dgo, gate.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(g2.data(), dgr, gate.size() * 4, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < g1.size(); ++i) gbad += g1[i] != g2[i];
+    }
+    // timing
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a, nullptr); launch_conv_pws(p, nullptr); hipEventRecord(b, nullptr); hipEventSynchronize(b);
+    float one; hipEventElapsedTime(&one, a, b); if (one < 1e-3f) one = 1e-3f;
+    for (int i = 0; i < (int)(80.f / one) + 1; ++i) launch_conv_pws(p, nullptr);
+    const int iters = (int)(40.f / one) + 1;
+    hipEventRecord(a, nullptr);
+    for (int i = 0; i < iters; ++i) launch_conv_pws(p, nullptr);
+    hipEventRecord(b, nullptr); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); ms /= iters;
+    const double flops = 2.0 * P * (double)Cd * K, bytes = 4.0 * P * (K + (mode == 2 ? 1.0 : 2.0) * Cd) + P * Cd / 8.0;
+    printf("%-16s %4d->%4d @%2d^2 N=%d mode %d nt %d | %7.1f us  %6.1f TFLOP/s  %5.2f TB/s | values %s (%zu differ%s) gates %s\n", sh.what, K, Cd, sh.H, N, mode, nt,
+           ms * 1e3, flops / ms * 1e-9, bytes / ms * 1e-9, bad ? "MISMATCH" : "bit-identical", bad, bad ? (", first at " + std::to_string(first)).c_str() : "",
+           mode == 1 ? "-" : (gbad ? "MISMATCH" : "bit-identical"));
+    hipFree(dw); hipFree(ds); hipFree(dd); hipFree(dr); hipFree(da); hipFree(dsh); hipFree(dg); hipFree(dgo); hipFree(dgr);
+    return bad || gbad ? 1 : 0;
+}
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 128;
+    static const Shape S[] = {{64, 256, 56, "layer1 expand"}, {128, 512, 28, "layer2 expand"}, {256, 1024, 14, "layer3 expand"}, {64, 64, 56, "layer1 first"},
+                              {256, 64, 56, "layer1 reduce"}, {256, 128, 56, "layer2.0 reduce"}};
+    int rc = 0;
+    for (int mode = 0; mode < 3; ++mode)
+        for (const Shape& sh : S)
+            for (int nt = 0; nt < 2; ++nt) rc |= run(N, sh, mode, nt);
+    // odd frame counts: pixel tiles that straddle frames, a pixel tail, streams with unequal tile counts
+    for (int n : {1, 3, 7, 33}) rc |= run(n, S[1], 0, 0), rc |= run(n, S[0], 1, 0), rc |= run(n + 8, S[2], 0, 0);
+    printf(rc ? "FAILED\n" : "all bit-identical\n");
+    return rc;
+}
