@@ -1090,15 +1090,18 @@ conv_igemm_tail(const I2VConvParams p, const int n_cd_a, const int nA, const int
 // =============================================================================================
 // The short-K pointwise launches (64 -> 256 @56^2, 128 -> 512 @28^2 and their input gradients) run a 4-8 chunk K loop and then a
 // byte-heavy epilogue, serially inside every block of conv_igemm; seven co-resident blocks overlap the two only statistically
-// (PMC: matrix pipe 0.58 busy, HBM at 0.43 of its peak -- on neither roof).  Here ONE 512-thread workgroup per CU owns a 64-channel
+// (PMC: matrix pipe 0.58 busy, HBM at 0.43 of its peak -- on neither roof).  Here ONE 768-thread workgroup per CU owns a 64-channel
 // tile for the whole launch and walks its share of the pixel tiles:
 //   * the [K][64] weight panel is staged into LDS ONCE and stays;
-//   * waves 0-3 ("matrix waves", one per SIMD) only issue MFMAs from LDS -- K / 2 of them back to back per tile, no wait inside a
-//     tile -- and, behind the first ones, the LDS-DMA of the NEXT tile's activations into the other buffer of a ring; at the end of a
-//     tile they deposit the accumulators transposed into one of two [64][64] hand-off buffers;
-//   * waves 4-7 ("epilogue waves", the SIMDs' second wave) meanwhile drain the PREVIOUS tile's hand-off buffer through
-//     conv_vec_rows -- addend / gate words prefetched into registers one to two tiles ahead, shift, ReLU, gates, 16-byte stores;
-//   * ONE s_barrier per tile hands the buffers over: B ring slot full / free, hand-off buffer full / free.
+//   * waves 0-3 ("matrix waves", one per SIMD) only read LDS and issue MFMAs -- K / 2 of them back to back per tile, no wait inside a
+//     tile; at the end of a tile they deposit the accumulators transposed into one of two [64][64] hand-off buffers;
+//   * waves 8-11 ("loader waves") issue the LDS-DMA of the activation tiles into a ring, NBUF - 1 slabs ahead of the matrix waves (the
+//     first version had the matrix waves issue them behind their MFMAs, as conv_tile does: with ONE matrix wave per SIMD every DMA issue
+//     stall -- 60-185 cycles against an MFMA's 64 -- idled the pipe, and a ring one tile deep exposed the memory latency every tile:
+//     45 / 70 / 89 TFLOP/s on 64 -> 256 / 128 -> 512 / 256 -> 1024 against conv_igemm's 69 / 108 / 117; tools/pw_stream_probe.cpp);
+//   * waves 4-7 ("epilogue waves") meanwhile drain the PREVIOUS tile's hand-off buffer through conv_vec_rows -- addend / gate words
+//     prefetched into registers up to three tiles ahead, shift, ReLU, gates, 16-byte stores;
+//   * ONE s_barrier per tile (per 128-row slab) hands the buffers over: ring slot full / free, hand-off buffer full / free.
 // So a CU's matrix pipe, its HBM reads (activations, addend) and its stores run concurrently by construction, not by luck of block
 // phases.  Every output element is the same k-ordered fmaf chain over the same values as in conv_igemm (a 32x32x2 fp32 MFMA is a
 // sequential chain along K whatever feeds it), and the row pass IS conv_igemm's: bit-identical.
@@ -1107,16 +1110,25 @@ conv_igemm_tail(const I2VConvParams p, const int n_cd_a, const int nA, const int
 // K = 256 (256 -> 1024 @14^2): the activations of a tile arrive as two 128-row SLABS through the same two-slot ring -- one barrier per
 // slab --, the 64 KB weight panel stays whole: 160 KB of LDS, all a workgroup may have.
 template <int K> constexpr int pws_slab() { return K < 128 ? K : 128; }                   // K rows per ring slot
-template <int K> constexpr int pws_nbuf() { return K <= 64 ? 3 : 2; }                      // activation ring slots ([slab][64] floats each)
+template <int K> constexpr int pws_nbuf() { return K <= 64 ? 4 : K <= 128 ? 3 : 2; }       // activation ring slots ([slab][64] floats each): all of the 160 KB
 template <int K> constexpr int pws_lds_floats() { return K * 64 + pws_nbuf<K>() * pws_slab<K>() * 64 + 2 * 64 * 64; }
 #ifndef I2V_PWS_NSET
 #define I2V_PWS_NSET 2                // epilogue-operand register sets (tiles of addend / gate words in flight per epilogue wave)
 #endif
+#define I2V_PWS_THREADS 768           // 4 matrix waves + 4 epilogue waves + 4 loader waves: three waves per SIMD
+#ifdef I2V_PWS_STAMPS      // diagnostic build (tools/pw_stream_probe.cpp -DI2V_PWS_STAMPS): per block, 100 MHz ticks summed over its tiles
+__device__ unsigned long long g_pws_stamps[256 * 8];
+#define PWS_NOW() __builtin_amdgcn_s_memrealtime()
+#define PWS_ACC(var, t0_) (var) += PWS_NOW() - (t0_)
+#else
+#define PWS_NOW() 0ull
+#define PWS_ACC(var, t0_) ((void)(t0_))
+#endif
 template <int K>
-__global__ void __launch_bounds__(512) conv_pw_stream(const I2VConvParams p, const int n_cd, const int n_streams, const int n_px_tiles) {
+__global__ void __launch_bounds__(I2V_PWS_THREADS) conv_pw_stream(const I2VConvParams p, const int n_cd, const int n_streams, const int n_px_tiles) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int KSL = pws_slab<K>(), S = K / KSL, NBUF = pws_nbuf<K>(), NSET = I2V_PWS_NSET, KS = KSL / 2, NPW = KSL / 16;     // NPW: DMA pieces per matrix wave per slab
-    static_assert(K % KSL == 0 && (S == 1 || NBUF == 2), "slabs: whole, and through a two-slot ring");
+    constexpr int KSL = pws_slab<K>(), S = K / KSL, NBUF = pws_nbuf<K>(), NSET = I2V_PWS_NSET, KS = KSL / 2, NPW = KSL / 16;     // NPW: DMA pieces per loader wave per slab
+    static_assert(K % KSL == 0, "whole slabs");
     __shared__ __attribute__((aligned(16))) float smem[pws_lds_floats<K>()];
     float* const Wl = smem;                                   // [K][64]   weight panel of this block's channel tile
     float* const Bl = smem + K * 64;                          // [NBUF][KSL][64] activation ring
@@ -1131,52 +1143,73 @@ __global__ void __launch_bounds__(512) conv_pw_stream(const I2VConvParams p, con
     const int HWg = p.Hg * p.Wg;
     const int64_t P = (int64_t)p.N * HWg;
     auto px_of = [&](const int i) { return ((int64_t)stream + (int64_t)i * n_streams) * 64; };
-    if (wv < 4) {
-        // ------------------------------------------------------------------ matrix waves
+    // Barrier #0 follows the weight panel and the ring's first slab; barrier #(g + 1) ends slab-phase g (g = i S + h: slab h of tile i):
+    // by then the matrix waves are done with slab g (its ring slot is free) and, at a tile's last slab, have deposited the tile; the loader
+    // waves have seen slab g + 1 land; the epilogue waves have finished reading the hand-off buffer of tile i - 1.
+    if (wv >= 8) {
+        // ------------------------------------------------------------------ loader waves: LDS-DMA only, so their vmcnt is exact
         constexpr unsigned OOB = 0x80000000u;
+        const int lw = wv - 8;
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.Kpad * p.Cdpad * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_span_bytes, 0x00020000);
         const int HWs = p.Hs * p.Ws;
-        const int wd = wv >> 1, wpx = wv & 1, l31 = lane & 31, lk = lane >> 5;
         // piece `ins` of a [rows][64] image = its rows 4 ins .. 4 ins + 3; lane l moves 16 bytes: row 4 ins + l / 16, columns 4 (l % 16) ..
         const unsigned aoff = (unsigned)(((lane >> 4) * p.Cdpad + cd0 + (lane & 15) * 4) * 4);
-        auto b_off = [&](const int i) -> unsigned {           // byte offset of this lane's 4 pixels of tile i in row 0 of piece 0 of slab 0
+        auto issue_slab = [&](const int g, const int slot_) {                             // this wave's NPW pieces of slab g % S of tile g / S
+            const int i = g / S, h = g - i * S;
             const int64_t pp = px_of(i) + (lane & 15) * 4;
-            if (i >= n_mine || pp >= P) return OOB;
-            const int64_t n = fastdiv((unsigned)pp, p.dv_hw_m, p.dv_hw_s);
-            return (unsigned)((n * p.src_nstride + (pp - n * HWg) + (int64_t)(lane >> 4) * HWs) * 4);
+            unsigned bo = OOB;                                                            // beyond this block's tiles / the launch: zero fill, same counts
+            if (i < n_mine && pp < P) {
+                const int64_t n = fastdiv((unsigned)pp, p.dv_hw_m, p.dv_hw_s);
+                bo = (unsigned)((n * p.src_nstride + (pp - n * HWg) + (int64_t)(lane >> 4) * HWs) * 4);
+            }
+#pragma unroll
+            for (int q = 0; q < NPW; ++q) {
+                const int ins = lw + 4 * q;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(Bl + slot_ * (KSL * 64) + ins * 256), 16, bo, (h * KSL + ins * 4) * HWs * 4, 0, 0);
+            }
         };
-        auto issue_b = [&]<int Q>(std::integral_constant<int, Q>, const unsigned bo, const int slot_, const int h) {      // piece wv + 4 Q of slab h of a tile
-            const int ins = wv + 4 * Q;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(Bl + slot_ * (KSL * 64) + ins * 256), 16, bo, (h * KSL + ins * 4) * HWs * 4, 0, 0);
-        };
-        auto issue_slab = [&](const int i, const int h, const int slot_) {                // all of this wave's pieces of one slab at once
-            const unsigned bo = b_off(i);
-            [&]<int... Q>(std::integer_sequence<int, Q...>) { ((issue_b(std::integral_constant<int, Q>{}, bo, slot_, h)), ...); }(std::make_integer_sequence<int, NPW>{});
-        };
-        // prologue: the weight panel, then the first NBUF - 1 slabs of the sequence (tile 0 slab 0, ...)
 #pragma unroll
         for (int q = 0; q < K / 16; ++q) {
-            const int ins = wv + 4 * q;
+            const int ins = lw + 4 * q;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Wl + ins * 256), 16, aoff, ins * 4 * p.Cdpad * 4, 0, 0);
         }
 #pragma unroll
-        for (int g = 0; g < NBUF - 1; ++g) issue_slab(g / S, g % S, g);
-        if constexpr (NBUF > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * NPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                                     // #0: panel + the first slab in LDS
+        for (int g = 0; g < NBUF - 1; ++g) issue_slab(g, g);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * NPW) : "memory");           // the panel and slab 0
+        __builtin_amdgcn_s_barrier();                                                     // #0
+        int slot = NBUF - 1;                                                              // ring slot of slab g + NBUF - 1
+        const int n_slabs = n_mine * S;
+        unsigned long long l_issue = 0, l_wait = 0, l_bar = 0; (void)l_issue; (void)l_wait; (void)l_bar;
+        for (int g = 0; g < n_slabs; ++g) {
+            unsigned long long ts = PWS_NOW();
+            issue_slab(g + NBUF - 1, slot);                                               // its slot held slab g - 1: free since barrier #g
+            PWS_ACC(l_issue, ts); ts = PWS_NOW();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * NPW) : "memory");       // slab g + 1 has landed (g + 2 .. may still fly)
+            PWS_ACC(l_wait, ts); ts = PWS_NOW();
+            __builtin_amdgcn_s_barrier();                                                 // #(g + 1)
+            PWS_ACC(l_bar, ts);
+            slot = slot + 1 == NBUF ? 0 : slot + 1;
+        }
+#ifdef I2V_PWS_STAMPS
+        if (t == 512 && blockIdx.x < 256) { g_pws_stamps[8 * blockIdx.x + 5] = l_issue; g_pws_stamps[8 * blockIdx.x + 6] = l_wait; g_pws_stamps[8 * blockIdx.x + 7] = l_bar; }
+#endif
+    } else if (wv < 4) {
+        // ------------------------------------------------------------------ matrix waves: LDS reads and MFMAs, nothing else
+        const int wd = wv >> 1, wpx = wv & 1, l31 = lane & 31, lk = lane >> 5;
+        __builtin_amdgcn_s_barrier();                                                     // #0
         int slot = 0;
+        unsigned long long m_loop = 0, m_bar = 0; (void)m_loop; (void)m_bar;
         for (int i = 0; i < n_mine; ++i) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             [&]<int... H>(std::integer_sequence<int, H...>) {
                 (([&] {
-                    constexpr int h = H, hn = (H + NBUF - 1) % S, di = (H + NBUF - 1) / S;      // the slab issued now: slab hn of tile i + di
+                    constexpr int h = H;
+                    unsigned long long ts = PWS_NOW();
                     const float* const wbase = Wl + (h * KSL + lk) * 64 + wd * 32 + l31;
                     const float* const bbase = Bl + slot * (KSL * 64) + lk * 64 + wpx * 32 + l31;
-                    const int nslot = slot + (NBUF - 1) >= NBUF ? slot + (NBUF - 1) - NBUF : slot + (NBUF - 1);
-                    const unsigned bo = b_off(i + di);                                    // OOB beyond this block's tiles: zero fill, same counts
                     float fa[3], fb[3];
                     fa[0] = wbase[0]; fb[0] = bbase[0];
                     fa[1] = wbase[128]; fb[1] = bbase[128];
@@ -1186,7 +1219,6 @@ __global__ void __launch_bounds__(512) conv_pw_stream(const I2VConvParams p, con
                             if constexpr (s_ + 2 < KS) { fa[nx2] = wbase[(s_ + 2) * 128]; fb[nx2] = bbase[(s_ + 2) * 128]; }
                             __builtin_amdgcn_sched_barrier(0);
                             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur], fb[cur], acc, 0, 0, 0);
-                            if constexpr (s_ < NPW) issue_b(std::integral_constant<int, s_>{}, bo, nslot, hn);      // the ring's next slab, one piece per MFMA
                         }()), ...);
                     }(std::make_integer_sequence<int, KS>{});
                     if constexpr (h == S - 1) {      // hand the tile over: accumulators transposed into the hand-off buffer (conv_vec_epilogue's deposit)
@@ -1194,14 +1226,17 @@ __global__ void __launch_bounds__(512) conv_pw_stream(const I2VConvParams p, con
 #pragma unroll
                         for (int r = 0; r < 16; ++r) Cs[wd * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk][wpx * 32 + l31] = acc[r];
                     }
-                    if constexpr (NBUF > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * NPW) : "memory");      // the next slab has landed
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    PWS_ACC(m_loop, ts); ts = PWS_NOW();
                     __builtin_amdgcn_s_barrier();                                         // #(i S + h + 1)
+                    PWS_ACC(m_bar, ts);
                     slot = slot + 1 == NBUF ? 0 : slot + 1;
                 }()), ...);
             }(std::make_integer_sequence<int, S>{});
         }
+#ifdef I2V_PWS_STAMPS
+        if (t == 0 && blockIdx.x < 256) { g_pws_stamps[8 * blockIdx.x + 0] = m_loop; g_pws_stamps[8 * blockIdx.x + 1] = m_bar; }
+#endif
     } else {
         // ------------------------------------------------------------------ epilogue waves
         const int te = t - 256;
@@ -1222,8 +1257,60 @@ __global__ void __launch_bounds__(512) conv_pw_stream(const I2VConvParams p, con
                 gw[q] = (ok && p.gate) ? p.gate[(int64_t)cd * p.gate_stride + ((p.gate_pix0 + e_pp) >> 5)] : 0xffffffffu;
             }
         };
+        // The row pass: conv_vec_rows' expressions in conv_vec_rows' order (shift, addend, ReLU, gate bits, store, own gate word) for the
+        // launches this kernel admits (no second addend, no fp32 mask, no pre-activation gate: conv_pws_grid), with every operand
+        // already in a register.  conv_vec_rows itself reads `shift[cd]` inside its row loop behind an `s_waitcnt vmcnt(0)` -- harmless
+        // among seven co-resident blocks, but here ONE epilogue wave per SIMD is the critical path: each of its four rows then waited
+        // for the previous row's store to be acknowledged (3-4 us per tile against 1.9 us of MFMAs: the probe's first two versions).  A
+        // thread's four channel rows are the same for every tile, so their shifts are loaded once.
+        const bool has_shift = p.shift != nullptr, has_gate = p.gate != nullptr, has_gout = p.gate_out != nullptr, relu = p.relu != 0;
+        const bool nt_store = p.cfg > 0 && ((p.cfg - 1) & 128);
+        float shv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int cd = cd0 + (te >> 4) + q * 16; shv[q] = (has_shift && cd < p.Cd) ? p.shift[cd] : 0.f; }
+        const int HoWo_ = p.Ho * p.Wo;
+        auto rows = [&](const int64_t px0, const float (*const Cs)[64], const float4 (&a0)[4], const unsigned (&gw)[4]) {
+            const int c4 = te & 15, rbase = te >> 4;
+            const int64_t pp = px0 + (int64_t)c4 * 4;
+            const bool pok = pp < P;
+            const int64_t n = pok ? fastdiv((unsigned)pp, p.dv_hw_m, p.dv_hw_s) : 0;
+            const int64_t poff = pp - n * HWg;
+            float* const drow = p.dst + n * p.dst_nstride + poff;
+            const unsigned gsh = (unsigned)(p.gate_pix0 + pp) & 31u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = rbase + q * 16, cd = cd0 + row;
+                const bool valid = pok && cd < p.Cd;
+                float4 v = *reinterpret_cast<const float4*>(&Cs[row][c4 * 4]);
+                if (has_shift) { const float sh = shv[q]; v.x += sh; v.y += sh; v.z += sh; v.w += sh; }
+                v.x += a0[q].x; v.y += a0[q].y; v.z += a0[q].z; v.w += a0[q].w;
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (has_gate) {
+                    const unsigned g = gw[q] >> gsh;
+                    if (!(g & 1u)) v.x = 0.f;
+                    if (!(g & 2u)) v.y = 0.f;
+                    if (!(g & 4u)) v.z = 0.f;
+                    if (!(g & 8u)) v.w = 0.f;
+                }
+                if (valid) {
+                    float* const d = drow + (int64_t)cd * HoWo_;
+                    if (nt_store) { typedef float nt4 __attribute__((ext_vector_type(4))); const nt4 w4 = {v.x, v.y, v.z, v.w};
+                                    __builtin_nontemporal_store(w4, reinterpret_cast<nt4*>(d)); }
+                    else *reinterpret_cast<float4*>(d) = v;
+                }
+                if (has_gout) {      // this tensor's own gates: 8 consecutive lanes hold 32 consecutive pixels of one channel row (conv_vec_rows)
+                    unsigned nib = valid ? ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) : 0u;
+                    nib <<= 4 * (lane & 7);
+                    nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0xB1, 0xF, 0xF, true);
+                    nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x4E, 0xF, 0xF, true);
+                    nib |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x141, 0xF, 0xF, true);
+                    if (valid && (lane & 7) == 0) p.gate_out[(int64_t)cd * p.gate_out_stride + ((p.gate_out_pix0 + pp) >> 5)] = nib;
+                }
+            }
+        };
         [&]<int... T>(std::integer_sequence<int, T...>) { ((prefetch(T, pa[T], pg[T])), ...); }(std::make_integer_sequence<int, NSET>{});
         __builtin_amdgcn_s_barrier();                                                     // #0
+        unsigned long long e_rows = 0, e_pref = 0, e_bar = 0; (void)e_rows; (void)e_pref; (void)e_bar;
         // phase i: the rows of tile i - 1 (deposited before barrier #(i S)), then the prefetch of tile i - 1 + NSET into the set just freed
         for (int i0 = 0; i0 <= n_mine; i0 += NSET) {
             [&]<int... U>(std::integer_sequence<int, U...>) {
@@ -1232,18 +1319,26 @@ __global__ void __launch_bounds__(512) conv_pw_stream(const I2VConvParams p, con
                     const int i = i0 + u;
                     if (i <= n_mine) {
                         if (i >= 1) {
-                            conv_vec_rows<64, 64, 2, true, false, false>(p, 0, cd0, px_of(i - 1), Cl[(i - 1) & 1], te, pa[set], pg[set], nullptr);
+                            unsigned long long ts = PWS_NOW();
+                            rows(px_of(i - 1), Cl[(i - 1) & 1], pa[set], pg[set]);
+                            PWS_ACC(e_rows, ts); ts = PWS_NOW();
                             prefetch(i - 1 + NSET, pa[set], pg[set]);
+                            PWS_ACC(e_pref, ts);
                         }
                         if (i < n_mine) {
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's reads of the hand-off buffer are done
+                            unsigned long long ts = PWS_NOW();
 #pragma unroll
                             for (int h = 0; h < S; ++h) __builtin_amdgcn_s_barrier();     // #(i S + 1) .. #(i S + S)
+                            PWS_ACC(e_bar, ts);
                         }
                     }
                 }()), ...);
             }(std::make_integer_sequence<int, NSET>{});
         }
+#ifdef I2V_PWS_STAMPS
+        if (te == 0 && blockIdx.x < 256) { g_pws_stamps[8 * blockIdx.x + 2] = e_rows; g_pws_stamps[8 * blockIdx.x + 3] = e_pref; g_pws_stamps[8 * blockIdx.x + 4] = e_bar; }
+#endif
     }
 #endif
 }
@@ -1252,6 +1347,7 @@ __global__ void __launch_bounds__(512) conv_pw_stream(const I2VConvParams p, con
 // count divides the 32 blocks of an XCD, and enough pixel tiles to give every stream a few
 static int conv_pws_grid(const I2VConvParams& p) {           // blocks (one per CU), 0 = not applicable
     if (!p.pointwise || !p.vec_epilogue || p.temporal || p.quad || p.pre_scale || p.gate_scale || p.blk > 1 || p.blkt > 1) return 0;
+    if (p.add1 || p.mask) return 0;                          // (a second addend / an fp32 mask are read inside conv_vec_rows' row loop: not on this kernel's critical path)
     if (p.K != p.Kpad || (p.K != 64 && p.K != 128 && p.K != 256) || p.Cd % 64 != 0 || p.add0_stride > 1 || p.Hs != p.Hg || p.Ws != p.Wg) return 0;
     const int n_cd = p.Cd / 64;
     if (n_cd > 32 || 32 % n_cd != 0) return 0;
@@ -1265,9 +1361,9 @@ static int conv_pws_grid(const I2VConvParams& p) {           // blocks (one per 
 static int launch_conv_pws(const I2VConvParams& p, hipStream_t s) {
     const int grid = conv_pws_grid(p), n_cd = p.Cd / 64, n_streams = grid / n_cd;
     const int n_px = (int)(((int64_t)p.N * p.Hg * p.Wg + 63) / 64);
-    if (p.K == 64) hipLaunchKernelGGL((conv_pw_stream<64>), dim3(grid), dim3(512), 0, s, p, n_cd, n_streams, n_px);
-    else if (p.K == 128) hipLaunchKernelGGL((conv_pw_stream<128>), dim3(grid), dim3(512), 0, s, p, n_cd, n_streams, n_px);
-    else hipLaunchKernelGGL((conv_pw_stream<256>), dim3(grid), dim3(512), 0, s, p, n_cd, n_streams, n_px);
+    if (p.K == 64) hipLaunchKernelGGL((conv_pw_stream<64>), dim3(grid), dim3(I2V_PWS_THREADS), 0, s, p, n_cd, n_streams, n_px);
+    else if (p.K == 128) hipLaunchKernelGGL((conv_pw_stream<128>), dim3(grid), dim3(I2V_PWS_THREADS), 0, s, p, n_cd, n_streams, n_px);
+    else hipLaunchKernelGGL((conv_pw_stream<256>), dim3(grid), dim3(I2V_PWS_THREADS), 0, s, p, n_cd, n_streams, n_px);
     LAUNCH_CHECK("conv_pw_stream");
     return 0;
 }
@@ -1435,8 +1531,11 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
     static const bool no_dc = [] { const char* e = getenv("I2V_DC"); return e && e[0] == '0'; }();
     if (conv_dc_ok(p) && !no_dc) out[n++] = 3 | 64;                          // 64x64 with two chunks per barrier (32-row LDS buffers)
     if (p.Cd <= 16) out[n++] = 5;                        // 16x256 tile on 16x16x4 MFMA fragments
-    static const bool no_pws = [] { const char* e = getenv("I2V_PWS"); return e && e[0] == '0'; }();
-    if (conv_pws_grid(p) && !no_pws) out[n++] = 3 | 256;                      // conv_pw_stream: one persistent role-split workgroup per CU
+    // conv_pw_stream (one persistent role-split workgroup per CU) is built, bit-identical and SLOWER than conv_igemm on every shape it
+    // admits (round 5, tools/pw_stream_probe.cpp, profiles/r5_pw_stream_probe.txt: 56 / 80 / 91 TFLOP/s on 64 -> 256 / 128 -> 512 /
+    // 256 -> 1024 at 128 frames against 69 / 108 / 117): offered to the autotuner only on request (I2V_PWS=1), like the fused pair
+    static const bool want_pws = [] { const char* e = getenv("I2V_PWS"); return e && e[0] == '1'; }();
+    if (want_pws && conv_pws_grid(p)) out[n++] = 3 | 256;
     return n;
 }
 

@@ -11,10 +11,7 @@ confines itself to `threads` of the host's CPUs (slot k takes the k-th group of 
 mean|delta_10|, seconds) -- the npz appears last and atomically (rename), so its presence means the row is complete.
 `--f64_rows` adds the float64 oracle's run of those rows (`{row}-oracle64*`: the yardstick of `oracle/size_parity.py`).
 
-Measured on the GPU box's host (2 x 64 cores, 256 threads): EIGHT workers of 28 threads -- their slots running into the SMT siblings
-of the first ones, beside an unpinned 32-thread oracle in the caller -- took 43 s per clip in aggregate, three times LONGER than one
-32-thread process alone (13.4 s per clip): ATen's convolutions are bound by the memory system long before the host runs out of
-threads.  Hence the default of FOUR workers of 32 threads on the first 128 CPUs (physical cores), and a caller that waits idle.
+How many workers of how many threads: `oracle/size_parity.start_oracle_workers` (one thread each, as many as the host's CPU quota).
 """
 import argparse
 import os
@@ -38,7 +35,7 @@ def pin(slot, threads):
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--rows", required=True, help="comma-separated row indices of the sample list")
+    ap.add_argument("--rows", default="", help="comma-separated row indices of the sample list")
     ap.add_argument("--f64_rows", default="", help="rows to attack with the FLOAT64 oracle as well (the yardstick run; done first)")
     ap.add_argument("--threads", type=int, default=32)
     ap.add_argument("--slot", type=int, default=None)

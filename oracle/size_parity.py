@@ -131,25 +131,54 @@ def compare_sampled(costs, delta, adv, yard, lr=0.005):
             "max_abs_adv_diff_pixel_units": float(un.max())}
 
 
-def start_oracle_workers(rows, out_dir, workers=4, threads=32, steps=10, lr=0.005, extra=(), f64_rows=()):
-    """Start `workers` CPU child processes of `oracle.fooling_worker` over `rows` (dealt round-robin, so the early rows of every worker
-    finish first); returns the Popen objects.  Children of the caller -- never an exec of the caller itself, which may hold the GPU.
-    `f64_rows`: rows whose float64 run the LAST worker does first.  (Four workers of 32 threads: see the worker's docstring.)"""
+def effective_cpus():
+    """CPUs this process may really use at once: the affinity mask capped by the cgroup's CFS quota (the GPU box shows 256 CPUs and
+    grants 16: `cpu.max` = `1600000 100000`)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def start_oracle_workers(rows, out_dir, workers=None, threads=1, steps=10, lr=0.005, extra=(), f64_rows=(), f64_threads=4, pin=False):
+    """Start CPU child processes of `oracle.fooling_worker` over `rows` (dealt round-robin, so the early rows of every worker finish
+    first) and, for `f64_rows`, one more with `f64_threads` threads that runs the float64 oracle on those rows; returns the Popen
+    objects.  Children of the caller -- never an exec of the caller itself, which may hold the GPU.
+    Default: ONE THREAD per worker and as many workers as the host really grants CPUs (`effective_cpus`, minus the float64 worker's).
+    Measured on the GPU box (tools/oracle_scaling_probe.py; 256 CPUs visible, CFS quota 16): seconds per clip with 1 x 32 threads
+    16.0, 2 x 16 11.0, 4 x 8 6.9, 4 x 4 4.8, 8 x 2 4.2, 16 x 1 3.3 -- ATen's convolutions scale poorly over threads, processes do not
+    care; anything beyond the quota is throttled (8 x 28 threads beside a 32-thread caller: 43 s per clip)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncpu = effective_cpus()
+    if workers is None:
+        workers = max(1, (ncpu - (f64_threads if f64_rows else 0)) // max(1, threads))
     workers = max(1, min(workers, len(rows)))
-    threads = max(1, min(threads, ncpu // workers))
-    procs = []
-    for w in range(workers):
-        mine = rows[w::workers]
-        cmd = [sys.executable, "-m", "oracle.fooling_worker", "--rows", ",".join(str(r) for r in mine), "--threads", str(threads), "--slot", str(w),
-               "--out", out_dir, "--steps", str(steps), "--lr", str(lr)] + list(extra)
-        if f64_rows and w == workers - 1:
-            cmd += ["--f64_rows", ",".join(str(r) for r in f64_rows)]
-        procs.append(subprocess.Popen(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))))
+
+    def launch(mine, thr, slot, f64):
+        cmd = [sys.executable, "-m", "oracle.fooling_worker", "--rows", ",".join(str(r) for r in mine), "--threads", str(thr),
+               "--out", out_dir, "--steps", str(steps), "--lr", str(lr)] + (["--slot", str(slot)] if pin else []) + list(extra)
+        if f64:
+            cmd += ["--f64_rows", ",".join(str(r) for r in f64)]
+        return subprocess.Popen(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS=str(thr), MKL_NUM_THREADS=str(thr)))
+
+    procs = [launch(rows[w::workers], threads, w, ()) for w in range(workers)]
+    if f64_rows:
+        procs.append(launch([], max(1, min(f64_threads, ncpu)), workers, list(f64_rows)))
     return procs
 
 

@@ -45,14 +45,12 @@ def eng():
 
 @pytest.fixture(scope="module")
 def oracle_rows(tmp_path_factory):
-    """The fp32 oracle's attacks on rows 0..ROWS-1 and the float64 oracle's on row 0, as CPU child processes: four workers of 32
-    threads on the first 128 CPUs (`oracle/fooling_worker.py` on why not more), started before anything else in this module; the
-    test process itself only waits and drives the GPU meanwhile."""
+    """The fp32 oracle's attacks on rows 0..ROWS-1 and the float64 oracle's on row 0, as CPU child processes: single-thread fp32 workers,
+    as many as the host's CPU quota leaves beside the 4-thread float64 worker (`size_parity.start_oracle_workers` on why: 16 x 1 thread
+    is five times the clips per second of 1 x 32 on the GPU box), started before anything else in this module; the test process itself
+    only waits and drives the GPU meanwhile."""
     out = str(tmp_path_factory.mktemp("oracle_rows"))
-    ncpu = len(os.sched_getaffinity(0))
-    workers = max(1, min(4, ncpu // 32))
-    procs = size_parity.start_oracle_workers(list(range(ROWS)), out, workers=workers, threads=min(32, max(1, ncpu // workers)), steps=STEPS, lr=LR,
-                                             f64_rows=[0])
+    procs = size_parity.start_oracle_workers(list(range(ROWS)), out, steps=STEPS, lr=LR, f64_rows=[0])
     yield out, procs
     for p in procs:
         if p.poll() is None:

@@ -97,6 +97,17 @@ static int run(int N, const Shape& sh, int mode, int nt) {
     printf("%-16s %4d->%4d @%2d^2 N=%d mode %d nt %d | %7.1f us  %6.1f TFLOP/s  %5.2f TB/s | values %s (%zu differ%s) gates %s\n", sh.what, K, Cd, sh.H, N, mode, nt,
            ms * 1e3, flops / ms * 1e-9, bytes / ms * 1e-9, bad ? "MISMATCH" : "bit-identical", bad, bad ? (", first at " + std::to_string(first)).c_str() : "",
            mode == 1 ? "-" : (gbad ? "MISMATCH" : "bit-identical"));
+#ifdef I2V_PWS_STAMPS
+    {   // per-role time of the LAST launch, mean over blocks, per tile: 100 MHz ticks -> us
+        std::vector<unsigned long long> h(256 * 8);
+        hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pws_stamps), h.size() * 8);
+        double a[8] = {0};
+        for (int b = 0; b < 256; ++b) for (int k = 0; k < 8; ++k) a[k] += (double)h[8 * b + k] / 256;
+        const double tiles = (double)((P + 63) / 64) / (256 / (Cd / 64));
+        printf("      per tile (us): matrix loop+deposit %.2f, matrix barrier wait %.2f | epilogue rows %.2f, prefetch issue %.2f, barrier wait %.2f | loader issue %.2f, landing wait %.2f, barrier wait %.2f | tiles per block %.1f\n",
+               a[0] * 0.01 / tiles, a[1] * 0.01 / tiles, a[2] * 0.01 / tiles, a[3] * 0.01 / tiles, a[4] * 0.01 / tiles, a[5] * 0.01 / tiles, a[6] * 0.01 / tiles, a[7] * 0.01 / tiles, tiles);
+    }
+#endif
     hipFree(dw); hipFree(ds); hipFree(dd); hipFree(dr); hipFree(da); hipFree(dsh); hipFree(dg); hipFree(dgo); hipFree(dgr);
     return bad || gbad ? 1 : 0;
 }
