@@ -205,7 +205,7 @@ def test_native_ilaf_against_reference_fixture(eng, name):
 
 
 ILAF_FULL_STEPS = {"slowfast_resnet50": 60, "i3d_resnet50": 3}        # SlowFast: the reference's whole loop (image_attacks.py:502)
-ILAF_TIGHT_STEPS = 12                                                 # free-running steps held to rtol 2e-4
+ILAF_TIGHT_STEPS = 60                                                 # free-running steps held to rtol 2e-4: all of them (measured: <= 1.6e-4)
 
 
 @pytest.mark.parametrize("mt", ["slowfast_resnet50", "i3d_resnet50"])
@@ -213,9 +213,9 @@ def test_native_ilaf_full_size_against_oracle(eng, mt):
     """BASELINE.json configs[4] shape (1 clip of 32 x 224 x 224 per call), SlowFast res2 hooks / the non-local I3D's res3 hook (two
     non-local blocks inside the hooked stage): the native loop against the oracle's restatement run on the torch module (CPU,
     float32), free-running.  Round 5: SlowFast -- configs[4]'s guide -- runs the reference's WHOLE loop, 60 steps
-    (`image_attacks.py:502,579-629`): the cost of each of the first 12 steps within rtol 2e-4, of every later step within 2e-3 (sign
-    steps move every element by +-0.005 whatever its gradient, so two fp32 runs drift apart element by element -- 14 % of the elements
-    differ after 4 steps of the I3D -- while the cost, a mean over millions of them, stays close); the non-local I3D for 3 steps at
+    (`image_attacks.py:502,579-629`): the cost of EVERY one of the 60 steps within rtol 2e-4 (measured: 4e-6 ... 1.6e-4; sign steps
+    move every element by +-0.005 whatever its gradient, so two fp32 runs drift apart element by element -- 3.4 % of the output
+    elements differ after the 60 steps -- while the cost, a mean over millions of them, stays close); the non-local I3D for 3 steps at
     2e-4 (measured: 6e-5, 5e-5, 7e-5, then 7.5e-4 at its fourth step -- its softmax blocks amplify the drift).
     Then a MID-TRAJECTORY TEACHER-FORCED sign step: from the native modifier after those steps, one native step and one float64
     oracle step from the same state -- cost rtol 2e-4, and the update direction `sign(d cost / d modifier)` agreeing on >= 99.9 % of
@@ -252,7 +252,14 @@ def test_native_ilaf_full_size_against_oracle(eng, mt):
     np.testing.assert_allclose(one.last_costs[0], c64[0], rtol=2e-4)
     g_ref = g64[0].permute(1, 0, 2, 3).numpy()                                    # (f, c, h, w)
     step = (m_in - m_out).numpy()                                                 # = 0.005 * sign(d cost / d modifier) * mask
-    well = np.abs(g_ref) >= 5e-2 * np.abs(g_ref).max()
+    # elements sitting ON a clamp boundary after `steps` sign steps (|modifier| = eps, or the perturbed pixel at 0 / 1) are left out: the
+    # inclusive masks decide them on the last bit of eps, and the float64 oracle's eps = 16/255 is not the fp32 one (0.2 % of the
+    # well-conditioned elements at step 60, none at step 3)
+    u_fm = (ori * torch.tensor(gu.STD).view(1, 3, 1, 1, 1) + torch.tensor(gu.MEAN).view(1, 3, 1, 1, 1))[0].permute(1, 0, 2, 3).numpy()
+    m_np, eps = m_in.numpy(), 16 / 255
+    pix = u_fm + np.clip(m_np, -eps, eps)
+    interior = (np.abs(np.abs(m_np) - eps) > 1e-6) & (pix > 1e-6) & (pix < 1 - 1e-6)
+    well = (np.abs(g_ref) >= 5e-2 * np.abs(g_ref).max()) & interior
     agree = np.sign(step)[well] == np.sign(g_ref)[well]
     m_ref = m64[0].permute(1, 0, 2, 3).float().numpy()
     print(f"    teacher-forced step {steps}: cost native {one.last_costs[0]:.6f} f64 oracle {c64[0]:.6f}; well-conditioned elements "
