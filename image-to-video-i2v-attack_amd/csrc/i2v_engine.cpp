@@ -56,6 +56,7 @@ struct Tensor { int buf, c_off, C; bool post_relu; float bwd_gain = 1.f; };   //
 
 struct Packed {               // one implicit-GEMM operand set
     float* wp = nullptr; I2VKEntry* ktab = nullptr;
+    uint16_t* wp3 = nullptr;  // split-bf16 copy of `wp` (I2VConvParams::wp3), only in the bf16x3 math mode
     int K = 0, Kpad = 0, Cd = 0, Cdpad = 0, tap_uniform = 0;
     int halo = 0;           // 9 for a 3x3 / stride-1 / pad-1 packing in (16-channel group, tap, channel) order (kernel MODE 5), else 0
     int ph = 0, pw = 0, Hg = 0, Wg = 0;
@@ -153,6 +154,34 @@ static int upload(Net& n, const std::vector<T>& host, T** dev) {
     return 0;
 }
 
+// Math mode of a plan.  Default: every convolution on fp32-input MFMAs (exact fp32: a k-ordered fmaf chain, the bit-exact rungs of
+// the parity ladder).  I2V_MATH=bf16x3 (opt-in, round 5): launches the split-bf16 K loop admits (conv_bf3_ok) run on three-term bf16
+// operands -- six bf16 MFMAs per 16 K rows in place of eight fp32 ones at twice the cycles, every product term down to 2^-26 of |w||x|
+// kept, fp32 accumulation.  Read when a net is PLANNED (one process may hold plans of both kinds); results of a plan do not depend on
+// the autotuner's tile choices in either mode.
+static bool math_bf16x3() { const char* e = getenv("I2V_MATH"); return e && !strcmp(e, "bf16x3"); }
+
+// w = w1 + w2 + w3 in bf16 (round to nearest even at every level; the residuals are exact in fp32), laid out in the 32x32x16 bf16 MFMA's
+// A-fragment order: [Kpad / 16][Cdpad / 32][term][lane][8]: lane l holds row 32 tile + (l & 31), K rows 16 chunk + 8 (l >> 5) + j.
+static int upload_split_bf16(Net& n, const std::vector<float>& wp, Packed& P) {
+    if (!math_bf16x3() || P.quad || P.Kpad % I2V_KC || P.Cdpad % 32 || P.Kpad == 0) return 0;
+    auto bf = [](float x) { uint32_t u; memcpy(&u, &x, 4); u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u; float y; memcpy(&y, &u, 4); return y; };
+    const int nch = P.Kpad / I2V_KC, nt = P.Cdpad / 32;
+    std::vector<uint16_t> w3((size_t)nch * nt * 3 * 64 * 8);
+    for (int c = 0; c < nch; ++c)
+        for (int t = 0; t < nt; ++t)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    float w = wp[(size_t)(16 * c + 8 * (l >> 5) + j) * P.Cdpad + 32 * t + (l & 31)];
+                    for (int term = 0; term < 3; ++term) {
+                        const float b = bf(w); uint32_t u; memcpy(&u, &b, 4);
+                        w3[((((size_t)c * nt + t) * 3 + term) * 64 + l) * 8 + j] = (uint16_t)(u >> 16);
+                        w -= b;
+                    }
+                }
+    return upload(n, w3, &P.wp3);
+}
+
 static Net* get_net(i2v_handle h, int id) {
     if (!h || id < 0 || id >= (int)h->nets.size() || !h->nets[id]) { fail("bad net id %d", id); return nullptr; }
     return h->nets[id];
@@ -239,7 +268,7 @@ static int pack_fwd(Net& n, Node& nd) {
                         wp[(size_t)k * P.Cdpad + co] = nd.w[((((size_t)co * c.cin + ci) * c.kt + q) * c.kh + r) * c.kw + s];
                 }
     for (const I2VKEntry& e : kt) if (e.valid >> 1) P.has_dt = 1;
-    if (upload(n, wp, &P.wp)) return 1;
+    if (upload(n, wp, &P.wp) || upload_split_bf16(n, wp, P)) return 1;
     return upload(n, kt, &P.ktab);
 }
 
@@ -284,7 +313,7 @@ static int pack_bwd(Net& n, Node& nd) {
                     ++t;
                 }
             for (const I2VKEntry& e : kt) if (e.valid >> 1) P.has_dt = 1;
-            if (upload(n, wp, &P.wp)) return 1;
+            if (upload(n, wp, &P.wp) || upload_split_bf16(n, wp, P)) return 1;
             if (upload(n, kt, &P.ktab)) return 1;
             nd.bwd.push_back(P);
         }
@@ -617,6 +646,7 @@ extern "C" int i2v_net_add_attention(i2v_handle h, int net, const i2v_attn_desc*
 static void conv_common(I2VConvParams& p, const Packed& P) {
     memset(&p, 0, sizeof p);
     p.wp = P.wp; p.ktab = P.ktab; p.K = P.K; p.Kpad = P.Kpad; p.tap_uniform = P.tap_uniform; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
+    p.wp3 = P.wp3; p.bf3 = P.wp3 ? 1 : 0;
     p.add0_stride = 1;
     p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1; p.ot0 = 0; p.oct = 1;
     p.temporal = P.has_dt;      // conv_run adds the frame-mapping half of the condition

@@ -35,10 +35,11 @@ static int hip_fail(hipError_t e, const char* what) {
 #define LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return hip_fail(e_, name); } while (0)
 
 const char* be_name() { return "hip:gfx950"; }
-static long long g_stat_conv = 0, g_stat_pws = 0;      // (relaxed counters: diagnostics only)
+static long long g_stat_conv = 0, g_stat_pws = 0, g_stat_bf3 = 0;      // (relaxed counters: diagnostics only)
 long long be_stat(const char* name) {
     if (!strcmp(name, "conv_launches")) return __atomic_load_n(&g_stat_conv, __ATOMIC_RELAXED);
     if (!strcmp(name, "pws_launches")) return __atomic_load_n(&g_stat_pws, __ATOMIC_RELAXED);
+    if (!strcmp(name, "bf3_launches")) return __atomic_load_n(&g_stat_bf3, __ATOMIC_RELAXED);
     return -1;
 }
 const char* be_error() { return g_be_has_err ? g_be_err : nullptr; }
@@ -161,9 +162,10 @@ static constexpr int conv_waves_per_simd(int BD, int BP, bool PREF, bool hi, int
 // The pointwise variant with prefetched epilogue operands (short K, HBM-bound) stages four chunks instead of two (conv_tile, DEEP)
 static constexpr bool conv_deep(int MODE, bool PREF) { return I2V_DEEP && PREF && MODE == 1; }
 // LDS floats one tile needs: operand staging [NST][KC][BD] + [NST][KC][BP], re-used by the epilogue as a [WD*FR][BP] transpose buffer
-template <int BD, int BP, int WD, bool MF16, int NST = 2, int CPB = 1>
+template <int BD, int BP, int WD, bool MF16, int NST = 2, int CPB = 1, int BF3 = 0>
 constexpr int conv_lds_floats() {
-    constexpr int stage = NST * CPB * I2V_KC * (BD + BP), epi = WD * (MF16 ? 16 : 32) * BP;
+    // (BF3: the weight tile of a chunk is 3 bf16 planes in MFMA-fragment order, 3 KB per 32 rows instead of fp32's 2 KB)
+    constexpr int stage = NST * CPB * (I2V_KC * BP + (BF3 ? (BD / 32) * 768 : I2V_KC * BD)), epi = WD * (MF16 ? 16 : 32) * BP;
     return stage > epi ? stage : epi;
 }
 
@@ -318,7 +320,7 @@ __device__ __forceinline__ void conv_vec_epilogue(const PT& p, ACC (&acc)[BD / W
 // MFMA.  Those are what a block that is alone on its CU (an under-filled launch: a single 32-frame clip leaves the 14x14 layers
 // with 1.5 tiles per CU) cannot hide behind a neighbour.  Costs LDS (64x64: 32 KB, 5 resident blocks), so it is one more
 // configuration of the autotuner (bit 6), for launches whose chunk count is a multiple of CPB.
-template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false, int HWM = 0, int CPB = 1, int FUSE = 0>
+template <int BD, int BP, int WD, int WP, int MODE, bool PREF, bool PRE = false, bool VID = false, bool MF16 = false, int HWM = 0, int CPB = 1, int FUSE = 0, int BF3 = 0>
 __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd_tiles, const int bid, const int nwg, const int64_t px_base,
                                           float* const smem, I2V_PROBE_T& probe, const int probe_slot, const int prio_arg = I2V_PRIO_LEVELS,
                                           float* const mid = nullptr) {
@@ -341,8 +343,14 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     static_assert(!HALO || (HWM > 0 && BD == 64 && BP == 64 && !PREF && !PRE && !VID && !MF16), "halo staging: the plain 64x64 image tile only");
     static_assert(CPB == 1 || (!HALO && !DEEP && !PREF && !PRE && MODE != 4 && MODE != 0), "several chunks per barrier: the plain pointwise / tap-uniform loops only");
     constexpr int KB = CPB * KC;                              // K rows per LDS buffer
-    float (*As)[KB][BD] = reinterpret_cast<float (*)[KB][BD]>(smem);
-    float (*Bs)[KB][BP] = reinterpret_cast<float (*)[KB][BP]>(smem + NST * KB * BD);
+    // BF3 (round 5, "split-bf16" arithmetic): the weights arrive pre-split into three bf16 planes in the 32x32x16 MFMA's own fragment
+    // order (I2VConvParams::wp3: per K chunk and 32-row tile 3 x 64 lanes x 16 bytes), the activations stay fp32 in LDS and are split
+    // in registers when a fragment is read; six bf16 MFMAs per 16 K rows replace eight fp32 ones at twice the cycles each.
+    static_assert(!BF3 || (!MF16 && !PRE && !PREF && !HALO && (MODE == 1 || MODE == 2) && FUSE == 0 && BD % 32 == 0), "split-bf16 K loop: the plain pointwise / tap-uniform tiles");
+    constexpr int AF = BF3 ? CPB * (BD / 32) * 768 : KB * BD;    // floats of weight staging per LDS buffer
+    float (*As)[KB][BD] = reinterpret_cast<float (*)[KB][BD]>(smem);         // (fp32 path)
+    float* const As3 = smem;                                                   // (BF3 path: [NST][CPB][BD / 32][3][64 lanes][4 floats])
+    float (*Bs)[KB][BP] = reinterpret_cast<float (*)[KB][BP]>(smem + NST * AF);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wd = wave / WP, wpx = wave % WP;
@@ -371,14 +379,14 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     // Wave w issues instructions w, w+4, ...; with that assignment a lane always serves ONE pixel column.
     constexpr unsigned OOB = 0x80000000u;                     // >= num_records (spans are kept < 2 GiB)
     const int wv = __builtin_amdgcn_readfirstlane(wave);      // scalar copy: LDS bases / M0 stay in SGPRs
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.wp, 0, p.Kpad * p.Cdpad * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = BF3 ? __builtin_amdgcn_make_buffer_rsrc((void*)p.wp3, 0, (p.Kpad / KC) * (p.Cdpad / 32) * 3072, 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, p.Kpad * p.Cdpad * 4, 0x00020000);
     // MODE 4 reads up to 3 pixels before / 6 behind a row (masked afterwards): the resource starts 64 bytes early and ends 64
     // late -- a lane whose 16 bytes START out of range is zero-filled as a whole, its in-range pixels included -- and every
     // offset carries +64 (the executor keeps that slack around the staged input: Net::in_stage)
     constexpr unsigned XB = QUAD ? 64u : 0u;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src - XB), 0, p.src_span_bytes + 2 * XB, 0x00020000);
-    constexpr int NA = KC * BD / 256, NAQ = (NA + 3) / 4;     // weights: instructions of 256 floats
+    constexpr int NA = BF3 ? (BD / 32) * 3 : KC * BD / 256, NAQ = (NA + 3) / 4;     // weights: instructions of 256 floats (BF3: 1 KB = one plane of a 32-row tile)
     constexpr int BPER = (PW || QUAD) ? 256 : 64;             // activations: 16-byte or 4-byte pieces (floats per instruction)
     constexpr int NB = HALO ? 0 : KC * BP / BPER, NBQ = (NB + 3) / 4;      // MODE 5 stages its activations as halo rows
     const int bcol = PW ? (lane * 4) % BP : (BP >= 64 ? ((wave * 64) % BP) + lane : lane % BP);
@@ -407,7 +415,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
 #pragma unroll
     for (int q = 0; q < NAQ; ++q) {
         const int f = (wave + 4 * q) * 256 + lane * 4;
-        aoff[q] = (unsigned)(((f / BD) * p.Cdpad + f % BD + cd0) * 4);
+        aoff[q] = BF3 ? (unsigned)(((cd0 / 32) * 3 + wave + 4 * q) * 1024 + lane * 16) : (unsigned)(((f / BD) * p.Cdpad + f % BD + cd0) * 4);
     }
     unsigned boff[PW ? NBQ : 1];                              // PW: + row inside the chunk (lane dependent)
     if (PW) {
@@ -426,9 +434,14 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         const int k0 = (k0_);                                                                             \
         if constexpr (jj < NAQ) {                                                                         \
             const int ins = wv + 4 * jj;                                                                  \
-            if (NA % 4 == 0 || ins < NA)                                                                  \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(&As[buf_][(sub_) * KC][0] + ins * 256), 16, aoff[jj],  \
-                                                         k0 * p.Cdpad * 4, 0, 0);                         \
+            if (NA % 4 == 0 || ins < NA) {                                                                \
+                if constexpr (BF3)                                                                        \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(As3 + (buf_) * AF + (sub_) * (BD / 32) * 768 + ins * 256), 16, aoff[jj], \
+                                                             (k0 / KC) * (p.Cdpad / 32) * 3072, 0, 0);   \
+                else                                                                                      \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(&As[buf_][(sub_) * KC][0] + ins * 256), 16, aoff[jj],  \
+                                                             k0 * p.Cdpad * 4, 0, 0);                     \
+            }                                                                                             \
         } else {                                                                                          \
             constexpr int q = jj - NAQ;                                                                   \
             const int ins = wv + 4 * q;                                                                   \
@@ -709,6 +722,67 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
             }
         }
         (void)vb;
+        if constexpr (BF3) {
+            // ---- split-bf16 chunk: per 16 K rows, 3 x TD weight fragments (ds_read_b128, pre-split) and TP activation fragments read as
+            // fp32 (8 values per lane: K rows 8 lk .. 8 lk + 7 of this lane's pixel) and split into three bf16 terms x = x1 + x2 + x3
+            // (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): the residuals are exact in fp32, what is left after x3 is below
+            // 2^-26 |x|).  Products kept: w1 x1, w1 x2, w2 x1, w1 x3, w2 x2, w3 x1 -- everything down to 2^-26 of |w||x|, i.e. below an
+            // fp32 product's own rounding; each bf16 x bf16 product is exact in the MFMA's fp32 accumulation.  Fixed order, small terms
+            // first.  The DMA pieces of the next buffer fill follow the MFMAs one at a time, as in the fp32 loop.
+            typedef short bf8 __attribute__((ext_vector_type(8)));
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            auto split2 = [](const float lo, const float hi, unsigned& p1, unsigned& p2, unsigned& p3) {
+                unsigned a, b, c;
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(a) : "v"(lo), "v"(hi));
+                const float rl = lo - __builtin_bit_cast(float, a << 16), rh = hi - __builtin_bit_cast(float, a & 0xffff0000u);
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(b) : "v"(rl), "v"(rh));
+                const float sl = rl - __builtin_bit_cast(float, b << 16), sh = rh - __builtin_bit_cast(float, b & 0xffff0000u);
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(c) : "v"(sl), "v"(sh));
+                p1 = a; p2 = b; p3 = c;
+            };
+            int piece = 0; (void)piece;
+            [&]<int... SB>(std::integer_sequence<int, SB...>) {
+                (([&] {
+                    constexpr int sub = SB;
+                    bf8 wa[TD][3], xb[TP][3];
+                    const float* const abase = As3 + buf * AF + sub * (BD / 32) * 768 + lane * 4;
+#pragma unroll
+                    for (int i = 0; i < TD; ++i)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            wa[i][pl] = __builtin_bit_cast(bf8, *reinterpret_cast<const f4*>(abase + ((wd * TD + i) * 3 + pl) * 256));
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) {
+                        float x[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = Bs[buf][sub * KC + 8 * lk + e][wpx * (BP / WP) + j * FR + l31];
+                        unsigned q1[4], q2[4], q3[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) split2(x[2 * e], x[2 * e + 1], q1[e], q2[e], q3[e]);
+                        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                        xb[j][0] = __builtin_bit_cast(bf8, (u4){q1[0], q1[1], q1[2], q1[3]});
+                        xb[j][1] = __builtin_bit_cast(bf8, (u4){q2[0], q2[1], q2[2], q2[3]});
+                        xb[j][2] = __builtin_bit_cast(bf8, (u4){q3[0], q3[1], q3[2], q3[3]});
+                    }
+                    // (weight term, activation term) pairs, smallest products first
+                    constexpr int TW[6] = {2, 1, 0, 1, 0, 0}, TX[6] = {0, 1, 2, 0, 1, 0};
+                    [&]<int... M>(std::integer_sequence<int, M...>) {
+                        (([&] {
+                            constexpr int m = M, term = m / (TD * TP), ij = m % (TD * TP), i = ij / TP, j = ij % TP;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][TW[term]], xb[j][TX[term]], acc[i][j], 0, 0, 0);
+                            if constexpr (MORE) {
+                                constexpr int jp = sub * 6 * TD * TP + m;          // one DMA piece behind each of the first CPB * NL MFMAs
+                                if constexpr (jp < CPB * NL) {
+                                    constexpr int sb2 = jp / NL;
+                                    I2V_ISSUE_PIECE_SUB(jp % NL, ((c + AHEAD) * CPB + sb2) * KC, buf ^ 1, vb[sb2], sb2);
+                                }
+                            }
+                        }()), ...);
+                    }(std::make_integer_sequence<int, 6 * TD * TP>{});
+                }()), ...);
+            }(std::make_integer_sequence<int, CPB>{});
+            return;
+        }
         float fa[2][TD], fb[2][TP];
         auto read_frags = [&](const int s, const int set) {
 #pragma unroll
@@ -1059,6 +1133,19 @@ conv_igemm_dc(const I2VConvParams p, const int n_cd_tiles) {
     probe.entry();
     conv_tile<64, 64, 2, 2, MODE, false, false, false, false, 0, CPB>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x);
     probe.exit(blockIdx.x);
+}
+
+// Split-bf16 arithmetic (conv_tile, BF3): the plain pointwise / tap-uniform image tiles on three-term bf16 operands.
+template <int BD, int BP, int WD, int WP, int MODE, int CPB>
+__global__ void __launch_bounds__(256) conv_igemm_bf3(const I2VConvParams p, const int n_cd_tiles) {
+    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<BD, BP, WD, false, 2, CPB, 1>()];
+    I2V_PROBE_T probe;
+    probe.entry();
+    conv_tile<BD, BP, WD, WP, MODE, false, false, false, false, 0, CPB, 0, 1>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x);
+    probe.exit(blockIdx.x);
+}
+static bool conv_bf3_ok(const I2VConvParams& p) {
+    return p.bf3 && p.wp3 && (p.pointwise || p.tap_uniform) && !p.temporal && !p.pre_scale && !p.quad && p.blk <= 1 && p.Cd > 32;
 }
 
 // "Tail split": the first `nA` blocks compute 64x64 tiles over the pixel tiles [0, px_base_b / 64); the remaining blocks cover the
@@ -1413,6 +1500,21 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     const int64_t grid = n_px * n_cd;
     if (grid <= 0) return 0;
     if (grid > 0x7fffffff) { snprintf(g_be_err, sizeof g_be_err, "conv grid too large"); g_be_has_err = true; return 1; }
+    if constexpr (!MF16) {
+        if (conv_bf3_ok(p)) {     // split-bf16 K loop (bit 6 of the configuration: two chunks per barrier)
+            __atomic_fetch_add(&g_stat_bf3, 1, __ATOMIC_RELAXED);
+            const bool two = p.cfg > 0 && ((p.cfg - 1) & 64) && (p.Kpad / I2V_KC) % 2 == 0;
+            if (p.pointwise) {
+                if (two) hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 1, 2>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+                else hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+            } else {
+                if (two) hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 2, 2>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+                else hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 2, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+            }
+            LAUNCH_CHECK("conv_igemm_bf3");
+            return 0;
+        }
+    }
     if (p.quad) {           // "quad rows" stems (MODE 4)
         if (p.pre_scale || (p.quad != 1 && p.quad != 2)) { snprintf(g_be_err, sizeof g_be_err, "bad quad-row launch"); g_be_has_err = true; return 1; }
         if (p.temporal) hipLaunchKernelGGL((conv_igemm<BD, BP, WD, WP, 4, false, false, true, MF16>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
@@ -1485,6 +1587,7 @@ static int conv_pick(const I2VConvParams& p) {
     const char* force = getenv("I2V_FORCE_CFG");     // developer / test knob (only consulted for launches the autotuner did not pin)
     if (force && *force) { const int f = atoi(force); return (p.pre_scale && f != 0 && f != 3) ? 3 : f; }
     if (p.Cd <= 16 && !p.pre_scale) return 5;        // 16-row fragments: no padding rows to speak of
+    if (conv_bf3_ok(p)) return p.Cd > 64 ? 2 : 3;    // (without the autotuner)
     if (conv_wants_prefetch(p)) return 3;
     if (p.pre_scale) {              // pre-activation variants exist for the 128x128 and 64x64 tiles only
         const double blocks128 = ceil(p.Cd / 128.0) * ceil((double)p.N * p.Hg * p.Wg / 128.0);
@@ -1518,6 +1621,15 @@ static int conv_pick(const I2VConvParams& p) {
 int k_conv_candidates(const I2VConvParams& p, int* out) {
     int n = 0;
     if (p.pre_scale) { if (p.Cd > 64) out[n++] = 0; out[n++] = 3; return n; }
+    if (conv_bf3_ok(p)) {          // split-bf16 K loop: the four square-ish tiles, each with one or two chunks per barrier
+        static const int BD3[4] = {128, 64, 128, 64};
+        for (int i = 0; i < 4; ++i) {
+            if (p.Cd <= BD3[i] / 2) continue;
+            out[n++] = i;
+            if ((p.Kpad / I2V_KC) % 2 == 0) out[n++] = i | 64;
+        }
+        return n;
+    }
     static const int BD[5] = {128, 64, 128, 64, 32};
     for (int i = 0; i < 5; ++i) {
         if (BD[i] > 32 && p.Cd <= BD[i] / 2) continue;

@@ -81,6 +81,10 @@ struct I2VConvParams {
     // hardware has no integer divide; the 64-bit software divisions of round 1 cost a block more VALU issue slots than a
     // K = 64 tile spends on its MFMAs)
     uint32_t dv_hw_m, dv_hw_s, dv_w_m, dv_w_s, dv_t_m, dv_t_s, dv_wo_m, dv_wo_s;
+    // Split-bf16 arithmetic (round 5; opt-in, I2V_MATH=bf16x3): `wp3` = the same weights pre-split into three bf16 terms w = w1 + w2 + w3, in
+    // the 32x32x16 bf16 MFMA's fragment order: [Kpad / 16][Cdpad / 32][3 terms][64 lanes][8 bf16] -- lane l of a (chunk, 32-row tile) holds
+    // rows cd = 32 tile + (l & 31), K rows 16 chunk + 8 (l >> 5) .. + 7.  bf3 != 0: the launch's K loop runs on it (conv_tile, BF3).
+    const void* wp3; int32_t bf3;
     int32_t cfg;            // 0: pick the tile configuration with the cost model; c+1: use configuration c (autotuned; bit 3 of c = no epilogue-operand prefetch)
 };
 

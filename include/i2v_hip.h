@@ -38,7 +38,8 @@ int i2v_abi_version(void);
  * the HIP build.) */
 const char* i2v_backend(void);
 /* Launch counters of the kernel backend since the library was loaded: "conv_launches" (every conv_igemm-family launch),
- * "pws_launches" (of those, the persistent role-split pointwise kernel conv_pw_stream), anything else -1.  Diagnostics for the
+ * "pws_launches" (of those, the persistent role-split pointwise kernel conv_pw_stream), "bf3_launches" (of those, launches on the
+ * split-bf16 K loop of the opt-in I2V_MATH=bf16x3 mode), anything else -1.  Diagnostics for the
  * tests (a forced configuration must really have run); results never depend on it.  No counterpart in the reference. */
 long long i2v_backend_stat(const char* name);
 

@@ -96,7 +96,29 @@ static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
     p.pointwise = (k == 1 && st == 1 && (H * H) % 4 == 0 && !getenv("CMB_NOPW")); p.tap_uniform = tu;
     p.vec_epilogue = ((Ho * Ho) % 4 == 0);
     p.cfg = cfg + 1;
+    void* dw3 = nullptr;
+    if (getenv("CMB_BF3") && !quad) {      // split-bf16 arithmetic: three bf16 terms per weight in the 32x32x16 MFMA's fragment order
+        auto bf = [](float x) { unsigned u; memcpy(&u, &x, 4); u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u; float y; memcpy(&y, &u, 4); return y; };
+        std::vector<uint16_t> w3((size_t)(Kpad / 16) * (Cdpad / 32) * 3 * 64 * 8);
+        for (int c = 0; c < Kpad / 16; ++c) for (int t = 0; t < Cdpad / 32; ++t) for (int l = 0; l < 64; ++l) for (int j = 0; j < 8; ++j) {
+            float w = wp[(size_t)(16 * c + 8 * (l >> 5) + j) * Cdpad + 32 * t + (l & 31)];
+            for (int term = 0; term < 3; ++term) {
+                const float b = bf(w); unsigned u; memcpy(&u, &b, 4);
+                w3[((((size_t)c * (Cdpad / 32) + t) * 3 + term) * 64 + l) * 8 + j] = (uint16_t)(u >> 16);
+                w -= b;
+            }
+        }
+        hipMalloc(&dw3, w3.size() * 2); hipMemcpy(dw3, w3.data(), w3.size() * 2, hipMemcpyHostToDevice);
+        p.wp3 = dw3; p.bf3 = 1;
+    }
     if (tu && k == 3 && st == 1) p.halo = 9;      // the K order above is (16-channel group, tap, channel): I2V_FORCE_CFG=19 (3 | 16) runs MODE 5
+    if (getenv("CMB_CHECK") && p.bf3) {    // split-bf16 result against the fp32-MFMA result of the same launch: max |diff| / max |value|
+        std::vector<float> r3(outn), r1(outn);
+        k_conv(p, nullptr); hipDeviceSynchronize(); hipMemcpy(r3.data(), dd, outn * 4, hipMemcpyDeviceToHost);
+        I2VConvParams q = p; q.bf3 = 0; k_conv(q, nullptr); hipDeviceSynchronize(); hipMemcpy(r1.data(), dd, outn * 4, hipMemcpyDeviceToHost);
+        double md = 0, mv = 0, sd = 0; for (size_t i = 0; i < outn; ++i) { md = std::max(md, (double)fabsf(r3[i] - r1[i])); mv = std::max(mv, (double)fabsf(r1[i])); sd += fabs((double)r3[i] - r1[i]); }
+        printf("   [split-bf16 vs fp32 MFMA: max|diff| %.3e, mean|diff| %.3e, max|value| %.3e -> relative %.2e]\n", md, sd / outn, mv, md / mv);
+    }
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     // steady state: the chip's clock takes milliseconds to settle after an idle period (a 3 ms measurement right after the host
     // prepared the operands read 1.8-1.9 GHz where a long run holds 2.2): >= CMB_WARM_MS (default 80) ms of back-to-back
@@ -146,7 +168,7 @@ static double run(int N, const Shape& sh, int cfg, int iters, int with_epi) {
         static std::vector<unsigned long long> z(NW, 0); hipMemcpyToSymbol(HIP_SYMBOL(g_xclk), z.data(), NW * 8);
     }
 #endif
-    hipFree(dw); hipFree(ds - 64); hipFree(dd); hipFree(da); hipFree(dk); hipEventDestroy(a); hipEventDestroy(b);
+    if (dw3) hipFree(dw3); hipFree(dw); hipFree(ds - 64); hipFree(dd); hipFree(da); hipFree(dk); hipEventDestroy(a); hipEventDestroy(b);
     if (be_error()) { printf("ERROR %s\n", be_error()); exit(1); }
     return 2.0 * N * Ho * Ho * (double)Cout * (k * k * Cin) / ms * 1e-9;      // algorithmic flops (not the padded quad rows)
 }
