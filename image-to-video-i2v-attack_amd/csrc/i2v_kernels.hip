@@ -139,6 +139,9 @@ __device__ __forceinline__ I2VKEntry load_kentry(const I2VKEntry* tab, int k) {
 #ifndef I2V_DEEP_STAGES      // LDS buffers of that loop: 3 = two chunks ahead at the two-buffer loop's residency (24 KB, 6 blocks)
 #define I2V_DEEP_STAGES 3
 #endif
+#ifndef I2V_BF3_STAGES       // LDS buffers of the split-bf16 loop (conv_tile, BF3 == 1): chunks in flight = stages - 1.  Measured (tools/bf3_sweep.sh,
+#define I2V_BF3_STAGES 2     // profiles/r5_split_bf16.txt): 3 and 4 buffers change nothing on the 128x128 tile and cost the smaller tiles a resident block
+#endif
 #ifndef I2V_SMALL_WPE
 #define I2V_SMALL_WPE 7
 #endif
@@ -165,7 +168,8 @@ static constexpr bool conv_deep(int MODE, bool PREF) { return I2V_DEEP && PREF &
 template <int BD, int BP, int WD, bool MF16, int NST = 2, int CPB = 1, int BF3 = 0>
 constexpr int conv_lds_floats() {
     // (BF3: the weight tile of a chunk is 3 bf16 planes in MFMA-fragment order, 3 KB per 32 rows instead of fp32's 2 KB)
-    constexpr int stage = NST * CPB * (I2V_KC * BP + (BF3 ? (BD / 32) * 768 : I2V_KC * BD)), epi = WD * (MF16 ? 16 : 32) * BP;
+    // (BF3 == 1: (BD / 32) * 3 one-KB pieces per chunk, rounded up to a multiple of 4 so that every wave issues the same number; BF3 == 2: weights never enter LDS)
+    constexpr int stage = NST * CPB * (I2V_KC * BP + (BF3 == 2 ? 0 : BF3 ? ((BD / 32) * 3 + 3) / 4 * 4 * 256 : I2V_KC * BD)), epi = WD * (MF16 ? 16 : 32) * BP;
     return stage > epi ? stage : epi;
 }
 
@@ -334,8 +338,10 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     // [WD*32][BP] transpose buffer
     // LDS operand buffers: chunk c is consumed while chunk c+1 is in flight -- or, for the short-K HBM-bound pointwise launches
     // (DEEP, see the main loop), while chunks c+1 .. c+3 are
-    constexpr bool DEEP = conv_deep(MODE, PREF);
-    constexpr int NST = DEEP ? I2V_DEEP_STAGES : 2, AHEAD = NST - 1;
+    // ... and the split-bf16 loop with staged weights (BF3 == 1), whose chunks last 6 x 32 cycles per fragment pair instead of 8 x 64: one
+    // chunk of look-ahead no longer covers an L2 round trip
+    constexpr bool DEEP = conv_deep(MODE, PREF) || (BF3 == 1 && I2V_BF3_STAGES > 2);
+    constexpr int NST = BF3 == 1 ? I2V_BF3_STAGES : DEEP ? I2V_DEEP_STAGES : 2, AHEAD = NST - 1;
     // MODE 5 ("halo"): a 3x3 / stride-1 / pad-1 launch on planes exactly HWM wide stages, per 16-channel group, ONE halo row per
     // channel -- the tile's 64 pixels plus a source row and a pixel on either side -- instead of nine shifted copies of the tile
     constexpr bool HALO = MODE == 5;
@@ -347,7 +353,12 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     // order (I2VConvParams::wp3: per K chunk and 32-row tile 3 x 64 lanes x 16 bytes), the activations stay fp32 in LDS and are split
     // in registers when a fragment is read; six bf16 MFMAs per 16 K rows replace eight fp32 ones at twice the cycles each.
     static_assert(!BF3 || (!MF16 && !PRE && !PREF && !HALO && (MODE == 1 || MODE == 2) && FUSE == 0 && BD % 32 == 0), "split-bf16 K loop: the plain pointwise / tap-uniform tiles");
-    constexpr int AF = BF3 ? CPB * (BD / 32) * 768 : KB * BD;    // floats of weight staging per LDS buffer
+    // BF3 == 2: the weight fragments do not go through LDS at all -- they are already in fragment order in memory, so every wave loads
+    // its own (16 bytes per lane and term, coalesced 1 KB per load, served by L1 / L2 for the waves that share rows) one chunk ahead into
+    // registers.  The LDS-DMA instruction stream of a chunk then carries only the activations: with A staged (BF3 == 1) a 128x64 tile
+    // issued 12 weight pieces + 4 activation pieces per 48 MFMAs, and a bf16 MFMA lasts 32 cycles where a DMA piece costs its wave
+    // 60-185 to issue -- the loop was bound by DMA issue (matrix pipe 41 % busy on the layer3 3x3 shape).
+    constexpr int AF = BF3 == 2 ? 0 : BF3 ? CPB * (((BD / 32) * 3 + 3) / 4 * 4) * 256 : KB * BD;    // floats of weight staging per LDS buffer
     float (*As)[KB][BD] = reinterpret_cast<float (*)[KB][BD]>(smem);         // (fp32 path)
     float* const As3 = smem;                                                   // (BF3 path: [NST][CPB][BD / 32][3][64 lanes][4 floats])
     float (*Bs)[KB][BP] = reinterpret_cast<float (*)[KB][BP]>(smem + NST * AF);
@@ -386,7 +397,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     // offset carries +64 (the executor keeps that slack around the staged input: Net::in_stage)
     constexpr unsigned XB = QUAD ? 64u : 0u;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src - XB), 0, p.src_span_bytes + 2 * XB, 0x00020000);
-    constexpr int NA = BF3 ? (BD / 32) * 3 : KC * BD / 256, NAQ = (NA + 3) / 4;     // weights: instructions of 256 floats (BF3: 1 KB = one plane of a 32-row tile)
+    constexpr int NA = BF3 == 2 ? 0 : BF3 ? (BD / 32) * 3 : KC * BD / 256, NAQ = (NA + 3) / 4;     // weights: instructions of 256 floats (BF3 == 1: 1 KB = one plane of a 32-row tile)
     constexpr int BPER = (PW || QUAD) ? 256 : 64;             // activations: 16-byte or 4-byte pieces (floats per instruction)
     constexpr int NB = HALO ? 0 : KC * BP / BPER, NBQ = (NB + 3) / 4;      // MODE 5 stages its activations as halo rows
     const int bcol = PW ? (lane * 4) % BP : (BP >= 64 ? ((wave * 64) % BP) + lane : lane % BP);
@@ -411,7 +422,7 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         xoff = (unsigned)((pns * p.src_nstride + (int64_t)h0 * p.Ws + w0) * 4) + XB;
     }
     if (!pvalid) xoff = OOB;
-    unsigned aoff[NAQ];
+    unsigned aoff[NAQ ? NAQ : 1];
 #pragma unroll
     for (int q = 0; q < NAQ; ++q) {
         const int f = (wave + 4 * q) * 256 + lane * 4;
@@ -434,10 +445,12 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         const int k0 = (k0_);                                                                             \
         if constexpr (jj < NAQ) {                                                                         \
             const int ins = wv + 4 * jj;                                                                  \
-            if (NA % 4 == 0 || ins < NA) {                                                                \
-                if constexpr (BF3)                                                                        \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(As3 + (buf_) * AF + (sub_) * (BD / 32) * 768 + ins * 256), 16, aoff[jj], \
-                                                             (k0 / KC) * (p.Cdpad / 32) * 3072, 0, 0);   \
+            if constexpr (BF3) {   /* every wave issues NAQ pieces (the wait at the top of a chunk counts them): a piece beyond the tile's reads nothing */ \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(As3 + (buf_) * AF + (sub_) * (AF / CPB) + ins * 256), 16, ins < NA ? aoff[jj] : OOB, \
+                                                         (k0 / KC) * (p.Cdpad / 32) * 3072, 0, 0);       \
+            } else if (NA % 4 == 0 || ins < NA) {                                                         \
+                if constexpr (false)                                                                      \
+                    ;                                                                                     \
                 else                                                                                      \
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(&As[buf_][(sub_) * KC][0] + ins * 256), 16, aoff[jj],  \
                                                              k0 * p.Cdpad * 4, 0, 0);                     \
@@ -511,6 +524,24 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     }
 
     probe.loop_begin();
+    typedef short bf8 __attribute__((ext_vector_type(8)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int TD_ = BD / WD / (MF16 ? 16 : 32);
+    bf8 wcur[BF3 == 2 ? CPB : 1][BF3 == 2 ? TD_ : 1][3];      // BF3 == 2: this wave's weight fragments of the current buffer fill
+    const char* const w3lane = BF3 ? (const char*)p.wp3 + (size_t)lane * 16 + (size_t)(cd0 / 32 + (wave / WP) * TD_) * 3072 : nullptr;
+    const size_t w3chunk = BF3 ? (size_t)(p.Cdpad / 32) * 3072 : 0;          // bytes of one K chunk of wp3
+    auto load_w3 = [&](const int chunk, const int i, const int pl) {
+        return __builtin_bit_cast(bf8, *reinterpret_cast<const f4*>(w3lane + (size_t)chunk * w3chunk + (i * 3 + pl) * 1024));
+    };
+    if constexpr (BF3 == 2) {
+#pragma unroll
+        for (int sb = 0; sb < CPB; ++sb)
+#pragma unroll
+            for (int i = 0; i < TD_; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wcur[sb][i][pl] = load_w3(sb, i, pl);
+    }
+    (void)wcur; (void)w3lane; (void)w3chunk;
     typedef typename std::conditional<MF16, f32x4, f32x16>::type acc_t;
     acc_t acc[TD][TP];
 #pragma unroll
@@ -661,10 +692,16 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
 #pragma unroll
             for (int h = 0; h < CPB; ++h) { const I2VKEntry e0 = load_kentry(p.ktab, h * KC); vb0[h] = I2V_CHUNK_VB(e0); }
 #pragma unroll
-            for (int h = 0; h < CPB; ++h) e_next[h] = load_kentry(p.ktab, (nsuper > 1 ? CPB + h : h) * KC);
+            for (int h = 0; h < CPB; ++h) e_next[h] = load_kentry(p.ktab, (nsuper > AHEAD ? AHEAD * CPB + h : h) * KC);      // the rows of fill AHEAD (issued in iteration 0)
         }
         (void)vb0;
         for (int c0 = 0; c0 < AHEAD && c0 < nsuper; ++c0) {
+            if constexpr (MODE == 2 && AHEAD > 1) {      // (deeper look-ahead: every prologue fill has its own tap)
+                if (c0 > 0) {
+#pragma unroll
+                    for (int h = 0; h < CPB; ++h) { const I2VKEntry e0 = load_kentry(p.ktab, (c0 * CPB + h) * KC); vb0[h] = I2V_CHUNK_VB(e0); }
+                }
+            }
             [&]<int... J>(std::integer_sequence<int, J...>) {
                 (([&] { constexpr int sub = J / NL; I2V_ISSUE_PIECE_SUB(J % NL, (c0 * CPB + sub) * KC, c0, vb0[sub], sub); }()), ...);
             }(std::make_integer_sequence<int, CPB * NL>{});
@@ -714,10 +751,10 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
         for (int h = 0; h < CPB; ++h) vb[h] = OOB;
         if constexpr (MORE && MODE == 2) {
 #pragma unroll
-            for (int h = 0; h < CPB; ++h) vb[h] = I2V_CHUNK_VB(e_next[h]);      // taps of the next fill's chunks (rows fetched last iteration)
+            for (int h = 0; h < CPB; ++h) vb[h] = I2V_CHUNK_VB(e_next[h]);      // taps of the fill issued now, c + AHEAD (rows fetched last iteration)
 #pragma unroll
             for (int h = 0; h < CPB; ++h) {
-                const int c2 = (c + 2) * CPB + h < nchunks ? (c + 2) * CPB + h : nchunks - 1;
+                const int c2 = (c + AHEAD + 1) * CPB + h < nchunks ? (c + AHEAD + 1) * CPB + h : nchunks - 1;
                 e_next[h] = load_kentry(p.ktab, c2 * KC);                       // prefetch the rows of the fill after that
             }
         }
@@ -729,8 +766,6 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
             // 2^-26 |x|).  Products kept: w1 x1, w1 x2, w2 x1, w1 x3, w2 x2, w3 x1 -- everything down to 2^-26 of |w||x|, i.e. below an
             // fp32 product's own rounding; each bf16 x bf16 product is exact in the MFMA's fp32 accumulation.  Fixed order, small terms
             // first.  The DMA pieces of the next buffer fill follow the MFMAs one at a time, as in the fp32 loop.
-            typedef short bf8 __attribute__((ext_vector_type(8)));
-            typedef float f4 __attribute__((ext_vector_type(4)));
             auto split2 = [](const float lo, const float hi, unsigned& p1, unsigned& p2, unsigned& p3) {
                 unsigned a, b, c;
                 asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(a) : "v"(lo), "v"(hi));
@@ -740,17 +775,33 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
                 asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(c) : "v"(sl), "v"(sh));
                 p1 = a; p2 = b; p3 = c;
             };
-            int piece = 0; (void)piece;
+            bf8 wnxt[BF3 == 2 ? CPB : 1][BF3 == 2 ? TD : 1][3];      // the next buffer fill's weight fragments, in flight during this one's MFMAs
+            if constexpr (BF3 == 2 && MORE) {
+#pragma unroll
+                for (int sb = 0; sb < CPB; ++sb)
+#pragma unroll
+                    for (int i = 0; i < TD; ++i)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) wnxt[sb][i][pl] = load_w3((c + 1) * CPB + sb, i, pl);
+            }
+            (void)wnxt;
             [&]<int... SB>(std::integer_sequence<int, SB...>) {
                 (([&] {
                     constexpr int sub = SB;
                     bf8 wa[TD][3], xb[TP][3];
-                    const float* const abase = As3 + buf * AF + sub * (BD / 32) * 768 + lane * 4;
+                    if constexpr (BF3 == 2) {
 #pragma unroll
-                    for (int i = 0; i < TD; ++i)
+                        for (int i = 0; i < TD; ++i)
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl)
-                            wa[i][pl] = __builtin_bit_cast(bf8, *reinterpret_cast<const f4*>(abase + ((wd * TD + i) * 3 + pl) * 256));
+                            for (int pl = 0; pl < 3; ++pl) wa[i][pl] = wcur[sub][i][pl];
+                    } else {
+                        const float* const abase = As3 + buf * AF + sub * (AF / CPB) + lane * 4;
+#pragma unroll
+                        for (int i = 0; i < TD; ++i)
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl)
+                                wa[i][pl] = __builtin_bit_cast(bf8, *reinterpret_cast<const f4*>(abase + ((wd * TD + i) * 3 + pl) * 256));
+                    }
 #pragma unroll
                     for (int j = 0; j < TP; ++j) {
                         float x[8];
@@ -774,13 +825,21 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
                                 constexpr int jp = sub * 6 * TD * TP + m;          // one DMA piece behind each of the first CPB * NL MFMAs
                                 if constexpr (jp < CPB * NL) {
                                     constexpr int sb2 = jp / NL;
-                                    I2V_ISSUE_PIECE_SUB(jp % NL, ((c + AHEAD) * CPB + sb2) * KC, buf ^ 1, vb[sb2], sb2);
+                                    I2V_ISSUE_PIECE_SUB(jp % NL, ((c + AHEAD) * CPB + sb2) * KC, (buf + AHEAD) % NST, vb[sb2], sb2);
                                 }
                             }
                         }()), ...);
                     }(std::make_integer_sequence<int, 6 * TD * TP>{});
                 }()), ...);
             }(std::make_integer_sequence<int, CPB>{});
+            if constexpr (BF3 == 2 && MORE) {
+#pragma unroll
+                for (int sb = 0; sb < CPB; ++sb)
+#pragma unroll
+                    for (int i = 0; i < TD; ++i)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) wcur[sb][i][pl] = wnxt[sb][i][pl];
+            }
             return;
         }
         float fa[2][TD], fb[2][TP];
@@ -1136,12 +1195,15 @@ conv_igemm_dc(const I2VConvParams p, const int n_cd_tiles) {
 }
 
 // Split-bf16 arithmetic (conv_tile, BF3): the plain pointwise / tap-uniform image tiles on three-term bf16 operands.
+#ifndef I2V_BF3_VARIANT
+#define I2V_BF3_VARIANT 1        // 1: weight fragments staged through LDS by DMA, I2V_BF3_STAGES buffers; 2: loaded straight into registers, one chunk ahead
+#endif
 template <int BD, int BP, int WD, int WP, int MODE, int CPB>
 __global__ void __launch_bounds__(256) conv_igemm_bf3(const I2VConvParams p, const int n_cd_tiles) {
-    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<BD, BP, WD, false, 2, CPB, 1>()];
+    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<BD, BP, WD, false, I2V_BF3_VARIANT == 1 ? I2V_BF3_STAGES : 2, CPB, I2V_BF3_VARIANT>()];
     I2V_PROBE_T probe;
     probe.entry();
-    conv_tile<BD, BP, WD, WP, MODE, false, false, false, false, 0, CPB, 0, 1>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x);
+    conv_tile<BD, BP, WD, WP, MODE, false, false, false, false, 0, CPB, 0, I2V_BF3_VARIANT>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x);
     probe.exit(blockIdx.x);
 }
 static bool conv_bf3_ok(const I2VConvParams& p) {
@@ -1503,13 +1565,24 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     if constexpr (!MF16) {
         if (conv_bf3_ok(p)) {     // split-bf16 K loop (bit 6 of the configuration: two chunks per barrier)
             __atomic_fetch_add(&g_stat_bf3, 1, __ATOMIC_RELAXED);
-            const bool two = p.cfg > 0 && ((p.cfg - 1) & 64) && (p.Kpad / I2V_KC) % 2 == 0;
+            const bool two = I2V_BF3_VARIANT != 1 && p.cfg > 0 && ((p.cfg - 1) & 64) && (p.Kpad / I2V_KC) % 2 == 0;      // (the deep-staged variant synchronises per chunk)
+            // The loop is bound by VALU issue -- splitting an activation fragment costs 44 vector instructions, and a bf16 MFMA hides about
+            // five --, so the 128x128 tile puts its four waves SIDE BY SIDE along the pixels (each 128 rows x 32 pixels): one activation
+            // fragment split per 24 MFMAs instead of two, the four weight fragments are plain 16-byte LDS reads.
+            if constexpr (BD == 128 && BP == 128 && WD == 2) {
+                if (!getenv("I2V_BF3_SQUARE")) {
+                    if (p.pointwise) hipLaunchKernelGGL((conv_igemm_bf3<128, 128, 1, 4, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+                    else hipLaunchKernelGGL((conv_igemm_bf3<128, 128, 1, 4, 2, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+                    LAUNCH_CHECK("conv_igemm_bf3");
+                    return 0;
+                }
+            }
             if (p.pointwise) {
-                if (two) hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 1, 2>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
-                else hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+                if constexpr (I2V_BF3_VARIANT != 1) { if (two) { hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 1, I2V_BF3_VARIANT != 1 ? 2 : 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd); LAUNCH_CHECK("conv_igemm_bf3"); return 0; } }
+                hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
             } else {
-                if (two) hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 2, 2>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
-                else hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 2, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+                if constexpr (I2V_BF3_VARIANT != 1) { if (two) { hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 2, I2V_BF3_VARIANT != 1 ? 2 : 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd); LAUNCH_CHECK("conv_igemm_bf3"); return 0; } }
+                hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 2, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
             }
             LAUNCH_CHECK("conv_igemm_bf3");
             return 0;
@@ -1626,7 +1699,7 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
         for (int i = 0; i < 4; ++i) {
             if (p.Cd <= BD3[i] / 2) continue;
             out[n++] = i;
-            if ((p.Kpad / I2V_KC) % 2 == 0) out[n++] = i | 64;
+            if (I2V_BF3_VARIANT != 1 && (p.Kpad / I2V_KC) % 2 == 0) out[n++] = i | 64;
         }
         return n;
     }
