@@ -59,7 +59,7 @@ def build_id():
     return h.hexdigest()[:16]
 
 
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r4_traffic_by_instantiation.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r5_traffic_by_instantiation.json")
 PMC_MFMA_BUSY = None      # MFMA-busy fraction of the conv launches from the same PMC summary (same build-id rule as the traffic)
 
 
@@ -72,7 +72,7 @@ def measured_traffic():
         with open(TRAFFIC_JSON) as fh:
             t = json.load(fh)
         if t.get("build_id") != build_id():
-            return None, f"profiles/r4_traffic_by_instantiation.json is from build {t.get('build_id')}, running {build_id()}"
+            return None, f"profiles/r5_traffic_by_instantiation.json is from build {t.get('build_id')}, running {build_id()}"
         global PMC_MFMA_BUSY
         PMC_MFMA_BUSY = t["conv_igemm"].get("mfma_busy_frac")
         return round(t["conv_igemm"]["hbm_bytes_per_launch"]), None
@@ -560,6 +560,8 @@ def run_rank(args):
         "config": {"workload": f"I2V ResNet-50 layer3, batch={b} synthetic 32-frame 224^2 clips per GPU, "
                                f"{ATTACK_STEPS} steps eps=16/255 lr=0.005 (BASELINE.json configs[1])",
                    "frames_per_gpu": b * FRAMES, "attack_steps": ATTACK_STEPS, "weights": "seeded synthetic (seed 0)",
+                   "math": ("fp32-input MFMA (exact fp32: the default)" if os.environ.get("I2V_MATH", "") != "bf16x3" else
+                            "NOT THE DEFAULT: the caller set I2V_MATH=bf16x3 (split-bf16 operands, fp32 accumulation) for the whole run"),
                    "parallelism": f"clips sharded over {world} GPU(s), no collective"},
         "end_to_end_tflops_per_gpu": round(value / world * flop_per_frame / 1e12, 2),
         "algorithmic_gflop_per_frame": round(flop_per_frame / 1e9, 2),
@@ -574,6 +576,8 @@ def run_rank(args):
                                             "backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend()}
     if args.share_device:
         out["metric"] = "FUNCTIONAL CHECK (all ranks share device 0, not a measurement): " + out["metric"]
+    if os.environ.get("I2V_MATH", "") == "bf16x3":
+        out["metric"] = "OPT-IN MATH MODE I2V_MATH=bf16x3 (not the headline configuration): " + out["metric"]
     if kt is not None and kt["conv_igemm_fwd"]["launches"]:
         # every instantiation of conv_igemm: backbone fwd + dgrad, and the class-packed image gradient
         parts = ("conv_igemm_fwd", "conv_igemm_dgrad", "conv_igemm_imggrad")
@@ -594,7 +598,7 @@ def run_rank(args):
                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                            "traffic": traffic,
-                           "traffic_unit": "B per launch (rocprofv3 PMC passes of this build: 2*FETCH_SIZE + WRITE_SIZE, profiles/r4_traffic_by_instantiation.json)",
+                           "traffic_unit": "B per launch (rocprofv3 PMC passes of this build: 2*FETCH_SIZE + WRITE_SIZE, profiles/r5_traffic_by_instantiation.json)",
                            "launches": int(c["launches"]), "avg_launch_us": round(1e3 * c["ms"] / c["launches"], 2),
                            "avg_gflop_per_launch": round(c["flops"] / c["launches"] / 1e9, 3),
                            "algorithmic_bytes_per_launch": round(c["bytes"] / c["launches"]),
@@ -657,7 +661,7 @@ def run_rank(args):
     # AFTER and APART from the headline: a fresh attack object planned in that mode, the same K steps un-instrumented, and its own parity
     # check against the committed float64 run.  `value` above is the default exact-fp32 path and stays so.
     split = None
-    if args.workload == "i2v" and not args.no_split_bf16 and timing and world == 1:
+    if args.workload == "i2v" and not args.no_split_bf16 and timing and world == 1 and os.environ.get("I2V_MATH", "") != "bf16x3":
         os.environ["I2V_MATH"] = "bf16x3"
         try:
             atk3 = attacks.ImageGuidedFMDirection_Adam([MODEL], depth=DEPTH, step_size=0.005, steps=ATTACK_STEPS, engine=eng, weight_seed=0)

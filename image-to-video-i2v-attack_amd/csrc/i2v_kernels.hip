@@ -1198,16 +1198,16 @@ conv_igemm_dc(const I2VConvParams p, const int n_cd_tiles) {
 #ifndef I2V_BF3_VARIANT
 #define I2V_BF3_VARIANT 1        // 1: weight fragments staged through LDS by DMA, I2V_BF3_STAGES buffers; 2: loaded straight into registers, one chunk ahead
 #endif
-template <int BD, int BP, int WD, int WP, int MODE, int CPB>
+template <int BD, int BP, int WD, int WP, int MODE, int CPB, bool VID = false>
 __global__ void __launch_bounds__(256) conv_igemm_bf3(const I2VConvParams p, const int n_cd_tiles) {
     __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<BD, BP, WD, false, I2V_BF3_VARIANT == 1 ? I2V_BF3_STAGES : 2, CPB, I2V_BF3_VARIANT>()];
     I2V_PROBE_T probe;
     probe.entry();
-    conv_tile<BD, BP, WD, WP, MODE, false, false, false, false, 0, CPB, 0, I2V_BF3_VARIANT>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x);
+    conv_tile<BD, BP, WD, WP, MODE, false, false, VID, false, 0, CPB, 0, I2V_BF3_VARIANT>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x);
     probe.exit(blockIdx.x);
 }
-static bool conv_bf3_ok(const I2VConvParams& p) {
-    return p.bf3 && p.wp3 && (p.pointwise || p.tap_uniform) && !p.temporal && !p.pre_scale && !p.quad && p.blk <= 1 && p.Cd > 32;
+static bool conv_bf3_ok(const I2VConvParams& p) {      // (temporal launches -- video networks' k x 1 x 1 and strided convolutions -- only as tap-uniform ones: the staging of MODE 2, VID)
+    return p.bf3 && p.wp3 && (p.pointwise || p.tap_uniform) && (!p.temporal || p.tap_uniform) && !p.pre_scale && !p.quad && p.blk <= 1 && p.blkt <= 1 && p.Cd > 32;
 }
 
 // "Tail split": the first `nA` blocks compute 64x64 tiles over the pixel tiles [0, px_base_b / 64); the remaining blocks cover the
@@ -1570,12 +1570,17 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
             // five --, so the 128x128 tile puts its four waves SIDE BY SIDE along the pixels (each 128 rows x 32 pixels): one activation
             // fragment split per 24 MFMAs instead of two, the four weight fragments are plain 16-byte LDS reads.
             if constexpr (BD == 128 && BP == 128 && WD == 2) {
-                if (!getenv("I2V_BF3_SQUARE")) {
+                if (!p.temporal && !getenv("I2V_BF3_SQUARE")) {
                     if (p.pointwise) hipLaunchKernelGGL((conv_igemm_bf3<128, 128, 1, 4, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
                     else hipLaunchKernelGGL((conv_igemm_bf3<128, 128, 1, 4, 2, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
                     LAUNCH_CHECK("conv_igemm_bf3");
                     return 0;
                 }
+            }
+            if (p.temporal) {
+                hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 2, 1, true>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+                LAUNCH_CHECK("conv_igemm_bf3");
+                return 0;
             }
             if (p.pointwise) {
                 if constexpr (I2V_BF3_VARIANT != 1) { if (two) { hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 1, I2V_BF3_VARIANT != 1 ? 2 : 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd); LAUNCH_CHECK("conv_igemm_bf3"); return 0; } }

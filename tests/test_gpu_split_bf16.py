@@ -153,3 +153,29 @@ def test_split_bf16_headline_attack_against_the_float64_yardstick(eng, monkeypat
     # deterministic: the same call again, bit for bit (a fresh plan: the autotuner's choices do not enter the result)
     atk2 = attacks.ImageGuidedFMDirection_Adam(["resnet50"], depth=3, step_size=0.005, steps=10, weight_seed=0)
     assert torch.equal(atk2(vid, torch.zeros(1, dtype=torch.long), ["clip0"]).cpu(), adv)
+
+
+@pytest.mark.parametrize("mt", ["slowfast_resnet50", "i3d_resnet50"])
+def test_split_bf16_video_backbones_ilaf_costs(eng, monkeypatch, mt):
+    """The video graphs in the bf16x3 mode (BASELINE.json configs[4] shape: 1 x 32 x 224^2): spatial, pointwise and TEMPORAL tap-uniform
+    launches run on the split-bf16 loop (`conv_igemm_bf3<..., VID>`), stems / attention products / fast-pathway layers stay fp32.  Three
+    ILAF steps against the oracle's torch-module run: every cost within rtol 2e-4, as in the default mode."""
+    from i2v_amd import sign_attacks, video
+    from oracle import video_models as vm
+    monkeypatch.setenv("I2V_MATH", "bf16x3")
+    thw = (32, 224, 224)
+    gen = torch.Generator().manual_seed(11)
+    ori_u8 = torch.randint(0, 256, (1, 3, *thw), generator=gen, dtype=torch.uint8)
+    adv_u8 = (ori_u8.long() + torch.randint(-10, 11, ori_u8.shape, generator=gen)).clamp(0, 255).to(torch.uint8)
+    ori, adv = gu.videos_of({"clip_u8": ori_u8.numpy()}), gu.videos_of({"clip_u8": adv_u8.numpy()})
+    model = video.VideoModel(mt, thw)
+    atk = sign_attacks.ILAF(model, mt, step_size=0.005, steps=3)
+    before = eng.capi.i2v_backend_stat(b"bf3_launches")
+    atk(adv.clone(), ori.clone(), torch.zeros(1, dtype=torch.long), ["v"])
+    ran = eng.capi.i2v_backend_stat(b"bf3_launches") - before
+    g = graphs.build_video(mt, thw)
+    tm = vm.load_weights(vm.make(mt, False), weights.synthetic_state_dict(g, 0))
+    _, costs, _, _ = restate.run_ilaf(tm, vm.hook_modules(tm, mt), adv, ori, steps=3)
+    print(f"\nbf16x3 ILAF {mt}: {ran} split-bf16 launches; costs {atk.last_costs} oracle {costs}")
+    assert ran > 50
+    np.testing.assert_allclose(atk.last_costs, costs, rtol=2e-4)
