@@ -366,7 +366,14 @@ static int pack_img(Net& n, Node& nd) {
     // few output channels (SlowFast's fast stem: 8) cannot use the tap-uniform path; instead of the per-row path they take the
     // "quad rows" order (channel, frame tap, row tap, column-tap quad x 4): see pack_fwd
     static const bool no_quad = [] { const char* e = getenv("I2V_QUAD"); return e && e[0] == '0'; }();
-    const bool quad = !no_quad && c.cout % I2V_KC != 0 && TW >= 2 && TW <= 8;
+    // Round 5, measured and NOT taken (opt-in I2V_IMG_QUAD=1): quad rows for the stride-2 7x7 stems with 64 output channels (ResNet, I3D, SlowFast's
+    // slow pathway) too.  Their class-packed gradient has exactly FOUR column taps per row run (TW = 4: one quad, no padding) and issues 16
+    // four-byte im2col DMA pieces per wave and chunk beside 16 MFMAs of 32 cycles (PMC: matrix pipe 0.59 busy); as quad rows the same chunk is four
+    // 16-byte pieces per wave.  Slower all the same: image gradient 52.0 -> 44.6 TFLOP/s on the I2V stem, 60.7 -> 53.6 on I3D's, 43.7 -> 40.0 on
+    // SlowFast's (gpurun_out r5p, same box, alternated): the channel-major K order sweeps one channel's 4 x 4 window per chunk, and the masked
+    // fragment reads of MODE 4 cost more than the DMA instructions they save.  Same products either way (the host simulation follows the k-table).
+    static const bool img_quad = [] { const char* e = getenv("I2V_IMG_QUAD"); return e && e[0] == '1'; }();
+    const bool quad = !no_quad && (c.cout % I2V_KC != 0 || (img_quad && TW == 4)) && TW >= 2 && TW <= 8;
     const int TWq = quad ? (TW + 3) / 4 * 4 : TW;               // column taps per run, padded to whole quads
     P.K = TT * TH * TWq * c.cout; P.Kpad = (int)align_up(P.K, I2V_KC);
     P.Cd = Bt * B * B * c.cin; P.Cdpad = (int)align_up(P.Cd, 128);

@@ -169,7 +169,7 @@ template <int BD, int BP, int WD, bool MF16, int NST = 2, int CPB = 1, int BF3 =
 constexpr int conv_lds_floats() {
     // (BF3: the weight tile of a chunk is 3 bf16 planes in MFMA-fragment order, 3 KB per 32 rows instead of fp32's 2 KB)
     // (BF3 == 1: (BD / 32) * 3 one-KB pieces per chunk, rounded up to a multiple of 4 so that every wave issues the same number; BF3 == 2: weights never enter LDS)
-    constexpr int stage = NST * CPB * (I2V_KC * BP + (BF3 == 2 ? 0 : BF3 ? ((BD / 32) * 3 + 3) / 4 * 4 * 256 : I2V_KC * BD)), epi = WD * (MF16 ? 16 : 32) * BP;
+    constexpr int stage = NST * CPB * (I2V_KC * BP + (BF3 == 2 ? 0 : BF3 ? ((BD / 32) * 3 + 3) / 4 * 4 * 256 : I2V_KC * BD)), epi = WD * (MF16 ? 16 : 32) * BP;      // (BF3 == 3: NST = 3)
     return stage > epi ? stage : epi;
 }
 
@@ -340,8 +340,10 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     // (DEEP, see the main loop), while chunks c+1 .. c+3 are
     // ... and the split-bf16 loop with staged weights (BF3 == 1), whose chunks last 6 x 32 cycles per fragment pair instead of 8 x 64: one
     // chunk of look-ahead no longer covers an L2 round trip
-    constexpr bool DEEP = conv_deep(MODE, PREF) || (BF3 == 1 && I2V_BF3_STAGES > 2);
-    constexpr int NST = BF3 == 1 ? I2V_BF3_STAGES : DEEP ? I2V_DEEP_STAGES : 2, AHEAD = NST - 1;
+    // BF3 == 3: variant 1 with the ACTIVATION fragments of chunk c + 1 read and split under the MFMAs of chunk c (software pipelining across the
+    // barrier): three staging buffers -- chunk c + 2 is in flight, chunk c + 1 is being read, chunk c's weights are being read
+    constexpr bool DEEP = conv_deep(MODE, PREF) || (BF3 == 1 && I2V_BF3_STAGES > 2) || BF3 == 3;
+    constexpr int NST = BF3 == 3 ? 3 : BF3 == 1 ? I2V_BF3_STAGES : DEEP ? I2V_DEEP_STAGES : 2, AHEAD = NST - 1;
     // MODE 5 ("halo"): a 3x3 / stride-1 / pad-1 launch on planes exactly HWM wide stages, per 16-channel group, ONE halo row per
     // channel -- the tile's 64 pixels plus a source row and a pixel on either side -- instead of nine shifted copies of the tile
     constexpr bool HALO = MODE == 5;
@@ -542,6 +544,31 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
                 for (int pl = 0; pl < 3; ++pl) wcur[sb][i][pl] = load_w3(sb, i, pl);
     }
     (void)wcur; (void)w3lane; (void)w3chunk;
+    constexpr int TP_ = BP / WP / (MF16 ? 16 : 32);
+    bf8 xcur[BF3 == 3 ? TP_ : 1][3];                           // BF3 == 3: the split activation fragments of the CURRENT chunk
+    (void)xcur;
+    auto bf3_split2 = [](const float lo, const float hi, unsigned& p1, unsigned& p2, unsigned& p3) {
+        // (plain casts, not inline asm: hipcc emits v_cvt_pk_bf16_f32 for them on gfx950 -- round to nearest even -- and, unlike asm
+        //  statements, the instruction scheduler may interleave them with the MFMAs)
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const unsigned a = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo, hi}, bf2));
+        const float rl = lo - __builtin_bit_cast(float, a << 16), rh = hi - __builtin_bit_cast(float, a & 0xffff0000u);
+        const unsigned b = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){rl, rh}, bf2));
+        const float sl = rl - __builtin_bit_cast(float, b << 16), sh = rh - __builtin_bit_cast(float, b & 0xffff0000u);
+        const unsigned c = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){sl, sh}, bf2));
+        p1 = a; p2 = b; p3 = c;
+    };
+    auto bf3_split_frag = [&](const float (&x)[8], bf8 (&out)[3]) {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        unsigned q1[4], q2[4], q3[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bf3_split2(x[2 * e], x[2 * e + 1], q1[e], q2[e], q3[e]);
+        out[0] = __builtin_bit_cast(bf8, (u4){q1[0], q1[1], q1[2], q1[3]});
+        out[1] = __builtin_bit_cast(bf8, (u4){q2[0], q2[1], q2[2], q2[3]});
+        out[2] = __builtin_bit_cast(bf8, (u4){q3[0], q3[1], q3[2], q3[3]});
+    };
+    (void)bf3_split_frag;
     typedef typename std::conditional<MF16, f32x4, f32x16>::type acc_t;
     acc_t acc[TD][TP];
 #pragma unroll
@@ -734,7 +761,8 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
     // the YOUNGER chunks that may stay in flight (every wave issues the same NL per chunk; the epilogue prefetch loads are older).
     auto chunk_body = [&](const int c, const int buf, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;                // a chunk c+AHEAD exists: its DMA is issued here
-        if constexpr (DEEP) {
+        if constexpr (BF3 == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk c + 1 has landed too (c + 2 is issued below)
+        else if constexpr (DEEP) {
             const int younger = nsuper - 1 - c < AHEAD - 1 ? nsuper - 1 - c : AHEAD - 1;      // chunks behind c already issued
             if (NST > 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
             else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
@@ -759,6 +787,56 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
             }
         }
         (void)vb;
+        if constexpr (BF3 == 3) {
+            // ---- split-bf16 chunk, software-pipelined: weight fragments of chunk c and RAW activation values of chunk c + 1 are requested
+            // first, the MFMAs of chunk c run on the activation fragments split during chunk c - 1 (with the DMA pieces of chunk c + 2 and the
+            // split of chunk c + 1 interleaved behind them by the scheduling hints below), so the matrix pipe does not wait for LDS latency
+            // and the 44-instruction split at the top of every chunk.
+            static_assert(CPB == 1, "one chunk per barrier");
+            bf8 wa[TD][3];
+            const float* const abase = As3 + buf * AF + lane * 4;
+#pragma unroll
+            for (int i = 0; i < TD; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    wa[i][pl] = __builtin_bit_cast(bf8, *reinterpret_cast<const f4*>(abase + ((wd * TD + i) * 3 + pl) * 256));
+            // (branch-free on purpose: after the last chunk this reads and splits whatever the ring's next buffer holds and nothing uses it --
+            //  a branch would end the scheduling region and put the split back behind the MFMAs)
+            const int nb = buf + 1 == NST ? 0 : buf + 1;
+            float xr[TP][8];
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xr[j][e] = Bs[nb][8 * lk + e][wpx * (BP / WP) + j * FR + l31];
+            constexpr int TW[6] = {2, 1, 0, 1, 0, 0}, TX[6] = {0, 1, 2, 0, 1, 0};
+            constexpr int NM = 6 * TD * TP, NS = 4 * TP;                  // MFMAs of the chunk; slices of the split (one value pair each)
+            unsigned nq[TP][3][4];                                        // the next chunk's fragments, pair by pair
+            [&]<int... M>(std::integer_sequence<int, M...>) {
+                (([&] {
+                    constexpr int m = M, term = m / (TD * TP), ij = m % (TD * TP), i = ij / TP, j = ij % TP;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][TW[term]], xcur[j][TX[term]], acc[i][j], 0, 0, 0);
+                    if constexpr (MORE) {
+                        if constexpr (m < NL) { I2V_ISSUE_PIECE_SUB(m, (c + AHEAD) * KC, (buf + AHEAD) % NST, vb[0], 0); }
+                    }
+                    // one slice of the split behind every (NM / NS)-th MFMA, pinned there: left to itself the scheduler issues all MFMAs first
+                    // and the 44 vector instructions after them, where nothing overlaps them
+                    [&]<int... KK>(std::integer_sequence<int, KK...>) {      // slice k sits behind MFMA (k + 1) NM / NS - 1
+                        (([&] {
+                            constexpr int k = KK, jj = k / 4, e = k % 4;
+                            if constexpr ((k + 1) * NM / NS - 1 == m)
+                                bf3_split2(xr[jj][2 * e], xr[jj][2 * e + 1], nq[jj][0][e], nq[jj][1][e], nq[jj][2][e]);
+                        }()), ...);
+                    }(std::make_integer_sequence<int, NS>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }()), ...);
+            }(std::make_integer_sequence<int, NM>{});
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) xcur[j][pl] = __builtin_bit_cast(bf8, (u4){nq[j][pl][0], nq[j][pl][1], nq[j][pl][2], nq[j][pl][3]});
+            return;
+        }
         if constexpr (BF3) {
             // ---- split-bf16 chunk: per 16 K rows, 3 x TD weight fragments (ds_read_b128, pre-split) and TP activation fragments read as
             // fp32 (8 values per lane: K rows 8 lk .. 8 lk + 7 of this lane's pixel) and split into three bf16 terms x = x1 + x2 + x3
@@ -896,6 +974,18 @@ __device__ __forceinline__ void conv_tile(const I2VConvParams& p, const int n_cd
             }()), ...);
         }(std::make_integer_sequence<int, CPB * KS>{});
     };
+    if constexpr (BF3 == 3) {      // the first chunk's activation fragments, before the loop
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int l31_ = lane & 31, lk_ = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < TP_; ++j) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = Bs[0][8 * lk_ + e][(wave % WP) * (BP / WP) + j * 32 + l31_];
+            bf3_split_frag(x, xcur[j]);
+        }
+    }
     if constexpr (!HALO) {
         int c = 0, buf = 0;
         for (; c + AHEAD < nsuper; ++c) { chunk_body(c, buf, std::true_type{}); buf = buf + 1 == NST ? 0 : buf + 1; }
@@ -1198,12 +1288,12 @@ conv_igemm_dc(const I2VConvParams p, const int n_cd_tiles) {
 #ifndef I2V_BF3_VARIANT
 #define I2V_BF3_VARIANT 1        // 1: weight fragments staged through LDS by DMA, I2V_BF3_STAGES buffers; 2: loaded straight into registers, one chunk ahead
 #endif
-template <int BD, int BP, int WD, int WP, int MODE, int CPB, bool VID = false>
+template <int BD, int BP, int WD, int WP, int MODE, int CPB, bool VID = false, int VAR = I2V_BF3_VARIANT>
 __global__ void __launch_bounds__(256) conv_igemm_bf3(const I2VConvParams p, const int n_cd_tiles) {
-    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<BD, BP, WD, false, I2V_BF3_VARIANT == 1 ? I2V_BF3_STAGES : 2, CPB, I2V_BF3_VARIANT>()];
+    __shared__ __attribute__((aligned(16))) float smem[conv_lds_floats<BD, BP, WD, false, VAR == 3 ? 3 : VAR == 1 ? I2V_BF3_STAGES : 2, CPB, VAR>()];
     I2V_PROBE_T probe;
     probe.entry();
-    conv_tile<BD, BP, WD, WP, MODE, false, false, VID, false, 0, CPB, 0, I2V_BF3_VARIANT>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x);
+    conv_tile<BD, BP, WD, WP, MODE, false, false, VID, false, 0, CPB, 0, VAR>(p, n_cd_tiles, blockIdx.x, gridDim.x, 0, smem, probe, blockIdx.x);
     probe.exit(blockIdx.x);
 }
 static bool conv_bf3_ok(const I2VConvParams& p) {      // (temporal launches -- video networks' k x 1 x 1 and strided convolutions -- only as tap-uniform ones: the staging of MODE 2, VID)
@@ -1565,13 +1655,20 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
     if constexpr (!MF16) {
         if (conv_bf3_ok(p)) {     // split-bf16 K loop (bit 6 of the configuration: two chunks per barrier)
             __atomic_fetch_add(&g_stat_bf3, 1, __ATOMIC_RELAXED);
-            const bool two = I2V_BF3_VARIANT != 1 && p.cfg > 0 && ((p.cfg - 1) & 64) && (p.Kpad / I2V_KC) % 2 == 0;      // (the deep-staged variant synchronises per chunk)
+            const bool two = I2V_BF3_VARIANT == 2 && p.cfg > 0 && ((p.cfg - 1) & 64) && (p.Kpad / I2V_KC) % 2 == 0;      // (the deep-staged variant synchronises per chunk)
             // The loop is bound by VALU issue -- splitting an activation fragment costs 44 vector instructions, and a bf16 MFMA hides about
             // five --, so the 128x128 tile puts its four waves SIDE BY SIDE along the pixels (each 128 rows x 32 pixels): one activation
             // fragment split per 24 MFMAs instead of two, the four weight fragments are plain 16-byte LDS reads.
             if constexpr (BD == 128 && BP == 128 && WD == 2) {
                 if (!p.temporal && !getenv("I2V_BF3_SQUARE")) {
-                    if (p.pointwise) hipLaunchKernelGGL((conv_igemm_bf3<128, 128, 1, 4, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+                    // bit 6 of the configuration on this tile: the software-pipelined loop (BF3 == 3: the next chunk's activation fragments read and
+                    // split under this chunk's MFMAs, three staging buffers).  Measured on the wide tile (tools/bf3_sweep.sh): layer3 3x3 172 -> 187
+                    // TFLOP/s, layer2 3x3 174 -> 177, the pointwise shapes 0 ... -8 %; on the smaller tiles the third buffer costs a resident
+                    // block and 10-25 % -- so it is one more candidate of the autotuner for this tile only.  Same arithmetic in the same order.
+                    if (I2V_BF3_VARIANT == 1 && p.cfg > 0 && ((p.cfg - 1) & 64)) {
+                        if (p.pointwise) hipLaunchKernelGGL((conv_igemm_bf3<128, 128, 1, 4, 1, 1, false, 3>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+                        else hipLaunchKernelGGL((conv_igemm_bf3<128, 128, 1, 4, 2, 1, false, 3>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
+                    } else if (p.pointwise) hipLaunchKernelGGL((conv_igemm_bf3<128, 128, 1, 4, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
                     else hipLaunchKernelGGL((conv_igemm_bf3<128, 128, 1, 4, 2, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
                     LAUNCH_CHECK("conv_igemm_bf3");
                     return 0;
@@ -1583,10 +1680,10 @@ static int launch_conv_cfg(const I2VConvParams& p, hipStream_t s) {
                 return 0;
             }
             if (p.pointwise) {
-                if constexpr (I2V_BF3_VARIANT != 1) { if (two) { hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 1, I2V_BF3_VARIANT != 1 ? 2 : 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd); LAUNCH_CHECK("conv_igemm_bf3"); return 0; } }
+                if constexpr (I2V_BF3_VARIANT == 2) { if (two) { hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 1, I2V_BF3_VARIANT == 2 ? 2 : 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd); LAUNCH_CHECK("conv_igemm_bf3"); return 0; } }
                 hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
             } else {
-                if constexpr (I2V_BF3_VARIANT != 1) { if (two) { hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 2, I2V_BF3_VARIANT != 1 ? 2 : 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd); LAUNCH_CHECK("conv_igemm_bf3"); return 0; } }
+                if constexpr (I2V_BF3_VARIANT == 2) { if (two) { hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 2, I2V_BF3_VARIANT == 2 ? 2 : 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd); LAUNCH_CHECK("conv_igemm_bf3"); return 0; } }
                 hipLaunchKernelGGL((conv_igemm_bf3<BD, BP, WD, WP, 2, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, n_cd);
             }
             LAUNCH_CHECK("conv_igemm_bf3");
@@ -1704,7 +1801,8 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
         for (int i = 0; i < 4; ++i) {
             if (p.Cd <= BD3[i] / 2) continue;
             out[n++] = i;
-            if (I2V_BF3_VARIANT != 1 && (p.Kpad / I2V_KC) % 2 == 0) out[n++] = i | 64;
+            if (I2V_BF3_VARIANT == 2 && (p.Kpad / I2V_KC) % 2 == 0) out[n++] = i | 64;
+            if (I2V_BF3_VARIANT == 1 && i == 0 && !p.temporal) out[n++] = 0 | 64;      // 128x128: the software-pipelined loop
         }
         return n;
     }

@@ -104,7 +104,7 @@ def test_split_bf16_tiles_are_bit_identical_and_deterministic(eng, monkeypatch):
     frames = 5
     xin = dev(torch.randn(frames, 3, 28, 28, generator=torch.Generator().manual_seed(0)))
     outs = []
-    for cfg in (3, 3, 2, 1, 0, 3 | 64, 2 | 64):
+    for cfg in (3, 3, 2, 1, 0, 0 | 64, 3 | 64):          # (0 | 64: the software-pipelined loop of the 128x128 tile)
         monkeypatch.setenv("I2V_FORCE_CFG", str(cfg))
         net = eng.build_net(g, sd, [h], frames)
         before = eng.capi.i2v_backend_stat(b"bf3_launches")
