@@ -1,6 +1,8 @@
 """CPU: the free-running rung's machinery (`oracle/size_parity.py`: oracle attack, float64 yardstick, statistics, bounds) on a tiny
 backbone, with the planner's host simulation standing in for the device -- the `-m gpu` twin at BASELINE size is
 tests/test_gpu_size_parity.py.  Rung: `/root/reference/image_attacks.py:325-364`, SURVEY.md 7.3-1 (iv)."""
+import os
+
 import numpy as np
 import torch
 
@@ -56,3 +58,22 @@ def test_committed_float64_yardstick_fixture():
     assert abs(st["mean_abs_delta_ratio"] - 1) < 1e-6
     # the sample's values are normalised pixels of a clamped clip: inside the ImageNet-normalised [0, 1] box
     assert float(y["adv_sample"].min()) >= (0 - 0.485) / 0.229 - 1e-5 and float(y["adv_sample"].max()) <= (1 - 0.406) / 0.225 + 1e-5
+
+
+def test_oracle_worker_processes_on_the_tiny_backbone(tmp_path):
+    """`oracle/fooling_worker.py` through `size_parity.start_oracle_workers` (the plumbing of tests/test_gpu_size_parity.py and
+    tools/fooling_parity.py), on the tiny backbone: single-thread fp32 workers dealt round-robin + the float64 worker; a row is complete
+    when its npz appears; the fp32 and float64 runs of one row agree to fp32 rounding; `effective_cpus` honours the cgroup quota."""
+    from oracle import size_parity
+    n = size_parity.effective_cpus()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    procs = size_parity.start_oracle_workers([0, 1, 2], str(tmp_path), workers=2, steps=2, extra=["--tiny", "--frames", "4", "--hw", "64"],
+                                             f64_rows=[1], f64_threads=2)
+    assert len(procs) == 3
+    rows = [size_parity.wait_oracle_row(str(tmp_path), r, procs, timeout=300) for r in range(3)]
+    o64 = size_parity.wait_oracle_row(str(tmp_path), 1, procs, timeout=300, tag="oracle64")
+    assert [p.wait() for p in procs] == [0, 0, 0]
+    for o in rows:
+        assert o["costs"].shape == (2,) and abs(float(o["costs"][0]) - 4.0) < 1e-5 and o["adv"].shape == (1, 3, 4, 64, 64)
+    st = size_parity.compare(rows[1]["costs"], rows[1]["mean_abs_delta"], rows[1]["adv"], o64)
+    assert st["max_rel_cost_err"] < 1e-5 and abs(st["mean_abs_delta_ratio"] - 1) < 0.01
