@@ -64,6 +64,7 @@ struct Packed {               // one implicit-GEMM operand set
     int has_dt = 0;           // some k-table row carries a temporal tap offset
     int quad = 0, quad_kw = 0, quad_dw0 = 0;     // "quad rows" packing (I2VConvParams::quad): quads per row run, taps per run, first tap
     int tpair = 0;            // forward packing with TWO output frames per grid frame (rows = (frame class, channel)): see pack_fwd
+    int ig_tt = 0, ig_th = 0, ig_tw = 0;      // image-gradient packing in tap-uniform order: union taps per axis (I2VConvParams::ig_*)
 };
 
 struct Node {
@@ -379,6 +380,8 @@ static int pack_img(Net& n, Node& nd) {
     P.Cd = Bt * B * B * c.cin; P.Cdpad = (int)align_up(P.Cd, 128);
     P.tap_uniform = (!quad && c.cout % I2V_KC == 0) ? 1 : 0;
     if (quad) { P.quad = TWq / 4; P.quad_kw = TW; P.quad_dw0 = dw_lo; }
+    if (P.tap_uniform) { P.ig_tt = TT; P.ig_th = TH; P.ig_tw = TW; }
+    else if (quad && TWq == 4 && TH == 4) { P.ig_tt = TT; P.ig_th = TH; P.ig_tw = TWq; }      // (conv_imggrad_halo, QUAD: one 4 x 4 plane per chunk)
     P.Tg = sparse ? (sb.T - ct0 + stt - 1) / stt : (sb.T + Bt - 1) / Bt; P.Hg = (sb.H + B - 1) / B; P.Wg = (sb.W + B - 1) / B;
     nd.img_blk = B; nd.img_sh = m; nd.img_blkt = Bt; nd.img_ost = sparse ? stt : Bt; nd.img_ot0 = ct0; nd.img_skips = sparse;
     if (pairs) { P.Tg = (P.Tg + 1) / 2; nd.img_ost = 2 * stt; nd.img_st = 2; nd.img_oct = stt; }
@@ -659,6 +662,7 @@ static void conv_common(I2VConvParams& p, const Packed& P) {
     p.temporal = P.has_dt;      // conv_run adds the frame-mapping half of the condition
     p.quad = P.quad; p.quad_kw = P.quad_kw; p.quad_dw0 = P.quad_dw0;
     p.halo = P.halo;
+    p.ig_tt = P.ig_tt; p.ig_th = P.ig_th; p.ig_tw = P.ig_tw;
 }
 
 static bool overlaps(const Tensor& a, const Tensor& b) {

@@ -35,11 +35,12 @@ static int hip_fail(hipError_t e, const char* what) {
 #define LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return hip_fail(e_, name); } while (0)
 
 const char* be_name() { return "hip:gfx950"; }
-static long long g_stat_conv = 0, g_stat_pws = 0, g_stat_bf3 = 0;      // (relaxed counters: diagnostics only)
+static long long g_stat_conv = 0, g_stat_pws = 0, g_stat_bf3 = 0, g_stat_igh = 0;      // (relaxed counters: diagnostics only)
 long long be_stat(const char* name) {
     if (!strcmp(name, "conv_launches")) return __atomic_load_n(&g_stat_conv, __ATOMIC_RELAXED);
     if (!strcmp(name, "pws_launches")) return __atomic_load_n(&g_stat_pws, __ATOMIC_RELAXED);
     if (!strcmp(name, "bf3_launches")) return __atomic_load_n(&g_stat_bf3, __ATOMIC_RELAXED);
+    if (!strcmp(name, "ighalo_launches")) return __atomic_load_n(&g_stat_igh, __ATOMIC_RELAXED);
     return -1;
 }
 const char* be_error() { return g_be_has_err ? g_be_err : nullptr; }
@@ -1129,6 +1130,256 @@ conv_igemm_halo(const I2VConvParams p, const int n_cd_tiles) {
 }
 
 // =============================================================================================
+// Image gradient on a 2-D halo tile (round 5, autotuner bit 9)
+// =============================================================================================
+// The class-packed gradient w.r.t. the 3-channel input (I2VConvParams::blk / blkt; K order (16-channel group, frame tap, row tap,
+// column tap, channel) -- the tap-uniform packing of pack_img) through conv_tile stages, per K chunk, one SHIFTED copy of its
+// pixel tile: sixteen 4-byte LDS-DMA instructions per wave beside sixteen 32-cycle MFMAs, and the PMC shows the matrix pipe 0.59 busy --
+// the launch is bound by DMA issue.  The TH x TW taps of a (group, frame tap) read the SAME 16 channel planes, so this kernel gives a
+// block a 16 x 16 tile of the class grid of ONE grid frame, stages the tile plus its halo once per (group, frame tap) --
+// [16 channels][16 + TH - 1 rows][16 + TW - 1 columns], 6 DMA instructions per plane instead of 16 per tap -- and reads every tap's B
+// fragments from it at a shifted LDS address.  The weight fragments never enter LDS: a lane loads its own A values (L1 / L2 hits: 64 KB
+// shared by every block) four chunks ahead into a register ring.  Same products in the same k order as the conv_tile launch (chunk =
+// one tap of 16 channels, 16x16x4 fragments, rows 4s + lk of k-step s): bit-identical, which is what lets the autotuner choose
+// between them.  Eligible (conv_ighalo_ok): tap-uniform packing, grid stride 1 (stride-2 stems: B = 2, m = 1), TH, TW <= 4 and
+// TH * TW % 4 == 0, at most 32 class rows (TD = 1: 12 of 16 -- image stems, SlowFast's slow stem; TD = 2: 24 of 32 -- I3D's stem).
+// Measured (tools/ig_halo_probe.cpp, ResNet's 7x7/2 stem, 128 frames of 224^2, random operands; conv_tile 16x256: 640 us = 47 TFLOP/s
+// of algorithmic flops): two halo buffers with the next stage's burst under this stage's MFMAs, 3 blocks per CU: 486-490 us (whatever
+// the look-ahead of the B fragments: 1, 2 or 3 k-steps); ONE buffer, two barriers per stage, 6 blocks per CU: 451 us = 67 TFLOP/s --
+// what the loop needs is waves per SIMD, not depth per wave (with stores, DMA, weight traffic and LDS reads all removed the
+// two-buffer version still took 458 us).  Shipped: one buffer.  The ceiling of this formulation is 157 x 12/16 rows x 49/64 taps x
+// ~0.9 (raw fp32 MFMA issue on this part, tools/mfma_rate.cpp) = 80.  The I3D's stem (TD = 2, 24 of 32 rows, 5 of 6 frame taps; 4 blocks per
+// CU by registers -- compiled for 5 it spills and gains nothing): 58.5 -> 64.4 TFLOP/s, against a ceiling of 157 x 24/32 x 49/64 x 5/6 x 0.9 = 68.
+static constexpr int IGH_RS = 20, IGH_PL = 400, IGH_NPC = 6;      // LDS row / plane stride in floats (400 % 32 == 16: the four K rows of a
+                                                                  // fragment read land on disjoint bank halves), DMA pieces per plane
+// QUAD: the "quad rows" packing of a stem with fewer than 16 output channels (SlowFast's fast pathway: 8), K order (channel, frame tap, row
+// tap, column tap x 4) with 4 x 4 taps: a K chunk is ONE channel plane of one frame tap, k-step s is row tap s and a lane's K row lk is column
+// tap lk.  A stage then holds the TT frame-tap planes of 1, 2 or 4 channels (whichever makes a whole number of four-chunk groups: <= 16 planes)
+// and a chunk moves on by a plane instead of by a tap shift.  The zero-weight taps that pad a 7-wide kernel to two quads read real (finite)
+// pixels here where conv_tile's MODE 4 substitutes zeros: the product is a zero either way and the chain's value the same.
+template <int TD, bool VID, bool QUAD = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TD == 1 ? 6 : 4, TD == 1 ? 6 : 4)))
+conv_imggrad_halo(const I2VConvParams p, const int tiles_x, const int tiles_xy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KC = I2V_KC, RS = IGH_RS, PL = IGH_PL, NPC = IGH_NPC;
+    __shared__ __attribute__((aligned(16))) float Hb[KC * PL];             // 25 600 bytes: six blocks per CU (TD = 2: four, by registers)
+    typedef __attribute__((address_space(3))) float* lds_fp_t;
+    constexpr unsigned OOB = 0x80000000u;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int n16 = lane & 15, lk = lane >> 4;
+    // block -> (grid frame, tile): consecutive tiles of a frame on one XCD (their halos overlap in its L2)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    // (readfirstlane: the quotients are uniform but computed on the vector unit; inline asm takes an "s" operand as it finds it)
+    const int ng = __builtin_amdgcn_readfirstlane(lid / tiles_xy), tl = lid - ng * tiles_xy;
+    const int ty = __builtin_amdgcn_readfirstlane(tl / tiles_x), tx = tl - ty * tiles_x;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const int TT = VID ? p.ig_tt : 1, TH = p.ig_th, TW = p.ig_tw, NTs = TH * TW;
+    const I2VKEntry e0 = load_kentry(p.ktab, 0);
+    const int dh_lo = e0.dh, dw_lo = e0.dw, dt_lo = VID ? (e0.valid >> 1) : 0;
+    const int HWs = p.Hs * p.Ws;
+    const int cps = !QUAD ? 0 : TT % 4 == 0 ? 1 : TT % 2 == 0 ? 2 : 4;       // QUAD: channels per stage
+    const int npl = QUAD ? cps * TT : KC;                                     // planes per stage
+    const int nstages = QUAD ? p.Cs / cps : (p.Cs / KC) * TT;
+    const int ngroups = QUAD ? npl / 4 : NTs / 4;                             // four-chunk groups per stage
+    int clip = ng, ts0 = 0;
+    if (VID) { clip = __builtin_amdgcn_readfirstlane(ng / p.Tg); ts0 = (ng - clip * p.Tg) * p.st; }
+    const int sframe0 = VID ? clip * p.Ts + ts0 : ng;                      // source frame of frame tap dt = 0
+    const int nstr4 = (int)p.src_nstride * 4;
+    // Every VMEM instruction of the main loop is inline asm and every vmcnt wait is written by hand: the wave's VMEM queue is a fixed
+    // sequence (per tap 4 TD weight loads, per stage one burst of 24 LDS-DMA pieces), so the count that lets exactly the OLDEST ring slot
+    // through is a compile-time number.  Left to the compiler (builtins for both), its wait-count pass put `s_waitcnt vmcnt(0)` in front
+    // of the first LDS read behind a DMA burst (LDS-DMA may alias any LDS read) and at the head of the tap loop (loop-carried loads),
+    // i.e. it drained the queue every four taps.
+    // buffer resources as plain 4-dword scalars (what __builtin_amdgcn_make_buffer_rsrc builds: base, stride 0, bytes, raw dword access)
+    auto make_rsrc = [](const void* base, const unsigned bytes) {
+        const unsigned long long b = (unsigned long long)base;
+        return (i2v_v4i){(int)(unsigned)b, (int)(unsigned)((b >> 32) & 0xffffu), (int)bytes, 0x00020000};
+    };
+    const i2v_v4i rs_w = make_rsrc(p.wp, (unsigned)(p.Kpad * p.Cdpad * 4));
+    const i2v_v4i rs_x = make_rsrc(p.src, (unsigned)p.src_span_bytes);
+    // halo element e = 64 q + lane of a plane: row e / RS, column e % RS of the staged window, whose corner is source pixel
+    // (y0 + dh_lo, x0 + dw_lo); elements outside the window or outside the plane are zero-filled by the range check
+    unsigned hoff[NPC];
+#pragma unroll
+    for (int q = 0; q < NPC; ++q) {
+        const int e = 64 * q + lane, r = e / RS, c = e - r * RS;
+        const int ys = y0 + dh_lo + r, xs = x0 + dw_lo + c;
+        const bool ok = r < 16 + TH - 1 && c < 16 + TW - 1 && (unsigned)ys < (unsigned)p.Hs && (unsigned)xs < (unsigned)p.Ws;
+        hoff[q] = ok ? (unsigned)((ys * p.Ws + xs) * 4) : OOB;
+    }
+    // stage q = (group g, frame tap tt): 16 planes of source frame sframe0 + dt_lo + tt (QUAD: channels q cps .. + cps - 1, plane = (channel,
+    // frame tap)); wave w moves planes w, w + 4, w + 8, w + 12 as six pieces each.  A frame tap outside the clip reads nothing: every lane
+    // out of range, zeros into the buffer.
+    const unsigned ld0 = __builtin_bit_cast(unsigned, (lds_fp_t)Hb) + (unsigned)(wv * PL * 4);
+    auto issue_stage = [&](const int q) {
+        const int g = QUAD ? 0 : VID ? __builtin_amdgcn_readfirstlane(q / TT) : q, tt0 = QUAD ? 0 : VID ? q - g * TT : 0;
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) {
+            const int plane = wv + 4 * pl;
+            if (QUAD && plane >= npl) break;
+            const int cl = QUAD ? (plane >= TT) + (plane >= 2 * TT) + (plane >= 3 * TT) : 0;      // QUAD: plane = cl TT + tt
+            const int tt = QUAD ? plane - cl * TT : tt0, chan = QUAD ? q * cps + cl : g * KC + plane;
+            const bool fok = !VID || (unsigned)(ts0 + dt_lo + tt) < (unsigned)p.Ts;
+            const unsigned so = fok ? (unsigned)((sframe0 + dt_lo + tt) * nstr4 + chan * HWs * 4) : 0u;
+#pragma unroll
+            for (int h = 0; h < NPC; ++h) {
+                const unsigned vo = fok ? hoff[h] : OOB;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                             :: "s"(__builtin_amdgcn_readfirstlane((int)(ld0 + (unsigned)((4 * pl * PL + 64 * h) * 4)))), "v"(vo), "s"(rs_x),
+                                "s"(__builtin_amdgcn_readfirstlane((int)so)) : "memory");
+                // (M0 is not on the clobber list -- the compiler rejects reserved registers there -- and need not be: it never keeps a value in
+                //  M0 across statements, it sets it immediately in front of each instruction of its own that reads it)
+            }
+        }
+    };
+    // A fragments of chunk c: lane (row n16 of fragment i, K row 4 s + lk of k-step s) -> wp[(16 c + 4 s + lk)][16 i + n16]; chunks beyond
+    // the last read zeros (range check) -- the ring runs four chunks ahead of the MFMAs to the very end
+    const unsigned aoff = (unsigned)((lk * p.Cdpad + n16) * 4);
+    auto load_a = [&](const int c, float (&a)[4][TD]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TD; ++i)
+                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(a[s][i]) : "v"(aoff), "s"(rs_w), "s"(__builtin_amdgcn_readfirstlane(((c * KC + 4 * s) * p.Cdpad + 16 * i) * 4)) : "memory");
+    };
+    // `s_waitcnt vmcnt(N)` that the ring slot's registers pass THROUGH: the MFMAs reading them cannot be scheduled in front of it
+    auto wait_a = [&]<int N>(std::integral_constant<int, N>, float (&a)[4][TD]) {
+        if constexpr (TD == 1) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0][0]), "+v"(a[1][0]), "+v"(a[2][0]), "+v"(a[3][0]) : "n"(N) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a[0][0]), "+v"(a[1][0]), "+v"(a[2][0]), "+v"(a[3][0]), "+v"(a[0][1]), "+v"(a[1][1]), "+v"(a[2][1]), "+v"(a[3][1]) : "n"(N) : "memory");
+    };
+    f32x4 acc[TD][4];
+#pragma unroll
+    for (int i = 0; i < TD; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float ring[4][4][TD];
+    issue_stage(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_a(u, ring[u]);
+    // this lane's B element of fragment j (grid row 4 wave + j, column n16), K row lk (a channel plane; QUAD: a column tap), tap (0, 0)
+    const float* const hb = Hb + (QUAD ? lk : lk * PL) + (4 * wave) * RS + n16;
+    int chunk = 0;
+    // The wave's VMEM queue: a stage ends with the reloads of ring slots 0 .. 3 and, behind the second barrier, the next stage's burst.
+    //   stage top   vmcnt(0): the burst -- the youngest thing in the queue -- has landed, and with it all four slots; barrier
+    //   taps 0-3    no wait;   taps >= 4: slot u is followed by the three reloads behind it: vmcnt(3 x 4 TD)
+    //   stage end   every wave has read its last fragment (lgkmcnt(0), barrier) before the next stage's planes overwrite the buffer
+    constexpr int W_IN = 3 * 4 * TD;
+    for (int q = 0; q < nstages; ++q) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wait_a(std::integral_constant<int, 0>{}, ring[u]);
+        __builtin_amdgcn_s_barrier();
+        int th = 0, tw = 0, pli = 0;
+        // Four taps = sixteen k-steps as one software pipeline: the B fragments of k-step ks + 1 are requested before the MFMAs of k-step ks
+        // (two register sets), across the tap boundaries.
+        auto four_taps = [&](auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const float* hp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (QUAD) hp[u] = hb + (pli++) * PL;
+                else { hp[u] = hb + th * RS + tw; if (++tw == TW) { tw = 0; ++th; } }
+            }
+            float fb[2][4];
+            auto rd = [&]<int KS>(std::integral_constant<int, KS>) {
+                if constexpr (KS < 16) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[KS % 2][j] = hp[KS / 4][(QUAD ? (KS % 4) * RS : 4 * (KS % 4) * PL) + j * RS];
+                }
+            };
+            rd(std::integral_constant<int, 0>{});
+            [&]<int... KS>(std::integer_sequence<int, KS...>) {
+                (([&] {
+                    constexpr int ks = KS, u = KS / 4, s = KS % 4;
+                    rd(std::integral_constant<int, ks + 1>{});
+                    if constexpr (s == 0 && !FIRST) wait_a(std::integral_constant<int, W_IN>{}, ring[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < TD; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][s][i], fb[ks % 2][j], acc[i][j], 0, 0, 0);
+                    if constexpr (s == 3) {
+                        // the slot's reload BEHIND the tap's MFMAs, its last readers: the new values may land in the same registers
+                        // (issued in front of them, the compiler copied the whole ring at the top of every iteration)
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_a(chunk + 4, ring[u]);
+                        ++chunk;
+                    }
+                }()), ...);
+            }(std::make_integer_sequence<int, 16>{});
+        };
+        four_taps(std::true_type{});
+        for (int gq = 1; gq < ngroups; ++gq) four_taps(std::false_type{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (q + 1 < nstages) issue_stage(q + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the ring's run-out: nothing may still target a register)
+    // ---- epilogue: the class-packed store of conv_tile, element for element ----
+    const int HoWo = p.Ho * p.Wo;
+    const int bb = p.blk * p.blk, Creal = p.Cd / ((VID ? p.blkt : 1) * bb);
+    const int otb = VID ? (ng - clip * p.Tg) * p.ost + p.ot0 : 0;
+    const int gj = x0 + n16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gi = y0 + 4 * wave + j;
+        if (gi >= p.Hg || gj >= p.Wg) continue;
+#pragma unroll
+        for (int i = 0; i < TD; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cd = 16 * i + 4 * lk + r;
+                if (cd >= p.Cd) continue;
+                const int cls3 = cd / Creal, c = cd - cls3 * Creal;
+                const int ct = VID ? cls3 / bb : 0, cls = cls3 - ct * bb;
+                const int oh = gi * p.osh + cls / p.blk + p.oh0, ow = gj * p.osw + cls % p.blk + p.ow0;
+                if (oh >= p.Ho || ow >= p.Wo || (VID && otb + ct * p.oct >= p.To)) continue;
+                const int64_t n = VID ? (int64_t)clip * p.To + otb + ct * p.oct : ng;
+                const int64_t o = (int64_t)c * HoWo + oh * p.Wo + ow;
+                float v = acc[i][j][r];
+                if (p.shift) v += p.shift[c];
+                if (p.add1) v += p.add1[n * p.add1_nstride + o];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.mask && !(p.mask[n * p.mask_nstride + o] > 0.f)) v = 0.f;
+                p.dst[n * p.dst_nstride + o] = v;
+            }
+    }
+#endif
+}
+static bool conv_ighalo_ok(const I2VConvParams& p) {
+    if (p.ig_th <= 0 || p.ig_tw <= 0 || p.pre_scale || p.sh != 1 || p.sw != 1 || p.blk <= 1 || p.Cd > 32 || p.Kpad != p.K || p.gate || p.gate_out || p.add0 || p.gate_scale) return false;
+    const int TT = p.ig_tt > 0 ? p.ig_tt : 1;
+    if (p.quad) {       // quad-row order: a chunk is the 4 x 4 taps of one (channel, frame tap) plane
+        if (p.quad != 1 || p.ig_th != 4 || p.ig_tw != 4 || p.K != p.Cs * TT * 16) return false;
+        const int cps = TT % 4 == 0 ? 1 : TT % 2 == 0 ? 2 : 4;
+        return cps * TT <= 16 && p.Cs % cps == 0;
+    }
+    return p.tap_uniform && p.ig_th <= 4 && p.ig_tw <= 4 && (p.ig_th * p.ig_tw) % 4 == 0 && p.Cs % I2V_KC == 0 && p.K == TT * p.ig_th * p.ig_tw * p.Cs;
+}
+template <int TD, bool VID, bool QUAD>
+static void launch_conv_ighalo_t(const I2VConvParams& p, const int64_t grid, const int tiles_x, const int tiles_xy, hipStream_t s) {
+    hipLaunchKernelGGL((conv_imggrad_halo<TD, VID, QUAD>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_x, tiles_xy);
+}
+static int launch_conv_ighalo(const I2VConvParams& p, hipStream_t s) {
+    const int tiles_x = (p.Wg + 15) / 16, tiles_y = (p.Hg + 15) / 16, txy = tiles_x * tiles_y;
+    const int64_t grid = (int64_t)p.N * txy;
+    if (grid <= 0) return 0;
+    if (grid > 0x7fffffff) { snprintf(g_be_err, sizeof g_be_err, "conv grid too large"); g_be_has_err = true; return 1; }
+    const bool two = p.Cd > 16;
+    if (p.quad) {       // (quad-row stems exist in video networks only)
+        if (two) launch_conv_ighalo_t<2, true, true>(p, grid, tiles_x, txy, s); else launch_conv_ighalo_t<1, true, true>(p, grid, tiles_x, txy, s);
+    } else if (p.temporal) {
+        if (two) launch_conv_ighalo_t<2, true, false>(p, grid, tiles_x, txy, s); else launch_conv_ighalo_t<1, true, false>(p, grid, tiles_x, txy, s);
+    } else {
+        if (two) launch_conv_ighalo_t<2, false, false>(p, grid, tiles_x, txy, s); else launch_conv_ighalo_t<1, false, false>(p, grid, tiles_x, txy, s);
+    }
+    LAUNCH_CHECK("conv_imggrad_halo");
+    return 0;
+}
+
+// =============================================================================================
 // Fused pair (round 4): 3x3 convolution -> pointwise convolution over its channels, one launch
 // =============================================================================================
 // A bottleneck's conv2 (3x3, Cmid -> Cmid) and conv3 (1x1, Cmid -> 4 Cmid, + residual, ReLU) -- and, in the backward pass, the input
@@ -1819,6 +2070,8 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
     static const bool no_dc = [] { const char* e = getenv("I2V_DC"); return e && e[0] == '0'; }();
     if (conv_dc_ok(p) && !no_dc) out[n++] = 3 | 64;                          // 64x64 with two chunks per barrier (32-row LDS buffers)
     if (p.Cd <= 16) out[n++] = 5;                        // 16x256 tile on 16x16x4 MFMA fragments
+    static const bool no_igh = [] { const char* e = getenv("I2V_IGHALO"); return e && e[0] == '0'; }();
+    if (conv_ighalo_ok(p) && !no_igh) out[n++] = (p.Cd <= 16 ? 5 : 4) | 512;      // the class-packed image gradient on a 2-D halo tile (conv_imggrad_halo)
     // conv_pw_stream (one persistent role-split workgroup per CU) is built, bit-identical and SLOWER than conv_igemm on every shape it
     // admits (round 5, tools/pw_stream_probe.cpp, profiles/r5_pw_stream_probe.txt: 56 / 80 / 91 TFLOP/s on 64 -> 256 / 128 -> 512 /
     // 256 -> 1024 at 128 frames against 69 / 108 / 117): offered to the autotuner only on request (I2V_PWS=1), like the fused pair
@@ -1869,6 +2122,10 @@ int k_conv(const I2VConvParams& p_in, i2v_stream_t s) {
     conv_magics(p);
     if (p.cfg <= 0) p.cfg = conv_pick(p) + 1;          // the model's pick -- or $I2V_FORCE_CFG, which may carry the variant bits too
     __atomic_fetch_add(&g_stat_conv, 1, __ATOMIC_RELAXED);
+    if (((p.cfg - 1) & 512) && conv_ighalo_ok(p)) {     // image gradient on a 2-D halo tile (autotuner bit 9)
+        __atomic_fetch_add(&g_stat_igh, 1, __ATOMIC_RELAXED);
+        return launch_conv_ighalo(p, st);
+    }
     if (((p.cfg - 1) & 256) && conv_pws_grid(p)) {     // persistent role-split pointwise kernel (autotuner bit 8)
         __atomic_fetch_add(&g_stat_pws, 1, __ATOMIC_RELAXED);
         return launch_conv_pws(p, st);

@@ -77,6 +77,10 @@ struct I2VConvParams {
     // channel and group (tile pixels + a row and a pixel on either side) instead of nine shifted copies of the tile.  Same
     // products in the same order: results are bit-identical.
     int32_t halo;
+    // ig_th > 0: a class-packed image-gradient packing (pack_img) in tap-uniform order (16-channel group, frame tap, row tap, column tap,
+    // channel) with ig_tt x ig_th x ig_tw union taps, the first k-table row being the lowest tap of each axis: conv_imggrad_halo may
+    // stage one 2-D halo tile per (group, frame tap) instead of one shifted copy per tap.  Same products, same order.
+    int32_t ig_tt, ig_th, ig_tw;
     // exact division of a pixel index (< 2^31) by Hg*Wg, Wg, Tg and Wo as multiply-high + shift: filled in by k_conv (the
     // hardware has no integer divide; the 64-bit software divisions of round 1 cost a block more VALU issue slots than a
     // K = 64 tile spends on its MFMAs)

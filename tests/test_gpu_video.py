@@ -368,6 +368,47 @@ def test_tile_configurations_are_bit_identical(eng, monkeypatch):
         assert torch.equal(f, outs[0][0]) and torch.equal(gx, outs[0][1])
 
 
+def test_image_gradient_halo_kernel_is_bit_identical(eng, monkeypatch):
+    """conv_imggrad_halo (round 5, autotuner bit 9: the class-packed image gradient on a 2-D halo tile, one staged window per
+    16-channel group and frame tap instead of one shifted copy per tap) against the conv_tile launch it replaces, on stems of
+    REAL width -- ResNet's 7x7/2 with 64 channels (12 class rows), SqueezeNet 1.1's 3x3/2 (2 x 2 union taps: one four-tap group per
+    stage), the I3D's 5x7x7 / (2,2,2) (24 class rows, three frame taps, frame taps outside the clip) and SlowFast's slow stem (every
+    8th frame, the rest left to a memset) together with its FAST stem (8 channels: the quad-row K order, one channel plane per chunk,
+    pairs of sampled frames as temporal classes, accumulating onto the slow stem's result) -- on sizes that leave partial 16 x 16
+    tiles: every word of the input gradient bit for bit.  It is the same k-ordered chain."""
+    monkeypatch.setenv("I2V_AUTOTUNE", "0")
+    cases = [(graphs.resnet((1, 1, 1, 1), 64, (72, 88), "resnet_w64"), None, 3, 5, 1),
+             (graphs.squeezenet(1, (70, 70)), None, 2, 5, 1),
+             (graphs.i3d_resnet((1, 1, 1, 1), 64, (8, 40, 56), "i3d_w64", inflate=((1,), (1,), (1,), (0,))), "i3d_resnet50", None, 4, 1),
+             (graphs.slowfast_res2(64, (16, 40, 56), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 5, 2),
+             (graphs.slowfast_res2(64, (32, 24, 40), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 4, 2)]
+    for g, video_type, depth, base_cfg, expect in cases:
+        sd = weights.synthetic_state_dict(g, 0)
+        hooks = graphs.video_hooks(g, video_type) if video_type else [g.hooks[depth]]
+        T = g.tensors[g.input].T if video_type else 1
+        clips = 2 if video_type else 3
+        frames = clips * T
+        x = dev(torch.randn(frames, 3, *g.in_hw, generator=torch.Generator().manual_seed(0)))
+        outs = []
+        for cfg in (base_cfg, base_cfg | 512):
+            monkeypatch.setenv("I2V_FORCE_CFG", str(cfg))
+            net = eng.build_net(g, sd, hooks, frames)
+            net.forward(x)
+            feats = [net.save_hook(i, clips * hi.T).cpu() for i, hi in enumerate(net.hooks)]
+            hg = [torch.randn(f.shape, generator=torch.Generator().manual_seed(7 + i)) for i, f in enumerate(feats)]
+            write_hook_grads(net, feats, hg)
+            before = eng.capi.i2v_backend_stat(b"ighalo_launches")
+            gx = torch.full((frames, 3, *g.in_hw), float("nan"), device="cuda:0")
+            net.backward(gx)
+            torch.cuda.synchronize()
+            ran = eng.capi.i2v_backend_stat(b"ighalo_launches") - before
+            assert ran == (expect if cfg & 512 else 0), (g.arch, cfg, ran)
+            outs.append(gx.cpu())
+            net.close()
+        assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
+        assert torch.equal(outs[0], outs[1]), g.arch
+
+
 def test_batch_buckets_of_the_autotuner_are_bit_identical(eng):
     """Round 3: a planned net keeps one tuned tile configuration per batch bucket (its planned size, 1/2, 1/4, 1/8 of it) and a call
     picks the bucket that covers its frames -- whatever it picks, a frame's result is the one a net planned for exactly that batch
