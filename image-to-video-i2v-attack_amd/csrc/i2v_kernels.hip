@@ -35,12 +35,13 @@ static int hip_fail(hipError_t e, const char* what) {
 #define LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return hip_fail(e_, name); } while (0)
 
 const char* be_name() { return "hip:gfx950"; }
-static long long g_stat_conv = 0, g_stat_pws = 0, g_stat_bf3 = 0, g_stat_igh = 0;      // (relaxed counters: diagnostics only)
+static long long g_stat_conv = 0, g_stat_pws = 0, g_stat_bf3 = 0, g_stat_igh = 0, g_stat_sth = 0;      // (relaxed counters: diagnostics only)
 long long be_stat(const char* name) {
     if (!strcmp(name, "conv_launches")) return __atomic_load_n(&g_stat_conv, __ATOMIC_RELAXED);
     if (!strcmp(name, "pws_launches")) return __atomic_load_n(&g_stat_pws, __ATOMIC_RELAXED);
     if (!strcmp(name, "bf3_launches")) return __atomic_load_n(&g_stat_bf3, __ATOMIC_RELAXED);
     if (!strcmp(name, "ighalo_launches")) return __atomic_load_n(&g_stat_igh, __ATOMIC_RELAXED);
+    if (!strcmp(name, "stemhalo_launches")) return __atomic_load_n(&g_stat_sth, __ATOMIC_RELAXED);
     return -1;
 }
 const char* be_error() { return g_be_has_err ? g_be_err : nullptr; }
@@ -1380,6 +1381,172 @@ static int launch_conv_ighalo(const I2VConvParams& p, hipStream_t s) {
 }
 
 // =============================================================================================
+// Narrow forward stem on a 2-D halo tile (round 5, autotuner bit 10)
+// =============================================================================================
+// SlowFast's fast stem (3 -> 8 channels, 5x7x7, spatial stride 2; frame pairs: 16 class rows, K = (channel, frame tap, row tap, column
+// quad x 4) = 1008) through conv_tile's MODE 4 re-stages, for every 16-row K chunk, a 256-pixel B tile that only 16 output rows use:
+// 16 KB of L2 -> LDS traffic per 64 MFMAs, 41 TFLOP/s of algorithmic flops where the zeros of the packing allow 100 -- the launch is
+// bound by the operand fetch, not by the matrix pipe.  The 56 K rows of a (channel, frame tap) read ONE source plane, so this kernel
+// gives a block a 16 x 16 tile of output pixels of one grid frame and stages the tile's source window -- 37 rows x 40 columns, its
+// left edge moved one pixel out so that rows start 16-byte aligned: six 16-byte DMA instructions per plane -- once per plane; two
+// planes (112 K rows = 7 chunks) form a stage, every B fragment address is a compile-time offset from the lane's base, and the seven
+// chunks' weight fragments sit in a seven-slot register ring that is reloaded a whole stage ahead (no wait inside a stage).  One
+// buffer, two barriers per stage, six blocks per CU, as conv_imggrad_halo.  Same k order, same products (a padded column tap reads a
+// real pixel against a zero weight where MODE 4 substitutes a zero): bit-identical to the conv_tile launch.
+// Eligible (conv_stemhalo_ok): quad-row packing of a 7 x 7 / stride-2 / pad-3 kernel, <= 16 class rows, plane width a multiple of 4.
+static constexpr int SH_RS = 40, SH_WR = 37, SH_NPC = 6, SH_PL = SH_NPC * 256, SH_RPP = 56, SH_CPS = 7;     // window row stride / rows, DMA pieces per plane, plane floats (whole
+                                                                                                            // pieces: the last one's zero-filled tail must not land in the next plane),
+                                                                                                            // K rows per plane, chunks per stage
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6)))
+conv_stem_halo(const I2VConvParams p, const int tiles_x, const int tiles_xy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KC = I2V_KC, RS = SH_RS, PL = SH_PL, NPC = SH_NPC, CPS = SH_CPS;
+    __shared__ __attribute__((aligned(16))) float Hb[2 * PL];               // two planes, 12 288 bytes
+    typedef __attribute__((address_space(3))) float* lds_fp_t;
+    constexpr unsigned OOB = 0x80000000u;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int n16 = lane & 15, lk = lane >> 4;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int ng = __builtin_amdgcn_readfirstlane(lid / tiles_xy), tl = lid - ng * tiles_xy;
+    const int ty = __builtin_amdgcn_readfirstlane(tl / tiles_x), tx = tl - ty * tiles_x;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const int HWs = p.Hs * p.Ws;
+    const int nstages = p.K / (2 * SH_RPP);
+    const int clip = __builtin_amdgcn_readfirstlane(ng / p.Tg), ts0 = (ng - clip * p.Tg) * p.st;      // source frame (in the clip) of frame tap 0
+    const int nstr4 = (int)p.src_nstride * 4;
+    auto make_rsrc = [](const void* base, const unsigned bytes) {
+        const unsigned long long b = (unsigned long long)base;
+        return (i2v_v4i){(int)(unsigned)b, (int)(unsigned)((b >> 32) & 0xffffu), (int)bytes, 0x00020000};
+    };
+    const i2v_v4i rs_w = make_rsrc(p.wp, (unsigned)(p.Kpad * p.Cdpad * 4));
+    const i2v_v4i rs_x = make_rsrc(p.src, (unsigned)p.src_span_bytes);
+    // window piece e = 64 h + lane: row e / 10, columns 4 (e % 10) .. + 3; the window's corner is source pixel (2 y0 - 3, 2 x0 - 4)
+    unsigned hoff[NPC];
+#pragma unroll
+    for (int h = 0; h < NPC; ++h) {
+        const int e = 64 * h + lane, r = e / 10, c4 = e - r * 10;
+        const int ys = 2 * y0 - 3 + r, xs = 2 * x0 - 4 + 4 * c4;
+        const bool ok = r < SH_WR && (unsigned)ys < (unsigned)p.Hs && (unsigned)xs < (unsigned)p.Ws;
+        hoff[h] = ok ? (unsigned)((ys * p.Ws + xs) * 4) : OOB;
+    }
+    // stage q: planes 2 q and 2 q + 1 (plane = (channel, frame tap): k-table row 56 plane); pieces h = wave, wave + 4, wave + 8 of the 12
+    const unsigned ld0 = __builtin_bit_cast(unsigned, (lds_fp_t)Hb);
+    auto issue_stage = [&](const int q) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int pc = wv + 4 * i, pl = pc >= NPC ? 1 : 0, h = pc - pl * NPC;      // (uniform)
+            const I2VKEntry e = load_kentry(p.ktab, (2 * q + pl) * SH_RPP);
+            const int dt = e.valid >> 1;
+            const bool fok = (unsigned)(ts0 + dt) < (unsigned)p.Ts;
+            const unsigned so = fok ? (unsigned)((clip * p.Ts + ts0 + dt) * nstr4 + e.chan_off * 4) : 0u;
+            unsigned vo = hoff[0];
+#pragma unroll
+            for (int hh = 1; hh < NPC; ++hh) vo = h == hh ? hoff[hh] : vo;
+            vo = fok ? vo : OOB;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(__builtin_amdgcn_readfirstlane((int)(ld0 + (unsigned)((pl * PL + 256 * h) * 4)))), "v"(vo), "s"(rs_x),
+                            "s"(__builtin_amdgcn_readfirstlane((int)so)) : "memory");
+        }
+    };
+    const unsigned aoff = (unsigned)((lk * p.Cdpad + n16) * 4);
+    auto load_a = [&](const int c, float (&a)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(a[s]) : "v"(aoff), "s"(rs_w), "s"(__builtin_amdgcn_readfirstlane(((c * KC + 4 * s) * p.Cdpad) * 4)) : "memory");
+    };
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float ring[CPS][4];
+    issue_stage(0);
+#pragma unroll
+    for (int u = 0; u < CPS; ++u) load_a(u, ring[u]);
+    // this lane's B element: output pixel (4 wave + j, n16) reads window (2 (4 wave + j) + r, 2 n16 + 1 + s4), column tap s4 = 4 quad + lk
+    const float* const hb = Hb + (8 * wave) * RS + 2 * n16 + 1 + lk;
+    int chunk = 0;
+    for (int q = 0; q < nstages; ++q) {
+        // every slot was reloaded a stage ago and the burst is the youngest thing in the queue: one wait for all
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[0][0]), "+v"(ring[0][1]), "+v"(ring[0][2]), "+v"(ring[0][3]) :: "memory");
+#pragma unroll
+        for (int u = 1; u < CPS; ++u)      // (the other slots pass through an empty statement behind the wait: volatile statements keep their order)
+            asm volatile("" : "+v"(ring[u][0]), "+v"(ring[u][1]), "+v"(ring[u][2]), "+v"(ring[u][3]) :: "memory");
+        __builtin_amdgcn_s_barrier();
+        float fb[2][4];
+        // k-step ks of the stage: K row 4 ks + lk of the stage's 112 = plane (4 ks) / 56, kernel row r, column quad: all compile-time
+        auto rd = [&]<int KS>(std::integral_constant<int, KS>) {
+            if constexpr (KS < 4 * CPS) {
+                constexpr int row = 4 * KS, pl = row / SH_RPP, rr = row % SH_RPP, r = rr / 8, c0 = rr % 8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[KS % 2][j] = hb[pl * PL + (2 * j + r) * RS + c0];
+            }
+        };
+        rd(std::integral_constant<int, 0>{});
+        [&]<int... KS>(std::integer_sequence<int, KS...>) {
+            (([&] {
+                constexpr int ks = KS, u = KS / 4, s = KS % 4;
+                rd(std::integral_constant<int, ks + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][s], fb[ks % 2][j], acc[j], 0, 0, 0);
+                if constexpr (s == 3) {      // the slot's reload (the chunk a stage ahead) behind its last readers
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_a(chunk + CPS, ring[u]);
+                    ++chunk;
+                }
+            }()), ...);
+        }(std::make_integer_sequence<int, 4 * CPS>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (q + 1 < nstages) issue_stage(q + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- epilogue: conv_tile's class-packed store with blk = 1 (row = (frame class, channel)), element for element ----
+    const int HoWo = p.Ho * p.Wo;
+    const int Creal = p.Cd / p.blkt;
+    const int otb = (ng - clip * p.Tg) * p.ost + p.ot0;
+    const int gj = x0 + n16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gi = y0 + 4 * wave + j;
+        if (gi >= p.Hg || gj >= p.Wg) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cd = 4 * lk + r;
+            if (cd >= p.Cd) continue;
+            const int ct = cd / Creal, c = cd - ct * Creal;
+            const int oh = gi * p.osh + p.oh0, ow = gj * p.osw + p.ow0;
+            if (oh >= p.Ho || ow >= p.Wo || otb + ct * p.oct >= p.To) continue;
+            const int64_t n = (int64_t)clip * p.To + otb + ct * p.oct;
+            const int64_t o = (int64_t)c * HoWo + oh * p.Wo + ow;
+            float v = acc[j][r];
+            if (p.shift) v += p.shift[c];
+            if (p.add1) v += p.add1[n * p.add1_nstride + o];
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (p.mask && !(p.mask[n * p.mask_nstride + o] > 0.f)) v = 0.f;
+            p.dst[n * p.dst_nstride + o] = v;
+        }
+    }
+#endif
+}
+static bool conv_stemhalo_ok(const I2VConvParams& p) {
+    return p.quad == 2 && p.quad_kw == 7 && p.quad_dw0 == -3 && p.sh == 2 && p.sw == 2 && p.blk == 1 && p.blkt == 2 && p.Cd <= 16 && p.Kpad == p.K &&
+           p.K % (2 * SH_RPP) == 0 && p.Ws % 4 == 0 && p.src_nstride % 4 == 0 && p.osh == 1 && p.osw == 1 && p.oct == 1 && !p.pre_scale && !p.gate && !p.gate_out &&
+           !p.add0 && !p.gate_scale && !p.ig_th;
+}
+static int launch_conv_stemhalo(const I2VConvParams& p, hipStream_t s) {
+    const int tiles_x = (p.Wg + 15) / 16, tiles_y = (p.Hg + 15) / 16, txy = tiles_x * tiles_y;
+    const int64_t grid = (int64_t)p.N * txy;
+    if (grid <= 0) return 0;
+    if (grid > 0x7fffffff || ((uintptr_t)p.src & 15)) { snprintf(g_be_err, sizeof g_be_err, "stem halo launch: grid too large or source not 16-byte aligned"); g_be_has_err = true; return 1; }
+    hipLaunchKernelGGL(conv_stem_halo, dim3((unsigned)grid), dim3(256), 0, s, p, tiles_x, txy);
+    LAUNCH_CHECK("conv_stem_halo");
+    return 0;
+}
+
+// =============================================================================================
 // Fused pair (round 4): 3x3 convolution -> pointwise convolution over its channels, one launch
 // =============================================================================================
 // A bottleneck's conv2 (3x3, Cmid -> Cmid) and conv3 (1x1, Cmid -> 4 Cmid, + residual, ReLU) -- and, in the backward pass, the input
@@ -2072,6 +2239,7 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
     if (p.Cd <= 16) out[n++] = 5;                        // 16x256 tile on 16x16x4 MFMA fragments
     static const bool no_igh = [] { const char* e = getenv("I2V_IGHALO"); return e && e[0] == '0'; }();
     if (conv_ighalo_ok(p) && !no_igh) out[n++] = (p.Cd <= 16 ? 5 : 4) | 512;      // the class-packed image gradient on a 2-D halo tile (conv_imggrad_halo)
+    if (conv_stemhalo_ok(p) && !no_igh) out[n++] = 5 | 1024;                       // the narrow forward stem on a 2-D halo tile (conv_stem_halo)
     // conv_pw_stream (one persistent role-split workgroup per CU) is built, bit-identical and SLOWER than conv_igemm on every shape it
     // admits (round 5, tools/pw_stream_probe.cpp, profiles/r5_pw_stream_probe.txt: 56 / 80 / 91 TFLOP/s on 64 -> 256 / 128 -> 512 /
     // 256 -> 1024 at 128 frames against 69 / 108 / 117): offered to the autotuner only on request (I2V_PWS=1), like the fused pair
@@ -2122,6 +2290,10 @@ int k_conv(const I2VConvParams& p_in, i2v_stream_t s) {
     conv_magics(p);
     if (p.cfg <= 0) p.cfg = conv_pick(p) + 1;          // the model's pick -- or $I2V_FORCE_CFG, which may carry the variant bits too
     __atomic_fetch_add(&g_stat_conv, 1, __ATOMIC_RELAXED);
+    if (((p.cfg - 1) & 1024) && conv_stemhalo_ok(p) && !((uintptr_t)p.src & 15)) {     // narrow forward stem on a 2-D halo tile (autotuner bit 10)
+        __atomic_fetch_add(&g_stat_sth, 1, __ATOMIC_RELAXED);
+        return launch_conv_stemhalo(p, st);
+    }
     if (((p.cfg - 1) & 512) && conv_ighalo_ok(p)) {     // image gradient on a 2-D halo tile (autotuner bit 9)
         __atomic_fetch_add(&g_stat_igh, 1, __ATOMIC_RELAXED);
         return launch_conv_ighalo(p, st);

@@ -368,21 +368,24 @@ def test_tile_configurations_are_bit_identical(eng, monkeypatch):
         assert torch.equal(f, outs[0][0]) and torch.equal(gx, outs[0][1])
 
 
-def test_image_gradient_halo_kernel_is_bit_identical(eng, monkeypatch):
-    """conv_imggrad_halo (round 5, autotuner bit 9: the class-packed image gradient on a 2-D halo tile, one staged window per
-    16-channel group and frame tap instead of one shifted copy per tap) against the conv_tile launch it replaces, on stems of
-    REAL width -- ResNet's 7x7/2 with 64 channels (12 class rows), SqueezeNet 1.1's 3x3/2 (2 x 2 union taps: one four-tap group per
-    stage), the I3D's 5x7x7 / (2,2,2) (24 class rows, three frame taps, frame taps outside the clip) and SlowFast's slow stem (every
-    8th frame, the rest left to a memset) together with its FAST stem (8 channels: the quad-row K order, one channel plane per chunk,
-    pairs of sampled frames as temporal classes, accumulating onto the slow stem's result) -- on sizes that leave partial 16 x 16
-    tiles: every word of the input gradient bit for bit.  It is the same k-ordered chain."""
+def test_stem_halo_kernels_are_bit_identical(eng, monkeypatch):
+    """The two 2-D halo-tile kernels of round 5 against the conv_tile launches they replace, forced onto real-width stems:
+    * conv_imggrad_halo (autotuner bit 9: the class-packed image gradient, one staged window per 16-channel group and frame tap
+      instead of one shifted copy per tap) -- ResNet's 7x7/2 with 64 channels (12 class rows), SqueezeNet 1.1's 3x3/2 (2 x 2 union
+      taps: one four-tap group per stage), the I3D's 5x7x7 / (2,2,2) (24 class rows, three frame taps, frame taps outside the clip),
+      SlowFast's slow stem (every 8th frame, the rest left to a memset) and its FAST stem (8 channels: the quad-row K order, one
+      channel plane per chunk, pairs of sampled frames as temporal classes, accumulating onto the slow stem's result);
+    * conv_stem_halo (bit 10: SlowFast's fast stem FORWARD, 3 -> 8 channels in frame pairs, the source window staged once per
+      (channel, frame tap) plane instead of a shifted 256-pixel tile per K chunk);
+    on sizes that leave partial 16 x 16 tiles: every word of the hooked features and of the input gradient bit for bit.  They are
+    the same k-ordered chains."""
     monkeypatch.setenv("I2V_AUTOTUNE", "0")
-    cases = [(graphs.resnet((1, 1, 1, 1), 64, (72, 88), "resnet_w64"), None, 3, 5, 1),
-             (graphs.squeezenet(1, (70, 70)), None, 2, 5, 1),
-             (graphs.i3d_resnet((1, 1, 1, 1), 64, (8, 40, 56), "i3d_w64", inflate=((1,), (1,), (1,), (0,))), "i3d_resnet50", None, 4, 1),
-             (graphs.slowfast_res2(64, (16, 40, 56), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 5, 2),
-             (graphs.slowfast_res2(64, (32, 24, 40), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 4, 2)]
-    for g, video_type, depth, base_cfg, expect in cases:
+    cases = [(graphs.resnet((1, 1, 1, 1), 64, (72, 88), "resnet_w64"), None, 3, 5, 1, 0),
+             (graphs.squeezenet(1, (70, 70)), None, 2, 5, 1, 0),
+             (graphs.i3d_resnet((1, 1, 1, 1), 64, (8, 40, 56), "i3d_w64", inflate=((1,), (1,), (1,), (0,))), "i3d_resnet50", None, 4, 1, 0),
+             (graphs.slowfast_res2(64, (16, 40, 56), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 5, 2, 1),
+             (graphs.slowfast_res2(64, (32, 24, 40), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 4, 2, 1)]
+    for g, video_type, depth, base_cfg, expect_grad, expect_fwd in cases:
         sd = weights.synthetic_state_dict(g, 0)
         hooks = graphs.video_hooks(g, video_type) if video_type else [g.hooks[depth]]
         T = g.tensors[g.input].T if video_type else 1
@@ -390,23 +393,25 @@ def test_image_gradient_halo_kernel_is_bit_identical(eng, monkeypatch):
         frames = clips * T
         x = dev(torch.randn(frames, 3, *g.in_hw, generator=torch.Generator().manual_seed(0)))
         outs = []
-        for cfg in (base_cfg, base_cfg | 512):
+        for cfg in (base_cfg, base_cfg | 512 | 1024):
             monkeypatch.setenv("I2V_FORCE_CFG", str(cfg))
             net = eng.build_net(g, sd, hooks, frames)
+            before = [eng.capi.i2v_backend_stat(b"ighalo_launches"), eng.capi.i2v_backend_stat(b"stemhalo_launches")]
             net.forward(x)
             feats = [net.save_hook(i, clips * hi.T).cpu() for i, hi in enumerate(net.hooks)]
             hg = [torch.randn(f.shape, generator=torch.Generator().manual_seed(7 + i)) for i, f in enumerate(feats)]
             write_hook_grads(net, feats, hg)
-            before = eng.capi.i2v_backend_stat(b"ighalo_launches")
             gx = torch.full((frames, 3, *g.in_hw), float("nan"), device="cuda:0")
             net.backward(gx)
             torch.cuda.synchronize()
-            ran = eng.capi.i2v_backend_stat(b"ighalo_launches") - before
-            assert ran == (expect if cfg & 512 else 0), (g.arch, cfg, ran)
-            outs.append(gx.cpu())
+            ran = [eng.capi.i2v_backend_stat(b"ighalo_launches") - before[0], eng.capi.i2v_backend_stat(b"stemhalo_launches") - before[1]]
+            assert ran == ([expect_grad, expect_fwd] if cfg & 512 else [0, 0]), (g.arch, cfg, ran)
+            outs.append((feats, gx.cpu()))
             net.close()
-        assert torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0
-        assert torch.equal(outs[0], outs[1]), g.arch
+        assert torch.isfinite(outs[0][1]).all() and float(outs[0][1].abs().max()) > 0
+        for fa, fb in zip(outs[0][0], outs[1][0]):
+            assert torch.equal(fa, fb), g.arch
+        assert torch.equal(outs[0][1], outs[1][1]), g.arch
 
 
 def test_batch_buckets_of_the_autotuner_are_bit_identical(eng):
