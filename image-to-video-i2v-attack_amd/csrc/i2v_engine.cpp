@@ -252,6 +252,8 @@ static int pack_fwd(Net& n, Node& nd) {
         if (upload(n, wq, &P.wp)) return 1;
         return upload(n, kq, &P.ktab);
     }
+    // the 7x7 / stride-2 / pad-3 stem over 3 channels in (tap, channel) order: conv_stem64_halo may walk it without the k-table
+    if (!P.tap_uniform && c.cin == 3 && c.kt == 1 && c.kh == 7 && c.kw == 7 && c.stride == 2 && c.pad == 3 && c.dil_t == 1 && c.pad_t == 0 && !nd.preact()) P.halo = 49;
     std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
     std::vector<I2VKEntry> kt(P.Kpad, I2VKEntry{0, 0, 0, 0});
     // K order: (16-channel chunk, tap, channel in chunk) when the channel count allows -- each 16-row chunk keeps a

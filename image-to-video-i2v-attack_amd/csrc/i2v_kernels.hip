@@ -1317,7 +1317,11 @@ conv_imggrad_halo(const I2VConvParams p, const int tiles_x, const int tiles_xy) 
         __builtin_amdgcn_s_barrier();
         if (q + 1 < nstages) issue_stage(q + 1);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the ring's run-out: nothing may still target a register)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the ring's run-out: nothing may still target a register ...
+#pragma unroll
+    for (int u = 0; u < 4; ++u)                             //  ... and the run-out loads' registers stay reserved until here)
+#pragma unroll
+        for (int i = 0; i < TD; ++i) asm volatile("" :: "v"(ring[u][0][i]), "v"(ring[u][1][i]), "v"(ring[u][2][i]), "v"(ring[u][3][i]));
     // ---- epilogue: the class-packed store of conv_tile, element for element ----
     const int HoWo = p.Ho * p.Wo;
     const int bb = p.blk * p.blk, Creal = p.Cd / ((VID ? p.blkt : 1) * bb);
@@ -1503,6 +1507,8 @@ conv_stem_halo(const I2VConvParams p, const int tiles_x, const int tiles_xy) {
         if (q + 1 < nstages) issue_stage(q + 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < CPS; ++u) asm volatile("" :: "v"(ring[u][0]), "v"(ring[u][1]), "v"(ring[u][2]), "v"(ring[u][3]));      // (the run-out loads' registers stay reserved until here)
     // ---- epilogue: conv_tile's class-packed store with blk = 1 (row = (frame class, channel)), element for element ----
     const int HoWo = p.Ho * p.Wo;
     const int Creal = p.Cd / p.blkt;
@@ -1543,6 +1549,173 @@ static int launch_conv_stemhalo(const I2VConvParams& p, hipStream_t s) {
     if (grid > 0x7fffffff || ((uintptr_t)p.src & 15)) { snprintf(g_be_err, sizeof g_be_err, "stem halo launch: grid too large or source not 16-byte aligned"); g_be_has_err = true; return 1; }
     hipLaunchKernelGGL(conv_stem_halo, dim3((unsigned)grid), dim3(256), 0, s, p, tiles_x, txy);
     LAUNCH_CHECK("conv_stem_halo");
+    return 0;
+}
+
+// ... and the WIDE 7x7 / stride-2 stem of the image backbones (3 -> 64 channels: ResNet, DenseNet, SlowFast's slow pathway; K = (tap,
+// channel) = 147; autotuner bit 10 as well).  conv_tile's MODE 0 stages it row by row -- one 4-byte DMA instruction and one k-table row
+// per K row and 64 pixels -- and reaches 86 TFLOP/s at 128 frames.  Here a block takes a 16 x 16 tile of output pixels and ALL 64
+// channels (sixteen 16x16x4 accumulators per wave), stages the three source planes' windows once (18 DMA instructions of 16 bytes per
+// lane), and walks the 147 K rows as 37 fully unrolled k-steps: K row 4 ks + lk is (tap, channel) -> a compile-time LDS offset per
+// quarter-wave, no k-table, no barrier in the loop; the weight fragments come through a three-slot register ring.  The epilogue is
+// conv_tile's scalar one for 16-pixel fragments (shift, ReLU, 16-bit halves of the 1-bit gate words).  Same chain: bit-identical.
+static constexpr int SW_PL = 6 * 256, SW_K = 147, SW_KS = 37, SW_D = 3;      // plane floats (6 pieces), K rows, k-steps, ring depth
+static constexpr int stem64_off(int k) {       // LDS offset of K row k = (7 r + s) 3 + c relative to the lane's window corner
+    k = k > SW_K - 1 ? SW_K - 1 : k;           // (the 148th row has zero weights: any finite element will do)
+    const int tap = k / 3, ci = k % 3, r = tap / 7, sx = tap % 7;
+    return ci * SW_PL + r * SH_RS + sx;
+}
+template <bool VID>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+conv_stem64_halo(const I2VConvParams p, const int tiles_x, const int tiles_xy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int RS = SH_RS, PL = SW_PL, NPC = 6, D = SW_D;
+    __shared__ __attribute__((aligned(16))) float Hb[3 * PL];               // three channel planes, 18 432 bytes
+    typedef __attribute__((address_space(3))) float* lds_fp_t;
+    constexpr unsigned OOB = 0x80000000u;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int n16 = lane & 15, lk = lane >> 4;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int ng = __builtin_amdgcn_readfirstlane(lid / tiles_xy), tl = lid - ng * tiles_xy;
+    const int ty = __builtin_amdgcn_readfirstlane(tl / tiles_x), tx = tl - ty * tiles_x;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const int HWs = p.Hs * p.Ws;
+    int clip = ng, tg = 0;
+    if (VID) { clip = __builtin_amdgcn_readfirstlane(ng / p.Tg); tg = ng - clip * p.Tg; }
+    const int sframe = VID ? clip * p.Ts + tg * p.st : ng;
+    const bool fok = !VID || tg * p.st < p.Ts;
+    auto make_rsrc = [](const void* base, const unsigned bytes) {
+        const unsigned long long b = (unsigned long long)base;
+        return (i2v_v4i){(int)(unsigned)b, (int)(unsigned)((b >> 32) & 0xffffu), (int)bytes, 0x00020000};
+    };
+    const i2v_v4i rs_w = make_rsrc(p.wp, (unsigned)(p.Kpad * p.Cdpad * 4));
+    const i2v_v4i rs_x = make_rsrc(p.src, (unsigned)p.src_span_bytes);
+    // the 18 window pieces (plane pc / 6, piece pc % 6), wave w issuing pc = w, w + 4, ...: piece e = 64 h + lane is row e / 10, columns
+    // 4 (e % 10) .. + 3 of the window whose corner is source pixel (2 y0 - 3, 2 x0 - 4)
+    const unsigned ld0 = __builtin_bit_cast(unsigned, (lds_fp_t)Hb);
+    const unsigned sbase = (unsigned)(sframe * (int)p.src_nstride * 4);
+    unsigned vo[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int pc = wv + 4 * i, pl = pc / NPC, h = pc - pl * NPC;
+        const int e = 64 * h + lane, r = e / 10, c4 = e - r * 10;
+        const int ys = 2 * y0 - 3 + r, xs = 2 * x0 - 4 + 4 * c4;
+        const bool ok = fok && pc < 3 * NPC && r < SH_WR && (unsigned)ys < (unsigned)p.Hs && (unsigned)xs < (unsigned)p.Ws;
+        vo[i] = ok ? (unsigned)((ys * p.Ws + xs) * 4) : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int pc = wv + 4 * i;
+        if (pc >= 3 * NPC) break;
+        const int pl = pc / NPC, h = pc - pl * NPC;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(__builtin_amdgcn_readfirstlane((int)(ld0 + (unsigned)((pl * PL + 256 * h) * 4)))), "v"(vo[i]), "s"(rs_x),
+                        "s"(__builtin_amdgcn_readfirstlane((int)(sbase + (unsigned)(pl * HWs * 4)))) : "memory");
+    }
+    // A fragments of k-step ks: lane (row n16 of fragment i, K row 4 ks + lk) -> wp[4 ks + lk][16 i + n16]
+    const unsigned aoff = (unsigned)((lk * p.Cdpad + n16) * 4);
+    auto load_a = [&](const int ks, float (&a)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(a[i]) : "v"(aoff), "s"(rs_w), "s"(__builtin_amdgcn_readfirstlane((4 * ks * p.Cdpad + 16 * i) * 4)) : "memory");
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    float ring[D][4];
+#pragma unroll
+    for (int u = 0; u < D; ++u) load_a(u, ring[u]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the window pieces have landed (and the ring's first loads)
+    // (the pieces' offset registers and the source descriptor stay allocated until here)
+    asm volatile("" :: "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(vo[4]), "s"(rs_x) : "memory");
+    __builtin_amdgcn_s_barrier();
+    // this lane's window corner: output pixel (4 wave + j, n16) reads window (2 (4 wave + j) + r, 2 n16 + 1 + s)
+    const float* const hb = Hb + (8 * wave) * RS + 2 * n16 + 1;
+    float fb[2][4];
+    auto rd = [&]<int KS>(std::integral_constant<int, KS>) {
+        if constexpr (KS < SW_KS) {
+            constexpr int o0 = stem64_off(4 * KS), o1 = stem64_off(4 * KS + 1), o2 = stem64_off(4 * KS + 2), o3 = stem64_off(4 * KS + 3);
+            const int off = lk == 0 ? o0 : lk == 1 ? o1 : lk == 2 ? o2 : o3;
+            const float* const q = hb + off;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[KS % 2][j] = q[2 * j * RS];
+        }
+    };
+    rd(std::integral_constant<int, 0>{});
+    [&]<int... KS>(std::integer_sequence<int, KS...>) {
+        (([&] {
+            constexpr int ks = KS, u = KS % D;
+            rd(std::integral_constant<int, ks + 1>{});
+            // slot u is followed in the queue by the D - 1 younger slots' loads (the ring runs D k-steps ahead to the very end: rows up
+            // to 4 (SW_KS + D) - 1 < Kpad = 160 hold zero weights)
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ring[u][0]), "+v"(ring[u][1]), "+v"(ring[u][2]), "+v"(ring[u][3]) : "n"(4 * (D - 1)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][i], fb[ks % 2][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(ks + D, ring[u]);
+        }()), ...);
+    }(std::make_integer_sequence<int, SW_KS>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The ring's run-out loads are never read; named here, BEHIND the wait, their destination registers stay reserved until the data has
+    // landed.  (In this fully unrolled loop the compiler sees that they are dead: without this it pointed all of them at one scratch
+    // register and handed that register to an accumulator while the loads were still in flight -- a load landing in a live accumulator.)
+#pragma unroll
+    for (int u = 0; u < D; ++u) asm volatile("" :: "v"(ring[u][0]), "v"(ring[u][1]), "v"(ring[u][2]), "v"(ring[u][3]));
+    // ---- epilogue: conv_tile's scalar one on 16-pixel fragments ----
+    const int HoWo = p.Ho * p.Wo, HWg = p.Hg * p.Wg;
+    const int64_t n = VID ? (int64_t)clip * p.To + tg * p.ost + p.ot0 : ng;
+    const bool nok = !VID || tg * p.ost + p.ot0 < p.To;
+    const int gj = x0 + n16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gi = y0 + 4 * wave + j;
+        const bool ok = nok && gi < p.Hg && gj < p.Wg;
+        const int64_t pp = (int64_t)ng * HWg + gi * p.Wg + gj;               // grid pixel: this element's bit in a gate row
+        float* const dstn = p.dst + n * p.dst_nstride + gi * p.Wo + gj;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cd = 16 * i + 4 * lk + r;
+                float v = 0.f;
+                if (ok) {
+                    v = acc[i][j][r];
+                    if (p.shift) v += p.shift[cd];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    dstn[(int64_t)cd * HoWo] = v;
+                }
+                if (p.gate_out) {
+                    const unsigned long long bal = __ballot(ok && v > 0.f);
+                    if (n16 == 0 && nok && gi < p.Hg)
+                        reinterpret_cast<uint16_t*>(p.gate_out + (int64_t)cd * p.gate_out_stride)[((int64_t)p.gate_out_pix0 + pp) >> 4] = (uint16_t)(bal >> (16 * lk));
+                }
+            }
+    }
+#endif
+}
+static bool conv_stem64_ok(const I2VConvParams& p) {
+    return p.halo == 49 && !p.quad && !p.tap_uniform && !p.pointwise && p.K == SW_K && p.Kpad >= 4 * (SW_KS + SW_D) && p.Cd == 64 && p.sh == 2 && p.sw == 2 &&
+           p.blk <= 1 && p.blkt <= 1 && p.Ws % 4 == 0 && p.src_nstride % 4 == 0 && p.osh == 1 && p.osw == 1 && p.oh0 == 0 && p.ow0 == 0 && p.Hg == p.Ho && p.Wg == p.Wo &&
+           !p.pre_scale && !p.gate && !p.add0 && !p.add1 && !p.mask && !p.gate_scale && (!p.gate_out || p.Wg % 16 == 0);
+}
+static int launch_conv_stem64(const I2VConvParams& p, hipStream_t s) {
+    const int tiles_x = (p.Wg + 15) / 16, tiles_y = (p.Hg + 15) / 16, txy = tiles_x * tiles_y;
+    const int64_t grid = (int64_t)p.N * txy;
+    if (grid <= 0) return 0;
+    if (grid > 0x7fffffff) { snprintf(g_be_err, sizeof g_be_err, "conv grid too large"); g_be_has_err = true; return 1; }
+    if (p.temporal) hipLaunchKernelGGL(conv_stem64_halo<true>, dim3((unsigned)grid), dim3(256), 0, s, p, tiles_x, txy);
+    else hipLaunchKernelGGL(conv_stem64_halo<false>, dim3((unsigned)grid), dim3(256), 0, s, p, tiles_x, txy);
+    LAUNCH_CHECK("conv_stem64_halo");
     return 0;
 }
 
@@ -2240,6 +2413,12 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
     static const bool no_igh = [] { const char* e = getenv("I2V_IGHALO"); return e && e[0] == '0'; }();
     if (conv_ighalo_ok(p) && !no_igh) out[n++] = (p.Cd <= 16 ? 5 : 4) | 512;      // the class-packed image gradient on a 2-D halo tile (conv_imggrad_halo)
     if (conv_stemhalo_ok(p) && !no_igh) out[n++] = 5 | 1024;                       // the narrow forward stem on a 2-D halo tile (conv_stem_halo)
+    // conv_stem64_halo (the wide 7x7 / 2 forward stem on a 2-D halo tile) is built, bit-identical (values and gate words) and faster in
+    // isolation (tools/stem_halo_probe.cpp, 128 frames, random operands: 435 -> 363 us), but in the attack the conv_tile launch it would
+    // replace runs at 351 us and the forward pass was 0.3 % SLOWER with it (same box, alternated, gpurun_out r5u): its scalar epilogue
+    // -- 64 four-byte stores and 64 ballots per lane -- costs what the staging saves.  Offered to the autotuner only on request (I2V_STEM64=1).
+    static const bool want_stem64 = [] { const char* e = getenv("I2V_STEM64"); return e && e[0] == '1'; }();
+    if (conv_stem64_ok(p) && want_stem64) out[n++] = 3 | 1024;
     // conv_pw_stream (one persistent role-split workgroup per CU) is built, bit-identical and SLOWER than conv_igemm on every shape it
     // admits (round 5, tools/pw_stream_probe.cpp, profiles/r5_pw_stream_probe.txt: 56 / 80 / 91 TFLOP/s on 64 -> 256 / 128 -> 512 /
     // 256 -> 1024 at 128 frames against 69 / 108 / 117): offered to the autotuner only on request (I2V_PWS=1), like the fused pair
@@ -2290,6 +2469,10 @@ int k_conv(const I2VConvParams& p_in, i2v_stream_t s) {
     conv_magics(p);
     if (p.cfg <= 0) p.cfg = conv_pick(p) + 1;          // the model's pick -- or $I2V_FORCE_CFG, which may carry the variant bits too
     __atomic_fetch_add(&g_stat_conv, 1, __ATOMIC_RELAXED);
+    if (((p.cfg - 1) & 1024) && conv_stem64_ok(p) && !((uintptr_t)p.src & 15)) {       // wide 7x7 / 2 forward stem on a 2-D halo tile (autotuner bit 10)
+        __atomic_fetch_add(&g_stat_sth, 1, __ATOMIC_RELAXED);
+        return launch_conv_stem64(p, st);
+    }
     if (((p.cfg - 1) & 1024) && conv_stemhalo_ok(p) && !((uintptr_t)p.src & 15)) {     // narrow forward stem on a 2-D halo tile (autotuner bit 10)
         __atomic_fetch_add(&g_stat_sth, 1, __ATOMIC_RELAXED);
         return launch_conv_stemhalo(p, st);

@@ -376,15 +376,18 @@ def test_stem_halo_kernels_are_bit_identical(eng, monkeypatch):
       SlowFast's slow stem (every 8th frame, the rest left to a memset) and its FAST stem (8 channels: the quad-row K order, one
       channel plane per chunk, pairs of sampled frames as temporal classes, accumulating onto the slow stem's result);
     * conv_stem_halo (bit 10: SlowFast's fast stem FORWARD, 3 -> 8 channels in frame pairs, the source window staged once per
-      (channel, frame tap) plane instead of a shifted 256-pixel tile per K chunk);
+      (channel, frame tap) plane instead of a shifted 256-pixel tile per K chunk) and conv_stem64_halo (bit 10 too: the wide 7x7/2
+      stem of ResNet / SlowFast's slow pathway, all 64 channels of a 16 x 16 pixel tile from one staged window, values AND 1-bit gates);
     on sizes that leave partial 16 x 16 tiles: every word of the hooked features and of the input gradient bit for bit.  They are
     the same k-ordered chains."""
     monkeypatch.setenv("I2V_AUTOTUNE", "0")
-    cases = [(graphs.resnet((1, 1, 1, 1), 64, (72, 88), "resnet_w64"), None, 3, 5, 1, 0),
+    cases = [(graphs.resnet((1, 1, 1, 1), 64, (72, 88), "resnet_w64"), None, 3, 5, 1, 0),        # (output 44 wide: gate words not 16-bit aligned per tile row)
+             (graphs.resnet((1, 1, 1, 1), 64, (72, 96), "resnet_w64"), None, 3, 3, 1, 1),
              (graphs.squeezenet(1, (70, 70)), None, 2, 5, 1, 0),
              (graphs.i3d_resnet((1, 1, 1, 1), 64, (8, 40, 56), "i3d_w64", inflate=((1,), (1,), (1,), (0,))), "i3d_resnet50", None, 4, 1, 0),
              (graphs.slowfast_res2(64, (16, 40, 56), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 5, 2, 1),
-             (graphs.slowfast_res2(64, (32, 24, 40), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 4, 2, 1)]
+             (graphs.slowfast_res2(64, (32, 24, 40), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 4, 2, 1),
+             (graphs.slowfast_res2(64, (16, 40, 64), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 3, 2, 2)]
     for g, video_type, depth, base_cfg, expect_grad, expect_fwd in cases:
         sd = weights.synthetic_state_dict(g, 0)
         hooks = graphs.video_hooks(g, video_type) if video_type else [g.hooks[depth]]
