@@ -1578,11 +1578,22 @@ extern "C" int i2v_net_forward(i2v_handle h, int net, const float* x, int frames
     if (!x) return fail("null input");
     n->frames = frames;
     if (n->stage_input) {
-        const Buffer& ib = n->bufs[n->tens[n->input].buf];
-        const size_t bytes = (size_t)frames * ib.C * ib.H * ib.W * sizeof(float);
-        float* staged = n->arena + n->in_stage_off;
-        CHECK_BE(be_d2d_2d(staged, bytes, x, bytes, bytes, 1, stream));
-        x = staged;
+        // The slack around the source is what conv_tile's quad-row staging (MODE 4) needs.  When the autotuner gave every quad-row
+        // launch that reads the input the halo-tile kernel for this batch bucket (configuration bit 10: conv_stem_halo stages whole
+        // windows and range-checks every piece) and the caller's frames are 16-byte aligned, nothing reads outside them and the copy --
+        // 2 % of an ILAF step on SlowFast -- is skipped.
+        static const bool always = [] { const char* e = getenv("I2V_STAGE_COPY"); return e && e[0] == '1'; }();      // (developer knob: A/B)
+        bool need = always || ((uintptr_t)x & 15) != 0;
+        const int bucket = cfg_bucket(frames / n->Tin(), n->maxN / n->Tin());
+        for (const Launch& l : n->fwd)
+            if (l.kind == L_CONV && l.src_is_input && l.conv.quad && !(l.cfg_b[bucket] > 0 && ((l.cfg_b[bucket] - 1) & 1024))) need = true;
+        if (need) {
+            const Buffer& ib = n->bufs[n->tens[n->input].buf];
+            const size_t bytes = (size_t)frames * ib.C * ib.H * ib.W * sizeof(float);
+            float* staged = n->arena + n->in_stage_off;
+            CHECK_BE(be_d2d_2d(staged, bytes, x, bytes, bytes, 1, stream));
+            x = staged;
+        }
     }
     return run_list(h, *n, n->fwd, frames, x, nullptr, 0, stream, false);
 }
