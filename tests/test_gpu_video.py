@@ -417,6 +417,42 @@ def test_stem_halo_kernels_are_bit_identical(eng, monkeypatch):
         assert torch.equal(outs[0][1], outs[1][1]), g.arch
 
 
+def test_autotuned_slowfast_stems_match_the_plain_tiles(eng, monkeypatch):
+    """A SlowFast stem pair of real width planned WITH the autotuner -- which may pick the halo-tile kernels per launch and batch
+    bucket, and then lets `i2v_net_forward` read the caller's frames in place instead of copying them into the arena (the slack
+    only conv_tile's quad-row staging needs) -- against the same net on one forced plain tile (staging copy, conv_tile everywhere):
+    hooked features and input gradient bit for bit, at the planned batch and at a smaller bucket."""
+    g = graphs.slowfast_res2(64, (16, 56, 64), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1)
+    sd = weights.synthetic_state_dict(g, 0)
+    hooks = graphs.video_hooks(g, "slowfast_resnet50")
+    T = g.tensors[g.input].T
+    outs = {}
+    for mode in ("auto", "plain"):
+        if mode == "plain":
+            monkeypatch.setenv("I2V_AUTOTUNE", "0"); monkeypatch.setenv("I2V_FORCE_CFG", "5")
+        net = eng.build_net(g, sd, hooks, 4 * T)
+        for clips in (4, 1):
+            frames = clips * T
+            x = dev(torch.randn(frames, 3, *g.in_hw, generator=torch.Generator().manual_seed(clips)))
+            before = eng.capi.i2v_backend_stat(b"stemhalo_launches")
+            net.forward(x)
+            feats = [net.save_hook(i, clips * hi.T).cpu() for i, hi in enumerate(net.hooks)]
+            hg = [torch.randn(f.shape, generator=torch.Generator().manual_seed(3 + i)) for i, f in enumerate(feats)]
+            write_hook_grads(net, feats, hg)
+            gx = torch.full((frames, 3, *g.in_hw), float("nan"), device="cuda:0")
+            net.backward(gx)
+            torch.cuda.synchronize()
+            outs[(mode, clips)] = (feats, gx.cpu(), eng.capi.i2v_backend_stat(b"stemhalo_launches") - before)
+        net.close()
+    for clips in (4, 1):
+        fa, ga, used = outs[("auto", clips)]
+        fb, gb, _ = outs[("plain", clips)]
+        print(f"clips {clips}: conv_stem_halo launches in the autotuned forward pass: {used}")
+        for a, b in zip(fa, fb):
+            assert torch.equal(a, b), clips
+        assert torch.equal(ga, gb) and torch.isfinite(ga).all(), clips
+
+
 def test_batch_buckets_of_the_autotuner_are_bit_identical(eng):
     """Round 3: a planned net keeps one tuned tile configuration per batch bucket (its planned size, 1/2, 1/4, 1/8 of it) and a call
     picks the bucket that covers its frames -- whatever it picks, a frame's result is the one a net planned for exactly that batch
