@@ -80,9 +80,14 @@ struct Node {
     float* shift_d = nullptr; float* pre_scale_d = nullptr; float* pre_shift_d = nullptr;   // *_d padded to Kpad
     bool preact() const { return !pre_scale.empty(); }
     Packed fwd; std::vector<Packed> bwd;
-    Packed img; int img_blk = 0, img_sh = 1, img_blkt = 1;   // input-gradient of the first conv (class-packed)
-    int img_ost = 1, img_ot0 = 0;                            // its temporal output stride / offset
-    int img_st = 1, img_oct = 1; bool img_skips = false;     // dz frames per grid frame, frames between its temporal classes, frames left to a memset
+    // input gradient of a convolution that reads the network input (class-packed): one launch -- or one per temporal class (pack_img)
+    struct ImgGrad {
+        Packed P; int blk = 0, sh = 1, blkt = 1;
+        int ost = 1, ot0 = 0;                                // temporal output stride / offset
+        int st = 1, oct = 1; bool skips = false;             // dz frames per grid frame, frames between its temporal classes, frames left to a memset
+        double flop_share = 1.0;                             // this launch's part of the node's algorithmic flops
+    };
+    std::vector<ImgGrad> imgs;
     size_t idx_off = 0;                           // maxpool: arg-max bytes, arena offset in floats
 };
 
@@ -327,7 +332,9 @@ static int pack_bwd(Net& n, Node& nd) {
 // cut into B x B position blocks (B = stride, or 2 for stride 1) and the B*B*Cin (class, channel)
 // pairs form the Cd axis: out[(ph,pw),ci][i][j] = sum_{co,dh,dw} w'[(co,dh,dw)][(ph,pw),ci] *
 // dz[co][i*m + dh][j*m + dw], m = B/stride, with zero weights where a class has no such tap.
-static int pack_img(Net& n, Node& nd) {
+// `only_ct` >= 0: pack that temporal class ALONE -- grid = its own frames, its own frame taps --, as the frame-skipping case below does
+// for the one class that has taps (pack_img decides when a dense temporal stride is split into one launch per class).
+static int pack_img_one(Net& n, Node& nd, Node::ImgGrad& ig, const int only_ct) {
     const i2v_conv3d_desc& c = nd.cd;
     const Buffer& sb = n.bufs[n.tens[c.src].buf];
     const Buffer& db = n.bufs[n.tens[c.dst].buf];
@@ -343,7 +350,9 @@ static int pack_img(Net& n, Node& nd) {
         for (int q = 0; q < c.kt; ++q) if (posmod(ct + c.pad_t - q * c.dil_t, stt) == 0) any = true;
         if (any) { with_taps++; only = ct; }
     }
-    const bool sparse = stt > 1 && with_taps == 1;
+    const bool forced = only_ct >= 0;
+    if (forced) only = only_ct;
+    const bool sparse = forced || (stt > 1 && with_taps == 1);
     int Bt = sparse ? 1 : stt; const int ct0 = sparse ? only : 0;
     static const bool no_tpair = [] { const char* e = getenv("I2V_TPAIR"); return e && e[0] == '0'; }();
     // (Tried and dropped for the DENSE temporal stride of I3D's stem: two stride periods per grid frame -- 48 of 64 rows over 4 dz frames
@@ -356,7 +365,7 @@ static int pack_img(Net& n, Node& nd) {
     // time (SlowFast's fast stem: every 2nd frame, 5 taps) gives each sampled frame 5 dz frames, two neighbouring sampled frames 6
     // between them -- both as temporal classes of ONE grid frame: 24 of 32 rows over 6 frame taps instead of two launches' worth
     // of 12 of 16 rows over 5.  The classes lie stt frames apart (I2VConvParams::oct).  Zero weights where a class has no tap: same bits.
-    const bool pairs = sparse && !no_tpair && dt_hi > dt_lo && 2 * B * B * c.cin <= 32 && (sb.T - ct0 + stt - 1) / stt >= 2;
+    const bool pairs = sparse && !forced && !no_tpair && dt_hi > dt_lo && 2 * B * B * c.cin <= 32 && (sb.T - ct0 + stt - 1) / stt >= 2;
     if (pairs) { Bt = 2; dt_hi += 1; }
     for (int ph = 0; ph < B; ++ph)
         for (int r = 0; r < c.kh; ++r)
@@ -365,7 +374,7 @@ static int pack_img(Net& n, Node& nd) {
         for (int s = 0; s < c.kw; ++s)
             if (posmod(pw + c.pad - s, st) == 0) { int d = floordiv(pw + c.pad - s, st); dw_lo = d < dw_lo ? d : dw_lo; dw_hi = d > dw_hi ? d : dw_hi; }
     const int TT = dt_hi - dt_lo + 1, TH = dh_hi - dh_lo + 1, TW = dw_hi - dw_lo + 1;
-    Packed& P = nd.img;
+    Packed& P = ig.P;
     // few output channels (SlowFast's fast stem: 8) cannot use the tap-uniform path; instead of the per-row path they take the
     // "quad rows" order (channel, frame tap, row tap, column-tap quad x 4): see pack_fwd
     static const bool no_quad = [] { const char* e = getenv("I2V_QUAD"); return e && e[0] == '0'; }();
@@ -385,8 +394,15 @@ static int pack_img(Net& n, Node& nd) {
     if (P.tap_uniform) { P.ig_tt = TT; P.ig_th = TH; P.ig_tw = TW; }
     else if (quad && TWq == 4 && TH == 4) { P.ig_tt = TT; P.ig_th = TH; P.ig_tw = TWq; }      // (conv_imggrad_halo, QUAD: one 4 x 4 plane per chunk)
     P.Tg = sparse ? (sb.T - ct0 + stt - 1) / stt : (sb.T + Bt - 1) / Bt; P.Hg = (sb.H + B - 1) / B; P.Wg = (sb.W + B - 1) / B;
-    nd.img_blk = B; nd.img_sh = m; nd.img_blkt = Bt; nd.img_ost = sparse ? stt : Bt; nd.img_ot0 = ct0; nd.img_skips = sparse;
-    if (pairs) { P.Tg = (P.Tg + 1) / 2; nd.img_ost = 2 * stt; nd.img_st = 2; nd.img_oct = stt; }
+    ig.blk = B; ig.sh = m; ig.blkt = Bt; ig.ost = sparse ? stt : Bt; ig.ot0 = ct0; ig.skips = sparse && !forced;
+    if (pairs) { P.Tg = (P.Tg + 1) / 2; ig.ost = 2 * stt; ig.st = 2; ig.oct = stt; }
+    {   // this launch's part of the node's algorithmic flops: its classes' frame taps over all of them
+        int mine = 0, all = 0;
+        for (int ct = 0; ct < stt; ++ct)
+            for (int q = 0; q < c.kt; ++q)
+                if (posmod(ct + c.pad_t - q * c.dil_t, stt) == 0) { ++all; if (!forced || ct == only_ct) ++mine; }
+        ig.flop_share = all > 0 ? (double)mine / all : 1.0;
+    }
     std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
     std::vector<I2VKEntry> kt(P.Kpad, I2VKEntry{0, 0, 0, 0});
     // K order = (16-channel chunk, tap, channel in chunk) when the channel count allows: every 16-row K chunk
@@ -427,6 +443,32 @@ static int pack_img(Net& n, Node& nd) {
     for (const I2VKEntry& e : kt) if (e.valid >> 1) P.has_dt = 1;
     if (upload(n, wp, &P.wp)) return 1;
     return upload(n, kt, &P.ktab);
+}
+
+// The input gradient of a stem as one class-packed launch -- or, for a DENSE temporal stride (I3D: 5x7x7 / (2,2,2): two temporal classes
+// with 3 and 2 frame taps), one launch per temporal class: packed together the classes share the union of their frame taps (3) and a
+// 32-row fragment (24 of 32 rows), alone each runs its own taps on 12 of 16 rows -- 5 x 16 instead of 3 x 32 row-taps per pair of
+// frames, and the 16-row conv_imggrad_halo keeps six blocks per CU where the 32-row one keeps four.  Only when that kernel is among the
+// candidates (tap-uniform packing of a stride-2 stem, I2V_IGHALO not 0): conv_tile prefers the packed form.  A zero weight adds an exact
+// +0 to the k-ordered chain and the real taps keep their order: same bits either way.
+static int pack_img(Net& n, Node& nd) {
+    const i2v_conv3d_desc& c = nd.cd;
+    const int stt = c.stride_t, B = c.stride == 1 ? 2 : c.stride;
+    static const bool no_igh = [] { const char* e = getenv("I2V_IGHALO"); return e && e[0] == '0'; }();
+    const char* const es = getenv("I2V_IMG_SPLIT"); const bool no_split = es && es[0] == '0';      // (read per plan: tests compare the two packings)
+    int classes_with_taps = 0;
+    for (int ct = 0; ct < stt; ++ct) {
+        bool any = false;
+        for (int q = 0; q < c.kt; ++q) if (posmod(ct + c.pad_t - q * c.dil_t, stt) == 0) any = true;
+        classes_with_taps += any ? 1 : 0;
+    }
+    const bool split = !no_igh && !no_split && stt > 1 && classes_with_taps == stt && c.cout % I2V_KC == 0 && c.stride == 2 && B * B * c.cin <= 16 &&
+                       c.kh <= 8 && c.kw <= 8 && (((c.kh + 1) / 2) * ((c.kw + 1) / 2)) % 4 == 0 && n.bufs[n.tens[c.src].buf].T >= stt;
+    nd.imgs.clear();
+    if (!split) { nd.imgs.emplace_back(); return pack_img_one(n, nd, nd.imgs.back(), -1); }
+    nd.imgs.resize(stt);
+    for (int ct = 0; ct < stt; ++ct) if (pack_img_one(n, nd, nd.imgs[ct], ct)) return 1;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -926,7 +968,7 @@ struct Planner {
         }
         // ---------------- backward ----------------
         for (const Node& nd : n.nodes)
-            if (nd.type == 0 && nd.cd.src == n.input && nd.img_skips) {     // a stem gradient that skips frames
+            if (nd.type == 0 && nd.cd.src == n.input && !nd.imgs.empty() && nd.imgs[0].skips) {     // a stem gradient that skips frames
                 const Buffer& ib = n.bufs[n.tens[n.input].buf];
                 Launch l; l.kind = L_MEMSET; l.ms_gx = true; l.ms_floats_per_frame = (size_t)ib.C * ib.H * ib.W; l.T = ib.T;
                 emit(n.bwd, l);
@@ -980,17 +1022,20 @@ struct Planner {
                 const i2v_conv3d_desc& c = nd.cd;
                 if (c.residual >= 0 && !contribute_alias(c.residual, dz)) return false;
                 if (c.src == n.input) {
-                    Launch l; l.kind = L_IMGGRAD; conv_common(l.conv, nd.img);
-                    l.img_accumulate = img_seen++ > 0;
+                    const bool acc_node = img_seen++ > 0;          // (a node's temporal classes write disjoint frames: one flag for all of them)
+                    for (const Node::ImgGrad& ig : nd.imgs) {
+                    Launch l; l.kind = L_IMGGRAD; conv_common(l.conv, ig.P);
+                    l.img_accumulate = acc_node;
                     const Buffer& ib = n.bufs[n.tens[n.input].buf];
                     I2VConvParams& p = l.conv;
                     p.src = dz.p; p.src_nstride = dz.nstride; p.Hs = dz.H; p.Ws = dz.W; p.Cs = dz.C;
-                    p.Hg = nd.img.Hg; p.Wg = nd.img.Wg; p.sh = p.sw = nd.img_sh;
+                    p.Hg = ig.P.Hg; p.Wg = ig.P.Wg; p.sh = p.sw = ig.sh;
                     p.dst = nullptr; p.dst_nstride = (int64_t)ib.C * ib.H * ib.W; p.Ho = ib.H; p.Wo = ib.W;
-                    p.osh = p.osw = nd.img_blk; p.blk = nd.img_blk;
-                    p.blkt = nd.img_blkt; p.Tg = nd.img.Tg; p.Ts = dz.T; p.st = nd.img_st; p.To = ib.T; p.ost = nd.img_ost; p.ot0 = nd.img_ot0; p.oct = nd.img_oct; l.T = nd.img.Tg;
-                    l.alg_flops_per_frame = 2.0 * dz.T * dz.H * dz.W * c.cout * c.cin * c.kt * c.kh * c.kw / nd.img.Tg;   // per grid frame
+                    p.osh = p.osw = ig.blk; p.blk = ig.blk;
+                    p.blkt = ig.blkt; p.Tg = ig.P.Tg; p.Ts = dz.T; p.st = ig.st; p.To = ib.T; p.ost = ig.ost; p.ot0 = ig.ot0; p.oct = ig.oct; l.T = ig.P.Tg;
+                    l.alg_flops_per_frame = ig.flop_share * 2.0 * dz.T * dz.H * dz.W * c.cout * c.cin * c.kt * c.kh * c.kw / ig.P.Tg;   // per grid frame
                     emit(n.bwd, l);
+                    }
                 } else if (nd.preact()) {
                     // G(view) += W'^T dz gated by the pre-activation sign; W' carries the BN scale per input channel
                     View g = view(c.src, true), x = view(c.src, false);

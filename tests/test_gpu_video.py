@@ -372,7 +372,8 @@ def test_stem_halo_kernels_are_bit_identical(eng, monkeypatch):
     """The two 2-D halo-tile kernels of round 5 against the conv_tile launches they replace, forced onto real-width stems:
     * conv_imggrad_halo (autotuner bit 9: the class-packed image gradient, one staged window per 16-channel group and frame tap
       instead of one shifted copy per tap) -- ResNet's 7x7/2 with 64 channels (12 class rows), SqueezeNet 1.1's 3x3/2 (2 x 2 union
-      taps: one four-tap group per stage), the I3D's 5x7x7 / (2,2,2) (24 class rows, three frame taps, frame taps outside the clip),
+      taps: one four-tap group per stage), the I3D's 5x7x7 / (2,2,2) (one launch per temporal class: three and two frame taps, frame
+      taps outside the clip, an odd frame count),
       SlowFast's slow stem (every 8th frame, the rest left to a memset) and its FAST stem (8 channels: the quad-row K order, one
       channel plane per chunk, pairs of sampled frames as temporal classes, accumulating onto the slow stem's result);
     * conv_stem_halo (bit 10: SlowFast's fast stem FORWARD, 3 -> 8 channels in frame pairs, the source window staged once per
@@ -384,7 +385,8 @@ def test_stem_halo_kernels_are_bit_identical(eng, monkeypatch):
     cases = [(graphs.resnet((1, 1, 1, 1), 64, (72, 88), "resnet_w64"), None, 3, 5, 1, 0),        # (output 44 wide: gate words not 16-bit aligned per tile row)
              (graphs.resnet((1, 1, 1, 1), 64, (72, 96), "resnet_w64"), None, 3, 3, 1, 1),
              (graphs.squeezenet(1, (70, 70)), None, 2, 5, 1, 0),
-             (graphs.i3d_resnet((1, 1, 1, 1), 64, (8, 40, 56), "i3d_w64", inflate=((1,), (1,), (1,), (0,))), "i3d_resnet50", None, 4, 1, 0),
+             (graphs.i3d_resnet((1, 1, 1, 1), 64, (8, 40, 56), "i3d_w64", inflate=((1,), (1,), (1,), (0,))), "i3d_resnet50", None, 4, 2, 0),        # (one launch per temporal class)
+             (graphs.i3d_resnet((1, 1, 1, 1), 64, (7, 40, 56), "i3d_w64", inflate=((1,), (1,), (1,), (0,))), "i3d_resnet50", None, 5, 2, 0),
              (graphs.slowfast_res2(64, (16, 40, 56), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 5, 2, 1),
              (graphs.slowfast_res2(64, (32, 24, 40), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 4, 2, 1),
              (graphs.slowfast_res2(64, (16, 40, 64), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 3, 2, 2)]
@@ -451,6 +453,34 @@ def test_autotuned_slowfast_stems_match_the_plain_tiles(eng, monkeypatch):
         for a, b in zip(fa, fb):
             assert torch.equal(a, b), clips
         assert torch.equal(ga, gb) and torch.isfinite(ga).all(), clips
+
+
+def test_i3d_stem_gradient_split_by_temporal_class_is_bit_identical(eng, monkeypatch):
+    """The I3D stem's input gradient as one launch per temporal class (round 5, pack_img; conv_imggrad_halo on 16-row fragments) against
+    the single launch over both classes (24 of 32 rows, union of the frame taps): bit for bit on the device, halo kernel forced in both."""
+    monkeypatch.setenv("I2V_AUTOTUNE", "0")
+    monkeypatch.setenv("I2V_FORCE_CFG", str(4 | 512))
+    g = graphs.i3d_resnet((1, 1, 1, 1), 64, (9, 40, 56), "i3d_w64", inflate=((1,), (1,), (1,), (0,)))
+    sd = weights.synthetic_state_dict(g, 0)
+    hooks = graphs.video_hooks(g, "i3d_resnet50")
+    T = g.tensors[g.input].T
+    x = dev(torch.randn(2 * T, 3, *g.in_hw, generator=torch.Generator().manual_seed(0)))
+    outs = []
+    for split, expect in (("1", 2), ("0", 1)):
+        monkeypatch.setenv("I2V_IMG_SPLIT", split)
+        net = eng.build_net(g, sd, hooks, 2 * T)
+        net.forward(x)
+        feats = [net.save_hook(i, 2 * hi.T).cpu() for i, hi in enumerate(net.hooks)]
+        hg = [torch.randn(f.shape, generator=torch.Generator().manual_seed(7 + i)) for i, f in enumerate(feats)]
+        write_hook_grads(net, feats, hg)
+        before = eng.capi.i2v_backend_stat(b"ighalo_launches")
+        gx = torch.full((2 * T, 3, *g.in_hw), float("nan"), device="cuda:0")
+        net.backward(gx)
+        torch.cuda.synchronize()
+        assert eng.capi.i2v_backend_stat(b"ighalo_launches") - before == expect
+        outs.append(gx.cpu())
+        net.close()
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
 
 
 def test_batch_buckets_of_the_autotuner_are_bit_identical(eng):

@@ -193,3 +193,35 @@ def test_ilaf_kernels_against_autograd():
     eng.sign_step_delta_gx(delta, gx, u, eps, step)
     assert torch.equal(delta, want) and mask.float().mean() < 1
     net.close()
+
+
+@pytest.mark.parametrize("thw", [(8, 24, 40), (7, 20, 20)])
+def test_stem_gradient_per_temporal_class_equals_the_packed_launch(thw, monkeypatch):
+    """Round 5: the input gradient of a stem with a DENSE temporal stride (the I3D's 5x7x7 / (2,2,2)) runs as one launch per temporal
+    class when the 16-row halo-tile kernel is a candidate (pack_img) instead of one launch over the union of the classes' frame
+    taps: zero weights add exact zeros to the k-ordered chains and the real taps keep their order, so the two packings must agree
+    bit for bit -- here on the host simulation, with a stem of 16 channels (the split needs whole 16-channel groups), an odd frame
+    count included, and accumulating onto an existing gradient."""
+    eng = hostsim_engine()
+    g = graphs.i3d_resnet((1, 1, 1, 1), 16, thw, "i3d_w16", inflate=((1,), (1,), (1,), (0,)))
+    sd = weights.synthetic_state_dict(g, 2)
+    hooks = [g.hooks[2]]
+    T, clips = thw[0], 2
+    x = torch.randn(clips * T, 3, thw[1], thw[2], generator=torch.Generator().manual_seed(1))
+    outs = []
+    for split in ("1", "0"):
+        monkeypatch.setenv("I2V_IMG_SPLIT", split)
+        net = eng.build_net(g, sd, hooks, clips * T)
+        net.forward(x)
+        nf = net.hook_frames(0, clips * T)
+        f = net.save_hook(0, nf)
+        hg = torch.randn(f.shape, generator=torch.Generator().manual_seed(4))
+        write_hook_grads(net, [f], [hg], None)
+        gx = torch.full((clips * T, 3, thw[1], thw[2]), float("nan"))
+        net.backward(gx)
+        gacc = gx.clone()
+        net.backward(gacc, accumulate=True)
+        outs.append((gx, gacc))
+        net.close()
+    assert torch.isfinite(outs[0][0]).all() and float(outs[0][0].abs().max()) > 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
