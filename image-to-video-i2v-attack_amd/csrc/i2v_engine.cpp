@@ -332,6 +332,13 @@ static int pack_bwd(Net& n, Node& nd) {
 // cut into B x B position blocks (B = stride, or 2 for stride 1) and the B*B*Cin (class, channel)
 // pairs form the Cd axis: out[(ph,pw),ci][i][j] = sum_{co,dh,dw} w'[(co,dh,dw)][(ph,pw),ci] *
 // dz[co][i*m + dh][j*m + dw], m = B/stride, with zero weights where a class has no such tap.
+// The packings that suit the 16-row halo-tile kernel (conv_imggrad_halo) are chosen when it is among the autotuner's candidates
+// (I2V_IGHALO not 0) and not switched off (I2V_IMG_SPLIT=0: the round-3 packings; read per plan so that tests can compare the two)
+static bool img_prefer_16_rows() {
+    static const bool no_igh = [] { const char* e = getenv("I2V_IGHALO"); return e && e[0] == '0'; }();
+    const char* const es = getenv("I2V_IMG_SPLIT");
+    return !no_igh && !(es && es[0] == '0');
+}
 // `only_ct` >= 0: pack that temporal class ALONE -- grid = its own frames, its own frame taps --, as the frame-skipping case below does
 // for the one class that has taps (pack_img decides when a dense temporal stride is split into one launch per class).
 static int pack_img_one(Net& n, Node& nd, Node::ImgGrad& ig, const int only_ct) {
@@ -361,19 +368,26 @@ static int pack_img_one(Net& n, Node& nd, Node::ImgGrad& ig, const int only_ct) 
     for (int ct = ct0; ct < ct0 + Bt; ++ct)
         for (int q = 0; q < c.kt; ++q)
             if (posmod(ct + c.pad_t - q * c.dil_t, stt) == 0) { int d = floordiv(ct + c.pad_t - q * c.dil_t, stt); dt_lo = d < dt_lo ? d : dt_lo; dt_hi = d > dt_hi ? d : dt_hi; }
-    // Pairs of SAMPLED frames (round 3; the gradient-side twin of pack_fwd's frame pairs): a frame-skipping stem whose kernel spans
-    // time (SlowFast's fast stem: every 2nd frame, 5 taps) gives each sampled frame 5 dz frames, two neighbouring sampled frames 6
-    // between them -- both as temporal classes of ONE grid frame: 24 of 32 rows over 6 frame taps instead of two launches' worth
-    // of 12 of 16 rows over 5.  The classes lie stt frames apart (I2VConvParams::oct).  Zero weights where a class has no tap: same bits.
-    const bool pairs = sparse && !forced && !no_tpair && dt_hi > dt_lo && 2 * B * B * c.cin <= 32 && (sb.T - ct0 + stt - 1) / stt >= 2;
-    if (pairs) { Bt = 2; dt_hi += 1; }
     for (int ph = 0; ph < B; ++ph)
         for (int r = 0; r < c.kh; ++r)
             if (posmod(ph + c.pad - r, st) == 0) { int d = floordiv(ph + c.pad - r, st); dh_lo = d < dh_lo ? d : dh_lo; dh_hi = d > dh_hi ? d : dh_hi; }
     for (int pw = 0; pw < B; ++pw)
         for (int s = 0; s < c.kw; ++s)
             if (posmod(pw + c.pad - s, st) == 0) { int d = floordiv(pw + c.pad - s, st); dw_lo = d < dw_lo ? d : dw_lo; dw_hi = d > dw_hi ? d : dw_hi; }
-    const int TT = dt_hi - dt_lo + 1, TH = dh_hi - dh_lo + 1, TW = dw_hi - dw_lo + 1;
+    const int TH = dh_hi - dh_lo + 1, TW = dw_hi - dw_lo + 1;
+    // Pairs of SAMPLED frames (round 3; the gradient-side twin of pack_fwd's frame pairs): a frame-skipping stem whose kernel spans
+    // time (SlowFast's fast stem: every 2nd frame, 5 taps) gives each sampled frame 5 dz frames, two neighbouring sampled frames 6
+    // between them -- both as temporal classes of ONE grid frame: 24 of 32 rows over 6 frame taps instead of two launches' worth
+    // of 12 of 16 rows over 5.  The classes lie stt frames apart (I2VConvParams::oct).  Zero weights where a class has no tap: same bits.
+    // ... unless the 16-row halo-tile kernel can take the UNPAIRED quad-row packing (round 5: a 4 x 4 tap window, the frame-tap planes of
+    // 1, 2 or 4 channels -- a whole number of four-chunk groups -- within its 20 planes): 12 of 16 rows over the sampled frame's own 5
+    // taps is 17 % less matrix work than 24 of 32 over 6, and that kernel stages a plane once whatever the row count.
+    const int TTu = dt_hi - dt_lo + 1, cps_u = TTu % 4 == 0 ? 1 : TTu % 2 == 0 ? 2 : 4;
+    const bool unpaired_halo = img_prefer_16_rows() && c.cout % I2V_KC != 0 && TH == 4 && TW >= 2 && TW <= 4 && c.cout % cps_u == 0 && cps_u * TTu <= 20 &&
+                               B * B * c.cin <= 16 && m == 1;
+    const bool pairs = sparse && !forced && !no_tpair && !unpaired_halo && dt_hi > dt_lo && 2 * B * B * c.cin <= 32 && (sb.T - ct0 + stt - 1) / stt >= 2;
+    if (pairs) { Bt = 2; dt_hi += 1; }
+    const int TT = dt_hi - dt_lo + 1;
     Packed& P = ig.P;
     // few output channels (SlowFast's fast stem: 8) cannot use the tap-uniform path; instead of the per-row path they take the
     // "quad rows" order (channel, frame tap, row tap, column-tap quad x 4): see pack_fwd
@@ -454,15 +468,13 @@ static int pack_img_one(Net& n, Node& nd, Node::ImgGrad& ig, const int only_ct) 
 static int pack_img(Net& n, Node& nd) {
     const i2v_conv3d_desc& c = nd.cd;
     const int stt = c.stride_t, B = c.stride == 1 ? 2 : c.stride;
-    static const bool no_igh = [] { const char* e = getenv("I2V_IGHALO"); return e && e[0] == '0'; }();
-    const char* const es = getenv("I2V_IMG_SPLIT"); const bool no_split = es && es[0] == '0';      // (read per plan: tests compare the two packings)
     int classes_with_taps = 0;
     for (int ct = 0; ct < stt; ++ct) {
         bool any = false;
         for (int q = 0; q < c.kt; ++q) if (posmod(ct + c.pad_t - q * c.dil_t, stt) == 0) any = true;
         classes_with_taps += any ? 1 : 0;
     }
-    const bool split = !no_igh && !no_split && stt > 1 && classes_with_taps == stt && c.cout % I2V_KC == 0 && c.stride == 2 && B * B * c.cin <= 16 &&
+    const bool split = img_prefer_16_rows() && stt > 1 && classes_with_taps == stt && c.cout % I2V_KC == 0 && c.stride == 2 && B * B * c.cin <= 16 &&
                        c.kh <= 8 && c.kw <= 8 && (((c.kh + 1) / 2) * ((c.kw + 1) / 2)) % 4 == 0 && n.bufs[n.tens[c.src].buf].T >= stt;
     nd.imgs.clear();
     if (!split) { nd.imgs.emplace_back(); return pack_img_one(n, nd, nd.imgs.back(), -1); }

@@ -1155,15 +1155,16 @@ static constexpr int IGH_RS = 20, IGH_PL = 400, IGH_NPC = 6;      // LDS row / p
                                                                   // fragment read land on disjoint bank halves), DMA pieces per plane
 // QUAD: the "quad rows" packing of a stem with fewer than 16 output channels (SlowFast's fast pathway: 8), K order (channel, frame tap, row
 // tap, column tap x 4) with 4 x 4 taps: a K chunk is ONE channel plane of one frame tap, k-step s is row tap s and a lane's K row lk is column
-// tap lk.  A stage then holds the TT frame-tap planes of 1, 2 or 4 channels (whichever makes a whole number of four-chunk groups: <= 16 planes)
-// and a chunk moves on by a plane instead of by a tap shift.  The zero-weight taps that pad a 7-wide kernel to two quads read real (finite)
+// tap lk.  A stage then holds the TT frame-tap planes of 1, 2 or 4 channels (whichever makes a whole number of four-chunk groups)
+// and a chunk moves on by a plane instead of by a tap shift (<= 20 planes: the fast stem's gradient UNPAIRED has five frame taps of four channels).  The zero-weight taps that pad a 7-wide kernel to two quads read real (finite)
 // pixels here where conv_tile's MODE 4 substitutes zeros: the product is a zero either way and the chain's value the same.
 template <int TD, bool VID, bool QUAD = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TD == 1 ? 6 : 4, TD == 1 ? 6 : 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TD == 2 ? 4 : QUAD ? 5 : 6, TD == 2 ? 4 : QUAD ? 5 : 6)))      // (QUAD: 32 KB of LDS)
 conv_imggrad_halo(const I2VConvParams p, const int tiles_x, const int tiles_xy) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int KC = I2V_KC, RS = IGH_RS, PL = IGH_PL, NPC = IGH_NPC;
-    __shared__ __attribute__((aligned(16))) float Hb[KC * PL];             // 25 600 bytes: six blocks per CU (TD = 2: four, by registers)
+    constexpr int NPLMAX = QUAD ? 20 : KC;                                 // planes of a stage (QUAD: five frame taps of four channels)
+    __shared__ __attribute__((aligned(16))) float Hb[NPLMAX * PL];         // 25 600 bytes: six blocks per CU (TD = 2: four, by registers); QUAD: 32 000, five
     typedef __attribute__((address_space(3))) float* lds_fp_t;
     constexpr unsigned OOB = 0x80000000u;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1218,7 +1219,7 @@ conv_imggrad_halo(const I2VConvParams p, const int tiles_x, const int tiles_xy) 
     auto issue_stage = [&](const int q) {
         const int g = QUAD ? 0 : VID ? __builtin_amdgcn_readfirstlane(q / TT) : q, tt0 = QUAD ? 0 : VID ? q - g * TT : 0;
 #pragma unroll
-        for (int pl = 0; pl < 4; ++pl) {
+        for (int pl = 0; pl < NPLMAX / 4; ++pl) {
             const int plane = wv + 4 * pl;
             if (QUAD && plane >= npl) break;
             const int cl = QUAD ? (plane >= TT) + (plane >= 2 * TT) + (plane >= 3 * TT) : 0;      // QUAD: plane = cl TT + tt
@@ -1359,7 +1360,7 @@ static bool conv_ighalo_ok(const I2VConvParams& p) {
     if (p.quad) {       // quad-row order: a chunk is the 4 x 4 taps of one (channel, frame tap) plane
         if (p.quad != 1 || p.ig_th != 4 || p.ig_tw != 4 || p.K != p.Cs * TT * 16) return false;
         const int cps = TT % 4 == 0 ? 1 : TT % 2 == 0 ? 2 : 4;
-        return cps * TT <= 16 && p.Cs % cps == 0;
+        return cps * TT <= 20 && p.Cs % cps == 0;
     }
     return p.tap_uniform && p.ig_th <= 4 && p.ig_tw <= 4 && (p.ig_th * p.ig_tw) % 4 == 0 && p.Cs % I2V_KC == 0 && p.K == TT * p.ig_th * p.ig_tw * p.Cs;
 }
