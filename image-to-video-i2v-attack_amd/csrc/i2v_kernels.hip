@@ -1151,6 +1151,8 @@ conv_igemm_halo(const I2VConvParams p, const int n_cd_tiles) {
 // two-buffer version still took 458 us).  Shipped: one buffer.  The ceiling of this formulation is 157 x 12/16 rows x 49/64 taps x
 // ~0.9 (raw fp32 MFMA issue on this part, tools/mfma_rate.cpp) = 80.  The I3D's stem (TD = 2, 24 of 32 rows, 5 of 6 frame taps; 4 blocks per
 // CU by registers -- compiled for 5 it spills and gains nothing): 58.5 -> 64.4 TFLOP/s, against a ceiling of 157 x 24/32 x 49/64 x 5/6 x 0.9 = 68.
+// (Since pack_img packs a dense temporal stride as ONE LAUNCH PER TEMPORAL CLASS when this kernel is a candidate -- 12 of 16 rows, each class
+// its own frame taps, TD = 1 at six blocks per CU: 74 TFLOP/s on that stem -- TD = 2 runs only under I2V_IMG_SPLIT=0.)
 static constexpr int IGH_RS = 20, IGH_PL = 400, IGH_NPC = 6;      // LDS row / plane stride in floats (400 % 32 == 16: the four K rows of a
                                                                   // fragment read land on disjoint bank halves), DMA pieces per plane
 // QUAD: the "quad rows" packing of a stem with fewer than 16 output channels (SlowFast's fast pathway: 8), K order (channel, frame tap, row
