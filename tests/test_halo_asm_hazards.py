@@ -104,3 +104,15 @@ def test_no_instruction_touches_a_register_with_a_load_in_flight(tmp_path):
         assert loads >= 8, (k, loads)                    # the ring is there (the walk would pass vacuously on an empty stream)
         hits = scan(body)
         assert not hits, (k, hits[:5])
+        # M0 (the LDS-DMA base) is written by the kernels' own asm and is not on its clobber list (the compiler rejects reserved registers
+        # there): that is sound only while nothing else in the kernel touches M0 -- every mention must be one of those writes, each
+        # followed by its `s_nop` and its `buffer_load ... lds`
+        ins = [l.split(";")[0].strip() for l in body]
+        ins = [t for t in ins if t and not t.startswith(".") and not t.endswith(":")]
+        dma = 0
+        for i, t in enumerate(ins):
+            if re.search(r"\bm0\b", t):
+                assert re.match(r"s_mov_b32 m0, s\d+$", t), (k, t)
+                assert ins[i + 1].startswith("s_nop") and ins[i + 2].startswith("buffer_load_dword") and ins[i + 2].endswith(" lds"), (k, ins[i:i + 3])
+                dma += 1
+        assert dma == sum(1 for t in ins if t.startswith("buffer_load_dword") and t.endswith(" lds")) and dma >= 5, (k, dma)
