@@ -1420,12 +1420,15 @@ static int autotune(Net& n) {
                 auto time_cfg = [&](int cfg_plus_1, float* per_launch) -> int {
                     l.conv.cfg = cfg_plus_1;
                     if (conv_run(l, lf, xin, scratch + img, 0, nullptr)) return 1;                   // warm-up
+                    // (the stem gradients -- one to three launches per net, their candidates 5-15 % apart -- are timed over four launches: with two,
+                    //  alternated runs of one build disagreed about the I3D stem's kernel, an 8 % difference on 18 % of an ILAF step)
+                    const int reps = l.kind == L_IMGGRAD ? 4 : 2;
                     be_event_record(e0, nullptr);
-                    for (int r = 0; r < 2; ++r) if (conv_run(l, lf, xin, scratch + img, 0, nullptr)) return 1;
+                    for (int r = 0; r < reps; ++r) if (conv_run(l, lf, xin, scratch + img, 0, nullptr)) return 1;
                     be_event_record(e1, nullptr);
                     if (be_stream_sync(nullptr)) return 1;
                     float ms = 0.f; be_event_elapsed_ms(e0, e1, &ms);
-                    *per_launch = ms / 2;
+                    *per_launch = ms / reps;
                     return 0;
                 };
                 float best = 1e30f; int best_c = -1;
