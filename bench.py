@@ -59,7 +59,7 @@ def build_id():
     return h.hexdigest()[:16]
 
 
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r5_traffic_by_instantiation.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r6_traffic_by_instantiation.json")
 PMC_MFMA_BUSY = None      # MFMA-busy fraction of the conv launches from the same PMC summary (same build-id rule as the traffic)
 
 
@@ -72,7 +72,7 @@ def measured_traffic():
         with open(TRAFFIC_JSON) as fh:
             t = json.load(fh)
         if t.get("build_id") != build_id():
-            return None, f"profiles/r5_traffic_by_instantiation.json is from build {t.get('build_id')}, running {build_id()}"
+            return None, f"profiles/r6_traffic_by_instantiation.json is from build {t.get('build_id')}, running {build_id()}"
         global PMC_MFMA_BUSY
         PMC_MFMA_BUSY = t["conv_igemm"].get("mfma_busy_frac")
         return round(t["conv_igemm"]["hbm_bytes_per_launch"]), None
@@ -110,6 +110,72 @@ def cpu_baseline():
             "sample": f"1 clip x {FRAMES} frames x 224^2, ResNet-50 layer3: 1 warm-up iteration, then the whole attack timed -- "
                       f"clean pass {t_clean:.2f}s + {ATTACK_STEPS} iterations {t_iters:.2f}s on {cores} of {ncpu} host threads"}
     return base, ora
+
+
+def framework_baseline_child():
+    """`bench.py --framework-baseline-child` (started by the bench BEFORE it touches the GPU, idle until told to go): the oracle's
+    restatement of the reference loop (`oracle/restate.py`, `oracle/size_parity.oracle_attack`: the same torch ops the reference's
+    modules execute, minus autograd's weight gradients) with every tensor on cuda:0 -- ATen -> MIOpen / rocBLAS, i.e. what
+    PyTorch-ROCm does with this attack on this very GPU.  One 4-clip attack (configs[1]) after one warm-up iteration.  A BASELINE beside
+    `cpu_baseline`: never the target, never imported by the package."""
+    if sys.stdin.readline().strip() != "go":
+        return 0
+    t_start = time.time()
+    from i2v_amd import graphs, weights
+    from oracle import restate, size_parity
+    torch.backends.cudnn.benchmark = False            # MIOpen immediate mode (no exhaustive find): what a default PyTorch run does
+    g = graphs.build(MODEL, (HW, HW))
+    net = restate.OracleNet(g, weights.synthetic_state_dict(g, 0), [g.hooks[DEPTH]], device="cuda:0")
+    vid = synthetic_clips(CLIPS_PER_GPU).to("cuda:0")
+    t0 = time.time()
+    w = size_parity.oracle_attack(net, vid[:1].contiguous(), steps=1, lr=0.005)        # first use: MIOpen picks / compiles its kernels
+    torch.cuda.synchronize()
+    t_first = time.time() - t0
+    ora = size_parity.oracle_attack(net, vid, steps=ATTACK_STEPS, lr=0.005, warmup=True)
+    torch.cuda.synchronize()
+    t = ora["t_clean"] + ora["t_iters"]
+    print(json.dumps({"value": round(CLIPS_PER_GPU * FRAMES / t, 2), "unit": "adversarial frames/s",
+                      "kind": "oracle port on PyTorch-ROCm/MIOpen (ATen conv2d / conv2d_input, eager, fp32)",
+                      "seconds": {"first_touch_one_clip_one_step": round(t_first, 2), "clean_pass": round(ora["t_clean"], 3),
+                                  "iterations": round(ora["t_iters"], 3), "child_total": round(time.time() - t_start, 1)},
+                      "costs": [float(f"{c:.7g}") for c in ora["costs"]],
+                      "note": f"{CLIPS_PER_GPU} clips x {FRAMES} frames x 224^2, ResNet-50 layer3, {ATTACK_STEPS} steps, tensors resident on cuda:0, one warm-up "
+                              "iteration, then the whole attack timed; torch " + torch.__version__ + ", torch.backends.cudnn.benchmark=False (MIOpen "
+                              "immediate mode, no find); a baseline, not the target"}), flush=True)
+    return 0
+
+
+def start_framework_baseline():
+    """The child of `framework_baseline_child`, started before this process initialises HIP; it waits on its stdin."""
+    import subprocess
+    return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--framework-baseline-child"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                            stderr=subprocess.DEVNULL, text=True, cwd=ROOT)
+
+
+def collect_framework_baseline(child, budget_s):
+    """Tell the child to go and wait at most `budget_s` for its line (a fresh box may have MIOpen compile its kernels first)."""
+    import threading
+    if child is None:
+        return None
+    out = {}
+
+    def reader():
+        out["line"] = child.stdout.readline()
+    try:
+        child.stdin.write("go\n"); child.stdin.flush()
+    except OSError:
+        return {"value": None, "note": "the baseline process had already exited"}
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    th.join(budget_s)
+    if th.is_alive() or not out.get("line", "").startswith("{"):
+        child.kill()                              # exactly the process started above
+        child.wait()
+        return {"value": None, "unit": "adversarial frames/s", "kind": "oracle port on PyTorch-ROCm/MIOpen",
+                "note": f"no result within the {budget_s:.0f} s budget of a default run (MIOpen building its kernels on a fresh box?); "
+                        "the measured figure of a longer run is in profiles/ (tools/run_r6final.sh: --framework-budget 900)"}
+    child.wait()
+    return json.loads(out["line"])
 
 
 def parity_check(ora, costs, delta, adv, f64=False):
@@ -170,6 +236,10 @@ def parse_args(argv=None):
                          "reference's own model list (resnet101+vgg16+squeezenet1_1+alexnet); aens carries the one data-path "
                          "collective (2L floats all-reduced per step, TPAMI_attack.py:265,293-297) inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-framework-baseline", action="store_true",
+                    help="skip `gpu_framework_baseline` (the oracle's restatement of the reference loop run by PyTorch-ROCm / MIOpen on cuda:0, after the timed regions)")
+    ap.add_argument("--framework-budget", type=float, default=75.0, help="seconds the default run waits for `gpu_framework_baseline` before reporting null")
+    ap.add_argument("--framework-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-split-bf16", action="store_true",
                     help="skip the extra, clearly separated `split_bf16_mode` measurement (the opt-in I2V_MATH=bf16x3 arithmetic; never `value`)")
     ap.add_argument("--parity-f64", action="store_true",
@@ -191,8 +261,8 @@ def parse_args(argv=None):
         ap.error("--clips and --ilaf_clips both given with different values")
     if args.workload == "ilaf":
         args.clips = max(1, args.clips if args.clips is not None else (args.ilaf_clips if args.ilaf_clips is not None else 8))
-    elif args.clips is None:
-        args.clips = 8 if args.workload == "aens" else CLIPS_PER_GPU
+    elif args.clips is None:      # configs[2]: batch = 8; configs[3]: batch 64 over 8 GPUs = 8 per GPU; configs[1]: batch = 4
+        args.clips = 8 if args.workload in ("aens", "config2") else CLIPS_PER_GPU
     return args
 
 
@@ -244,11 +314,21 @@ def spawn_ranks(args, argv):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
+    if args.framework_baseline_child:
+        return framework_baseline_child()
     if args.gpus > 1 and not under_launcher():
         return spawn_ranks(args, argv)
     if args.selftest_hostsim:
         return selftest_hostsim(args)
-    return run_rank(args)
+    # the same-GPU framework baseline runs in a child started NOW, before this process initialises HIP (it idles until the timed regions are over)
+    alone = args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1
+    child = start_framework_baseline() if (alone and args.workload == "i2v" and not args.no_cpu_baseline and not args.no_framework_baseline) else None
+    try:
+        return run_rank(args, child)
+    finally:
+        if child is not None and child.poll() is None:
+            child.kill()
+            child.wait()
 
 
 CPU_PIN = None        # what affinity.pin_rank did for this rank (reported in the JSON line)
@@ -394,7 +474,48 @@ def selftest_hostsim(args):
     return 0
 
 
-def run_rank(args):
+def split_bf16_measurement(args, eng, attacks, videos, labels, names, b, value, flop_per_frame):
+    """The opt-in split-bf16 arithmetic of an EXPERIMENTAL build, AFTER and APART from the headline: a fresh attack object planned in
+    that mode, the same K steps un-instrumented, its own parity check against the committed float64 run."""
+    atk3 = attacks.ImageGuidedFMDirection_Adam([MODEL], depth=DEPTH, step_size=0.005, steps=ATTACK_STEPS, engine=eng, weight_seed=0)
+    atk3.clip_lanes = 1
+    atk3(videos, labels, names)
+    torch.cuda.synchronize()
+    b0 = eng.capi.i2v_backend_stat(b"bf3_launches")
+    atk3(videos, labels, names)                # (the launch counter around ONE call)
+    torch.cuda.synchronize()
+    per_call = int(eng.capi.i2v_backend_stat(b"bf3_launches") - b0)
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        atk3(videos, labels, names)
+    torch.cuda.synchronize()
+    el3 = time.perf_counter() - t1
+    atk3.clip_lanes = None                 # product default: two concurrent clip lanes (bit-identical output)
+    atk3(videos, labels, names)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        atk3(videos, labels, names)
+    torch.cuda.synchronize()
+    el3b = time.perf_counter() - t1
+    adv3 = atk3(videos[:1].contiguous(), labels[:1], names[:1])
+    torch.cuda.synchronize()
+    from oracle import size_parity
+    yard = size_parity.load_yardstick(os.path.join(ROOT, "tests", "golden"), seed=1000, steps=ATTACK_STEPS, lr=0.005)
+    st3 = size_parity.compare_sampled(atk3.last_costs, atk3._delta.cpu(), adv3.cpu(), yard) if yard is not None and b >= 1 else None
+    v3 = args.steps * b * FRAMES / el3
+    return {"math": "I2V_MATH=bf16x3 (opt-in, experimental build): conv launches on three-term bf16 operands, 6 bf16 MFMAs per 16 K rows, fp32 accumulation; "
+                    "product terms kept down to 2^-26 |w||x|",
+            "value": round(v3, 2), "unit": "adversarial frames/s", "ms_per_step": round(1e3 * el3 / args.steps, 3),
+            "speedup_vs_value": round(v3 / value, 3), "end_to_end_tflops_equivalent": round(v3 * flop_per_frame / 1e12, 2),
+            "value_product_default_lanes": round(args.steps * b * FRAMES / el3b, 2),
+            "bf3_launches_per_step": per_call,
+            "device_vs_f64_oracle": {k: float(f"{v:.4g}") for k, v in st3.items()} if st3 else None,
+            "note": "NOT the headline: `value` is the exact-fp32 path.  Same clips, same K steps, one clip lane, no per-launch events; "
+                    "parity of this mode: tests/test_gpu_split_bf16.py, DESIGN.md section 12"}
+
+
+def run_rank(args, framework_child=None):
     dist, rank, local_rank, world, dev, rank_sum = init_ranks(args)
 
     import __graft_entry__ as ge
@@ -598,7 +719,7 @@ def run_rank(args):
                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                            "traffic": traffic,
-                           "traffic_unit": "B per launch (rocprofv3 PMC passes of this build: 2*FETCH_SIZE + WRITE_SIZE, profiles/r5_traffic_by_instantiation.json)",
+                           "traffic_unit": "B per launch (rocprofv3 PMC passes of this build: 2*FETCH_SIZE + WRITE_SIZE, profiles/r6_traffic_by_instantiation.json)",
                            "launches": int(c["launches"]), "avg_launch_us": round(1e3 * c["ms"] / c["launches"], 2),
                            "avg_gflop_per_launch": round(c["flops"] / c["launches"] / 1e9, 3),
                            "algorithmic_bytes_per_launch": round(c["bytes"] / c["launches"]),
@@ -644,9 +765,26 @@ def run_rank(args):
         out["config"]["workload"] = f"{args.workload} ensemble ({models}), batch={b} clips per GPU"
         for k in ("end_to_end_tflops_per_gpu", "algorithmic_gflop_per_frame"):
             out.pop(k, None)
+    # which BASELINE.json entry this line measures, verbatim (and what, if anything, differs from it as run)
+    idx = {"i2v": 1, "config2": 2, "aens": 3, "ilaf": 4}.get(args.workload)
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as fh:
+            entries = json.load(fh)["configs"]
+    except Exception:       # noqa: BLE001
+        entries = None
+    if idx is not None and entries:
+        differs = {"i2v": None if b == CLIPS_PER_GPU else f"batch={b}",
+                   "config2": None if b == 8 else f"batch={b}",
+                   "aens": f"this GPU's share: {b} clips per GPU x {world} GPU(s)" + ("" if world == 8 and b == 8 else " (the entry: 64 over 8)")
+                           + "; model list = the reference CLI's (resnet101+vgg16+squeezenet1_1+alexnet, depths [2,3])",
+                   "ilaf": f"{args.white_model} feature guide, {world} GPU(s), replicas only" + ("" if "slowfast" in args.white_model else " (the entry names SlowFast-R50)")}[args.workload]
+        out["config"]["baseline_entry"] = f"configs[{idx}]: {entries[idx]}"
+        out["config"]["differs_from_entry"] = ((differs + "; ") if differs else "") + "synthetic clips and seeded synthetic weights (no dataset / checkpoints offline)"
+    elif args.workload == "ens":
+        out["config"]["baseline_entry"] = "none: ENS-I2V on the reference CLI's own model list (an extra beside configs[2])"
     if args.workload == "aens":
         out["aens"] = aens_fields(atk, dist, world, dev)
-    if args.workload == "i2v" and getattr(atk, "_nets", None):       # what the autotuner did with the fusable 3x3 -> pointwise pairs (headline plan)
+    if args.workload == "i2v" and getattr(atk, "_nets", None) and eng.capi.i2v_backend_stat(b"experimental") == 1:       # what the autotuner did with the fusable 3x3 -> pointwise pairs (headline plan)
         fi = atk._nets[0].fusion_info()
         out["fused_pairs"] = {"eligible_fwd": fi[0], "eligible_bwd": fi[1], "fused_fwd": fi[2], "fused_bwd": fi[3],
                               "note": "pairs run as one conv_fused_kernel launch at the planned batch size (autotuned per pair; DESIGN.md section 10)"}
@@ -661,44 +799,18 @@ def run_rank(args):
     # AFTER and APART from the headline: a fresh attack object planned in that mode, the same K steps un-instrumented, and its own parity
     # check against the committed float64 run.  `value` above is the default exact-fp32 path and stays so.
     split = None
+    experimental = eng.capi.i2v_backend_stat(b"experimental") == 1
     if args.workload == "i2v" and not args.no_split_bf16 and timing and world == 1 and os.environ.get("I2V_MATH", "") != "bf16x3":
-        os.environ["I2V_MATH"] = "bf16x3"
-        try:
-            atk3 = attacks.ImageGuidedFMDirection_Adam([MODEL], depth=DEPTH, step_size=0.005, steps=ATTACK_STEPS, engine=eng, weight_seed=0)
-            atk3.clip_lanes = 1
-            b0 = eng.capi.i2v_backend_stat(b"bf3_launches")
-            atk3(videos, labels, names)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                atk3(videos, labels, names)
-            torch.cuda.synchronize()
-            el3 = time.perf_counter() - t1
-            atk3.clip_lanes = None                 # product default: two concurrent clip lanes (bit-identical output)
-            atk3(videos, labels, names)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                atk3(videos, labels, names)
-            torch.cuda.synchronize()
-            el3b = time.perf_counter() - t1
-            adv3 = atk3(videos[:1].contiguous(), labels[:1], names[:1])
-            torch.cuda.synchronize()
-            from oracle import size_parity
-            yard = size_parity.load_yardstick(os.path.join(ROOT, "tests", "golden"), seed=1000, steps=ATTACK_STEPS, lr=0.005)
-            st3 = size_parity.compare_sampled(atk3.last_costs, atk3._delta.cpu(), adv3.cpu(), yard) if yard is not None and b >= 1 else None
-            v3 = args.steps * b * FRAMES / el3
-            split = {"math": "I2V_MATH=bf16x3 (opt-in): conv launches on three-term bf16 operands, 6 bf16 MFMAs per 16 K rows, fp32 accumulation; "
-                             "product terms kept down to 2^-26 |w||x|",
-                     "value": round(v3, 2), "unit": "adversarial frames/s", "ms_per_step": round(1e3 * el3 / args.steps, 3),
-                     "speedup_vs_value": round(v3 / value, 3), "end_to_end_tflops_equivalent": round(v3 * flop_per_frame / 1e12, 2),
-                     "value_product_default_lanes": round(args.steps * b * FRAMES / el3b, 2),
-                     "bf3_launches_per_step": int((eng.capi.i2v_backend_stat(b"bf3_launches") - b0) // (args.steps + 2)),
-                     "device_vs_f64_oracle": {k: float(f"{v:.4g}") for k, v in st3.items()} if st3 else None,
-                     "note": "NOT the headline: `value` is the exact-fp32 path.  Same clips, same K steps, one clip lane, no per-launch events; "
-                             "parity of this mode: tests/test_gpu_split_bf16.py, DESIGN.md section 12"}
-        finally:
-            os.environ.pop("I2V_MATH", None)
+        if not experimental:
+            split = "not built: the split-bf16 K loop is an EXPERIMENTAL kernel (csrc/i2v_conv_exp.hip, -DI2V_EXPERIMENTAL), not part of the product library"
+        else:
+            os.environ["I2V_MATH"] = "bf16x3"
+            try:
+                split = split_bf16_measurement(args, eng, attacks, videos, labels, names, b, value, flop_per_frame)
+            except Exception as e:       # noqa: BLE001 -- an optional side measurement must never cost the headline line
+                split = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                os.environ.pop("I2V_MATH", None)
     if split is not None:
         out["split_bf16_mode"] = split
     if rank == 0:
@@ -708,6 +820,9 @@ def run_rank(args):
             adv1 = atk(videos[:1].contiguous(), labels[:1], names[:1])
             torch.cuda.synchronize()
             dev_costs, dev_delta = atk.last_costs.copy(), atk._delta.clone()
+            out["gpu_framework_baseline"] = collect_framework_baseline(framework_child, args.framework_budget)
+            if out["gpu_framework_baseline"] is None:
+                out.pop("gpu_framework_baseline")
             out["cpu_baseline"], ora = cpu_baseline()
             out["parity_check"] = parity_check(ora, dev_costs, dev_delta, adv1, f64=args.parity_f64)
         print(json.dumps(out), flush=True)

@@ -236,6 +236,7 @@ static int pack_fwd(Net& n, Node& nd) {
         if (classes == 2) { P.tpair = 2; P.Cd = 2 * c.cout; P.Cdpad = (int)align_up(P.Cd, 128); }
         P.K = c.cin * NU * c.kh * kwq * 4; P.Kpad = (int)align_up(P.K, I2V_KC); P.tap_uniform = 0;
         P.quad = kwq; P.quad_kw = c.kw; P.quad_dw0 = -c.pad;
+        if (c.kh == 7 && c.kw == 7 && c.pad == 3) P.halo = 77;      // seven row taps from -3: what conv_stem_halo's window (37 rows from 2 y0 - 3, 56 K rows per plane) is built for
         std::vector<float> wq((size_t)P.Kpad * P.Cdpad, 0.f);
         std::vector<I2VKEntry> kq(P.Kpad, I2VKEntry{0, 0, 0, 0});
         for (int ci = 0; ci < c.cin; ++ci)
@@ -1138,6 +1139,10 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
     if (n.planned) return fail("net already planned");
     if (n.input < 0) return fail("input tensor not set");
     if (n_hooks <= 0 || max_frames <= 0) return fail("need >=1 hook and >=1 frame");
+    // the split-bf16 loop lives in the EXPERIMENTAL build only (i2v_conv_exp.hip): asking the product library for it is an error, not
+    // a silent fp32 run under another name
+    if (math_bf16x3() && strncmp(be_name(), "hip", 3) == 0 && be_stat("experimental") != 1)
+        return fail("I2V_MATH=bf16x3 needs a library built with -DI2V_EXPERIMENTAL (python __graft_entry__.py --experimental, then I2V_LIB=...)");
     for (int i = 0; i < n_hooks; ++i)
         if (hook_tensors[i] < 0 || hook_tensors[i] >= (int)n.tens.size()) return fail("bad hook tensor");
     n.hooks.assign(hook_tensors, hook_tensors + n_hooks);
@@ -1412,6 +1417,7 @@ static int autotune(Net& n) {
                 const int lf = clips_b * l.conv.Tg;             // grid frames of this launch at the bucket's size
                 if (lf * l.conv.Hg * l.conv.Wg == 0) continue;
                 int cand[16]; I2VConvParams probe = l.conv; probe.N = lf;
+                probe.temporal = conv_prep(l, xin, scratch + img, 0).temporal;      // (the frame-map half of `temporal` is derived at run time: candidates must see what the launch will be)
                 const int nc = k_conv_candidates(probe, cand);
                 if (nc <= 1) { if (nc == 1) l.cfg_b[b] = cand[0] + 1; continue; }
                 // one configuration: a warm-up launch, then two timed launches; returns ms per launch.  (Timing short launches until a

@@ -105,7 +105,8 @@ class NativeClassifier(object):
     def eval(self):
         return self
 
-    def __call__(self, clips):
+    def _forward(self, clips):
+        """Backbone forward of a (b,3,f,h,w) batch to the classifier's features; returns (engine, net, frames, clips)."""
         import torch
         from .attacks import get_engine
         eng = self._engine or get_engine()
@@ -124,8 +125,28 @@ class NativeClassifier(object):
         x, u = torch.empty(N, 3, h, w, **kw), torch.empty(N, 3, h, w, **kw)
         eng.frames_from_video(clips, x, u)
         net.forward(x)
-        W, bias = self._head
+        return eng, net, N, b
+
+    def _head_apply(self, eng, net, N, b, W, bias):
+        import torch
+        kw = dict(dtype=torch.float32, device=eng.device)
         logits = torch.empty(b, W.shape[0], **kw)
         scratch = torch.empty(eng.capi.i2v_head_scratch_bytes(W.shape[1], b), dtype=torch.uint8, device=eng.device)
         net.head_logits(list(range(len(net.hooks))), W, bias, N, logits, scratch)
         return logits
+
+    def __call__(self, clips):
+        eng, net, N, b = self._forward(clips)
+        W, bias = self._head
+        return self._head_apply(eng, net, N, b, W, bias)
+
+    def pooled_features(self, clips):
+        """The pooled pre-`fc` features (clips, C) the head multiplies (`i2v_head_pool_f32`; SlowFast: slow then fast): the same
+        launches as a call, with the identity in place of `fc` (x + 0 sums are exact).  What an evaluator head is fitted on
+        (`tools/fooling_parity.py`: a least-squares head on the clean clips of the sample list)."""
+        import torch
+        eng, net, N, b = self._forward(clips)
+        C_ = self._head[0].shape[1]
+        if getattr(self, "_eye", None) is None or self._eye.shape[0] != C_:
+            self._eye = torch.eye(C_, dtype=torch.float32, device=eng.device)
+        return self._head_apply(eng, net, N, b, self._eye, None)

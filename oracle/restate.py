@@ -30,7 +30,7 @@ COS_EPS = 1e-8                   # F.cosine_similarity default, image_attacks.py
 
 
 def _cvec(v, like):
-    return torch.tensor(v, dtype=like.dtype).view(1, 3, 1, 1)
+    return torch.tensor(v, dtype=like.dtype, device=like.device).view(1, 3, 1, 1)
 
 
 # ---------------------------------------------------------------------------
@@ -41,10 +41,13 @@ class OracleNet:
     frozen in eval mode (`image_attacks.py:253-256,318,334`); backward is what
     `cost.backward()` (`:352`) delivers to the input, minus the wasted weight gradients."""
 
-    def __init__(self, graph, state_dict, hook_tensors: Sequence[int], dtype=torch.float32):
+    def __init__(self, graph, state_dict, hook_tensors: Sequence[int], dtype=torch.float32, device="cpu"):
+        """`device`: "cpu" for everything the parity ladder uses; `bench.py`'s `gpu_framework_baseline` leg runs the same
+        restatement with its tensors on cuda:0 (ATen -> MIOpen), as what PyTorch-ROCm would do with the reference's loop."""
         self.g = graph.truncated(list(hook_tensors))
         self.hooks = list(hook_tensors)
-        self.sd = {k: v.to(dtype) for k, v in state_dict.items()}
+        self.device = torch.device(device)
+        self.sd = {k: v.to(dtype).to(self.device) for k, v in state_dict.items()}
         self.dtype = dtype
         self.buf: Dict[int, torch.Tensor] = {}
         self.pool_idx: Dict[int, torch.Tensor] = {}
@@ -52,7 +55,7 @@ class OracleNet:
     def _view(self, store, tid, N=None):
         t = self.g.tensors[tid]
         if t.buf not in store:
-            store[t.buf] = torch.zeros(N, self.g.buffers[t.buf], t.H, t.W, dtype=self.dtype)
+            store[t.buf] = torch.zeros(N, self.g.buffers[t.buf], t.H, t.W, dtype=self.dtype, device=self.device)
         return store[t.buf][:, t.c_off:t.c_off + t.C]
 
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
@@ -140,7 +143,7 @@ class OracleNet:
             else:
                 idx = self.pool_idx[i]
                 C = src.shape[1]
-                gx = torch.zeros(N, C, src.shape[2] * src.shape[3], dtype=self.dtype)
+                gx = torch.zeros(N, C, src.shape[2] * src.shape[3], dtype=self.dtype, device=self.device)
                 gx.scatter_add_(2, idx.reshape(N, C, -1), gd.reshape(N, C, -1))
                 self._view(gb, nd.src, N).add_(gx.view_as(src))
         self.last_grads = gb          # buffer id -> gradient (tests read intermediate gradients from it)

@@ -35,3 +35,13 @@ def _built_library(request):
         import __graft_entry__ as ge
         if not os.path.exists(ge.LIB):
             ge.build()
+
+
+@pytest.fixture
+def experimental_build():
+    """Tests of the kernels that are NOT in the product library (fused 3x3 -> pointwise pair, split-bf16 loop, conv_pw_stream,
+    conv_stem64_halo: `csrc/i2v_conv_exp.hip`, compiled only with -DI2V_EXPERIMENTAL) run when the loaded library carries them --
+    `python __graft_entry__.py --experimental`, then `I2V_LIB=.../libi2v_hip_exp.so pytest -m gpu` -- and skip on the default build."""
+    from i2v_amd import lib
+    if lib.load().i2v_backend_stat(b"experimental") != 1:
+        pytest.skip("the loaded libi2v_hip.so is the product build (no -DI2V_EXPERIMENTAL): this kernel is not in it")

@@ -34,6 +34,11 @@ def eng():
     return e
 
 
+@pytest.fixture(autouse=True)
+def _needs_the_experimental_library(experimental_build):
+    """Every test of this module plans nets with I2V_MATH=bf16x3, which the product library refuses (`i2v_net_plan`)."""
+
+
 def dev(t):
     return t.to("cuda:0").contiguous()
 

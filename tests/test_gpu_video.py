@@ -382,15 +382,18 @@ def test_stem_halo_kernels_are_bit_identical(eng, monkeypatch):
     on sizes that leave partial 16 x 16 tiles: every word of the hooked features and of the input gradient bit for bit.  They are
     the same k-ordered chains."""
     monkeypatch.setenv("I2V_AUTOTUNE", "0")
-    cases = [(graphs.resnet((1, 1, 1, 1), 64, (72, 88), "resnet_w64"), None, 3, 5, 1, 0),        # (output 44 wide: gate words not 16-bit aligned per tile row)
-             (graphs.resnet((1, 1, 1, 1), 64, (72, 96), "resnet_w64"), None, 3, 3, 1, 1),
-             (graphs.squeezenet(1, (70, 70)), None, 2, 5, 1, 0),
-             (graphs.i3d_resnet((1, 1, 1, 1), 64, (8, 40, 56), "i3d_w64", inflate=((1,), (1,), (1,), (0,))), "i3d_resnet50", None, 4, 2, 0),        # (one launch per temporal class)
-             (graphs.i3d_resnet((1, 1, 1, 1), 64, (7, 40, 56), "i3d_w64", inflate=((1,), (1,), (1,), (0,))), "i3d_resnet50", None, 5, 2, 0),
-             (graphs.slowfast_res2(64, (16, 40, 56), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 5, 2, 1),
-             (graphs.slowfast_res2(64, (32, 24, 40), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 4, 2, 1),
-             (graphs.slowfast_res2(64, (16, 40, 64), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 3, 2, 2)]
-    for g, video_type, depth, base_cfg, expect_grad, expect_fwd in cases:
+    cases = [(graphs.resnet((1, 1, 1, 1), 64, (72, 88), "resnet_w64"), None, 3, 5, 1, 0, 0),        # (output 44 wide: gate words not 16-bit aligned per tile row)
+             (graphs.resnet((1, 1, 1, 1), 64, (72, 96), "resnet_w64"), None, 3, 3, 1, 1, 1),
+             (graphs.squeezenet(1, (70, 70)), None, 2, 5, 1, 0, 0),
+             (graphs.i3d_resnet((1, 1, 1, 1), 64, (8, 40, 56), "i3d_w64", inflate=((1,), (1,), (1,), (0,))), "i3d_resnet50", None, 4, 2, 0, 0),        # (one launch per temporal class)
+             (graphs.i3d_resnet((1, 1, 1, 1), 64, (7, 40, 56), "i3d_w64", inflate=((1,), (1,), (1,), (0,))), "i3d_resnet50", None, 5, 2, 0, 0),
+             (graphs.slowfast_res2(64, (16, 40, 56), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 5, 2, 1, 0),
+             (graphs.slowfast_res2(64, (32, 24, 40), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 4, 2, 1, 0),
+             (graphs.slowfast_res2(64, (16, 40, 64), "sf_w64", slow_stride=8, fast_stride=2, fusion_kernel=7, blocks=1), "slowfast_resnet50", None, 3, 2, 2, 1)]
+    # (last column: how many of the forward launches are conv_stem64_halo's -- the wide stem's kernel exists in an EXPERIMENTAL build only)
+    has_stem64 = eng.capi.i2v_backend_stat(b"experimental") == 1
+    for g, video_type, depth, base_cfg, expect_grad, expect_fwd, n_stem64 in cases:
+        expect_fwd -= 0 if has_stem64 else n_stem64
         sd = weights.synthetic_state_dict(g, 0)
         hooks = graphs.video_hooks(g, video_type) if video_type else [g.hooks[depth]]
         T = g.tensors[g.input].T if video_type else 1
@@ -582,7 +585,7 @@ def test_two_chunks_per_barrier_is_bit_identical(eng, monkeypatch):
 
 
 @pytest.mark.parametrize("frames", [1, 5, 21])
-def test_persistent_pointwise_kernel_is_bit_identical(eng, monkeypatch, frames):
+def test_persistent_pointwise_kernel_is_bit_identical(eng, monkeypatch, frames, experimental_build):
     """`conv_pw_stream` (round 5): ONE persistent 512-thread workgroup per CU with the weight panel resident in LDS, matrix waves that only
     issue MFMAs (+ the next tile's LDS-DMA) and epilogue waves that drain the previous tile through `conv_vec_rows` -- the same k-ordered
     fmaf chain and the same row pass as conv_igemm.  Forced (configuration 3 | 256, `I2V_PWS_MIN_TILES=0` so that small launches
@@ -627,7 +630,7 @@ def test_persistent_pointwise_kernel_is_bit_identical(eng, monkeypatch, frames):
     assert float(outs[0][1].abs().max()) > 0
 
 
-def test_fused_3x3_pointwise_pairs_are_bit_identical(eng, monkeypatch):
+def test_fused_3x3_pointwise_pairs_are_bit_identical(eng, monkeypatch, experimental_build):
     """`conv_fused_kernel` (round 4): a 3x3 convolution and the pointwise convolution over its output as ONE launch, the intermediate kept
     in LDS -- a bottleneck's conv2 -> conv3 and, in the backward list, the input gradients of conv2 -> conv1.  Forced onto every pair
     the planner admits (I2V_FORCE_FUSE = 1: plain staging, 2: halo staging where the plane is 14 / 28 / 56 wide), on a three-stage

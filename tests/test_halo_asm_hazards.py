@@ -83,8 +83,10 @@ def test_scanner_sees_a_load_landing_in_a_live_register():
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="no hipcc: the kernels cannot be compiled here")
 def test_no_instruction_touches_a_register_with_a_load_in_flight(tmp_path):
     asm = tmp_path / "halo.s"
+    # the product's own translation unit of these kernels, with the experimental wide-stem kernel compiled in as well (device pass only)
     cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++20", "-Wno-unused-value",
-           "-Wno-unused-result", "-x", "hip", "-DI2V_NO_CONV_DISPATCH", "--cuda-device-only", "-S", os.path.join(ROOT, "tools", "stem_halo_probe.cpp"), "-o", str(asm)]
+           "-Wno-unused-result", "-x", "hip", "-DI2V_EXPERIMENTAL", "--cuda-device-only", "-S",
+           os.path.join(ROOT, "image-to-video-i2v-attack_amd", "csrc", "i2v_conv_stems.hip"), "-o", str(asm)]
     subprocess.run(cmd, check=True, capture_output=True, timeout=600)
     text = asm.read_text().splitlines()
     kernels = {}
