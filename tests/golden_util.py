@@ -39,8 +39,9 @@ def videos_of(fx, dtype=torch.float32):
 def hook_lists(fx):
     """[(graph, state_dict, [hook tensor ids])] per model, in the reference's hook order."""
     out = []
+    build = graphs.build if fx.get("full_size") else graphs.build_tiny
     for m in fx["models"]:
-        g = graphs.build_tiny(m, (fx["hw"], fx["hw"]))
+        g = build(m, (fx["hw"], fx["hw"]))
         sd = weights.synthetic_state_dict(g, fx["wseed"])
         d = fx["depth"][m] if isinstance(fx["depth"], dict) else fx["depth"]
         ds = d if isinstance(d, list) else [d]

@@ -8,6 +8,7 @@ test sizes; at full size (~10^8 ReLU gates, a few decided by the last bit) relat
 ILAF cost trajectories rtol 2e-4 (f64 fixtures) / 5e-3 (f32 fixture, whose own reference run is chaotic in the last bits).
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -15,6 +16,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 from i2v_amd import attacks, graphs, sign_attacks, video, weights  # noqa: E402
 from oracle import restate, video_models as vm  # noqa: E402
@@ -204,23 +206,29 @@ def test_native_ilaf_against_reference_fixture(eng, name):
     assert torch.equal(atk2(adv.clone(), ori.clone(), torch.zeros(fx["b"], dtype=torch.long), ["v"]).cpu(), out)
 
 
-ILAF_FULL_STEPS = {"slowfast_resnet50": 60, "i3d_resnet50": 3}        # SlowFast: the reference's whole loop (image_attacks.py:502)
-ILAF_TIGHT_STEPS = 60                                                 # free-running steps held to rtol 2e-4: all of them (measured: <= 1.6e-4)
+ILAF_FULL_STEPS = {"slowfast_resnet50": 60, "i3d_resnet50": 24}       # SlowFast: the reference's whole loop (image_attacks.py:502); I3D-NL: the committed yardstick's length
+ILAF_TIGHT_STEPS = 60                                                 # SlowFast: free-running steps held to rtol 2e-4: all of them (measured: <= 1.6e-4)
 
 
 @pytest.mark.parametrize("mt", ["slowfast_resnet50", "i3d_resnet50"])
 def test_native_ilaf_full_size_against_oracle(eng, mt):
     """BASELINE.json configs[4] shape (1 clip of 32 x 224 x 224 per call), SlowFast res2 hooks / the non-local I3D's res3 hook (two
     non-local blocks inside the hooked stage): the native loop against the oracle's restatement run on the torch module (CPU,
-    float32), free-running.  Round 5: SlowFast -- configs[4]'s guide -- runs the reference's WHOLE loop, 60 steps
+    float32), free-running.  SlowFast -- configs[4]'s guide -- runs the reference's WHOLE loop, 60 steps
     (`image_attacks.py:502,579-629`): the cost of EVERY one of the 60 steps within rtol 2e-4 (measured: 4e-6 ... 1.6e-4; sign steps
     move every element by +-0.005 whatever its gradient, so two fp32 runs drift apart element by element -- 3.4 % of the output
-    elements differ after the 60 steps -- while the cost, a mean over millions of them, stays close); the non-local I3D for 3 steps at
-    2e-4 (measured: 6e-5, 5e-5, 7e-5, then 7.5e-4 at its fourth step -- its softmax blocks amplify the drift).
+    elements differ after the 60 steps -- while the cost, a mean over millions of them, stays close).
+    The non-local I3D (round 6): its softmax blocks amplify that drift -- the fp32 ORACLE is 1.5e-3 away from the float64 oracle at its
+    second step and 1e-2 at its seventh (`tests/golden/ilaf_i3d_full_size_yardstick.npz`, `oracle/make_ilaf_yardstick.py`: both
+    trajectories of this very clip pair, 24 steps) -- so the device is held to THAT yardstick for 24 free steps: at every step its
+    relative cost distance from the float64 run must not exceed 1.25 x the largest distance the reference arithmetic's own fp32 run
+    (the committed one, or the live one of this host: fp32 runs differ between hosts too) has shown up to that step, plus rtol 2e-4; a
+    device that drifted faster than the oracle does would have a bug in its attention path (`attn_gemm_kernel`, `softmax_rows_kernel`).
     Then a MID-TRAJECTORY TEACHER-FORCED sign step: from the native modifier after those steps, one native step and one float64
     oracle step from the same state -- cost rtol 2e-4, and the update direction `sign(d cost / d modifier)` agreeing on >= 99.9 % of
     the elements whose gradient is >= 5 % of max|g| (a sign step moves EVERY element by 0.005 whatever |g|: elements with a
     gradient that is zero to rounding flip freely in any two correct implementations)."""
+    from oracle import make_ilaf_yardstick as yd
     thw = (32, 224, 224)
     steps = ILAF_FULL_STEPS[mt]
     gen = torch.Generator().manual_seed(11)
@@ -233,11 +241,26 @@ def test_native_ilaf_full_size_against_oracle(eng, mt):
     g = graphs.build_video(mt, thw)
     tm = vm.load_weights(vm.make(mt, False), weights.synthetic_state_dict(g, 0))
     ref, costs, _, _ = restate.run_ilaf(tm, vm.hook_modules(tm, mt), adv, ori, steps=steps)
-    rel = np.abs(np.asarray(atk.last_costs, np.float64) - costs) / np.abs(costs)
-    print(f"ILAF {mt} full size, {steps} free steps: cost rel. err per step {np.array2string(rel, precision=2)}; "
+    dev = np.asarray(atk.last_costs, np.float64)
+    rel = np.abs(dev - costs) / np.abs(costs)
+    print(f"ILAF {mt} full size, {steps} free steps: cost rel. err per step vs the live fp32 oracle {np.array2string(rel, precision=2)}; "
           f"mean|out - ref| {float((out - ref).abs().mean()):.2e}, elements differing {float((out != ref).float().mean()):.4f}")
-    np.testing.assert_allclose(atk.last_costs[:ILAF_TIGHT_STEPS], costs[:ILAF_TIGHT_STEPS], rtol=2e-4)
-    np.testing.assert_allclose(atk.last_costs, costs, rtol=2e-3)
+    if mt == "slowfast_resnet50":
+        np.testing.assert_allclose(atk.last_costs[:ILAF_TIGHT_STEPS], costs[:ILAF_TIGHT_STEPS], rtol=2e-4)
+        np.testing.assert_allclose(atk.last_costs, costs, rtol=2e-3)
+    else:
+        z = np.load(os.path.join(HERE, "golden", "ilaf_i3d_full_size_yardstick.npz"))
+        assert str(z["model_type"]) == mt and int(z["seed"]) == 11 and int(z["steps"]) >= steps and yd.SEED == 11 and yd.THW == thw
+        c64 = z["costs_f64"][:steps]
+        d_dev = np.abs(dev - c64) / np.abs(c64)
+        d_fix = np.abs(z["costs_f32"][:steps] - c64) / np.abs(c64)               # the committed fp32 oracle run
+        d_live = np.abs(np.asarray(costs, np.float64) - c64) / np.abs(c64)         # this host's fp32 oracle run
+        envelope = np.maximum.accumulate(np.maximum(d_fix, d_live))
+        print(f"    distance from the float64 oracle per step: device {np.array2string(d_dev, precision=2)}\n    fp32 oracle (committed) "
+              f"{np.array2string(d_fix, precision=2)}\n    fp32 oracle (live) {np.array2string(d_live, precision=2)}")
+        assert d_dev[0] <= 2e-4 and d_live[0] <= 2e-4                               # the first step is deterministic to rounding
+        assert np.all(d_dev <= 1.25 * envelope + 2e-4), (d_dev, envelope)
+        assert d_dev.max() <= 1.25 * max(d_fix.max(), d_live.max()) + 2e-4
     assert abs(atk.last_costs[0] + 1.5 * len(graphs.video_hooks(g, mt))) < 1e-4     # every hooked layer: -(0.5 + 1) at the start
     assert float((out - ref).abs().mean()) < 0.02                                   # (+-eps = 0.27 in these units bounds it; equal clips would give 0)
     # ---- teacher-forced step from the native state (float64 oracle)

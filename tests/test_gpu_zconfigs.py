@@ -190,3 +190,42 @@ def test_aens_8clips_tiny_against_oracle(eng):
     np.testing.assert_allclose(np.stack(atk.weights), np.stack(ref["weights"]), rtol=1e-4)
     np.testing.assert_allclose(atk.coeffs.cpu().numpy(), ref["coeffs"].float().numpy(), rtol=1e-4)
     assert (adv.cpu() - ref["adv"].float()).abs().mean() < 5e-3
+
+
+def test_aens_full_size_backbones_against_oracle(eng):
+    """configs[3]'s coefficient path on the REAL backbones (round 6): the reference's model list -- ResNet-101, VGG-16, SqueezeNet 1.1,
+    AlexNet (`image_main.py:73-79`) -- at 224^2 with list depths [2, 3] (eight layers, feature sizes up to D = 802 816), momentum 0.5,
+    5 steps of 0.02 (at the CLI's 0.005 the eight layer sums of 8 frames stay within 1e-6 of each other for the first steps and the
+    double softmax answers "uniform" to 1e-6: a comparison of weights would be vacuous; at 0.02 they are 2e-3 apart by step 5), 8 clips
+    of ONE frame each: the batch coupling of `AENS_I2V_MF` is over clips x frames (`TPAMI_attack.py:258-312`: the
+    per-layer sums over all frames feed the double softmax), so one frame per clip keeps all eight layers and the global sums at a
+    size the float64 oracle runs in under a minute.  Weights of every step, `cost_saved`, the final coefficients against
+    `restate.run_attack(mode='aens')` in float64; then the same run through the clip-sharded code path's kernels (`aens_reduce` ->
+    exchange -> `aens_coeffs`) must be byte-equal (a 1-rank group's all-reduce is the identity)."""
+    from oracle import size_parity
+    b, f, hw = 8, 1, 224
+    names = ["resnet", "vgg", "squeezenet", "alexnet"]
+    u8 = clips_u8(b, f, hw, 3300)
+    fx = dict(clip_u8=u8.numpy(), models=names, depth={n: [2, 3] for n in names}, hw=hw, wseed=0, full_size=True)
+    vid = gu.videos_of(fx)
+    STEPS, LR = 5, 0.02
+    atk = attacks.AENS_I2V_MF(names, depths=fx["depth"], step_size=LR, steps=STEPS, momentum=0.5, weight_seed=0)
+    adv, _, cost_saved = atk(vid, torch.zeros(b, dtype=torch.long), [f"v{i}" for i in range(b)])
+    torch.cuda.synchronize()
+    w = np.stack(atk.weights)
+    assert w.shape == (STEPS, 8) and np.allclose(w.sum(1), 1, atol=1e-5)
+    thr = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(16, size_parity.effective_cpus())))
+    try:
+        nets = [restate.OracleNet(g, sd, h, dtype=torch.float64) for g, sd, h in gu.hook_lists(fx)]
+        assert [len(n.hooks) for n in nets] == [2, 2, 2, 2]
+        ref = restate.run_attack(nets, vid.double(), steps=STEPS, step_size=LR, mode="aens", coeffs=torch.ones(8, dtype=torch.float64), momentum=0.5)
+    finally:
+        torch.set_num_threads(thr)
+    print("\nAENS full size: device weights", w[-1], "\noracle weights", ref["weights"][-1], "\ncost_saved", cost_saved, ref["costs"])
+    np.testing.assert_allclose(cost_saved, ref["costs"], rtol=2e-4)
+    np.testing.assert_allclose(w, np.stack(ref["weights"]), rtol=1e-4)
+    np.testing.assert_allclose(atk.coeffs.cpu().numpy(), ref["coeffs"].float().numpy(), rtol=1e-4)
+    assert float(np.abs(w[-1] - 1 / 8).max()) > 1e-3            # the weights did move off uniform (oracle: 0.1227 ... 0.1259): the comparison is not vacuous
+    assert (adv.cpu() - ref["adv"].float()).abs().mean() < 5e-3
+    check_box(adv.cpu(), u8)
