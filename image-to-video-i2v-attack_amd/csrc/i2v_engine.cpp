@@ -110,6 +110,13 @@ struct Launch {
     // (mark_fusable); fuse_b[bucket]: what the autotuner measured -- 0 two launches, 1 fused (plain staging), 2 fused (halo staging).
     int fuse_ok = 0;
     int fuse_b[4] = {0, 0, 0, 0};
+    // Fused fast-pathway block (k_fastblock, round 6): this launch and the next fb_ok - 1 launches of its list -- forward 3: conv1, conv2,
+    // conv3; 4: conv1, conv2, the projection shortcut, conv3; backward 2: the input gradients of conv3 and conv2 -- may run as ONE kernel
+    // that never stores the intermediates.  0 when anything else reads an intermediate (mark_fastblocks); fb_b[bucket]: what the
+    // autotuner measured (0: separate launches, 1: fused).
+    int node = -1;                 // conv launches: the graph node they belong to
+    int fb_ok = 0;
+    int fb_b[4] = {0, 0, 0, 0};
 };
 static int cfg_bucket(int clips, int max_clips) {
     int b = 0;
@@ -803,6 +810,7 @@ struct Planner {
             if (compact && (P.ph || P.pw || P.pt)) continue;
             if (P.Hg <= 0 || P.Wg <= 0 || P.Tg <= 0) continue;
             Launch l; l.kind = L_CONV; conv_common(l.conv, P);
+            l.node = (int)(&nd - n.nodes.data());
             I2VConvParams& p = l.conv;
             p.src = dz.p; p.src_nstride = dz.nstride; p.Hs = dz.H; p.Ws = dz.W; p.Cs = dz.C;
             p.Hg = P.Hg; p.Wg = P.Wg; p.sh = 1; p.sw = 1;
@@ -918,6 +926,7 @@ struct Planner {
             if (nd.type == 0) {
                 const i2v_conv3d_desc& c = nd.cd;
                 l.kind = L_CONV; conv_common(l.conv, nd.fwd);
+                l.node = (int)(&nd - n.nodes.data());
                 I2VConvParams& p = l.conv;
                 View d = view(c.dst, false);
                 const Buffer& sb = n.bufs[n.tens[c.src].buf];
@@ -1275,6 +1284,19 @@ static int fused_run(const Launch& a, const Launch& b, int frames, const float* 
     return 0;
 }
 
+// The fused fast-pathway block: launches L[li] .. L[li + fb_ok - 1] as ONE kernel.  Returns 0 done, 1 error, 2 not eligible at this frame
+// count (the caller runs the separate launches).
+static int fast_run(const std::vector<Launch>& L, size_t li, int frames, const float* x, i2v_stream_t s) {
+    const int g = L[li].fb_ok;
+    I2VConvParams q[4];
+    for (int j = 0; j < g; ++j) { q[j] = conv_prep(L[li + j], x, nullptr, 0); q[j].N = frames; }
+    const I2VConvParams* c = g == 3 ? &q[2] : g == 4 ? &q[3] : nullptr;
+    const I2VConvParams* d = g == 4 ? &q[2] : nullptr;
+    if (i2v_fastblock_rows(q[0], q[1], c, d) <= 0) return 2;
+    if (k_fastblock(q[0], q[1], c, d, s)) { fail("k_fastblock: %s", be_error() ? be_error() : "backend error"); return 1; }
+    return 0;
+}
+
 // One convolution launch over `frames` grid frames (= clips * Tg), possibly sliced over whole clips: 32-bit
 // buffer offsets keep a launch's source span < 2 GiB
 static int conv_run(const Launch& l, int frames, const float* x, float* gx, int accumulate, i2v_stream_t s) {
@@ -1381,6 +1403,77 @@ static void mark_fusable(Net& n) {
                 fprintf(stderr, "[i2v fuse] %s pair %zu: 3x3 Cd=%d K=%d %dx%d -> 1x1 Cd=%d K=%d: eligible=%d other_reader=%d\n", L == &n.fwd ? "fwd" : "bwd", i,
                         a.conv.Cd, a.conv.K, a.conv.Hg, a.conv.Wg, b.conv.Cd, b.conv.K, ok, (int)other);
         }
+    // ---- fused fast-pathway blocks (k_fastblock): groups of consecutive launches, found from the graph nodes behind them ----
+    {
+        const bool fb_off = [] { const char* e = getenv("I2V_FASTBLOCK"); return e && e[0] == '0'; }();      // (read per plan)
+        auto cd_of = [&](const Launch& l) -> const i2v_conv3d_desc* { return (l.kind == L_CONV && l.node >= 0 && n.nodes[l.node].type == 0 && !n.nodes[l.node].preact()) ? &n.nodes[l.node].cd : nullptr; };
+        auto unit = [](const i2v_conv3d_desc& c) { return c.stride == 1 && c.stride_t == 1 && c.dil_t == 1; };
+        auto is_pw = [&](const i2v_conv3d_desc& c) { return unit(c) && c.kt == 1 && c.kh == 1 && c.kw == 1 && c.pad == 0 && c.pad_t == 0; };
+        auto is_t = [&](const i2v_conv3d_desc& c) { return unit(c) && c.kh == 1 && c.kw == 1 && c.pad == 0 && (c.kt & 1) && 2 * c.pad_t == c.kt - 1; };      // k x 1 x 1, "same"
+        auto is_33 = [&](const i2v_conv3d_desc& c) { return unit(c) && c.kt == 1 && c.kh == 3 && c.kw == 3 && c.pad == 1 && c.pad_t == 0; };
+        // nothing but the group's own launches may touch an intermediate, and it must not be hooked
+        auto private_to = [&](std::vector<Launch>* L, size_t first, size_t last, const Launch& w) {
+            const Range r = dst_of(w);
+            for (auto& hk : hooked) if (meet(hk, r)) return false;
+            for (std::vector<Launch>* M : {&n.fwd, &n.bwd})
+                for (size_t j = 0; j < M->size(); ++j) {
+                    if (M == L && j >= first && j <= last) continue;
+                    if (touches((*M)[j], r, false, false)) return false;
+                }
+            return true;
+        };
+        for (Launch& l : n.fwd) l.fb_ok = 0;
+        for (Launch& l : n.bwd) l.fb_ok = 0;
+        // backward: [conv3's input gradient, X, conv2's input gradient] with X independent of both (a first block's projection-shortcut
+        // gradient sits between them): X moves in front
+        for (size_t i = 0; !fb_off && i + 2 < n.bwd.size(); ++i) {
+            Launch& a = n.bwd[i]; Launch& x = n.bwd[i + 1]; Launch& b = n.bwd[i + 2];
+            const i2v_conv3d_desc* ca = cd_of(a); const i2v_conv3d_desc* cb = cd_of(b);
+            if (!ca || !cb || !is_pw(*ca) || !is_33(*cb) || b.conv.src != a.conv.dst || x.kind != L_CONV) continue;
+            const I2VConvParams& px = x.conv;
+            const bool dep = touches(x, dst_of(a), false, false) || touches(a, dst_of(x), false, false) || touches(x, dst_of(b), false, false) || touches(b, dst_of(x), false, false) ||
+                             (px.gate_out && (px.gate_out == a.conv.gate || px.gate_out == b.conv.gate));
+            if (!dep) { Launch t = x; n.bwd[i + 1] = n.bwd[i]; n.bwd[i] = t; }
+        }
+        for (size_t i = 0; !fb_off && i + 1 < n.bwd.size(); ++i) {
+            Launch& a = n.bwd[i]; Launch& b = n.bwd[i + 1];
+            const i2v_conv3d_desc* ca = cd_of(a); const i2v_conv3d_desc* cb = cd_of(b);
+            if (!ca || !cb || !is_pw(*ca) || !is_33(*cb) || a.T != b.T || b.conv.src != a.conv.dst) continue;
+            if (i2v_fastblock_rows(a.conv, b.conv, nullptr, nullptr) <= 0) continue;
+            if (!private_to(&n.bwd, i, i + 1, a)) continue;
+            a.fb_ok = 2;
+        }
+        for (size_t i = 0; !fb_off && i + 2 < n.fwd.size(); ++i) {
+            Launch& a = n.fwd[i]; Launch& b = n.fwd[i + 1];
+            const i2v_conv3d_desc* ca = cd_of(a); const i2v_conv3d_desc* cb = cd_of(b);
+            if (!ca || !cb || a.src_is_input || !(is_t(*ca) || is_pw(*ca)) || !is_33(*cb) || !ca->relu || !cb->relu || ca->residual >= 0 || cb->residual >= 0 || cb->src != ca->dst) continue;
+            Launch& c3 = n.fwd[i + 2];
+            const i2v_conv3d_desc* cc = cd_of(c3);
+            if (!cc || !is_pw(*cc)) continue;
+            if (cc->src == cb->dst && cc->residual >= 0 && cc->relu && a.T == b.T && a.T == c3.T) {               // identity shortcut
+                if (i2v_fastblock_rows(a.conv, b.conv, &c3.conv, nullptr) <= 0) continue;
+                if (!private_to(&n.fwd, i, i + 2, a) || !private_to(&n.fwd, i, i + 2, b)) continue;
+                a.fb_ok = 3;
+            } else if (i + 3 < n.fwd.size() && cc->src == ca->src && !cc->relu && cc->residual < 0) {             // projection shortcut, then conv3
+                Launch& c4 = n.fwd[i + 3];
+                const i2v_conv3d_desc* c4d = cd_of(c4);
+                if (!c4d || !is_pw(*c4d) || c4d->src != cb->dst || c4d->residual != cc->dst || !c4d->relu || a.T != b.T || a.T != c3.T || a.T != c4.T) continue;
+                if (i2v_fastblock_rows(a.conv, b.conv, &c4.conv, &c3.conv) <= 0) continue;
+                if (!private_to(&n.fwd, i, i + 3, a) || !private_to(&n.fwd, i, i + 3, b) || !private_to(&n.fwd, i, i + 3, c3)) continue;
+                a.fb_ok = 4;
+            }
+        }
+        // without the autotuner (I2V_AUTOTUNE=0: tests, tools, the host simulation) a group is fused only on request
+        const bool fb_force = [] { const char* e = getenv("I2V_FORCE_FASTBLOCK"); return e && e[0] == '1'; }();      // (read per plan: tests compare both)
+        for (std::vector<Launch>* L : {&n.fwd, &n.bwd})
+            for (Launch& a : *L)
+                for (int bk = 0; bk < 4; ++bk) a.fb_b[bk] = (a.fb_ok && fb_force) ? 1 : 0;
+        if (getenv("I2V_FUSE_DEBUG"))
+            for (std::vector<Launch>* L : {&n.fwd, &n.bwd})
+                for (size_t i = 0; i < L->size(); ++i)
+                    if ((*L)[i].fb_ok) fprintf(stderr, "[i2v fastblock] %s launch %zu: group of %d (Cs %d -> %d mid channels, %dx%d)\n", L == &n.fwd ? "fwd" : "bwd", i, (*L)[i].fb_ok,
+                                               (*L)[i].conv.Cs, (*L)[i].conv.Cd, (*L)[i].conv.Hg, (*L)[i].conv.Wg);
+    }
     // without the autotuner (I2V_AUTOTUNE=0: tests, tools) a pair is fused only on request: I2V_FORCE_FUSE = 1 (plain) / 2 (halo where it applies)
     const char* force = getenv("I2V_FORCE_FUSE");
     const int f = force ? atoi(force) : 0;
@@ -1456,6 +1549,41 @@ static int autotune(Net& n) {
             l.conv.cfg = l.cfg_b[0] ? l.cfg_b[0] : planned_cfg;
             if (rc) break;
         }
+    // Fused fast-pathway blocks, per batch bucket: the group's launches on their tuned tiles against the group as one kernel; taken when
+    // at least 3 % faster (two timed runs each after a warm-up).  Only where timing means something (the device).
+    if (!rc && strncmp(be_name(), "hip", 3) == 0) {
+        const bool fb_force = [] { const char* e = getenv("I2V_FORCE_FASTBLOCK"); return e && e[0] == '1'; }();      // (read per plan: tests compare both)
+        for (std::vector<Launch>* L : {&n.fwd, &n.bwd})
+            for (size_t i = 0; i < L->size() && !rc; ++i) {
+                Launch& a = (*L)[i];
+                if (!a.fb_ok || i + a.fb_ok > L->size()) continue;
+                for (int bk = 3; bk >= 0 && !rc; --bk) {
+                    a.fb_b[bk] = 0;
+                    const int clips_b = max_clips >> bk;
+                    if (clips_b < 1 || (bk > 0 && clips_b == (max_clips >> (bk - 1)))) continue;
+                    const int lf = clips_b * a.conv.Tg;
+                    auto run_sep = [&]() { for (int j = 0; j < a.fb_ok; ++j) { Launch& m = (*L)[i + j]; if (m.cfg_b[bk]) m.conv.cfg = m.cfg_b[bk]; if (conv_run(m, lf, xin, scratch + img, 0, nullptr)) return 1; } return 0; };
+                    auto run_fb = [&]() { return fast_run(*L, i, lf, xin, nullptr); };
+                    auto timed = [&](auto&& fn, float* ms) -> int {
+                        if (fn()) return 1;
+                        be_event_record(e0, nullptr);
+                        for (int r = 0; r < 3; ++r) if (fn()) return 1;
+                        be_event_record(e1, nullptr);
+                        if (be_stream_sync(nullptr)) return 1;
+                        be_event_elapsed_ms(e0, e1, ms);
+                        return 0;
+                    };
+                    float t_sep = 0.f, t_fb = 0.f;
+                    if (run_fb() != 0) continue;                       // not eligible at this size (or it failed: the separate launches stay)
+                    if (timed(run_sep, &t_sep) || timed(run_fb, &t_fb)) { rc = 1; break; }
+                    a.fb_b[bk] = (fb_force || t_fb < 0.97f * t_sep) ? 1 : 0;
+                    if (getenv("I2V_FUSE_DEBUG"))
+                        fprintf(stderr, "[i2v fastblock] %s group %zu (%d launches, %d -> %d mid channels) at %d frames: separate %.1f us, fused %.1f us -> %s\n",
+                                L == &n.fwd ? "fwd" : "bwd", i, a.fb_ok, a.conv.Cs, a.conv.Cd, lf, 1e3f * t_sep / 3, 1e3f * t_fb / 3, a.fb_b[bk] ? "fused" : "separate");
+                }
+                for (int j = 0; j < a.fb_ok; ++j) { Launch& m = (*L)[i + j]; m.conv.cfg = m.cfg_b[0] ? m.cfg_b[0] : m.conv.cfg; }
+            }
+    }
     // Fused pairs, per batch bucket: the two launches on their tuned tiles against the pair as one kernel (plain / halo staging).
     // (Only where timing means something: the host simulation of the tests has one configuration of everything.)
     // Opt-in (I2V_FUSE=1) since round 5: the fused kernel loses 7-35 % on every pair at the headline size and wins 1-2 % on three pairs at
@@ -1537,8 +1665,11 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
         // this 3x3 launch and the pointwise launch behind it as ONE kernel (mark_fusable / autotune): the next entry is skipped
         const int fuse = (l.kind == L_CONV && l.fuse_ok && li + 1 < L.size() && frames * l.conv.Hg * l.conv.Wg > 0 && fused_fits(l, L[li + 1], frames))
                              ? l.fuse_b[cfg_bucket(clips, n.maxN / n.Tin())] : 0;
+        // this launch and the next fb_ok - 1 as ONE fused fast-pathway block (mark_fusable / autotune): those entries are skipped
+        const int fb = (l.kind == L_CONV && l.fb_ok && li + l.fb_ok <= L.size() && frames * l.conv.Hg * l.conv.Wg > 0) ? l.fb_b[cfg_bucket(clips, n.maxN / n.Tin())] * l.fb_ok : 0;
         double flops = 0.0;
-        if (l.kind == L_CONV && l.alg_flops_per_frame > 0) flops = l.alg_flops_per_frame * frames;     // quad-row packings pad K
+        if (fb) { for (int j = 0; j < fb; ++j) { const Launch& m = L[li + j]; flops += m.alg_flops_per_frame > 0 ? m.alg_flops_per_frame * frames : 2.0 * frames * m.conv.Hg * m.conv.Wg * (double)m.conv.Cd * m.conv.K; } }
+        else if (l.kind == L_CONV && l.alg_flops_per_frame > 0) flops = l.alg_flops_per_frame * frames;     // quad-row packings pad K
         else if (l.kind == L_CONV) flops = 2.0 * frames * l.conv.Hg * l.conv.Wg * ((double)l.conv.Cd * l.conv.K + (fuse ? (double)L[li + 1].conv.Cd * L[li + 1].conv.K : 0.0));
         else if (l.kind == L_IMGGRAD) flops = l.alg_flops_per_frame * frames;
         else if (l.kind == L_AGEMM) flops = 2.0 * clips * (double)l.ag.Cc * l.ag.M * l.ag.N;
@@ -1575,6 +1706,17 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
             if (q.mask) b += 4.0 * out;
             if (q.gate) b += out / 8.0;
             if (q.gate_out) b += out / 8.0;
+            if (fb) {         // a fused fast-pathway block: its source, every member's weights and gate words, the last member's output (+ an identity residual)
+                const I2VConvParams& last = L[li + fb - 1].conv;
+                const double outl = (double)frames * last.Hg * last.Wg * last.Cd;
+                b = 4.0 * (src + outl);
+                for (int j = 0; j < fb; ++j) {
+                    const I2VConvParams& r = L[li + j].conv;
+                    const double o = (double)frames * r.Hg * r.Wg * r.Cd;
+                    b += 4.0 * (double)r.K * r.Cd + (r.gate ? o / 8.0 : 0.0) + (r.gate_out ? o / 8.0 : 0.0);
+                }
+                if (fb == 3) b += 4.0 * outl;
+            }
             if (fuse) {       // + the pointwise half: its weights, output and epilogue operands; the intermediate is neither written nor read
                 const I2VConvParams& r = L[li + 1].conv;
                 const double out2 = (double)frames * r.Hg * r.Wg * r.Cd;
@@ -1599,6 +1741,12 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
             case L_IMGGRAD: {
                 if (frames * l.conv.Hg * l.conv.Wg == 0) break;
                 if (fuse) { if (fused_run(l, L[li + 1], frames, x, fuse == 2, s)) return 1; ++li; break; }
+                if (fb) {
+                    const int rc = fast_run(L, li, frames, x, s);
+                    if (rc == 1) return 1;
+                    if (rc == 0) { li += fb - 1; break; }
+                    // (rc == 2: not eligible at this frame count -- the separate launches run, this one now and the others in their turn)
+                }
                 const int cb = l.cfg_b[cfg_bucket(clips, n.maxN / n.Tin())];
                 if (cb) l.conv.cfg = cb;
                 if (conv_run(l, frames, x, gx, accumulate, s)) return 1;
@@ -1748,6 +1896,20 @@ extern "C" int i2v_net_read_tensor(i2v_handle h, int net, int tensor, int which,
             if (vlo < hi && lo < vhi)
                 return fail("i2v_net_read_tensor: this tensor is the intermediate of a fused 3x3 -> pointwise pair and is never stored "
                             "(plan without I2V_FUSE / I2V_FORCE_FUSE to read it)");
+        }
+    // ... and so are the intermediates of a fused fast-pathway block (k_fastblock): every member's output but the last
+    for (const std::vector<Launch>* L : {&n->fwd, &n->bwd})
+        for (size_t i = 0; i < L->size(); ++i) {
+            const Launch& l = (*L)[i];
+            if (l.kind != L_CONV || !l.fb_ok || !(l.fb_b[0] | l.fb_b[1] | l.fb_b[2] | l.fb_b[3])) continue;
+            for (int j = 0; j + 1 < l.fb_ok && i + j < L->size(); ++j) {
+                const I2VConvParams& q = (*L)[i + j].conv;
+                const float* lo = q.dst; const float* hi = lo + (int64_t)(n->maxN / n->Tin() * std::max(1, q.To) - 1) * q.dst_nstride + (int64_t)q.Cd * q.Ho * q.Wo;
+                const float* vlo = v.p; const float* vhi = v.p + (int64_t)(frames - 1) * v.nstride + (int64_t)v.C * v.H * v.W;
+                if (vlo < hi && lo < vhi)
+                    return fail("i2v_net_read_tensor: this tensor is an intermediate of a fused fast-pathway block and is never stored "
+                                "(plan with I2V_FASTBLOCK=0 to read it)");
+            }
         }
     size_t row = (size_t)v.C * v.H * v.W * sizeof(float);
     CHECK_BE(be_d2d_2d(out, row, v.p, (size_t)v.nstride * sizeof(float), row, frames, stream));

@@ -1,0 +1,323 @@
+// Fused bottleneck of SlowFast's fast pathway (round 6): I2VFastBlockParams / k_fastblock.
+//
+// The fast pathway's res-stage blocks have 8 mid channels -- half of a 16-row MFMA fragment -- on 128 frames of 56 x 56: as separate
+// conv_igemm launches (conv1 3x1x1 32 -> 8, conv2 1x3x3 8 -> 8, conv3 1x1x1 8 -> 32 + residual + ReLU; backward: the input gradients
+// in reverse) they take 17-45 us each at 1-17 TFLOP/s and 0.7-3.8 TB/s: on neither roof, per-launch latency and half-empty fragments
+// (profiles/r5_ilaf_breakdown_slowfast.txt; a quarter of an ILAF step).  Here a block of 128 threads takes R whole rows of ONE frame and
+// runs the block's convolutions back to back:
+//   stage A  (conv1, or conv3's input gradient) on the R + 2 rows the 3 x 3 stage needs, one position per lane, operands straight
+//            from global memory (consecutive lanes = consecutive pixels: 256-byte requests), results into LDS as [channel][row][col + 2]
+//            with zero columns / rows where the 3 x 3 stage pads;
+//   stage B  (conv2 or its input gradient) on the R rows, operands from LDS at k-table offsets;
+//   stage C  (forward: conv3 + the residual -- a tensor, or the projection shortcut computed here -- + ReLU) on the lane's own pixel.
+// The arithmetic is packed fp32 FMA on the vector unit: a lane holds the channel PAIRS of its pixel (v_pk_fma_f32: weight pair from
+// SGPRs, the operand broadcast to both halves), 2 FMAs per lane and issue slot -- the fp32 MFMA's own rate without its empty rows.
+// An fp32 MFMA is a k-ordered fmaf chain per output element; this kernel walks the SAME packed K order (the launches' own weights and
+// k-tables) with fmaf, applies the same epilogue operations in the same order, and skips only what adds an exact zero (zero-weight
+// padding rows, taps outside the clip or the plane): bit-identical to the launches it replaces (tests/test_gpu_video.py), which is
+// what lets the plan-time autotuner choose between the two.
+#include "i2v_be.h"
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) f2* wptr_t;       // packed weights through the constant address space: scalar loads, SGPR operands
+
+long long g_stat_fastblock = 0;
+
+__device__ __forceinline__ unsigned fb_ballot_lo(unsigned long long b) { return (unsigned)b; }
+
+typedef const __attribute__((address_space(4))) float* cfptr_t;   // per-channel vectors (shifts) through the constant address space: scalar loads
+
+// 1-bit gates of NC channels for this wave's 64 consecutive pixels (first one at bit index `bit0`, a multiple of 32; the strip ends at
+// `bit_end`, a multiple of 32): lane c keeps channel c's two words (`fb_gate_collect`, one ballot per channel), then lanes 0 .. NC - 1
+// store them (`fb_gate_store`: two store instructions for all channels)
+__device__ __forceinline__ void fb_gate_collect(unsigned& lo, unsigned& hi, const int c, const bool on, const int lane) {
+    const unsigned long long m = __ballot(on);
+    if (lane == c) { lo = (unsigned)m; hi = (unsigned)(m >> 32); }
+}
+__device__ __forceinline__ void fb_gate_store(uint32_t* rows, const int stride, const int NC, const unsigned lo, const unsigned hi, const int64_t bit0, const int64_t bit_end,
+                                              const int lane) {
+    if (lane < NC) {
+        uint32_t* const w = rows + (int64_t)lane * stride + (bit0 >> 5);
+        if (bit0 < bit_end) w[0] = lo;
+        if (bit0 + 32 < bit_end) w[1] = hi;
+    }
+}
+
+// LDS image of a block: the decoded k-tables of stages A and B (int per K row: element offset, or FB_SKIP for a row that adds an exact
+// zero), then stage A's result [CM][R + 2][W + 2].
+#define FB_SKIP (-0x40000000)
+// CM: mid channels (8: SlowFast's fast pathway; 4: the tiny test graphs).  FWD: forward block (stages A, B, C: shift + ReLU + own gates each)
+// or backward (stages A, B: the gates of the tensors whose gradients they are).  PROJ: the forward block's shortcut is a projection.
+template <int CM, bool FWD, bool PROJ>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4)))      // (7 blocks of 2 waves per CU at 128 frames of 56 x 56: all resident at once)
+fast_block_kernel(const I2VFastBlockParams p) {
+    constexpr int CP = CM / 2, C3 = 4 * CM, C3P = C3 / 2, PA = 3;      // PA: stage-A positions a lane works on at once (their loads in flight together)
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int H = p.H, W = p.W, R = p.R, HW = H * W, AR = R + 2, AW = W + 2;
+    int* const tabA = reinterpret_cast<int*>(lds_f);                    // [a.Kpad]
+    int* const tabB = tabA + p.a.Kpad;                                   // [b.Kpad]
+    float* const A1 = lds_f + ((p.a.Kpad + p.b.Kpad + 3) & ~3);          // [CM][AR][AW]
+    // Block -> (clip, frame, strip).  Workgroups go to the 8 XCDs round robin, each XCD with its own L2: a UNIT -- one clip's frames over
+    // a group of strips -- is given to ONE XCD and walked frame by frame there, so that a frame read as tap t - 1, t, t + 1 (and a halo
+    // row read by two strips) comes from HBM once and from that L2 afterwards.  All of it in scalar registers (uniform base addresses).
+    const unsigned b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
+    const unsigned uix = fastdiv(slot, p.dv_bu_m, p.dv_bu_s), i = slot - uix * p.BU, u = xcd + 8u * uix;      // unit, block within the unit
+    if (u >= (unsigned)p.U) return;
+    const int clip = (int)fastdiv(u, p.dv_s_m, p.dv_s_s), sg = (int)u - clip * p.S;
+    const int t = (int)fastdiv(i, p.dv_g_m, p.dv_g_s), strip = sg * p.G + ((int)i - t * p.G);
+    const int n = clip * p.T + t, r0 = strip * R;
+    // ---- decode the k-tables once per block: what a K row reads, as an offset; rows that add an exact zero (padding rows, taps outside
+    // the clip) are marked and skipped ----
+    for (int k = tid; k < p.a.Kpad; k += 128) {
+        const I2VKEntry e = p.a.ktab[k];
+        const int tf = t + (e.valid >> 1);
+        tabA[k] = ((e.valid & 1) && tf >= 0 && tf < p.T) ? (int)((int64_t)tf * p.src_nstride) + e.chan_off : FB_SKIP;      // (elements from the clip's first frame: < 2^30, k_fastblock checks)
+    }
+    for (int k = tid; k < p.b.Kpad; k += 128) {
+        const I2VKEntry e = p.b.ktab[k];
+        tabB[k] = (e.valid & 1) ? ((int)fastdiv((unsigned)e.chan_off, p.dv_hw_m, p.dv_hw_s) * AR + e.dh) * AW + e.dw : FB_SKIP;
+    }
+    // zero borders of stage A's image: columns 0 and W + 1 of every (channel, row)
+    for (int i = tid; i < CM * AR * 2; i += 128) A1[(i >> 1) * AW + ((i & 1) ? AW - 1 : 0)] = 0.f;
+    __syncthreads();
+    // ---------------- stage A: R + 2 rows, PA positions per lane at once ----------------
+    {
+        const wptr_t w = (wptr_t)p.a.wp;
+        const int wrow = p.a.Cdpad / 2;
+        const float* const fbase = p.src + (int64_t)(clip * p.T) * p.src_nstride;          // the clip's first frame
+        for (int q0 = tid; q0 < AR * W; q0 += 128 * PA) {
+            // position q of the (R + 2) x W grid is plane pixel (r0 - 1) W + q: rows are contiguous (only the LDS image, two columns wider, needs the row)
+            int pix[PA]; unsigned pxu[PA];
+#pragma unroll
+            for (int u = 0; u < PA; ++u) {
+                const int px = (r0 - 1) * W + q0 + 128 * u;
+                pix[u] = (q0 + 128 * u < AR * W && px >= 0 && px < HW) ? px : -1;           // -1: outside the plane (zero padding of the 3 x 3 stage) or no such position
+                pxu[u] = pix[u] < 0 ? 0u : (unsigned)pix[u];
+            }
+            unsigned gw[PA][FWD ? 1 : CM];            // backward: the gate words of this stage's tensor at the lane's positions, requested with the operands
+            if (!FWD) {
+#pragma unroll
+                for (int u = 0; u < PA; ++u)
+#pragma unroll
+                    for (int c = 0; c < CM; ++c) gw[u][c] = p.a.gate[(int64_t)c * p.a.gate_stride + (((int64_t)n * HW + pxu[u]) >> 5)];
+            }
+            f2 acc[PA][CP];
+#pragma unroll
+            for (int u = 0; u < PA; ++u)
+#pragma unroll
+                for (int c = 0; c < CP; ++c) acc[u][c] = f2{0.f, 0.f};
+            float xa[PA][8], xb[PA][8];
+            // software pipeline over chunks of 8 K rows: the next chunk's operands are requested before this chunk's FMAs
+#define FB_LOAD(K0, X)                                                                                     \
+            {                                                                                              \
+                const int4 o0 = *reinterpret_cast<const int4*>(tabA + (K0)), o1 = *reinterpret_cast<const int4*>(tabA + (K0) + 4);      \
+                const int off[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};                         \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
+                    const int ou = __builtin_amdgcn_readfirstlane(off[j]);       /* (uniform: a scalar base, the lane's pixel as the 32-bit offset) */ \
+                    const float* const bk = fbase + (ou == FB_SKIP ? 0 : ou);                              \
+                    _Pragma("unroll") for (int u = 0; u < PA; ++u) X[u][j] = bk[pxu[u]];                    \
+                    if (ou == FB_SKIP) { _Pragma("unroll") for (int u = 0; u < PA; ++u) X[u][j] = 0.f; }     \
+                }                                                                                          \
+            }
+#define FB_FMA(K0, X)                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                \
+                f2 wv[CP];                                                                                 \
+                _Pragma("unroll") for (int c = 0; c < CP; ++c) wv[c] = w[(int64_t)((K0) + j) * wrow + c];   \
+                _Pragma("unroll") for (int u = 0; u < PA; ++u) {                                           \
+                    const f2 xx = f2{X[u][j], X[u][j]};                                                    \
+                    _Pragma("unroll") for (int c = 0; c < CP; ++c) acc[u][c] = __builtin_elementwise_fma(wv[c], xx, acc[u][c]);      \
+                }                                                                                          \
+            }
+            FB_LOAD(0, xa)
+            for (int k0 = 0; k0 < p.a.Kpad; k0 += 16) {           // (Kpad is a multiple of 16)
+                FB_LOAD(k0 + 8, xb)
+                FB_FMA(k0, xa)
+                if (k0 + 16 < p.a.Kpad) FB_LOAD(k0 + 16, xa)
+                FB_FMA(k0 + 8, xb)
+            }
+#undef FB_LOAD
+#undef FB_FMA
+            float sh[CM];
+#pragma unroll
+            for (int c = 0; c < CM; ++c) sh[c] = FWD ? ((cfptr_t)p.a.shift)[c] : 0.f;
+#pragma unroll
+            for (int u = 0; u < PA; ++u) {
+                const int q = q0 + 128 * u;
+                if (q >= AR * W) continue;
+                const int row = (int)fastdiv((unsigned)q, p.dv_w_m, p.dv_w_s), col = q - row * W;
+                const bool inside = pix[u] >= 0;
+                const unsigned bitn = (unsigned)(((int64_t)n * HW + pxu[u]) & 31);
+#pragma unroll
+                for (int c = 0; c < CM; ++c) {
+                    float v = (c & 1) ? acc[u][c >> 1].y : acc[u][c >> 1].x;
+                    if (FWD) v = fmaxf(v + sh[c], 0.f);
+                    else if (!((gw[u][c] >> bitn) & 1u)) v = 0.f;
+                    A1[(c * AR + row) * AW + col + 1] = inside ? v : 0.f;                   // rows outside the plane: the 3 x 3 stage's zero padding
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------- stages B (and C): the R rows, one pixel per lane ----------------
+    const int RW = R * W;
+    const int64_t bit_strip = (int64_t)n * HW + (int64_t)r0 * W, bit_end = bit_strip + RW;
+    for (int pp0 = tid - lane; pp0 < RW; pp0 += 128) {           // (every lane of a wave runs the round: the gate words come from ballots)
+        const int pp = pp0 + lane;
+        const bool act = pp < RW;
+        const int ppc = act ? pp : 0;
+        const int row = (int)fastdiv((unsigned)ppc, p.dv_w_m, p.dv_w_s), col = ppc - row * W;
+        const unsigned upix = (unsigned)(r0 * W + ppc);          // (uniform base + this 32-bit offset: one address register per access)
+        const int64_t bit0 = bit_strip + pp0;
+        const float* const ctr = A1 + (row + 1) * AW + col + 1;     // the lane's own position in channel 0
+        // operands of the later stages, requested now: the residual (an identity shortcut) or the projection's inputs; backward: gate words
+        f2 res[FWD ? C3P : 1];
+        float xs_[PROJ ? CM : 1];
+        unsigned gw[FWD ? 1 : CM];
+        if (FWD && !PROJ) {
+            const float* const rs = p.add0 + (int64_t)n * p.add0_nstride;
+#pragma unroll
+            for (int c = 0; c < C3P; ++c) res[c] = f2{(rs + (int64_t)(2 * c) * HW)[upix], (rs + (int64_t)(2 * c + 1) * HW)[upix]};
+        }
+        if (PROJ) {
+            const float* const xs = p.src + (int64_t)n * p.src_nstride;
+#pragma unroll
+            for (int k = 0; k < CM; ++k) xs_[k] = (xs + (int64_t)k * HW)[upix];
+        }
+        if (!FWD) {
+#pragma unroll
+            for (int c = 0; c < CM; ++c) gw[c] = p.b.gate[(int64_t)c * p.b.gate_stride + (((int64_t)n * HW + upix) >> 5)];
+        }
+        if (FWD) {                   // stage A's own gates, from the finished values in LDS (post-ReLU: > 0 is the bit)
+            unsigned glo = 0, ghi = 0;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) fb_gate_collect(glo, ghi, c, act && ctr[c * AR * AW] > 0.f, lane);
+            fb_gate_store(p.a.gate_out, p.a.gate_out_stride, CM, glo, ghi, bit0, bit_end, lane);
+        }
+        f2 acc[CP];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) acc[c] = f2{0.f, 0.f};
+        {
+            const wptr_t w = (wptr_t)p.b.wp;
+            const int wrow = p.b.Cdpad / 2;
+            for (int k0 = 0; k0 < p.b.Kpad; k0 += 8) {
+                const int4 o0 = *reinterpret_cast<const int4*>(tabB + k0), o1 = *reinterpret_cast<const int4*>(tabB + k0 + 4);
+                const int off[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float v = ctr[off[j] == FB_SKIP ? 0 : off[j]]; x[j] = off[j] == FB_SKIP ? 0.f : v; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f2 xx = f2{x[j], x[j]};
+#pragma unroll
+                    for (int c = 0; c < CP; ++c) acc[c] = __builtin_elementwise_fma(w[(int64_t)(k0 + j) * wrow + c], xx, acc[c]);
+                }
+            }
+        }
+        float a2[CM];
+        {
+            const unsigned bitn = (unsigned)(((int64_t)n * HW + upix) & 31);
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                float v = (c & 1) ? acc[c >> 1].y : acc[c >> 1].x;
+                if (FWD) v = fmaxf(v + ((cfptr_t)p.b.shift)[c], 0.f);
+                else if (!((gw[c] >> bitn) & 1u)) v = 0.f;
+                a2[c] = v;
+            }
+        }
+        if (!FWD) {                  // backward: stage B's result is the output
+            if (act) {
+                float* const o = p.dst + (int64_t)n * p.dst_nstride;
+#pragma unroll
+                for (int c = 0; c < CM; ++c) (o + (int64_t)c * HW)[upix] = a2[c];
+            }
+            continue;
+        }
+        {
+            unsigned glo = 0, ghi = 0;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) fb_gate_collect(glo, ghi, c, act && a2[c] > 0.f, lane);
+            fb_gate_store(p.b.gate_out, p.b.gate_out_stride, CM, glo, ghi, bit0, bit_end, lane);
+        }
+        // ---------------- stage C: conv3 (pointwise over the lane's own a2: K row k is channel k) + residual + ReLU ----------------
+        if (PROJ) {                  // projection shortcut: pointwise over x[t] (K row k is channel k), + its shift: the value the separate launch stores
+#pragma unroll
+            for (int c = 0; c < C3P; ++c) res[c] = f2{0.f, 0.f};
+            const wptr_t w = (wptr_t)p.d.wp;
+            const int wrow = p.d.Cdpad / 2;
+#pragma unroll
+            for (int k = 0; k < CM; ++k) {
+                const f2 xx = f2{xs_[k], xs_[k]};
+#pragma unroll
+                for (int c = 0; c < C3P; ++c) res[c] = __builtin_elementwise_fma(w[(int64_t)k * wrow + c], xx, res[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < C3P; ++c) res[c] = f2{res[c].x + ((cfptr_t)p.d.shift)[2 * c], res[c].y + ((cfptr_t)p.d.shift)[2 * c + 1]};
+        }
+        f2 o3[C3P];
+#pragma unroll
+        for (int c = 0; c < C3P; ++c) o3[c] = f2{0.f, 0.f};
+        {
+            const wptr_t w = (wptr_t)p.c.wp;
+            const int wrow = p.c.Cdpad / 2;
+#pragma unroll
+            for (int k = 0; k < CM; ++k) {
+                const f2 xx = f2{a2[k], a2[k]};
+#pragma unroll
+                for (int c = 0; c < C3P; ++c) o3[c] = __builtin_elementwise_fma(w[(int64_t)k * wrow + c], xx, o3[c]);
+            }
+        }
+        float* const o = p.dst + (int64_t)n * p.dst_nstride;
+        unsigned glo = 0, ghi = 0;
+#pragma unroll
+        for (int c = 0; c < C3; ++c) {
+            float v = ((c & 1) ? o3[c >> 1].y : o3[c >> 1].x) + ((cfptr_t)p.c.shift)[c];
+            v += (c & 1) ? res[c >> 1].y : res[c >> 1].x;
+            v = fmaxf(v, 0.f);
+            if (act) (o + (int64_t)c * HW)[upix] = v;
+            fb_gate_collect(glo, ghi, c, act && v > 0.f, lane);
+        }
+        fb_gate_store(p.c.gate_out, p.c.gate_out_stride, C3, glo, ghi, bit0, bit_end, lane);
+    }
+}
+
+static void fb_stage(I2VFastStage& st, const I2VConvParams& q) {
+    st.wp = q.wp; st.ktab = q.ktab; st.Kpad = q.Kpad; st.Cdpad = q.Cdpad; st.shift = q.shift; st.relu = q.relu;
+    st.gate = q.gate; st.gate_stride = q.gate_stride; st.gate_pix0 = q.gate_pix0;
+    st.gate_out = q.gate_out; st.gate_out_stride = q.gate_out_stride; st.gate_out_pix0 = q.gate_out_pix0;
+}
+
+int k_fastblock(const I2VConvParams& a, const I2VConvParams& b, const I2VConvParams* c, const I2VConvParams* d, i2v_stream_t s) {
+    const int R = i2v_fastblock_rows(a, b, c, d);
+    if (R <= 0) { snprintf(g_be_err, sizeof g_be_err, "fast-block launch: the convolutions are not eligible"); g_be_has_err = true; return 1; }
+    I2VFastBlockParams p;
+    memset(&p, 0, sizeof p);
+    p.mode = c ? 0 : 1; p.CM = a.Cd;
+    p.src = a.src; p.src_nstride = a.src_nstride; p.Cs = a.Cs;
+    p.N = a.N; p.T = a.Tg; p.H = a.Hg; p.W = a.Wg; p.R = R;
+    fb_stage(p.a, a); fb_stage(p.b, b);
+    if (c) { fb_stage(p.c, *c); p.dst = c->dst; p.dst_nstride = c->dst_nstride; if (!d) { p.add0 = c->add0; p.add0_nstride = c->add0_nstride; } }
+    else { p.dst = b.dst; p.dst_nstride = b.dst_nstride; }
+    if (d) fb_stage(p.d, *d);
+    fastdiv_magic((unsigned)p.W, &p.dv_w_m, &p.dv_w_s);
+    fastdiv_magic((unsigned)(p.H * p.W), &p.dv_hw_m, &p.dv_hw_s);
+    if (p.N <= 0) return 0;
+    // units for the XCD mapping: a clip's frames over a group of G strips, S groups per frame -- the fewest groups that give every XCD a unit
+    const int strips = p.H / R, clips = p.N / p.T;
+    int S = strips;
+    for (int dv = 1; dv <= strips; ++dv) if (strips % dv == 0 && (int64_t)clips * dv >= 8) { S = dv; break; }
+    p.S = S; p.G = strips / S; p.U = clips * S; p.BU = p.T * p.G;
+    fastdiv_magic((unsigned)p.BU, &p.dv_bu_m, &p.dv_bu_s); fastdiv_magic((unsigned)p.S, &p.dv_s_m, &p.dv_s_s); fastdiv_magic((unsigned)p.G, &p.dv_g_m, &p.dv_g_s);
+    const int64_t nblk = 8ll * ((p.U + 7) / 8) * p.BU;
+    if (nblk > 0x7fffffff) { snprintf(g_be_err, sizeof g_be_err, "fast-block grid too large"); g_be_has_err = true; return 1; }
+    const dim3 grid((unsigned)nblk);
+    if ((int64_t)p.T * p.src_nstride >= (1ll << 30)) { snprintf(g_be_err, sizeof g_be_err, "fast-block launch: a clip's frames span more than 2^30 elements"); g_be_has_err = true; return 1; }
+    const size_t lds = (((size_t)a.Kpad + b.Kpad + 3) & ~(size_t)3) * sizeof(int) + (size_t)p.CM * (R + 2) * (p.W + 2) * sizeof(float);
+    __atomic_fetch_add(&g_stat_fastblock, 1, __ATOMIC_RELAXED);
+#define FB_GO(CMV, FW, PR) hipLaunchKernelGGL((fast_block_kernel<CMV, FW, PR>), grid, dim3(128), lds, (hipStream_t)s, p)
+    if (p.CM == 8) { if (!c) FB_GO(8, false, false); else if (d) FB_GO(8, true, true); else FB_GO(8, true, false); }
+    else { if (!c) FB_GO(4, false, false); else if (d) FB_GO(4, true, true); else FB_GO(4, true, false); }
+#undef FB_GO
+    LAUNCH_CHECK("fast_block_kernel");
+    return 0;
+}

@@ -45,7 +45,44 @@ inline bool i2v_conv_pair_fusable(const I2VConvParams& a, const I2VConvParams& b
     return true;
 }
 int k_conv_fused(const I2VConvParams& a, const I2VConvParams& b, int halo, i2v_stream_t s);
-int k_conv_candidates(const I2VConvParams& p, int* out);   // tile configurations valid for p (ids 0..5, +8 = no epilogue prefetch), returns count
+int k_conv_candidates(const I2VConvParams& p, int* out);
+// Fused fast-pathway block (I2VFastBlockParams; i2v_fastblock.hip): `a`, `b` and -- forward -- `c` (+ `d`, the projection shortcut, or
+// null) are the PREPPED parameters of the separate launches it replaces; backward: c == d == null.  The structural rule below is shared
+// by every backend (the k-tables are not inspected: that `a` has temporal / pointwise taps only and `b` is a 3 x 3 / pad-1 convolution
+// is the planner's statement, made from the graph nodes).  Returns the rows per block R (> 0) or 0.
+inline int i2v_fastblock_rows(const I2VConvParams& a, const I2VConvParams& b, const I2VConvParams* c, const I2VConvParams* d) {
+    auto plain = [](const I2VConvParams& q) {
+        return !q.pre_scale && !q.gate_scale && q.blk <= 1 && q.blkt <= 1 && q.sh == 1 && q.sw == 1 && q.osh == 1 && q.osw == 1 && q.oh0 == 0 &&
+               q.ow0 == 0 && q.Hs == q.Hg && q.Hg == q.Ho && q.Ws == q.Wg && q.Wg == q.Wo && q.Tg == q.Ts && q.Ts == q.To && q.st == 1 && q.ost == 1 && q.ot0 == 0 &&
+               !q.add1 && !q.mask && q.Kpad % 8 == 0 && q.Kpad <= 512 && q.gate_pix0 == 0 && q.gate_out_pix0 == 0;
+    };
+    if (!plain(a) || !plain(b) || a.quad || a.add0 || b.add0) return 0;
+    const int CM = a.Cd;
+    if ((CM != 4 && CM != 8) || b.Cd != CM || b.Cs != CM || b.src != a.dst || b.src_nstride != a.dst_nstride) return 0;
+    if (b.Hg != a.Hg || b.Wg != a.Wg || b.Tg != a.Tg || b.N != a.N) return 0;
+    const int H = a.Hg, W = a.Wg;
+    if ((H * W) % 32 != 0 || (int64_t)a.N * a.src_nstride * 4 >= (1ll << 31)) return 0;
+    if (c) {        // forward
+        if (!plain(*c) || c->quad || !a.relu || !b.relu || a.gate || b.gate || c->gate || !c->relu || !a.shift || !b.shift || !c->shift || !a.gate_out || !b.gate_out || !c->gate_out) return 0;
+        if (c->src != b.dst || c->src_nstride != b.dst_nstride || c->Cs != CM || c->K != CM || c->Cd != 4 * CM || c->Hg != H || c->Wg != W || c->Tg != a.Tg || c->N != a.N) return 0;
+        if (!c->add0 || c->add0_stride != 1) return 0;
+        if (d) {
+            if (!plain(*d) || d->quad || d->relu || d->add0 || d->gate || d->gate_out || !d->shift || d->src != a.src || d->src_nstride != a.src_nstride || d->Cs != a.Cs ||
+                d->K != a.Cs || d->K != CM || d->Cd != c->Cd || d->Hg != H || d->Wg != W || d->Tg != a.Tg || d->N != a.N || c->add0 != d->dst || c->add0_nstride != d->dst_nstride) return 0;
+        }
+    } else {        // backward: plain input gradients (their gates, no ReLU)
+        if (d || a.relu || b.relu || a.gate_out || b.gate_out || a.shift || b.shift || !a.gate || !b.gate || a.K != a.Cs || a.K > 64) return 0;
+    }
+    int g = W, r32 = 32; while (r32) { const int t = g % r32; g = r32; r32 = t; }      // gcd(W, 32)
+    const int Rq = 32 / g;
+    if (H % Rq != 0) return 0;
+    int R = Rq;
+    while (R * W < 192 && R * 2 <= H && H % (R * 2) == 0) R *= 2;
+    if ((size_t)CM * (R + 2) * (W + 2) * 4 > 60 * 1024) return 0;
+    return R;
+}
+int k_fastblock(const I2VConvParams& a, const I2VConvParams& b, const I2VConvParams* c, const I2VConvParams* d, i2v_stream_t s);
+   // tile configurations valid for p (ids 0..5, +8 = no epilogue prefetch), returns count
 int k_pool_fwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_pool_bwd(const I2VPoolParams& p, i2v_stream_t s);
 int k_pool3d_fwd(const I2VPoolParams& p, i2v_stream_t s);  // video max pooling (kt/stride_t/pad_t honoured)

@@ -27,6 +27,7 @@ long long be_stat(const char* name) {
     if (!strcmp(name, "bf3_launches")) return __atomic_load_n(&g_stat_bf3, __ATOMIC_RELAXED);
     if (!strcmp(name, "ighalo_launches")) return __atomic_load_n(&g_stat_igh, __ATOMIC_RELAXED);
     if (!strcmp(name, "stemhalo_launches")) return __atomic_load_n(&g_stat_sth, __ATOMIC_RELAXED);
+    if (!strcmp(name, "fastblock_launches")) return __atomic_load_n(&g_stat_fastblock, __ATOMIC_RELAXED);
 #ifdef I2V_EXPERIMENTAL      // 1: the library carries the experimental kernels (fused pair, split-bf16 loop, conv_pw_stream, conv_stem64_halo)
     if (!strcmp(name, "experimental")) return 1;
 #else
@@ -173,7 +174,7 @@ int k_conv(const I2VConvParams& p_in, i2v_stream_t s) {
     }
     // Bit 10 pins a halo-tile stem kernel, and the executor then hands the caller's frames over WITHOUT the staging copy whose slack
     // conv_tile's quad-row staging (MODE 4) reads: a quad-row stem that carries the bit and is not eligible must not fall through to it.
-    if (((p.cfg - 1) & 1024) && p.quad && !p.ig_th) {      // (a forward quad-row stem; other launches ignore the bit, as under I2V_FORCE_CFG)
+    if (((p.cfg - 1) & 1024) && p.quad && !p.ig_th && p.sh > 1) {      // (a STRIDED forward quad-row launch is a stem reading the caller's frames; other launches ignore the bit, as under I2V_FORCE_CFG)
         snprintf(g_be_err, sizeof g_be_err, "conv launch pinned to a halo-tile stem kernel (configuration bit 10) is not eligible for one (source %s16-byte aligned)",
                  ((uintptr_t)p.src & 15) ? "not " : "");
         g_be_has_err = true;

@@ -93,6 +93,34 @@ struct I2VConvParams {
     int32_t cfg;            // 0: pick the tile configuration with the cost model; c+1: use configuration c (autotuned; bit 3 of c = no epilogue-operand prefetch)
 };
 
+// One convolution stage of a fused fast-pathway block (I2VFastBlockParams): its packed weights / k-table and the parts of its epilogue.
+struct I2VFastStage {
+    const float* wp; const I2VKEntry* ktab; int32_t Kpad, Cdpad;
+    const float* shift; int32_t relu;
+    const uint32_t* gate; int32_t gate_stride, gate_pix0;          // input-gradient stages: the 1-bit gates of the tensor whose gradient this is
+    uint32_t* gate_out; int32_t gate_out_stride, gate_out_pix0;    // forward stages: this tensor's own gates
+};
+// A bottleneck of SlowFast's FAST pathway (8 mid channels: half a 16-row MFMA fragment, 17-45 us launches at 1-17 TFLOP/s when run one
+// convolution at a time) as ONE launch on packed-fp32 vector FMAs, intermediates in LDS / registers (k_fastblock, i2v_fastblock.hip):
+//   forward  (mode 0):  A = conv1 (k x 1 x 1 temporal or pointwise, Cs -> CM) -> B = conv2 (1 x 3 x 3, CM -> CM) ->
+//                       C = conv3 (pointwise, CM -> 4 CM) + residual (a tensor, or the projection D = downsample(x) computed here) + ReLU
+//   backward (mode 1):  A = conv3's input gradient (pointwise, 4 CM -> CM) -> B = conv2's input gradient (3 x 3) -> stored (CM channels)
+// Every output element is the same k-ordered fmaf chain over the same fp32 values as in the separate conv_igemm launches (an fp32 MFMA
+// IS such a chain; rows with zero weights or zero operands add exact zeros), followed by the same epilogue operations in the same
+// order: bit-identical, which is what lets the autotuner choose.  A block takes R whole rows of one frame (R W a multiple of 32: gate
+// words are never shared between blocks); stage A is computed on R + 2 rows (the 3 x 3 stage's halo).
+struct I2VFastBlockParams {
+    int32_t mode, CM;
+    const float* src; int64_t src_nstride; int32_t Cs;      // stage A's source view (x, or the gradient of the block's output)
+    int32_t N, T, H, W, R;                                   // frames, frames per clip, plane, rows per block
+    I2VFastStage a, b, c, d;                                 // c / d: forward only (d.wp == nullptr: no projection)
+    const float* add0; int64_t add0_nstride;                 // forward without projection: the residual tensor
+    float* dst; int64_t dst_nstride;                         // forward: the block's output (4 CM channels); backward: stage B's output (CM)
+    uint32_t dv_w_m, dv_w_s, dv_hw_m, dv_hw_s;               // exact division by W and by H W
+    int32_t U, S, G, BU;                                     // XCD mapping: units (= clips x S strip groups of G strips), blocks per unit (T G)
+    uint32_t dv_bu_m, dv_bu_s, dv_s_m, dv_s_s, dv_g_m, dv_g_s;
+};
+
 struct I2VPoolParams {
     const float* x;    int64_t x_nstride;    int32_t C, Hs, Ws;
     float* y;          int64_t y_nstride;    int32_t Ho, Wo;       // fwd: output; bwd: upstream grad

@@ -29,7 +29,8 @@ int be_d2d_2d(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t row
 }
 int be_memset0(void* p, size_t b, i2v_stream_t) { memset(p, 0, b); return 0; }
 const char* be_error() { return nullptr; }
-long long be_stat(const char*) { return -1; }
+static long long g_fastblock_launches = 0;
+long long be_stat(const char* name) { return !strcmp(name, "fastblock_launches") ? g_fastblock_launches : -1; }
 void* be_event_create() { return malloc(8); }
 void be_event_destroy(void* e) { free(e); }
 int be_event_record(void*, i2v_stream_t) { return 0; }
@@ -50,6 +51,22 @@ int k_conv_fused(const I2VConvParams& a, const I2VConvParams& b, int, i2v_stream
     // in the CPU tests instead of passing on values the GPU would not have
     for (int64_t f = 0; f < (int64_t)a.N / a.Tg * a.To; ++f)
         std::fill(a.dst + f * a.dst_nstride, a.dst + f * a.dst_nstride + (int64_t)a.Cd * a.Ho * a.Wo, std::numeric_limits<float>::quiet_NaN());
+    return 0;
+}
+// the fused fast-pathway block on the host: its convolutions one after the other (the device kernel keeps the intermediates in LDS /
+// registers -- same values either way), then the intermediates POISONED: a reader the planner overlooked shows up as NaN here instead
+// of passing on values the GPU would not have.  Forward order: a, b, [d], c; backward: a, b.
+int k_fastblock(const I2VConvParams& a, const I2VConvParams& b, const I2VConvParams* c, const I2VConvParams* d, i2v_stream_t s) {
+    if (i2v_fastblock_rows(a, b, c, d) <= 0) return 1;
+    ++g_fastblock_launches;
+    if (k_conv(a, s) || k_conv(b, s) || (d && k_conv(*d, s)) || (c && k_conv(*c, s))) return 1;
+    auto poison = [](const I2VConvParams& q) {
+        for (int64_t f = 0; f < (int64_t)q.N / q.Tg * q.To; ++f)
+            std::fill(q.dst + f * q.dst_nstride, q.dst + f * q.dst_nstride + (int64_t)q.Cd * q.Ho * q.Wo, std::numeric_limits<float>::quiet_NaN());
+    };
+    poison(a);
+    if (c) poison(b);
+    if (d) poison(*d);
     return 0;
 }
 int k_conv(const I2VConvParams& p, i2v_stream_t) {

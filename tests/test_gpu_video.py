@@ -704,6 +704,42 @@ def test_fused_3x3_pointwise_pairs_are_bit_identical(eng, monkeypatch, experimen
     assert float(outs[0][1].abs().max()) > 0
 
 
+@pytest.mark.parametrize("thw,width,clips", [((8, 32, 32), 16, 3), ((16, 64, 64), 64, 2), ((32, 224, 224), 64, 1)])
+def test_fast_pathway_block_kernel_is_bit_identical(eng, monkeypatch, thw, width, clips):
+    """`fast_block_kernel` (round 6): SlowFast's fast-pathway bottlenecks as ONE launch each way -- forward conv1 (3x1x1) -> conv2 (1x3x3)
+    -> [projection] -> conv3 + residual + ReLU with all three tensors' 1-bit gates, backward the input gradients of conv3 and conv2 --
+    on packed fp32 vector FMAs, forced onto every group the planner finds, against the separate conv_igemm launches: hooked features
+    and input gradient bit for bit.  4 mid channels on 8 x 8 planes (one strip per frame), 8 on 16 x 16, and the real thing: 8 mid
+    channels, 16 fast frames of 56 x 56 (14 strips of 4 rows per frame: strip borders, halo rows, first / last frame of a clip)."""
+    monkeypatch.setenv("I2V_AUTOTUNE", "0")
+    mt = "slowfast_resnet50"
+    g = graphs.slowfast_res2(width, thw, "sf_fb", **(graphs.SLOWFAST_8X8 if thw[0] >= 16 else dict(slow_stride=4, fast_stride=1, beta_inv=4)), blocks=3)
+    sd = weights.synthetic_state_dict(g, 0)
+    hooks = graphs.video_hooks(g, mt)
+    T = g.tensors[g.input].T
+    frames = clips * T
+    x = dev(torch.randn(frames, 3, *g.in_hw, generator=torch.Generator().manual_seed(0)))
+    outs, ran = [], []
+    for force in ("0", "1"):
+        monkeypatch.setenv("I2V_FORCE_FASTBLOCK", force)
+        net = eng.build_net(g, sd, hooks, frames)
+        before = eng.capi.i2v_backend_stat(b"fastblock_launches")
+        net.forward(x)
+        feats = [net.save_hook(i, clips * hi.T).cpu() for i, hi in enumerate(net.hooks)]
+        hg = [torch.randn(f.shape, generator=torch.Generator().manual_seed(7 + i)) for i, f in enumerate(feats)]
+        write_hook_grads(net, feats, hg)
+        gx = torch.full((frames, 3, *g.in_hw), float("nan"), device="cuda:0")
+        net.backward(gx)
+        torch.cuda.synchronize()
+        ran.append(eng.capi.i2v_backend_stat(b"fastblock_launches") - before)
+        outs.append((feats, gx.cpu()))
+        net.close()
+    assert ran == [0, 6], ran                      # three blocks forward, three backward
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b), thw
+    assert torch.equal(outs[0][1], outs[1][1]) and bool(torch.isfinite(outs[0][1]).all()) and float(outs[0][1].abs().max()) > 0
+
+
 def test_tail_split_is_bit_identical(eng, monkeypatch):
     """`conv_igemm_tail`: the remainder tiles of a launch as 16x64 quarter tiles in the same grid.  Forced onto every eligible launch
     (configuration 3 | 32) of a net whose layers leave remainders of 64 / 16 pixel tiles over the 256 CUs (576 and 144+... tiles), against
@@ -730,8 +766,9 @@ def test_tail_split_is_bit_identical(eng, monkeypatch):
 
 @pytest.mark.parametrize("name,hw,depths", [("resnet", 64, [2, 3]), ("vgg", 32, [3]), ("squeezenet", 64, [2, 3]), ("alexnet", 64, [3]),
                                             ("densenet121", 64, [2]), ("i3d_plain_resnet50", (8, 32, 32), None),
-                                            ("slowfast_resnet50", (8, 32, 32), None)])      # (i3d_plain: the non-local blocks' softmax
-def test_hip_kernels_bit_exact_against_scalar_restatement(eng, name, hw, depths):            #  calls expf, whose last bit is the math library's)
+                                            ("slowfast_resnet50", (8, 32, 32), None),      # (i3d_plain: the non-local blocks' softmax
+                                            ("slowfast_resnet50+fastblock", (8, 32, 32), None)])    #  calls expf, whose last bit is the math library's)
+def test_hip_kernels_bit_exact_against_scalar_restatement(eng, name, hw, depths, monkeypatch):
     """The strongest statement about the kernels: run the SAME planned launch lists on the gfx950 kernels and on their
     scalar host restatement (tests/hostsim/hostsim_backend.cpp: the literal definition of every launch-parameter struct,
     one fmaf per K row in packed-K order) and compare every activation and the input gradient BIT FOR BIT.  Holds because
@@ -740,6 +777,15 @@ def test_hip_kernels_bit_exact_against_scalar_restatement(eng, name, hw, depths)
     from tests.hostsim_util import hostsim_engine
     cpu = hostsim_engine()
     video = not isinstance(hw, int)
+    # "+fastblock" (round 6): the fast pathway's bottlenecks forced through the fused block kernel (`k_fastblock`: packed-fp32 vector FMAs
+    # walking the launches' own packed K order) on the device -- against the host's member-by-member restatement.  Otherwise the fused
+    # blocks are OFF on both sides: this test reads every intermediate back.
+    fast = name.endswith("+fastblock")
+    name = name.split("+")[0]
+    monkeypatch.setenv("I2V_FORCE_FASTBLOCK", "1" if fast else "0")
+    monkeypatch.setenv("I2V_FASTBLOCK", "1" if fast else "0")
+    if fast:
+        monkeypatch.setenv("I2V_AUTOTUNE", "0")
     if video:
         g = graphs.build_video_tiny(name, hw)
         hooks = graphs.video_hooks(g, name)
@@ -751,11 +797,20 @@ def test_hip_kernels_bit_exact_against_scalar_restatement(eng, name, hw, depths)
     sd = weights.synthetic_state_dict(g, 0)
     x = torch.randn(frames, 3, *shape, generator=torch.Generator().manual_seed(0))
     ng, nc = eng.build_net(g, sd, hooks, frames), cpu.build_net(g, sd, hooks, frames)
+    before = eng.capi.i2v_backend_stat(b"fastblock_launches")
     ng.forward(dev(x))
     nc.forward(x)
+    assert (eng.capi.i2v_backend_stat(b"fastblock_launches") - before > 0) == fast
     for nd in ng.graph.nodes:
         nf = frames // g.tensors[g.input].T * g.tensors[nd.dst].T
-        assert torch.equal(ng.read_tensor(nd.dst, nf).cpu(), nc.read_tensor(nd.dst, nf)), nd
+        try:
+            on_dev = ng.read_tensor(nd.dst, nf).cpu()
+        except RuntimeError as e:           # an intermediate of a fused block is never stored: refused by name (on both backends)
+            assert fast and "never stored" in str(e), (nd, e)
+            with pytest.raises(RuntimeError, match="never stored"):
+                nc.read_tensor(nd.dst, nf)
+            continue
+        assert torch.equal(on_dev, nc.read_tensor(nd.dst, nf)), nd
     feats = [nc.save_hook(i, nc.hook_frames(i, frames)) for i in range(len(hooks))]
     hg = [torch.randn(f.shape, generator=torch.Generator().manual_seed(1 + i)) for i, f in enumerate(feats)]
     write_hook_grads(ng, feats, hg)

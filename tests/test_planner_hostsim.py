@@ -403,3 +403,49 @@ def test_fusable_pairs_of_resnet50_are_found_and_change_nothing(monkeypatch):
     net = eng.build_net(g, sd, [g.hooks[3], t_conv2], 2)
     assert net.fusion_info()[0] == 5
     net.close()
+
+
+def test_fast_pathway_blocks_are_found_and_change_nothing(monkeypatch):
+    """Round 6, planner side of the fused fast-pathway block (`mark_fusable` -> `k_fastblock`): in SlowFast's fast res2 stage every
+    bottleneck's forward launches (conv1 -> conv2 -> [projection] -> conv3) form a group, and so do the input gradients of conv3 and
+    conv2 in the backward list (a first block's projection gradient, planned between them, is moved in front).  Forcing the groups
+    executes them through `k_fastblock` (on the host: the member convolutions one after the other, intermediates POISONED afterwards)
+    -- hooked features and input gradient unchanged; an intermediate cannot be read back; a hook on one removes its group."""
+    eng = hostsim_engine()
+    mt = "slowfast_resnet50"
+    g = graphs.build_video_tiny(mt, (8, 32, 32))
+    sd = weights.synthetic_state_dict(g, 0)
+    hooks = graphs.video_hooks(g, mt)
+    T = g.tensors[g.input].T
+    x = torch.randn(2 * T, 3, 32, 32, generator=torch.Generator().manual_seed(0))
+    outs, ran = [], []
+    for force in ("0", "1"):
+        monkeypatch.setenv("I2V_FORCE_FASTBLOCK", force)
+        net = eng.build_net(g, sd, hooks, 2 * T)
+        before = eng.capi.i2v_backend_stat(b"fastblock_launches")
+        net.forward(x)
+        feats = [net.save_hook(i, 2 * hi.T).clone() for i, hi in enumerate(net.hooks)]
+        write_hook_grads(net, feats, [torch.randn(f.shape, generator=torch.Generator().manual_seed(7 + i)) for i, f in enumerate(feats)], 2 * T)
+        gx = torch.empty(2 * T, 3, 32, 32)
+        net.backward(gx)
+        ran.append(eng.capi.i2v_backend_stat(b"fastblock_launches") - before)
+        outs.append((feats, gx.clone()))
+        if force == "1":
+            names = {(t.name or ""): i for i, t in enumerate(g.tensors)}
+            for nm, grad in (("fast_res2.1.conv1", False), ("fast_res2.1.conv2", False), ("fast_res2.0.downsample", False), ("fast_res2.1.conv2", True)):
+                with pytest.raises(RuntimeError, match="never stored"):
+                    net.read_tensor(names[nm], 2 * g.tensors[names[nm]].T, grad=grad)
+            assert bool(torch.isfinite(net.read_tensor(names["fast_res2.1.out"], 2 * g.tensors[names["fast_res2.1.out"]].T)).all())
+        net.close()
+    assert ran == [0, 4], ran                 # two blocks: forward (one with, one without the projection) and backward
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[0][1], outs[1][1]) and bool(torch.isfinite(outs[1][1]).all()) and float(outs[1][1].abs().max()) > 0
+    # a hook on block 1's conv2 output: that tensor has another reader now -- its forward group is gone, the other three stay
+    monkeypatch.setenv("I2V_FORCE_FASTBLOCK", "1")
+    names = {(t.name or ""): i for i, t in enumerate(g.tensors)}
+    net = eng.build_net(g, sd, hooks + [names["fast_res2.1.conv2"]], 2 * T)
+    before = eng.capi.i2v_backend_stat(b"fastblock_launches")
+    net.forward(x)
+    assert eng.capi.i2v_backend_stat(b"fastblock_launches") - before == 1
+    net.close()

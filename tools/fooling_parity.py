@@ -101,7 +101,10 @@ def calibrate(models, all_rows, rank, log=print):
         sd = dict(base.model.state_dict_for(g))
         sd["fc.weight"], sd["fc.bias"] = torch.from_numpy(W), torch.from_numpy(b)
         base._net.close()
-        _MODELS[m] = NativeClassifier(VideoModel(m, num_classes=400, state_dict=sd))
+        clf = NativeClassifier(VideoModel(m, num_classes=400, state_dict=sd))
+        _MODELS[m] = clf
+        import importlib                      # (run as a script this file is `__main__`; the evaluator's factory string imports it as `tools.fooling_parity`: fill both tables)
+        importlib.import_module("tools.fooling_parity")._MODELS[m] = clf
         log(f"[fooling_parity] calibrated head of {m}: {infos[m]}")
     return infos, feats
 
