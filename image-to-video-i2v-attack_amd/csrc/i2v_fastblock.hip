@@ -171,14 +171,8 @@ fast_block_kernel(const I2VFastBlockParams p) {
         const int64_t bit0 = bit_strip + pp0;
         const float* const ctr = A1 + (row + 1) * AW + col + 1;     // the lane's own position in channel 0
         // operands of the later stages, requested now: the residual (an identity shortcut) or the projection's inputs; backward: gate words
-        f2 res[FWD ? C3P : 1];
         float xs_[PROJ ? CM : 1];
         unsigned gw[FWD ? 1 : CM];
-        if (FWD && !PROJ) {
-            const float* const rs = p.add0 + (int64_t)n * p.add0_nstride;
-#pragma unroll
-            for (int c = 0; c < C3P; ++c) res[c] = f2{(rs + (int64_t)(2 * c) * HW)[upix], (rs + (int64_t)(2 * c + 1) * HW)[upix]};
-        }
         if (PROJ) {
             const float* const xs = p.src + (int64_t)n * p.src_nstride;
 #pragma unroll
@@ -240,42 +234,37 @@ fast_block_kernel(const I2VFastBlockParams p) {
             fb_gate_store(p.b.gate_out, p.b.gate_out_stride, CM, glo, ghi, bit0, bit_end, lane);
         }
         // ---------------- stage C: conv3 (pointwise over the lane's own a2: K row k is channel k) + residual + ReLU ----------------
-        if (PROJ) {                  // projection shortcut: pointwise over x[t] (K row k is channel k), + its shift: the value the separate launch stores
-#pragma unroll
-            for (int c = 0; c < C3P; ++c) res[c] = f2{0.f, 0.f};
-            const wptr_t w = (wptr_t)p.d.wp;
-            const int wrow = p.d.Cdpad / 2;
-#pragma unroll
-            for (int k = 0; k < CM; ++k) {
-                const f2 xx = f2{xs_[k], xs_[k]};
-#pragma unroll
-                for (int c = 0; c < C3P; ++c) res[c] = __builtin_elementwise_fma(w[(int64_t)k * wrow + c], xx, res[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < C3P; ++c) res[c] = f2{res[c].x + ((cfptr_t)p.d.shift)[2 * c], res[c].y + ((cfptr_t)p.d.shift)[2 * c + 1]};
-        }
-        f2 o3[C3P];
-#pragma unroll
-        for (int c = 0; c < C3P; ++c) o3[c] = f2{0.f, 0.f};
-        {
-            const wptr_t w = (wptr_t)p.c.wp;
-            const int wrow = p.c.Cdpad / 2;
-#pragma unroll
-            for (int k = 0; k < CM; ++k) {
-                const f2 xx = f2{a2[k], a2[k]};
-#pragma unroll
-                for (int c = 0; c < C3P; ++c) o3[c] = __builtin_elementwise_fma(w[(int64_t)k * wrow + c], xx, o3[c]);
-            }
-        }
+        // One output-channel PAIR per iteration of a ROLLED loop: its CM weight pairs (and the projection's) are scalar loads that live for
+        // one iteration -- unrolled over the 4 CM channels the allocator kept 8 CM^2 weights in SGPRs and spilled whole 16-register tuples to
+        // VGPR lanes around every FMA (3300 v_readlane / v_writelane in the first version).  Each output element still sums its K rows in order.
         float* const o = p.dst + (int64_t)n * p.dst_nstride;
+        const float* const rs = PROJ ? nullptr : p.add0 + (int64_t)n * p.add0_nstride;
         unsigned glo = 0, ghi = 0;
+        f2 rnext = f2{0.f, 0.f};
+        if (!PROJ) rnext = f2{rs[upix], (rs + HW)[upix]};
+#pragma unroll 1
+        for (int c = 0; c < C3P; ++c) {
+            f2 r = rnext;
+            if (!PROJ && c + 1 < C3P) rnext = f2{(rs + (int64_t)(2 * c + 2) * HW)[upix], (rs + (int64_t)(2 * c + 3) * HW)[upix]};      // the next pair's residual, a whole iteration ahead
+            if (PROJ) {              // projection shortcut: pointwise over x[t] (K row k is channel k), + its shift: the value the separate launch stores
+                r = f2{0.f, 0.f};
+                const wptr_t wd = (wptr_t)p.d.wp + c;
+                const int wrow = p.d.Cdpad / 2;
 #pragma unroll
-        for (int c = 0; c < C3; ++c) {
-            float v = ((c & 1) ? o3[c >> 1].y : o3[c >> 1].x) + ((cfptr_t)p.c.shift)[c];
-            v += (c & 1) ? res[c >> 1].y : res[c >> 1].x;
-            v = fmaxf(v, 0.f);
-            if (act) (o + (int64_t)c * HW)[upix] = v;
-            fb_gate_collect(glo, ghi, c, act && v > 0.f, lane);
+                for (int k = 0; k < CM; ++k) r = __builtin_elementwise_fma(wd[(int64_t)k * wrow], f2{xs_[k], xs_[k]}, r);
+                r = f2{r.x + ((cfptr_t)p.d.shift)[2 * c], r.y + ((cfptr_t)p.d.shift)[2 * c + 1]};
+            }
+            f2 ov = f2{0.f, 0.f};
+            {
+                const wptr_t w = (wptr_t)p.c.wp + c;
+                const int wrow = p.c.Cdpad / 2;
+#pragma unroll
+                for (int k = 0; k < CM; ++k) ov = __builtin_elementwise_fma(w[(int64_t)k * wrow], f2{a2[k], a2[k]}, ov);
+            }
+            const float v0 = fmaxf((ov.x + ((cfptr_t)p.c.shift)[2 * c]) + r.x, 0.f), v1 = fmaxf((ov.y + ((cfptr_t)p.c.shift)[2 * c + 1]) + r.y, 0.f);
+            if (act) { (o + (int64_t)(2 * c) * HW)[upix] = v0; (o + (int64_t)(2 * c + 1) * HW)[upix] = v1; }
+            fb_gate_collect(glo, ghi, 2 * c, act && v0 > 0.f, lane);
+            fb_gate_collect(glo, ghi, 2 * c + 1, act && v1 > 0.f, lane);
         }
         fb_gate_store(p.c.gate_out, p.c.gate_out_stride, C3, glo, ghi, bit0, bit_end, lane);
     }

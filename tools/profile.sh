@@ -3,7 +3,7 @@
 # Kernel-trace/stats and each PMC group are separate runs (never combine --pmc with sys/hip traces); the program
 # itself follows `--` (no env/bash hop).  The sources' build id (bench.build_id) is stored next to the results so that
 # bench.py only quotes traffic measured on the build it is running.
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
