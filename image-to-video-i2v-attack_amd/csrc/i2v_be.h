@@ -23,7 +23,7 @@ extern thread_local bool g_be_has_err;
 int hip_fail(hipError_t e, const char* what);
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x); } while (0)
 #define LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return hip_fail(e_, name); } while (0)
-extern long long g_stat_conv, g_stat_pws, g_stat_bf3, g_stat_igh, g_stat_sth, g_stat_fastblock;      // (relaxed counters: diagnostics only)
+extern long long g_stat_conv, g_stat_pws, g_stat_bf3, g_stat_igh, g_stat_sth, g_stat_fastblock, g_stat_vfma;      // (relaxed counters: diagnostics only)
 
 // n / d for 0 <= n < 2^31 with the precomputed (m, s) of fastdiv_magic: exact
 __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned m, unsigned s) {
@@ -112,6 +112,8 @@ bool conv_ighalo_ok(const I2VConvParams& p);                      // the 3-chann
 int launch_conv_ighalo(const I2VConvParams& p, hipStream_t s);
 bool conv_stemhalo_ok(const I2VConvParams& p);
 int launch_conv_stemhalo(const I2VConvParams& p, hipStream_t s);
+bool conv_vfma_ok(const I2VConvParams& p);                        // one narrow launch on packed-fp32 vector FMAs   i2v_fastblock.hip
+int launch_conv_vfma(const I2VConvParams& p, hipStream_t s);
 #ifdef I2V_EXPERIMENTAL
 #ifndef I2V_BF3_VARIANT
 #define I2V_BF3_VARIANT 1        // 1: weight fragments staged through LDS by DMA, I2V_BF3_STAGES buffers; 2: loaded straight into registers, one chunk ahead

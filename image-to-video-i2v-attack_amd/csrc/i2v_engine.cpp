@@ -267,6 +267,7 @@ static int pack_fwd(Net& n, Node& nd) {
     }
     // the 7x7 / stride-2 / pad-3 stem over 3 channels in (tap, channel) order: conv_stem64_halo may walk it without the k-table
     if (!P.tap_uniform && c.cin == 3 && c.kt == 1 && c.kh == 7 && c.kw == 7 && c.stride == 2 && c.pad == 3 && c.dil_t == 1 && c.pad_t == 0 && !nd.preact()) P.halo = 49;
+    if (c.kh == 1 && c.kw == 1 && c.pad == 0 && c.stride == 1 && !nd.preact()) P.halo = 1;      // every tap at (0, 0): k x 1 x 1 (conv_vfma_kernel's mark)
     std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
     std::vector<I2VKEntry> kt(P.Kpad, I2VKEntry{0, 0, 0, 0});
     // K order: (16-channel chunk, tap, channel in chunk) when the channel count allows -- each 16-row chunk keeps a
@@ -310,6 +311,7 @@ static int pack_bwd(Net& n, Node& nd) {
             P.K = K; P.Kpad = (int)align_up(K, I2V_KC); P.Cd = c.cin; P.Cdpad = (int)align_up(c.cin, 128);
             P.tap_uniform = (c.cout % I2V_KC == 0) ? 1 : 0;
             if (P.tap_uniform && st == 1 && stt == 1 && c.kt == 1 && c.kh == 3 && c.kw == 3 && c.pad == 1 && !nd.preact()) P.halo = 9;
+            if (c.kh == 1 && c.kw == 1 && c.pad == 0 && st == 1 && !nd.preact()) P.halo = 1;      // every tap at (0, 0)
             std::vector<float> wp((size_t)P.Kpad * P.Cdpad, 0.f);
             std::vector<I2VKEntry> kt(P.Kpad ? P.Kpad : 1, I2VKEntry{0, 0, 0, 0});
             int t = 0;

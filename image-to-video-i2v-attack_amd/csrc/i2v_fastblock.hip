@@ -21,7 +21,7 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) f2* wptr_t;       // packed weights through the constant address space: scalar loads, SGPR operands
 
-long long g_stat_fastblock = 0;
+long long g_stat_fastblock = 0, g_stat_vfma = 0;
 
 __device__ __forceinline__ unsigned fb_ballot_lo(unsigned long long b) { return (unsigned)b; }
 
@@ -308,5 +308,134 @@ int k_fastblock(const I2VConvParams& a, const I2VConvParams& b, const I2VConvPar
     else { if (!c) FB_GO(4, false, false); else if (d) FB_GO(4, true, true); else FB_GO(4, true, false); }
 #undef FB_GO
     LAUNCH_CHECK("fast_block_kernel");
+    return 0;
+}
+
+// =============================================================================================
+// conv_vfma: ONE narrow convolution launch on packed-fp32 vector FMAs (autotuner bit 11)
+// =============================================================================================
+// The launches of the fast pathway that the fused block leaves alone -- conv1's input gradient (3 x 1 x 1 transposed: K = 24 -> 32 channels,
+// + the shortcut's gradient, gated), a first block's projection gradient and conv1 gradient (K = 32 / 24 -> 8) -- are <= 32 K rows deep and
+// <= 32 channels wide, with taps at (0, 0) only: through conv_tile they run at 5-14 TFLOP/s in 28-45 us (16-row fragments half empty, a
+// 16-row K chunk per barrier, 64 x 64-pixel tiles for 8 channels).  Here a lane owns TWO pixels of one grid frame, requests all their K
+// operands at once (<= 64 registers, every load in flight together), then walks the output channel PAIRS in a rolled loop: K packed FMAs
+// per pixel (the weight pair a scalar load, alive for one iteration), the dense epilogue of conv_vec_rows for the two channels (shift,
+// addends, ReLU, gate bit, store, own gate words by ballot), the next pair's addends requested an iteration ahead.  Every output element is
+// the same k-ordered fmaf chain (rows that add an exact zero skipped): bit-identical to the conv_tile launch, so the autotuner may choose.
+template <int KP>       // K rows held in registers: 16 or 32
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3)))      // (168 VGPRs; 128 frames of 56 x 56 are 6 blocks of 2 waves per CU: all resident)
+conv_vfma_kernel(const I2VConvParams p) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int HW = p.Hg * p.Wg;
+    const int n = blockIdx.y;                                                       // grid frame (scalar)
+    const int clip = (int)fastdiv((unsigned)n, p.dv_t_m, p.dv_t_s), tg = n - clip * p.Tg;
+    const int nf = clip * p.To + tg;                                                // destination frame (dense: To == Tg, ost == 1, ot0 == 0)
+    // lane k decodes K row k: element offset from the clip's first source frame, or FB_SKIP (padding row / tap outside the clip: an exact zero)
+    int myoff = FB_SKIP;
+    if (lane < KP && lane < p.Kpad) {
+        const I2VKEntry e = p.ktab[lane];
+        const int tf = tg * p.st + (e.valid >> 1);
+        if ((e.valid & 1) && tf >= 0 && tf < p.Ts) myoff = (int)((int64_t)tf * p.src_nstride) + e.chan_off;
+    }
+    const float* const fbase = p.src + (int64_t)(clip * p.Ts) * p.src_nstride;
+    const int pix0 = blockIdx.x * 256 + tid;
+    bool act[2]; unsigned upx[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { act[u] = pix0 + 128 * u < HW; upx[u] = act[u] ? (unsigned)(pix0 + 128 * u) : 0u; }
+    float x[2][KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int o = __builtin_amdgcn_readlane(myoff, k);                          // (uniform: a scalar base per K row)
+        const float* const bk = fbase + (o == FB_SKIP ? 0 : o);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) x[u][k] = bk[upx[u]];
+        if (o == FB_SKIP) { x[0][k] = 0.f; x[1][k] = 0.f; }
+    }
+    const int CP = (p.Cd + 1) / 2, wrow = p.Cdpad / 2;
+    float* const ob = p.dst + (int64_t)nf * p.dst_nstride;
+    const float* const a0 = p.add0 ? p.add0 + (int64_t)nf * p.add0_nstride : nullptr;
+    const float* const a1 = p.add1 ? p.add1 + (int64_t)nf * p.add1_nstride : nullptr;
+    const int64_t bitw0 = (int64_t)nf * HW + blockIdx.x * 256 + (tid - lane);       // this wave's first pixel (u = 0) as a bit index: a multiple of 32 (HW % 32 == 0 when gates are present)
+    unsigned glo[2] = {0, 0}, ghi[2] = {0, 0};
+    // operands of the epilogue, one channel pair ahead
+    float ad[2][2] = {{0.f, 0.f}, {0.f, 0.f}}; unsigned gwn[2][2] = {{~0u, ~0u}, {~0u, ~0u}};
+    auto fetch = [&](int c, float (&av)[2][2], unsigned (&gv)[2][2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ch = 2 * c + h;
+            const bool on = ch < p.Cd;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                av[h][u] = (a0 && on) ? (a0 + (int64_t)ch * HW)[upx[u]] : 0.f;
+                gv[h][u] = (p.gate && on) ? p.gate[(int64_t)ch * p.gate_stride + ((p.gate_pix0 + (int64_t)nf * HW + upx[u]) >> 5)] : ~0u;
+            }
+        }
+    };
+    fetch(0, ad, gwn);
+#pragma unroll 1
+    for (int c = 0; c < CP; ++c) {
+        float adc[2][2]; unsigned gwc[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { adc[h][u] = ad[h][u]; gwc[h][u] = gwn[h][u]; }
+        if (c + 1 < CP) fetch(c + 1, ad, gwn);
+        float a1v[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        if (a1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) if (2 * c + h < p.Cd) a1v[h][u] = (a1 + (int64_t)(2 * c + h) * HW)[upx[u]];
+        }
+        const wptr_t w = (wptr_t)p.wp + c;
+        f2 acc[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const f2 wv = w[(int64_t)k * wrow];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[u] = __builtin_elementwise_fma(wv, f2{x[u][k], x[u][k]}, acc[u]);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ch = 2 * c + h;
+            const bool on = ch < p.Cd;
+            const float sh = (p.shift && on) ? ((cfptr_t)p.shift)[ch] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float v = h ? acc[u].y : acc[u].x;
+                if (p.shift) v += sh;
+                if (a0) v += adc[h][u];
+                if (a1) v += a1v[h][u];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.gate && !((gwc[h][u] >> ((unsigned)(p.gate_pix0 + (int64_t)nf * HW + upx[u]) & 31u)) & 1u)) v = 0.f;
+                if (act[u] && on) (ob + (int64_t)ch * HW)[upx[u]] = v;
+                if (p.gate_out) fb_gate_collect(glo[u], ghi[u], ch, act[u] && on && v > 0.f, lane);
+            }
+        }
+    }
+    if (p.gate_out) {
+        const int64_t bit_end = (int64_t)(nf + 1) * HW;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) fb_gate_store(p.gate_out, p.gate_out_stride, p.Cd, glo[u], ghi[u], p.gate_out_pix0 + bitw0 + 128 * u, p.gate_out_pix0 + bit_end, lane);
+    }
+}
+
+// eligibility on the planned parameters (no field the executor fills in later is read): a dense same-size launch with taps at (0, 0) only
+// (the planner's mark: halo == 1), at most 32 K rows and 32 output channels
+bool conv_vfma_ok(const I2VConvParams& p) {
+    if (p.halo != 1 || p.quad || p.pre_scale || p.gate_scale || p.mask || p.blk > 1 || p.blkt > 1 || p.Kpad > 32 || p.Cd > 32 || p.Cd < 2) return false;
+    if (p.sh != 1 || p.sw != 1 || p.osh != 1 || p.osw != 1 || p.oh0 || p.ow0 || p.Hs != p.Hg || p.Hg != p.Ho || p.Ws != p.Wg || p.Wg != p.Wo) return false;
+    if (p.Tg != p.To || p.ost != 1 || p.ot0 != 0 || (p.add0 && p.add0_stride != 1)) return false;
+    if ((p.gate || p.gate_out) && (p.Hg * p.Wg) % 32 != 0) return false;
+    return (int64_t)p.Ts * p.src_nstride < (1ll << 30);
+}
+int launch_conv_vfma(const I2VConvParams& p, hipStream_t s) {
+    const int HW = p.Hg * p.Wg;
+    if (p.N <= 0 || HW <= 0) return 0;
+    if (p.N > 65535) { snprintf(g_be_err, sizeof g_be_err, "conv_vfma launch: more than 65535 frames"); g_be_has_err = true; return 1; }
+    const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)p.N);
+    if (p.Kpad <= 16) hipLaunchKernelGGL((conv_vfma_kernel<16>), grid, dim3(128), 0, s, p);
+    else hipLaunchKernelGGL((conv_vfma_kernel<32>), grid, dim3(128), 0, s, p);
+    LAUNCH_CHECK("conv_vfma_kernel");
     return 0;
 }

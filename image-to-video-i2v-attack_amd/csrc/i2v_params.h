@@ -75,7 +75,8 @@ struct I2VConvParams {
     // halo = 9 (kernel MODE 5): a tap-uniform 3x3 / stride-1 / pad-1 launch whose K rows are ordered (16-channel group, tap, channel).
     // The nine chunks of a group read the SAME 16 channel planes shifted by their tap, so the kernel may stage one halo row per
     // channel and group (tile pixels + a row and a pixel on either side) instead of nine shifted copies of the tile.  Same
-    // products in the same order: results are bit-identical.  halo = 49: the 7x7 / 2 / pad-3 stem over 3 channels in (tap, channel)
+    // products in the same order: results are bit-identical.  halo = 1: every tap at (0, 0) (a k x 1 x 1 kernel: conv_vfma_kernel);
+    // halo = 49: the 7x7 / 2 / pad-3 stem over 3 channels in (tap, channel)
     // order (conv_stem64_halo); halo = 77: a quad-row stem with SEVEN row taps from -3 (7x7, pad 3: the window conv_stem_halo stages).
     int32_t halo;
     // ig_th > 0: a class-packed image-gradient packing (pack_img) in tap-uniform order (16-channel group, frame tap, row tap, column tap,

@@ -740,6 +740,42 @@ def test_fast_pathway_block_kernel_is_bit_identical(eng, monkeypatch, thw, width
     assert torch.equal(outs[0][1], outs[1][1]) and bool(torch.isfinite(outs[0][1]).all()) and float(outs[0][1].abs().max()) > 0
 
 
+@pytest.mark.parametrize("thw,width,clips", [((8, 32, 32), 16, 3), ((16, 64, 64), 64, 2), ((32, 224, 224), 64, 1)])
+def test_narrow_launches_on_vector_fmas_are_bit_identical(eng, monkeypatch, thw, width, clips):
+    """`conv_vfma_kernel` (round 6, autotuner bit 11): a launch of at most 32 K rows and 32 output channels whose taps all sit at (0, 0)
+    -- the fast pathway's 3x1x1 / 1x1x1 convolutions and their input gradients with addends, gates and own gate words -- on packed
+    fp32 vector FMAs, forced onto every eligible launch (configuration 3 | 2048, fused blocks off) of a SlowFast res2 graph against
+    the plain 64x64 tile: hooked features and input gradient bit for bit."""
+    monkeypatch.setenv("I2V_AUTOTUNE", "0")
+    monkeypatch.setenv("I2V_FASTBLOCK", "0")
+    mt = "slowfast_resnet50"
+    g = graphs.slowfast_res2(width, thw, "sf_vf", **(graphs.SLOWFAST_8X8 if thw[0] >= 16 else dict(slow_stride=4, fast_stride=1, beta_inv=4)), blocks=3)
+    sd = weights.synthetic_state_dict(g, 0)
+    hooks = graphs.video_hooks(g, mt)
+    T = g.tensors[g.input].T
+    frames = clips * T
+    x = dev(torch.randn(frames, 3, *g.in_hw, generator=torch.Generator().manual_seed(0)))
+    outs, ran = [], []
+    for cfg in (3, 3 | 2048):
+        monkeypatch.setenv("I2V_FORCE_CFG", str(cfg))
+        net = eng.build_net(g, sd, hooks, frames)
+        before = eng.capi.i2v_backend_stat(b"vfma_launches")
+        net.forward(x)
+        feats = [net.save_hook(i, clips * hi.T).cpu() for i, hi in enumerate(net.hooks)]
+        hg = [torch.randn(f.shape, generator=torch.Generator().manual_seed(7 + i)) for i, f in enumerate(feats)]
+        write_hook_grads(net, feats, hg)
+        gx = torch.full((frames, 3, *g.in_hw), float("nan"), device="cuda:0")
+        net.backward(gx)
+        torch.cuda.synchronize()
+        ran.append(eng.capi.i2v_backend_stat(b"vfma_launches") - before)
+        outs.append((feats, gx.cpu()))
+        net.close()
+    assert ran[0] == 0 and ran[1] >= 10, ran         # conv1 / conv3 / projection of three blocks forward, their input gradients backward
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b), thw
+    assert torch.equal(outs[0][1], outs[1][1]) and bool(torch.isfinite(outs[0][1]).all()) and float(outs[0][1].abs().max()) > 0
+
+
 def test_tail_split_is_bit_identical(eng, monkeypatch):
     """`conv_igemm_tail`: the remainder tiles of a launch as 16x64 quarter tiles in the same grid.  Forced onto every eligible launch
     (configuration 3 | 32) of a net whose layers leave remainders of 64 / 16 pixel tiles over the 256 CUs (576 and 144+... tiles), against
