@@ -21,13 +21,18 @@ share of the clips when r is small.  So the head is
 
 with (W_r, b) trained on the 400 clean clips by a multiclass hinge loss until EVERY clip holds its label with margin >= 1 over every
 other class (least-squares start, full-batch Adam, float64; converges in 10^2..10^3 steps because 400 points in general position in
-r >= 8 dimensions are all vertices of their hull).  `rank` is the one knob; `DEFAULT_RANK` was chosen on the round-6 probe
-(`tools/fooling_features_probe.py`, 400 HIP-attacked clips) so that the fooling rate lands between 5 % and 95 %: I3D-NL 16 -> 42 %,
-SlowFast 8 -> 12 % (32 / 16 give 12 % / 0 %).  Nothing about the ORACLE's set enters the choice.
+r >= 8 dimensions are all vertices of their hull).  `rank` is the one knob.  The rule for it, stated on the HIP set alone (nothing about
+the ORACLE's set enters): of RANK_SWEEP, the LARGEST rank -- the least sensitive head, which also amplifies the fp32-level noise between
+two correct runs of the attack least -- under which the attack still fools at least 10 % of the list.  On round 6's data (400 clips):
+I3D-NL 32 (11.75 %; 48 gives 3.5 %), SlowFast 8 (11.75 %; 12 gives 0.25 %) = DEFAULT_RANK; `rank_by_rule` re-derives it from a run's
+own features and `tools/fooling_parity.py` records whether it agrees.  (The first n = 400 run of the round used rank 16 for the I3D-NL --
+the probe's mid-range pick -- and is kept in the sweep: fooling rates 38.25 / 42.00 %, 31 + 46 discordant clips, McNemar p = 0.11.)
 """
 import numpy as np
 
-DEFAULT_RANK = {"i3d_resnet50": 16, "slowfast_resnet50": 8}
+DEFAULT_RANK = {"i3d_resnet50": 32, "slowfast_resnet50": 8}
+RANK_SWEEP = (8, 12, 16, 24, 32, 48)
+MIN_FOOLING_FOR_RANK = 10.0
 MARGIN = 1.0
 
 
@@ -85,3 +90,43 @@ def mcnemar_exact(b, c):
     k = min(b, c)
     p = sum(comb(nd, i) for i in range(k + 1)) / 2.0 ** nd * 2.0
     return min(1.0, p)
+
+
+def own_margin(logits, labels):
+    """Own-label logit minus the best other per row: > 0 <=> classified as its label."""
+    lg = np.asarray(logits, np.float64)
+    idx = np.arange(len(labels))
+    own = lg[idx, labels]
+    other = lg.copy()
+    other[idx, labels] = -np.inf
+    return own - other.max(1)
+
+
+def rank_sweep(clean_feats, labels, sets, ranks=RANK_SWEEP, num_classes=400):
+    """The head at every rank of the sweep, applied to pooled features of each set in `sets` ({name: (n, C)}; rows = the first n rows of
+    the list): fooling rate per set and, for every pair of sets, the discordant split and the exact McNemar p.  float64 on the host from
+    the features the device pooled (the device's `fc` accumulates in double as well)."""
+    lab = np.asarray(labels, np.int64)
+    out = []
+    for r in ranks:
+        W, b, info = fit_head(clean_feats, lab, r, num_classes=num_classes)
+        fooled = {}
+        for name, F in sets.items():
+            n = len(F)
+            fooled[name] = own_margin(np.asarray(F, np.float64) @ W.astype(np.float64).T + b.astype(np.float64), lab[:n]) <= 0
+        row = {"rank": int(r), "clean_top1": info["clean_top1"], "fooling_rate": {k: round(100.0 * float(v.mean()), 4) for k, v in fooled.items()}, "pairs": {}}
+        names = list(fooled)
+        for i in range(len(names)):
+            for j in range(i + 1, len(names)):
+                a, c = fooled[names[i]], fooled[names[j]]
+                n = min(len(a), len(c))
+                oa, oc = int((a[:n] & ~c[:n]).sum()), int((c[:n] & ~a[:n]).sum())
+                row["pairs"][f"{names[i]}|{names[j]}"] = {"n": n, "only_first_fooled": oa, "only_second_fooled": oc, "mcnemar_exact_p": round(mcnemar_exact(oa, oc), 4)}
+        out.append(row)
+    return out
+
+
+def rank_by_rule(sweep, on="hip"):
+    """The largest rank of a `rank_sweep` whose fooling rate on set `on` is at least MIN_FOOLING_FOR_RANK (None if there is none)."""
+    ok = [row["rank"] for row in sweep if row["fooling_rate"].get(on, 0.0) >= MIN_FOOLING_FOR_RANK]
+    return max(ok) if ok else None

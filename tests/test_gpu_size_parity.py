@@ -176,9 +176,11 @@ def test_csv_keyed_clips_fooling_rate_parity(eng, oracle_rows, clip0, tmp_path, 
         print(name, {"clean_top1": c[name], "fooling_rate_oracle": 100 - a[name], "fooling_rate_hip": 100 - b[name], "only_oracle_fooled": only_o,
                      "only_hip_fooled": only_h, "mcnemar_p": p, "median_gap": float(gap.median()), "max_gap": float(gap.max()), "yardstick_gap_row0": yard,
                      "median_abs_margin": float(mo.abs().median())})
-        # the calibrated evaluator: every clean clip right; both attacked sets strictly inside (5, 95) -- it sees the attack and is not saturated
+        # the calibrated evaluator: every clean clip right; both attacked sets neither untouched nor saturated -- it sees the attack
         assert c[name] == 100.0, (name, c)
-        assert 5.0 < 100 - a[name] < 95.0 and 5.0 < 100 - b[name] < 95.0, (name, a, b)
+        # (the (5, 95) % window is the n = 400 statement, tools/fooling_parity.py; at 32 rows one clip is 3.1 points: here the evaluator must fool
+        #  and spare at least one clip of each set)
+        assert 0.0 < 100 - a[name] < 100.0 and 0.0 < 100 - b[name] < 100.0, (name, a, b)
         # the evaluator's numbers are this pass's numbers
         assert abs((100 - a[name]) - 100.0 * int(fo.sum()) / ROWS) < 1e-6 and abs((100 - b[name]) - 100.0 * int(fh.sum()) / ROWS) < 1e-6
         # parity of the METRIC, paired: the two rates differ only through clips on which exactly one set is fooled; under exchangeable sets

@@ -181,9 +181,8 @@ def run(args, work, ora_dir, procs, STEPS, LR, t_start):
                 rs = cl[b0:b0 + 8]
                 ls = [labels[r] for r in rs]
                 lo, lh, lc = model(load("oracle", ls)).cpu(), model(load("hip", ls)).cpu(), model(load("clean", ls)).cpu()
-                if args.dump_features:
-                    dump[m]["oracle"].append(model.pooled_features(load("oracle", ls)).cpu().numpy())
-                    dump[m]["hip"].append(model.pooled_features(load("hip", ls)).cpu().numpy())
+                dump[m]["oracle"].append(model.pooled_features(load("oracle", ls)).cpu().numpy())        # (for the rank sweep: the head at other ranks, on the host)
+                dump[m]["hip"].append(model.pooled_features(load("hip", ls)).cpu().numpy())
                 mo, mh, mc = own_margin(lo, ls), own_margin(lh, ls), own_margin(lc, ls)
                 for k, r in enumerate(rs):
                     rec[m][r] = {"margin_clean": float(mc[k]), "margin_oracle": float(mo[k]), "margin_hip": float(mh[k]),
@@ -195,8 +194,7 @@ def run(args, work, ora_dir, procs, STEPS, LR, t_start):
                         rec[m][r]["pred_oracle64"] = int(l64[0].argmax())
                         rec[m][r]["logit_gap_oracle_vs_f64"] = float((lo[k] - l64[0]).abs().max())
                         rec[m][r]["logit_gap_hip_vs_f64"] = float((lh[k] - l64[0]).abs().max())
-                        if args.dump_features:
-                            dump[m]["oracle64"].append(model.pooled_features(o64["adv"]).cpu().numpy())
+                        dump[m]["oracle64"].append(model.pooled_features(o64["adv"]).cpu().numpy())
         n_done += len(cl)
         for d in dirs.values():
             shutil.rmtree(d, ignore_errors=True)
@@ -220,7 +218,7 @@ def run(args, work, ora_dir, procs, STEPS, LR, t_start):
         nd = len(only_o) + len(only_h)
         # cross-check of this pass against the evaluator's csv (which keeps the reference's re-ordering by argsort(labels), reference.py:116-119:
         # rows are not addressable by label there, but the NUMBER of fooled clips per set is the same either way)
-        fooled_csv = {d: round(n - top1[d][m] * n / 100.0) for d in sets}
+        fooled_csv = {d: int(round(n - top1[d][m] / 100.0)) for d in sets}          # (top1[d][m] accumulates accuracy-percent x clips per chunk)
         res["paired"][m] = {
             "fooled_by_both": sum(fo[r] and fh[r] for r in range(n)), "fooled_by_neither": sum(not fo[r] and not fh[r] for r in range(n)),
             "only_oracle_set_fooled": len(only_o), "only_hip_set_fooled": len(only_h), "discordant": nd,
@@ -246,6 +244,16 @@ def run(args, work, ora_dir, procs, STEPS, LR, t_start):
             "logit_gap_median": {"fp32_oracle_vs_f64": round(float(np.median([R[r]["logit_gap_oracle_vs_f64"] for r in yr])), 4) if yr else None,
                                  "hip_vs_f64": round(float(np.median([R[r]["logit_gap_hip_vs_f64"] for r in yr])), 4) if yr else None,
                                  "hip_vs_fp32_oracle": round(float(np.median([R[r]["logit_gap"] for r in yr])), 4) if yr else None}}
+    # the same comparison at every rank of the sweep (host, float64, from the pooled features of this run): no rank is privileged, the
+    # differences between the two sets change sign from rank to rank -- and the rule that picks the reported rank, re-derived from this run
+    res["rank_sweep"], res["rank_rule"] = {}, {}
+    for m in models:
+        feats = {"oracle": np.concatenate(dump[m]["oracle"]), "hip": np.concatenate(dump[m]["hip"])}
+        if dump[m]["oracle64"]:
+            feats["oracle64"] = np.concatenate(dump[m]["oracle64"])
+        res["rank_sweep"][m] = eval_head.rank_sweep(clean_feats[m], [int(r["gt_label"]) for r in all_rows], feats)
+        res["rank_rule"][m] = {"rule": f"largest rank of {list(eval_head.RANK_SWEEP)} with a fooling rate >= {eval_head.MIN_FOOLING_FOR_RANK} % on the HIP set",
+                               "picks": eval_head.rank_by_rule(res["rank_sweep"][m]), "used": rank[m]}
     worst = max(per_clip, key=lambda s: s["max_rel_cost_err"])
     res["per_clip_statistics"] = {
         "worst_max_rel_cost_err": worst["max_rel_cost_err"], "worst_row": worst["row"],
