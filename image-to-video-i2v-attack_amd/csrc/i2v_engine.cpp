@@ -1536,6 +1536,9 @@ static int autotune(Net& n) {
                 for (int ci = 0; ci < nc && !rc; ++ci) {
                     float ms = 0.f;
                     if (time_cfg(cand[ci] + 1, &ms)) { rc = 1; break; }
+                    if ((cand[ci] & 2048) && getenv("I2V_FUSE_DEBUG"))
+                        fprintf(stderr, "[i2v vfma] %s launch Cd %d K %d (%dx%d) at %d frames: conv_vfma %.1f us, best tile so far %.1f us\n", L == &n.fwd ? "fwd" : "bwd",
+                                l.conv.Cd, l.conv.K, l.conv.Hg, l.conv.Wg, lf, 1e3f * ms, 1e3f * best);
                     if (ms < best) { best = ms; best_c = cand[ci]; }
                 }
                 // second stage: the winner with streaming (non-temporal) epilogue stores, bit 7 -- one more timing per launch

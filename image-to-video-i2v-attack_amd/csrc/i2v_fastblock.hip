@@ -240,12 +240,16 @@ fast_block_kernel(const I2VFastBlockParams p) {
         float* const o = p.dst + (int64_t)n * p.dst_nstride;
         const float* const rs = PROJ ? nullptr : p.add0 + (int64_t)n * p.add0_nstride;
         unsigned glo = 0, ghi = 0;
-        f2 rnext = f2{0.f, 0.f};
-        if (!PROJ) rnext = f2{rs[upix], (rs + HW)[upix]};
+        f2 rq[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};      // the residual of the next four pairs, in flight (requested four iterations ahead)
+        if (!PROJ) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rq[j] = f2{(rs + (int64_t)(2 * j) * HW)[upix], (rs + (int64_t)(2 * j + 1) * HW)[upix]};
+        }
 #pragma unroll 1
         for (int c = 0; c < C3P; ++c) {
-            f2 r = rnext;
-            if (!PROJ && c + 1 < C3P) rnext = f2{(rs + (int64_t)(2 * c + 2) * HW)[upix], (rs + (int64_t)(2 * c + 3) * HW)[upix]};      // the next pair's residual, a whole iteration ahead
+            f2 r = rq[0];
+            rq[0] = rq[1]; rq[1] = rq[2]; rq[2] = rq[3];
+            if (!PROJ && c + 4 < C3P) rq[3] = f2{(rs + (int64_t)(2 * c + 8) * HW)[upix], (rs + (int64_t)(2 * c + 9) * HW)[upix]};
             if (PROJ) {              // projection shortcut: pointwise over x[t] (K row k is channel k), + its shift: the value the separate launch stores
                 r = f2{0.f, 0.f};
                 const wptr_t wd = (wptr_t)p.d.wp + c;
@@ -322,8 +326,13 @@ int k_fastblock(const I2VConvParams& a, const I2VConvParams& b, const I2VConvPar
 // per pixel (the weight pair a scalar load, alive for one iteration), the dense epilogue of conv_vec_rows for the two channels (shift,
 // addends, ReLU, gate bit, store, own gate words by ballot), the next pair's addends requested an iteration ahead.  Every output element is
 // the same k-ordered fmaf chain (rows that add an exact zero skipped): bit-identical to the conv_tile launch, so the autotuner may choose.
-template <int KP>       // K rows held in registers: 16 or 32
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3)))      // (168 VGPRs; 128 frames of 56 x 56 are 6 blocks of 2 waves per CU: all resident)
+// One pixel per lane; EVERYTHING the lane will read is requested up front -- its K operands, its addends, its gate words (<= 96 loads in
+// flight per lane) -- so that a block is ONE memory round trip, the arithmetic, the stores.  (The first version fetched the addends of
+// channel pair c + 1 during pair c: sixteen dependent round trips per block, 108 us where conv_tile takes 38.)  The channel loop is
+// unrolled (register-resident addends need compile-time indices) with a compiler memory fence per channel pair: without it the
+// scheduler requests every pair's weight rows at once and spills SGPR tuples to VGPR lanes.
+template <int KP, int CDP>       // K rows held in registers (16 / 32), output channel pairs (4 / 8 / 16)
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4)))
 conv_vfma_kernel(const I2VConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int HW = p.Hg * p.Wg;
@@ -338,86 +347,61 @@ conv_vfma_kernel(const I2VConvParams p) {
         if ((e.valid & 1) && tf >= 0 && tf < p.Ts) myoff = (int)((int64_t)tf * p.src_nstride) + e.chan_off;
     }
     const float* const fbase = p.src + (int64_t)(clip * p.Ts) * p.src_nstride;
-    const int pix0 = blockIdx.x * 256 + tid;
-    bool act[2]; unsigned upx[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) { act[u] = pix0 + 128 * u < HW; upx[u] = act[u] ? (unsigned)(pix0 + 128 * u) : 0u; }
-    float x[2][KP];
+    const int pix = blockIdx.x * 128 + tid;
+    const bool act = pix < HW;
+    const unsigned upx = act ? (unsigned)pix : 0u;
+    const float* const a0 = p.add0 ? p.add0 + (int64_t)nf * p.add0_nstride : nullptr;
+    const float* const a1 = p.add1 ? p.add1 + (int64_t)nf * p.add1_nstride : nullptr;
+    const int64_t bitp = p.gate_pix0 + (int64_t)nf * HW + upx;
+    // ---- every load of the block, at once ----
+    float x[KP];
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
         const int o = __builtin_amdgcn_readlane(myoff, k);                          // (uniform: a scalar base per K row)
-        const float* const bk = fbase + (o == FB_SKIP ? 0 : o);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) x[u][k] = bk[upx[u]];
-        if (o == FB_SKIP) { x[0][k] = 0.f; x[1][k] = 0.f; }
+        x[k] = (fbase + (o == FB_SKIP ? 0 : o))[upx];
+        if (o == FB_SKIP) x[k] = 0.f;
     }
-    const int CP = (p.Cd + 1) / 2, wrow = p.Cdpad / 2;
+    float ad[2 * CDP];
+#pragma unroll
+    for (int ch = 0; ch < 2 * CDP; ++ch) {
+        ad[ch] = (a0 && ch < p.Cd) ? (a0 + (int64_t)ch * HW)[upx] : 0.f;          // (add1 -- a second shortcut, rare -- is read where it is added: the order v + add0 + add1 stays)
+    }
+    unsigned gbits = ~0u;                                                           // bit ch: the gate of channel ch at this pixel
+    if (p.gate) {
+        unsigned gw[2 * CDP];
+#pragma unroll
+        for (int ch = 0; ch < 2 * CDP; ++ch) gw[ch] = ch < p.Cd ? p.gate[(int64_t)ch * p.gate_stride + (bitp >> 5)] : ~0u;
+        gbits = 0u;
+#pragma unroll
+        for (int ch = 0; ch < 2 * CDP; ++ch) gbits |= ((gw[ch] >> ((unsigned)bitp & 31u)) & 1u) << ch;
+    }
+    // ---- the arithmetic: one output-channel pair at a time, K packed FMAs, the dense epilogue of conv_vec_rows ----
+    const int wrow = p.Cdpad / 2;
     float* const ob = p.dst + (int64_t)nf * p.dst_nstride;
-    const float* const a0 = p.add0 ? p.add0 + (int64_t)nf * p.add0_nstride : nullptr;
-    const float* const a1 = p.add1 ? p.add1 + (int64_t)nf * p.add1_nstride : nullptr;
-    const int64_t bitw0 = (int64_t)nf * HW + blockIdx.x * 256 + (tid - lane);       // this wave's first pixel (u = 0) as a bit index: a multiple of 32 (HW % 32 == 0 when gates are present)
-    unsigned glo[2] = {0, 0}, ghi[2] = {0, 0};
-    // operands of the epilogue, one channel pair ahead
-    float ad[2][2] = {{0.f, 0.f}, {0.f, 0.f}}; unsigned gwn[2][2] = {{~0u, ~0u}, {~0u, ~0u}};
-    auto fetch = [&](int c, float (&av)[2][2], unsigned (&gv)[2][2]) {
+    const int64_t bitw0 = p.gate_out_pix0 + (int64_t)nf * HW + blockIdx.x * 128 + (tid - lane);      // this wave's first pixel as a bit index: a multiple of 32
+    unsigned glo = 0, ghi = 0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ch = 2 * c + h;
-            const bool on = ch < p.Cd;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                av[h][u] = (a0 && on) ? (a0 + (int64_t)ch * HW)[upx[u]] : 0.f;
-                gv[h][u] = (p.gate && on) ? p.gate[(int64_t)ch * p.gate_stride + ((p.gate_pix0 + (int64_t)nf * HW + upx[u]) >> 5)] : ~0u;
-            }
-        }
-    };
-    fetch(0, ad, gwn);
-#pragma unroll 1
-    for (int c = 0; c < CP; ++c) {
-        float adc[2][2]; unsigned gwc[2][2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) { adc[h][u] = ad[h][u]; gwc[h][u] = gwn[h][u]; }
-        if (c + 1 < CP) fetch(c + 1, ad, gwn);
-        float a1v[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-        if (a1) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) if (2 * c + h < p.Cd) a1v[h][u] = (a1 + (int64_t)(2 * c + h) * HW)[upx[u]];
-        }
+    for (int c = 0; c < CDP; ++c) {
+        asm volatile("" ::: "memory");                                              // (one pair's weight rows in SGPRs at a time)
         const wptr_t w = (wptr_t)p.wp + c;
-        f2 acc[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
+        f2 acc = f2{0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const f2 wv = w[(int64_t)k * wrow];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) acc[u] = __builtin_elementwise_fma(wv, f2{x[u][k], x[u][k]}, acc[u]);
-        }
+        for (int k = 0; k < KP; ++k) acc = __builtin_elementwise_fma(w[(int64_t)k * wrow], f2{x[k], x[k]}, acc);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ch = 2 * c + h;
             const bool on = ch < p.Cd;
-            const float sh = (p.shift && on) ? ((cfptr_t)p.shift)[ch] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float v = h ? acc[u].y : acc[u].x;
-                if (p.shift) v += sh;
-                if (a0) v += adc[h][u];
-                if (a1) v += a1v[h][u];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (p.gate && !((gwc[h][u] >> ((unsigned)(p.gate_pix0 + (int64_t)nf * HW + upx[u]) & 31u)) & 1u)) v = 0.f;
-                if (act[u] && on) (ob + (int64_t)ch * HW)[upx[u]] = v;
-                if (p.gate_out) fb_gate_collect(glo[u], ghi[u], ch, act[u] && on && v > 0.f, lane);
-            }
+            float v = h ? acc.y : acc.x;
+            if (p.shift) v += on ? ((cfptr_t)p.shift)[ch] : 0.f;
+            if (a0) v += ad[ch];
+            if (a1 && on) v += (a1 + (int64_t)ch * HW)[upx];
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (p.gate && !((gbits >> ch) & 1u)) v = 0.f;
+            if (act && on) (ob + (int64_t)ch * HW)[upx] = v;
+            if (p.gate_out) fb_gate_collect(glo, ghi, ch, act && on && v > 0.f, lane);
         }
     }
-    if (p.gate_out) {
-        const int64_t bit_end = (int64_t)(nf + 1) * HW;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) fb_gate_store(p.gate_out, p.gate_out_stride, p.Cd, glo[u], ghi[u], p.gate_out_pix0 + bitw0 + 128 * u, p.gate_out_pix0 + bit_end, lane);
-    }
+    if (p.gate_out) fb_gate_store(p.gate_out, p.gate_out_stride, p.Cd, glo, ghi, bitw0, p.gate_out_pix0 + (int64_t)(nf + 1) * HW, lane);
 }
 
 // eligibility on the planned parameters (no field the executor fills in later is read): a dense same-size launch with taps at (0, 0) only
@@ -433,9 +417,12 @@ int launch_conv_vfma(const I2VConvParams& p, hipStream_t s) {
     const int HW = p.Hg * p.Wg;
     if (p.N <= 0 || HW <= 0) return 0;
     if (p.N > 65535) { snprintf(g_be_err, sizeof g_be_err, "conv_vfma launch: more than 65535 frames"); g_be_has_err = true; return 1; }
-    const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)p.N);
-    if (p.Kpad <= 16) hipLaunchKernelGGL((conv_vfma_kernel<16>), grid, dim3(128), 0, s, p);
-    else hipLaunchKernelGGL((conv_vfma_kernel<32>), grid, dim3(128), 0, s, p);
+    const dim3 grid((unsigned)((HW + 127) / 128), (unsigned)p.N);
+#define VF_GO(KPV, CDV) hipLaunchKernelGGL((conv_vfma_kernel<KPV, CDV>), grid, dim3(128), 0, s, p)
+    const int cdp = (p.Cd + 1) / 2;
+    if (p.Kpad <= 16) { if (cdp <= 4) VF_GO(16, 4); else if (cdp <= 8) VF_GO(16, 8); else VF_GO(16, 16); }
+    else { if (cdp <= 4) VF_GO(32, 4); else if (cdp <= 8) VF_GO(32, 8); else VF_GO(32, 16); }
+#undef VF_GO
     LAUNCH_CHECK("conv_vfma_kernel");
     return 0;
 }
