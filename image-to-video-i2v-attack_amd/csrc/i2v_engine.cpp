@@ -117,6 +117,11 @@ struct Launch {
     int node = -1;                 // conv launches: the graph node they belong to
     int fb_ok = 0;
     int fb_b[4] = {0, 0, 0, 0};
+    // Launch overlap (mark_overlap, round 6): a convolution launch that does not depend on its predecessors back to launch ov_after
+    // (-1: on nothing in its list) may run on the net's SIDE stream, issued right after launch ov_after, while the main stream goes on;
+    // ov_join is the first later launch that touches what it writes or reads (list size: none in this list) and waits for it.
+    // ov_after == -2: runs in place.  No launch changes, so no result changes.
+    int ov_after = -2, ov_join = -1;
 };
 static int cfg_bucket(int clips, int max_clips) {
     int b = 0;
@@ -137,6 +142,10 @@ struct Net {
     std::vector<float*> hook_tmp;  // per hook: separate gradient buffer when the hooked tensor is also consumed
     size_t in_stage_off = 0; bool stage_input = false;   // quad-row stems read up to 64 bytes around a view: the caller's frames are
                                                          // copied into the arena (slack on both sides) before the forward pass
+    // launch overlap (mark_overlap / run_list): the side stream, its event pool, and per list (0 forward, 1 backward) the hoisted
+    // launches to issue right after main launch p (index p + 1; index 0: at the start of the list)
+    i2v_stream_t side = nullptr; std::vector<void*> ov_ev; size_t ov_used = 0;
+    std::vector<std::vector<int>> ov_at[2]; int ov_max_frames = 0;
 };
 
 }  // namespace
@@ -515,7 +524,11 @@ static View view_of(Net& n, int t, bool grad) {
 extern "C" const char* i2v_last_error(void) { return g_err.c_str(); }
 extern "C" int i2v_abi_version(void) { return 1; }
 extern "C" const char* i2v_backend(void) { return be_name(); }
-extern "C" long long i2v_backend_stat(const char* name) { return name ? be_stat(name) : -1; }
+static long long g_overlap_launches = 0;        // launches issued on a side stream (mark_overlap): a relaxed counter, diagnostics only
+extern "C" long long i2v_backend_stat(const char* name) {
+    if (name && !strcmp(name, "overlap_launches")) return __atomic_load_n(&g_overlap_launches, __ATOMIC_RELAXED);
+    return name ? be_stat(name) : -1;
+}
 
 extern "C" int i2v_create(int device, i2v_handle* out) {
     if (!out) return fail("i2v_create: null out");
@@ -530,6 +543,8 @@ static void free_net(Net* n) {
     if (!n) return;
     for (void* p : n->dev_allocs) be_free(p);
     if (n->arena) be_free(n->arena);
+    for (void* e : n->ov_ev) be_event_destroy(e);
+    if (n->side) be_stream_destroy(n->side);
     delete n;
 }
 
@@ -1143,6 +1158,7 @@ struct Planner {
 
 static int autotune(Net& n);
 static void mark_fusable(Net& n);
+static void mark_overlap(Net& n);
 
 extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int n_hooks, int max_frames) {
     Net* np = get_net(h, net); if (!np) return 1;
@@ -1221,6 +1237,7 @@ extern "C" int i2v_net_plan(i2v_handle h, int net, const int* hook_tensors, int 
     n.hook_tmp = real.hook_tmp;
     mark_fusable(n);
     if (autotune(n)) return 1;
+    mark_overlap(n);
     // planning works on the null stream (uploads, arena clears, tuning probes); the caller may execute the net on any
     // stream, including non-blocking ones that do not order against it
     CHECK_BE(be_stream_sync(nullptr));
@@ -1484,6 +1501,106 @@ static void mark_fusable(Net& n) {
             for (int b = 0; b < 4; ++b) a.fuse_b[b] = (a.fuse_ok && f) ? ((f == 2 && (a.fuse_ok & 2)) ? 2 : 1) : 0;
 }
 
+// Launch overlap (round 6): a single 32-frame clip leaves the 14 x 14 layers with 1.5 tiles per CU, and a launch
+// list is a chain -- except where a block has a projection shortcut: forward, the shortcut convolution depends on the block's input
+// only (conv3 adds its result); backward, its input gradient depends on the gradient of the block's output only (conv1's input
+// gradient adds it).  Such a launch is HOISTED: issued on the net's side stream as soon as the launch it depends on has been issued
+// on the main stream, joined (event wait on the main stream) in front of the first launch that touches its operands.  Which launches
+// qualify is decided from the address ranges every launch of a list reads and writes -- data operands, 1-bit gate rows, arg-max
+// bytes, the caller's gradient tensor as one opaque range; attention launches are barriers -- conservatively (ranges at the planned
+// frame count; any overlap counts).  No launch changes, so every result stays bit-identical; the host simulation, which executes
+// launches synchronously in ISSUE order, really runs a hoisted launch early and so tests the analysis (tests/test_planner_hostsim.py).
+// Active for calls of at most ov_max_frames frames ($I2V_OVERLAP_MAX_FRAMES, default 32: one clip of the headline shape -- at 128
+// frames the launches fill the chip on their own and concurrency only perturbs them) and never while launches are being timed.
+static void mark_overlap(Net& n) {
+    for (int k = 0; k < 2; ++k) n.ov_at[k].clear();
+    for (std::vector<Launch>* L : {&n.fwd, &n.bwd}) for (Launch& l : *L) { l.ov_after = -2; l.ov_join = -1; }
+    const char* e = getenv("I2V_OVERLAP_MAX_FRAMES");
+    n.ov_max_frames = e ? atoi(e) : 32;
+    if (n.ov_max_frames <= 0) return;
+    const int64_t clips = n.maxN / n.Tin();
+    typedef std::pair<const char*, const char*> Range;
+    struct RW { std::vector<Range> r, w; bool barrier = false; };
+    static const char gx_tag[16] = {0};          // stands for the caller's gradient tensor (every launch that touches it conflicts with every other)
+    const Range GX(gx_tag, gx_tag + 16);
+    auto rng = [](const void* q, int64_t fr, int64_t stride_bytes, int64_t plane_bytes) {
+        const char* f = (const char*)q;
+        return f ? Range(f, f + (fr > 0 ? (fr - 1) * stride_bytes : 0) + std::max<int64_t>(plane_bytes, 1)) : Range(nullptr, nullptr);
+    };
+    auto rw_of = [&](const Launch& c) {
+        RW o;
+        auto rd = [&](const Range& x) { if (x.first) o.r.push_back(x); };
+        auto wr = [&](const Range& x) { if (x.first) o.w.push_back(x); };
+        if (c.kind == L_CONV || c.kind == L_IMGGRAD) {
+            const I2VConvParams& q = c.conv;
+            const int64_t fs = clips * std::max(1, q.Ts), fo = clips * std::max(1, q.To);
+            const int64_t dplane = 4ll * (q.blk > 1 ? q.Cd / (q.blk * q.blk) : q.Cd) * q.Ho * q.Wo;
+            if (!c.src_is_input) rd(rng(q.src, fs, 4 * q.src_nstride, 4ll * q.Cs * q.Hs * q.Ws));
+            rd(rng(q.add0, fo, 4 * q.add0_nstride, dplane)); rd(rng(q.add1, fo, 4 * q.add1_nstride, dplane)); rd(rng(q.mask, fo, 4 * q.mask_nstride, dplane));
+            rd(rng(q.gate, 1, 0, 4ll * q.Cd * q.gate_stride)); wr(rng(q.gate_out, 1, 0, 4ll * q.Cd * q.gate_out_stride));
+            if (c.kind == L_IMGGRAD) { wr(GX); rd(GX); } else wr(rng(q.dst, fo, 4 * q.dst_nstride, dplane));
+        } else if (c.kind == L_ADDMASK) {
+            const int64_t fr = clips * std::max(1, c.T), pl = 4ll * c.am.C * c.am.HW;
+            wr(rng(c.am.out, fr, 4 * c.am.out_nstride, pl));
+            for (int i = 0; i < 3; ++i) rd(rng(c.am.a[i], fr, 4 * c.am.a_nstride[i], pl));
+            rd(rng(c.am.mask, fr, 4 * c.am.mask_nstride, pl)); rd(rng(c.am.gate, 1, 0, 4ll * c.am.C * c.am.gate_stride));
+        } else if (c.kind == L_MEMSET) {
+            if (c.ms_gx) wr(GX); else wr(rng(c.ms_ptr, 1, 0, 4ll * (int64_t)c.ms_floats_per_frame * clips * std::max(1, c.T)));
+        } else if (c.kind == L_AGEMM || c.kind == L_SOFTMAX || c.kind == L_CONVB_UNUSED) {
+            o.barrier = true;
+        } else {
+            const I2VPoolParams& q = c.pool;
+            const int64_t fr = clips * std::max(std::max(1, c.T), std::max(q.Ts, q.To)), pin = 4ll * q.C * q.Hs * q.Ws, pout = 4ll * q.C * q.Ho * q.Wo;
+            const Range idx = rng(q.idx, 1, 0, fr * (int64_t)q.C * q.Ho * q.Wo);
+            const bool fwd = c.kind == L_POOLF || c.kind == L_POOL3F || c.kind == L_AVGF;
+            if (fwd) { rd(rng(q.x, fr, 4 * q.x_nstride, pin)); wr(rng(q.y, fr, 4 * q.y_nstride, pout)); wr(idx); }
+            else { rd(rng(q.x, fr, 4 * q.x_nstride, pin)); rd(rng(q.y, fr, 4 * q.y_nstride, pout)); rd(rng(q.yact, fr, 4 * q.yact_nstride, pout)); rd(idx);
+                   wr(rng(q.gx, fr * std::max(1, q.stride_t), 4 * q.gx_nstride, pin)); }
+        }
+        return o;
+    };
+    auto meet = [](const std::vector<Range>& A, const std::vector<Range>& B) {
+        for (const Range& a : A) for (const Range& b : B) if (a.first < b.second && b.first < a.second) return true;
+        return false;
+    };
+    auto conflict = [&](const RW& a, const RW& b) { return a.barrier || b.barrier || meet(a.r, b.w) || meet(a.w, b.w) || meet(a.w, b.r); };
+    int k = 0;
+    for (std::vector<Launch>* L : {&n.fwd, &n.bwd}) {
+        const int M = (int)L->size();
+        std::vector<RW> rw; rw.reserve(M);
+        for (const Launch& l : *L) rw.push_back(rw_of(l));
+        std::vector<char> member(M, 0);          // part of a group that may run as ONE kernel (fused pair, fused fast-pathway block): stays in place
+        for (int i = 0; i < M; ++i) {
+            const Launch& l = (*L)[i];
+            for (int j = 0; j < l.fb_ok && i + j < M; ++j) member[i + j] = 1;
+            if (l.fuse_ok) { member[i] = 1; if (i + 1 < M) member[i + 1] = 1; }
+        }
+        n.ov_at[k].assign(M + 1, {});
+        int hoisted = 0;
+        for (int i = 1; i < M; ++i) {
+            Launch& l = (*L)[i];
+            if (l.kind != L_CONV || member[i] || l.src_is_input) continue;
+            int dep = -1;
+            for (int j = i - 1; j >= 0; --j) if (conflict(rw[i], rw[j])) { dep = j; break; }
+            if (dep >= i - 1) continue;                                   // depends on its predecessor: nothing to overlap with
+            if (dep >= 0 && (*L)[dep].ov_after != -2) continue;            // depends on a hoisted launch: stays on the main stream (which joins in front of it)
+            int join = M;
+            for (int j = i + 1; j < M; ++j) if (conflict(rw[j], rw[i])) { join = j; break; }
+            l.ov_after = dep; l.ov_join = join;
+            n.ov_at[k][dep + 1].push_back(i);
+            ++hoisted;
+            if (getenv("I2V_FUSE_DEBUG"))
+                fprintf(stderr, "[i2v overlap] %s launch %d (Cd %d, K %d, %dx%d): side stream after launch %d, joined before launch %d of %d\n", k ? "bwd" : "fwd", i,
+                        l.conv.Cd, l.conv.K, l.conv.Hg, l.conv.Wg, dep, join, M);
+        }
+        if (!hoisted) n.ov_at[k].clear();
+        ++k;
+    }
+    if (n.ov_at[0].empty() && n.ov_at[1].empty()) return;
+    n.side = be_stream_create();
+    if (!n.side) { n.ov_at[0].clear(); n.ov_at[1].clear(); }
+}
+
 // Plan-time autotuning ("measure, don't guess"): every convolution launch of both passes is timed with each
 // valid tile configuration on the planned shapes (max_frames) and the fastest is pinned.  Tile choice never
 // changes results: each output element is the same k-ordered fmaf chain whatever the tile.
@@ -1664,14 +1781,53 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
     const int clips = in_frames / n.Tin();
     TimedLaunch* prev_timed = nullptr;                   // the first launch of the list records its own start event
     TimedLaunch* seg = nullptr;                          // segment mode: the open segment
+    // launch overlap (mark_overlap): hoisted launches go to the side stream right after the launch they depend on was issued here
+    const std::vector<std::vector<int>>& ov_at = n.ov_at[backward_pass ? 1 : 0];
+    const bool overlap = !h->timing && n.side && !ov_at.empty() && in_frames <= n.ov_max_frames;
+    struct SidePending { int join; void* done; };
+    std::vector<SidePending> side_pending;
+    if (overlap) n.ov_used = 0;
+    auto ov_event = [&]() -> void* {
+        if (n.ov_used == n.ov_ev.size()) { void* e = be_event_create(); if (!e) return nullptr; n.ov_ev.push_back(e); }
+        return n.ov_ev[n.ov_used++];
+    };
+    auto issue_side = [&](int p) -> int {                // the hoisted launches that follow main launch p (-1: the start of the list)
+        for (int i : ov_at[p + 1]) {
+            void* ready = ov_event(); void* done = ov_event();
+            if (!ready || !done) return fail("launch overlap: event creation failed");
+            CHECK_BE(be_event_record(ready, s)); CHECK_BE(be_stream_wait_event(n.side, ready));
+            Launch& m = L[i];
+            const int fr = clips * m.T;
+            if (fr * m.conv.Hg * m.conv.Wg != 0) {
+                const int cb = m.cfg_b[cfg_bucket(clips, n.maxN / n.Tin())];
+                if (cb) m.conv.cfg = cb;
+                if (conv_run(m, fr, x, gx, accumulate, n.side)) return 1;
+                __atomic_fetch_add(&g_overlap_launches, 1, __ATOMIC_RELAXED);
+            }
+            CHECK_BE(be_event_record(done, n.side));
+            side_pending.push_back(SidePending{m.ov_join, done});
+        }
+        return 0;
+    };
+    auto join_side = [&](int upto) -> int {              // the main stream waits for every hoisted launch whose first dependent is at or before `upto`
+        for (size_t i = 0; i < side_pending.size();) {
+            if (side_pending[i].join <= upto) { CHECK_BE(be_stream_wait_event(s, side_pending[i].done)); side_pending[i] = side_pending.back(); side_pending.pop_back(); }
+            else ++i;
+        }
+        return 0;
+    };
+    if (overlap && issue_side(-1)) return 1;
     for (size_t li = 0; li < L.size(); ++li) {
         Launch& l = L[li];
         const int frames = clips * l.T;                  // frames this launch iterates over
+        const size_t li0 = li;
+        if (overlap && l.ov_after != -2) continue;       // hoisted: already issued on the side stream
         // this 3x3 launch and the pointwise launch behind it as ONE kernel (mark_fusable / autotune): the next entry is skipped
         const int fuse = (l.kind == L_CONV && l.fuse_ok && li + 1 < L.size() && frames * l.conv.Hg * l.conv.Wg > 0 && fused_fits(l, L[li + 1], frames))
                              ? l.fuse_b[cfg_bucket(clips, n.maxN / n.Tin())] : 0;
         // this launch and the next fb_ok - 1 as ONE fused fast-pathway block (mark_fusable / autotune): those entries are skipped
         const int fb = (l.kind == L_CONV && l.fb_ok && li + l.fb_ok <= L.size() && frames * l.conv.Hg * l.conv.Wg > 0) ? l.fb_b[cfg_bucket(clips, n.maxN / n.Tin())] * l.fb_ok : 0;
+        if (overlap && join_side((int)li + (fb ? fb - 1 : fuse ? 1 : 0))) return 1;
         double flops = 0.0;
         if (fb) { for (int j = 0; j < fb; ++j) { const Launch& m = L[li + j]; flops += m.alg_flops_per_frame > 0 ? m.alg_flops_per_frame * frames : 2.0 * frames * m.conv.Hg * m.conv.Wg * (double)m.conv.Cd * m.conv.K; } }
         else if (l.kind == L_CONV && l.alg_flops_per_frame > 0) flops = l.alg_flops_per_frame * frames;     // quad-row packings pad K
@@ -1784,7 +1940,9 @@ static int run_list(i2v_ctx* h, Net& n, std::vector<Launch>& L, int in_frames, c
             case L_AGEMM: { I2VAttnGemm p = l.ag; p.clips = clips; CHECK_BE(k_attn_gemm(p, s)); } break;
             case L_SOFTMAX: { I2VSoftmaxRows p = l.sm; p.rows = (int64_t)clips * l.sm_rows_per_clip; CHECK_BE(k_softmax_rows(p, s)); } break;
         }
+        if (overlap) for (size_t p = li0; p <= li; ++p) if (issue_side((int)p)) return 1;      // (a fused group advanced li past its members)
     }
+    if (overlap && join_side((int)L.size())) return 1;   // nothing of this list is still running on the side stream when the caller's next kernel starts
     if (seg) be_event_record(seg->stop, s);
     return 0;
 }

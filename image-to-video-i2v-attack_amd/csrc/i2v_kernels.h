@@ -23,6 +23,9 @@ void be_event_destroy(void* ev);
 int  be_event_record(void* ev, i2v_stream_t s);
 int  be_event_elapsed_ms(void* start, void* stop, float* ms);           // both must have completed
 int  be_stream_sync(i2v_stream_t s);
+i2v_stream_t be_stream_create();                                          // a non-blocking stream of its own (side stream of run_list's launch overlap); null on failure
+void be_stream_destroy(i2v_stream_t s);
+int  be_stream_wait_event(i2v_stream_t s, void* ev);                       // work queued on `s` after this call starts after `ev` has completed
 int  be_device_sync();                                                       // last backend error or null
 
 int k_conv(const I2VConvParams& p, i2v_stream_t s);

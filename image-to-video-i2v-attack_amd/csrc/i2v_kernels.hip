@@ -53,6 +53,9 @@ int be_event_record(void* ev, i2v_stream_t s) { HIPCHK(hipEventRecord((hipEvent_
 int be_event_elapsed_ms(void* a, void* b, float* ms) { HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return 0; }
 int be_stream_sync(i2v_stream_t s) { HIPCHK(hipStreamSynchronize((hipStream_t)s)); return 0; }
 int be_device_sync() { HIPCHK(hipDeviceSynchronize()); return 0; }
+i2v_stream_t be_stream_create() { hipStream_t s = nullptr; if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr; return (i2v_stream_t)s; }
+void be_stream_destroy(i2v_stream_t s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
+int be_stream_wait_event(i2v_stream_t s, void* ev) { HIPCHK(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)ev, 0)); return 0; }
 
 __constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};
 __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};

@@ -37,6 +37,9 @@ int be_event_record(void*, i2v_stream_t) { return 0; }
 int be_event_elapsed_ms(void*, void*, float* ms) { *ms = 0.f; return 0; }
 int be_stream_sync(i2v_stream_t) { return 0; }
 int be_device_sync() { return 0; }
+i2v_stream_t be_stream_create() { return malloc(8); }       // (the host simulation runs every launch synchronously, in ISSUE order: a hoisted launch really runs early)
+void be_stream_destroy(i2v_stream_t s) { free(s); }
+int be_stream_wait_event(i2v_stream_t, void*) { return 0; }
 int cos_nblk(int64_t D) { return (int)std::min<int64_t>(64, std::max<int64_t>(1, D / 4096)); }
 
 int k_conv_candidates(const I2VConvParams&, int* out) { out[0] = 0; return 1; }

@@ -457,6 +457,34 @@ def test_clip_lanes_full_size_bit_identical(eng):
     assert torch.equal(two(vid[:1], torch.zeros(1, dtype=torch.long), names[:1]).cpu(), ref[:1])
 
 
+def test_launch_overlap_full_size_bit_identical(eng, monkeypatch):
+    """Round 6: one 32-frame 224^2 clip, ResNet-50 layer3, 10 steps -- the reference CLI's default batch -- with the
+    projection shortcuts (and their input gradients) overlapped on the net's side stream (`mark_overlap`, the default for calls of <= 32
+    frames) against the same attack planned with the overlap off: same bytes out, same costs, and the side stream really ran launches."""
+    vid = gu.videos_of({"clip_u8": torch.randint(0, 256, (1, 3, 32, 224, 224), generator=torch.Generator().manual_seed(1000), dtype=torch.uint8).numpy()})
+    lab = torch.zeros(1, dtype=torch.long)
+    monkeypatch.setenv("I2V_OVERLAP_MAX_FRAMES", "0")
+    off = attacks.ImageGuidedFMDirection_Adam(["resnet50"], depth=3, step_size=0.005, steps=10)
+    before = eng.capi.i2v_backend_stat(b"overlap_launches")
+    ref = off(vid, lab, ["c0"]).cpu()
+    assert eng.capi.i2v_backend_stat(b"overlap_launches") == before
+    monkeypatch.delenv("I2V_OVERLAP_MAX_FRAMES")
+    on = attacks.ImageGuidedFMDirection_Adam(["resnet50"], depth=3, step_size=0.005, steps=10)
+    got = on(vid, lab, ["c0"]).cpu()
+    ran = eng.capi.i2v_backend_stat(b"overlap_launches") - before
+    assert ran >= 11 * 3 + 10 * 3, ran          # three projection shortcuts: 11 forward passes, 10 backward passes
+    assert torch.equal(got, ref) and np.array_equal(on.last_costs, off.last_costs)
+    assert torch.equal(on(vid, lab, ["c0"]).cpu(), ref)          # and again (event pool reused)
+    # ResNet-101 to layer2 and the four-backbone ensemble's nets take the same path
+    for models, depth in ((["resnet"], 2), (["squeezenet"], 2)):
+        monkeypatch.setenv("I2V_OVERLAP_MAX_FRAMES", "0")
+        a = attacks.ImageGuidedFMDirection_Adam(models, depth=depth, step_size=0.005, steps=3)
+        ra = a(vid[:, :, :8].contiguous(), lab, ["c0"]).cpu()
+        monkeypatch.setenv("I2V_OVERLAP_MAX_FRAMES", "32")
+        b = attacks.ImageGuidedFMDirection_Adam(models, depth=depth, step_size=0.005, steps=3)
+        assert torch.equal(b(vid[:, :, :8].contiguous(), lab, ["c0"]).cpu(), ra)
+
+
 def test_clip_lanes_ensemble_and_odd_split(eng):
     """ENS-I2V (four backbones, gradient accumulation) with 3 clips -> lanes of 1 and 2 clips; and a 24-frame single
     clip -> frame lanes of 12 + 12: same bytes as one lane."""

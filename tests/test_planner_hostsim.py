@@ -449,3 +449,44 @@ def test_fast_pathway_blocks_are_found_and_change_nothing(monkeypatch):
     net.forward(x)
     assert eng.capi.i2v_backend_stat(b"fastblock_launches") - before == 1
     net.close()
+
+
+@pytest.mark.parametrize("model,depths,hw", [("resnet", [3], 64), ("resnet", [2, 3], 64), ("resnet", [4], 64), ("squeezenet", [2, 3], 64),
+                                             ("densenet121", [2, 4], 64), ("vgg", [3], 32)])
+def test_launch_overlap_keeps_every_bit(model, depths, hw, monkeypatch):
+    """Round 6, `mark_overlap` / `run_list`: launches that do not depend on their predecessors (a first
+    bottleneck's projection shortcut, its input gradient) are ISSUED early, on the net's side stream.  The host simulation executes
+    every launch synchronously in issue order, so a hoisted launch really runs before the launches it was moved over: the dependency
+    analysis is right iff every activation and the input gradient stay bit-identical to the in-order run."""
+    eng = hostsim_engine()
+    g = graphs.build_tiny(model, (hw, hw))
+    sd = weights.synthetic_state_dict(g, 3)
+    hooks = [g.hooks[d] for d in depths]
+    N = 2
+    torch.manual_seed(7)
+    x = torch.randn(N, 3, hw, hw)
+    hgs = None
+    out = {}
+    for mode in ("0", "1000"):
+        monkeypatch.setenv("I2V_OVERLAP_MAX_FRAMES", mode)
+        net = eng.build_net(g, sd, hooks, N)
+        before = eng.capi.i2v_backend_stat(b"overlap_launches")
+        net.forward(x)
+        acts = [net.read_tensor(nd.dst, N).clone() for nd in net.graph.nodes]
+        feats = [net.read_tensor(h, N) for h in hooks]
+        if hgs is None:
+            hgs = [torch.randn_like(f) for f in feats]
+        write_hook_grads(net, feats, hgs, N)
+        gx = torch.empty(N, 3, hw, hw)
+        net.backward(gx)
+        gx2 = gx.clone()
+        net.backward(gx2, accumulate=True)
+        out[mode] = (acts, gx, gx2, eng.capi.i2v_backend_stat(b"overlap_launches") - before)
+    a0, g0, h0, n0 = out["0"]
+    a1, g1, h1, n1 = out["1000"]
+    assert n0 == 0
+    if model == "resnet":
+        assert n1 >= 2 * len([1 for _ in range(max(depths))]), n1      # every projection shortcut, both passes (+ the extra backward call)
+    for u, v in zip(a0, a1):
+        assert torch.equal(u, v)
+    assert torch.equal(g0, g1) and torch.equal(h0, h1)
