@@ -274,15 +274,406 @@ fast_block_kernel(const I2VFastBlockParams p) {
     }
 }
 
+// =============================================================================================
+// fast_block2_kernel: the same fused block, re-blocked (round 6, second version)
+// =============================================================================================
+// What the first version measured (profiles/r6_fastblock_*.txt): 64-80 us per forward block at 128 frames where its HBM bytes take 35 and
+// its FMAs 10 -- every block of the launch is resident at once and walks the same phases in step (load-bound, issue-bound,
+// store-bound: the phases add up instead of overlapping), with one pixel per lane per stage, so that every scalar weight row feeds ONE
+// packed FMA per lane, a 64-bit address is computed for every load, and R = 4 rows per block recompute half of stage A for the halo.
+// Here a block is 2 waves on a strip of R = 8 rows (halo 10 / 8), and a wave owns up to PA = 5 chunks of 64 consecutive positions in
+// stage A and PB = 4 chunks of 64 consecutive pixels in stages B / C:
+//   * a weight row (one s_load_dwordx8) feeds PA (PB) packed FMAs per channel pair; the rows that contribute are COMPACTED once per
+//     block (k-table rows that add an exact zero -- padding rows, taps outside the clip -- are not walked at all);
+//   * global operands move through buffer instructions: one descriptor per tensor, the lane's position as a 32-bit offset computed once
+//     per chunk, the row / channel / frame part as the scalar offset -- no per-access address arithmetic; positions outside the plane
+//     carry an out-of-range offset (loads return 0, stores are dropped);
+//   * stage A runs four K rows per step, the next four rows' operands and weights requested before this step's FMAs; the residual (or
+//     the projection's inputs) and the gate words of stage B are requested before stage B starts and arrive under it.
+// Same k-ordered fmaf chain per output element, same epilogue operations in the same order as the first version: bit-identical to the
+// separate launches (tests/test_gpu_video.py runs both versions against them).
+typedef float f8 __attribute__((ext_vector_type(8)));
+constexpr int FB2_PA = 5, FB2_PB = 4;
+constexpr unsigned FB2_OOB = 0x80000000u;
+template <int CM> struct fb2_row;                                    // one packed weight row of CM output channels, as scalar loads see it
+template <> struct fb2_row<8> { typedef f8 type; };
+template <> struct fb2_row<4> { typedef f32x4 type; };
+#define FB2_RFL(x) __builtin_amdgcn_readfirstlane(x)
+__device__ __forceinline__ float fb2_ld(const __amdgpu_buffer_rsrc_t rs, const unsigned vo, const int so) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo, so, 0));
+}
+// gate words of channel c for a chunk of 64 pixels: the ballot's two words written straight into lane c (no per-channel lane masks: the
+// first build kept 32 of them in SGPR pairs and spilled).  Pixels past the strip's end contribute bits to words fb_gate_store drops
+// (a strip is a whole number of words), so the caller need not mask them.
+extern "C" __device__ int fb2_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");      // v_writelane_b32 (clang has no builtin for it)
+__device__ __forceinline__ void fb2_gate_collect(unsigned& lo, unsigned& hi, const int c, const bool on) {
+    const unsigned long long m = __ballot(on);
+    lo = (unsigned)fb2_writelane((int)(unsigned)m, c, (int)lo);
+    hi = (unsigned)fb2_writelane((int)(unsigned)(m >> 32), c, (int)hi);
+}
+__device__ __forceinline__ void fb2_st(const float v, const __amdgpu_buffer_rsrc_t rs, const unsigned vo, const int so) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)vo, so, 0);
+}
+
+template <int CM, int MODE>       // MODE 0: forward, identity shortcut; 1: forward, projection shortcut; 2: backward
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+fast_block2_kernel(const I2VFastBlockParams p) {
+    constexpr bool FWD = MODE != 2, PROJ = MODE == 1;
+    constexpr int CP = CM / 2, C3 = 4 * CM, NG = C3 / 8, PA = FB2_PA, PB = FB2_PB;
+    typedef typename fb2_row<CM>::type wrow_t;
+    typedef const __attribute__((address_space(4))) wrow_t* wrowp_t;
+    typedef const __attribute__((address_space(4))) f8* w8p_t;
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = FB2_RFL(tid >> 6);
+    const int H = p.H, W = p.W, R = p.R, HW = H * W, AR = R + 2, AW = W + 2, CH = AR * AW;      // CH: channel stride of stage A's LDS image
+    int* const tabA = reinterpret_cast<int*>(lds_f);                     // [Kpad_a] (byte offset of the row's plane in the source tensor, K row): the rows that contribute
+    int* const tabB = tabA + 2 * p.a.Kpad;                               // [Kpad_b] (float offset in the LDS image, K row)
+    int* const cnts = tabB + 2 * p.b.Kpad;                               // rows in tabA, tabB
+    float* const A1 = lds_f + ((2 * p.a.Kpad + 2 * p.b.Kpad + 4 + 3) & ~3);      // [CM][AR][AW]
+    // block -> (clip, frame, strip): as in the first version (a clip's frames over a group of strips on ONE XCD)
+    const unsigned b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
+    const unsigned uix = fastdiv(slot, p.dv_bu_m, p.dv_bu_s), bi = slot - uix * p.BU, un = xcd + 8u * uix;
+    if (un >= (unsigned)p.U) return;
+    const int clip = (int)fastdiv(un, p.dv_s_m, p.dv_s_s), sg = (int)un - clip * p.S;
+    const int t = (int)fastdiv(bi, p.dv_g_m, p.dv_g_s), strip = sg * p.G + ((int)bi - t * p.G);
+    const int n = clip * p.T + t, r0 = strip * R;
+    // ---- the K rows that contribute, compacted (wave 0: stage A's, wave 1: stage B's) ----
+    {
+        const I2VFastStage& st = wave == 0 ? p.a : p.b;
+        int* const tab = wave == 0 ? tabA : tabB;
+        int cnt = 0;
+        for (int k0 = 0; k0 < st.Kpad; k0 += 64) {
+            const int k = k0 + lane;
+            bool ok = false; int off = 0;
+            if (k < st.Kpad) {
+                const I2VKEntry e = st.ktab[k];
+                if (wave == 0) {
+                    const int tf = t + (e.valid >> 1);
+                    ok = (e.valid & 1) && tf >= 0 && tf < p.T;
+                    off = (int)(((int64_t)(clip * p.T + tf) * p.src_nstride + e.chan_off) * 4);          // (< 2^31: k_fastblock checks)
+                } else {
+                    ok = (e.valid & 1) != 0;
+                    off = ((int)fastdiv((unsigned)e.chan_off, p.dv_hw_m, p.dv_hw_s) * AR + e.dh) * AW + e.dw;
+                }
+            }
+            const unsigned long long m = __ballot(ok);
+            const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (ok) { tab[2 * pos] = off; tab[2 * pos + 1] = k; }
+            cnt += __popcll(m);
+        }
+        if (lane == 0) cnts[wave] = cnt;
+    }
+    for (int i = tid; i < CM * AR * 2; i += 128) A1[(i >> 1) * AW + ((i & 1) ? AW - 1 : 0)] = 0.f;      // zero columns 0 and W + 1 of every (channel, row)
+    __syncthreads();
+    const int NPOS = AR * W, NPIX = R * W;
+    const int64_t pix_n = (int64_t)n * HW;                               // bit index of the frame's first pixel in a gate row
+    // ---------------- stage A: the R + 2 rows, chunks wave, wave + 2, ... of 64 consecutive positions ----------------
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((int64_t)p.N * p.src_nstride * 4), 0x00020000);
+        unsigned voff[PA]; int la[PA];
+#pragma unroll
+        for (int u = 0; u < PA; ++u) {
+            const int q = (wave + 2 * u) * 64 + lane;                    // position of the (R + 2) x W grid: plane pixel (r0 - 1) W + q (rows are contiguous)
+            const int rowq = (int)fastdiv((unsigned)q, p.dv_w_m, p.dv_w_s), colq = q - rowq * W, prow = r0 - 1 + rowq;
+            const bool ok = q < NPOS && prow >= 0 && prow < H;           // (outside the plane: the 3 x 3 stage's zero padding)
+            voff[u] = ok ? (unsigned)(((r0 - 1) * W + q) * 4) : FB2_OOB;
+            la[u] = q < NPOS ? rowq * AW + colq + 1 : -1;
+        }
+        unsigned gw[PA][FWD ? 1 : CM];                                    // backward: the gate words of this stage's tensor at the lane's positions
+        if (!FWD) {
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.a.gate, 0, CM * p.a.gate_stride * 4, 0x00020000);
+#pragma unroll
+            for (int u = 0; u < PA; ++u) {
+                const unsigned wo = voff[u] == FB2_OOB ? FB2_OOB : (unsigned)(((pix_n + (voff[u] >> 2)) >> 5) * 4);
+#pragma unroll
+                for (int c = 0; c < CM; ++c) gw[u][c] = __builtin_amdgcn_raw_buffer_load_b32(rg, (int)wo, c * p.a.gate_stride * 4, 0);
+            }
+        }
+        f2 acc[PA][CP];
+#pragma unroll
+        for (int u = 0; u < PA; ++u)
+#pragma unroll
+            for (int c = 0; c < CP; ++c) acc[u][c] = f2{0.f, 0.f};
+        const int nvA = FB2_RFL(cnts[0]), ng = nvA >> 2;
+        const int wstride = p.a.Cdpad;
+        float xa[4][PA], xb[4][PA];
+        int ka[4], kb[4];
+        // (the weight rows are requested where they are used: a group's 4 rows are 32 SGPRs, and a second group in flight made the
+        // allocator park whole rows in VGPR lanes -- one v_readlane per FMA in the first build)
+#define FB2_A_LOAD(I0, X, KK)                                                                                  \
+        {                                                                                                      \
+            const i2v_v4i e0 = *reinterpret_cast<const i2v_v4i*>(tabA + 2 * (I0)), e1 = *reinterpret_cast<const i2v_v4i*>(tabA + 2 * (I0) + 4);      \
+            const int so[4] = {FB2_RFL(e0.x), FB2_RFL(e0.z), FB2_RFL(e1.x), FB2_RFL(e1.z)};                     \
+            KK[0] = FB2_RFL(e0.y); KK[1] = FB2_RFL(e0.w); KK[2] = FB2_RFL(e1.y); KK[3] = FB2_RFL(e1.w);         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+                _Pragma("unroll") for (int u = 0; u < PA; ++u) X[j][u] = fb2_ld(rs, voff[u], so[j]);            \
+        }
+#define FB2_A_FMA(X, KK)                                                                                       \
+        {                                                                                                      \
+            wrow_t wv[4];                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) wv[j] = *(wrowp_t)(p.a.wp + (int64_t)KK[j] * wstride);      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+                _Pragma("unroll") for (int u = 0; u < PA; ++u)                                                 \
+                    _Pragma("unroll") for (int c = 0; c < CP; ++c)                                             \
+                        acc[u][c] = __builtin_elementwise_fma(f2{wv[j][2 * c], wv[j][2 * c + 1]}, f2{X[j][u], X[j][u]}, acc[u][c]);      \
+            asm volatile("" ::: "memory");                                                                     \
+        }
+        if (ng > 0) FB2_A_LOAD(0, xa, ka)
+        int g = 0;
+        for (; g + 2 <= ng; g += 2) {
+            FB2_A_LOAD(4 * (g + 1), xb, kb)
+            FB2_A_FMA(xa, ka)
+            if (g + 2 < ng) FB2_A_LOAD(4 * (g + 2), xa, ka)
+            FB2_A_FMA(xb, kb)
+        }
+        if (g < ng) { FB2_A_FMA(xa, ka) }
+        for (int i = 4 * ng; i < nvA; ++i) {                             // (a row count that is not a multiple of 4: the last rows one by one)
+            const int so = FB2_RFL(tabA[2 * i]), kk = FB2_RFL(tabA[2 * i + 1]);
+            const wrow_t wv = *(wrowp_t)(p.a.wp + (int64_t)kk * wstride);
+#pragma unroll
+            for (int u = 0; u < PA; ++u) {
+                const float x = fb2_ld(rs, voff[u], so);
+#pragma unroll
+                for (int c = 0; c < CP; ++c) acc[u][c] = __builtin_elementwise_fma(f2{wv[2 * c], wv[2 * c + 1]}, f2{x, x}, acc[u][c]);
+            }
+        }
+#undef FB2_A_LOAD
+#undef FB2_A_FMA
+        float sh[CM];
+#pragma unroll
+        for (int c = 0; c < CM; ++c) sh[c] = FWD ? ((cfptr_t)p.a.shift)[c] : 0.f;
+#pragma unroll
+        for (int u = 0; u < PA; ++u) {
+            if (la[u] < 0) continue;
+            const bool inside = voff[u] != FB2_OOB;
+            const unsigned bitn = (unsigned)((pix_n + (voff[u] >> 2)) & 31);
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                float v = (c & 1) ? acc[u][c >> 1].y : acc[u][c >> 1].x;
+                if (FWD) v = fmaxf(v + sh[c], 0.f);
+                else if (!((gw[u][c] >> bitn) & 1u)) v = 0.f;
+                A1[c * CH + la[u]] = inside ? v : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------- stages B (and C): the R rows, chunks 1 - wave, 3 - wave, ... of 64 consecutive pixels ----------------
+    const int64_t bit_strip = pix_n + (int64_t)r0 * W, bit_end = bit_strip + NPIX;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dst, 0, (int)((int64_t)p.N * p.dst_nstride * 4), 0x00020000);
+    const int dst_n = (int)((int64_t)n * p.dst_nstride * 4);
+    int ctr[PB]; unsigned vo[PB]; bool act[PB];
+#pragma unroll
+    for (int u = 0; u < PB; ++u) {
+        const int pp = ((1 - wave) + 2 * u) * 64 + lane;
+        act[u] = pp < NPIX;
+        const int ppc = act[u] ? pp : 0;
+        const int row = (int)fastdiv((unsigned)ppc, p.dv_w_m, p.dv_w_s), col = ppc - row * W;
+        ctr[u] = (row + 1) * AW + col + 1;                               // the lane's own position in channel 0 of the LDS image
+        vo[u] = act[u] ? (unsigned)((r0 * W + pp) * 4) : FB2_OOB;        // ... and in a channel plane of a global tensor (bytes)
+    }
+    // operands of the later stages, requested now: the residual (identity shortcut) or the projection's inputs; backward: gate words
+    float res[(FWD && !PROJ) ? PB : 1][(FWD && !PROJ) ? C3 : 1];
+    float xs[PROJ ? PB : 1][PROJ ? CM : 1];
+    unsigned gwb[FWD ? 1 : PB][FWD ? 1 : CM];
+    if (FWD && !PROJ) {
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.add0, 0, (int)((int64_t)p.N * p.add0_nstride * 4), 0x00020000);
+        const int add_n = (int)((int64_t)n * p.add0_nstride * 4);
+#pragma unroll
+        for (int c = 0; c < C3; ++c)
+#pragma unroll
+            for (int u = 0; u < PB; ++u) res[u][c] = fb2_ld(rr, vo[u], add_n + c * HW * 4);
+    }
+    if (PROJ) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((int64_t)p.N * p.src_nstride * 4), 0x00020000);
+        const int src_n = (int)((int64_t)n * p.src_nstride * 4);
+#pragma unroll
+        for (int k = 0; k < CM; ++k)
+#pragma unroll
+            for (int u = 0; u < PB; ++u) xs[u][k] = fb2_ld(rs, vo[u], src_n + k * HW * 4);
+    }
+    if (!FWD) {
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.b.gate, 0, CM * p.b.gate_stride * 4, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const unsigned wo = act[u] ? (unsigned)(((pix_n + (vo[u] >> 2)) >> 5) * 4) : FB2_OOB;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) gwb[u][c] = __builtin_amdgcn_raw_buffer_load_b32(rg, (int)wo, c * p.b.gate_stride * 4, 0);
+        }
+    }
+    if (FWD) {                       // stage A's own gates, from the finished values in LDS (post-ReLU: > 0 is the bit)
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int64_t bit0 = bit_strip + ((1 - wave) + 2 * u) * 64;
+            if (bit0 >= bit_end) continue;                               // (wave-uniform: this chunk does not exist)
+            unsigned glo = 0, ghi = 0;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) fb2_gate_collect(glo, ghi, c, A1[c * CH + ctr[u]] > 0.f);
+            fb_gate_store(p.a.gate_out, p.a.gate_out_stride, CM, glo, ghi, bit0, bit_end, lane);
+        }
+    }
+    float a2[PB][CM];
+    {
+        f2 acc[PB][CP];
+#pragma unroll
+        for (int u = 0; u < PB; ++u)
+#pragma unroll
+            for (int c = 0; c < CP; ++c) acc[u][c] = f2{0.f, 0.f};
+        const int nvB = FB2_RFL(cnts[1]);
+        const int wstride = p.b.Cdpad;
+        int i = 0;
+        for (; i + 4 <= nvB; i += 4) {
+            const i2v_v4i e0 = *reinterpret_cast<const i2v_v4i*>(tabB + 2 * i), e1 = *reinterpret_cast<const i2v_v4i*>(tabB + 2 * i + 4);
+            const int so[4] = {FB2_RFL(e0.x), FB2_RFL(e0.z), FB2_RFL(e1.x), FB2_RFL(e1.z)}, kk[4] = {FB2_RFL(e0.y), FB2_RFL(e0.w), FB2_RFL(e1.y), FB2_RFL(e1.w)};
+            float x[4][PB]; wrow_t wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int u = 0; u < PB; ++u) x[j][u] = A1[ctr[u] + so[j]];
+                wv[j] = *(wrowp_t)(p.b.wp + (int64_t)kk[j] * wstride);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int u = 0; u < PB; ++u)
+#pragma unroll
+                    for (int c = 0; c < CP; ++c) acc[u][c] = __builtin_elementwise_fma(f2{wv[j][2 * c], wv[j][2 * c + 1]}, f2{x[j][u], x[j][u]}, acc[u][c]);
+        }
+        for (; i < nvB; ++i) {
+            const int so = FB2_RFL(tabB[2 * i]), kk = FB2_RFL(tabB[2 * i + 1]);
+            const wrow_t wv = *(wrowp_t)(p.b.wp + (int64_t)kk * wstride);
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const float x = A1[ctr[u] + so];
+#pragma unroll
+                for (int c = 0; c < CP; ++c) acc[u][c] = __builtin_elementwise_fma(f2{wv[2 * c], wv[2 * c + 1]}, f2{x, x}, acc[u][c]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const unsigned bitn = (unsigned)((pix_n + (vo[u] >> 2)) & 31);
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                float v = (c & 1) ? acc[u][c >> 1].y : acc[u][c >> 1].x;
+                if (FWD) v = fmaxf(v + ((cfptr_t)p.b.shift)[c], 0.f);
+                else if (!((gwb[u][c] >> bitn) & 1u)) v = 0.f;
+                a2[u][c] = v;
+            }
+        }
+    }
+    if (!FWD) {                      // backward: stage B's result is the output
+#pragma unroll
+        for (int c = 0; c < CM; ++c)
+#pragma unroll
+            for (int u = 0; u < PB; ++u) fb2_st(a2[u][c], rd, vo[u], dst_n + c * HW * 4);
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < PB; ++u) {
+        const int64_t bit0 = bit_strip + ((1 - wave) + 2 * u) * 64;
+        if (bit0 >= bit_end) continue;
+        unsigned glo = 0, ghi = 0;
+#pragma unroll
+        for (int c = 0; c < CM; ++c) fb2_gate_collect(glo, ghi, c, a2[u][c] > 0.f);
+        fb_gate_store(p.b.gate_out, p.b.gate_out_stride, CM, glo, ghi, bit0, bit_end, lane);
+    }
+    // ---------------- stage C: conv3 (pointwise over the lane's own a2: K row k is channel k) + residual + ReLU, 8 output channels at a time ----------------
+    unsigned glo[PB], ghi[PB];
+#pragma unroll
+    for (int u = 0; u < PB; ++u) glo[u] = ghi[u] = 0u;
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+        asm volatile("" ::: "memory");                                   // (one group's weight rows in SGPRs at a time)
+        f2 ov[PB][4];
+#pragma unroll
+        for (int u = 0; u < PB; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ov[u][j] = f2{0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < CM; ++k) {
+            const f8 w8 = *(w8p_t)(p.c.wp + (int64_t)k * p.c.Cdpad + 8 * gq);
+#pragma unroll
+            for (int u = 0; u < PB; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ov[u][j] = __builtin_elementwise_fma(f2{w8[2 * j], w8[2 * j + 1]}, f2{a2[u][k], a2[u][k]}, ov[u][j]);
+            if (k & 1) asm volatile("" ::: "memory");                    // (two weight rows in SGPRs at a time)
+        }
+        f2 rv[PB][4];
+        if (PROJ) {                  // projection shortcut: pointwise over x[t] (K row k is channel k), + its shift: the value the separate launch stores
+#pragma unroll
+            for (int u = 0; u < PB; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rv[u][j] = f2{0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < CM; ++k) {
+                const f8 w8 = *(w8p_t)(p.d.wp + (int64_t)k * p.d.Cdpad + 8 * gq);
+#pragma unroll
+                for (int u = 0; u < PB; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rv[u][j] = __builtin_elementwise_fma(f2{w8[2 * j], w8[2 * j + 1]}, f2{xs[u][k], xs[u][k]}, rv[u][j]);
+                if (k & 1) asm volatile("" ::: "memory");
+            }
+            const f8 sd = *(w8p_t)(p.d.shift + 8 * gq);
+#pragma unroll
+            for (int u = 0; u < PB; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rv[u][j] = f2{rv[u][j].x + sd[2 * j], rv[u][j].y + sd[2 * j + 1]};
+        } else {
+#pragma unroll
+            for (int u = 0; u < PB; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rv[u][j] = f2{res[u][8 * gq + 2 * j], res[u][8 * gq + 2 * j + 1]};
+        }
+        const f8 sc = *(w8p_t)(p.c.shift + 8 * gq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ch = 8 * gq + 2 * j + h;
+#pragma unroll
+                for (int u = 0; u < PB; ++u) {
+                    const float v = fmaxf(((h ? ov[u][j].y : ov[u][j].x) + sc[2 * j + h]) + (h ? rv[u][j].y : rv[u][j].x), 0.f);
+                    fb2_st(v, rd, vo[u], dst_n + ch * HW * 4);
+                    fb2_gate_collect(glo[u], ghi[u], ch, v > 0.f);
+                }
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < PB; ++u) {
+        const int64_t bit0 = bit_strip + ((1 - wave) + 2 * u) * 64;
+        if (bit0 >= bit_end) continue;
+        fb_gate_store(p.c.gate_out, p.c.gate_out_stride, C3, glo[u], ghi[u], bit0, bit_end, lane);
+    }
+}
+
 static void fb_stage(I2VFastStage& st, const I2VConvParams& q) {
     st.wp = q.wp; st.ktab = q.ktab; st.Kpad = q.Kpad; st.Cdpad = q.Cdpad; st.shift = q.shift; st.relu = q.relu;
     st.gate = q.gate; st.gate_stride = q.gate_stride; st.gate_pix0 = q.gate_pix0;
     st.gate_out = q.gate_out; st.gate_out_stride = q.gate_out_stride; st.gate_out_pix0 = q.gate_out_pix0;
 }
 
+// Rows per block for the second version: the largest R (whole gate words per strip, a divisor of H) whose R + 2 rows fit 2 x FB2_PA chunks
+// of 64 positions and whose R rows fit 2 x FB2_PB chunks of 64 pixels; 0: the first version runs the block.
+static int fb2_rows(const I2VConvParams& a, const I2VConvParams& b, const I2VConvParams* c, const I2VConvParams* d) {
+    const char* const e1 = getenv("I2V_FB_V1");                       // (read per launch: the GPU test runs both versions in one process)
+    if (e1 && e1[0] == '1') return 0;
+    const int H = a.Hg, W = a.Wg;
+    int g = W, r32 = 32; while (r32) { const int t = g % r32; g = r32; r32 = t; }      // gcd(W, 32)
+    const int Rq = 32 / g;
+    int best = 0;
+    for (int R = Rq; R <= H; R += Rq)
+        if (H % R == 0 && (R + 2) * W <= 128 * FB2_PA && R * W <= 128 * FB2_PB && (size_t)a.Cd * (R + 2) * (W + 2) * 4 <= 56 * 1024) best = R;
+    if (!best) return 0;
+    auto small = [&](int64_t nstride) { return (int64_t)a.N * nstride * 4 < (1ll << 31); };       // every tensor through one buffer descriptor, offsets in 32 bits
+    if (!small(a.src_nstride) || !small(c ? c->dst_nstride : b.dst_nstride) || (c && !d && !small(c->add0_nstride))) return 0;
+    if (c && (c->Cd % 8 != 0 || c->Cdpad < c->Cd || (d && d->Cdpad < d->Cd))) return 0;
+    return best;
+}
+
 int k_fastblock(const I2VConvParams& a, const I2VConvParams& b, const I2VConvParams* c, const I2VConvParams* d, i2v_stream_t s) {
-    const int R = i2v_fastblock_rows(a, b, c, d);
+    int R = i2v_fastblock_rows(a, b, c, d);
     if (R <= 0) { snprintf(g_be_err, sizeof g_be_err, "fast-block launch: the convolutions are not eligible"); g_be_has_err = true; return 1; }
+    const int R2 = fb2_rows(a, b, c, d);
+    if (R2 > 0) R = R2;
     I2VFastBlockParams p;
     memset(&p, 0, sizeof p);
     p.mode = c ? 0 : 1; p.CM = a.Cd;
@@ -305,8 +696,17 @@ int k_fastblock(const I2VConvParams& a, const I2VConvParams& b, const I2VConvPar
     if (nblk > 0x7fffffff) { snprintf(g_be_err, sizeof g_be_err, "fast-block grid too large"); g_be_has_err = true; return 1; }
     const dim3 grid((unsigned)nblk);
     if ((int64_t)p.T * p.src_nstride >= (1ll << 30)) { snprintf(g_be_err, sizeof g_be_err, "fast-block launch: a clip's frames span more than 2^30 elements"); g_be_has_err = true; return 1; }
-    const size_t lds = (((size_t)a.Kpad + b.Kpad + 3) & ~(size_t)3) * sizeof(int) + (size_t)p.CM * (R + 2) * (p.W + 2) * sizeof(float);
     __atomic_fetch_add(&g_stat_fastblock, 1, __ATOMIC_RELAXED);
+    if (R2 > 0) {
+        const size_t lds2 = (((size_t)2 * a.Kpad + 2 * b.Kpad + 4 + 3) & ~(size_t)3) * sizeof(int) + (size_t)p.CM * (R + 2) * (p.W + 2) * sizeof(float);
+#define FB2_GO(CMV, MD) hipLaunchKernelGGL((fast_block2_kernel<CMV, MD>), grid, dim3(128), lds2, (hipStream_t)s, p)
+        if (p.CM == 8) { if (!c) FB2_GO(8, 2); else if (d) FB2_GO(8, 1); else FB2_GO(8, 0); }
+        else { if (!c) FB2_GO(4, 2); else if (d) FB2_GO(4, 1); else FB2_GO(4, 0); }
+#undef FB2_GO
+        LAUNCH_CHECK("fast_block2_kernel");
+        return 0;
+    }
+    const size_t lds = (((size_t)a.Kpad + b.Kpad + 3) & ~(size_t)3) * sizeof(int) + (size_t)p.CM * (R + 2) * (p.W + 2) * sizeof(float);
 #define FB_GO(CMV, FW, PR) hipLaunchKernelGGL((fast_block_kernel<CMV, FW, PR>), grid, dim3(128), lds, (hipStream_t)s, p)
     if (p.CM == 8) { if (!c) FB_GO(8, false, false); else if (d) FB_GO(8, true, true); else FB_GO(8, true, false); }
     else { if (!c) FB_GO(4, false, false); else if (d) FB_GO(4, true, true); else FB_GO(4, true, false); }

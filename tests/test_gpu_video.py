@@ -704,14 +704,19 @@ def test_fused_3x3_pointwise_pairs_are_bit_identical(eng, monkeypatch, experimen
     assert float(outs[0][1].abs().max()) > 0
 
 
-@pytest.mark.parametrize("thw,width,clips", [((8, 32, 32), 16, 3), ((16, 64, 64), 64, 2), ((32, 224, 224), 64, 1)])
-def test_fast_pathway_block_kernel_is_bit_identical(eng, monkeypatch, thw, width, clips):
+@pytest.mark.parametrize("version", ["v2", "v1"])
+@pytest.mark.parametrize("thw,width,clips", [((8, 32, 32), 16, 3), ((16, 64, 64), 64, 2), ((32, 224, 224), 64, 1), ((32, 224, 224), 64, 3)])
+def test_fast_pathway_block_kernel_is_bit_identical(eng, monkeypatch, thw, width, clips, version):
     """`fast_block_kernel` (round 6): SlowFast's fast-pathway bottlenecks as ONE launch each way -- forward conv1 (3x1x1) -> conv2 (1x3x3)
     -> [projection] -> conv3 + residual + ReLU with all three tensors' 1-bit gates, backward the input gradients of conv3 and conv2 --
     on packed fp32 vector FMAs, forced onto every group the planner finds, against the separate conv_igemm launches: hooked features
     and input gradient bit for bit.  4 mid channels on 8 x 8 planes (one strip per frame), 8 on 16 x 16, and the real thing: 8 mid
-    channels, 16 fast frames of 56 x 56 (14 strips of 4 rows per frame: strip borders, halo rows, first / last frame of a clip)."""
+    channels, 16 fast frames of 56 x 56 (14 strips of 4 rows per frame: strip borders, halo rows, first / last frame of a clip).
+    Both versions of the kernel: `fast_block2_kernel` (v2: two waves on a strip of 8 rows, up to five chunks of 64 positions per wave,
+    buffer instructions, compacted K rows -- what runs by default) and `fast_block_kernel` (v1: `I2V_FB_V1=1`, also the fallback for
+    planes v2 does not take); 3 clips of the real shape cross clip boundaries inside a launch."""
     monkeypatch.setenv("I2V_AUTOTUNE", "0")
+    monkeypatch.setenv("I2V_FB_V1", "1" if version == "v1" else "0")
     mt = "slowfast_resnet50"
     g = graphs.slowfast_res2(width, thw, "sf_fb", **(graphs.SLOWFAST_8X8 if thw[0] >= 16 else dict(slow_stride=4, fast_stride=1, beta_inv=4)), blocks=3)
     sd = weights.synthetic_state_dict(g, 0)
