@@ -566,6 +566,10 @@ def run_rank(args, framework_child=None):
             a2.independent_clips = True
             lanes.append((a2, (o2 + n2).contiguous(), o2, torch.cuda.Stream(device=dev)))
 
+        for a_, v_, _, _ in lanes:            # plan every stream's net now, one after the other, on a quiet device (plan-time autotuning
+            a_.plan_for(v_)                   # under the other streams' traffic picked different kernels per stream)
+        torch.cuda.synchronize()
+
         def lane_calls(lane, reps):
             a, v, o, st = lane
             torch.cuda.set_device(dev)                    # per-thread state (a new thread starts on device 0)

@@ -1510,13 +1510,15 @@ static void mark_fusable(Net& n) {
 // bytes, the caller's gradient tensor as one opaque range; attention launches are barriers -- conservatively (ranges at the planned
 // frame count; any overlap counts).  No launch changes, so every result stays bit-identical; the host simulation, which executes
 // launches synchronously in ISSUE order, really runs a hoisted launch early and so tests the analysis (tests/test_planner_hostsim.py).
-// Active for calls of at most ov_max_frames frames ($I2V_OVERLAP_MAX_FRAMES, default 32: one clip of the headline shape -- at 128
-// frames the launches fill the chip on their own and concurrency only perturbs them) and never while launches are being timed.
+// MEASURED AND NOT TAKEN (tools/overlap_probe.py, profiles/r6_overlap_probe.txt): one 32-frame clip 610 -> 589 frames/s (-3.4 %), four
+// clips 761 -> 755 -- every hoisted launch costs two event records and two cross-queue waits, and a queue that waits on another
+// queue's signal resumes tens of microseconds late, more than the idle tail it was meant to fill.  OFF by default; active only for
+// calls of at most $I2V_OVERLAP_MAX_FRAMES frames (the tests set it) and never while launches are being timed.
 static void mark_overlap(Net& n) {
     for (int k = 0; k < 2; ++k) n.ov_at[k].clear();
     for (std::vector<Launch>* L : {&n.fwd, &n.bwd}) for (Launch& l : *L) { l.ov_after = -2; l.ov_join = -1; }
     const char* e = getenv("I2V_OVERLAP_MAX_FRAMES");
-    n.ov_max_frames = e ? atoi(e) : 32;
+    n.ov_max_frames = e ? atoi(e) : 0;
     if (n.ov_max_frames <= 0) return;
     const int64_t clips = n.maxN / n.Tin();
     typedef std::pair<const char*, const char*> Range;

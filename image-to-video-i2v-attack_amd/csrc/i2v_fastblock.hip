@@ -281,19 +281,21 @@ fast_block_kernel(const I2VFastBlockParams p) {
 // its FMAs 10 -- every block of the launch is resident at once and walks the same phases in step (load-bound, issue-bound,
 // store-bound: the phases add up instead of overlapping), with one pixel per lane per stage, so that every scalar weight row feeds ONE
 // packed FMA per lane, a 64-bit address is computed for every load, and R = 4 rows per block recompute half of stage A for the halo.
-// Here a block is 2 waves on a strip of R = 8 rows (halo 10 / 8), and a wave owns up to PA = 5 chunks of 64 consecutive positions in
-// stage A and PB = 4 chunks of 64 consecutive pixels in stages B / C:
+// Here a block is FB2_NW = 4 waves on a strip of R = 8 rows (halo 10 / 8), and a wave owns up to PA = 3 chunks of 64 consecutive positions
+// in stage A and PB = 2 chunks of 64 consecutive pixels in stages B / C (the first build of this version ran 2 waves with 5 / 4 chunks:
+// 1.6 waves per SIMD, parked at s_waitcnt for half of their cycles with one group of K rows in flight -- PMC in profiles/r6_fastblock_pmc.txt):
 //   * a weight row (one s_load_dwordx8) feeds PA (PB) packed FMAs per channel pair; the rows that contribute are COMPACTED once per
 //     block (k-table rows that add an exact zero -- padding rows, taps outside the clip -- are not walked at all);
 //   * global operands move through buffer instructions: one descriptor per tensor, the lane's position as a 32-bit offset computed once
 //     per chunk, the row / channel / frame part as the scalar offset -- no per-access address arithmetic; positions outside the plane
 //     carry an out-of-range offset (loads return 0, stores are dropped);
-//   * stage A runs four K rows per step, the next four rows' operands and weights requested before this step's FMAs; the residual (or
-//     the projection's inputs) and the gate words of stage B are requested before stage B starts and arrive under it.
+//   * stage A runs four K rows per step with the operands of the next THREE steps in flight (48 loads per wave, ~3.3 waves per SIMD);
+//     the residual of the first eight output channels (or the projection's inputs) and the gate words of stage B are requested before
+//     stage B starts and arrive under it, the residual of the next eight channels under each stage-C group.
 // Same k-ordered fmaf chain per output element, same epilogue operations in the same order as the first version: bit-identical to the
 // separate launches (tests/test_gpu_video.py runs both versions against them).
 typedef float f8 __attribute__((ext_vector_type(8)));
-constexpr int FB2_PA = 5, FB2_PB = 4;
+constexpr int FB2_NW = 4, FB2_PA = 3, FB2_PB = 2;          // waves per block, chunks of 64 positions / pixels per wave
 constexpr unsigned FB2_OOB = 0x80000000u;
 template <int CM> struct fb2_row;                                    // one packed weight row of CM output channels, as scalar loads see it
 template <> struct fb2_row<8> { typedef f8 type; };
@@ -315,11 +317,35 @@ __device__ __forceinline__ void fb2_st(const float v, const __amdgpu_buffer_rsrc
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)vo, so, 0);
 }
 
+// Backward stages read the 1-bit gates of CM channels at a chunk of 64 consecutive pixels that starts at bit index `bit0` of the gate
+// rows (any alignment: stage A's chunks start a row above the strip).  Lane l < 3 CM requests word (bit0 >> 5) + l % 3 of channel l / 3 --
+// ONE load instruction per chunk, requested with the stage's operands -- and fb2_gate_bits turns it into the lane's own bits (bit c =
+// the gate of channel c at this lane's pixel): three v_readlane and a scalar funnel shift per channel.  (The first build loaded CM words
+// per lane and chunk: 24 registers in flight and spills at four waves per SIMD.)
+__device__ __forceinline__ unsigned fb2_gate_request(const __amdgpu_buffer_rsrc_t rg, const int stride, const int64_t bit0, const int CM, const int lane) {
+    const int64_t w = (bit0 >> 5) + (lane % 3);                         // (floor: bit0 may be negative in front of the first frame -- such words read as 0)
+    const unsigned vo = (lane < 3 * CM && w >= 0) ? (unsigned)((w + (int64_t)(lane / 3) * stride) * 4) : FB2_OOB;
+    return __builtin_amdgcn_raw_buffer_load_b32(rg, (int)vo, 0, 0);
+}
+template <int CM>
+__device__ __forceinline__ unsigned fb2_gate_bits(const unsigned words, const int64_t bit0, const int lane) {
+    const unsigned sh = (unsigned)FB2_RFL((int)(bit0 & 31));
+    unsigned bits = 0u;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        const unsigned long long lo = (unsigned)__builtin_amdgcn_readlane((int)words, 3 * c), mid = (unsigned)__builtin_amdgcn_readlane((int)words, 3 * c + 1),
+                                 hi = (unsigned)__builtin_amdgcn_readlane((int)words, 3 * c + 2);
+        const unsigned long long m = (((mid << 32) | lo) >> sh) | ((hi << (63u - sh)) << 1);      // bits bit0 .. bit0 + 63 of channel c's row
+        bits |= (unsigned)((m >> lane) & 1ull) << c;
+    }
+    return bits;
+}
+
 template <int CM, int MODE>       // MODE 0: forward, identity shortcut; 1: forward, projection shortcut; 2: backward
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(64 * FB2_NW) __attribute__((amdgpu_waves_per_eu(4, 4)))      // (3.5 blocks per CU at 128 frames of 56 x 56: all resident at once)
 fast_block2_kernel(const I2VFastBlockParams p) {
     constexpr bool FWD = MODE != 2, PROJ = MODE == 1;
-    constexpr int CP = CM / 2, C3 = 4 * CM, NG = C3 / 8, PA = FB2_PA, PB = FB2_PB;
+    constexpr int CP = CM / 2, C3 = 4 * CM, NG = C3 / 8, NW = FB2_NW, NT = 64 * FB2_NW, PA = FB2_PA, PB = FB2_PB;
     typedef typename fb2_row<CM>::type wrow_t;
     typedef const __attribute__((address_space(4))) wrow_t* wrowp_t;
     typedef const __attribute__((address_space(4))) f8* w8p_t;
@@ -338,7 +364,7 @@ fast_block2_kernel(const I2VFastBlockParams p) {
     const int t = (int)fastdiv(bi, p.dv_g_m, p.dv_g_s), strip = sg * p.G + ((int)bi - t * p.G);
     const int n = clip * p.T + t, r0 = strip * R;
     // ---- the K rows that contribute, compacted (wave 0: stage A's, wave 1: stage B's) ----
-    {
+    if (wave < 2) {
         const I2VFastStage& st = wave == 0 ? p.a : p.b;
         int* const tab = wave == 0 ? tabA : tabB;
         int cnt = 0;
@@ -363,31 +389,29 @@ fast_block2_kernel(const I2VFastBlockParams p) {
         }
         if (lane == 0) cnts[wave] = cnt;
     }
-    for (int i = tid; i < CM * AR * 2; i += 128) A1[(i >> 1) * AW + ((i & 1) ? AW - 1 : 0)] = 0.f;      // zero columns 0 and W + 1 of every (channel, row)
+    for (int i = tid; i < CM * AR * 2; i += NT) A1[(i >> 1) * AW + ((i & 1) ? AW - 1 : 0)] = 0.f;      // zero columns 0 and W + 1 of every (channel, row)
     __syncthreads();
     const int NPOS = AR * W, NPIX = R * W;
     const int64_t pix_n = (int64_t)n * HW;                               // bit index of the frame's first pixel in a gate row
-    // ---------------- stage A: the R + 2 rows, chunks wave, wave + 2, ... of 64 consecutive positions ----------------
+    // ---------------- stage A: the R + 2 rows, chunks wave, wave + NW, ... of 64 consecutive positions ----------------
     {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((int64_t)p.N * p.src_nstride * 4), 0x00020000);
         unsigned voff[PA]; int la[PA];
 #pragma unroll
         for (int u = 0; u < PA; ++u) {
-            const int q = (wave + 2 * u) * 64 + lane;                    // position of the (R + 2) x W grid: plane pixel (r0 - 1) W + q (rows are contiguous)
+            const int q = (wave + NW * u) * 64 + lane;                    // position of the (R + 2) x W grid: plane pixel (r0 - 1) W + q (rows are contiguous)
             const int rowq = (int)fastdiv((unsigned)q, p.dv_w_m, p.dv_w_s), colq = q - rowq * W, prow = r0 - 1 + rowq;
             const bool ok = q < NPOS && prow >= 0 && prow < H;           // (outside the plane: the 3 x 3 stage's zero padding)
             voff[u] = ok ? (unsigned)(((r0 - 1) * W + q) * 4) : FB2_OOB;
             la[u] = q < NPOS ? rowq * AW + colq + 1 : -1;
         }
-        unsigned gw[PA][FWD ? 1 : CM];                                    // backward: the gate words of this stage's tensor at the lane's positions
+        unsigned gb[PA];                                                  // backward: the gate words of this stage's tensor for the lane's chunks (fb2_gate_request), bits after the K loop
+#pragma unroll
+        for (int u = 0; u < PA; ++u) gb[u] = 0u;
         if (!FWD) {
             const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.a.gate, 0, CM * p.a.gate_stride * 4, 0x00020000);
 #pragma unroll
-            for (int u = 0; u < PA; ++u) {
-                const unsigned wo = voff[u] == FB2_OOB ? FB2_OOB : (unsigned)(((pix_n + (voff[u] >> 2)) >> 5) * 4);
-#pragma unroll
-                for (int c = 0; c < CM; ++c) gw[u][c] = __builtin_amdgcn_raw_buffer_load_b32(rg, (int)wo, c * p.a.gate_stride * 4, 0);
-            }
+            for (int u = 0; u < PA; ++u) gb[u] = fb2_gate_request(rg, p.a.gate_stride, pix_n + (int64_t)(r0 - 1) * W + (wave + NW * u) * 64, CM, lane);
         }
         f2 acc[PA][CP];
 #pragma unroll
@@ -396,37 +420,57 @@ fast_block2_kernel(const I2VFastBlockParams p) {
             for (int c = 0; c < CP; ++c) acc[u][c] = f2{0.f, 0.f};
         const int nvA = FB2_RFL(cnts[0]), ng = nvA >> 2;
         const int wstride = p.a.Cdpad;
-        float xa[4][PA], xb[4][PA];
-        int ka[4], kb[4];
-        // (the weight rows are requested where they are used: a group's 4 rows are 32 SGPRs, and a second group in flight made the
-        // allocator park whole rows in VGPR lanes -- one v_readlane per FMA in the first build)
-#define FB2_A_LOAD(I0, X, KK)                                                                                  \
+        // Four K rows per step, the operands of the next three steps in flight: a ring of four register buffers, the loop unrolled over
+        // them.  (The weight rows are requested where they are used: a second step's rows in SGPRs made the allocator park whole rows in
+        // VGPR lanes -- one v_readlane per FMA in the first build.)
+        f2 xr[4][2][PA];                                                 // (two K rows per register PAIR: v_pk_fma_f32 takes its broadcast operand from either half of an aligned pair;
+                                                                         //  one value per pair left every odd register of the ring empty -- 137 VGPRs, spills at four waves per SIMD)
+        int kr[4][4];
+#define FB2_A_LOAD(G, B)                                                                                       \
         {                                                                                                      \
-            const i2v_v4i e0 = *reinterpret_cast<const i2v_v4i*>(tabA + 2 * (I0)), e1 = *reinterpret_cast<const i2v_v4i*>(tabA + 2 * (I0) + 4);      \
+            const i2v_v4i e0 = *reinterpret_cast<const i2v_v4i*>(tabA + 8 * (G)), e1 = *reinterpret_cast<const i2v_v4i*>(tabA + 8 * (G) + 4);      \
             const int so[4] = {FB2_RFL(e0.x), FB2_RFL(e0.z), FB2_RFL(e1.x), FB2_RFL(e1.z)};                     \
-            KK[0] = FB2_RFL(e0.y); KK[1] = FB2_RFL(e0.w); KK[2] = FB2_RFL(e1.y); KK[3] = FB2_RFL(e1.w);         \
+            kr[B][0] = FB2_RFL(e0.y); kr[B][1] = FB2_RFL(e0.w); kr[B][2] = FB2_RFL(e1.y); kr[B][3] = FB2_RFL(e1.w);      \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
-                _Pragma("unroll") for (int u = 0; u < PA; ++u) X[j][u] = fb2_ld(rs, voff[u], so[j]);            \
+                _Pragma("unroll") for (int u = 0; u < PA; ++u) {                                               \
+                    const float xv = fb2_ld(rs, voff[u], so[j]);                                               \
+                    if (j & 1) xr[B][j >> 1][u].y = xv; else xr[B][j >> 1][u].x = xv;                          \
+                }                                                                                              \
         }
-#define FB2_A_FMA(X, KK)                                                                                       \
+#define FB2_A_FMA(B)                                                                                           \
         {                                                                                                      \
             wrow_t wv[4];                                                                                      \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) wv[j] = *(wrowp_t)(p.a.wp + (int64_t)KK[j] * wstride);      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) wv[j] = *(wrowp_t)(p.a.wp + (int64_t)kr[B][j] * wstride);      \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
                 _Pragma("unroll") for (int u = 0; u < PA; ++u)                                                 \
                     _Pragma("unroll") for (int c = 0; c < CP; ++c)                                             \
-                        acc[u][c] = __builtin_elementwise_fma(f2{wv[j][2 * c], wv[j][2 * c + 1]}, f2{X[j][u], X[j][u]}, acc[u][c]);      \
+                        acc[u][c] = __builtin_elementwise_fma(f2{wv[j][2 * c], wv[j][2 * c + 1]},                                 \
+                                                              (j & 1) ? f2{xr[B][j >> 1][u].y, xr[B][j >> 1][u].y} : f2{xr[B][j >> 1][u].x, xr[B][j >> 1][u].x}, acc[u][c]);      \
             asm volatile("" ::: "memory");                                                                     \
         }
-        if (ng > 0) FB2_A_LOAD(0, xa, ka)
+        if (ng > 0) FB2_A_LOAD(0, 0)
+        if (ng > 1) FB2_A_LOAD(1, 1)
+        if (ng > 2) FB2_A_LOAD(2, 2)
         int g = 0;
-        for (; g + 2 <= ng; g += 2) {
-            FB2_A_LOAD(4 * (g + 1), xb, kb)
-            FB2_A_FMA(xa, ka)
-            if (g + 2 < ng) FB2_A_LOAD(4 * (g + 2), xa, ka)
-            FB2_A_FMA(xb, kb)
+        for (; g + 7 <= ng; g += 4) {                                    // steady state: every load unconditional (the compiler's vmcnt then counts exactly)
+            FB2_A_LOAD(g + 3, 3) FB2_A_FMA(0)
+            FB2_A_LOAD(g + 4, 0) FB2_A_FMA(1)
+            FB2_A_LOAD(g + 5, 1) FB2_A_FMA(2)
+            FB2_A_LOAD(g + 6, 2) FB2_A_FMA(3)
         }
-        if (g < ng) { FB2_A_FMA(xa, ka) }
+        for (; g + 4 <= ng; g += 4) {                                    // the last steps: buffers 0 .. 2 hold steps g .. g + 2
+            if (g + 3 < ng) FB2_A_LOAD(g + 3, 3)
+            FB2_A_FMA(0)
+            if (g + 4 < ng) FB2_A_LOAD(g + 4, 0)
+            FB2_A_FMA(1)
+            if (g + 5 < ng) FB2_A_LOAD(g + 5, 1)
+            FB2_A_FMA(2)
+            if (g + 6 < ng) FB2_A_LOAD(g + 6, 2)
+            FB2_A_FMA(3)
+        }
+        if (g < ng) FB2_A_FMA(0)
+        if (g + 1 < ng) FB2_A_FMA(1)
+        if (g + 2 < ng) FB2_A_FMA(2)
         for (int i = 4 * ng; i < nvA; ++i) {                             // (a row count that is not a multiple of 4: the last rows one by one)
             const int so = FB2_RFL(tabA[2 * i]), kk = FB2_RFL(tabA[2 * i + 1]);
             const wrow_t wv = *(wrowp_t)(p.a.wp + (int64_t)kk * wstride);
@@ -442,29 +486,32 @@ fast_block2_kernel(const I2VFastBlockParams p) {
         float sh[CM];
 #pragma unroll
         for (int c = 0; c < CM; ++c) sh[c] = FWD ? ((cfptr_t)p.a.shift)[c] : 0.f;
+        if (!FWD) {
+#pragma unroll
+            for (int u = 0; u < PA; ++u) gb[u] = fb2_gate_bits<CM>(gb[u], pix_n + (int64_t)(r0 - 1) * W + (wave + NW * u) * 64, lane);
+        }
 #pragma unroll
         for (int u = 0; u < PA; ++u) {
             if (la[u] < 0) continue;
             const bool inside = voff[u] != FB2_OOB;
-            const unsigned bitn = (unsigned)((pix_n + (voff[u] >> 2)) & 31);
 #pragma unroll
             for (int c = 0; c < CM; ++c) {
                 float v = (c & 1) ? acc[u][c >> 1].y : acc[u][c >> 1].x;
                 if (FWD) v = fmaxf(v + sh[c], 0.f);
-                else if (!((gw[u][c] >> bitn) & 1u)) v = 0.f;
+                else if (!((gb[u] >> c) & 1u)) v = 0.f;
                 A1[c * CH + la[u]] = inside ? v : 0.f;
             }
         }
     }
     __syncthreads();
-    // ---------------- stages B (and C): the R rows, chunks 1 - wave, 3 - wave, ... of 64 consecutive pixels ----------------
+    // ---------------- stages B (and C): the R rows, chunks NW - 1 - wave, 2 NW - 1 - wave, ... of 64 consecutive pixels ----------------
     const int64_t bit_strip = pix_n + (int64_t)r0 * W, bit_end = bit_strip + NPIX;
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dst, 0, (int)((int64_t)p.N * p.dst_nstride * 4), 0x00020000);
     const int dst_n = (int)((int64_t)n * p.dst_nstride * 4);
     int ctr[PB]; unsigned vo[PB]; bool act[PB];
 #pragma unroll
     for (int u = 0; u < PB; ++u) {
-        const int pp = ((1 - wave) + 2 * u) * 64 + lane;
+        const int pp = ((NW - 1 - wave) + NW * u) * 64 + lane;
         act[u] = pp < NPIX;
         const int ppc = act[u] ? pp : 0;
         const int row = (int)fastdiv((unsigned)ppc, p.dv_w_m, p.dv_w_s), col = ppc - row * W;
@@ -472,38 +519,35 @@ fast_block2_kernel(const I2VFastBlockParams p) {
         vo[u] = act[u] ? (unsigned)((r0 * W + pp) * 4) : FB2_OOB;        // ... and in a channel plane of a global tensor (bytes)
     }
     // operands of the later stages, requested now: the residual (identity shortcut) or the projection's inputs; backward: gate words
-    float res[(FWD && !PROJ) ? PB : 1][(FWD && !PROJ) ? C3 : 1];
-    float xs[PROJ ? PB : 1][PROJ ? CM : 1];
-    unsigned gwb[FWD ? 1 : PB][FWD ? 1 : CM];
-    if (FWD && !PROJ) {
-        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.add0, 0, (int)((int64_t)p.N * p.add0_nstride * 4), 0x00020000);
-        const int add_n = (int)((int64_t)n * p.add0_nstride * 4);
-#pragma unroll
-        for (int c = 0; c < C3; ++c)
-#pragma unroll
-            for (int u = 0; u < PB; ++u) res[u][c] = fb2_ld(rr, vo[u], add_n + c * HW * 4);
-    }
+    float res[2][(FWD && !PROJ) ? PB : 1][(FWD && !PROJ) ? 8 : 1];       // the residual of a group of 8 output channels, two groups (this one, the next one in flight)
+    f2 xs[PROJ ? PB : 1][PROJ ? CP : 1];                                   // the projection's inputs, two channels per register pair
+    unsigned gbb[PB];                                                     // backward: bit c = the gate of channel c of stage B's tensor at the lane's pixel
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)((FWD && !PROJ) ? p.add0 : p.src), 0,
+                                                                         (int)((int64_t)p.N * ((FWD && !PROJ) ? p.add0_nstride : p.src_nstride) * 4), 0x00020000);
+    const int add_n = (int)((int64_t)n * p.add0_nstride * 4);
+#define FB2_RES_LOAD(GQ, B)                                                                                    \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                              \
+        _Pragma("unroll") for (int u = 0; u < PB; ++u) res[B][u][c] = fb2_ld(rr, vo[u], add_n + (8 * (GQ) + c) * HW * 4);
+    if (FWD && !PROJ) { FB2_RES_LOAD(0, 0) }
     if (PROJ) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((int64_t)p.N * p.src_nstride * 4), 0x00020000);
         const int src_n = (int)((int64_t)n * p.src_nstride * 4);
 #pragma unroll
         for (int k = 0; k < CM; ++k)
 #pragma unroll
-            for (int u = 0; u < PB; ++u) xs[u][k] = fb2_ld(rs, vo[u], src_n + k * HW * 4);
+            for (int u = 0; u < PB; ++u) { const float xv = fb2_ld(rs, vo[u], src_n + k * HW * 4); if (k & 1) xs[u][k >> 1].y = xv; else xs[u][k >> 1].x = xv; }
     }
+#pragma unroll
+    for (int u = 0; u < PB; ++u) gbb[u] = 0u;
     if (!FWD) {
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.b.gate, 0, CM * p.b.gate_stride * 4, 0x00020000);
 #pragma unroll
-        for (int u = 0; u < PB; ++u) {
-            const unsigned wo = act[u] ? (unsigned)(((pix_n + (vo[u] >> 2)) >> 5) * 4) : FB2_OOB;
-#pragma unroll
-            for (int c = 0; c < CM; ++c) gwb[u][c] = __builtin_amdgcn_raw_buffer_load_b32(rg, (int)wo, c * p.b.gate_stride * 4, 0);
-        }
+        for (int u = 0; u < PB; ++u) gbb[u] = fb2_gate_request(rg, p.b.gate_stride, bit_strip + ((NW - 1 - wave) + NW * u) * 64, CM, lane);
     }
     if (FWD) {                       // stage A's own gates, from the finished values in LDS (post-ReLU: > 0 is the bit)
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
-            const int64_t bit0 = bit_strip + ((1 - wave) + 2 * u) * 64;
+            const int64_t bit0 = bit_strip + ((NW - 1 - wave) + NW * u) * 64;
             if (bit0 >= bit_end) continue;                               // (wave-uniform: this chunk does not exist)
             unsigned glo = 0, ghi = 0;
 #pragma unroll
@@ -511,7 +555,7 @@ fast_block2_kernel(const I2VFastBlockParams p) {
             fb_gate_store(p.a.gate_out, p.a.gate_out_stride, CM, glo, ghi, bit0, bit_end, lane);
         }
     }
-    float a2[PB][CM];
+    f2 a2[PB][CP];                                                        // stage B's result, two channels per register pair
     {
         f2 acc[PB][CP];
 #pragma unroll
@@ -524,11 +568,11 @@ fast_block2_kernel(const I2VFastBlockParams p) {
         for (; i + 4 <= nvB; i += 4) {
             const i2v_v4i e0 = *reinterpret_cast<const i2v_v4i*>(tabB + 2 * i), e1 = *reinterpret_cast<const i2v_v4i*>(tabB + 2 * i + 4);
             const int so[4] = {FB2_RFL(e0.x), FB2_RFL(e0.z), FB2_RFL(e1.x), FB2_RFL(e1.z)}, kk[4] = {FB2_RFL(e0.y), FB2_RFL(e0.w), FB2_RFL(e1.y), FB2_RFL(e1.w)};
-            float x[4][PB]; wrow_t wv[4];
+            f2 x[2][PB]; wrow_t wv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int u = 0; u < PB; ++u) x[j][u] = A1[ctr[u] + so[j]];
+                for (int u = 0; u < PB; ++u) { const float xv = A1[ctr[u] + so[j]]; if (j & 1) x[j >> 1][u].y = xv; else x[j >> 1][u].x = xv; }
                 wv[j] = *(wrowp_t)(p.b.wp + (int64_t)kk[j] * wstride);
             }
 #pragma unroll
@@ -536,7 +580,8 @@ fast_block2_kernel(const I2VFastBlockParams p) {
 #pragma unroll
                 for (int u = 0; u < PB; ++u)
 #pragma unroll
-                    for (int c = 0; c < CP; ++c) acc[u][c] = __builtin_elementwise_fma(f2{wv[j][2 * c], wv[j][2 * c + 1]}, f2{x[j][u], x[j][u]}, acc[u][c]);
+                    for (int c = 0; c < CP; ++c)
+                        acc[u][c] = __builtin_elementwise_fma(f2{wv[j][2 * c], wv[j][2 * c + 1]}, (j & 1) ? f2{x[j >> 1][u].y, x[j >> 1][u].y} : f2{x[j >> 1][u].x, x[j >> 1][u].x}, acc[u][c]);
         }
         for (; i < nvB; ++i) {
             const int so = FB2_RFL(tabB[2 * i]), kk = FB2_RFL(tabB[2 * i + 1]);
@@ -548,15 +593,18 @@ fast_block2_kernel(const I2VFastBlockParams p) {
                 for (int c = 0; c < CP; ++c) acc[u][c] = __builtin_elementwise_fma(f2{wv[2 * c], wv[2 * c + 1]}, f2{x, x}, acc[u][c]);
             }
         }
+        if (!FWD) {
+#pragma unroll
+            for (int u = 0; u < PB; ++u) gbb[u] = fb2_gate_bits<CM>(gbb[u], bit_strip + ((NW - 1 - wave) + NW * u) * 64, lane);
+        }
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
-            const unsigned bitn = (unsigned)((pix_n + (vo[u] >> 2)) & 31);
 #pragma unroll
             for (int c = 0; c < CM; ++c) {
                 float v = (c & 1) ? acc[u][c >> 1].y : acc[u][c >> 1].x;
                 if (FWD) v = fmaxf(v + ((cfptr_t)p.b.shift)[c], 0.f);
-                else if (!((gwb[u][c] >> bitn) & 1u)) v = 0.f;
-                a2[u][c] = v;
+                else if (!((gbb[u] >> c) & 1u)) v = 0.f;
+                if (c & 1) a2[u][c >> 1].y = v; else a2[u][c >> 1].x = v;
             }
         }
     }
@@ -564,16 +612,16 @@ fast_block2_kernel(const I2VFastBlockParams p) {
 #pragma unroll
         for (int c = 0; c < CM; ++c)
 #pragma unroll
-            for (int u = 0; u < PB; ++u) fb2_st(a2[u][c], rd, vo[u], dst_n + c * HW * 4);
+            for (int u = 0; u < PB; ++u) fb2_st((c & 1) ? a2[u][c >> 1].y : a2[u][c >> 1].x, rd, vo[u], dst_n + c * HW * 4);
         return;
     }
 #pragma unroll
     for (int u = 0; u < PB; ++u) {
-        const int64_t bit0 = bit_strip + ((1 - wave) + 2 * u) * 64;
+        const int64_t bit0 = bit_strip + ((NW - 1 - wave) + NW * u) * 64;
         if (bit0 >= bit_end) continue;
         unsigned glo = 0, ghi = 0;
 #pragma unroll
-        for (int c = 0; c < CM; ++c) fb2_gate_collect(glo, ghi, c, a2[u][c] > 0.f);
+        for (int c = 0; c < CM; ++c) fb2_gate_collect(glo, ghi, c, ((c & 1) ? a2[u][c >> 1].y : a2[u][c >> 1].x) > 0.f);
         fb_gate_store(p.b.gate_out, p.b.gate_out_stride, CM, glo, ghi, bit0, bit_end, lane);
     }
     // ---------------- stage C: conv3 (pointwise over the lane's own a2: K row k is channel k) + residual + ReLU, 8 output channels at a time ----------------
@@ -594,7 +642,7 @@ fast_block2_kernel(const I2VFastBlockParams p) {
 #pragma unroll
             for (int u = 0; u < PB; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ov[u][j] = __builtin_elementwise_fma(f2{w8[2 * j], w8[2 * j + 1]}, f2{a2[u][k], a2[u][k]}, ov[u][j]);
+                for (int j = 0; j < 4; ++j) ov[u][j] = __builtin_elementwise_fma(f2{w8[2 * j], w8[2 * j + 1]}, (k & 1) ? f2{a2[u][k >> 1].y, a2[u][k >> 1].y} : f2{a2[u][k >> 1].x, a2[u][k >> 1].x}, ov[u][j]);
             if (k & 1) asm volatile("" ::: "memory");                    // (two weight rows in SGPRs at a time)
         }
         f2 rv[PB][4];
@@ -609,7 +657,7 @@ fast_block2_kernel(const I2VFastBlockParams p) {
 #pragma unroll
                 for (int u = 0; u < PB; ++u)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) rv[u][j] = __builtin_elementwise_fma(f2{w8[2 * j], w8[2 * j + 1]}, f2{xs[u][k], xs[u][k]}, rv[u][j]);
+                    for (int j = 0; j < 4; ++j) rv[u][j] = __builtin_elementwise_fma(f2{w8[2 * j], w8[2 * j + 1]}, (k & 1) ? f2{xs[u][k >> 1].y, xs[u][k >> 1].y} : f2{xs[u][k >> 1].x, xs[u][k >> 1].x}, rv[u][j]);
                 if (k & 1) asm volatile("" ::: "memory");
             }
             const f8 sd = *(w8p_t)(p.d.shift + 8 * gq);
@@ -618,10 +666,11 @@ fast_block2_kernel(const I2VFastBlockParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) rv[u][j] = f2{rv[u][j].x + sd[2 * j], rv[u][j].y + sd[2 * j + 1]};
         } else {
+            if (gq + 1 < NG) { FB2_RES_LOAD(gq + 1, (gq + 1) & 1) }
 #pragma unroll
             for (int u = 0; u < PB; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) rv[u][j] = f2{res[u][8 * gq + 2 * j], res[u][8 * gq + 2 * j + 1]};
+                for (int j = 0; j < 4; ++j) rv[u][j] = f2{res[gq & 1][u][2 * j], res[gq & 1][u][2 * j + 1]};
         }
         const f8 sc = *(w8p_t)(p.c.shift + 8 * gq);
 #pragma unroll
@@ -639,7 +688,7 @@ fast_block2_kernel(const I2VFastBlockParams p) {
     }
 #pragma unroll
     for (int u = 0; u < PB; ++u) {
-        const int64_t bit0 = bit_strip + ((1 - wave) + 2 * u) * 64;
+        const int64_t bit0 = bit_strip + ((NW - 1 - wave) + NW * u) * 64;
         if (bit0 >= bit_end) continue;
         fb_gate_store(p.c.gate_out, p.c.gate_out_stride, C3, glo[u], ghi[u], bit0, bit_end, lane);
     }
@@ -651,8 +700,8 @@ static void fb_stage(I2VFastStage& st, const I2VConvParams& q) {
     st.gate_out = q.gate_out; st.gate_out_stride = q.gate_out_stride; st.gate_out_pix0 = q.gate_out_pix0;
 }
 
-// Rows per block for the second version: the largest R (whole gate words per strip, a divisor of H) whose R + 2 rows fit 2 x FB2_PA chunks
-// of 64 positions and whose R rows fit 2 x FB2_PB chunks of 64 pixels; 0: the first version runs the block.
+// Rows per block for the second version: the largest R (whole gate words per strip, a divisor of H) whose R + 2 rows fit FB2_NW x FB2_PA chunks
+// of 64 positions and whose R rows fit FB2_NW x FB2_PB chunks of 64 pixels; 0: the first version runs the block.
 static int fb2_rows(const I2VConvParams& a, const I2VConvParams& b, const I2VConvParams* c, const I2VConvParams* d) {
     const char* const e1 = getenv("I2V_FB_V1");                       // (read per launch: the GPU test runs both versions in one process)
     if (e1 && e1[0] == '1') return 0;
@@ -661,7 +710,7 @@ static int fb2_rows(const I2VConvParams& a, const I2VConvParams& b, const I2VCon
     const int Rq = 32 / g;
     int best = 0;
     for (int R = Rq; R <= H; R += Rq)
-        if (H % R == 0 && (R + 2) * W <= 128 * FB2_PA && R * W <= 128 * FB2_PB && (size_t)a.Cd * (R + 2) * (W + 2) * 4 <= 56 * 1024) best = R;
+        if (H % R == 0 && (R + 2) * W <= 64 * FB2_NW * FB2_PA && R * W <= 64 * FB2_NW * FB2_PB && (size_t)a.Cd * (R + 2) * (W + 2) * 4 <= 56 * 1024) best = R;
     if (!best) return 0;
     auto small = [&](int64_t nstride) { return (int64_t)a.N * nstride * 4 < (1ll << 31); };       // every tensor through one buffer descriptor, offsets in 32 bits
     if (!small(a.src_nstride) || !small(c ? c->dst_nstride : b.dst_nstride) || (c && !d && !small(c->add0_nstride))) return 0;
@@ -699,7 +748,7 @@ int k_fastblock(const I2VConvParams& a, const I2VConvParams& b, const I2VConvPar
     __atomic_fetch_add(&g_stat_fastblock, 1, __ATOMIC_RELAXED);
     if (R2 > 0) {
         const size_t lds2 = (((size_t)2 * a.Kpad + 2 * b.Kpad + 4 + 3) & ~(size_t)3) * sizeof(int) + (size_t)p.CM * (R + 2) * (p.W + 2) * sizeof(float);
-#define FB2_GO(CMV, MD) hipLaunchKernelGGL((fast_block2_kernel<CMV, MD>), grid, dim3(128), lds2, (hipStream_t)s, p)
+#define FB2_GO(CMV, MD) hipLaunchKernelGGL((fast_block2_kernel<CMV, MD>), grid, dim3(64 * FB2_NW), lds2, (hipStream_t)s, p)
         if (p.CM == 8) { if (!c) FB2_GO(8, 2); else if (d) FB2_GO(8, 1); else FB2_GO(8, 0); }
         else { if (!c) FB2_GO(4, 2); else if (d) FB2_GO(4, 1); else FB2_GO(4, 0); }
 #undef FB2_GO

@@ -657,6 +657,19 @@ def run_concurrent(make_attack, items, streams=2, device=None, on_result=None):
         finally:
             if ctx is not None:
                 ctx.__exit__(None, None, None)
+    # plan every worker's net BEFORE the first stream starts (plan-time autotuning wants a quiet device): on the first item's shape
+    first = next(it, None)
+    if first is not None:
+        import itertools
+        it = itertools.chain([first], it)
+        for a in attacks_:
+            if hasattr(a, "plan_for"):
+                try:
+                    a.plan_for(*first[1])
+                except Exception:            # noqa: BLE001 -- planning here is an optimisation; the call itself will plan (or raise) in its worker
+                    pass
+        if use_cuda:
+            torch.cuda.synchronize(device)
     threads = [threading.Thread(target=worker, args=(a,)) for a in attacks_]
     for t in threads:
         t.start()
@@ -714,6 +727,25 @@ class ILAF(object):
     #: whole-tensor norms of image_attacks.py:563-567,595-613 run over all b clips together.
     independent_clips = False
 
+    def _ensure_net(self, eng, b, f, h, w):
+        N, key = b * f, (f, h, w)
+        if self._net is None or self._net_key != key or self._net.max_frames < N:
+            if self._net is not None:
+                self._net.close()
+            g = self.model.graph_for((f, h, w))
+            self._net = eng.build_net(g, self.model.state_dict_for(g), self.model.hook_tensors(g), N)
+            self._net_key = key
+        return self._net
+
+    def plan_for(self, videos, *_unused):
+        """Plan (and autotune) the native net for calls of this shape NOW, in the calling thread.  Planning times every launch on the
+        device, so it wants the device to itself: callers that run several attack objects on concurrent streams (`run_concurrent`,
+        `bench.py --workload ilaf`) plan them one after the other before the first stream starts -- nets planned while other streams
+        were already executing picked different kernels per stream from polluted timings (round 6)."""
+        if isinstance(self.model, VideoModel):
+            b, _, f, h, w = videos.shape
+            self._ensure_net(self._engine or get_engine(), b, f, h, w)
+
     def forward_independent(self, videos, ori_videos, labels, video_names):
         """K one-clip ILAF problems in ONE launch list (segmented loss kernels, `i2v_ilaf_*_seg_f32`): the convolution launches
         see K times the frames -- real occupancy instead of HIP-stream concurrency.  Native models only."""
@@ -736,14 +768,7 @@ class ILAF(object):
         independent = self.independent_clips if independent is None else independent
         nseg = b if independent else 1                                          # loss segments: one per clip, or the whole batch
         N, eps = b * f, float(self.epsilon)
-        key = (f, h, w)
-        if self._net is None or self._net_key != key or self._net.max_frames < N:
-            if self._net is not None:
-                self._net.close()
-            g = self.model.graph_for((f, h, w))
-            self._net = eng.build_net(g, self.model.state_dict_for(g), self.model.hook_tensors(g), N)
-            self._net_key = key
-        net = self._net
+        net = self._ensure_net(eng, b, f, h, w)
         L = len(net.hooks)
         x, u_adv, u_ori = (torch.empty(N, 3, h, w, **kw) for _ in range(3))
         eng.frames_from_video(ori, x, u_ori)                                     # :572 `_transform_video_ILAF(..,'back')`
