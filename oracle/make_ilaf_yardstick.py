@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE -- writes `tests/golden/ilaf_i3d_full_size_yardstick.npz`: the COST trajectories of ILAF
 (`/root/reference/image_attacks.py:534-629`, restated in `oracle/restate.run_ilaf`) on the non-local I3D at BASELINE.json configs[4]'s
 shape -- one clip of 32 x 224 x 224, the clip pair of `tests/test_gpu_video.py::test_native_ilaf_full_size_against_oracle` (seed 11) --
-run free for STEPS sign steps by the torch-module oracle in float32 AND in float64 (costs only: a few hundred bytes).
+run free for STEPS sign steps by the torch-module oracle in float32 AND in float64 (costs, and three scalars about the two final clips:
+a few hundred bytes).
 
 Why.  Sign steps move every element of the perturbation by +-0.005 whatever the size of its gradient, and the I3D's five non-local
 (softmax attention) blocks amplify the element-wise drift between any two fp32 runs: the native loop stayed within rtol 2e-4 of the
@@ -43,16 +44,24 @@ def main(steps=24):
     adv, ori = clip_pair()
     g = graphs.build_video(MT, THW)
     tm = vm.load_weights(vm.make(MT, False), weights.synthetic_state_dict(g, 0))
-    out = {}
+    out, clips = {}, {}
     for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
         t0 = time.time()
         tm.to(dt)
-        _, costs, _, _ = restate.run_ilaf(tm, vm.hook_modules(tm, MT), adv.to(dt), ori.to(dt), steps=steps)
+        clip, costs, _, _ = restate.run_ilaf(tm, vm.hook_modules(tm, MT), adv.to(dt), ori.to(dt), steps=steps)
+        clips[tag] = clip.double()
         out["costs_" + tag] = np.asarray(costs, np.float64)
         print(tag, f"{time.time() - t0:.0f} s", costs, flush=True)
         np.savez(OUT + ".partial.npz", **out)
     rel = np.abs(out["costs_f32"] - out["costs_f64"]) / np.abs(out["costs_f64"])
     print("fp32 oracle vs float64 oracle, relative cost distance per step:", np.array2string(rel, precision=2))
+    # the element-wise distance between the two runs' final clips (sign steps are chaotic element by element: DESIGN.md section 6): the
+    # yardstick the device's distance from the live fp32 oracle is held to
+    diff = (clips["f32"] - clips["f64"]).abs()
+    out["mean_abs_out_f32_f64"] = float(diff.mean())
+    out["frac_differing_f32_f64"] = float((diff > 0).double().mean())
+    out["mean_abs_pert_f64"] = float((clips["f64"] - adv.double()).abs().mean())
+    print("final clips, fp32 oracle vs float64 oracle: mean|diff|", out["mean_abs_out_f32_f64"], "elements differing", out["frac_differing_f32_f64"])
     np.savez(OUT, model_type=MT, seed=SEED, steps=steps, step_size=0.005, threads=torch.get_num_threads(), **out)
     os.remove(OUT + ".partial.npz")
     print("wrote", OUT, os.path.getsize(OUT), "bytes")

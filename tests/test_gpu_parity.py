@@ -172,7 +172,10 @@ def write_hook_grads(net, feats, hg, N):
 
 
 @pytest.mark.parametrize("model,depths,hw", CASES)
-def test_net_forward_backward_match_oracle(eng, model, depths, hw):
+def test_net_forward_backward_match_oracle(eng, model, depths, hw, monkeypatch):
+    # (every activation is read back: the tiny ResNet's 4- / 8-channel bottlenecks qualify for the fused fast-pathway block, whose
+    #  intermediates are never stored -- planned here as separate launches; the fused block has its own tests in test_gpu_video.py)
+    monkeypatch.setenv("I2V_FASTBLOCK", "0")
     g = graphs.build_tiny(model, (hw, hw))
     sd = weights.synthetic_state_dict(g, 3)
     hooks = [g.hooks[d] for d in depths]

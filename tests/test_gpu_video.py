@@ -262,7 +262,15 @@ def test_native_ilaf_full_size_against_oracle(eng, mt):
         assert np.all(d_dev <= 1.25 * envelope + 2e-4), (d_dev, envelope)
         assert d_dev.max() <= 1.25 * max(d_fix.max(), d_live.max()) + 2e-4
     assert abs(atk.last_costs[0] + 1.5 * len(graphs.video_hooks(g, mt))) < 1e-4     # every hooked layer: -(0.5 + 1) at the start
-    assert float((out - ref).abs().mean()) < 0.02                                   # (+-eps = 0.27 in these units bounds it; equal clips would give 0)
+    if mt == "slowfast_resnet50":
+        assert float((out - ref).abs().mean()) < 0.02                               # (+-eps = 0.27 in these units bounds it; equal clips would give 0)
+    else:
+        # the non-local I3D after 24 sign steps: element by element the two fp32 runs are as far apart as sign steps through softmax blocks
+        # put ANY two runs -- the yardstick file holds the fp32 oracle's own distance from the float64 oracle's final clip; two fp32 runs
+        # are each one such distance from exact arithmetic, so up to two from each other (x 1.25, the margin of the other yardsticks)
+        yard = float(z["mean_abs_out_f32_f64"])
+        print(f"    mean|out - ref| {float((out - ref).abs().mean()):.4f} against the yardstick (fp32 oracle vs float64 oracle) {yard:.4f}")
+        assert 0 < yard < 0.27 and float((out - ref).abs().mean()) <= 2 * 1.25 * yard
     # ---- teacher-forced step from the native state (float64 oracle)
     m_t = atk._modifier.clone()                                                  # (f, 3, h, w), frame-major
     one = sign_attacks.ILAF(model, mt, step_size=0.005, steps=1)

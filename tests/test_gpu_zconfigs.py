@@ -227,5 +227,11 @@ def test_aens_full_size_backbones_against_oracle(eng):
     np.testing.assert_allclose(w, np.stack(ref["weights"]), rtol=1e-4)
     np.testing.assert_allclose(atk.coeffs.cpu().numpy(), ref["coeffs"].float().numpy(), rtol=1e-4)
     assert float(np.abs(w[-1] - 1 / 8).max()) > 1e-3            # the weights did move off uniform (oracle: 0.1227 ... 0.1259): the comparison is not vacuous
-    assert (adv.cpu() - ref["adv"].float()).abs().mean() < 5e-3
+    # the perturbed PIXELS: Adam's first steps move every pixel by +-lr whatever the size of its gradient, so pixels whose gradient is zero
+    # to rounding end up 2 lr apart in any two correct implementations (rung 4) -- the well-conditioned statistic is the
+    # mean size of the perturbation (within 1 %); the element-wise distance is held to a quarter of ONE step (0.02 / 0.225 = 0.089 in
+    # normalised units; measured 0.012 after the 5 steps)
+    d_dev, d_ref = (adv.cpu() - vid).abs().mean(), (ref["adv"].float() - vid).abs().mean()
+    assert abs(float(d_dev / d_ref) - 1) < 0.01, (float(d_dev), float(d_ref))
+    assert float((adv.cpu() - ref["adv"].float()).abs().mean()) < 0.25 * LR / 0.225
     check_box(adv.cpu(), u8)

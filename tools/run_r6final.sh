@@ -20,6 +20,7 @@ I2V_FUSE_DEBUG=1 python bench.py --workload ilaf --steps 3 --warmup 1 2> $O/ilaf
 grep "i2v fastblock" $O/ilaf_slowfast.err | sort | uniq > $O/profiles/r6_fastblock_autotune.txt
 python bench.py --workload ilaf --white_model i3d_resnet50 --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench_ilaf_i3d.json
 I2V_FASTBLOCK=0 python bench.py --workload ilaf --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench_ilaf_slowfast_no_fastblock.json
+for st in 1 2 4; do python bench.py --workload ilaf --streams $st --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench_ilaf_slowfast_streams$st.json; done
 I2V_CLIP_LANES=1 I2V_TIMING_DUMP=/tmp/d1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split-bf16 --no-framework-baseline > /dev/null 2>&1; python tools/timing_dump_agg.py /tmp/d1 40 > $O/layer_breakdown.txt
 I2V_TIMING_DUMP=/tmp/d2 python bench.py --workload ilaf --streams 1 --steps 1 --warmup 1 > /dev/null 2>&1; python tools/timing_dump_agg.py /tmp/d2 40 > $O/ilaf_breakdown_slowfast.txt
 du -sh gpurun_out
