@@ -363,6 +363,7 @@ fast_block2_kernel(const I2VFastBlockParams p) {
     const int clip = (int)fastdiv(un, p.dv_s_m, p.dv_s_s), sg = (int)un - clip * p.S;
     const int t = (int)fastdiv(bi, p.dv_g_m, p.dv_g_s), strip = sg * p.G + ((int)bi - t * p.G);
     const int n = clip * p.T + t, r0 = strip * R;
+    if (p.delay > 0 && (bi & 1u)) { for (int d = 0; d < p.delay; ++d) __builtin_amdgcn_s_sleep(127); }      // (probe: de-phase every other block)
     // ---- the K rows that contribute, compacted (wave 0: stage A's, wave 1: stage B's) ----
     if (wave < 2) {
         const I2VFastStage& st = wave == 0 ? p.a : p.b;
@@ -747,6 +748,7 @@ int k_fastblock(const I2VConvParams& a, const I2VConvParams& b, const I2VConvPar
     if ((int64_t)p.T * p.src_nstride >= (1ll << 30)) { snprintf(g_be_err, sizeof g_be_err, "fast-block launch: a clip's frames span more than 2^30 elements"); g_be_has_err = true; return 1; }
     __atomic_fetch_add(&g_stat_fastblock, 1, __ATOMIC_RELAXED);
     if (R2 > 0) {
+        { const char* e = getenv("I2V_FB_DELAY"); p.delay = e ? atoi(e) : 0; }
         const size_t lds2 = (((size_t)2 * a.Kpad + 2 * b.Kpad + 4 + 3) & ~(size_t)3) * sizeof(int) + (size_t)p.CM * (R + 2) * (p.W + 2) * sizeof(float);
 #define FB2_GO(CMV, MD) hipLaunchKernelGGL((fast_block2_kernel<CMV, MD>), grid, dim3(64 * FB2_NW), lds2, (hipStream_t)s, p)
         if (p.CM == 8) { if (!c) FB2_GO(8, 2); else if (d) FB2_GO(8, 1); else FB2_GO(8, 0); }

@@ -120,6 +120,7 @@ struct I2VFastBlockParams {
     uint32_t dv_w_m, dv_w_s, dv_hw_m, dv_hw_s;               // exact division by W and by H W
     int32_t U, S, G, BU;                                     // XCD mapping: units (= clips x S strip groups of G strips), blocks per unit (T G)
     uint32_t dv_bu_m, dv_bu_s, dv_s_m, dv_s_s, dv_g_m, dv_g_s;
+    int32_t delay;                                           // probe (I2V_FB_DELAY): every other block sleeps this many x 127 x 64 clocks first
 };
 
 struct I2VPoolParams {

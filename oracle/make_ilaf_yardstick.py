@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE -- writes `tests/golden/ilaf_i3d_full_size_yardstick.npz`: the COST trajectories of ILAF
 (`/root/reference/image_attacks.py:534-629`, restated in `oracle/restate.run_ilaf`) on the non-local I3D at BASELINE.json configs[4]'s
 shape -- one clip of 32 x 224 x 224, the clip pair of `tests/test_gpu_video.py::test_native_ilaf_full_size_against_oracle` (seed 11) --
-run free for STEPS sign steps by the torch-module oracle in float32 AND in float64 (costs, and three scalars about the two final clips:
+run free for STEPS sign steps by the torch-module oracle in float32 AND in float64 (costs, and two scalars about the two final clips:
 a few hundred bytes).
 
 Why.  Sign steps move every element of the perturbation by +-0.005 whatever the size of its gradient, and the I3D's five non-local
@@ -11,7 +11,7 @@ yardstick: the distance of the reference arithmetic's OWN fp32 run from exact ar
 1.25 x that distance from the float64 run (`test_native_ilaf_full_size_against_oracle[i3d_resnet50]`), for STEPS >= 20 steps; if it
 drifted faster than the oracle does, the attention path would have a bug.
 
-    python -m oracle.make_ilaf_yardstick [steps]          (from the repo root; float64 run: about 1.5 min per step on 8 cores)
+    python -m oracle.make_ilaf_yardstick [steps]          (from the repo root; about 15 min on 8 cores)
 """
 import os
 import sys
@@ -60,7 +60,6 @@ def main(steps=24):
     diff = (clips["f32"] - clips["f64"]).abs()
     out["mean_abs_out_f32_f64"] = float(diff.mean())
     out["frac_differing_f32_f64"] = float((diff > 0).double().mean())
-    out["mean_abs_pert_f64"] = float((clips["f64"] - adv.double()).abs().mean())
     print("final clips, fp32 oracle vs float64 oracle: mean|diff|", out["mean_abs_out_f32_f64"], "elements differing", out["frac_differing_f32_f64"])
     np.savez(OUT, model_type=MT, seed=SEED, steps=steps, step_size=0.005, threads=torch.get_num_threads(), **out)
     os.remove(OUT + ".partial.npz")
