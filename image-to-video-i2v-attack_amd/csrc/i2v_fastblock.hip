@@ -289,9 +289,15 @@ fast_block_kernel(const I2VFastBlockParams p) {
 //   * global operands move through buffer instructions: one descriptor per tensor, the lane's position as a 32-bit offset computed once
 //     per chunk, the row / channel / frame part as the scalar offset -- no per-access address arithmetic; positions outside the plane
 //     carry an out-of-range offset (loads return 0, stores are dropped);
-//   * stage A runs four K rows per step with the operands of the next THREE steps in flight (48 loads per wave, ~3.3 waves per SIMD);
-//     the residual of the first eight output channels (or the projection's inputs) and the gate words of stage B are requested before
+//   * a block is a CHAIN of round trips (tools/fb_phase_probe.py, profiles/r6_fastblock_phase_probe.txt: at 64 frames a block's stages cost
+//     6 + 8 + 10 + 10 us one after the other, and de-phasing the blocks only adds the delay): the compacted table therefore lives in
+//     REGISTERS (an entry is a v_readlane away), weight rows are requested EIGHT at a time (one scalar round trip, ~0.35 us under this
+//     load, for 64 SGPRs -- behind a scheduling barrier: left alone the scheduler spreads them between the FMAs), stage A's operands run
+//     in steps of four K rows with three steps in flight (36-48 loads per wave, ~3.3 waves per SIMD);
+//   * the residual of the first eight output channels (or the projection's inputs) and the gate words of stage B are requested before
 //     stage B starts and arrive under it, the residual of the next eight channels under each stage-C group.
+// At 128 frames the block is then HBM-bound in its own way: 13 us of chain + the marginal 16.4 us per 64 frames = 4.7 TB/s over the
+// 153 MB it moves (x in, the residual read again 20 us later -- evicted from the 4 MB L2 by then --, the output).
 // Same k-ordered fmaf chain per output element, same epilogue operations in the same order as the first version: bit-identical to the
 // separate launches (tests/test_gpu_video.py runs both versions against them).
 typedef float f8 __attribute__((ext_vector_type(8)));
@@ -363,7 +369,12 @@ fast_block2_kernel(const I2VFastBlockParams p) {
     const int clip = (int)fastdiv(un, p.dv_s_m, p.dv_s_s), sg = (int)un - clip * p.S;
     const int t = (int)fastdiv(bi, p.dv_g_m, p.dv_g_s), strip = sg * p.G + ((int)bi - t * p.G);
     const int n = clip * p.T + t, r0 = strip * R;
-    if (p.delay > 0 && (bi & 1u)) { for (int d = 0; d < p.delay; ++d) __builtin_amdgcn_s_sleep(127); }      // (probe: de-phase every other block)
+#ifdef I2V_EXPERIMENTAL          // probe hooks (tools/fb_phase_probe.py, experimental build only): I2V_FB_DELAY low byte = every other block sleeps first; bits 8 .. 10 = a stage's rows skipped
+    const int probe = p.delay;
+    if ((probe & 0xff) > 0 && (bi & 1u)) { for (int d = 0; d < (probe & 0xff); ++d) __builtin_amdgcn_s_sleep(127); }
+#else
+    constexpr int probe = 0;
+#endif
     // ---- the K rows that contribute, compacted (wave 0: stage A's, wave 1: stage B's) ----
     if (wave < 2) {
         const I2VFastStage& st = wave == 0 ? p.a : p.b;
@@ -419,61 +430,70 @@ fast_block2_kernel(const I2VFastBlockParams p) {
         for (int u = 0; u < PA; ++u)
 #pragma unroll
             for (int c = 0; c < CP; ++c) acc[u][c] = f2{0.f, 0.f};
-        const int nvA = FB2_RFL(cnts[0]), ng = nvA >> 2;
+        const int nvA = (probe & 0x100) ? 0 : FB2_RFL(cnts[0]);
         const int wstride = p.a.Cdpad;
-        // Four K rows per step, the operands of the next three steps in flight: a ring of four register buffers, the loop unrolled over
-        // them.  (The weight rows are requested where they are used: a second step's rows in SGPRs made the allocator park whole rows in
-        // VGPR lanes -- one v_readlane per FMA in the first build.)
-        f2 xr[4][2][PA];                                                 // (two K rows per register PAIR: v_pk_fma_f32 takes its broadcast operand from either half of an aligned pair;
-                                                                         //  one value per pair left every odd register of the ring empty -- 137 VGPRs, spills at four waves per SIMD)
-        int kr[4][4];
+        // the compacted table in registers: lane l holds rows l and 64 + l (a stage has at most 128 rows: fb2_rows)
+        const int tS0 = tabA[2 * lane], tK0 = tabA[2 * lane + 1], tS1 = tabA[2 * (64 + lane)], tK1 = tabA[2 * (64 + lane) + 1];
+        // Operands in steps of FOUR K rows, three steps in flight (a ring of four register buffers: 36-48 loads per wave); weight rows in
+        // batches of EIGHT (two steps), one scalar round trip each.  (Eight-row operand steps one ahead waited a memory round trip per
+        // step -- 11.8 us of a block's 32 at 64 frames; three eight-row steps in flight do not fit 128 registers.)
+        f2 xr[4][2][PA];                                                 // (two K rows per register PAIR: v_pk_fma_f32 takes its broadcast operand from either half of an aligned pair)
+        wrow_t wv[8];
 #define FB2_A_LOAD(G, B)                                                                                       \
         {                                                                                                      \
-            const i2v_v4i e0 = *reinterpret_cast<const i2v_v4i*>(tabA + 8 * (G)), e1 = *reinterpret_cast<const i2v_v4i*>(tabA + 8 * (G) + 4);      \
-            const int so[4] = {FB2_RFL(e0.x), FB2_RFL(e0.z), FB2_RFL(e1.x), FB2_RFL(e1.z)};                     \
-            kr[B][0] = FB2_RFL(e0.y); kr[B][1] = FB2_RFL(e0.w); kr[B][2] = FB2_RFL(e1.y); kr[B][3] = FB2_RFL(e1.w);      \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+            const int r0_ = 4 * (G);                                                                           \
+            const int tv = r0_ >= 64 ? tS1 : tS0;                                                              \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
+                const int so = __builtin_amdgcn_readlane(tv, (r0_ + j) & 63);                                  \
                 _Pragma("unroll") for (int u = 0; u < PA; ++u) {                                               \
-                    const float xv = fb2_ld(rs, voff[u], so[j]);                                               \
+                    const float xv = fb2_ld(rs, voff[u], so);                                                  \
                     if (j & 1) xr[B][j >> 1][u].y = xv; else xr[B][j >> 1][u].x = xv;                          \
                 }                                                                                              \
+            }                                                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
         }
-#define FB2_A_FMA(B)                                                                                           \
+#define FB2_A_W(G, NR)      /* the weight rows of steps G and G + 1 (NR = 8), or of step G alone (NR = 4): requested back to back, ONE round trip */ \
         {                                                                                                      \
-            wrow_t wv[4];                                                                                      \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) wv[j] = *(wrowp_t)(p.a.wp + (int64_t)kr[B][j] * wstride);      \
+            const int r0_ = 4 * (G);                                                                           \
+            const int tv = r0_ >= 64 ? tK1 : tK0;                                                              \
+            _Pragma("unroll") for (int j = 0; j < (NR); ++j)                                                   \
+                wv[j] = *(wrowp_t)(p.a.wp + (int64_t)__builtin_amdgcn_readlane(tv, (r0_ + j) & 63) * wstride);      \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+        }
+#define FB2_A_FMA(B, J0)                                                                                       \
+        {                                                                                                      \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
                 _Pragma("unroll") for (int u = 0; u < PA; ++u)                                                 \
                     _Pragma("unroll") for (int c = 0; c < CP; ++c)                                             \
-                        acc[u][c] = __builtin_elementwise_fma(f2{wv[j][2 * c], wv[j][2 * c + 1]},                                 \
+                        acc[u][c] = __builtin_elementwise_fma(f2{wv[(J0) + j][2 * c], wv[(J0) + j][2 * c + 1]},                   \
                                                               (j & 1) ? f2{xr[B][j >> 1][u].y, xr[B][j >> 1][u].y} : f2{xr[B][j >> 1][u].x, xr[B][j >> 1][u].x}, acc[u][c]);      \
-            asm volatile("" ::: "memory");                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
         }
+        const int ng = nvA >> 2;
         if (ng > 0) FB2_A_LOAD(0, 0)
         if (ng > 1) FB2_A_LOAD(1, 1)
         if (ng > 2) FB2_A_LOAD(2, 2)
         int g = 0;
         for (; g + 7 <= ng; g += 4) {                                    // steady state: every load unconditional (the compiler's vmcnt then counts exactly)
-            FB2_A_LOAD(g + 3, 3) FB2_A_FMA(0)
-            FB2_A_LOAD(g + 4, 0) FB2_A_FMA(1)
-            FB2_A_LOAD(g + 5, 1) FB2_A_FMA(2)
-            FB2_A_LOAD(g + 6, 2) FB2_A_FMA(3)
+            FB2_A_LOAD(g + 3, 3) FB2_A_W(g, 8) FB2_A_FMA(0, 0)
+            FB2_A_LOAD(g + 4, 0) FB2_A_FMA(1, 4)
+            FB2_A_LOAD(g + 5, 1) FB2_A_W(g + 2, 8) FB2_A_FMA(2, 0)
+            FB2_A_LOAD(g + 6, 2) FB2_A_FMA(3, 4)
         }
         for (; g + 4 <= ng; g += 4) {                                    // the last steps: buffers 0 .. 2 hold steps g .. g + 2
             if (g + 3 < ng) FB2_A_LOAD(g + 3, 3)
-            FB2_A_FMA(0)
+            FB2_A_W(g, 8) FB2_A_FMA(0, 0)
             if (g + 4 < ng) FB2_A_LOAD(g + 4, 0)
-            FB2_A_FMA(1)
+            FB2_A_FMA(1, 4)
             if (g + 5 < ng) FB2_A_LOAD(g + 5, 1)
-            FB2_A_FMA(2)
+            FB2_A_W(g + 2, 8) FB2_A_FMA(2, 0)
             if (g + 6 < ng) FB2_A_LOAD(g + 6, 2)
-            FB2_A_FMA(3)
+            FB2_A_FMA(3, 4)
         }
-        if (g < ng) FB2_A_FMA(0)
-        if (g + 1 < ng) FB2_A_FMA(1)
-        if (g + 2 < ng) FB2_A_FMA(2)
+        if (g + 2 <= ng) { FB2_A_W(g, 8) FB2_A_FMA(0, 0) FB2_A_FMA(1, 4) if (g + 2 < ng) { FB2_A_W(g + 2, 4) FB2_A_FMA(2, 0) } }
+        else if (g < ng) { FB2_A_W(g, 4) FB2_A_FMA(0, 0) }
         for (int i = 4 * ng; i < nvA; ++i) {                             // (a row count that is not a multiple of 4: the last rows one by one)
-            const int so = FB2_RFL(tabA[2 * i]), kk = FB2_RFL(tabA[2 * i + 1]);
+            const int so = __builtin_amdgcn_readlane(i >= 64 ? tS1 : tS0, i & 63), kk = __builtin_amdgcn_readlane(i >= 64 ? tK1 : tK0, i & 63);
             const wrow_t wv = *(wrowp_t)(p.a.wp + (int64_t)kk * wstride);
 #pragma unroll
             for (int u = 0; u < PA; ++u) {
@@ -483,6 +503,7 @@ fast_block2_kernel(const I2VFastBlockParams p) {
             }
         }
 #undef FB2_A_LOAD
+#undef FB2_A_W
 #undef FB2_A_FMA
         float sh[CM];
 #pragma unroll
@@ -563,29 +584,32 @@ fast_block2_kernel(const I2VFastBlockParams p) {
         for (int u = 0; u < PB; ++u)
 #pragma unroll
             for (int c = 0; c < CP; ++c) acc[u][c] = f2{0.f, 0.f};
-        const int nvB = FB2_RFL(cnts[1]);
+        const int nvB = (probe & 0x200) ? 0 : FB2_RFL(cnts[1]);
         const int wstride = p.b.Cdpad;
+        const int tS0 = tabB[2 * lane], tK0 = tabB[2 * lane + 1], tS1 = tabB[2 * (64 + lane)], tK1 = tabB[2 * (64 + lane) + 1];      // the table in registers, as in stage A
         int i = 0;
-        for (; i + 4 <= nvB; i += 4) {
-            const i2v_v4i e0 = *reinterpret_cast<const i2v_v4i*>(tabB + 2 * i), e1 = *reinterpret_cast<const i2v_v4i*>(tabB + 2 * i + 4);
-            const int so[4] = {FB2_RFL(e0.x), FB2_RFL(e0.z), FB2_RFL(e1.x), FB2_RFL(e1.z)}, kk[4] = {FB2_RFL(e0.y), FB2_RFL(e0.w), FB2_RFL(e1.y), FB2_RFL(e1.w)};
-            f2 x[2][PB]; wrow_t wv[4];
+        for (; i + 8 <= nvB; i += 8) {                                   // eight K rows per step: operands (LDS) and weight rows (one scalar round trip) requested together
+            const int tvs = i >= 64 ? tS1 : tS0, tvk = i >= 64 ? tK1 : tK0;
+            f2 x[4][PB]; wrow_t wv[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 8; ++j) {
+                const int so = __builtin_amdgcn_readlane(tvs, (i + j) & 63);
 #pragma unroll
-                for (int u = 0; u < PB; ++u) { const float xv = A1[ctr[u] + so[j]]; if (j & 1) x[j >> 1][u].y = xv; else x[j >> 1][u].x = xv; }
-                wv[j] = *(wrowp_t)(p.b.wp + (int64_t)kk[j] * wstride);
+                for (int u = 0; u < PB; ++u) { const float xv = A1[ctr[u] + so]; if (j & 1) x[j >> 1][u].y = xv; else x[j >> 1][u].x = xv; }
+                wv[j] = *(wrowp_t)(p.b.wp + (int64_t)__builtin_amdgcn_readlane(tvk, (i + j) & 63) * wstride);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int u = 0; u < PB; ++u)
 #pragma unroll
                     for (int c = 0; c < CP; ++c)
                         acc[u][c] = __builtin_elementwise_fma(f2{wv[j][2 * c], wv[j][2 * c + 1]}, (j & 1) ? f2{x[j >> 1][u].y, x[j >> 1][u].y} : f2{x[j >> 1][u].x, x[j >> 1][u].x}, acc[u][c]);
+            asm volatile("" ::: "memory");
         }
         for (; i < nvB; ++i) {
-            const int so = FB2_RFL(tabB[2 * i]), kk = FB2_RFL(tabB[2 * i + 1]);
+            const int so = __builtin_amdgcn_readlane(i >= 64 ? tS1 : tS0, i & 63), kk = __builtin_amdgcn_readlane(i >= 64 ? tK1 : tK0, i & 63);
             const wrow_t wv = *(wrowp_t)(p.b.wp + (int64_t)kk * wstride);
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
@@ -625,6 +649,7 @@ fast_block2_kernel(const I2VFastBlockParams p) {
         for (int c = 0; c < CM; ++c) fb2_gate_collect(glo, ghi, c, ((c & 1) ? a2[u][c >> 1].y : a2[u][c >> 1].x) > 0.f);
         fb_gate_store(p.b.gate_out, p.b.gate_out_stride, CM, glo, ghi, bit0, bit_end, lane);
     }
+    if (probe & 0x400) return;
     // ---------------- stage C: conv3 (pointwise over the lane's own a2: K row k is channel k) + residual + ReLU, 8 output channels at a time ----------------
     unsigned glo[PB], ghi[PB];
 #pragma unroll
@@ -637,14 +662,19 @@ fast_block2_kernel(const I2VFastBlockParams p) {
         for (int u = 0; u < PB; ++u)
 #pragma unroll
             for (int j = 0; j < 4; ++j) ov[u][j] = f2{0.f, 0.f};
+        {
+            f8 w8[CM];                                                   // all CM rows of this group's weights: ONE scalar round trip
 #pragma unroll
-        for (int k = 0; k < CM; ++k) {
-            const f8 w8 = *(w8p_t)(p.c.wp + (int64_t)k * p.c.Cdpad + 8 * gq);
+            for (int k = 0; k < CM; ++k) w8[k] = *(w8p_t)(p.c.wp + (int64_t)k * p.c.Cdpad + 8 * gq);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < PB; ++u)
+            for (int k = 0; k < CM; ++k)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ov[u][j] = __builtin_elementwise_fma(f2{w8[2 * j], w8[2 * j + 1]}, (k & 1) ? f2{a2[u][k >> 1].y, a2[u][k >> 1].y} : f2{a2[u][k >> 1].x, a2[u][k >> 1].x}, ov[u][j]);
-            if (k & 1) asm volatile("" ::: "memory");                    // (two weight rows in SGPRs at a time)
+                for (int u = 0; u < PB; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        ov[u][j] = __builtin_elementwise_fma(f2{w8[k][2 * j], w8[k][2 * j + 1]}, (k & 1) ? f2{a2[u][k >> 1].y, a2[u][k >> 1].y} : f2{a2[u][k >> 1].x, a2[u][k >> 1].x}, ov[u][j]);
+            asm volatile("" ::: "memory");
         }
         f2 rv[PB][4];
         if (PROJ) {                  // projection shortcut: pointwise over x[t] (K row k is channel k), + its shift: the value the separate launch stores
@@ -652,14 +682,19 @@ fast_block2_kernel(const I2VFastBlockParams p) {
             for (int u = 0; u < PB; ++u)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) rv[u][j] = f2{0.f, 0.f};
+            {
+                f8 w8[CM];
 #pragma unroll
-            for (int k = 0; k < CM; ++k) {
-                const f8 w8 = *(w8p_t)(p.d.wp + (int64_t)k * p.d.Cdpad + 8 * gq);
+                for (int k = 0; k < CM; ++k) w8[k] = *(w8p_t)(p.d.wp + (int64_t)k * p.d.Cdpad + 8 * gq);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < PB; ++u)
+                for (int k = 0; k < CM; ++k)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) rv[u][j] = __builtin_elementwise_fma(f2{w8[2 * j], w8[2 * j + 1]}, (k & 1) ? f2{xs[u][k >> 1].y, xs[u][k >> 1].y} : f2{xs[u][k >> 1].x, xs[u][k >> 1].x}, rv[u][j]);
-                if (k & 1) asm volatile("" ::: "memory");
+                    for (int u = 0; u < PB; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            rv[u][j] = __builtin_elementwise_fma(f2{w8[k][2 * j], w8[k][2 * j + 1]}, (k & 1) ? f2{xs[u][k >> 1].y, xs[u][k >> 1].y} : f2{xs[u][k >> 1].x, xs[u][k >> 1].x}, rv[u][j]);
+                asm volatile("" ::: "memory");
             }
             const f8 sd = *(w8p_t)(p.d.shift + 8 * gq);
 #pragma unroll
@@ -716,6 +751,7 @@ static int fb2_rows(const I2VConvParams& a, const I2VConvParams& b, const I2VCon
     auto small = [&](int64_t nstride) { return (int64_t)a.N * nstride * 4 < (1ll << 31); };       // every tensor through one buffer descriptor, offsets in 32 bits
     if (!small(a.src_nstride) || !small(c ? c->dst_nstride : b.dst_nstride) || (c && !d && !small(c->add0_nstride))) return 0;
     if (c && (c->Cd % 8 != 0 || c->Cdpad < c->Cd || (d && d->Cdpad < d->Cd))) return 0;
+    if (a.Kpad > 128 || b.Kpad > 128) return 0;                       // (a stage's compacted table lives in two registers per lane)
     return best;
 }
 
