@@ -23,7 +23,7 @@ extern thread_local bool g_be_has_err;
 int hip_fail(hipError_t e, const char* what);
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x); } while (0)
 #define LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return hip_fail(e_, name); } while (0)
-extern long long g_stat_conv, g_stat_pws, g_stat_bf3, g_stat_igh, g_stat_sth, g_stat_fastblock, g_stat_vfma;      // (relaxed counters: diagnostics only)
+extern long long g_stat_conv, g_stat_pws, g_stat_bf3, g_stat_igh, g_stat_sth, g_stat_fastblock, g_stat_vfma, g_stat_igv;      // (relaxed counters: diagnostics only)
 
 // n / d for 0 <= n < 2^31 with the precomputed (m, s) of fastdiv_magic: exact
 __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned m, unsigned s) {
@@ -110,6 +110,8 @@ int launch_conv_cfg4(const I2VConvParams& p, hipStream_t s);      //  32 x 256  
 int launch_conv_cfg5(const I2VConvParams& p, hipStream_t s);      //  16 x 256 on 16x16x4 fragments   i2v_conv_cfg5.hip
 bool conv_ighalo_ok(const I2VConvParams& p);                      // the 3-channel stems on 2-D halo tiles   i2v_conv_stems.hip
 int launch_conv_ighalo(const I2VConvParams& p, hipStream_t s);
+bool conv_igvfma_ok(const I2VConvParams& p);                      // the quad-row image gradient of a narrow stem on packed-fp32 vector FMAs
+int launch_conv_igvfma(const I2VConvParams& p, hipStream_t s);
 bool conv_stemhalo_ok(const I2VConvParams& p);
 int launch_conv_stemhalo(const I2VConvParams& p, hipStream_t s);
 bool conv_vfma_ok(const I2VConvParams& p);                        // one narrow launch on packed-fp32 vector FMAs   i2v_fastblock.hip

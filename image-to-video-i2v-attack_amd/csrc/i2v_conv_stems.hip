@@ -596,3 +596,222 @@ int launch_conv_stem64(const I2VConvParams& p, hipStream_t s) {
     return 0;
 }
 #endif
+
+// =============================================================================================
+// Image gradient of a NARROW stem on packed-fp32 vector FMAs (round 6, autotuner bit 12)
+// =============================================================================================
+// SlowFast's fast stem (5 x 7 x 7 / (1, 2, 2), 3 -> 8 channels) is 13 % of an ILAF step in its input gradient alone, at 56 TFLOP/s: the
+// class-packed launch fills 12 of a 16-row fragment, 49 of its 64 tap slots carry weights, and a fp32 MFMA runs at the fp32 VECTOR rate
+// anyway (64 FLOP/clk/SIMD) -- so, as in the fused fast-pathway block (i2v_fastblock.hip), nothing is lost by leaving the matrix
+// pipe, and the empty rows and tap slots can then be skipped.  Quad-row packing (pack_img: K order (channel, frame tap, row tap, column
+// tap x 4), one 4 x 4 tap window per (channel, frame tap) PLANE of dz; 12 class rows = 2 x 2 positions x 3 input channels):
+//   * a wave takes a tile of 64 columns x PV = 2 rows of the class grid; a lane owns one column, i.e. 2 grid positions = 2 x (2 x 2
+//     pixels x 3 channels) = 24 accumulators in 12 register pairs;
+//   * per plane it loads the 5 rows x 4 column shifts its positions' windows cover (20 coalesced loads through a buffer descriptor:
+//     column shifts outside the plane carry an out-of-range offset per lane, rows outside it are skipped as a whole -- the row of a
+//     load is uniform over the wave), the next plane's loads in flight under this plane's FMAs;
+//   * and walks the plane's 16 K rows in order: weight row k (12 floats, one s_load_dwordx16; four rows = one row tap per round trip)
+//     times the window value, packed FMAs into the six class-row pairs -- except the pairs whose two weights are STRUCTURALLY zero for
+//     that tap (a stride-2 7 x 7 kernel: the last row tap belongs to the odd row class only, the last column tap to the odd column
+//     class: 77 of 96 pairs per plane remain; pack_img verifies the zeros and sets I2VConvParams::ig_p77).
+// Every output element is the k-ordered fmaf chain of the conv_tile launch minus terms that are exact zeros, then `+ add1` (a second
+// stem accumulating onto the first) and the store: bit-identical (tests/test_gpu_video.py::test_stem_halo_kernels_are_bit_identical).
+// Measured (ILAF on SlowFast, 128 fast frames of 224^2, inside the attack): conv_imggrad_halo 334 us (56.6 TFLOP/s of algorithmic flops) ->
+// 307 us (61.4) with two grid rows per wave at five waves per SIMD (96 registers, no spill); three rows per wave at four waves per SIMD:
+// 337 us -- slower (I2V_IGV_PV=3).  PMC (profiles/r6_fastblock_pmc.txt): the vector unit issues 51 % of the time, the waves are parked on
+// scalar / vector memory for 41 % of their cycles: four scalar round trips per plane (a row tap's four weight rows each) with 1.25 ready
+// waves per SIMD.  An autotuner candidate; the tap-uniform packings of the 64-channel stems stay on conv_imggrad_halo (66-74 TFLOP/s).
+static constexpr bool igv_pair_needed(const int th, const int tw, const int q) {       // does tap (th, tw) of a stride-2 7 x 7 kernel feed class-row pair q?
+    for (int cd = 2 * q; cd < 2 * q + 2; ++cd) {
+        const int cls = cd / 3, ph = cls / 2, pw = cls % 2;
+        if ((ph == 1 || th < 3) && (pw == 1 || tw < 3)) return true;
+    }
+    return false;
+}
+typedef float igv_f2 __attribute__((ext_vector_type(2)));
+typedef float igv_f8 __attribute__((ext_vector_type(8)));
+static constexpr int IGV_CDPAD = 128;   // row stride of the packed weights (12 class rows padded to 128: conv_igvfma_ok)
+template <bool VID, bool P77, int PVT>     // PVT: grid rows per wave -- 2 at five waves per SIMD (96 registers), 3 at four (128); 4 takes 160
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVT == 2 ? 5 : 4, PVT == 2 ? 5 : 4)))
+conv_igvfma_kernel(const I2VConvParams p, const int tiles_x, const int tiles_xy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PV = PVT, NR = PV + 3;
+    constexpr unsigned OOB = 0x80000000u;
+    typedef const __attribute__((address_space(4))) igv_f8* w8p_t;      // a weight row is 12 floats: one s_load_dwordx8 + one s_load_dwordx4 (a dwordx16 would hold 16 more
+    typedef const __attribute__((address_space(4))) f32x4* w4p_t;       // SGPRs per four-row batch, and the allocator then parks rows in VGPR lanes: 400 v_readlane / v_writelane per 616 FMAs)
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // block -> (grid frame, tile): consecutive tiles of a frame on one XCD (their windows overlap in its L2)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int ng = __builtin_amdgcn_readfirstlane(lid / tiles_xy), tl = lid - ng * tiles_xy;
+    const int ty = __builtin_amdgcn_readfirstlane(tl / tiles_x), tx = tl - ty * tiles_x;
+    const int y0 = ty * (4 * PV) + wave * PV, x = tx * 64 + lane;        // the wave's first grid row, the lane's grid column
+    const int TT = VID ? p.ig_tt : 1;
+    const I2VKEntry e0 = load_kentry(p.ktab, 0);
+    const int dh_lo = e0.dh, dw_lo = e0.dw, dt_lo = VID ? (e0.valid >> 1) : 0;
+    const int HWs = p.Hs * p.Ws;
+    int clip = ng, ts0 = 0, tgr = 0;
+    if (VID) { clip = __builtin_amdgcn_readfirstlane(ng / p.Tg); tgr = ng - clip * p.Tg; ts0 = tgr * p.st; }
+    const int sframe0 = VID ? clip * p.Ts + ts0 : ng;                    // source frame of frame tap dt = 0
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_span_bytes, 0x00020000);
+    // the lane's four column shifts as byte offsets within a plane row (out of range where the shifted column leaves the plane)
+    unsigned voffc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xx = x + dw_lo + j;
+        voffc[j] = (x < p.Wg && xx >= 0 && xx < p.Ws) ? (unsigned)(xx * 4) : OOB;
+    }
+    igv_f2 acc[PV][6];
+#pragma unroll
+    for (int i = 0; i < PV; ++i)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc[i][q] = igv_f2{0.f, 0.f};
+    if (y0 >= p.Hg) return;                                              // (a wave past the grid's last row: nothing to do)
+    const int nplanes = p.Cs * TT;
+    // The window rows of a plane: [row][column-shift pair].  Two buffers, A and B, alternate -- but of the plane AHEAD only the first PV
+    // rows (what its first row tap needs) are requested under this plane's FMAs; its last three rows are requested when this plane's
+    // registers are dead, at the head of its own FMAs, and arrive under its first row tap: 28 + 16 live registers instead of 56.
+    igv_f2 xa[NR][2], xb[NR][2];
+    // plane pl = (channel co, frame tap tt), walked with two counters: byte offset of its first row in the source view, or -1 when its
+    // frame lies outside the clip.  off_cur belongs to the plane whose FMAs run, off_nxt to the one ahead.
+    // (the frame part of the offset is tabulated once, lane l = frame tap l: one v_readlane per plane instead of 64-bit scalar arithmetic,
+    //  which cost 190 spilled SGPRs in the loop)
+    int ttoff_v = -1;
+    if (lane < TT) {
+        const int tf_ = ts0 + lane + dt_lo;
+        if (!VID || (tf_ >= 0 && tf_ < p.Ts)) ttoff_v = (int)((int64_t)(sframe0 + (VID ? lane + dt_lo : 0)) * p.src_nstride * 4);
+    }
+    const int plane_bytes = HWs * 4;
+    int pco = 0, ptt = 0;
+    auto plane_off = [&](const int co_, const int tt_) {
+        const int fo = __builtin_amdgcn_readlane(ttoff_v, tt_);
+        return fo < 0 ? -1 : fo + co_ * plane_bytes;
+    };
+    int off_cur = plane_off(0, 0), off_nxt = -1;
+#define IGV_ADVANCE() { ptt += 1; if (ptt == TT) { ptt = 0; pco += 1; } off_nxt = plane_off(pco, ptt); }
+    // rows R0 .. R1 - 1 of a plane into buffer X: a row outside the plane (or a frame outside the clip) is requested with every lane's
+    // offset out of range -- no branch, the load returns 0.  The row of a load is uniform over the wave; its kill word sits in a VECTOR
+    // register all the same (as 64-bit scalar conditions the seven of them were spilled and re-read around every load).
+    unsigned killv[NR];
+    const int rowstride = p.Ws * 4;
+    const int rowbase = (y0 + dh_lo) * rowstride;                       // (negative for a row above the plane: that row's loads are killed and its scalar offset is clamped)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int yy = y0 + dh_lo + r;
+        killv[r] = (yy >= 0 && yy < p.Hs) ? 0u : OOB;
+    }
+#define IGV_LOAD(OFF_, X, R0, R1)                                                                              \
+    {                                                                                                          \
+        const int off_ = (OFF_);                                                                               \
+        const unsigned pkill = off_ < 0 ? OOB : 0u;                                                            \
+        const int so0 = (off_ < 0 ? 0 : off_) + rowbase;                                                       \
+        _Pragma("unroll") for (int r = (R0); r < (R1); ++r) {                                                  \
+            const int so_ = so0 + r * rowstride < 0 ? 0 : so0 + r * rowstride;                                 \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voffc[j] | killv[r] | pkill), so_, 0));      \
+                if (j & 1) X[r][j >> 1].y = v; else X[r][j >> 1].x = v;                                         \
+            }                                                                                                  \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+    // which class-row pairs a tap (th, tw) feeds: P77 -- row class ph owns row tap th iff ph == 1 || th < 3, column class pw owns tw
+    // iff pw == 1 || tw < 3; class row cd = (2 ph + pw) 3 + ci, pair q = cd / 2.  (A column tap that only pads the quad has zero
+    // weights and a finite operand: computed like any other.)
+#define IGV_NEED(TH_, TW_, Q) (!P77 || igv_pair_needed(TH_, TW_, Q))
+#define IGV_FMA_TH(PL, X, TH_)                                                                                 \
+    {                                                                                                          \
+        igv_f8 wa[4]; f32x4 wb[4];                                                                             \
+        const float* const wth_ = p.wp + (int64_t)((PL) * 4 + (TH_)) * (4 * IGV_CDPAD);                        \
+        _Pragma("unroll") for (int tw = 0; tw < 4; ++tw) {                                                     \
+            const float* const wr_ = wth_ + tw * IGV_CDPAD;          /* (constant offsets from one base: immediates of the scalar loads) */ \
+            wa[tw] = *(w8p_t)wr_; wb[tw] = *(w4p_t)(wr_ + 8);                                                  \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        _Pragma("unroll") for (int tw = 0; tw < 4; ++tw)                                                       \
+            _Pragma("unroll") for (int i = 0; i < PV; ++i) {                                                   \
+                const igv_f2 xp = X[i + (TH_)][tw >> 1];                                                        \
+                const igv_f2 xx = (tw & 1) ? igv_f2{xp.y, xp.y} : igv_f2{xp.x, xp.x};                           \
+                _Pragma("unroll") for (int q = 0; q < 6; ++q)                                                  \
+                    if (IGV_NEED(TH_, tw, q))                                                                  \
+                        acc[i][q] = __builtin_elementwise_fma(q < 4 ? igv_f2{wa[tw][(2 * q) & 7], wa[tw][(2 * q + 1) & 7]} : igv_f2{wb[tw][(2 * q) & 3], wb[tw][(2 * q + 1) & 3]}, xx, acc[i][q]);      \
+            }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+    // plane PL from buffer X; HASNEXT: the first PV rows of plane PL + 1 go to buffer Y under it
+#define IGV_PLANE(PL, X, Y, HASNEXT)                                                                           \
+    {                                                                                                          \
+        IGV_LOAD(off_cur, X, PV, NR)                                /* this plane's last three rows */          \
+        IGV_FMA_TH(PL, X, 0)                                                                                   \
+        if (HASNEXT) { IGV_ADVANCE() IGV_LOAD(off_nxt, Y, 0, PV) }                                             \
+        IGV_FMA_TH(PL, X, 1) IGV_FMA_TH(PL, X, 2) IGV_FMA_TH(PL, X, 3)                                          \
+        off_cur = off_nxt;                                                                                     \
+    }
+    IGV_LOAD(off_cur, xa, 0, PV)
+    int pl = 0;
+    for (; pl + 2 < nplanes; pl += 2) {
+        IGV_PLANE(pl, xa, xb, true)
+        IGV_PLANE(pl + 1, xb, xa, true)
+    }
+    if (pl + 2 == nplanes) { IGV_PLANE(pl, xa, xb, true) IGV_PLANE(pl + 1, xb, xa, false) }
+    else { IGV_PLANE(pl, xa, xb, false) }
+#undef IGV_PLANE
+#undef IGV_FMA_TH
+#undef IGV_LOAD
+#undef IGV_NEED
+#undef IGV_ADVANCE
+    // ---- epilogue: class row cd = (2 ph + pw) 3 + ci -> channel ci at pixel (2 gi + ph, 2 gj + pw) of the destination frame; + add1; store ----
+    const int otb = VID ? tgr * p.ost + p.ot0 : 0;
+    if (VID && otb >= p.To) return;
+    const int64_t n = VID ? (int64_t)clip * p.To + otb : ng;
+    const int HoWo = p.Ho * p.Wo;
+    float* const dst = p.dst + n * p.dst_nstride;
+    const float* const ad1 = p.add1 ? p.add1 + n * p.add1_nstride : nullptr;
+    if (x >= p.Wg) return;
+#pragma unroll
+    for (int i = 0; i < PV; ++i) {
+        const int gi = y0 + i;
+        if (gi >= p.Hg) continue;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const int oh = gi * 2 + ph;
+            if (oh >= p.Ho) continue;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const int cd0 = (2 * ph + 0) * 3 + ci, cd1 = (2 * ph + 1) * 3 + ci;
+                float v0 = (cd0 & 1) ? acc[i][cd0 >> 1].y : acc[i][cd0 >> 1].x;
+                float v1 = (cd1 & 1) ? acc[i][cd1 >> 1].y : acc[i][cd1 >> 1].x;
+                const int64_t o = (int64_t)ci * HoWo + (int64_t)oh * p.Wo + 2 * x;
+                const bool two = 2 * x + 1 < p.Wo;
+                if (ad1) { v0 += ad1[o]; if (two) v1 += ad1[o + 1]; }
+                dst[o] = v0;
+                if (two) dst[o + 1] = v1;
+            }
+        }
+    }
+#endif
+}
+
+// Eligible: the quad-row packing of a narrow stride-2 stem's image gradient (one quad per row run, 4 x 4 union taps), 2 x 2 position classes
+// of 3 channels, no temporal classes, a plain epilogue (+ add1)
+bool conv_igvfma_ok(const I2VConvParams& p) {
+    const int TT = p.ig_tt > 0 ? p.ig_tt : 1;
+    return p.quad == 1 && p.ig_th == 4 && p.ig_tw == 4 && p.quad_kw >= 1 && p.quad_kw <= 4 && p.blk == 2 && p.blkt <= 1 && p.Cd == 12 && p.Cdpad == IGV_CDPAD &&
+           p.sh == 1 && p.sw == 1 && p.osh == 2 && p.osw == 2 && p.oh0 == 0 && p.ow0 == 0 && p.K == p.Cs * TT * 16 && p.Kpad == p.K &&
+           !p.shift && !p.relu && !p.mask && !p.gate && !p.gate_out && !p.add0 && !p.pre_scale && !p.gate_scale && p.Hg * 2 >= p.Ho && p.Wg * 2 >= p.Wo;
+}
+int launch_conv_igvfma(const I2VConvParams& p, hipStream_t s) {
+    static const int pv = [] { const char* e = getenv("I2V_IGV_PV"); return e && e[0] == '3' ? 3 : 2; }();      // (developer A/B knob)
+    const int tiles_x = (p.Wg + 63) / 64, tiles_y = (p.Hg + 4 * pv - 1) / (4 * pv), txy = tiles_x * tiles_y;
+    const int64_t grid = (int64_t)p.N * txy;
+    if (grid <= 0) return 0;
+    if (grid > 0x7fffffff) { snprintf(g_be_err, sizeof g_be_err, "image-gradient launch (vector FMAs): grid too large"); g_be_has_err = true; return 1; }
+#define IGV_GO(V, P7, PV_) hipLaunchKernelGGL((conv_igvfma_kernel<V, P7, PV_>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_x, txy)
+#define IGV_GO2(V, P7) { if (pv == 3) IGV_GO(V, P7, 3); else IGV_GO(V, P7, 2); }
+    if (p.temporal) { if (p.ig_p77) IGV_GO2(true, true) else IGV_GO2(true, false) }
+    else { if (p.ig_p77) IGV_GO2(false, true) else IGV_GO2(false, false) }
+#undef IGV_GO2
+#undef IGV_GO
+    LAUNCH_CHECK("conv_igvfma_kernel");
+    return 0;
+}

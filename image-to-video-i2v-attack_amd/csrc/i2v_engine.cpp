@@ -65,6 +65,7 @@ struct Packed {               // one implicit-GEMM operand set
     int quad = 0, quad_kw = 0, quad_dw0 = 0;     // "quad rows" packing (I2VConvParams::quad): quads per row run, taps per run, first tap
     int tpair = 0;            // forward packing with TWO output frames per grid frame (rows = (frame class, channel)): see pack_fwd
     int ig_tt = 0, ig_th = 0, ig_tw = 0;      // image-gradient packing in tap-uniform order: union taps per axis (I2VConvParams::ig_*)
+    int ig_p77 = 0;           // quad-row image gradient whose zero weights follow the stride-2 7 x 7 pattern (I2VConvParams::ig_p77)
 };
 
 struct Node {
@@ -474,6 +475,20 @@ static int pack_img_one(Net& n, Node& nd, Node::ImgGrad& ig, const int only_ct) 
                 }
     }
     for (const I2VKEntry& e : kt) if (e.valid >> 1) P.has_dt = 1;
+    // conv_igvfma_kernel skips the class-row pairs a tap cannot feed under the stride-2 7 x 7 geometry (row class ph owns row tap th iff
+    // ph == 1 || th < 3, column class alike): claimed only when EVERY weight outside that pattern is an exact zero in this packing
+    if (quad && TWq == 4 && TH == 4 && Bt == 1 && B == 2 && c.cin == 3 && P.Cd == 12) {
+        bool ok = true;
+        for (int k = 0; k < P.K && ok; ++k) {
+            const int tw = k % 4, th = (k / 4) % 4;
+            for (int cd = 0; cd < 12 && ok; ++cd) {
+                const int cls = cd / 3, ph = cls / 2, pw = cls % 2;
+                const bool owned = (ph == 1 || th < 3) && (pw == 1 || tw < 3);
+                if (!owned && wp[(size_t)k * P.Cdpad + cd] != 0.f) ok = false;
+            }
+        }
+        P.ig_p77 = ok ? 1 : 0;
+    }
     if (upload(n, wp, &P.wp)) return 1;
     return upload(n, kt, &P.ktab);
 }
@@ -743,7 +758,7 @@ static void conv_common(I2VConvParams& p, const Packed& P) {
     p.temporal = P.has_dt;      // conv_run adds the frame-mapping half of the condition
     p.quad = P.quad; p.quad_kw = P.quad_kw; p.quad_dw0 = P.quad_dw0;
     p.halo = P.halo;
-    p.ig_tt = P.ig_tt; p.ig_th = P.ig_th; p.ig_tw = P.ig_tw;
+    p.ig_tt = P.ig_tt; p.ig_th = P.ig_th; p.ig_tw = P.ig_tw; p.ig_p77 = P.ig_p77;
 }
 
 static bool overlaps(const Tensor& a, const Tensor& b) {

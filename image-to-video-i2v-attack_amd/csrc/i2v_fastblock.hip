@@ -21,7 +21,7 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) f2* wptr_t;       // packed weights through the constant address space: scalar loads, SGPR operands
 
-long long g_stat_fastblock = 0, g_stat_vfma = 0;
+long long g_stat_fastblock = 0, g_stat_vfma = 0, g_stat_igv = 0;
 
 __device__ __forceinline__ unsigned fb_ballot_lo(unsigned long long b) { return (unsigned)b; }
 

@@ -29,6 +29,7 @@ long long be_stat(const char* name) {
     if (!strcmp(name, "stemhalo_launches")) return __atomic_load_n(&g_stat_sth, __ATOMIC_RELAXED);
     if (!strcmp(name, "fastblock_launches")) return __atomic_load_n(&g_stat_fastblock, __ATOMIC_RELAXED);
     if (!strcmp(name, "vfma_launches")) return __atomic_load_n(&g_stat_vfma, __ATOMIC_RELAXED);
+    if (!strcmp(name, "igvfma_launches")) return __atomic_load_n(&g_stat_igv, __ATOMIC_RELAXED);
 #ifdef I2V_EXPERIMENTAL      // 1: the library carries the experimental kernels (fused pair, split-bf16 loop, conv_pw_stream, conv_stem64_halo)
     if (!strcmp(name, "experimental")) return 1;
 #else
@@ -130,7 +131,8 @@ int k_conv_candidates(const I2VConvParams& p, int* out) {
     if (conv_ighalo_ok(p) && !no_igh) out[n++] = (p.Cd <= 16 ? 5 : 4) | 512;      // the class-packed image gradient on a 2-D halo tile (conv_imggrad_halo)
     if (conv_stemhalo_ok(p) && !no_igh) out[n++] = 5 | 1024;                       // the narrow forward stem on a 2-D halo tile (conv_stem_halo)
     static const bool no_vfma = [] { const char* e = getenv("I2V_VFMA"); return e && e[0] == '0'; }();
-    if (conv_vfma_ok(p) && !no_vfma) out[n++] = (p.Cd <= 16 ? 5 : 4) | 2048;      // a narrow (<= 32 x 32) launch with taps at (0, 0) on packed-fp32 vector FMAs (conv_vfma_kernel)
+    if (conv_vfma_ok(p) && !no_vfma) out[n++] = (p.Cd <= 16 ? 5 : 4) | 2048;
+    if (conv_igvfma_ok(p) && !no_vfma) out[n++] = 5 | 4096;                        // the quad-row image gradient of a narrow stem on packed-fp32 vector FMAs (conv_igvfma_kernel)      // a narrow (<= 32 x 32) launch with taps at (0, 0) on packed-fp32 vector FMAs (conv_vfma_kernel)
 #ifdef I2V_EXPERIMENTAL
     // conv_stem64_halo (the wide 7x7 / 2 forward stem on a 2-D halo tile) is built, bit-identical (values and gate words) and faster in
     // isolation (tools/stem_halo_probe.cpp, 128 frames, random operands: 435 -> 363 us), but in the attack the conv_tile launch it would
@@ -177,6 +179,10 @@ int k_conv(const I2VConvParams& p_in, i2v_stream_t s) {
     if (((p.cfg - 1) & 2048) && conv_vfma_ok(p)) {      // narrow launch on packed-fp32 vector FMAs (autotuner bit 11)
         __atomic_fetch_add(&g_stat_vfma, 1, __ATOMIC_RELAXED);
         return launch_conv_vfma(p, st);
+    }
+    if (((p.cfg - 1) & 4096) && conv_igvfma_ok(p)) {    // quad-row image gradient on packed-fp32 vector FMAs (autotuner bit 12)
+        __atomic_fetch_add(&g_stat_igv, 1, __ATOMIC_RELAXED);
+        return launch_conv_igvfma(p, st);
     }
     if (((p.cfg - 1) & 512) && conv_ighalo_ok(p)) {     // image gradient on a 2-D halo tile (autotuner bit 9)
         __atomic_fetch_add(&g_stat_igh, 1, __ATOMIC_RELAXED);

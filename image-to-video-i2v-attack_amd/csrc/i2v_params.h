@@ -83,6 +83,7 @@ struct I2VConvParams {
     // channel) with ig_tt x ig_th x ig_tw union taps, the first k-table row being the lowest tap of each axis: conv_imggrad_halo may
     // stage one 2-D halo tile per (group, frame tap) instead of one shifted copy per tap.  Same products, same order.
     int32_t ig_tt, ig_th, ig_tw;
+    int32_t ig_p77;        // quad-row image gradient of a stride-2 7 x 7 kernel whose packed weights are zero exactly where that geometry says (pack_img checks): conv_igvfma_kernel skips those pairs
     // exact division of a pixel index (< 2^31) by Hg*Wg, Wg, Tg and Wo as multiply-high + shift: filled in by k_conv (the
     // hardware has no integer divide; the 64-bit software divisions of round 1 cost a block more VALU issue slots than a
     // K = 64 tile spends on its MFMAs)

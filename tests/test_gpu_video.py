@@ -432,10 +432,10 @@ def test_stem_halo_kernels_are_bit_identical(eng, monkeypatch):
         frames = clips * T
         x = dev(torch.randn(frames, 3, *g.in_hw, generator=torch.Generator().manual_seed(0)))
         outs = []
-        for cfg in (base_cfg, base_cfg | 512 | 1024):
+        for cfg in (base_cfg, base_cfg | 512 | 1024, base_cfg | 4096):
             monkeypatch.setenv("I2V_FORCE_CFG", str(cfg))
             net = eng.build_net(g, sd, hooks, frames)
-            before = [eng.capi.i2v_backend_stat(b"ighalo_launches"), eng.capi.i2v_backend_stat(b"stemhalo_launches")]
+            before = [eng.capi.i2v_backend_stat(b"ighalo_launches"), eng.capi.i2v_backend_stat(b"stemhalo_launches"), eng.capi.i2v_backend_stat(b"igvfma_launches")]
             net.forward(x)
             feats = [net.save_hook(i, clips * hi.T).cpu() for i, hi in enumerate(net.hooks)]
             hg = [torch.randn(f.shape, generator=torch.Generator().manual_seed(7 + i)) for i, f in enumerate(feats)]
@@ -445,12 +445,17 @@ def test_stem_halo_kernels_are_bit_identical(eng, monkeypatch):
             torch.cuda.synchronize()
             ran = [eng.capi.i2v_backend_stat(b"ighalo_launches") - before[0], eng.capi.i2v_backend_stat(b"stemhalo_launches") - before[1]]
             assert ran == ([expect_grad, expect_fwd] if cfg & 512 else [0, 0]), (g.arch, cfg, ran)
+            # round 6, bit 12: conv_igvfma_kernel -- the quad-row image gradient of a NARROW stem (SlowFast's fast stem: 8 channels) on packed-fp32
+            # vector FMAs, the class-row pairs a stride-2 7 x 7 tap cannot feed skipped
+            ran_igv = eng.capi.i2v_backend_stat(b"igvfma_launches") - before[2]
+            assert ran_igv == ((1 if video_type == "slowfast_resnet50" else 0) if cfg & 4096 else 0), (g.arch, cfg, ran_igv)
             outs.append((feats, gx.cpu()))
             net.close()
         assert torch.isfinite(outs[0][1]).all() and float(outs[0][1].abs().max()) > 0
-        for fa, fb in zip(outs[0][0], outs[1][0]):
-            assert torch.equal(fa, fb), g.arch
-        assert torch.equal(outs[0][1], outs[1][1]), g.arch
+        for other in outs[1:]:
+            for fa, fb in zip(outs[0][0], other[0]):
+                assert torch.equal(fa, fb), g.arch
+            assert torch.equal(outs[0][1], other[1]), g.arch
 
 
 def test_autotuned_slowfast_stems_match_the_plain_tiles(eng, monkeypatch):

@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/w -o p --output-format csv -- 
 python3 - "$OUT" > $OUT/summary.txt <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
-WANT = ("fast_block", "conv_vfma_kernel")
+WANT = ("fast_block", "conv_vfma_kernel", "conv_igvfma", "conv_imggrad_halo")
 def key(name): return name.split("(")[0].replace("void ", "")
 # durations from the stats run (no counters attached)
 dur = collections.defaultdict(list)
