@@ -669,9 +669,8 @@ conv_igvfma_kernel(const I2VConvParams p, const int tiles_x, const int tiles_xy)
         for (int q = 0; q < 6; ++q) acc[i][q] = igv_f2{0.f, 0.f};
     if (y0 >= p.Hg) return;                                              // (a wave past the grid's last row: nothing to do)
     const int nplanes = p.Cs * TT;
-    // The window rows of a plane: [row][column-shift pair].  Two buffers, A and B, alternate -- but of the plane AHEAD only the first PV
-    // rows (what its first row tap needs) are requested under this plane's FMAs; its last three rows are requested when this plane's
-    // registers are dead, at the head of its own FMAs, and arrive under its first row tap: 28 + 16 live registers instead of 56.
+    // The window rows of a plane: [row][column-shift pair].  Two buffers, A and B, alternate; the plane ahead is requested row by row
+    // as this plane's rows die (IGV_PLANE).
     igv_f2 xa[NR][2], xb[NR][2];
     // plane pl = (channel co, frame tap tt), walked with two counters: byte offset of its first row in the source view, or -1 when its
     // frame lies outside the clip.  off_cur belongs to the plane whose FMAs run, off_nxt to the one ahead.
@@ -738,16 +737,23 @@ conv_igvfma_kernel(const I2VConvParams p, const int tiles_x, const int tiles_xy)
             }                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
-    // plane PL from buffer X; HASNEXT: the first PV rows of plane PL + 1 go to buffer Y under it
+    // plane PL from buffer X; HASNEXT: plane PL + 1 goes to buffer Y under it, row by row as X's rows die -- its first PV rows after row
+    // tap 0, then one row behind each further row tap: every row is requested at least two row taps before its first use, and at most
+    // PV + 3 + PV rows are alive at a time.  (Requesting a plane's last three rows at the head of its own FMAs left each wave waiting
+    // for them after its first row tap.)
 #define IGV_PLANE(PL, X, Y, HASNEXT)                                                                           \
     {                                                                                                          \
-        IGV_LOAD(off_cur, X, PV, NR)                                /* this plane's last three rows */          \
         IGV_FMA_TH(PL, X, 0)                                                                                   \
         if (HASNEXT) { IGV_ADVANCE() IGV_LOAD(off_nxt, Y, 0, PV) }                                             \
-        IGV_FMA_TH(PL, X, 1) IGV_FMA_TH(PL, X, 2) IGV_FMA_TH(PL, X, 3)                                          \
+        IGV_FMA_TH(PL, X, 1)                                                                                   \
+        if (HASNEXT) IGV_LOAD(off_nxt, Y, PV, PV + 1)                                                          \
+        IGV_FMA_TH(PL, X, 2)                                                                                   \
+        if (HASNEXT) IGV_LOAD(off_nxt, Y, PV + 1, PV + 2)                                                      \
+        IGV_FMA_TH(PL, X, 3)                                                                                   \
+        if (HASNEXT) IGV_LOAD(off_nxt, Y, PV + 2, PV + 3)                                                      \
         off_cur = off_nxt;                                                                                     \
     }
-    IGV_LOAD(off_cur, xa, 0, PV)
+    IGV_LOAD(off_cur, xa, 0, NR)
     int pl = 0;
     for (; pl + 2 < nplanes; pl += 2) {
         IGV_PLANE(pl, xa, xb, true)
