@@ -620,7 +620,13 @@ int launch_conv_stem64(const I2VConvParams& p, hipStream_t s) {
 // 307 us (61.4) with two grid rows per wave at five waves per SIMD (96 registers, no spill); three rows per wave at four waves per SIMD:
 // 337 us -- slower (I2V_IGV_PV=3).  PMC (profiles/r6_fastblock_pmc.txt): the vector unit issues 51 % of the time, the waves are parked on
 // scalar / vector memory for 41 % of their cycles: four scalar round trips per plane (a row tap's four weight rows each) with 1.25 ready
-// waves per SIMD.  An autotuner candidate; the tap-uniform packings of the 64-channel stems stay on conv_imggrad_halo (66-74 TFLOP/s).
+// waves per SIMD.  The probe build (tools/igv_probe.sh, profiles/r6_igvfma_probe.txt) prices the waits: with every weight row the SAME row
+// (always a scalar-cache hit) a launch takes 224 us instead of 305, without operand loads 281, without either 218 -- the 30 KB of
+// weight rows (one 64-byte line each: the packing's rows are 512 bytes apart) do not stay in the 16 KB scalar cache while the CU's
+// twenty waves drift apart.  Sixteen-wave blocks with a barrier per plane (the CU's waves on the same rows at the same time) were
+// slower still (330 us; eight-wave blocks 394); a variant that stages the window once per block in LDS (four rows per wave) ran into
+// the same scalar-register ceiling (48 SGPRs of weights in flight) and was not finished.  An autotuner candidate; the tap-uniform packings of the 64-channel stems stay on
+// conv_imggrad_halo (66-74 TFLOP/s).
 static constexpr bool igv_pair_needed(const int th, const int tw, const int q) {       // does tap (th, tw) of a stride-2 7 x 7 kernel feed class-row pair q?
     for (int cd = 2 * q; cd < 2 * q + 2; ++cd) {
         const int cls = cd / 3, ph = cls / 2, pw = cls % 2;
@@ -662,6 +668,11 @@ conv_igvfma_kernel(const I2VConvParams p, const int tiles_x, const int tiles_xy)
         const int xx = x + dw_lo + j;
         voffc[j] = (x < p.Wg && xx >= 0 && xx < p.Ws) ? (unsigned)(xx * 4) : OOB;
     }
+#ifdef I2V_EXPERIMENTAL          // probe hooks (tools/igv_probe.sh, timing only): I2V_IGV_PROBE bit 0 = every weight row is row 0 (always a scalar-cache hit), bit 1 = no operand loads
+    const int probe = p.add0_H;
+#else
+    constexpr int probe = 0;
+#endif
     igv_f2 acc[PV][6];
 #pragma unroll
     for (int i = 0; i < PV; ++i)
@@ -703,7 +714,7 @@ conv_igvfma_kernel(const I2VConvParams p, const int tiles_x, const int tiles_xy)
 #define IGV_LOAD(OFF_, X, R0, R1)                                                                              \
     {                                                                                                          \
         const int off_ = (OFF_);                                                                               \
-        const unsigned pkill = off_ < 0 ? OOB : 0u;                                                            \
+        const unsigned pkill = (off_ < 0 || (probe & 2)) ? OOB : 0u;                                           \
         const int so0 = (off_ < 0 ? 0 : off_) + rowbase;                                                       \
         _Pragma("unroll") for (int r = (R0); r < (R1); ++r) {                                                  \
             const int so_ = so0 + r * rowstride < 0 ? 0 : so0 + r * rowstride;                                 \
@@ -721,7 +732,7 @@ conv_igvfma_kernel(const I2VConvParams p, const int tiles_x, const int tiles_xy)
 #define IGV_FMA_TH(PL, X, TH_)                                                                                 \
     {                                                                                                          \
         igv_f8 wa[4]; f32x4 wb[4];                                                                             \
-        const float* const wth_ = p.wp + (int64_t)((PL) * 4 + (TH_)) * (4 * IGV_CDPAD);                        \
+        const float* const wth_ = p.wp + ((probe & 1) ? 0 : (int64_t)((PL) * 4 + (TH_)) * (4 * IGV_CDPAD));     \
         _Pragma("unroll") for (int tw = 0; tw < 4; ++tw) {                                                     \
             const float* const wr_ = wth_ + tw * IGV_CDPAD;          /* (constant offsets from one base: immediates of the scalar loads) */ \
             wa[tw] = *(w8p_t)wr_; wb[tw] = *(w4p_t)(wr_ + 8);                                                  \
@@ -808,6 +819,10 @@ bool conv_igvfma_ok(const I2VConvParams& p) {
 }
 int launch_conv_igvfma(const I2VConvParams& p, hipStream_t s) {
     static const int pv = [] { const char* e = getenv("I2V_IGV_PV"); return e && e[0] == '3' ? 3 : 2; }();      // (developer A/B knob)
+#ifdef I2V_EXPERIMENTAL
+    I2VConvParams pp = p; { const char* e = getenv("I2V_IGV_PROBE"); pp.add0_H = e ? atoi(e) : 0; }
+#define p pp
+#endif
     const int tiles_x = (p.Wg + 63) / 64, tiles_y = (p.Hg + 4 * pv - 1) / (4 * pv), txy = tiles_x * tiles_y;
     const int64_t grid = (int64_t)p.N * txy;
     if (grid <= 0) return 0;
@@ -818,6 +833,9 @@ int launch_conv_igvfma(const I2VConvParams& p, hipStream_t s) {
     else { if (p.ig_p77) IGV_GO2(false, true) else IGV_GO2(false, false) }
 #undef IGV_GO2
 #undef IGV_GO
+#ifdef I2V_EXPERIMENTAL
+#undef p
+#endif
     LAUNCH_CHECK("conv_igvfma_kernel");
     return 0;
 }
