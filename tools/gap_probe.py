@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: where the wall time of an attack goes BETWEEN kernels.  Reads a rocprofv3 --kernel-trace csv, keeps the dispatches from
-the first Adam step (`adam_kernel`) on -- planning, autotuning and the first step's compose / forward / backward are left out, so the window
+the first Adam step (`adam_kernel`; ILAF: the second `sign_delta_gx_kernel`) on -- planning, autotuning and the first step's compose / forward / backward are left out, so the window
 is "steady state from the end of step 1" (`profiles/r4_gap_probe.txt` was produced with this cut) -- and reports -- per queue and overall -- the span, the sum of kernel durations, and the gaps
 between the end of one dispatch and the start of the next (median / mean / total), plus the durations by kernel name.
     python3 tools/gap_probe.py <dir-with-*_kernel_trace.csv>"""
@@ -17,7 +17,9 @@ for f in files:
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")))
 rows.sort()
-first = next(i for i, r in enumerate(rows) if "adam_kernel" in r[2])          # everything before the first Adam step: planning / autotuning
+# everything before the first optimiser step -- Adam's, or ILAF's second sign step (its first call is the warm-up) -- is planning / autotuning
+marks = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]] or [i for i, r in enumerate(rows) if "sign_delta_gx_kernel" in r[2]][1:]
+first = marks[0]
 rows = rows[first:]
 span = rows[-1][1] - rows[0][0]
 busy = sum(e - s for s, e, _, _ in rows)
