@@ -512,7 +512,7 @@ def split_bf16_measurement(args, eng, attacks, videos, labels, names, b, value, 
             "bf3_launches_per_step": per_call,
             "device_vs_f64_oracle": {k: float(f"{v:.4g}") for k, v in st3.items()} if st3 else None,
             "note": "NOT the headline: `value` is the exact-fp32 path.  Same clips, same K steps, one clip lane, no per-launch events; "
-                    "parity of this mode: tests/test_gpu_split_bf16.py, DESIGN.md section 12"}
+                    "parity of this mode: tests/test_gpu_split_bf16.py, DESIGN_HISTORY.md R5-12"}
 
 
 def run_rank(args, framework_child=None):
@@ -791,7 +791,7 @@ def run_rank(args, framework_child=None):
     if args.workload == "i2v" and getattr(atk, "_nets", None) and eng.capi.i2v_backend_stat(b"experimental") == 1:       # what the autotuner did with the fusable 3x3 -> pointwise pairs (headline plan)
         fi = atk._nets[0].fusion_info()
         out["fused_pairs"] = {"eligible_fwd": fi[0], "eligible_bwd": fi[1], "fused_fwd": fi[2], "fused_bwd": fi[3],
-                              "note": "pairs run as one conv_fused_kernel launch at the planned batch size (autotuned per pair; DESIGN.md section 10)"}
+                              "note": "pairs run as one conv_fused_kernel launch at the planned batch size (autotuned per pair; experimental build, DESIGN.md section 12)"}
     out["plan_ms"] = {"total": round(eng.plan_ms, 1), "plans": eng.plans,
                       "note": "host wall time of building the planned backbones (weight packing, upload, launch lists, plan-time "
                               "autotuning of every convolution launch); paid once per (backbone, resolution, max batch), never inside a timed region"}
