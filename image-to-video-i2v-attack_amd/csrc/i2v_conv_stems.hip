@@ -617,7 +617,8 @@ int launch_conv_stem64(const I2VConvParams& p, hipStream_t s) {
 // Every output element is the k-ordered fmaf chain of the conv_tile launch minus terms that are exact zeros, then `+ add1` (a second
 // stem accumulating onto the first) and the store: bit-identical (tests/test_gpu_video.py::test_stem_halo_kernels_are_bit_identical).
 // Measured (ILAF on SlowFast, 128 fast frames of 224^2, inside the attack): conv_imggrad_halo 334 us (56.6 TFLOP/s of algorithmic flops) ->
-// 307 us (61.4) with two grid rows per wave at five waves per SIMD (96 registers, no spill); three rows per wave at four waves per SIMD:
+// 307 us (61.4) with two grid rows per wave at five waves per SIMD (96 registers, no spill) -> 288 us (65.5) with the weight rows read
+// from a compact copy (64-byte rows instead of the packing's 512: I2VConvParams::wpc); three rows per wave at four waves per SIMD:
 // 337 us -- slower (I2V_IGV_PV=3).  PMC (profiles/r6_fastblock_pmc.txt): the vector unit issues 51 % of the time, the waves are parked on
 // scalar / vector memory for 41 % of their cycles: four scalar round trips per plane (a row tap's four weight rows each) with 1.25 ready
 // waves per SIMD.  The probe build (tools/igv_probe.sh, profiles/r6_igvfma_probe.txt) prices the waits: with every weight row the SAME row
@@ -636,7 +637,8 @@ static constexpr bool igv_pair_needed(const int th, const int tw, const int q) {
 }
 typedef float igv_f2 __attribute__((ext_vector_type(2)));
 typedef float igv_f8 __attribute__((ext_vector_type(8)));
-static constexpr int IGV_CDPAD = 128;   // row stride of the packed weights (12 class rows padded to 128: conv_igvfma_ok)
+static constexpr int IGV_CDPAD = 16;    // row stride of the compact weight copy (I2VConvParams::wpc: 12 class rows in 64 bytes -- at the packing's own 512-byte stride the
+                                        // 640 rows fall into one scalar-cache set in eight)
 template <bool VID, bool P77, int PVT>     // PVT: grid rows per wave -- 2 at five waves per SIMD (96 registers), 3 at four (128); 4 takes 160
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PVT == 2 ? 5 : 4, PVT == 2 ? 5 : 4)))
 conv_igvfma_kernel(const I2VConvParams p, const int tiles_x, const int tiles_xy) {
@@ -732,7 +734,7 @@ conv_igvfma_kernel(const I2VConvParams p, const int tiles_x, const int tiles_xy)
 #define IGV_FMA_TH(PL, X, TH_)                                                                                 \
     {                                                                                                          \
         igv_f8 wa[4]; f32x4 wb[4];                                                                             \
-        const float* const wth_ = p.wp + ((probe & 1) ? 0 : (int64_t)((PL) * 4 + (TH_)) * (4 * IGV_CDPAD));     \
+        const float* const wth_ = p.wpc + ((probe & 1) ? 0 : (int64_t)((PL) * 4 + (TH_)) * (4 * IGV_CDPAD));     \
         _Pragma("unroll") for (int tw = 0; tw < 4; ++tw) {                                                     \
             const float* const wr_ = wth_ + tw * IGV_CDPAD;          /* (constant offsets from one base: immediates of the scalar loads) */ \
             wa[tw] = *(w8p_t)wr_; wb[tw] = *(w4p_t)(wr_ + 8);                                                  \
@@ -813,7 +815,7 @@ conv_igvfma_kernel(const I2VConvParams p, const int tiles_x, const int tiles_xy)
 // of 3 channels, no temporal classes, a plain epilogue (+ add1)
 bool conv_igvfma_ok(const I2VConvParams& p) {
     const int TT = p.ig_tt > 0 ? p.ig_tt : 1;
-    return p.quad == 1 && p.ig_th == 4 && p.ig_tw == 4 && p.quad_kw >= 1 && p.quad_kw <= 4 && p.blk == 2 && p.blkt <= 1 && p.Cd == 12 && p.Cdpad == IGV_CDPAD &&
+    return p.quad == 1 && p.ig_th == 4 && p.ig_tw == 4 && p.quad_kw >= 1 && p.quad_kw <= 4 && p.blk == 2 && p.blkt <= 1 && p.Cd == 12 && p.wpc != nullptr &&
            p.sh == 1 && p.sw == 1 && p.osh == 2 && p.osw == 2 && p.oh0 == 0 && p.ow0 == 0 && p.K == p.Cs * TT * 16 && p.Kpad == p.K &&
            !p.shift && !p.relu && !p.mask && !p.gate && !p.gate_out && !p.add0 && !p.pre_scale && !p.gate_scale && p.Hg * 2 >= p.Ho && p.Wg * 2 >= p.Wo;
 }

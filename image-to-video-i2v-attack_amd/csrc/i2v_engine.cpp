@@ -56,6 +56,7 @@ struct Tensor { int buf, c_off, C; bool post_relu; float bwd_gain = 1.f; };   //
 
 struct Packed {               // one implicit-GEMM operand set
     float* wp = nullptr; I2VKEntry* ktab = nullptr;
+    float* wpc = nullptr;     // compact copy of wp for conv_igvfma_kernel (I2VConvParams::wpc)
     uint16_t* wp3 = nullptr;  // split-bf16 copy of `wp` (I2VConvParams::wp3), only in the bf16x3 math mode
     int K = 0, Kpad = 0, Cd = 0, Cdpad = 0, tap_uniform = 0;
     int halo = 0;           // 9 for a 3x3 / stride-1 / pad-1 packing in (16-channel group, tap, channel) order (kernel MODE 5), else 0
@@ -488,6 +489,9 @@ static int pack_img_one(Net& n, Node& nd, Node::ImgGrad& ig, const int only_ct) 
             }
         }
         P.ig_p77 = ok ? 1 : 0;
+        std::vector<float> wc((size_t)P.Kpad * 16, 0.f);             // rows of 16 floats for the vector-FMA kernel's scalar loads
+        for (int k = 0; k < P.K; ++k) for (int cd = 0; cd < 12; ++cd) wc[(size_t)k * 16 + cd] = wp[(size_t)k * P.Cdpad + cd];
+        if (upload(n, wc, &P.wpc)) return 1;
     }
     if (upload(n, wp, &P.wp)) return 1;
     return upload(n, kt, &P.ktab);
@@ -751,7 +755,7 @@ extern "C" int i2v_net_add_attention(i2v_handle h, int net, const i2v_attn_desc*
 // ---------------------------------------------------------------------------------------------
 static void conv_common(I2VConvParams& p, const Packed& P) {
     memset(&p, 0, sizeof p);
-    p.wp = P.wp; p.ktab = P.ktab; p.K = P.K; p.Kpad = P.Kpad; p.tap_uniform = P.tap_uniform; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
+    p.wp = P.wp; p.wpc = P.wpc; p.ktab = P.ktab; p.K = P.K; p.Kpad = P.Kpad; p.tap_uniform = P.tap_uniform; p.Cd = P.Cd; p.Cdpad = P.Cdpad;
     p.wp3 = P.wp3; p.bf3 = P.wp3 ? 1 : 0;
     p.add0_stride = 1;
     p.blkt = 1; p.Tg = p.Ts = p.To = p.st = p.ost = 1; p.ot0 = 0; p.oct = 1;

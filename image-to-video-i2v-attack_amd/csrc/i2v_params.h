@@ -84,6 +84,8 @@ struct I2VConvParams {
     // stage one 2-D halo tile per (group, frame tap) instead of one shifted copy per tap.  Same products, same order.
     int32_t ig_tt, ig_th, ig_tw;
     int32_t ig_p77;        // quad-row image gradient of a stride-2 7 x 7 kernel whose packed weights are zero exactly where that geometry says (pack_img checks): conv_igvfma_kernel skips those pairs
+    const float* wpc;      // quad-row image gradient with 12 class rows: the packed weights once more with rows of 16 floats (64 bytes) -- conv_igvfma_kernel's scalar loads;
+                           // at wp's 512-byte row stride its 640 rows fall into one scalar-cache set in eight (null: no such copy)
     // exact division of a pixel index (< 2^31) by Hg*Wg, Wg, Tg and Wo as multiply-high + shift: filled in by k_conv (the
     // hardware has no integer divide; the 64-bit software divisions of round 1 cost a block more VALU issue slots than a
     // K = 64 tile spends on its MFMAs)
